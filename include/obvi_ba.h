@@ -1,0 +1,243 @@
+/*
+ * obvi_ba.h -- C ABI of libobvi_ba, the MI355X (gfx950) bundle-adjustment backend
+ * that replaces the Ceres path behind ObVi-SLAM's optimisation entry points.
+ *
+ * Boundary being replaced (reference file:line, all under /root/reference):
+ *   - ObjectPoseGraphOptimizer::buildPoseGraphOptimization
+ *       include/refactoring/optimization/object_pose_graph_optimizer.h:126-632
+ *     -> obvi_ba_set_* (flat problem upload) + obvi_ba_set_active_mask
+ *   - ObjectPoseGraphOptimizer::solveOptimization  (ceres::Solve, SPARSE_SCHUR, HuberLoss, LM)
+ *       include/refactoring/optimization/object_pose_graph_optimizer.h:634-707
+ *     -> obvi_ba_solve  (+ obvi_ba_evaluate for the apply_loss_function=false pass at :682-693)
+ *   - pose_graph->makeCopyDeepCopyValues / setValuesFromAnotherPoseGraph
+ *       include/refactoring/optimization/object_pose_graph.h:1025-1121
+ *     -> obvi_ba_snapshot / obvi_ba_restore
+ *   - two-phase outlier selection  include/refactoring/offline/offline_problem_runner.h:689-800
+ *     -> obvi_ba_select_outliers
+ *
+ * Conventions
+ *   - every pointer argument is a HOST pointer owned by the caller; set_* copies to
+ *     the device, get_* copies back.  No torch / HIP types cross this boundary.
+ *   - all floating point is IEEE binary64 (the reference is fp64 throughout,
+ *     include/refactoring/types/vslam_basic_types_refactor.h:42).
+ *   - return value: 0 on success, negative obvi_status on error.  Nothing throws or aborts.
+ *   - one handle == one GPU == one HIP stream.  A handle is not re-entrant.
+ *   - parameter block layouts are the reference's raw blocks:
+ *       pose   [tx ty tz ax ay az]      (vslam_types_conversion.h:13-21)
+ *       point  [x y z]
+ *       object [x y z yaw dx dy dz]     (vslam_obj_opt_types_refactor.h:15-21,
+ *                                        CONSTRAIN_ELLIPSOID_ORIENTATION=ON, CMakeLists.txt:8-15)
+ *   - camera extrinsics are T_robot<-camera as [qx qy qz qw tx ty tz]
+ *     (reprojection_cost_functor.h:155-158); intrinsics [fx fy cx cy].
+ */
+#ifndef OBVI_BA_H_
+#define OBVI_BA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct obvi_ba_handle obvi_ba_handle;
+
+typedef enum {
+  OBVI_OK = 0,
+  OBVI_ERR_INVALID_ARGUMENT = -1,
+  OBVI_ERR_NO_DEVICE = -2,       /* HIP runtime/device unavailable: the product never falls back to CPU */
+  OBVI_ERR_HIP = -3,             /* a HIP API call failed; see obvi_ba_last_error */
+  OBVI_ERR_OUT_OF_RANGE = -4,    /* an index array refers to a block that was not uploaded */
+  OBVI_ERR_NOT_READY = -5,       /* solve/evaluate before the problem was uploaded */
+  OBVI_ERR_NUMERICAL = -6        /* non-finite value / non-SPD matrix in a set_* covariance */
+} obvi_status;
+
+/* Factor type ids: identical to the reference's FactorType constants
+ * (low_level_feature_pose_graph.h:18-23, object_pose_graph.h:18-20). */
+enum {
+  OBVI_FACTOR_REPROJECTION = 0,  /* kReprojectionErrorFactorTypeId  */
+  OBVI_FACTOR_BBOX = 2,          /* kObjectObservationFactorTypeId  */
+  OBVI_FACTOR_SHAPE_PRIOR = 3,   /* kShapeDimPriorFactorTypeId      */
+  OBVI_FACTOR_LTM_PRIOR = 4,     /* kLongTermMapFactorTypeId        */
+  OBVI_FACTOR_REL_POSE = 5       /* kPairwiseRobotPoseFactorTypeId  */
+};
+
+/* Residual block sizes per factor type: offline_problem_runner.h:697-719. */
+enum {
+  OBVI_RESIDUAL_DIM_REPROJECTION = 2,
+  OBVI_RESIDUAL_DIM_BBOX = 4,
+  OBVI_RESIDUAL_DIM_SHAPE_PRIOR = 3,
+  OBVI_RESIDUAL_DIM_LTM_PRIOR = 7,
+  OBVI_RESIDUAL_DIM_REL_POSE = 6
+};
+
+typedef struct {
+  int32_t device_id;          /* HIP device ordinal (LOCAL_RANK for one-process-per-GPU) */
+  int32_t object_block_size;  /* 7 = yaw-only ellipsoid (the only variant the reference compiles) */
+  int32_t reserved[6];
+} obvi_ba_options;
+
+/* Mirrors pose_graph_optimization::OptimizationSolverParams
+ * (optimization_solver_params.h:10-30) -- the knobs solveOptimization copies into
+ * ceres::Solver::Options (object_pose_graph_optimizer.h:662-672).  Everything else is
+ * the Ceres default: LM trust region, Jacobi scaling, min/max LM diagonal 1e-6/1e32,
+ * min_relative_decrease 1e-3, max_consecutive_nonmonotonic_steps 5. */
+typedef struct {
+  int32_t max_num_iterations;
+  int32_t allow_non_monotonic_steps;
+  double function_tolerance;
+  double gradient_tolerance;
+  double parameter_tolerance;
+  double initial_trust_region_radius;
+  double max_trust_region_radius;
+} obvi_solver_params;
+
+/* ceres::TerminationType order (CONVERGENCE, NO_CONVERGENCE, FAILURE). */
+enum { OBVI_CONVERGENCE = 0, OBVI_NO_CONVERGENCE = 1, OBVI_FAILURE = 2 };
+
+/* Fields of ceres::IterationSummary consumed by IterationLogger
+ * (include/debugging/optimization_logger.h:58-81). */
+typedef struct {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t reserved;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double iteration_time_in_seconds;
+} obvi_iteration_summary;
+
+/* Fields of ceres::Solver::Summary consumed by OptimizationLogger
+ * (include/debugging/optimization_logger.h:192-203) and solveOptimization (:698-706). */
+typedef struct {
+  int32_t termination_type;
+  int32_t is_solution_usable;        /* Summary::IsSolutionUsable() */
+  int32_t num_iterations;            /* == iterations.size(): includes the iteration-0 record */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_parameters_reduced;    /* scalar parameters in non-constant, used blocks */
+  int32_t num_residuals_reduced;
+  int32_t reduced_system_size;       /* rows of the Schur complement (poses + objects) */
+  double initial_cost;
+  double final_cost;
+  double fixed_cost;
+  double total_time_in_seconds;
+  double linear_solver_time_in_seconds;
+  double jacobian_evaluation_time_in_seconds;
+  double residual_evaluation_time_in_seconds;
+  char message[160];
+} obvi_summary;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out);
+void obvi_ba_destroy(obvi_ba_handle* h);
+const char* obvi_ba_last_error(const obvi_ba_handle* h);
+const char* obvi_ba_version(void);
+
+/* ---- parameter blocks  (getPosePointers low_level_feature_pose_graph.h:315-321,
+ *      getFeaturePointers :692-700, getObjectParamPointers object_pose_graph.h:495-503;
+ *      constness: object_pose_graph_optimizer.h:424-472, 532-603) --------------------- */
+int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* fx_fy_cx_cy /*[n][4]*/,
+                        const double* ext_qxyzw_t /*[n][7]*/);
+int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* pose6 /*[n][6]*/,
+                      const uint8_t* is_const /*[n] or NULL = all variable*/);
+int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* xyz /*[n][3]*/,
+                       const uint8_t* is_const);
+int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* ell7 /*[n][7]*/,
+                        const uint8_t* is_const);
+/* change constness without re-uploading values (window slide / PGO stage) */
+int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pose_const, const uint8_t* point_const,
+                            const uint8_t* object_const /* any may be NULL = unchanged */);
+
+/* ---- factors ----------------------------------------------------------------------- */
+/* ReprojectionErrorFactor -> ReprojectionCostFunctor (reprojection_cost_functor.h:56-93,
+ * .cpp:5-17) wrapped in HuberLoss(huber) (residual_creator.h:251-264). */
+int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, const uint32_t* point_idx,
+                       const uint16_t* cam_idx, const double* pixel_xy /*[n][2]*/,
+                       const double* sigma /*[n] or NULL*/, double sigma_scalar, double huber);
+/* ObjectObservationFactor -> BoundingBoxFactor (bounding_box_factor.h:68-136, .cpp:7-40);
+ * corners (min_x,max_x,min_y,max_y) px (vslam_obj_opt_types_refactor.h:184-191). */
+int obvi_ba_set_bbox(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, const uint32_t* pose_idx,
+                     const uint16_t* cam_idx, const double* corners /*[n][4]*/,
+                     const double* cov /*[n][16] row-major*/, double huber, double invalid_ellipse_error);
+/* ShapeDimPriorFactor -> ShapePriorFactor (shape_prior_factor.h:46-61, .cpp:7-11). */
+int obvi_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx,
+                             const double* mean3, const double* cov9, double huber);
+/* LTM prior -> IndependentObjectMapFactor (independent_object_map_factor.h:21-33, .cpp:7-11;
+ * long_term_map_factor_creator.h:265-322). */
+int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx,
+                           const double* mean7, const double* cov49, double huber);
+/* RelPoseFactor -> RelativePoseFactor (relative_pose_factor.h:32-61, .cpp:7-19); measured
+ * relative pose given as translation + axis-angle vector of Pose3D::orientation_. */
+int obvi_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx_a,
+                        const uint32_t* pose_idx_b, const double* t3, const double* aa3,
+                        const double* cov36, double huber);
+/* excluded_feature_factor_types_and_ids (object_pose_graph_optimizer.h:133-135): mask[i]==0
+ * drops factor i of that type from the problem; NULL = all active. */
+int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t factor_type, const uint8_t* mask);
+
+/* ---- evaluate / solve -------------------------------------------------------------- */
+/* problem->Evaluate(apply_loss_function, ...) (object_pose_graph_optimizer.h:682-693).
+ * residuals: concatenation in factor-type order 0,2,3,4,5, each factor its
+ * OBVI_RESIDUAL_DIM_* entries, inactive factors written as 0; block_sqnorm: one entry per
+ * factor in the same order (the per-block sum of squares the runner recomputes at
+ * offline_problem_runner.h:721-733).  Either may be NULL. */
+int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double* residuals,
+                     double* block_sqnorm);
+int64_t obvi_ba_num_residuals(const obvi_ba_handle* h);
+int64_t obvi_ba_num_factors(const obvi_ba_handle* h, int32_t factor_type);
+
+int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* params, obvi_summary* summary);
+/* copies min(cap, summary.num_iterations) records of the last solve; returns the count */
+int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap);
+
+/* per factor type: mask_out[i]=0 for the floor(n_active*fraction) active factors with the
+ * largest un-robustified squared residual at the current estimate, 1 otherwise
+ * (offline_problem_runner.h:769-800).  Runs on the device. */
+int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t factor_type, double fraction,
+                            uint8_t* mask_out, int64_t* num_excluded);
+
+/* ---- state ------------------------------------------------------------------------- */
+int obvi_ba_snapshot(obvi_ba_handle* h);
+int obvi_ba_restore(obvi_ba_handle* h);
+int obvi_ba_get_poses(obvi_ba_handle* h, double* out /*[n][6]*/);
+int obvi_ba_get_points(obvi_ba_handle* h, double* out /*[n][3]*/);
+int obvi_ba_get_objects(obvi_ba_handle* h, double* out /*[n][7]*/);
+/* overwrite values only (feature re-attachment after PGO,
+ * pose_graph_plus_objects_optimizer.h:238-283) */
+int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
+
+/* ---- multi-GPU (no reference counterpart) ------------------------------- */
+/* Called on the handle's stream between linearisation and the reduced solve of every LM
+ * step with the device buffer of packed shared-object blocks [n_obj][7*7 + 7 + 1]
+ * (H_oo, g_o, cost share).  The callee sums it across ranks in place (RCCL all-reduce).
+ * stream is a hipStream_t.  Return non-zero to abort the solve with OBVI_FAILURE. */
+typedef int (*obvi_allreduce_fn)(void* user, void* device_buf, int64_t count_f64, void* stream);
+int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user);
+
+/* ---- test / profiling hooks (parity tests call these through the C ABI) ------------ */
+/* raw (un-robustified) residual and Jacobians of every factor of one type at the current
+ * estimate, row-major: J0 w.r.t. the first block of the factor, J1 the second
+ *   type 0: r[n][2], J0 = d/dpose [n][2][6], J1 = d/dpoint  [n][2][3]
+ *   type 2: r[n][4], J0 = d/dobject [n][4][7], J1 = d/dpose [n][4][6]
+ *   type 3: r[n][3], J0 [n][3][7]          type 4: r[n][7], J0 [n][7][7]
+ *   type 5: r[n][6], J0 = d/dpose_a [n][6][6], J1 = d/dpose_b [n][6][6]  */
+int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t factor_type, double* r, double* J0, double* J1);
+/* dense reduced (Schur) system at the current estimate for LM diagonal 1/radius:
+ * lhs [m][m] row-major symmetric, rhs [m]; order = variable poses then variable objects. */
+int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, double* rhs, int32_t m_cap,
+                                 int32_t* m_out);
+/* per-kernel device timings of the last solve (ms, HIP events on the handle's stream):
+ * names is a NUL-separated list; returns number of entries. */
+int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms,
+                             int64_t* launches, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBVI_BA_H_ */

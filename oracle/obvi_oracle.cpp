@@ -1,0 +1,1040 @@
+// obvi_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU oracle for the bundle-adjustment hot path: the same flat problem the C ABI in
+// include/obvi_ba.h accepts, evaluated and solved on the host in scalar fp64.  Exposed as
+// `oracle_*` functions with the signatures of their `obvi_ba_*` counterparts so parity tests
+// feed both the same arrays.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library; the product (obvi-slam_amd/) never does.
+//
+// What it restates, and from where (all paths under /root/reference):
+//   factors          -> oracle_factors.h (cites each functor)
+//   evaluate         -> problem->Evaluate(apply_loss_function=false|true)
+//                       include/refactoring/optimization/object_pose_graph_optimizer.h:682-693
+//   solve            -> ceres::Solve with the option block at object_pose_graph_optimizer.h:651-676
+//                       (SPARSE_SCHUR, HuberLoss, Levenberg-Marquardt, Jacobi scaling,
+//                       non-monotonic steps).  Ceres itself is an un-vendored, un-pinned
+//                       dependency (CMakeLists.txt:41-44 "Recommended to use Ceres 1.14"); the
+//                       trust-region loop below restates its published algorithm
+//                       (trust_region_minimizer.cc / levenberg_marquardt_strategy.cc /
+//                       trust_region_step_evaluator.cc / schur_complement_solver.cc of Ceres
+//                       1.14-2.x) and is marked [Ceres-doc] where it does.
+//   select_outliers  -> include/refactoring/offline/offline_problem_runner.h:769-800
+//
+// PARITY STATUS: factor arithmetic is pinned by the two golden tuples the survey derived from
+// the reference's own code (tests/golden/reference_tuples.json) plus independent numpy
+// fixtures; the solver level is "parity unpinned" -- the reference holds no test or vector
+// for any residual, Jacobian, cost or solve and Ceres is not installed.
+#include "../include/obvi_ba.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "oracle_factors.h"
+
+namespace {
+using namespace oracle;  // NOLINT
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct OracleProblem {
+  std::vector<CameraConst> cams;
+  int64_t P = 0, L = 0, O = 0;
+  std::vector<double> poses, points, objects;
+  std::vector<uint8_t> pose_const, point_const, object_const;
+  // reprojection
+  int64_t n_rp = 0;
+  std::vector<uint32_t> rp_pose, rp_point; std::vector<uint16_t> rp_cam;
+  std::vector<double> rp_pixel, rp_sigma; double rp_huber = 1.0; std::vector<uint8_t> rp_active;
+  // bbox
+  int64_t n_bb = 0;
+  std::vector<uint32_t> bb_obj, bb_pose; std::vector<uint16_t> bb_cam;
+  std::vector<double> bb_rect, bb_sqrt_inf; double bb_huber = 1.0, bb_invalid = 1e6; std::vector<uint8_t> bb_active;
+  // shape prior
+  int64_t n_sp = 0;
+  std::vector<uint32_t> sp_obj; std::vector<double> sp_mean, sp_sqrt_inf; double sp_huber = 1.0; std::vector<uint8_t> sp_active;
+  // ltm prior
+  int64_t n_lt = 0;
+  std::vector<uint32_t> lt_obj; std::vector<double> lt_mean, lt_sqrt_inf; double lt_huber = 1.0; std::vector<uint8_t> lt_active;
+  // relative pose
+  int64_t n_rl = 0;
+  std::vector<uint32_t> rl_a, rl_b; std::vector<double> rl_t, rl_R, rl_sqrt_inf; double rl_huber = 1.0; std::vector<uint8_t> rl_active;
+  // snapshot
+  std::vector<double> snap_poses, snap_points, snap_objects;
+  // last solve
+  std::vector<obvi_iteration_summary> iterations;
+  std::string err;
+};
+
+// ---------------------------------------------------------------------------------------
+// linearised factor record: robustified residual and Jacobians w.r.t. up to two blocks
+// ---------------------------------------------------------------------------------------
+enum BlockKind { KIND_POSE = 0, KIND_POINT = 1, KIND_OBJECT = 2, KIND_NONE = 3 };
+static const int kBlockDim[4] = {6, 3, 7, 0};
+
+struct FactorLin {
+  int m = 0;                 // residual dim
+  BlockKind k0 = KIND_NONE, k1 = KIND_NONE;
+  int64_t i0 = -1, i1 = -1;  // block indices
+  double r[7];
+  double J0[49];             // m x dim(k0), row-major
+  double J1[49];             // m x dim(k1)
+  double cost = 0.0;         // 0.5 * rho(s)
+  double sqnorm = 0.0;       // un-robustified |r|^2
+};
+
+// Apply the loss the way ceres::ResidualBlock::Evaluate + Corrector do [Ceres-doc]: for
+// HuberLoss rho'' <= 0 always, so the corrector reduces to scaling r and J by sqrt(rho').
+void robustify(FactorLin* f, double huber_a, bool apply_loss) {
+  double s = 0.0;
+  for (int i = 0; i < f->m; ++i) s += f->r[i] * f->r[i];
+  f->sqnorm = s;
+  if (!apply_loss) { f->cost = 0.5 * s; return; }
+  double rho[3];
+  huber(s, huber_a, rho);
+  f->cost = 0.5 * rho[0];
+  const double w = std::sqrt(rho[1]);
+  if (w != 1.0) {
+    const int d0 = kBlockDim[f->k0], d1 = kBlockDim[f->k1];
+    for (int i = 0; i < f->m; ++i) f->r[i] *= w;
+    for (int i = 0; i < f->m * d0; ++i) f->J0[i] *= w;
+    for (int i = 0; i < f->m * d1; ++i) f->J1[i] *= w;
+  }
+}
+
+void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 2; f->k0 = KIND_POSE; f->k1 = KIND_POINT; f->i0 = pb.rp_pose[i]; f->i1 = pb.rp_point[i];
+  const double* pose = &pb.poses[6 * f->i0];
+  const double* pt = &pb.points[3 * f->i1];
+  const CameraConst& cam = pb.cams[pb.rp_cam[i]];
+  if (!jac) { reprojection_residual<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r); return; }
+  typedef Dual<9> D;
+  D dp[6], dx[3], dr[2];
+  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], k);
+  for (int k = 0; k < 3; ++k) dx[k] = D::var(pt[k], 6 + k);
+  reprojection_residual<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
+  for (int a = 0; a < 2; ++a) {
+    f->r[a] = dr[a].v;
+    for (int k = 0; k < 6; ++k) f->J0[6 * a + k] = dr[a].d[k];
+    for (int k = 0; k < 3; ++k) f->J1[3 * a + k] = dr[a].d[6 + k];
+  }
+}
+
+void lin_bbox(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 4; f->k0 = KIND_OBJECT; f->k1 = KIND_POSE; f->i0 = pb.bb_obj[i]; f->i1 = pb.bb_pose[i];
+  const double* ell = &pb.objects[7 * f->i0];
+  const double* pose = &pb.poses[6 * f->i1];
+  const CameraConst& cam = pb.cams[pb.bb_cam[i]];
+  if (!jac) { bbox_residual<double>(ell, pose, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, f->r); return; }
+  typedef Dual<13> D;
+  D de[7], dp[6], dr[4];
+  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
+  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], 7 + k);
+  bbox_residual<D>(de, dp, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, dr);
+  for (int a = 0; a < 4; ++a) {
+    f->r[a] = dr[a].v;
+    for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k];
+    for (int k = 0; k < 6; ++k) f->J1[6 * a + k] = dr[a].d[7 + k];
+  }
+}
+
+void lin_shape(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 3; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.sp_obj[i]; f->i1 = -1;
+  const double* ell = &pb.objects[7 * f->i0];
+  if (!jac) { shape_prior_residual<double>(ell, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], f->r); return; }
+  typedef Dual<7> D;
+  D de[7], dr[3];
+  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
+  shape_prior_residual<D>(de, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], dr);
+  for (int a = 0; a < 3; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
+}
+
+void lin_ltm(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 7; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.lt_obj[i]; f->i1 = -1;
+  const double* ell = &pb.objects[7 * f->i0];
+  if (!jac) { ltm_prior_residual<double>(ell, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], f->r); return; }
+  typedef Dual<7> D;
+  D de[7], dr[7];
+  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
+  ltm_prior_residual<D>(de, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], dr);
+  for (int a = 0; a < 7; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
+}
+
+void lin_relpose(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 6; f->k0 = KIND_POSE; f->k1 = KIND_POSE; f->i0 = pb.rl_a[i]; f->i1 = pb.rl_b[i];
+  const double* pa = &pb.poses[6 * f->i0];
+  const double* pbb = &pb.poses[6 * f->i1];
+  if (!jac) { relpose_residual<double>(pa, pbb, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], f->r); return; }
+  typedef Dual<12> D;
+  D da[6], db[6], dr[6];
+  for (int k = 0; k < 6; ++k) { da[k] = D::var(pa[k], k); db[k] = D::var(pbb[k], 6 + k); }
+  relpose_residual<D>(da, db, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], dr);
+  for (int a = 0; a < 6; ++a) {
+    f->r[a] = dr[a].v;
+    for (int k = 0; k < 6; ++k) { f->J0[6 * a + k] = dr[a].d[k]; f->J1[6 * a + k] = dr[a].d[6 + k]; }
+  }
+}
+
+// factor families in the fixed order 0,2,3,4,5 used by evaluate()
+struct Family {
+  int type; int m; int64_t n; const std::vector<uint8_t>* active; double huber;
+  void (*lin)(const OracleProblem&, int64_t, bool, FactorLin*);
+};
+std::vector<Family> families(const OracleProblem& pb) {
+  return {{OBVI_FACTOR_REPROJECTION, 2, pb.n_rp, &pb.rp_active, pb.rp_huber, lin_reproj},
+          {OBVI_FACTOR_BBOX, 4, pb.n_bb, &pb.bb_active, pb.bb_huber, lin_bbox},
+          {OBVI_FACTOR_SHAPE_PRIOR, 3, pb.n_sp, &pb.sp_active, pb.sp_huber, lin_shape},
+          {OBVI_FACTOR_LTM_PRIOR, 7, pb.n_lt, &pb.lt_active, pb.lt_huber, lin_ltm},
+          {OBVI_FACTOR_REL_POSE, 6, pb.n_rl, &pb.rl_active, pb.rl_huber, lin_relpose}};
+}
+
+bool block_const(const OracleProblem& pb, BlockKind k, int64_t i) {
+  switch (k) {
+    case KIND_POSE: return pb.pose_const[i] != 0;
+    case KIND_POINT: return pb.point_const[i] != 0;
+    case KIND_OBJECT: return pb.object_const[i] != 0;
+    default: return true;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Reduced-program bookkeeping [Ceres-doc: Program::RemoveFixedBlocks]: constant parameter
+// blocks are dropped, residual blocks whose every parameter block is constant go into
+// fixed_cost, parameter blocks touched by no remaining residual block are dropped too.
+// ---------------------------------------------------------------------------------------
+struct Reduced {
+  std::vector<int32_t> pose_vid, obj_vid;  // index among variable+used blocks or -1
+  std::vector<uint8_t> point_var;          // variable+used
+  int64_t nPv = 0, nOv = 0, nLv = 0;
+  int64_t m = 0;                           // reduced (Schur) system rows = 6 nPv + 7 nOv
+  int64_t num_params = 0, num_residuals = 0;
+  double fixed_cost = 0.0;
+};
+
+struct Workspace {
+  // per-factor linearisation records of the variable part of the problem
+  std::vector<FactorLin> lin;
+  // skyline storage of the reduced system: row i holds columns first[i]..i
+  std::vector<int64_t> first, rowptr;
+  std::vector<double> S, rhs;
+  // point blocks
+  std::vector<double> Hll, gl;            // 9 / 3 per point
+  std::vector<double> Hpp_diag;           // diag(J^T J) per reduced row (poses, objects)
+  std::vector<double> colsq_c, colsq_l;   // squared column norms: reduced rows / points (3 per point)
+  std::vector<double> g_c;                // gradient, reduced rows
+  std::vector<std::vector<int64_t>> point_obs;  // per point: indices into lin of its reprojection records
+};
+
+inline int64_t pose_row(const Reduced& rd, int64_t p) { return 6 * (int64_t)rd.pose_vid[p]; }
+inline int64_t obj_row(const Reduced& rd, int64_t o) { return 6 * rd.nPv + 7 * (int64_t)rd.obj_vid[o]; }
+
+void build_reduced(const OracleProblem& pb, Reduced* rd) {
+  rd->pose_vid.assign(pb.P, -1); rd->obj_vid.assign(pb.O, -1); rd->point_var.assign(pb.L, 0);
+  std::vector<uint8_t> pose_used(pb.P, 0), obj_used(pb.O, 0), point_used(pb.L, 0);
+  rd->num_residuals = 0; rd->fixed_cost = 0.0;
+  for (const Family& fam : families(pb)) {
+    for (int64_t i = 0; i < fam.n; ++i) {
+      if (!(*fam.active)[i]) continue;
+      FactorLin f; fam.lin(pb, i, false, &f);
+      const bool c0 = block_const(pb, f.k0, f.i0), c1 = block_const(pb, f.k1, f.i1);
+      if (c0 && c1) {  // all-constant residual block -> fixed cost
+        robustify(&f, fam.huber, true);
+        rd->fixed_cost += f.cost;
+        continue;
+      }
+      rd->num_residuals += fam.m;
+      auto mark = [&](BlockKind k, int64_t idx) {
+        if (k == KIND_POSE) pose_used[idx] = 1; else if (k == KIND_POINT) point_used[idx] = 1; else if (k == KIND_OBJECT) obj_used[idx] = 1;
+      };
+      if (!c0) mark(f.k0, f.i0);
+      if (!c1) mark(f.k1, f.i1);
+    }
+  }
+  rd->nPv = rd->nOv = rd->nLv = 0;
+  for (int64_t p = 0; p < pb.P; ++p) if (!pb.pose_const[p] && pose_used[p]) rd->pose_vid[p] = (int32_t)rd->nPv++;
+  for (int64_t o = 0; o < pb.O; ++o) if (!pb.object_const[o] && obj_used[o]) rd->obj_vid[o] = (int32_t)rd->nOv++;
+  for (int64_t l = 0; l < pb.L; ++l) if (!pb.point_const[l] && point_used[l]) { rd->point_var[l] = 1; rd->nLv++; }
+  rd->m = 6 * rd->nPv + 7 * rd->nOv;
+  rd->num_params = rd->m + 3 * rd->nLv;
+}
+
+bool is_var(const OracleProblem& pb, const Reduced& rd, BlockKind k, int64_t i) {
+  switch (k) {
+    case KIND_POSE: return rd.pose_vid[i] >= 0;
+    case KIND_POINT: return rd.point_var[i] != 0;
+    case KIND_OBJECT: return rd.obj_vid[i] >= 0;
+    default: return false;
+  }
+  (void)pb;
+}
+int64_t reduced_row(const Reduced& rd, BlockKind k, int64_t i) {
+  return k == KIND_POSE ? pose_row(rd, i) : obj_row(rd, i);
+}
+
+// Cost only (trial point evaluation) over the reduced program.
+double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
+  double cost = 0.0;
+  for (const Family& fam : families(pb)) {
+    for (int64_t i = 0; i < fam.n; ++i) {
+      if (!(*fam.active)[i]) continue;
+      FactorLin f; fam.lin(pb, i, false, &f);
+      if (!is_var(pb, rd, f.k0, f.i0) && !is_var(pb, rd, f.k1, f.i1)) continue;
+      robustify(&f, fam.huber, true);
+      cost += f.cost;
+    }
+  }
+  return cost;
+}
+
+// Full linearisation at the current estimate: robustified r, J per residual block;
+// squared column norms, gradient, point blocks; skyline envelope of the reduced system.
+double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
+  ws->lin.clear();
+  ws->point_obs.assign(pb.L, {});
+  double cost = 0.0;
+  for (const Family& fam : families(pb)) {
+    for (int64_t i = 0; i < fam.n; ++i) {
+      if (!(*fam.active)[i]) continue;
+      FactorLin f; fam.lin(pb, i, true, &f);
+      const bool v0 = is_var(pb, rd, f.k0, f.i0), v1 = is_var(pb, rd, f.k1, f.i1);
+      if (!v0 && !v1) continue;
+      robustify(&f, fam.huber, true);
+      cost += f.cost;
+      if (!v0) { std::memset(f.J0, 0, sizeof(f.J0)); }
+      if (!v1) { std::memset(f.J1, 0, sizeof(f.J1)); }
+      if (fam.type == OBVI_FACTOR_REPROJECTION && v1) ws->point_obs[f.i1].push_back((int64_t)ws->lin.size());
+      ws->lin.push_back(f);
+    }
+  }
+  // squared column norms and gradient
+  ws->colsq_c.assign(rd.m, 0.0); ws->g_c.assign(rd.m, 0.0);
+  ws->colsq_l.assign(3 * pb.L, 0.0); ws->gl.assign(3 * pb.L, 0.0); ws->Hll.assign(9 * pb.L, 0.0);
+  for (const FactorLin& f : ws->lin) {
+    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+    for (int b = 0; b < 2; ++b) {
+      if (!is_var(pb, rd, ks[b], is[b])) continue;
+      const int d = kBlockDim[ks[b]];
+      if (ks[b] == KIND_POINT) {
+        double* c = &ws->colsq_l[3 * is[b]]; double* g = &ws->gl[3 * is[b]]; double* H = &ws->Hll[9 * is[b]];
+        for (int a = 0; a < f.m; ++a) for (int k = 0; k < 3; ++k) {
+          const double j = Js[b][3 * a + k];
+          c[k] += j * j; g[k] += j * f.r[a];
+          for (int k2 = 0; k2 < 3; ++k2) H[3 * k + k2] += j * Js[b][3 * a + k2];
+        }
+      } else {
+        const int64_t row = reduced_row(rd, ks[b], is[b]);
+        for (int a = 0; a < f.m; ++a) for (int k = 0; k < d; ++k) {
+          const double j = Js[b][d * a + k];
+          ws->colsq_c[row + k] += j * j; ws->g_c[row + k] += j * f.r[a];
+        }
+      }
+    }
+  }
+  return cost;
+}
+
+// Envelope of the reduced system: block row r couples to the lowest reduced row it shares a
+// residual block (relpose, bbox) or an eliminated point with.
+void build_envelope(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
+  ws->first.resize(rd.m);
+  // every row of a diagonal block reaches back to the block's first row
+  for (int64_t v = 0; v < rd.nPv; ++v) for (int k = 0; k < 6; ++k) ws->first[6 * v + k] = 6 * v;
+  for (int64_t w = 0; w < rd.nOv; ++w) for (int k = 0; k < 7; ++k) ws->first[6 * rd.nPv + 7 * w + k] = 6 * rd.nPv + 7 * w;
+  auto couple = [&](int64_t ra, int da, int64_t rb, int db) {
+    if (ra < rb) { std::swap(ra, rb); std::swap(da, db); }
+    for (int k = 0; k < da; ++k) ws->first[ra + k] = std::min(ws->first[ra + k], rb);
+    (void)db;
+  };
+  for (const FactorLin& f : ws->lin) {
+    if (f.k0 == KIND_POINT || f.k1 == KIND_POINT || f.k1 == KIND_NONE) continue;
+    if (!is_var(pb, rd, f.k0, f.i0) || !is_var(pb, rd, f.k1, f.i1)) continue;
+    couple(reduced_row(rd, f.k0, f.i0), kBlockDim[f.k0], reduced_row(rd, f.k1, f.i1), kBlockDim[f.k1]);
+  }
+  for (int64_t l = 0; l < pb.L; ++l) {
+    const std::vector<int64_t>& obs = ws->point_obs[l];
+    int64_t lo = std::numeric_limits<int64_t>::max();
+    for (int64_t idx : obs) { const FactorLin& f = ws->lin[idx]; if (rd.pose_vid[f.i0] >= 0) lo = std::min(lo, pose_row(rd, f.i0)); }
+    for (int64_t idx : obs) {
+      const FactorLin& f = ws->lin[idx];
+      if (rd.pose_vid[f.i0] < 0) continue;
+      const int64_t row = pose_row(rd, f.i0);
+      for (int k = 0; k < 6; ++k) ws->first[row + k] = std::min(ws->first[row + k], lo);
+    }
+  }
+  ws->rowptr.assign(rd.m + 1, 0);
+  for (int64_t i = 0; i < rd.m; ++i) ws->rowptr[i + 1] = ws->rowptr[i] + (i - ws->first[i] + 1);
+  ws->S.assign(ws->rowptr[rd.m], 0.0);
+  ws->rhs.assign(rd.m, 0.0);
+}
+inline double& Sat(Workspace* ws, int64_t i, int64_t j) {  // i >= j >= first[i]
+  return ws->S[ws->rowptr[i] + (j - ws->first[i])];
+}
+
+// Assemble the Schur complement for the per-parameter damping lambda (unscaled normal
+// equations, see solve()):  (H + Lambda) y = g  with the points eliminated.
+// [Ceres-doc: SchurEliminator::Eliminate]
+bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vector<double>& lam_c,
+                    const std::vector<double>& lam_l, Workspace* ws, std::vector<double>* Hll_inv) {
+  std::fill(ws->S.begin(), ws->S.end(), 0.0);
+  for (int64_t i = 0; i < rd.m; ++i) { ws->rhs[i] = ws->g_c[i]; Sat(ws, i, i) = lam_c[i]; }
+  // camera/object blocks: J_c^T J_c (lower triangle).  A factor's two blocks are distinct
+  // parameter blocks (pose/object, or two different poses), so ra != rb whenever a != b.
+  for (const FactorLin& f : ws->lin) {
+    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+    for (int a = 0; a < 2; ++a) {
+      if (ks[a] == KIND_POINT || ks[a] == KIND_NONE || !is_var(pb, rd, ks[a], is[a])) continue;
+      const int da = kBlockDim[ks[a]]; const int64_t ra = reduced_row(rd, ks[a], is[a]);
+      for (int b = 0; b < 2; ++b) {
+        if (ks[b] == KIND_POINT || ks[b] == KIND_NONE || !is_var(pb, rd, ks[b], is[b])) continue;
+        const int db = kBlockDim[ks[b]]; const int64_t rb = reduced_row(rd, ks[b], is[b]);
+        if (rb > ra || (a != b && ra == rb)) continue;
+        for (int x = 0; x < da; ++x) for (int y = 0; y < db; ++y) {
+          if (ra == rb && y > x) continue;
+          double acc = 0.0;
+          for (int q = 0; q < f.m; ++q) acc += Js[a][da * q + x] * Js[b][db * q + y];
+          Sat(ws, ra + x, rb + y) += acc;
+        }
+      }
+    }
+  }
+  // eliminate points
+  Hll_inv->assign(9 * pb.L, 0.0);
+  for (int64_t l = 0; l < pb.L; ++l) {
+    if (!rd.point_var[l]) continue;
+    double H[9];
+    for (int k = 0; k < 9; ++k) H[k] = ws->Hll[9 * l + k];
+    for (int k = 0; k < 3; ++k) H[4 * k] += lam_l[3 * l + k];
+    // 3x3 symmetric inverse via cofactors
+    const double c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
+    const double det = H[0] * c00 + H[1] * c01 + H[2] * c02;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    double* Hi = &(*Hll_inv)[9 * l];
+    Hi[0] = c00 / det; Hi[1] = (H[2] * H[7] - H[1] * H[8]) / det; Hi[2] = (H[1] * H[5] - H[2] * H[4]) / det;
+    Hi[3] = Hi[1];     Hi[4] = (H[0] * H[8] - H[2] * H[6]) / det; Hi[5] = (H[2] * H[3] - H[0] * H[5]) / det;
+    Hi[6] = Hi[2];     Hi[7] = Hi[5];                             Hi[8] = (H[0] * H[4] - H[1] * H[3]) / det;
+    const std::vector<int64_t>& obs = ws->point_obs[l];
+    // W_i = J_p,i^T J_l,i (6x3) for observations with a variable pose
+    std::vector<double> W(18 * obs.size()), Y(18 * obs.size());
+    for (size_t a = 0; a < obs.size(); ++a) {
+      const FactorLin& f = ws->lin[obs[a]];
+      if (rd.pose_vid[f.i0] < 0) continue;
+      double* Wa = &W[18 * a]; double* Ya = &Y[18 * a];
+      for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
+        Wa[3 * x + k] = f.J0[x] * f.J1[k] + f.J0[6 + x] * f.J1[3 + k];
+      for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
+        Ya[3 * x + k] = Wa[3 * x] * Hi[k] + Wa[3 * x + 1] * Hi[3 + k] + Wa[3 * x + 2] * Hi[6 + k];
+      const int64_t ra = pose_row(rd, f.i0);
+      for (int x = 0; x < 6; ++x)
+        ws->rhs[ra + x] -= Ya[3 * x] * ws->gl[3 * l] + Ya[3 * x + 1] * ws->gl[3 * l + 1] + Ya[3 * x + 2] * ws->gl[3 * l + 2];
+    }
+    for (size_t a = 0; a < obs.size(); ++a) {
+      const FactorLin& fa = ws->lin[obs[a]];
+      if (rd.pose_vid[fa.i0] < 0) continue;
+      const int64_t ra = pose_row(rd, fa.i0);
+      for (size_t b = 0; b < obs.size(); ++b) {
+        const FactorLin& fb = ws->lin[obs[b]];
+        if (rd.pose_vid[fb.i0] < 0) continue;
+        const int64_t rb = pose_row(rd, fb.i0);
+        if (rb > ra) continue;
+        const double* Ya = &Y[18 * a]; const double* Wb = &W[18 * b];
+        for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
+          if (ra == rb && y > x) continue;
+          Sat(ws, ra + x, rb + y) -= Ya[3 * x] * Wb[3 * y] + Ya[3 * x + 1] * Wb[3 * y + 1] + Ya[3 * x + 2] * Wb[3 * y + 2];
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// In-place envelope (skyline) Cholesky S = L L^T and solve.  [Ceres-doc: the reduced system
+// is factorised exactly by a sparse Cholesky; the elimination order does not change the result.]
+bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
+  for (int64_t i = 0; i < m; ++i) {
+    const int64_t fi = ws->first[i];
+    double* Li = &ws->S[ws->rowptr[i]] - fi;
+    for (int64_t j = fi; j < i; ++j) {
+      const int64_t fj = ws->first[j];
+      const double* Lj = &ws->S[ws->rowptr[j]] - fj;
+      const int64_t k0 = std::max(fi, fj);
+      double s = Li[j];
+      for (int64_t k = k0; k < j; ++k) s -= Li[k] * Lj[k];
+      Li[j] = s / Lj[j];
+    }
+    double s = Li[i];
+    for (int64_t k = fi; k < i; ++k) s -= Li[k] * Li[k];
+    if (!(s > 0.0) || !std::isfinite(s)) return false;
+    Li[i] = std::sqrt(s);
+  }
+  x->assign(ws->rhs.begin(), ws->rhs.end());
+  for (int64_t i = 0; i < m; ++i) {  // L z = b
+    const int64_t fi = ws->first[i];
+    const double* Li = &ws->S[ws->rowptr[i]] - fi;
+    double s = (*x)[i];
+    for (int64_t k = fi; k < i; ++k) s -= Li[k] * (*x)[k];
+    (*x)[i] = s / Li[i];
+  }
+  for (int64_t i = m - 1; i >= 0; --i) {  // L^T y = z
+    const int64_t fi = ws->first[i];
+    const double* Li = &ws->S[ws->rowptr[i]] - fi;
+    const double xi = (*x)[i] / Li[i];
+    (*x)[i] = xi;
+    for (int64_t k = fi; k < i; ++k) (*x)[k] -= Li[k] * xi;
+  }
+  return true;
+}
+
+void copy_params(const OracleProblem& pb, std::vector<double>* a, std::vector<double>* b, std::vector<double>* c) {
+  *a = pb.poses; *b = pb.points; *c = pb.objects;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C interface (mirrors include/obvi_ba.h, prefix oracle_)
+// =========================================================================================
+extern "C" {
+
+struct oracle_handle { OracleProblem pb; };
+
+int oracle_ba_create(const obvi_ba_options* opt, oracle_handle** out) {
+  if (!out) return OBVI_ERR_INVALID_ARGUMENT;
+  if (opt && opt->object_block_size != 0 && opt->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  *out = new oracle_handle();
+  return OBVI_OK;
+}
+void oracle_ba_destroy(oracle_handle* h) { delete h; }
+
+int oracle_ba_set_cameras(oracle_handle* h, int32_t n, const double* K, const double* ext) {
+  if (!h || n < 0 || (n > 0 && (!K || !ext))) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.cams.resize(n);
+  for (int i = 0; i < n; ++i) make_camera_const(K + 4 * i, ext + 7 * i, &h->pb.cams[i]);
+  return OBVI_OK;
+}
+static void set_block(std::vector<double>* dst, std::vector<uint8_t>* cdst, int64_t n, int dim, const double* v, const uint8_t* c) {
+  dst->assign(v, v + n * dim);
+  if (c) cdst->assign(c, c + n); else cdst->assign(n, 0);
+}
+int oracle_ba_set_poses(oracle_handle* h, int64_t n, const double* v, const uint8_t* c) {
+  if (!h || n < 0 || (n > 0 && !v)) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.P = n; set_block(&h->pb.poses, &h->pb.pose_const, n, 6, v, c); return OBVI_OK;
+}
+int oracle_ba_set_points(oracle_handle* h, int64_t n, const double* v, const uint8_t* c) {
+  if (!h || n < 0 || (n > 0 && !v)) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.L = n; set_block(&h->pb.points, &h->pb.point_const, n, 3, v, c); return OBVI_OK;
+}
+int oracle_ba_set_objects(oracle_handle* h, int64_t n, const double* v, const uint8_t* c) {
+  if (!h || n < 0 || (n > 0 && !v)) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.O = n; set_block(&h->pb.objects, &h->pb.object_const, n, 7, v, c); return OBVI_OK;
+}
+int oracle_ba_set_const_flags(oracle_handle* h, const uint8_t* pc, const uint8_t* lc, const uint8_t* oc) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (pc) h->pb.pose_const.assign(pc, pc + h->pb.P);
+  if (lc) h->pb.point_const.assign(lc, lc + h->pb.L);
+  if (oc) h->pb.object_const.assign(oc, oc + h->pb.O);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_reproj(oracle_handle* h, int64_t n, const uint32_t* pose_idx, const uint32_t* point_idx,
+                         const uint16_t* cam_idx, const double* pixel, const double* sigma, double sigma_scalar, double huber) {
+  if (!h || n < 0 || (n > 0 && (!pose_idx || !point_idx || !pixel))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) {
+    const int cam = cam_idx ? cam_idx[i] : 0;
+    if (pose_idx[i] >= pb.P || point_idx[i] >= pb.L || cam >= (int)pb.cams.size()) return OBVI_ERR_OUT_OF_RANGE;
+  }
+  pb.n_rp = n; pb.rp_pose.assign(pose_idx, pose_idx + n); pb.rp_point.assign(point_idx, point_idx + n);
+  if (cam_idx) pb.rp_cam.assign(cam_idx, cam_idx + n); else pb.rp_cam.assign(n, 0);
+  pb.rp_pixel.assign(pixel, pixel + 2 * n);
+  if (sigma) pb.rp_sigma.assign(sigma, sigma + n); else pb.rp_sigma.assign(n, sigma_scalar);
+  pb.rp_huber = huber; pb.rp_active.assign(n, 1);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_bbox(oracle_handle* h, int64_t n, const uint32_t* obj_idx, const uint32_t* pose_idx, const uint16_t* cam_idx,
+                       const double* corners, const double* cov, double huber, double invalid_err) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !pose_idx || !corners || !cov))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) {
+    const int cam = cam_idx ? cam_idx[i] : 0;
+    if (obj_idx[i] >= pb.O || pose_idx[i] >= pb.P || cam >= (int)pb.cams.size()) return OBVI_ERR_OUT_OF_RANGE;
+  }
+  pb.n_bb = n; pb.bb_obj.assign(obj_idx, obj_idx + n); pb.bb_pose.assign(pose_idx, pose_idx + n);
+  if (cam_idx) pb.bb_cam.assign(cam_idx, cam_idx + n); else pb.bb_cam.assign(n, 0);
+  pb.bb_rect.resize(4 * n); pb.bb_sqrt_inf.resize(16 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    const CameraConst& c = pb.cams[pb.bb_cam[i]];
+    // bounding_box_factor.cpp:26-39
+    double si[16];
+    if (!spd_inverse_sqrt(cov + 16 * i, 4, si)) return OBVI_ERR_NUMERICAL;
+    const double scale[4] = {c.fx, c.fx, c.fy, c.fy};
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) pb.bb_sqrt_inf[16 * i + 4 * a + b] = si[4 * a + b] * scale[b];
+    pb.bb_rect[4 * i + 0] = (corners[4 * i + 0] - c.cx) / c.fx; pb.bb_rect[4 * i + 1] = (corners[4 * i + 1] - c.cx) / c.fx;
+    pb.bb_rect[4 * i + 2] = (corners[4 * i + 2] - c.cy) / c.fy; pb.bb_rect[4 * i + 3] = (corners[4 * i + 3] - c.cy) / c.fy;
+  }
+  pb.bb_huber = huber; pb.bb_invalid = invalid_err; pb.bb_active.assign(n, 1);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_shape_priors(oracle_handle* h, int64_t n, const uint32_t* obj_idx, const double* mean3, const double* cov9, double huber) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !mean3 || !cov9))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) if (obj_idx[i] >= pb.O) return OBVI_ERR_OUT_OF_RANGE;
+  pb.n_sp = n; pb.sp_obj.assign(obj_idx, obj_idx + n); pb.sp_mean.assign(mean3, mean3 + 3 * n); pb.sp_sqrt_inf.resize(9 * n);
+  for (int64_t i = 0; i < n; ++i) if (!spd_inverse_sqrt(cov9 + 9 * i, 3, &pb.sp_sqrt_inf[9 * i])) return OBVI_ERR_NUMERICAL;
+  pb.sp_huber = huber; pb.sp_active.assign(n, 1);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_ltm_priors(oracle_handle* h, int64_t n, const uint32_t* obj_idx, const double* mean7, const double* cov49, double huber) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !mean7 || !cov49))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) if (obj_idx[i] >= pb.O) return OBVI_ERR_OUT_OF_RANGE;
+  pb.n_lt = n; pb.lt_obj.assign(obj_idx, obj_idx + n); pb.lt_mean.assign(mean7, mean7 + 7 * n); pb.lt_sqrt_inf.resize(49 * n);
+  for (int64_t i = 0; i < n; ++i) if (!spd_inverse_sqrt(cov49 + 49 * i, 7, &pb.lt_sqrt_inf[49 * i])) return OBVI_ERR_NUMERICAL;
+  pb.lt_huber = huber; pb.lt_active.assign(n, 1);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_relpose(oracle_handle* h, int64_t n, const uint32_t* ia, const uint32_t* ib, const double* t3, const double* aa3,
+                          const double* cov36, double huber) {
+  if (!h || n < 0 || (n > 0 && (!ia || !ib || !t3 || !aa3 || !cov36))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) if (ia[i] >= pb.P || ib[i] >= pb.P) return OBVI_ERR_OUT_OF_RANGE;
+  pb.n_rl = n; pb.rl_a.assign(ia, ia + n); pb.rl_b.assign(ib, ib + n); pb.rl_t.assign(t3, t3 + 3 * n);
+  pb.rl_R.resize(9 * n); pb.rl_sqrt_inf.resize(36 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    // measured_pose_deviation.orientation_.toRotationMatrix()  (relative_pose_factor.cpp:11-12)
+    const double* a = aa3 + 3 * i;
+    const double ang = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (ang > 0.0) { const double ax[3] = {a[0] / ang, a[1] / ang, a[2] / ang}; angle_axis_to_matrix(ang, ax, &pb.rl_R[9 * i]); }
+    else { const double ax[3] = {1, 0, 0}; angle_axis_to_matrix(0.0, ax, &pb.rl_R[9 * i]); }
+    if (!spd_inverse_sqrt(cov36 + 36 * i, 6, &pb.rl_sqrt_inf[36 * i])) return OBVI_ERR_NUMERICAL;
+  }
+  pb.rl_huber = huber; pb.rl_active.assign(n, 1);
+  return OBVI_OK;
+}
+
+int oracle_ba_set_active_mask(oracle_handle* h, int32_t type, const uint8_t* mask) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  std::vector<uint8_t>* dst; int64_t n;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: dst = &pb.rp_active; n = pb.n_rp; break;
+    case OBVI_FACTOR_BBOX: dst = &pb.bb_active; n = pb.n_bb; break;
+    case OBVI_FACTOR_SHAPE_PRIOR: dst = &pb.sp_active; n = pb.n_sp; break;
+    case OBVI_FACTOR_LTM_PRIOR: dst = &pb.lt_active; n = pb.n_lt; break;
+    case OBVI_FACTOR_REL_POSE: dst = &pb.rl_active; n = pb.n_rl; break;
+    default: return OBVI_ERR_INVALID_ARGUMENT;
+  }
+  if (mask) dst->assign(mask, mask + n); else dst->assign(n, 1);
+  return OBVI_OK;
+}
+
+int64_t oracle_ba_num_factors(const oracle_handle* h, int32_t type) {
+  const OracleProblem& pb = h->pb;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: return pb.n_rp; case OBVI_FACTOR_BBOX: return pb.n_bb;
+    case OBVI_FACTOR_SHAPE_PRIOR: return pb.n_sp; case OBVI_FACTOR_LTM_PRIOR: return pb.n_lt;
+    case OBVI_FACTOR_REL_POSE: return pb.n_rl; default: return -1;
+  }
+}
+int64_t oracle_ba_num_residuals(const oracle_handle* h) {
+  const OracleProblem& pb = h->pb;
+  return 2 * pb.n_rp + 4 * pb.n_bb + 3 * pb.n_sp + 7 * pb.n_lt + 6 * pb.n_rl;
+}
+
+// problem->Evaluate: every active residual block (constant blocks included -- Problem::Evaluate
+// works on the full program), optional loss.  object_pose_graph_optimizer.h:682-693.
+int oracle_ba_evaluate(oracle_handle* h, int32_t apply_loss, double* cost, double* residuals, double* block_sqnorm) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  const OracleProblem& pb = h->pb;
+  double total = 0.0; int64_t ro = 0, bo = 0;
+  for (const Family& fam : families(pb)) {
+    for (int64_t i = 0; i < fam.n; ++i) {
+      if (!(*fam.active)[i]) {
+        if (residuals) for (int a = 0; a < fam.m; ++a) residuals[ro + a] = 0.0;
+        if (block_sqnorm) block_sqnorm[bo] = 0.0;
+      } else {
+        FactorLin f; fam.lin(pb, i, false, &f);
+        // k0/k1 used by robustify only for Jacobian scaling; residual-only here
+        f.k0 = KIND_NONE; f.k1 = KIND_NONE;
+        robustify(&f, fam.huber, apply_loss != 0);
+        total += f.cost;
+        if (residuals) for (int a = 0; a < fam.m; ++a) residuals[ro + a] = f.r[a];
+        if (block_sqnorm) block_sqnorm[bo] = f.sqnorm;
+      }
+      ro += fam.m; ++bo;
+    }
+  }
+  if (cost) *cost = total;
+  return OBVI_OK;
+}
+
+int oracle_ba_debug_linearize(oracle_handle* h, int32_t type, double* r, double* J0, double* J1) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  const OracleProblem& pb = h->pb;
+  for (const Family& fam : families(pb)) {
+    if (fam.type != type) continue;
+    for (int64_t i = 0; i < fam.n; ++i) {
+      FactorLin f; fam.lin(pb, i, true, &f);
+      const int d0 = kBlockDim[f.k0], d1 = kBlockDim[f.k1];
+      if (r) std::memcpy(r + fam.m * i, f.r, sizeof(double) * fam.m);
+      if (J0) std::memcpy(J0 + (int64_t)fam.m * d0 * i, f.J0, sizeof(double) * fam.m * d0);
+      if (J1 && d1) std::memcpy(J1 + (int64_t)fam.m * d1 * i, f.J1, sizeof(double) * fam.m * d1);
+    }
+    return OBVI_OK;
+  }
+  return OBVI_ERR_INVALID_ARGUMENT;
+}
+
+// Dense copy of the reduced system for LM diagonal computed from `radius` with the Jacobi
+// scaling of the current point (what iteration 1 of a solve would factorise).
+int oracle_ba_debug_reduced_system(oracle_handle* h, double radius, double* lhs, double* rhs, int32_t m_cap, int32_t* m_out) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  Reduced rd; build_reduced(pb, &rd);
+  if (m_out) *m_out = (int32_t)rd.m;
+  if (rd.m > m_cap) return OBVI_ERR_INVALID_ARGUMENT;
+  Workspace ws; linearize(pb, rd, &ws); build_envelope(pb, rd, &ws);
+  std::vector<double> lam_c(rd.m), lam_l(3 * pb.L, 0.0);
+  auto lam = [&](double c) {
+    const double s = 1.0 / (1.0 + std::sqrt(c));
+    const double d = std::min(std::max(c * s * s, 1e-6), 1e32);
+    return d / radius / (s * s);
+  };
+  for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = lam(ws.colsq_c[i]);
+  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) lam_l[3 * l + k] = lam(ws.colsq_l[3 * l + k]);
+  std::vector<double> Hinv;
+  if (!assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hinv)) return OBVI_ERR_NUMERICAL;
+  for (int64_t i = 0; i < rd.m; ++i) {
+    for (int64_t j = 0; j < rd.m; ++j) lhs[i * rd.m + j] = 0.0;
+    rhs[i] = ws.rhs[i];
+  }
+  for (int64_t i = 0; i < rd.m; ++i) for (int64_t j = ws.first[i]; j <= i; ++j) { lhs[i * rd.m + j] = Sat(&ws, i, j); lhs[j * rd.m + i] = Sat(&ws, i, j); }
+  return OBVI_OK;
+}
+
+// ceres::Solve restated.  [Ceres-doc] throughout; see header comment.
+int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summary* sum) {
+  if (!h || !prm || !sum) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  const double t_start = now_s();
+  std::memset(sum, 0, sizeof(*sum));
+  pb.iterations.clear();
+  double t_lin = 0, t_res = 0, t_solve = 0;
+
+  Reduced rd; build_reduced(pb, &rd);
+  sum->fixed_cost = rd.fixed_cost;
+  sum->num_parameters_reduced = (int32_t)rd.num_params;
+  sum->num_residuals_reduced = (int32_t)rd.num_residuals;
+  sum->reduced_system_size = (int32_t)rd.m;
+
+  auto finish = [&](int term, const char* msg) {
+    sum->termination_type = term;
+    std::snprintf(sum->message, sizeof(sum->message), "%s", msg);
+    sum->num_iterations = (int32_t)pb.iterations.size();
+    // Solver::Summary::final_cost = min over iterations (non-monotonic steps) [Ceres-doc solver.cc]
+    sum->final_cost = sum->initial_cost;
+    for (const auto& it : pb.iterations) sum->final_cost = std::min(sum->final_cost, it.cost);
+    sum->is_solution_usable = (term == OBVI_CONVERGENCE || term == OBVI_NO_CONVERGENCE) ? 1 : 0;
+    sum->total_time_in_seconds = now_s() - t_start;
+    sum->jacobian_evaluation_time_in_seconds = t_lin;
+    sum->residual_evaluation_time_in_seconds = t_res;
+    sum->linear_solver_time_in_seconds = t_solve;
+    return OBVI_OK;
+  };
+
+  if (rd.num_params == 0) {
+    // Nothing to optimise: Ceres reports CONVERGENCE with initial == final == fixed cost.
+    sum->initial_cost = rd.fixed_cost;
+    obvi_iteration_summary it; std::memset(&it, 0, sizeof(it)); it.cost = rd.fixed_cost; it.step_is_valid = 1; it.step_is_successful = 1;
+    pb.iterations.push_back(it);
+    return finish(OBVI_CONVERGENCE, "Function tolerance reached. No non-constant parameter blocks found.");
+  }
+
+  Workspace ws;
+  double tt = now_s();
+  double x_cost = linearize(pb, rd, &ws);
+  build_envelope(pb, rd, &ws);
+  t_lin += now_s() - tt;
+
+  // Jacobi scaling, computed once at iteration 0: s_j = 1 / (1 + sqrt(colsq_j))
+  std::vector<double> scale_c(rd.m), scale_l(3 * pb.L, 1.0);
+  for (int64_t i = 0; i < rd.m; ++i) scale_c[i] = 1.0 / (1.0 + std::sqrt(ws.colsq_c[i]));
+  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) scale_l[3 * l + k] = 1.0 / (1.0 + std::sqrt(ws.colsq_l[3 * l + k]));
+
+  auto grad_norms = [&](double* gmax, double* gnorm) {
+    double mx = 0.0, sq = 0.0;
+    for (int64_t i = 0; i < rd.m; ++i) { mx = std::max(mx, std::fabs(ws.g_c[i])); sq += ws.g_c[i] * ws.g_c[i]; }
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const double g = ws.gl[3 * l + k]; mx = std::max(mx, std::fabs(g)); sq += g * g; }
+    *gmax = mx; *gnorm = std::sqrt(sq);
+  };
+  auto x_norm_fn = [&]() {
+    double sq = 0.0;
+    for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) sq += pb.poses[6 * p + k] * pb.poses[6 * p + k];
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) sq += pb.objects[7 * o + k] * pb.objects[7 * o + k];
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) sq += pb.points[3 * l + k] * pb.points[3 * l + k];
+    return std::sqrt(sq);
+  };
+
+  // LevenbergMarquardtStrategy state
+  double radius = prm->initial_trust_region_radius;
+  const double max_radius = prm->max_trust_region_radius;
+  double decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  std::vector<double> diag_c(rd.m), diag_l(3 * pb.L, 0.0);
+  const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDecrease = 1e-3, kMinRadius = 1e-32;
+  const int kMaxInvalid = 5;
+  // TrustRegionStepEvaluator state
+  const int max_nonmono = prm->allow_non_monotonic_steps ? 5 : 0;
+  double minimum_cost = x_cost, current_cost = x_cost, reference_cost = x_cost, candidate_cost_ev = x_cost;
+  double acc_ref_model = 0.0, acc_cand_model = 0.0; int num_nonmono = 0;
+
+  // best (minimum-cost) iterate: what Ceres writes back to the user's parameter blocks
+  std::vector<double> best_poses, best_points, best_objects;
+  copy_params(pb, &best_poses, &best_points, &best_objects);
+  double best_cost = x_cost;
+
+  sum->initial_cost = x_cost + rd.fixed_cost;
+  obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
+  it.iteration = 0; it.cost = x_cost + rd.fixed_cost; it.step_is_valid = 1; it.step_is_successful = 1;
+  grad_norms(&it.gradient_max_norm, &it.gradient_norm);
+  it.trust_region_radius = radius;
+  double x_norm = x_norm_fn();
+  int num_invalid = 0;
+  double iter_t0 = now_s();
+  std::vector<double> y_c, Hll_inv, lam_c(rd.m), lam_l(3 * pb.L, 0.0), delta_l(3 * pb.L, 0.0);
+
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    it.trust_region_radius = radius;
+    it.iteration_time_in_seconds = now_s() - iter_t0;
+    pb.iterations.push_back(it);
+    if (it.step_is_successful) sum->num_successful_steps += (it.iteration > 0); else sum->num_unsuccessful_steps++;
+    if (it.iteration >= prm->max_num_iterations) { finish(OBVI_NO_CONVERGENCE, "Maximum number of iterations reached."); break; }
+    if (it.step_is_successful && it.gradient_max_norm <= prm->gradient_tolerance) { finish(OBVI_CONVERGENCE, "Gradient tolerance reached."); break; }
+    if (radius < kMinRadius) { finish(OBVI_CONVERGENCE, "Minimum trust region radius reached."); break; }
+
+    iter_t0 = now_s();
+    const double prev_gmax = it.gradient_max_norm, prev_gnorm = it.gradient_norm;
+    const int next_iter = it.iteration + 1;
+    std::memset(&it, 0, sizeof(it));
+    it.iteration = next_iter;
+
+    // ---- ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep) ----
+    tt = now_s();
+    if (!reuse_diagonal) {
+      for (int64_t i = 0; i < rd.m; ++i) diag_c[i] = std::min(std::max(ws.colsq_c[i] * scale_c[i] * scale_c[i], kMinDiag), kMaxDiag);
+      for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k)
+        diag_l[3 * l + k] = std::min(std::max(ws.colsq_l[3 * l + k] * scale_l[3 * l + k] * scale_l[3 * l + k], kMinDiag), kMaxDiag);
+    }
+    // scaled system (J_s^T J_s + D^2) y_s = J_s^T r, D^2 = diag/radius; in unscaled variables
+    // delta = s .* y_s this is (J^T J + D^2/s^2) delta = J^T r.
+    for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = diag_c[i] / radius / (scale_c[i] * scale_c[i]);
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k)
+      lam_l[3 * l + k] = diag_l[3 * l + k] / radius / (scale_l[3 * l + k] * scale_l[3 * l + k]);
+    bool ok = assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hll_inv);
+    if (ok) ok = skyline_cholesky_solve(&ws, rd.m, &y_c);
+    // back-substitution  y_l = Hll^-1 (g_l - W^T y_c)
+    if (ok) {
+      for (int64_t l = 0; l < pb.L; ++l) {
+        if (!rd.point_var[l]) continue;
+        double b[3] = {ws.gl[3 * l], ws.gl[3 * l + 1], ws.gl[3 * l + 2]};
+        for (int64_t idx : ws.point_obs[l]) {
+          const FactorLin& f = ws.lin[idx];
+          if (rd.pose_vid[f.i0] < 0) continue;
+          const int64_t ra = pose_row(rd, f.i0);
+          for (int k = 0; k < 3; ++k) {
+            double acc = 0.0;  // (W^T y)_k = sum_x W[x][k] y[x], W = Jp^T Jl
+            for (int x = 0; x < 6; ++x) acc += (f.J0[x] * f.J1[k] + f.J0[6 + x] * f.J1[3 + k]) * y_c[ra + x];
+            b[k] -= acc;
+          }
+        }
+        const double* Hi = &Hll_inv[9 * l];
+        for (int k = 0; k < 3; ++k) delta_l[3 * l + k] = -(Hi[3 * k] * b[0] + Hi[3 * k + 1] * b[1] + Hi[3 * k + 2] * b[2]);
+      }
+    }
+    reuse_diagonal = true;
+    t_solve += now_s() - tt;
+    bool finite = ok;
+    if (ok) {
+      for (int64_t i = 0; i < rd.m && finite; ++i) finite = std::isfinite(y_c[i]);
+      for (int64_t l = 0; l < pb.L && finite; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(delta_l[3 * l + k]);
+    }
+    // model_cost_change = -(J delta)^T (r + J delta / 2)
+    double model_cost_change = 0.0;
+    if (finite) {
+      for (const FactorLin& f : ws.lin) {
+        double Jd[7] = {0, 0, 0, 0, 0, 0, 0};
+        const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+        for (int b = 0; b < 2; ++b) {
+          if (!is_var(pb, rd, ks[b], is[b])) continue;
+          const int d = kBlockDim[ks[b]];
+          for (int k = 0; k < d; ++k) {
+            const double dk = (ks[b] == KIND_POINT) ? delta_l[3 * is[b] + k] : -y_c[reduced_row(rd, ks[b], is[b]) + k];
+            for (int a = 0; a < f.m; ++a) Jd[a] += Js[b][d * a + k] * dk;
+          }
+        }
+        for (int a = 0; a < f.m; ++a) model_cost_change -= Jd[a] * (f.r[a] + 0.5 * Jd[a]);
+      }
+    }
+    it.step_is_valid = (finite && model_cost_change > 0.0) ? 1 : 0;
+    if (!it.step_is_valid) {
+      // HandleInvalidStep
+      if (++num_invalid >= kMaxInvalid) {
+        pb.iterations.push_back(it);
+        finish(OBVI_FAILURE, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps");
+        break;
+      }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;  // StepIsInvalid
+      it.cost = x_cost + rd.fixed_cost; it.cost_change = 0.0; it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
+      it.step_norm = 0.0; it.relative_decrease = 0.0; it.step_is_successful = 0;
+      continue;
+    }
+    num_invalid = 0;
+
+    // ---- candidate point ----
+    std::vector<double> old_poses = pb.poses, old_points = pb.points, old_objects = pb.objects;
+    double step_sq = 0.0;
+    for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) { const double d = -y_c[pose_row(rd, p) + k]; pb.poses[6 * p + k] += d; step_sq += d * d; }
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const double d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] += d; step_sq += d * d; }
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const double d = delta_l[3 * l + k]; pb.points[3 * l + k] += d; step_sq += d * d; }
+    tt = now_s();
+    double cand_cost = reduced_cost(pb, rd);
+    t_res += now_s() - tt;
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+
+    auto revert = [&]() { pb.poses = old_poses; pb.points = old_points; pb.objects = old_objects; };
+    // ParameterToleranceReached
+    it.step_norm = std::sqrt(step_sq);
+    if (it.step_norm <= prm->parameter_tolerance * (x_norm + prm->parameter_tolerance)) {
+      revert();
+      finish(OBVI_CONVERGENCE, "Parameter tolerance reached.");
+      break;
+    }
+    // FunctionToleranceReached
+    it.cost_change = x_cost - cand_cost;
+    if (std::fabs(it.cost_change) <= prm->function_tolerance * x_cost) {
+      revert();
+      finish(OBVI_CONVERGENCE, "Function tolerance reached.");
+      break;
+    }
+    // IsStepSuccessful: TrustRegionStepEvaluator::StepQuality
+    {
+      const double rel = (current_cost - cand_cost) / model_cost_change;
+      const double hist = (reference_cost - cand_cost) / (acc_ref_model + model_cost_change);
+      it.relative_decrease = (cand_cost >= std::numeric_limits<double>::max()) ? -std::numeric_limits<double>::max() : std::max(rel, hist);
+    }
+    if (it.relative_decrease > kMinRelDecrease) {
+      // HandleSuccessfulStep
+      x_norm = x_norm_fn();
+      tt = now_s();
+      x_cost = linearize(pb, rd, &ws);
+      t_lin += now_s() - tt;
+      it.cost = x_cost + rd.fixed_cost;
+      grad_norms(&it.gradient_max_norm, &it.gradient_norm);
+      it.step_is_successful = 1;
+      // strategy->StepAccepted
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(max_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+      // step_evaluator->StepAccepted
+      current_cost = cand_cost; acc_cand_model += model_cost_change; acc_ref_model += model_cost_change;
+      if (cand_cost < minimum_cost) { minimum_cost = cand_cost; num_nonmono = 0; candidate_cost_ev = cand_cost; acc_cand_model = 0.0; }
+      else { ++num_nonmono; if (cand_cost > candidate_cost_ev) { candidate_cost_ev = cand_cost; acc_cand_model = 0.0; } }
+      if (num_nonmono == max_nonmono) { reference_cost = candidate_cost_ev; acc_ref_model = acc_cand_model; }
+      if (x_cost < best_cost) { best_cost = x_cost; copy_params(pb, &best_poses, &best_points, &best_objects); }
+    } else {
+      revert();
+      it.step_is_successful = 0;
+      it.cost = x_cost + rd.fixed_cost;
+      it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;  // StepRejected
+    }
+  }
+  // write back the minimum-cost iterate
+  pb.poses = best_poses; pb.points = best_points; pb.objects = best_objects;
+  return OBVI_OK;
+}
+
+int oracle_ba_get_iterations(const oracle_handle* h, obvi_iteration_summary* out, int32_t cap) {
+  const int n = std::min<int>(cap, (int)h->pb.iterations.size());
+  for (int i = 0; i < n; ++i) out[i] = h->pb.iterations[i];
+  return n;
+}
+
+// offline_problem_runner.h:769-800: per factor type, order blocks by un-robustified |r|^2
+// descending in a std::map keyed by the value (equal values collapse into one entry), take the
+// first floor(size * fraction) entries.
+int oracle_ba_select_outliers(oracle_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
+  if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
+  const OracleProblem& pb = h->pb;
+  for (const Family& fam : families(pb)) {
+    if (fam.type != type) continue;
+    std::vector<std::pair<double, int64_t>> v;
+    for (int64_t i = 0; i < fam.n; ++i) {
+      mask_out[i] = (*fam.active)[i];
+      if (!(*fam.active)[i]) continue;
+      FactorLin f; fam.lin(pb, i, false, &f);
+      double s = 0.0; for (int a = 0; a < fam.m; ++a) s += f.r[a] * f.r[a];
+      v.push_back({s, i});
+    }
+    // std::map<double, id, greater>: later insertions with an equal key overwrite; the map is
+    // filled by iterating an unordered_map, so which duplicate survives is unspecified.  We keep
+    // the highest index, and count distinct values like the map's size() does.
+    std::sort(v.begin(), v.end(), [](const std::pair<double, int64_t>& a, const std::pair<double, int64_t>& b) {
+      return a.first > b.first || (a.first == b.first && a.second > b.second); });
+    std::vector<std::pair<double, int64_t>> uniq;
+    for (const auto& e : v) if (uniq.empty() || uniq.back().first != e.first) uniq.push_back(e);
+    const size_t n_out = (size_t)(uniq.size() * fraction);
+    for (size_t k = 0; k < n_out; ++k) mask_out[uniq[k].second] = 0;
+    if (num_excluded) *num_excluded = (int64_t)n_out;
+    return OBVI_OK;
+  }
+  return OBVI_ERR_INVALID_ARGUMENT;
+}
+
+int oracle_ba_snapshot(oracle_handle* h) { h->pb.snap_poses = h->pb.poses; h->pb.snap_points = h->pb.points; h->pb.snap_objects = h->pb.objects; return OBVI_OK; }
+int oracle_ba_restore(oracle_handle* h) {
+  if ((int64_t)h->pb.snap_poses.size() != 6 * h->pb.P) return OBVI_ERR_NOT_READY;
+  h->pb.poses = h->pb.snap_poses; h->pb.points = h->pb.snap_points; h->pb.objects = h->pb.snap_objects; return OBVI_OK;
+}
+int oracle_ba_get_poses(oracle_handle* h, double* out) { std::memcpy(out, h->pb.poses.data(), sizeof(double) * h->pb.poses.size()); return OBVI_OK; }
+int oracle_ba_get_points(oracle_handle* h, double* out) { std::memcpy(out, h->pb.points.data(), sizeof(double) * h->pb.points.size()); return OBVI_OK; }
+int oracle_ba_get_objects(oracle_handle* h, double* out) { std::memcpy(out, h->pb.objects.data(), sizeof(double) * h->pb.objects.size()); return OBVI_OK; }
+int oracle_ba_update_points(oracle_handle* h, int64_t n, const double* xyz) {
+  if (n != h->pb.L) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.points.assign(xyz, xyz + 3 * n); return OBVI_OK;
+}
+
+// ---- factor-level entry points for golden-vector tests ---------------------------------
+void oracle_reproj(const double* pose6, const double* point3, const double* K4, const double* ext7, const double* pixel2,
+                   double sigma, double* r2, double* Jpose, double* Jpoint) {
+  CameraConst cam; make_camera_const(K4, ext7, &cam);
+  typedef Dual<9> D; D dp[6], dx[3], dr[2];
+  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose6[k], k);
+  for (int k = 0; k < 3; ++k) dx[k] = D::var(point3[k], 6 + k);
+  reprojection_residual<D>(dp, dx, cam, pixel2, sigma, dr);
+  for (int a = 0; a < 2; ++a) {
+    r2[a] = dr[a].v;
+    if (Jpose) for (int k = 0; k < 6; ++k) Jpose[6 * a + k] = dr[a].d[k];
+    if (Jpoint) for (int k = 0; k < 3; ++k) Jpoint[3 * a + k] = dr[a].d[6 + k];
+  }
+}
+int oracle_ellipsoid_corners(const double* ell7, const double* pose6, const double* K4, const double* ext7, double* corners4) {
+  CameraConst cam; make_camera_const(K4, ext7, &cam);
+  return ellipsoid_corners_rectified<double>(ell7, pose6, cam, corners4) ? 1 : 0;
+}
+int oracle_spd_inverse_sqrt(const double* cov, int n, double* out) { return spd_inverse_sqrt(cov, n, out) ? 1 : 0; }
+void oracle_huber(double s, double a, double* rho3) { huber(s, a, rho3); }
+
+}  // extern "C"

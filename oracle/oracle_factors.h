@@ -1,0 +1,369 @@
+// oracle_factors.h -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement, in scalar fp64 with forward-mode dual numbers, of the residual functors
+// on ObVi-SLAM's bundle-adjustment hot path.  Each function cites the reference file:line
+// (under /root/reference) whose arithmetic it follows.  The reference differentiates these
+// functors with ceres::AutoDiffCostFunction (ceres::Jet); Dual<N> below plays the role of
+// ceres::Jet<double,N> so that branch behaviour (small-angle guards, invalid-ellipse case)
+// and therefore the Jacobians are those the reference's Ceres path sees.
+//
+// Nothing under obvi-slam_amd/ may include this file.
+#ifndef OBVI_ORACLE_FACTORS_H_
+#define OBVI_ORACLE_FACTORS_H_
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------------------
+// forward-mode dual number (role of ceres::Jet<double,N>)
+// ---------------------------------------------------------------------------------------
+template <int N>
+struct Dual {
+  double v;
+  double d[N];
+  Dual() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+  Dual(double c) : v(c) { for (int i = 0; i < N; ++i) d[i] = 0.0; }  // NOLINT implicit
+  static Dual var(double c, int k) { Dual r(c); r.d[k] = 1.0; return r; }
+};
+template <int N> inline Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N>& a) {
+  Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N> inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.v * b.d[i] + a.d[i] * b.v; return r; }
+template <int N> inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; const double inv = 1.0 / b.v; r.v = a.v * inv;
+  for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+template <int N> inline Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> inline Dual<N> operator+(double a, const Dual<N>& b) { return b + a; }
+template <int N> inline Dual<N> operator-(const Dual<N>& a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> inline Dual<N> operator-(double a, const Dual<N>& b) { return Dual<N>(a) - b; }
+template <int N> inline Dual<N> operator*(const Dual<N>& a, double b) {
+  Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+template <int N> inline Dual<N> operator*(double a, const Dual<N>& b) { return b * a; }
+template <int N> inline Dual<N> operator/(const Dual<N>& a, double b) { return a * (1.0 / b); }
+template <int N> inline Dual<N> operator/(double a, const Dual<N>& b) { return Dual<N>(a) / b; }
+template <int N> inline Dual<N> sqrt(const Dual<N>& a) {
+  Dual<N> r; r.v = std::sqrt(a.v); const double s = 0.5 / r.v;
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int N> inline Dual<N> sin(const Dual<N>& a) {
+  Dual<N> r; r.v = std::sin(a.v); const double c = std::cos(a.v);
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+template <int N> inline Dual<N> cos(const Dual<N>& a) {
+  Dual<N> r; r.v = std::cos(a.v); const double s = -std::sin(a.v);
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int N> inline Dual<N> atan2(const Dual<N>& y, const Dual<N>& x) {
+  Dual<N> r; r.v = std::atan2(y.v, x.v); const double inv = 1.0 / (x.v * x.v + y.v * y.v);
+  for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * inv; return r; }
+template <int N> inline Dual<N> abs(const Dual<N>& a) { return a.v < 0.0 ? -a : a; }
+inline double sqrt(double a) { return std::sqrt(a); }
+inline double sin(double a) { return std::sin(a); }
+inline double cos(double a) { return std::cos(a); }
+inline double atan2(double y, double x) { return std::atan2(y, x); }
+inline double abs(double a) { return std::fabs(a); }
+inline double val(double a) { return a; }
+template <int N> inline double val(const Dual<N>& a) { return a.v; }
+
+// ---------------------------------------------------------------------------------------
+// small fixed-size helpers (row-major 3x3)
+// ---------------------------------------------------------------------------------------
+template <class T> inline void mat3_mul(const T* A, const T* B, T* C) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+    C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+template <class T, class U> inline void mat3_vec(const T* A, const U* x, T* y) {
+  for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+
+// Rotation matrix of an angle-axis pair: the Rodrigues form Eigen::AngleAxis::toRotationMatrix
+// evaluates (R = c I + (1-c) a a^T + s [a]x).
+template <class T> inline void angle_axis_to_matrix(const T& angle, const T* axis, T* R) {
+  const T s = sin(angle), c = cos(angle), one_c = T(1.0) - c;
+  const T cx = one_c * axis[0], cy = one_c * axis[1], cz = one_c * axis[2];
+  const T sx = s * axis[0], sy = s * axis[1], sz = s * axis[2];
+  T tmp = cx * axis[1]; R[1] = tmp - sz; R[3] = tmp + sz;
+  tmp = cx * axis[2];   R[2] = tmp + sy; R[6] = tmp - sy;
+  tmp = cy * axis[2];   R[5] = tmp - sx; R[7] = tmp + sx;
+  R[0] = cx * axis[0] + c; R[4] = cy * axis[1] + c; R[8] = cz * axis[2] + c;
+}
+
+static const double kSmallAngleThreshold = 1e-8;  // vslam_math_util.h:17
+
+// Inverse of the robot pose T_world<-robot given as [t(3), aa(3)]: (R^T, -R^T t).
+// Follows vslam_math_util.h:357-375 / ellipsoid_utils.h:172-192: angle = |aa|; if above the
+// threshold use AngleAxis(-angle, aa/angle), else AngleAxis(0, e_x) (constant => zero
+// derivative w.r.t. aa in that branch, exactly as autodiff sees it).
+template <class T> inline void inverse_robot_pose(const T* pose, T* Rinv, T* tinv) {
+  const T angle = sqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5]);
+  if (val(angle) > kSmallAngleThreshold) {
+    const T axis[3] = {pose[3] / angle, pose[4] / angle, pose[5] / angle};
+    angle_axis_to_matrix(-angle, axis, Rinv);
+  } else {
+    const T axis[3] = {T(1.0), T(0.0), T(0.0)};
+    angle_axis_to_matrix(T(0.0), axis, Rinv);
+  }
+  T rt[3];
+  mat3_vec(Rinv, pose, rt);
+  tinv[0] = -rt[0]; tinv[1] = -rt[1]; tinv[2] = -rt[2];
+}
+
+// Forward robot pose as used by RelativePoseFactor: PoseArrayToAffine, vslam_math_util.h:121-141
+// (angle < threshold -> AngleAxis(0, e_z); else VectorToAxisAngle :33-43).
+template <class T> inline void robot_pose_to_matrix(const T* pose, T* R) {
+  const T angle = sqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5]);
+  if (!(val(angle) > kSmallAngleThreshold)) {  // both reference branches give identity here
+    const T axis[3] = {T(0.0), T(0.0), T(1.0)};
+    angle_axis_to_matrix(T(0.0), axis, R);
+  } else {
+    const T axis[3] = {pose[3] / angle, pose[4] / angle, pose[5] / angle};
+    angle_axis_to_matrix(angle, axis, R);
+  }
+}
+
+// Camera constants shared by the reprojection and bbox functors: the inverse of the
+// extrinsics T_robot<-camera, i.e. cam_to_robot_tf_inv_ (reprojection_cost_functor.cpp:10-13)
+// == robot_to_cam_tf_ (bounding_box_factor.cpp:19-22).
+struct CameraConst {
+  double Rinv[9];  // R_e^T
+  double tinv[3];  // -R_e^T t_e
+  double fx, fy, cx, cy;
+};
+inline void make_camera_const(const double* K4, const double* ext7, CameraConst* c) {
+  double qx = ext7[0], qy = ext7[1], qz = ext7[2], qw = ext7[3];
+  const double n = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+  qx /= n; qy /= n; qz /= n; qw /= n;
+  const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                       2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                       2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c->Rinv[3 * i + j] = R[3 * j + i];
+  for (int i = 0; i < 3; ++i)
+    c->tinv[i] = -(c->Rinv[3 * i] * ext7[4] + c->Rinv[3 * i + 1] * ext7[5] + c->Rinv[3 * i + 2] * ext7[6]);
+  c->fx = K4[0]; c->fy = K4[1]; c->cx = K4[2]; c->cy = K4[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// a3: ReprojectionCostFunctor::runOperator (reprojection_cost_functor.h:56-93) +
+//     getProjectedPixelLocationRectified (vslam_math_util.h:347-394) + ctor (.cpp:5-17).
+// residual = (f/sigma) * (p_cam.xy / p_cam.z - (pixel - c)/f); no depth clamp.
+// ---------------------------------------------------------------------------------------
+template <class T>
+inline void reprojection_residual(const T* pose, const T* point, const CameraConst& cam,
+                                  const double* pixel, double sigma, T* residual) {
+  T Rinv[9], tinv[3];
+  inverse_robot_pose(pose, Rinv, tinv);
+  T pr[3];
+  mat3_vec(Rinv, point, pr);
+  pr[0] = pr[0] + tinv[0]; pr[1] = pr[1] + tinv[1]; pr[2] = pr[2] + tinv[2];
+  T pc[3];
+  for (int i = 0; i < 3; ++i)
+    pc[i] = pr[0] * cam.Rinv[3 * i] + pr[1] * cam.Rinv[3 * i + 1] + pr[2] * cam.Rinv[3 * i + 2] + cam.tinv[i];
+  const double rect_x = (pixel[0] - cam.cx) / cam.fx, rect_y = (pixel[1] - cam.cy) / cam.fy;
+  const double mult_x = cam.fx / sigma, mult_y = cam.fy / sigma;
+  residual[0] = (pc[0] / pc[2] - rect_x) * mult_x;
+  residual[1] = (pc[1] / pc[2] - rect_y) * mult_y;
+}
+
+// ---------------------------------------------------------------------------------------
+// a5: getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273), yaw-only ellipsoid.
+// Returns false in the invalid case (either radicand <= 0, :257-259).
+// ---------------------------------------------------------------------------------------
+static const double kDimensionRegularizationConstant = (double)1e-3f;  // a `float` in ellipsoid_utils.h:22
+
+template <class T>
+inline bool ellipsoid_corners_rectified(const T* ell, const T* pose, const CameraConst& cam, T* corners) {
+  T Rinv[9], tinv[3];
+  inverse_robot_pose(pose, Rinv, tinv);
+  // world_to_camera = robot_to_cam * robot_pose^-1   (:196-197)
+  T Rcw[9], tcw[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      Rcw[3 * i + j] = Rinv[j] * cam.Rinv[3 * i] + Rinv[3 + j] * cam.Rinv[3 * i + 1] + Rinv[6 + j] * cam.Rinv[3 * i + 2];
+    tcw[i] = tinv[0] * cam.Rinv[3 * i] + tinv[1] * cam.Rinv[3 * i + 1] + tinv[2] * cam.Rinv[3 * i + 2] + cam.tinv[i];
+  }
+  // ellipsoid pose: translation * Rz(yaw)   (:205-229)
+  const T cy = cos(ell[3]), sy = sin(ell[3]);
+  const T Ro[9] = {cy, -sy, T(0.0), sy, cy, T(0.0), T(0.0), T(0.0), T(1.0)};
+  T M[12];  // 3x4 [R | t] of world_to_camera * ellipsoid_pose   (:232-233)
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      M[4 * i + j] = Rcw[3 * i] * Ro[j] + Rcw[3 * i + 1] * Ro[3 + j] + Rcw[3 * i + 2] * Ro[6 + j];
+    M[4 * i + 3] = Rcw[3 * i] * ell[0] + Rcw[3 * i + 1] * ell[1] + Rcw[3 * i + 2] * ell[2] + tcw[i];
+  }
+  // dual quadric  Q = M diag((d/2)^2 + c, -1) M^T    (:208-216, :236-237)
+  T dm[4];
+  for (int k = 0; k < 3; ++k) { const T h = ell[4 + k] / 2.0; dm[k] = h * h + kDimensionRegularizationConstant; }
+  dm[3] = T(-1.0);
+  auto q = [&](int a, int b) {
+    return M[4 * a] * dm[0] * M[4 * b] + M[4 * a + 1] * dm[1] * M[4 * b + 1] +
+           M[4 * a + 2] * dm[2] * M[4 * b + 2] + M[4 * a + 3] * dm[3] * M[4 * b + 3];
+  };
+  const T q11 = q(0, 0), q13 = q(0, 2), q22 = q(1, 1), q23 = q(1, 2), q33 = q(2, 2);
+  const T x_inner = q13 * q13 - q11 * q33, y_inner = q23 * q23 - q22 * q33;
+  if (val(x_inner) <= 0.0 || val(y_inner) <= 0.0) return false;
+  const T xs = sqrt(x_inner), ys = sqrt(y_inner);
+  corners[0] = (q13 + xs) / q33; corners[1] = (q13 - xs) / q33;   // (:268-270)
+  corners[2] = (q23 + ys) / q33; corners[3] = (q23 - ys) / q33;
+  return true;
+}
+
+// a4: BoundingBoxFactor::operator() (bounding_box_factor.h:68-136); constants from the ctor
+// (bounding_box_factor.cpp:26-39): sqrt_inf = (cov^-1)^(1/2) diag(fx,fx,fy,fy), rectified
+// observed corners.  Invalid case: all four residuals = invalid_ellipse_error (constant).
+template <class T>
+inline bool bbox_residual(const T* ell, const T* pose, const CameraConst& cam, const double* rect_corners,
+                          const double* sqrt_inf /*4x4 row-major*/, double invalid_err, T* residual) {
+  T corners[4];
+  if (!ellipsoid_corners_rectified(ell, pose, cam, corners)) {
+    for (int i = 0; i < 4; ++i) residual[i] = T(invalid_err);
+    return false;
+  }
+  T dev[4];
+  for (int i = 0; i < 4; ++i) dev[i] = corners[i] - rect_corners[i];
+  for (int i = 0; i < 4; ++i)
+    residual[i] = dev[0] * sqrt_inf[4 * i] + dev[1] * sqrt_inf[4 * i + 1] + dev[2] * sqrt_inf[4 * i + 2] + dev[3] * sqrt_inf[4 * i + 3];
+  return true;
+}
+
+// a6: ShapePriorFactor::operator() (shape_prior_factor.h:46-61)
+template <class T>
+inline void shape_prior_residual(const T* ell, const double* mean3, const double* sqrt_inf /*3x3*/, T* residual) {
+  T dev[3];
+  for (int i = 0; i < 3; ++i) dev[i] = ell[4 + i] - mean3[i];
+  for (int i = 0; i < 3; ++i)
+    residual[i] = dev[0] * sqrt_inf[3 * i] + dev[1] * sqrt_inf[3 * i + 1] + dev[2] * sqrt_inf[3 * i + 2];
+}
+
+// a7: IndependentObjectMapFactor::operator() (independent_object_map_factor.h:21-33)
+template <class T>
+inline void ltm_prior_residual(const T* ell, const double* mean7, const double* sqrt_inf /*7x7*/, T* residual) {
+  T dev[7];
+  for (int i = 0; i < 7; ++i) dev[i] = ell[i] - mean7[i];
+  for (int i = 0; i < 7; ++i) {
+    T acc = dev[0] * sqrt_inf[7 * i];
+    for (int j = 1; j < 7; ++j) acc = acc + dev[j] * sqrt_inf[7 * i + j];
+    residual[i] = acc;
+  }
+}
+
+// Eigen::AngleAxis(Matrix3) == AngleAxis(Quaternion(Matrix3)): the rotation-matrix ->
+// quaternion branches of Eigen's quaternion constructor followed by AngleAxis::operator=(q)
+// (angle = 2 atan2(|vec|, |w|), axis = vec / (+-|vec|); |vec| == 0 -> angle 0, axis e_x).
+// Returns angle*axis, which is what relative_pose_factor.h:53-55 consumes.
+template <class T> inline void rotation_log(const T* R, T* out) {
+  T q[4];  // x y z w
+  T t = R[0] + R[4] + R[8];
+  if (val(t) > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = t * 0.5;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (val(R[4]) > val(R[0])) i = 1;
+    if (val(R[8]) > val(R[4 * i])) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = t * 0.5;
+    t = 0.5 / t;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+  }
+  T n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  if (val(n) != 0.0) {
+    const T angle = 2.0 * atan2(n, abs(q[3]));
+    if (val(q[3]) < 0.0) n = -n;
+    for (int a = 0; a < 3; ++a) out[a] = angle * (q[a] / n);
+  } else {
+    for (int a = 0; a < 3; ++a) out[a] = T(0.0);
+  }
+}
+
+// a8: RelativePoseFactor::operator() (relative_pose_factor.h:32-61): after_rel_before =
+// T_before^-1 T_after; residual = sqrt_inf [t_rel - t_meas ; Log(R_rel R_meas^T)].
+template <class T>
+inline void relpose_residual(const T* pose_before, const T* pose_after, const double* t_meas,
+                             const double* R_meas /*3x3 row-major*/, const double* sqrt_inf /*6x6*/, T* residual) {
+  T Rb[9], Ra[9];
+  robot_pose_to_matrix(pose_before, Rb);
+  robot_pose_to_matrix(pose_after, Ra);
+  T dt[3] = {pose_after[0] - pose_before[0], pose_after[1] - pose_before[1], pose_after[2] - pose_before[2]};
+  T u[6];
+  for (int i = 0; i < 3; ++i) u[i] = Rb[i] * dt[0] + Rb[3 + i] * dt[1] + Rb[6 + i] * dt[2] - t_meas[i];
+  T Rrel[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+    Rrel[3 * i + j] = Rb[i] * Ra[j] + Rb[3 + i] * Ra[3 + j] + Rb[6 + i] * Ra[6 + j];
+  T Rerr[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+    Rerr[3 * i + j] = Rrel[3 * i] * R_meas[3 * j] + Rrel[3 * i + 1] * R_meas[3 * j + 1] + Rrel[3 * i + 2] * R_meas[3 * j + 2];
+  rotation_log(Rerr, u + 3);
+  for (int i = 0; i < 6; ++i) {
+    T acc = u[0] * sqrt_inf[6 * i];
+    for (int j = 1; j < 6; ++j) acc = acc + u[j] * sqrt_inf[6 * i + j];
+    residual[i] = acc;
+  }
+}
+
+// ceres::HuberLoss::Evaluate [Ceres-doc]: rho(s) = s for s <= a^2, else 2 a sqrt(s) - a^2.
+inline void huber(double s, double a, double rho[3]) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = std::sqrt(s);
+    rho[0] = 2.0 * a * r - b;
+    rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
+    rho[2] = -rho[1] / (2.0 * s);
+  } else {
+    rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+// Symmetric positive-definite inverse square root  (cov.inverse().sqrt() of the factor ctors,
+// e.g. shape_prior_factor.cpp:11) by cyclic Jacobi eigen-decomposition: V diag(l^-1/2) V^T.
+// Returns false if cov is not SPD / not finite.
+inline bool spd_inverse_sqrt(const double* cov, int n, double* out) {
+  double A[49], V[49];
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    A[i * n + j] = 0.5 * (cov[i * n + j] + cov[j * n + i]);
+    V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    if (!std::isfinite(A[i * n + j])) return false;
+  }
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
+    if (off <= 1e-30 * diag || off == 0.0) break;
+    for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+      if (A[p * n + q] == 0.0) continue;
+      const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * A[p * n + q]);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+      const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < n; ++k) {
+        const double akp = A[k * n + p], akq = A[k * n + q];
+        A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < n; ++k) {
+        const double apk = A[p * n + k], aqk = A[q * n + k];
+        A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < n; ++k) {
+        const double vkp = V[k * n + p], vkq = V[k * n + q];
+        V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) if (!(A[i * n + i] > 0.0)) return false;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) acc += V[i * n + k] * V[j * n + k] / std::sqrt(A[k * n + k]);
+    out[i * n + j] = acc;
+  }
+  return true;
+}
+
+}  // namespace oracle
+#endif  // OBVI_ORACLE_FACTORS_H_
