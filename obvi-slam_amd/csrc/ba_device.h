@@ -1,0 +1,133 @@
+// ba_device.h -- HBM layout of one bundle-adjustment problem and the kernel launch entry points.
+// See DESIGN.md ("Data layout in HBM") for the rationale.
+#ifndef OBVI_BA_DEVICE_H_
+#define OBVI_BA_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ba_math.h"
+
+namespace obvi {
+
+// Tile edge of the reduced (Schur) system.  The reduced matrix is stored as a grid of
+// kTile x kTile fp64 tiles (row-major inside a tile, tiles row-major in the grid); only tiles
+// in the lower triangle that are structurally non-zero after symbolic fill are ever touched.
+constexpr int kTile = 64;
+
+// Slots of the device scalar block (fp64 unless noted).  One 256-byte D2H copy per LM step.
+enum Scalar {
+  SC_COST = 0,        // 0.5 sum rho(s) over the reduced program at the linearisation point
+  SC_COST_CAND,       // same at the candidate point
+  SC_COST_FIXED,      // residual blocks whose every parameter block is constant
+  SC_GSQ,             // |g|^2
+  SC_GMAX_BITS,       // max |g_i| (IEEE bits, via integer atomicMax; non-negative doubles order like u64)
+  SC_XSQ,             // |x|^2 over the reduced program
+  SC_STEPSQ,          // |delta|^2
+  SC_MODEL_CHANGE,    // -(J d)^T (r + J d / 2)
+  SC_CHOL_FAIL,       // (as double) count of non-positive pivots
+  SC_NONFINITE,       // (as double) count of non-finite step entries
+  SC_COUNT = 32
+};
+
+struct ReprojDev {          // observations sorted by (point, pose): CSC by point
+  int64_t n;
+  const uint32_t* pose;     // [n]
+  const uint32_t* point;    // [n]
+  const uint16_t* cam;      // [n]
+  const double2* pixel;     // [n]
+  const double* sigma;      // [n]
+  const uint8_t* active;    // [n]
+  const uint32_t* point_ptr;  // [L+1] offsets into the arrays above
+  double huber;
+};
+
+struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
+  int64_t P, L, O;
+  int64_t nPv, nOv;         // variable+used poses / objects
+  int64_t m;                // 6 nPv + 7 nOv
+  const int32_t* pose_vid;  // [P]  reduced index or -1
+  const int32_t* obj_vid;   // [O]
+  const uint8_t* point_var; // [L]
+};
+
+struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
+  // bounding boxes
+  int64_t n_bb; const uint32_t* bb_obj; const uint32_t* bb_pose; const uint16_t* bb_cam;
+  const double* bb_rect; const double* bb_sqrt_inf; const uint8_t* bb_active; double bb_huber, bb_invalid;
+  // shape priors
+  int64_t n_sp; const uint32_t* sp_obj; const double* sp_mean; const double* sp_sqrt_inf; const uint8_t* sp_active; double sp_huber;
+  // LTM priors
+  int64_t n_lt; const uint32_t* lt_obj; const double* lt_mean; const double* lt_sqrt_inf; const uint8_t* lt_active; double lt_huber;
+  // relative poses
+  int64_t n_rl; const uint32_t* rl_a; const uint32_t* rl_b; const double* rl_t; const double* rl_R; const double* rl_sqrt_inf;
+  const uint8_t* rl_active; double rl_huber;
+};
+
+struct ReducedDev {         // accumulators of the reduced system
+  double* Hdiag;            // pose v: 36 doubles at 36 v; object w: 49 doubles at 36 nPv + 49 w (row-major, full)
+  double* g;                // [m]   gradient J^T r
+  double* scale;            // [m]   Jacobi scaling (fixed at iteration 0)
+  double* lam;              // [m]   LM damping of the unscaled normal equations
+  double* S;                // tile grid
+  double* rhs;              // [m_pad] right-hand side -> forward-substituted z
+  double* y;                // [m_pad] solution
+  int32_t nt;               // tiles per dimension
+};
+
+struct PointDev {           // per eliminated point
+  double* Ci;               // [L][6]  inverse Cholesky factor of (Hll + lambda), lower-tri packed (00,10,11,20,21,22)
+  double* u;                // [L][3]  Ci * g_l
+  double* scale;            // [L][3]  Jacobi scaling
+  double* Z;                // [N_r][18] 6x3 row-major:  rho' Jp^T Jl Ci^T
+};
+
+// ---- launchers (ba_kernels.hip) --------------------------------------------------------
+void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out);
+void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc,
+                       const double* points, const ReducedDev& rd, const PointDev& pt, double radius, int first_iter,
+                       double* scal);
+void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams,
+                          const double* poses, const double* objects, const ReducedDev& rd, double* scal);
+void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects,
+                         const ReducedDev& rd, double radius, int first_iter, double* scal);
+void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
+                         const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt,
+                         const ReducedDev& rd);
+void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
+                          const double* points, double* points_cand, double* scal);
+void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,
+                               double* poses_cand, double* objects_cand, double* scal);
+// trial-point cost + model cost change.  mode 0: cost at (poses,points,objects) into SC_COST_CAND and
+// model change of the step (cand - current); mode 1: cost only, split into SC_COST / SC_COST_FIXED.
+void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const SmallFactorsDev& sf, const DevCam* cams,
+                 const PoseCache* pc_cur, const double* poses_cur, const double* points_cur, const double* objects_cur,
+                 const PoseCache* pc_cand, const double* poses_cand, const double* points_cand, const double* objects_cand,
+                 int mode, double* scal);
+// problem->Evaluate: raw / robustified residuals of every factor in caller order
+void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf,
+                     const DevCam* cams, const PoseCache* pc, const double* poses, const double* points, const double* objects,
+                     int apply_loss, double* residuals, double* sqnorm, double* scal);
+void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uint32_t* rp_perm, const DevCam* cams,
+                                   const PoseCache* pc, const double* points, double* r, double* J0, double* J1);
+void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFactorsDev& sf, const DevCam* cams,
+                                  const double* poses, const double* objects, double* r, double* J0, double* J1);
+void launch_fill(hipStream_t s, double* p, int64_t n, double v);
+
+// ---- tile Cholesky (chol_kernels.hip) --------------------------------------------------
+struct CholPlan {           // symbolic factorisation at tile granularity (host-built, device-resident lists)
+  int32_t nt;
+  // per step k: tiles i > k with L(i,k) != 0  -> trsm jobs; pairs (i >= j > k) -> update jobs
+  const int32_t* trsm_ptr;  // [nt+1] (host)
+  const int32_t* trsm_i;    // device
+  const int32_t* upd_ptr;   // [nt+1] (host)
+  const int32_t* upd_ij;    // device, 2 per job
+  // backward substitution: per step k, tiles j < k with L(k,j) != 0
+  const int32_t* back_ptr;  // [nt+1] (host)
+  const int32_t* back_j;    // device
+};
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t m);
+void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* scal);
+
+}  // namespace obvi
+#endif  // OBVI_BA_DEVICE_H_

@@ -1,0 +1,832 @@
+// ba_kernels.hip -- gfx950 kernels of the LM step outside the reduced-system factorisation:
+//   K0 pose_cache        per-pose R^T, -R^T t, SO(3) right Jacobian
+//   K1 point_pass        reprojection linearisation, one thread per eliminated point: Hll, g_l, cost,
+//                        pose-side J^T J / J^T r, per-point 3x3 Cholesky of (Hll + lambda), Z = rho' Jp^T Jl C^-T
+//   K2/K3 small factors  bbox / shape prior / LTM prior / relative pose (forward-mode duals)
+//   K4 schur_blocks      S(p,q) -= sum_l Z_pl Z_ql^T, rhs_p -= sum_l Z_pl u_l  -- one wavefront per 6x6 block
+//   K6 point_backsub     y_l = C^-T (u - sum Z^T y_p), candidate points
+//   K7 cost              trial-point cost + model cost change
+//   K9 apply step        candidate poses / objects
+// Reference arithmetic: see ba_math.h.  Solver algebra: [Ceres-doc] SchurEliminator / LM strategy.
+#include <algorithm>
+
+#include "ba_device.h"
+
+namespace obvi {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// block-wide sum -> one atomic per block
+__device__ __forceinline__ void block_accumulate(double v, double* dst) {
+  __shared__ double sm[kBlock / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) t += sm[i];
+    if (t != 0.0) atomic_add_f64(dst, t);
+  }
+}
+__device__ __forceinline__ void block_accumulate_max(double v, double* dst_bits) {
+  __shared__ double smx[kBlock / 64];
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smx[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) t = fmax(t, smx[i]);
+    if (t > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(dst_bits), (unsigned long long)__double_as_longlong(t));
+  }
+}
+
+__device__ __forceinline__ double* S_at(double* S, int32_t nt, int64_t i, int64_t j) {
+  return S + ((i / kTile) * (int64_t)nt + (j / kTile)) * (kTile * kTile) + (i % kTile) * kTile + (j % kTile);
+}
+
+__device__ __forceinline__ double lm_lambda(double colsq, double scale, double radius) {
+  // LevenbergMarquardtStrategy::ComputeStep [Ceres-doc]: D^2 = clamp(diag(Js^T Js), 1e-6, 1e32) / radius on
+  // the Jacobi-scaled Jacobian Js = J diag(scale); in unscaled variables the damping is D^2 / scale^2.
+  const double d = fmin(fmax(colsq * scale * scale, 1e-6), 1e32);
+  return d / radius / (scale * scale);
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* __restrict__ poses, PoseCache* __restrict__ out) {
+  const int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  if (p >= P) return;
+  double pose[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pose[k] = poses[6 * p + k];
+  PoseCache pc;
+  make_pose_cache(pose, &pc);
+  out[p] = pc;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1.  One thread per point; the point's observations are contiguous (CSC by point).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+                                                      const PoseCache* __restrict__ pc, const double* __restrict__ points,
+                                                      ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal) {
+  const int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
+  if (l < b.L) {
+    const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
+    const bool lvar = b.point_var[l] != 0;
+    const double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
+    double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (uint32_t a = beg; a < end; ++a) {
+      if (!rp.active[a]) continue;
+      const uint32_t p = rp.pose[a];
+      const int32_t vid = b.pose_vid[p];
+      if (vid < 0 && !lvar) continue;  // all-constant residual block: fixed cost, not part of the reduced program
+      const double2 px = rp.pixel[a];
+      double r[2], Jp[12], Jl[6];
+      reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
+      double rho0, w;
+      huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+      cost += 0.5 * rho0;
+      if (lvar) {
+        h00 += w * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); h10 += w * (Jl[1] * Jl[0] + Jl[4] * Jl[3]); h11 += w * (Jl[1] * Jl[1] + Jl[4] * Jl[4]);
+        h20 += w * (Jl[2] * Jl[0] + Jl[5] * Jl[3]); h21 += w * (Jl[2] * Jl[1] + Jl[5] * Jl[4]); h22 += w * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+        g0 += w * (Jl[0] * r[0] + Jl[3] * r[1]); g1 += w * (Jl[1] * r[0] + Jl[4] * r[1]); g2 += w * (Jl[2] * r[0] + Jl[5] * r[1]);
+      }
+      if (vid >= 0) {
+        double* Hd = rd.Hdiag + 36 * (int64_t)vid;
+        double* gd = rd.g + 6 * (int64_t)vid;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+#pragma unroll
+          for (int y = 0; y <= x; ++y) atomic_add_f64(Hd + 6 * x + y, w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]));
+          atomic_add_f64(gd + x, w * (Jp[x] * r[0] + Jp[6 + x] * r[1]));
+        }
+      }
+    }
+    if (lvar) {
+      xsq = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+      gsq = g0 * g0 + g1 * g1 + g2 * g2;
+      gmax = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+      double s0, s1, s2;
+      if (first_iter) {
+        s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); s2 = 1.0 / (1.0 + sqrt(h22));
+        pt.scale[3 * l] = s0; pt.scale[3 * l + 1] = s1; pt.scale[3 * l + 2] = s2;
+      } else {
+        s0 = pt.scale[3 * l]; s1 = pt.scale[3 * l + 1]; s2 = pt.scale[3 * l + 2];
+      }
+      const double a00 = h00 + lm_lambda(h00, s0, radius), a11 = h11 + lm_lambda(h11, s1, radius), a22 = h22 + lm_lambda(h22, s2, radius);
+      // 3x3 Cholesky A = C C^T and Ci = C^-1
+      const double c00 = sqrt(a00), c10 = h10 / c00, c20 = h20 / c00;
+      const double d11 = a11 - c10 * c10;
+      const double c11 = sqrt(d11), c21 = (h21 - c20 * c10) / c11;
+      const double d22 = a22 - c20 * c20 - c21 * c21;
+      const double c22 = sqrt(d22);
+      if (!(a00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) fail = 1.0;
+      const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+      const double i10 = -c10 * i00 * i11, i21 = -c21 * i11 * i22, i20 = -(c20 * i00 + c21 * i10) * i22;
+      double* Ci = pt.Ci + 6 * l;
+      Ci[0] = i00; Ci[1] = i10; Ci[2] = i11; Ci[3] = i20; Ci[4] = i21; Ci[5] = i22;
+      pt.u[3 * l] = i00 * g0; pt.u[3 * l + 1] = i10 * g0 + i11 * g1; pt.u[3 * l + 2] = i20 * g0 + i21 * g1 + i22 * g2;
+      // second sweep: Z = rho' Jp^T (Jl Ci^T)
+      for (uint32_t a = beg; a < end; ++a) {
+        if (!rp.active[a]) continue;
+        const uint32_t p = rp.pose[a];
+        if (b.pose_vid[p] < 0) continue;
+        const double2 px = rp.pixel[a];
+        double r[2], Jp[12], Jl[6];
+        reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
+        double rho0, w;
+        huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+        const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
+        const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
+        double* Z = pt.Z + 18 * (int64_t)a;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          Z[3 * x] = w * (Jp[x] * m00 + Jp[6 + x] * m10);
+          Z[3 * x + 1] = w * (Jp[x] * m01 + Jp[6 + x] * m11);
+          Z[3 * x + 2] = w * (Jp[x] * m02 + Jp[6 + x] * m12);
+        }
+      }
+    }
+  }
+  block_accumulate(cost, scal + SC_COST);
+  block_accumulate(gsq, scal + SC_GSQ);
+  block_accumulate(xsq, scal + SC_XSQ);
+  block_accumulate(fail, scal + SC_CHOL_FAIL);
+  block_accumulate_max(gmax, scal + SC_GMAX_BITS);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2/K3.  Small factor families: thread per factor, atomics into the reduced accumulators.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void add_diag_block(double* Hd, double* gd, int d, const double* J, const double* r, int m, double w) {
+  for (int x = 0; x < d; ++x) {
+    for (int y = 0; y <= x; ++y) {
+      double acc = 0.0;
+      for (int a = 0; a < m; ++a) acc += J[d * a + x] * J[d * a + y];
+      atomic_add_f64(Hd + d * x + y, w * acc);
+    }
+    double acc = 0.0;
+    for (int a = 0; a < m; ++a) acc += J[d * a + x] * r[a];
+    atomic_add_f64(gd + x, w * acc);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                                const double* __restrict__ objects, ReducedDev rd, double* scal) {
+  const int64_t i = blockIdx.x * 64LL + threadIdx.x;
+  double cost = 0.0;
+  if (i < sf.n_bb && sf.bb_active[i]) {
+    const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
+    const int32_t ov = b.obj_vid[o], pv = b.pose_vid[p];
+    if (ov >= 0 || pv >= 0) {
+      D13 res[4];
+      bbox_eval(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+      double r[4], Je[28], Jp[24];
+      for (int a = 0; a < 4; ++a) {
+        r[a] = res[a].v;
+        for (int k = 0; k < 7; ++k) Je[7 * a + k] = res[a].d[k];
+        for (int k = 0; k < 6; ++k) Jp[6 * a + k] = res[a].d[7 + k];
+      }
+      double rho0, w;
+      huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
+      cost = 0.5 * rho0;
+      const int64_t orow = 6 * b.nPv + 7 * (int64_t)ov, prow = 6 * (int64_t)pv;
+      if (ov >= 0) add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + orow, 7, Je, r, 4, w);
+      if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + prow, 6, Jp, r, 4, w);
+      if (ov >= 0 && pv >= 0) {
+        for (int x = 0; x < 7; ++x) for (int y = 0; y < 6; ++y) {
+          double acc = 0.0;
+          for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Jp[6 * a + y];
+          atomic_add_f64(S_at(rd.S, rd.nt, orow + x, prow + y), w * acc);
+        }
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+__global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ objects, ReducedDev rd, double* scal) {
+  const int64_t t = blockIdx.x * 64LL + threadIdx.x;
+  double cost = 0.0;
+  if (t < sf.n_sp) {
+    const int64_t i = t;
+    if (sf.sp_active[i]) {
+      const uint32_t o = sf.sp_obj[i];
+      const int32_t ov = b.obj_vid[o];
+      if (ov >= 0) {
+        double r[3], J[21];
+        shape_prior_eval(objects + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
+        double rho0, w;
+        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
+      }
+    }
+  } else if (t < sf.n_sp + sf.n_lt) {
+    const int64_t i = t - sf.n_sp;
+    if (sf.lt_active[i]) {
+      const uint32_t o = sf.lt_obj[i];
+      const int32_t ov = b.obj_vid[o];
+      if (ov >= 0) {
+        double r[7], J[49];
+        ltm_prior_eval(objects + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
+        double s = 0.0;
+        for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+        double rho0, w;
+        huber_eval(s, sf.lt_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+__global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ poses, ReducedDev rd, double* scal) {
+  const int64_t i = blockIdx.x * 64LL + threadIdx.x;
+  double cost = 0.0;
+  if (i < sf.n_rl && sf.rl_active[i]) {
+    const uint32_t pa = sf.rl_a[i], pb = sf.rl_b[i];
+    const int32_t va = b.pose_vid[pa], vb = b.pose_vid[pb];
+    if (va >= 0 || vb >= 0) {
+      D12 res[6];
+      relpose_eval(poses + 6 * (int64_t)pa, poses + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+      double r[6], Ja[36], Jb[36];
+      double s = 0.0;
+      for (int a = 0; a < 6; ++a) {
+        r[a] = res[a].v; s += r[a] * r[a];
+        for (int k = 0; k < 6; ++k) { Ja[6 * a + k] = res[a].d[k]; Jb[6 * a + k] = res[a].d[6 + k]; }
+      }
+      double rho0, w;
+      huber_eval(s, sf.rl_huber, &rho0, &w);
+      cost = 0.5 * rho0;
+      if (va >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)va, rd.g + 6 * (int64_t)va, 6, Ja, r, 6, w);
+      if (vb >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)vb, rd.g + 6 * (int64_t)vb, 6, Jb, r, 6, w);
+      if (va >= 0 && vb >= 0 && va != vb) {
+        const bool b_low = vb > va;  // lower triangle: larger reduced row first
+        const double* Jr_ = b_low ? Jb : Ja;
+        const double* Jc_ = b_low ? Ja : Jb;
+        const int64_t row = 6 * (int64_t)(b_low ? vb : va), col = 6 * (int64_t)(b_low ? va : vb);
+        for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
+          double acc = 0.0;
+          for (int a = 0; a < 6; ++a) acc += Jr_[6 * a + x] * Jc_[6 * a + y];
+          atomic_add_f64(S_at(rd.S, rd.nt, row + x, col + y), w * acc);
+        }
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+// diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
+__global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
+                                                        ReducedDev rd, double radius, int first_iter, double* scal) {
+  const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double gsq = 0.0, gmax = 0.0, xsq = 0.0;
+  const int64_t nblk = b.P + b.O;
+  if (t < nblk) {
+    const bool is_pose = t < b.P;
+    const int64_t idx = is_pose ? t : t - b.P;
+    const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
+    if (vid >= 0) {
+      const int d = is_pose ? 6 : 7;
+      const int64_t row = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;
+      const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
+      const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
+      for (int k = 0; k < d; ++k) {
+        const double c = Hd[d * k + k];
+        double s;
+        if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[row + k] = s; } else { s = rd.scale[row + k]; }
+        const double lam = lm_lambda(c, s, radius);
+        rd.lam[row + k] = lam;
+        for (int y = 0; y <= k; ++y) *S_at(rd.S, rd.nt, row + k, row + y) += Hd[d * k + y] + (y == k ? lam : 0.0);
+        const double g = rd.g[row + k];
+        rd.rhs[row + k] = g;
+        gsq += g * g; gmax = fmax(gmax, fabs(g)); xsq += x[k] * x[k];
+      }
+    }
+  }
+  block_accumulate(gsq, scal + SC_GSQ);
+  block_accumulate(xsq, scal + SC_XSQ);
+  block_accumulate_max(gmax, scal + SC_GMAX_BITS);
+}
+
+// ---------------------------------------------------------------------------------------
+// K4.  One wavefront per 6x6 block (p,q) of the Schur complement; the block's pair list
+// (observation a of pose p, observation b of pose q, same point) is contiguous.
+// lanes 0..35: element (x,y); lanes 36..41 on diagonal blocks: rhs component x.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
+                                                        const uint32_t* __restrict__ blk_ptr, const uint32_t* __restrict__ pair_a,
+                                                        const uint32_t* __restrict__ pair_b, const uint32_t* __restrict__ obs_point,
+                                                        PointDev pt, ReducedDev rd) {
+  const int64_t blk = blockIdx.x * (int64_t)(kBlock / 64) + (threadIdx.x >> 6);
+  if (blk >= nblk) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t row = blk_row[blk], col = blk_col[blk];
+  const uint32_t beg = blk_ptr[blk], end = blk_ptr[blk + 1];
+  const bool diag = row == col;
+  if (lane < 36) {
+    const int x = lane / 6, y = lane % 6;
+    double acc = 0.0;
+    for (uint32_t k = beg; k < end; ++k) {
+      const double* Za = pt.Z + 18 * (int64_t)pair_a[k] + 3 * x;
+      const double* Zb = pt.Z + 18 * (int64_t)pair_b[k] + 3 * y;
+      acc += Za[0] * Zb[0] + Za[1] * Zb[1] + Za[2] * Zb[2];
+    }
+    if (!diag || y <= x) *S_at(rd.S, rd.nt, (int64_t)row + x, (int64_t)col + y) -= acc;
+  } else if (diag && lane < 42) {
+    const int x = lane - 36;
+    double acc = 0.0;
+    for (uint32_t k = beg; k < end; ++k) {
+      const uint32_t a = pair_a[k];
+      if (a != pair_b[k]) continue;
+      const double* Za = pt.Z + 18 * (int64_t)a + 3 * x;
+      const double* u = pt.u + 3 * (int64_t)obs_point[a];
+      acc += Za[0] * u[0] + Za[1] * u[1] + Za[2] * u[2];
+    }
+    rd.rhs[row + x] -= acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K6.  Back-substitution of the eliminated points, candidate point.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points,
+                                                         double* __restrict__ points_cand, double* scal) {
+  const int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double stepsq = 0.0, bad = 0.0;
+  if (l < b.L) {
+    double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
+    if (b.point_var[l]) {
+      double t0 = pt.u[3 * l], t1 = pt.u[3 * l + 1], t2 = pt.u[3 * l + 2];
+      const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
+      for (uint32_t a = beg; a < end; ++a) {
+        if (!rp.active[a]) continue;
+        const int32_t vid = b.pose_vid[rp.pose[a]];
+        if (vid < 0) continue;
+        const double* Z = pt.Z + 18 * (int64_t)a;
+        const double* y = rd.y + 6 * (int64_t)vid;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { t0 -= Z[3 * x] * y[x]; t1 -= Z[3 * x + 1] * y[x]; t2 -= Z[3 * x + 2] * y[x]; }
+      }
+      const double* Ci = pt.Ci + 6 * l;
+      // y_l = Ci^T t ; delta = -y_l
+      const double d0 = -(Ci[0] * t0 + Ci[1] * t1 + Ci[3] * t2), d1 = -(Ci[2] * t1 + Ci[4] * t2), d2 = -(Ci[5] * t2);
+      if (!isfinite(d0) || !isfinite(d1) || !isfinite(d2)) bad = 1.0;
+      X[0] += d0; X[1] += d1; X[2] += d2;
+      stepsq = d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    points_cand[3 * l] = X[0]; points_cand[3 * l + 1] = X[1]; points_cand[3 * l + 2] = X[2];
+  }
+  block_accumulate(stepsq, scal + SC_STEPSQ);
+  block_accumulate(bad, scal + SC_NONFINITE);
+}
+
+__global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, ReducedDev rd, const double* __restrict__ poses, const double* __restrict__ objects,
+                                                              double* __restrict__ poses_cand, double* __restrict__ objects_cand, double* scal) {
+  const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double stepsq = 0.0, bad = 0.0;
+  if (t < b.P + b.O) {
+    const bool is_pose = t < b.P;
+    const int64_t idx = is_pose ? t : t - b.P;
+    const int d = is_pose ? 6 : 7;
+    const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
+    const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
+    double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
+    const int64_t row = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;
+    for (int k = 0; k < d; ++k) {
+      double v = x[k];
+      if (vid >= 0) {
+        const double dlt = -rd.y[row + k];
+        if (!isfinite(dlt)) bad = 1.0;
+        v += dlt; stepsq += dlt * dlt;
+      }
+      xc[k] = v;
+    }
+  }
+  block_accumulate(stepsq, scal + SC_STEPSQ);
+  block_accumulate(bad, scal + SC_NONFINITE);
+}
+
+// ---------------------------------------------------------------------------------------
+// K7.  Trial cost + model cost change  -(J d)^T (r + J d/2)  [Ceres-doc: TrustRegionMinimizer::
+// ComputeTrustRegionStep], with r, J the robustified residual/Jacobian at the current point.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+                                                       const PoseCache* __restrict__ pc_cur, const double* __restrict__ poses_cur, const double* __restrict__ points_cur,
+                                                       const PoseCache* __restrict__ pc_cand, const double* __restrict__ poses_cand, const double* __restrict__ points_cand,
+                                                       int mode, double* scal) {
+  const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double cost = 0.0, model = 0.0, fixed = 0.0;
+  if (a < rp.n && rp.active[a]) {
+    const uint32_t p = rp.pose[a], l = rp.point[a];
+    const bool var = b.pose_vid[p] >= 0 || b.point_var[l] != 0;
+    const DevCam cam = cams[rp.cam[a]];
+    const double2 px = rp.pixel[a];
+    const double sigma = rp.sigma[a];
+    if (mode == 1) {
+      if (!var) {
+        const double X[3] = {points_cur[3 * (int64_t)l], points_cur[3 * (int64_t)l + 1], points_cur[3 * (int64_t)l + 2]};
+        double r[2], rho0, w;
+        reproj_eval<false>(pc_cur[p], cam, X, px.x, px.y, sigma, r, nullptr, nullptr);
+        huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+        fixed = 0.5 * rho0;
+      }
+    } else if (var) {
+      const double Xc[3] = {points_cand[3 * (int64_t)l], points_cand[3 * (int64_t)l + 1], points_cand[3 * (int64_t)l + 2]};
+      double rc[2], rho0, w;
+      reproj_eval<false>(pc_cand[p], cam, Xc, px.x, px.y, sigma, rc, nullptr, nullptr);
+      huber_eval(rc[0] * rc[0] + rc[1] * rc[1], rp.huber, &rho0, &w);
+      cost = 0.5 * rho0;
+      const double X[3] = {points_cur[3 * (int64_t)l], points_cur[3 * (int64_t)l + 1], points_cur[3 * (int64_t)l + 2]};
+      double r[2], Jp[12], Jl[6];
+      reproj_eval<true>(pc_cur[p], cam, X, px.x, px.y, sigma, r, Jp, Jl);
+      huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+      double jd0 = 0.0, jd1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double d = poses_cand[6 * (int64_t)p + k] - poses_cur[6 * (int64_t)p + k]; jd0 += Jp[k] * d; jd1 += Jp[6 + k] * d; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double d = Xc[k] - X[k]; jd0 += Jl[k] * d; jd1 += Jl[3 + k] * d; }
+      model = -w * (jd0 * (r[0] + 0.5 * jd0) + jd1 * (r[1] + 0.5 * jd1));
+    }
+  }
+  block_accumulate(cost, scal + SC_COST_CAND);
+  block_accumulate(model, scal + SC_MODEL_CHANGE);
+  block_accumulate(fixed, scal + SC_COST_FIXED);
+}
+
+// small factors: one kernel, thread ranges [bbox | shape | ltm | relpose]
+__device__ __forceinline__ double model_term(const double* r, const double* Jd, int m, double w) {
+  double acc = 0.0;
+  for (int a = 0; a < m; ++a) acc += Jd[a] * (r[a] + 0.5 * Jd[a]);
+  return -w * acc;
+}
+__global__ void __launch_bounds__(64) k_cost_small(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams,
+                                                  const double* __restrict__ poses_cur, const double* __restrict__ objects_cur,
+                                                  const double* __restrict__ poses_cand, const double* __restrict__ objects_cand, int mode, double* scal) {
+  int64_t t = blockIdx.x * 64LL + threadIdx.x;
+  double cost = 0.0, model = 0.0, fixed = 0.0;
+  if (t < sf.n_bb) {
+    const int64_t i = t;
+    if (sf.bb_active[i]) {
+      const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
+      const bool var = b.obj_vid[o] >= 0 || b.pose_vid[p] >= 0;
+      const DevCam cam = cams[sf.bb_cam[i]];
+      D13 res[4];
+      double rho0, w;
+      if (mode == 1) {
+        if (!var) {
+          bbox_eval(objects_cur + 7 * (int64_t)o, poses_cur + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+          huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
+          fixed = 0.5 * rho0;
+        }
+      } else if (var) {
+        bbox_eval(objects_cand + 7 * (int64_t)o, poses_cand + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+        huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        bbox_eval(objects_cur + 7 * (int64_t)o, poses_cur + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+        double r[4], Jd[4];
+        for (int a = 0; a < 4; ++a) {
+          r[a] = res[a].v;
+          double acc = 0.0;
+          for (int k = 0; k < 7; ++k) acc += res[a].d[k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]);
+          for (int k = 0; k < 6; ++k) acc += res[a].d[7 + k] * (poses_cand[6 * (int64_t)p + k] - poses_cur[6 * (int64_t)p + k]);
+          Jd[a] = acc;
+        }
+        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
+        model = model_term(r, Jd, 4, w);
+      }
+    }
+  } else if ((t -= sf.n_bb) < sf.n_sp) {
+    const int64_t i = t;
+    if (sf.sp_active[i]) {
+      const uint32_t o = sf.sp_obj[i];
+      const bool var = b.obj_vid[o] >= 0;
+      double r[3], J[21], rho0, w;
+      if (mode == 1) {
+        if (!var) {
+          shape_prior_eval(objects_cur + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+          huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
+          fixed = 0.5 * rho0;
+        }
+      } else if (var) {
+        shape_prior_eval(objects_cand + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        shape_prior_eval(objects_cur + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
+        double Jd[3];
+        for (int a = 0; a < 3; ++a) { double acc = 0.0; for (int k = 0; k < 7; ++k) acc += J[7 * a + k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]); Jd[a] = acc; }
+        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
+        model = model_term(r, Jd, 3, w);
+      }
+    }
+  } else if ((t -= sf.n_sp) < sf.n_lt) {
+    const int64_t i = t;
+    if (sf.lt_active[i]) {
+      const uint32_t o = sf.lt_obj[i];
+      const bool var = b.obj_vid[o] >= 0;
+      double r[7], J[49], rho0, w, s = 0.0;
+      if (mode == 1) {
+        if (!var) {
+          ltm_prior_eval(objects_cur + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
+          for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+          huber_eval(s, sf.lt_huber, &rho0, &w);
+          fixed = 0.5 * rho0;
+        }
+      } else if (var) {
+        ltm_prior_eval(objects_cand + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
+        for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+        huber_eval(s, sf.lt_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        ltm_prior_eval(objects_cur + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
+        double Jd[7]; s = 0.0;
+        for (int a = 0; a < 7; ++a) { s += r[a] * r[a]; double acc = 0.0; for (int k = 0; k < 7; ++k) acc += J[7 * a + k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]); Jd[a] = acc; }
+        huber_eval(s, sf.lt_huber, &rho0, &w);
+        model = model_term(r, Jd, 7, w);
+      }
+    }
+  } else if ((t -= sf.n_lt) < sf.n_rl) {
+    const int64_t i = t;
+    if (sf.rl_active[i]) {
+      const uint32_t pa = sf.rl_a[i], pb = sf.rl_b[i];
+      const bool var = b.pose_vid[pa] >= 0 || b.pose_vid[pb] >= 0;
+      D12 res[6];
+      double rho0, w, s = 0.0;
+      if (mode == 1) {
+        if (!var) {
+          relpose_eval(poses_cur + 6 * (int64_t)pa, poses_cur + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+          for (int a = 0; a < 6; ++a) s += res[a].v * res[a].v;
+          huber_eval(s, sf.rl_huber, &rho0, &w);
+          fixed = 0.5 * rho0;
+        }
+      } else if (var) {
+        relpose_eval(poses_cand + 6 * (int64_t)pa, poses_cand + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+        for (int a = 0; a < 6; ++a) s += res[a].v * res[a].v;
+        huber_eval(s, sf.rl_huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        relpose_eval(poses_cur + 6 * (int64_t)pa, poses_cur + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+        double r[6], Jd[6]; s = 0.0;
+        for (int a = 0; a < 6; ++a) {
+          r[a] = res[a].v; s += r[a] * r[a];
+          double acc = 0.0;
+          for (int k = 0; k < 6; ++k) {
+            acc += res[a].d[k] * (poses_cand[6 * (int64_t)pa + k] - poses_cur[6 * (int64_t)pa + k]);
+            acc += res[a].d[6 + k] * (poses_cand[6 * (int64_t)pb + k] - poses_cur[6 * (int64_t)pb + k]);
+          }
+          Jd[a] = acc;
+        }
+        huber_eval(s, sf.rl_huber, &rho0, &w);
+        model = model_term(r, Jd, 6, w);
+      }
+    }
+  }
+  cost = wave_sum(cost); model = wave_sum(model); fixed = wave_sum(fixed);
+  if (threadIdx.x == 0) {
+    if (cost != 0.0) atomic_add_f64(scal + SC_COST_CAND, cost);
+    if (model != 0.0) atomic_add_f64(scal + SC_MODEL_CHANGE, model);
+    if (fixed != 0.0) atomic_add_f64(scal + SC_COST_FIXED, fixed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Problem::Evaluate -- every active factor, caller order
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_eval_reproj(ReprojDev rp, const uint32_t* __restrict__ perm, const DevCam* __restrict__ cams,
+                                                       const PoseCache* __restrict__ pc, const double* __restrict__ points, int apply_loss,
+                                                       double* residuals, double* sqnorm, double* scal) {
+  const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  double cost = 0.0;
+  if (a < rp.n) {
+    const uint32_t orig = perm[a];
+    double r[2] = {0.0, 0.0}, s = 0.0;
+    if (rp.active[a]) {
+      const uint32_t l = rp.point[a];
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      const double2 px = rp.pixel[a];
+      reproj_eval<false>(pc[rp.pose[a]], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, nullptr, nullptr);
+      s = r[0] * r[0] + r[1] * r[1];
+      if (apply_loss) {
+        double rho0, w;
+        huber_eval(s, rp.huber, &rho0, &w);
+        cost = 0.5 * rho0;
+        const double sw = sqrt(w);
+        r[0] *= sw; r[1] *= sw;
+      } else {
+        cost = 0.5 * s;
+      }
+    }
+    if (residuals) { residuals[2 * (int64_t)orig] = r[0]; residuals[2 * (int64_t)orig + 1] = r[1]; }
+    if (sqnorm) sqnorm[orig] = s;
+  }
+  block_accumulate(cost, scal + SC_COST);
+}
+
+template <int M>
+__device__ __forceinline__ double finish_eval(double* r, double huber, int apply_loss, double* residuals, double* sqnorm, int64_t i, bool active) {
+  double s = 0.0, cost = 0.0;
+  if (active) {
+    for (int a = 0; a < M; ++a) s += r[a] * r[a];
+    if (apply_loss) {
+      double rho0, w;
+      huber_eval(s, huber, &rho0, &w);
+      cost = 0.5 * rho0;
+      const double sw = sqrt(w);
+      for (int a = 0; a < M; ++a) r[a] *= sw;
+    } else {
+      cost = 0.5 * s;
+    }
+  } else {
+    for (int a = 0; a < M; ++a) r[a] = 0.0;
+  }
+  if (residuals) for (int a = 0; a < M; ++a) residuals[M * i + a] = r[a];
+  if (sqnorm) sqnorm[i] = s;
+  return cost;
+}
+
+__global__ void __launch_bounds__(64) k_eval_small(SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                                  const double* __restrict__ objects, int apply_loss, double* res_bb, double* sq_bb,
+                                                  double* res_sp, double* sq_sp, double* res_lt, double* sq_lt, double* res_rl, double* sq_rl, double* scal) {
+  int64_t t = blockIdx.x * 64LL + threadIdx.x;
+  double cost = 0.0;
+  if (t < sf.n_bb) {
+    const int64_t i = t;
+    double r[4] = {0, 0, 0, 0};
+    const bool act = sf.bb_active[i] != 0;
+    if (act) {
+      D13 res[4];
+      bbox_eval(objects + 7 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+      for (int a = 0; a < 4; ++a) r[a] = res[a].v;
+    }
+    cost = finish_eval<4>(r, sf.bb_huber, apply_loss, res_bb, sq_bb, i, act);
+  } else if ((t -= sf.n_bb) < sf.n_sp) {
+    const int64_t i = t;
+    double r[3] = {0, 0, 0};
+    const bool act = sf.sp_active[i] != 0;
+    if (act) shape_prior_eval(objects + 7 * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+    cost = finish_eval<3>(r, sf.sp_huber, apply_loss, res_sp, sq_sp, i, act);
+  } else if ((t -= sf.n_sp) < sf.n_lt) {
+    const int64_t i = t;
+    double r[7] = {0, 0, 0, 0, 0, 0, 0};
+    const bool act = sf.lt_active[i] != 0;
+    if (act) ltm_prior_eval(objects + 7 * (int64_t)sf.lt_obj[i], sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
+    cost = finish_eval<7>(r, sf.lt_huber, apply_loss, res_lt, sq_lt, i, act);
+  } else if ((t -= sf.n_lt) < sf.n_rl) {
+    const int64_t i = t;
+    double r[6] = {0, 0, 0, 0, 0, 0};
+    const bool act = sf.rl_active[i] != 0;
+    if (act) {
+      D12 res[6];
+      relpose_eval(poses + 6 * (int64_t)sf.rl_a[i], poses + 6 * (int64_t)sf.rl_b[i], sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+      for (int a = 0; a < 6; ++a) r[a] = res[a].v;
+    }
+    cost = finish_eval<6>(r, sf.rl_huber, apply_loss, res_rl, sq_rl, i, act);
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+__global__ void __launch_bounds__(kBlock) k_debug_lin_reproj(ReprojDev rp, const uint32_t* __restrict__ perm, const DevCam* __restrict__ cams,
+                                                            const PoseCache* __restrict__ pc, const double* __restrict__ points, double* r_out, double* J0, double* J1) {
+  const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  if (a >= rp.n) return;
+  const int64_t o = perm[a];
+  const uint32_t l = rp.point[a];
+  const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+  const double2 px = rp.pixel[a];
+  double r[2], Jp[12], Jl[6];
+  reproj_eval<true>(pc[rp.pose[a]], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
+  r_out[2 * o] = r[0]; r_out[2 * o + 1] = r[1];
+  for (int k = 0; k < 12; ++k) J0[12 * o + k] = Jp[k];
+  for (int k = 0; k < 6; ++k) J1[6 * o + k] = Jl[k];
+}
+
+__global__ void __launch_bounds__(64) k_debug_lin_small(int type, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                                       const double* __restrict__ objects, double* r_out, double* J0, double* J1) {
+  const int64_t i = blockIdx.x * 64LL + threadIdx.x;
+  if (type == 2 && i < sf.n_bb) {
+    D13 res[4];
+    bbox_eval(objects + 7 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+    for (int a = 0; a < 4; ++a) {
+      r_out[4 * i + a] = res[a].v;
+      for (int k = 0; k < 7; ++k) J0[28 * i + 7 * a + k] = res[a].d[k];
+      for (int k = 0; k < 6; ++k) J1[24 * i + 6 * a + k] = res[a].d[7 + k];
+    }
+  } else if (type == 3 && i < sf.n_sp) {
+    double r[3], J[21];
+    shape_prior_eval(objects + 7 * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
+    for (int a = 0; a < 3; ++a) r_out[3 * i + a] = r[a];
+    for (int k = 0; k < 21; ++k) J0[21 * i + k] = J[k];
+  } else if (type == 4 && i < sf.n_lt) {
+    double r[7], J[49];
+    ltm_prior_eval(objects + 7 * (int64_t)sf.lt_obj[i], sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
+    for (int a = 0; a < 7; ++a) r_out[7 * i + a] = r[a];
+    for (int k = 0; k < 49; ++k) J0[49 * i + k] = J[k];
+  } else if (type == 5 && i < sf.n_rl) {
+    D12 res[6];
+    relpose_eval(poses + 6 * (int64_t)sf.rl_a[i], poses + 6 * (int64_t)sf.rl_b[i], sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+    for (int a = 0; a < 6; ++a) {
+      r_out[6 * i + a] = res[a].v;
+      for (int k = 0; k < 6; ++k) { J0[36 * i + 6 * a + k] = res[a].d[k]; J1[36 * i + 6 * a + k] = res[a].d[6 + k]; }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill(double* p, int64_t n, double v) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+
+inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+// =========================================================================================
+void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out) {
+  if (P > 0) hipLaunchKernelGGL(k_pose_cache, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, P, poses, out);
+}
+void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
+                       const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal) {
+  if (b.L > 0 && rp.n > 0) hipLaunchKernelGGL(k_point_pass, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal);
+}
+void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
+                          const double* objects, const ReducedDev& rd, double* scal) {
+  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
+  if (sf.n_sp + sf.n_lt > 0) hipLaunchKernelGGL(k_object_priors_lin, dim3(grid_for(sf.n_sp + sf.n_lt, 64)), dim3(64), 0, s, b, sf, objects, rd, scal);
+  if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
+}
+void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
+                         int first_iter, double* scal) {
+  if (b.P + b.O > 0) hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
+}
+void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
+                         const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
+  if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(nblk, kBlock / 64)), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
+}
+void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
+                          double* points_cand, double* scal) {
+  if (b.L > 0) hipLaunchKernelGGL(k_point_backsub, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, scal);
+}
+void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,
+                               double* poses_cand, double* objects_cand, double* scal) {
+  if (b.P + b.O > 0) hipLaunchKernelGGL(k_apply_reduced_step, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, rd, poses, objects, poses_cand, objects_cand, scal);
+}
+void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
+                 const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
+                 const double* points_cand, const double* objects_cand, int mode, double* scal) {
+  if (rp.n > 0) hipLaunchKernelGGL(k_cost_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc_cur, poses_cur, points_cur, pc_cand, poses_cand, points_cand, mode, scal);
+  const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
+  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses_cur, objects_cur, poses_cand, objects_cand, mode, scal);
+}
+void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
+                     const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,
+                     double* sqnorm, double* scal) {
+  if (rp.n > 0) hipLaunchKernelGGL(k_eval_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, rp, rp_perm, cams, pc, points, apply_loss, residuals, sqnorm, scal);
+  const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
+  if (ns > 0) {
+    double* r_bb = residuals ? residuals + 2 * rp.n : nullptr;
+    double* r_sp = residuals ? r_bb + 4 * sf.n_bb : nullptr;
+    double* r_lt = residuals ? r_sp + 3 * sf.n_sp : nullptr;
+    double* r_rl = residuals ? r_lt + 7 * sf.n_lt : nullptr;
+    double* q_bb = sqnorm ? sqnorm + rp.n : nullptr;
+    double* q_sp = sqnorm ? q_bb + sf.n_bb : nullptr;
+    double* q_lt = sqnorm ? q_sp + sf.n_sp : nullptr;
+    double* q_rl = sqnorm ? q_lt + sf.n_lt : nullptr;
+    hipLaunchKernelGGL(k_eval_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, sf, cams, poses, objects, apply_loss, r_bb, q_bb, r_sp, q_sp, r_lt, q_lt, r_rl, q_rl, scal);
+  }
+  (void)b;
+}
+void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uint32_t* rp_perm, const DevCam* cams, const PoseCache* pc,
+                                   const double* points, double* r, double* J0, double* J1) {
+  if (rp.n > 0) hipLaunchKernelGGL(k_debug_lin_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, rp, rp_perm, cams, pc, points, r, J0, J1);
+}
+void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
+                                  const double* objects, double* r, double* J0, double* J1) {
+  const int64_t n = factor_type == 2 ? sf.n_bb : factor_type == 3 ? sf.n_sp : factor_type == 4 ? sf.n_lt : sf.n_rl;
+  if (n > 0) hipLaunchKernelGGL(k_debug_lin_small, dim3(grid_for(n, 64)), dim3(64), 0, s, factor_type, sf, cams, poses, objects, r, J0, J1);
+}
+void launch_fill(hipStream_t s, double* p, int64_t n, double v) {
+  if (n > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, p, n, v);
+}
+
+}  // namespace obvi

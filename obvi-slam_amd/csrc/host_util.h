@@ -1,0 +1,102 @@
+// host_util.h -- small host helpers of libobvi_ba: device buffers, error plumbing, and the
+// symmetric inverse square root the factor constructors of the reference apply to their
+// covariances (`cov.inverse().sqrt()`: bounding_box_factor.cpp:31-33, shape_prior_factor.cpp:11,
+// independent_object_map_factor.cpp:11, relative_pose_factor.cpp:13).
+#ifndef OBVI_HOST_UTIL_H_
+#define OBVI_HOST_UTIL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace obvi {
+
+struct HipError { hipError_t code; const char* what; const char* file; int line; };
+
+#define OBVI_HIP(expr)                                                         \
+  do {                                                                         \
+    hipError_t e__ = (expr);                                                   \
+    if (e__ != hipSuccess) throw ::obvi::HipError{e__, #expr, __FILE__, __LINE__}; \
+  } while (0)
+
+template <class T>
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() { if (p_) { (void)hipFree(p_); p_ = nullptr; } n_ = 0; cap_ = 0; }
+  // grow-only allocation; contents are undefined after a growing resize
+  void resize(size_t n) {
+    if (n > cap_) {
+      if (p_) { (void)hipFree(p_); p_ = nullptr; }
+      size_t c = n + n / 8 + 16;
+      OBVI_HIP(hipMalloc(reinterpret_cast<void**>(&p_), c * sizeof(T)));
+      cap_ = c;
+    }
+    n_ = n;
+  }
+  void upload(const T* h, size_t n, hipStream_t s) {
+    resize(n);
+    if (n) OBVI_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+  void download(T* h, size_t n, hipStream_t s) const {
+    if (n) OBVI_HIP(hipMemcpyAsync(h, p_, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+  void zero(hipStream_t s) { if (n_) OBVI_HIP(hipMemsetAsync(p_, 0, n_ * sizeof(T), s)); }
+  T* get() const { return p_; }
+  size_t size() const { return n_; }
+  void swap(DevBuf& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
+// out = (sym(cov))^(-1/2) for an n x n (n <= 7) symmetric positive definite matrix, row-major.
+// One-sided view: eigen-decomposition by threshold-free cyclic Jacobi sweeps on a working copy,
+// then out = sum_k v_k v_k^T / sqrt(lambda_k).  Returns false when cov is not finite / not SPD.
+inline bool sym_inverse_sqrt(const double* cov, int n, double* out) {
+  double a[7][7], v[7][7];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      a[i][j] = 0.5 * (cov[i * n + j] + cov[j * n + i]);
+      v[i][j] = i == j;
+      if (!std::isfinite(a[i][j])) return false;
+    }
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, tot = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) { tot += a[i][j] * a[i][j]; if (i != j) off += a[i][j] * a[i][j]; }
+    if (off <= tot * 1e-32) break;
+    for (int p = 0; p + 1 < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[p][q];
+        if (apq == 0.0) continue;
+        // rotation angle that annihilates a[p][q]
+        const double tau = (a[q][q] - a[p][p]) / (2.0 * apq);
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::hypot(1.0, tau));
+        const double c = 1.0 / std::hypot(1.0, t), s = t * c;
+        for (int k = 0; k < n; ++k) { const double x = a[k][p], y = a[k][q]; a[k][p] = c * x - s * y; a[k][q] = s * x + c * y; }
+        for (int k = 0; k < n; ++k) { const double x = a[p][k], y = a[q][k]; a[p][k] = c * x - s * y; a[q][k] = s * x + c * y; }
+        for (int k = 0; k < n; ++k) { const double x = v[k][p], y = v[k][q]; v[k][p] = c * x - s * y; v[k][q] = s * x + c * y; }
+      }
+  }
+  for (int k = 0; k < n; ++k) if (!(a[k][k] > 0.0)) return false;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += v[i][k] * v[j][k] / std::sqrt(a[k][k]);
+      out[i * n + j] = acc;
+    }
+  return true;
+}
+
+}  // namespace obvi
+#endif  // OBVI_HOST_UTIL_H_

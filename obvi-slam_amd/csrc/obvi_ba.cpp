@@ -1,0 +1,1033 @@
+// obvi_ba.cpp -- C ABI of libobvi_ba (include/obvi_ba.h): problem upload, reduced-program
+// bookkeeping, symbolic tile plan of the Schur complement and the Levenberg-Marquardt loop that
+// drives the gfx950 kernels.  One handle == one GPU == one HIP stream.  There is no CPU
+// compute path in this library: without a HIP device obvi_ba_create fails with OBVI_ERR_NO_DEVICE.
+//
+// Trust-region logic: [Ceres-doc] TrustRegionMinimizer / LevenbergMarquardtStrategy /
+// TrustRegionStepEvaluator with the options the reference sets at
+// include/refactoring/optimization/object_pose_graph_optimizer.h:651-672 and Ceres defaults
+// otherwise (Jacobi scaling, min/max LM diagonal 1e-6/1e32, min_relative_decrease 1e-3,
+// max 5 consecutive non-monotonic / invalid steps, min trust-region radius 1e-32).
+#include "../../include/obvi_ba.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ba_device.h"
+#include "host_util.h"
+
+using namespace obvi;  // NOLINT
+
+namespace {
+
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "small_factors", "reduced_diag", "schur_blocks",
+                                     "cholesky_solve", "point_backsub", "apply_step", "cost"};
+
+}  // namespace
+
+struct obvi_ba_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- host mirrors ----
+  std::vector<DevCam> h_cams;
+  int64_t P = 0, L = 0, O = 0;
+  std::vector<uint8_t> h_pose_const, h_point_const, h_object_const;
+  // reprojection: sorted by (point, pose); perm[sorted] = caller index
+  int64_t n_rp = 0;
+  std::vector<uint32_t> h_rp_pose, h_rp_point, h_rp_perm, h_rp_inv, h_point_ptr;
+  std::vector<uint8_t> h_rp_active;  // sorted order
+  double rp_huber = 1.0;
+  int64_t n_bb = 0, n_sp = 0, n_lt = 0, n_rl = 0;
+  std::vector<uint32_t> h_bb_obj, h_bb_pose, h_sp_obj, h_lt_obj, h_rl_a, h_rl_b;
+  std::vector<uint8_t> h_bb_active, h_sp_active, h_lt_active, h_rl_active;
+  double bb_huber = 1.0, bb_invalid = 1e6, sp_huber = 1.0, lt_huber = 1.0, rl_huber = 1.0;
+
+  // ---- device: parameters ----
+  DevBuf<DevCam> d_cams;
+  DevBuf<double> d_pose, d_point, d_obj;           // current
+  DevBuf<double> d_pose_c, d_point_c, d_obj_c;     // candidate
+  DevBuf<double> d_pose_b, d_point_b, d_obj_b;     // best (minimum cost) iterate
+  DevBuf<double> d_pose_s, d_point_s, d_obj_s;     // snapshot
+  bool have_snapshot = false;
+  DevBuf<PoseCache> d_pc, d_pc_c;
+  DevBuf<int32_t> d_pose_vid, d_obj_vid;
+  DevBuf<uint8_t> d_point_var;
+  // ---- device: factors ----
+  DevBuf<uint32_t> d_rp_pose, d_rp_point, d_rp_perm, d_point_ptr;
+  DevBuf<uint16_t> d_rp_cam;
+  DevBuf<double2> d_rp_pixel;
+  DevBuf<double> d_rp_sigma;
+  DevBuf<uint8_t> d_rp_active;
+  DevBuf<uint32_t> d_bb_obj, d_bb_pose, d_sp_obj, d_lt_obj, d_rl_a, d_rl_b;
+  DevBuf<uint16_t> d_bb_cam;
+  DevBuf<double> d_bb_rect, d_bb_sqrt_inf, d_sp_mean, d_sp_sqrt_inf, d_lt_mean, d_lt_sqrt_inf, d_rl_t, d_rl_R, d_rl_sqrt_inf;
+  DevBuf<uint8_t> d_bb_active, d_sp_active, d_lt_active, d_rl_active;
+  // ---- device: reduced system ----
+  DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
+  DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
+  DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b;
+  DevBuf<int32_t> d_tiles, d_trsm_i, d_upd_ij, d_back_j;
+  DevBuf<double> d_scal;
+  DevBuf<double> d_eval_res, d_eval_sq;
+  double* h_scal = nullptr;  // pinned
+
+  // ---- reduced-program bookkeeping (prepare()) ----
+  bool dirty = true;
+  int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, num_params = 0, num_residuals = 0;
+  int32_t nt = 0;
+  int64_t nblk = 0, npairs = 0;
+  std::vector<int32_t> h_trsm_ptr, h_upd_ptr, h_back_ptr;
+  int32_t ntiles = 0;
+  double chol_flops = 0.0;
+
+  // ---- last solve ----
+  std::vector<obvi_iteration_summary> iterations;
+  obvi_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+
+  // ---- phase timing ----
+  hipEvent_t ev[PH_COUNT + 1] = {};
+  double phase_ms[PH_COUNT] = {};
+  int64_t phase_launches[PH_COUNT] = {};
+};
+
+namespace {
+
+int fail(obvi_ba_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+int hip_fail(obvi_ba_handle* h, const HipError& e) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", e.what, hipGetErrorString(e.code), e.file, e.line);
+  return fail(h, OBVI_ERR_HIP, buf);
+}
+
+#define OBVI_API_BEGIN try {
+#define OBVI_API_END(h)                                           \
+  }                                                               \
+  catch (const HipError& e) { return hip_fail(h, e); }            \
+  catch (const std::bad_alloc&) { return fail(h, OBVI_ERR_HIP, "host allocation failed"); }
+
+void make_cam(const double* K4, const double* e, DevCam* c) {
+  // inverse of the extrinsics T_robot<-camera: cam_to_robot_tf_inv_ (reprojection_cost_functor.cpp:10-13)
+  double q[4] = {e[0], e[1], e[2], e[3]};
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (double& v : q) v /= n;
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                          {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                          {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) c->Rinv[3 * i + j] = R[j][i];
+    c->tinv[i] = -(R[0][i] * e[4] + R[1][i] * e[5] + R[2][i] * e[6]);
+  }
+  c->fx = K4[0]; c->fy = K4[1]; c->cx = K4[2]; c->cy = K4[3];
+}
+
+void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
+
+BlocksDev blocks_dev(const obvi_ba_handle* h) {
+  BlocksDev b;
+  b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.m = h->m;
+  b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
+  return b;
+}
+ReprojDev reproj_dev(const obvi_ba_handle* h) {
+  ReprojDev r;
+  r.n = h->n_rp; r.pose = h->d_rp_pose.get(); r.point = h->d_rp_point.get(); r.cam = h->d_rp_cam.get();
+  r.pixel = h->d_rp_pixel.get(); r.sigma = h->d_rp_sigma.get(); r.active = h->d_rp_active.get();
+  r.point_ptr = h->d_point_ptr.get(); r.huber = h->rp_huber;
+  return r;
+}
+SmallFactorsDev small_dev(const obvi_ba_handle* h) {
+  SmallFactorsDev s;
+  s.n_bb = h->n_bb; s.bb_obj = h->d_bb_obj.get(); s.bb_pose = h->d_bb_pose.get(); s.bb_cam = h->d_bb_cam.get();
+  s.bb_rect = h->d_bb_rect.get(); s.bb_sqrt_inf = h->d_bb_sqrt_inf.get(); s.bb_active = h->d_bb_active.get();
+  s.bb_huber = h->bb_huber; s.bb_invalid = h->bb_invalid;
+  s.n_sp = h->n_sp; s.sp_obj = h->d_sp_obj.get(); s.sp_mean = h->d_sp_mean.get(); s.sp_sqrt_inf = h->d_sp_sqrt_inf.get();
+  s.sp_active = h->d_sp_active.get(); s.sp_huber = h->sp_huber;
+  s.n_lt = h->n_lt; s.lt_obj = h->d_lt_obj.get(); s.lt_mean = h->d_lt_mean.get(); s.lt_sqrt_inf = h->d_lt_sqrt_inf.get();
+  s.lt_active = h->d_lt_active.get(); s.lt_huber = h->lt_huber;
+  s.n_rl = h->n_rl; s.rl_a = h->d_rl_a.get(); s.rl_b = h->d_rl_b.get(); s.rl_t = h->d_rl_t.get(); s.rl_R = h->d_rl_R.get();
+  s.rl_sqrt_inf = h->d_rl_sqrt_inf.get(); s.rl_active = h->d_rl_active.get(); s.rl_huber = h->rl_huber;
+  return s;
+}
+ReducedDev reduced_dev(const obvi_ba_handle* h) {
+  ReducedDev r;
+  r.Hdiag = h->d_Hdiag.get(); r.g = h->d_g.get(); r.scale = h->d_scale.get(); r.lam = h->d_lam.get();
+  r.S = h->d_S.get(); r.rhs = h->d_rhs.get(); r.y = h->d_y.get(); r.nt = h->nt;
+  return r;
+}
+PointDev point_dev(const obvi_ba_handle* h) {
+  PointDev p;
+  p.Ci = h->d_Ci.get(); p.u = h->d_u.get(); p.scale = h->d_scale_l.get(); p.Z = h->d_Z.get();
+  return p;
+}
+CholPlan chol_plan(const obvi_ba_handle* h) {
+  CholPlan c;
+  c.nt = h->nt; c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_i = h->d_trsm_i.get(); c.upd_ptr = h->h_upd_ptr.data();
+  c.upd_ij = h->d_upd_ij.get(); c.back_ptr = h->h_back_ptr.data(); c.back_j = h->d_back_j.get();
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// Reduced program [Ceres-doc Program::RemoveFixedBlocks], Schur pair lists, tile plan.
+// ---------------------------------------------------------------------------------------
+void prepare(obvi_ba_handle* h) {
+  if (!h->dirty) return;
+  const int64_t P = h->P, L = h->L, O = h->O;
+  std::vector<uint8_t> pose_used(P, 0), obj_used(O, 0), point_used(L, 0);
+  int64_t nres = 0;
+  for (int64_t a = 0; a < h->n_rp; ++a) {
+    if (!h->h_rp_active[a]) continue;
+    const uint32_t p = h->h_rp_pose[a], l = h->h_rp_point[a];
+    const bool cp = h->h_pose_const[p], cl = h->h_point_const[l];
+    if (cp && cl) continue;
+    nres += 2;
+    if (!cp) pose_used[p] = 1;
+    if (!cl) point_used[l] = 1;
+  }
+  for (int64_t i = 0; i < h->n_bb; ++i) {
+    if (!h->h_bb_active[i]) continue;
+    const uint32_t o = h->h_bb_obj[i], p = h->h_bb_pose[i];
+    const bool co = h->h_object_const[o], cp = h->h_pose_const[p];
+    if (co && cp) continue;
+    nres += 4;
+    if (!co) obj_used[o] = 1;
+    if (!cp) pose_used[p] = 1;
+  }
+  for (int64_t i = 0; i < h->n_sp; ++i) if (h->h_sp_active[i] && !h->h_object_const[h->h_sp_obj[i]]) { nres += 3; obj_used[h->h_sp_obj[i]] = 1; }
+  for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += 7; obj_used[h->h_lt_obj[i]] = 1; }
+  for (int64_t i = 0; i < h->n_rl; ++i) {
+    if (!h->h_rl_active[i]) continue;
+    const uint32_t a = h->h_rl_a[i], b = h->h_rl_b[i];
+    const bool ca = h->h_pose_const[a], cb = h->h_pose_const[b];
+    if (ca && cb) continue;
+    nres += 6;
+    if (!ca) pose_used[a] = 1;
+    if (!cb) pose_used[b] = 1;
+  }
+  std::vector<int32_t> pose_vid(P, -1), obj_vid(O, -1);
+  std::vector<uint8_t> point_var(L, 0);
+  h->nPv = h->nOv = h->nLv = 0;
+  for (int64_t p = 0; p < P; ++p) if (!h->h_pose_const[p] && pose_used[p]) pose_vid[p] = (int32_t)h->nPv++;
+  for (int64_t o = 0; o < O; ++o) if (!h->h_object_const[o] && obj_used[o]) obj_vid[o] = (int32_t)h->nOv++;
+  for (int64_t l = 0; l < L; ++l) if (!h->h_point_const[l] && point_used[l]) { point_var[l] = 1; h->nLv++; }
+  h->m = 6 * h->nPv + 7 * h->nOv;
+  h->num_params = h->m + 3 * h->nLv;
+  h->num_residuals = nres;
+  h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
+  const int32_t nt = h->nt;
+  const int64_t m_pad = (int64_t)nt * kTile;
+
+  // ---- Schur pair lists: per eliminated point, all ordered observation pairs (a, b) with reduced
+  //      row(a) >= row(b); grouped by 6x6 block (row, col) of the Schur complement.
+  struct Pair { uint64_t key; uint32_t a, b; };
+  std::vector<Pair> pairs;
+  {
+    std::vector<std::pair<uint32_t, int32_t>> obs;  // (sorted obs index, pose vid)
+    for (int64_t l = 0; l < L; ++l) {
+      if (!point_var[l]) continue;
+      obs.clear();
+      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
+        if (!h->h_rp_active[a]) continue;
+        const int32_t v = pose_vid[h->h_rp_pose[a]];
+        if (v >= 0) obs.push_back({a, v});
+      }
+      for (const auto& x : obs)
+        for (const auto& y : obs)
+          if (x.second >= y.second) pairs.push_back({(uint64_t)x.second * (uint64_t)(h->nPv + 1) + (uint64_t)y.second, x.first, y.first});
+    }
+  }
+  std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key || (x.key == y.key && (x.a < y.a || (x.a == y.a && x.b < y.b))); });
+  std::vector<uint32_t> blk_row, blk_col, blk_ptr, pair_a(pairs.size()), pair_b(pairs.size());
+  for (size_t k = 0; k < pairs.size(); ++k) {
+    if (k == 0 || pairs[k].key != pairs[k - 1].key) {
+      blk_row.push_back(6u * (uint32_t)(pairs[k].key / (uint64_t)(h->nPv + 1)));
+      blk_col.push_back(6u * (uint32_t)(pairs[k].key % (uint64_t)(h->nPv + 1)));
+      blk_ptr.push_back((uint32_t)k);
+    }
+    pair_a[k] = pairs[k].a; pair_b[k] = pairs[k].b;
+  }
+  blk_ptr.push_back((uint32_t)pairs.size());
+  h->nblk = (int64_t)blk_row.size();
+  h->npairs = (int64_t)pairs.size();
+  pairs.clear(); pairs.shrink_to_fit();
+
+  // ---- tile mask of the reduced matrix (lower triangle) and symbolic fill ----
+  std::vector<uint8_t> mask((size_t)nt * nt, 0);
+  auto mark = [&](int64_t row, int dr, int64_t col, int dc) {
+    const int t0 = (int)(row / kTile), t1 = (int)((row + dr - 1) / kTile), c0 = (int)(col / kTile), c1 = (int)((col + dc - 1) / kTile);
+    for (int ti = t0; ti <= t1; ++ti) for (int tj = c0; tj <= c1; ++tj) if (ti >= tj) mask[(size_t)ti * nt + tj] = 1;
+  };
+  for (int k = 0; k < nt; ++k) mask[(size_t)k * nt + k] = 1;
+  for (int64_t b = 0; b < h->nblk; ++b) mark(blk_row[b], 6, blk_col[b], 6);
+  for (int64_t i = 0; i < h->n_bb; ++i) {
+    if (!h->h_bb_active[i]) continue;
+    const int32_t ov = obj_vid[h->h_bb_obj[i]], pv = pose_vid[h->h_bb_pose[i]];
+    if (ov >= 0 && pv >= 0) mark(6 * h->nPv + 7 * (int64_t)ov, 7, 6 * (int64_t)pv, 6);
+  }
+  for (int64_t i = 0; i < h->n_rl; ++i) {
+    if (!h->h_rl_active[i]) continue;
+    const int32_t va = pose_vid[h->h_rl_a[i]], vb = pose_vid[h->h_rl_b[i]];
+    if (va >= 0 && vb >= 0 && va != vb) mark(6 * (int64_t)std::max(va, vb), 6, 6 * (int64_t)std::min(va, vb), 6);
+  }
+  std::vector<int32_t> trsm_i, upd_ij, back_j;
+  h->h_trsm_ptr.assign(nt + 1, 0); h->h_upd_ptr.assign(nt + 1, 0); h->h_back_ptr.assign(nt + 1, 0);
+  std::vector<int32_t> rows;
+  double flops = 0.0;
+  const double t3 = (double)kTile * kTile * kTile;
+  for (int k = 0; k < nt; ++k) {
+    rows.clear();
+    for (int i = k + 1; i < nt; ++i) if (mask[(size_t)i * nt + k]) rows.push_back(i);
+    for (int i : rows) trsm_i.push_back(i);
+    for (size_t x = 0; x < rows.size(); ++x)
+      for (size_t y = 0; y <= x; ++y) { upd_ij.push_back(rows[x]); upd_ij.push_back(rows[y]); mask[(size_t)rows[x] * nt + rows[y]] = 1; }
+    h->h_trsm_ptr[k + 1] = (int32_t)trsm_i.size();
+    h->h_upd_ptr[k + 1] = (int32_t)(upd_ij.size() / 2);
+    flops += t3 / 3.0 + t3 * rows.size() + 2.0 * t3 * (rows.size() * (rows.size() + 1) / 2);
+  }
+  h->chol_flops = flops;
+  for (int k = 0; k < nt; ++k) {  // backward: tiles (k, j), j < k, non-zero in L
+    for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) back_j.push_back(j);
+    h->h_back_ptr[k + 1] = (int32_t)back_j.size();
+  }
+  std::vector<int32_t> tiles;
+  for (int i = 0; i < nt; ++i) for (int j = 0; j <= i; ++j) if (mask[(size_t)i * nt + j]) { tiles.push_back(i); tiles.push_back(j); }
+  h->ntiles = (int32_t)(tiles.size() / 2);
+
+  // ---- upload ----
+  hipStream_t s = h->stream;
+  h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
+  h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
+  h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
+  h->d_tiles.upload(tiles, s); h->d_trsm_i.upload(trsm_i, s); h->d_upd_ij.upload(upd_ij, s); h->d_back_j.upload(back_j, s);
+  h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
+  h->d_g.resize((size_t)h->m + 1); h->d_scale.resize((size_t)h->m + 1); h->d_lam.resize((size_t)h->m + 1);
+  h->d_S.resize((size_t)nt * nt * kTile * kTile);
+  h->d_Linv.resize((size_t)nt * kTile * kTile);
+  h->d_rhs.resize((size_t)m_pad); h->d_y.resize((size_t)m_pad);
+  h->d_Ci.resize((size_t)6 * L + 1); h->d_u.resize((size_t)3 * L + 1); h->d_scale_l.resize((size_t)3 * L + 1);
+  h->d_Z.resize((size_t)18 * h->n_rp + 1);
+  h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)7 * O + 1);
+  h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
+  h->d_pc.resize((size_t)P + 1); h->d_pc_c.resize((size_t)P + 1);
+  sync(h);  // host vectors above go out of scope
+  h->dirty = false;
+}
+
+void record(obvi_ba_handle* h, int idx) { OBVI_HIP(hipEventRecord(h->ev[idx], h->stream)); }
+
+// One LM step on the device: linearise at the current point, assemble and solve the damped reduced
+// system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
+void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) {
+  hipStream_t s = h->stream;
+  const BlocksDev b = blocks_dev(h);
+  const ReprojDev rp = reproj_dev(h);
+  const SmallFactorsDev sf = small_dev(h);
+  const ReducedDev rd = reduced_dev(h);
+  const PointDev pt = point_dev(h);
+  double* scal = h->d_scal.get();
+  const double fixed = h->h_scal[SC_COST_FIXED];
+  OBVI_HIP(hipMemsetAsync(scal, 0, sizeof(double) * SC_COUNT, s));
+  OBVI_HIP(hipMemcpyAsync(scal + SC_COST_FIXED, &fixed, sizeof(double), hipMemcpyHostToDevice, s));
+  h->d_Hdiag.zero(s); h->d_g.zero(s);
+  record(h, PH_POSE_CACHE);
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->m);
+  h->d_rhs.zero(s);
+  record(h, PH_POINT_PASS);
+  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal);
+  record(h, PH_SMALL);
+  launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
+  record(h, PH_DIAG);
+  launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
+  record(h, PH_SCHUR);
+  if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  record(h, PH_CHOL);
+  if (solve && h->m > 0) launch_cholesky_solve(s, chol_plan(h), rd.S, h->d_Linv.get(), rd.rhs, rd.y, scal);
+  record(h, PH_BACKSUB);
+  if (solve) launch_point_backsub(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), scal);
+  record(h, PH_APPLY);
+  if (solve) {
+    launch_apply_reduced_step(s, b, rd, h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), scal);
+    launch_pose_cache(s, h->P, h->d_pose_c.get(), h->d_pc_c.get());
+  }
+  record(h, PH_COST);
+  if (solve) launch_cost(s, b, rp, sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
+                         h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);
+  record(h, PH_COUNT);
+  OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+  sync(h);
+  for (int p = 0; p < PH_COUNT; ++p) {
+    float ms = 0.f;
+    OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev[p + 1]));
+    h->phase_ms[p] += ms;
+    h->phase_launches[p] += 1;
+  }
+}
+
+double scal_gmax(const obvi_ba_handle* h) { double v; std::memcpy(&v, &h->h_scal[SC_GMAX_BITS], sizeof(v)); return v; }
+
+void copy_current(obvi_ba_handle* h, DevBuf<double>& dp, DevBuf<double>& dl, DevBuf<double>& dobj) {
+  hipStream_t s = h->stream;
+  dp.resize((size_t)6 * h->P + 1); dl.resize((size_t)3 * h->L + 1); dobj.resize((size_t)7 * h->O + 1);
+  if (h->P) OBVI_HIP(hipMemcpyAsync(dp.get(), h->d_pose.get(), sizeof(double) * 6 * h->P, hipMemcpyDeviceToDevice, s));
+  if (h->L) OBVI_HIP(hipMemcpyAsync(dl.get(), h->d_point.get(), sizeof(double) * 3 * h->L, hipMemcpyDeviceToDevice, s));
+  if (h->O) OBVI_HIP(hipMemcpyAsync(dobj.get(), h->d_obj.get(), sizeof(double) * 7 * h->O, hipMemcpyDeviceToDevice, s));
+}
+void restore_from(obvi_ba_handle* h, const DevBuf<double>& dp, const DevBuf<double>& dl, const DevBuf<double>& dobj) {
+  hipStream_t s = h->stream;
+  if (h->P) OBVI_HIP(hipMemcpyAsync(h->d_pose.get(), dp.get(), sizeof(double) * 6 * h->P, hipMemcpyDeviceToDevice, s));
+  if (h->L) OBVI_HIP(hipMemcpyAsync(h->d_point.get(), dl.get(), sizeof(double) * 3 * h->L, hipMemcpyDeviceToDevice, s));
+  if (h->O) OBVI_HIP(hipMemcpyAsync(h->d_obj.get(), dobj.get(), sizeof(double) * 7 * h->O, hipMemcpyDeviceToDevice, s));
+}
+
+bool check_ready(obvi_ba_handle* h) {
+  if (h->h_cams.empty() && (h->n_rp > 0 || h->n_bb > 0)) return false;
+  return true;
+}
+
+template <class T>
+void set_mask(std::vector<uint8_t>& host, DevBuf<uint8_t>& dev, const uint8_t* mask, int64_t n, hipStream_t s, const T* perm_sorted_to_orig) {
+  host.resize(n);
+  for (int64_t i = 0; i < n; ++i) host[i] = mask ? (mask[perm_sorted_to_orig ? perm_sorted_to_orig[i] : i] != 0) : 1;
+  dev.upload(host, s);
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* obvi_ba_version(void) { return "obvi_ba 0.1 (gfx950)"; }
+const char* obvi_ba_last_error(const obvi_ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
+  if (!out) return OBVI_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (options && options->object_block_size != 0 && options->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return OBVI_ERR_NO_DEVICE;
+  const int dev = options ? options->device_id : 0;
+  if (dev < 0 || dev >= count) return OBVI_ERR_NO_DEVICE;
+  obvi_ba_handle* h = new (std::nothrow) obvi_ba_handle();
+  if (!h) return OBVI_ERR_HIP;
+  h->device = dev;
+  try {
+    OBVI_HIP(hipSetDevice(dev));
+    OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * SC_COUNT, hipHostMallocDefault));
+    std::memset(h->h_scal, 0, sizeof(double) * SC_COUNT);
+    h->d_scal.resize(SC_COUNT);
+    for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
+  } catch (const HipError&) {
+    delete h;
+    return OBVI_ERR_HIP;
+  }
+  *out = h;
+  return OBVI_OK;
+}
+
+void obvi_ba_destroy(obvi_ba_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  // DevBuf members free in ~obvi_ba_handle
+  hipStream_t s = h->stream;
+  delete h;
+  if (s) (void)hipStreamDestroy(s);
+}
+
+int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const double* ext) {
+  if (!h || n < 0 || (n > 0 && (!K || !ext))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_cameras: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  h->h_cams.resize(n);
+  for (int i = 0; i < n; ++i) make_cam(K + 4 * i, ext + 7 * i, &h->h_cams[i]);
+  h->d_cams.upload(h->h_cams, h->stream);
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+static int set_blocks(obvi_ba_handle* h, int64_t n, int dim, const double* v, const uint8_t* c, int64_t* count, std::vector<uint8_t>* hc, DevBuf<double>* dv) {
+  if (!h || n < 0 || (n > 0 && !v)) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_blocks: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  *count = n;
+  if (c) hc->assign(c, c + n); else hc->assign(n, 0);
+  dv->resize((size_t)n * dim + 1);
+  if (n) OBVI_HIP(hipMemcpyAsync(dv->get(), v, sizeof(double) * n * dim, hipMemcpyHostToDevice, h->stream));
+  sync(h);
+  h->dirty = true;
+  h->have_snapshot = false;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 6, v, c, h ? &h->P : nullptr, h ? &h->h_pose_const : nullptr, h ? &h->d_pose : nullptr); }
+int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 3, v, c, h ? &h->L : nullptr, h ? &h->h_point_const : nullptr, h ? &h->d_point : nullptr); }
+int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr); }
+
+int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pc, const uint8_t* lc, const uint8_t* oc) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (pc) h->h_pose_const.assign(pc, pc + h->P);
+  if (lc) h->h_point_const.assign(lc, lc + h->L);
+  if (oc) h->h_object_const.assign(oc, oc + h->O);
+  h->dirty = true;
+  return OBVI_OK;
+}
+
+int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz) {
+  if (!h || n != h->L || (n > 0 && !xyz)) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "update_points: size mismatch");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  if (n) OBVI_HIP(hipMemcpyAsync(h->d_point.get(), xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, const uint32_t* point_idx, const uint16_t* cam_idx,
+                       const double* pixel, const double* sigma, double sigma_scalar, double huber) {
+  if (!h || n < 0 || (n > 0 && (!pose_idx || !point_idx || !pixel))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_reproj: bad arguments");
+  if (n >= (int64_t)0xffffffffu) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_reproj: more than 2^32-1 observations");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  for (int64_t i = 0; i < n; ++i) {
+    const int cam = cam_idx ? cam_idx[i] : 0;
+    if (pose_idx[i] >= h->P || point_idx[i] >= h->L || cam >= (int)h->h_cams.size()) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_reproj: index out of range");
+  }
+  // CSC by point: counting sort on the point index, then by pose inside each point
+  std::vector<uint32_t> perm(n), ptr(h->L + 1, 0);
+  for (int64_t i = 0; i < n; ++i) ptr[point_idx[i] + 1]++;
+  for (int64_t l = 0; l < h->L; ++l) ptr[l + 1] += ptr[l];
+  {
+    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
+  }
+  for (int64_t l = 0; l < h->L; ++l)
+    std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], [&](uint32_t x, uint32_t y) { return pose_idx[x] < pose_idx[y] || (pose_idx[x] == pose_idx[y] && x < y); });
+  h->n_rp = n; h->rp_huber = huber;
+  h->h_rp_perm = perm; h->h_point_ptr = ptr;
+  h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
+  std::vector<uint16_t> cam(n);
+  std::vector<double2> pix(n);
+  std::vector<double> sg(n);
+  for (int64_t a = 0; a < n; ++a) {
+    const uint32_t i = perm[a];
+    h->h_rp_inv[i] = (uint32_t)a;
+    h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i]; cam[a] = cam_idx ? cam_idx[i] : 0;
+    pix[a] = make_double2(pixel[2 * (int64_t)i], pixel[2 * (int64_t)i + 1]);
+    sg[a] = sigma ? sigma[i] : sigma_scalar;
+  }
+  hipStream_t s = h->stream;
+  h->d_rp_pose.upload(h->h_rp_pose, s); h->d_rp_point.upload(h->h_rp_point, s); h->d_rp_perm.upload(perm, s); h->d_point_ptr.upload(ptr, s);
+  h->d_rp_cam.upload(cam, s); h->d_rp_pixel.upload(pix, s); h->d_rp_sigma.upload(sg, s); h->d_rp_active.upload(h->h_rp_active, s);
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_bbox(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, const uint32_t* pose_idx, const uint16_t* cam_idx,
+                     const double* corners, const double* cov, double huber, double invalid_err) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !pose_idx || !corners || !cov))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_bbox: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  std::vector<uint16_t> cam(n);
+  std::vector<double> rect(4 * n), si(16 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    cam[i] = cam_idx ? cam_idx[i] : 0;
+    if (obj_idx[i] >= h->O || pose_idx[i] >= h->P || cam[i] >= h->h_cams.size()) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_bbox: index out of range");
+    const DevCam& c = h->h_cams[cam[i]];
+    // bounding_box_factor.cpp:26-39: sqrt_inf = (cov^-1)^(1/2) diag(fx,fx,fy,fy); corners rectified
+    double m4[16];
+    if (!sym_inverse_sqrt(cov + 16 * i, 4, m4)) return fail(h, OBVI_ERR_NUMERICAL, "set_bbox: covariance not SPD");
+    const double sc[4] = {c.fx, c.fx, c.fy, c.fy};
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) si[16 * i + 4 * a + b] = m4[4 * a + b] * sc[b];
+    rect[4 * i] = (corners[4 * i] - c.cx) / c.fx; rect[4 * i + 1] = (corners[4 * i + 1] - c.cx) / c.fx;
+    rect[4 * i + 2] = (corners[4 * i + 2] - c.cy) / c.fy; rect[4 * i + 3] = (corners[4 * i + 3] - c.cy) / c.fy;
+  }
+  h->n_bb = n; h->bb_huber = huber; h->bb_invalid = invalid_err;
+  h->h_bb_obj.assign(obj_idx, obj_idx + n); h->h_bb_pose.assign(pose_idx, pose_idx + n); h->h_bb_active.assign(n, 1);
+  hipStream_t s = h->stream;
+  h->d_bb_obj.upload(h->h_bb_obj, s); h->d_bb_pose.upload(h->h_bb_pose, s); h->d_bb_cam.upload(cam, s);
+  h->d_bb_rect.upload(rect, s); h->d_bb_sqrt_inf.upload(si, s); h->d_bb_active.upload(h->h_bb_active, s);
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, const double* mean3, const double* cov9, double huber) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !mean3 || !cov9))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_shape_priors: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  std::vector<double> si(9 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (obj_idx[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_shape_priors: index out of range");
+    if (!sym_inverse_sqrt(cov9 + 9 * i, 3, &si[9 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_shape_priors: covariance not SPD");
+  }
+  h->n_sp = n; h->sp_huber = huber;
+  h->h_sp_obj.assign(obj_idx, obj_idx + n); h->h_sp_active.assign(n, 1);
+  hipStream_t s = h->stream;
+  h->d_sp_obj.upload(h->h_sp_obj, s); h->d_sp_mean.upload(mean3, 3 * n, s); h->d_sp_sqrt_inf.upload(si, s); h->d_sp_active.upload(h->h_sp_active, s);
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, const double* mean7, const double* cov49, double huber) {
+  if (!h || n < 0 || (n > 0 && (!obj_idx || !mean7 || !cov49))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_ltm_priors: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  std::vector<double> si(49 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (obj_idx[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_ltm_priors: index out of range");
+    if (!sym_inverse_sqrt(cov49 + 49 * i, 7, &si[49 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_ltm_priors: covariance not SPD");
+  }
+  h->n_lt = n; h->lt_huber = huber;
+  h->h_lt_obj.assign(obj_idx, obj_idx + n); h->h_lt_active.assign(n, 1);
+  hipStream_t s = h->stream;
+  h->d_lt_obj.upload(h->h_lt_obj, s); h->d_lt_mean.upload(mean7, 7 * n, s); h->d_lt_sqrt_inf.upload(si, s); h->d_lt_active.upload(h->h_lt_active, s);
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* ia, const uint32_t* ib, const double* t3, const double* aa3,
+                        const double* cov36, double huber) {
+  if (!h || n < 0 || (n > 0 && (!ia || !ib || !t3 || !aa3 || !cov36))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_relpose: bad arguments");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  std::vector<double> R(9 * n), si(36 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (ia[i] >= h->P || ib[i] >= h->P) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_relpose: index out of range");
+    // measured_pose_deviation.orientation_.toRotationMatrix() (relative_pose_factor.cpp:11-12)
+    const double* a = aa3 + 3 * i;
+    const double th = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    double* Ri = &R[9 * i];
+    if (th > 0.0) {
+      const double ux = a[0] / th, uy = a[1] / th, uz = a[2] / th, s = std::sin(th), c = std::cos(th), oc = 1.0 - c;
+      Ri[0] = oc * ux * ux + c;      Ri[1] = oc * ux * uy - s * uz; Ri[2] = oc * ux * uz + s * uy;
+      Ri[3] = oc * ux * uy + s * uz; Ri[4] = oc * uy * uy + c;      Ri[5] = oc * uy * uz - s * ux;
+      Ri[6] = oc * ux * uz - s * uy; Ri[7] = oc * uy * uz + s * ux; Ri[8] = oc * uz * uz + c;
+    } else {
+      for (int k = 0; k < 9; ++k) Ri[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    }
+    if (!sym_inverse_sqrt(cov36 + 36 * i, 6, &si[36 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_relpose: covariance not SPD");
+  }
+  h->n_rl = n; h->rl_huber = huber;
+  h->h_rl_a.assign(ia, ia + n); h->h_rl_b.assign(ib, ib + n); h->h_rl_active.assign(n, 1);
+  hipStream_t s = h->stream;
+  h->d_rl_a.upload(h->h_rl_a, s); h->d_rl_b.upload(h->h_rl_b, s); h->d_rl_t.upload(t3, 3 * n, s); h->d_rl_R.upload(R, s);
+  h->d_rl_sqrt_inf.upload(si, s); h->d_rl_active.upload(h->h_rl_active, s);
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t type, const uint8_t* mask) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: set_mask(h->h_rp_active, h->d_rp_active, mask, h->n_rp, s, h->h_rp_perm.data()); break;
+    case OBVI_FACTOR_BBOX: set_mask<uint32_t>(h->h_bb_active, h->d_bb_active, mask, h->n_bb, s, nullptr); break;
+    case OBVI_FACTOR_SHAPE_PRIOR: set_mask<uint32_t>(h->h_sp_active, h->d_sp_active, mask, h->n_sp, s, nullptr); break;
+    case OBVI_FACTOR_LTM_PRIOR: set_mask<uint32_t>(h->h_lt_active, h->d_lt_active, mask, h->n_lt, s, nullptr); break;
+    case OBVI_FACTOR_REL_POSE: set_mask<uint32_t>(h->h_rl_active, h->d_rl_active, mask, h->n_rl, s, nullptr); break;
+    default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_active_mask: unknown factor type");
+  }
+  sync(h);
+  h->dirty = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int64_t obvi_ba_num_factors(const obvi_ba_handle* h, int32_t type) {
+  if (!h) return -1;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: return h->n_rp; case OBVI_FACTOR_BBOX: return h->n_bb; case OBVI_FACTOR_SHAPE_PRIOR: return h->n_sp;
+    case OBVI_FACTOR_LTM_PRIOR: return h->n_lt; case OBVI_FACTOR_REL_POSE: return h->n_rl; default: return -1;
+  }
+}
+int64_t obvi_ba_num_residuals(const obvi_ba_handle* h) { return h ? 2 * h->n_rp + 4 * h->n_bb + 3 * h->n_sp + 7 * h->n_lt + 6 * h->n_rl : -1; }
+
+int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double* residuals, double* block_sqnorm) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "evaluate: cameras not set");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  prepare(h);
+  hipStream_t s = h->stream;
+  const int64_t nres = obvi_ba_num_residuals(h), nfac = h->n_rp + h->n_bb + h->n_sp + h->n_lt + h->n_rl;
+  h->d_eval_res.resize((size_t)nres + 1); h->d_eval_sq.resize((size_t)nfac + 1);
+  OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_evaluate(s, blocks_dev(h), reproj_dev(h), h->d_rp_perm.get(), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(),
+                  h->d_point.get(), h->d_obj.get(), apply_loss, h->d_eval_res.get(), h->d_eval_sq.get(), h->d_scal.get());
+  double c = 0.0;
+  OBVI_HIP(hipMemcpyAsync(&c, h->d_scal.get() + SC_COST, sizeof(double), hipMemcpyDeviceToHost, s));
+  if (residuals) h->d_eval_res.download(residuals, (size_t)nres, s);
+  if (block_sqnorm) h->d_eval_sq.download(block_sqnorm, (size_t)nfac, s);
+  sync(h);
+  if (cost) *cost = c;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t type, double* r, double* J0, double* J1) {
+  if (!h || !r || !J0) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  prepare(h);
+  hipStream_t s = h->stream;
+  int m, d0, d1; int64_t n;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: m = 2; d0 = 6; d1 = 3; n = h->n_rp; break;
+    case OBVI_FACTOR_BBOX: m = 4; d0 = 7; d1 = 6; n = h->n_bb; break;
+    case OBVI_FACTOR_SHAPE_PRIOR: m = 3; d0 = 7; d1 = 0; n = h->n_sp; break;
+    case OBVI_FACTOR_LTM_PRIOR: m = 7; d0 = 7; d1 = 0; n = h->n_lt; break;
+    case OBVI_FACTOR_REL_POSE: m = 6; d0 = 6; d1 = 6; n = h->n_rl; break;
+    default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_linearize: unknown factor type");
+  }
+  DevBuf<double> dr, dJ0, dJ1;
+  dr.resize((size_t)n * m + 1); dJ0.resize((size_t)n * m * d0 + 1); dJ1.resize((size_t)n * m * d1 + 1);
+  if (type == OBVI_FACTOR_REPROJECTION) {
+    launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+    launch_debug_linearize_reproj(s, reproj_dev(h), h->d_rp_perm.get(), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), dr.get(), dJ0.get(), dJ1.get());
+  } else {
+    launch_debug_linearize_small(s, type, small_dev(h), h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), dr.get(), dJ0.get(), dJ1.get());
+  }
+  dr.download(r, (size_t)n * m, s); dJ0.download(J0, (size_t)n * m * d0, s);
+  if (J1 && d1) dJ1.download(J1, (size_t)n * m * d1, s);
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, double* rhs, int32_t m_cap, int32_t* m_out) {
+  if (!h || !lhs || !rhs) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  prepare(h);
+  if (m_out) *m_out = (int32_t)h->m;
+  if (h->m > m_cap) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_reduced_system: buffer too small");
+  hipStream_t s = h->stream;
+  const BlocksDev b = blocks_dev(h); const ReprojDev rp = reproj_dev(h); const SmallFactorsDev sf = small_dev(h);
+  const ReducedDev rd = reduced_dev(h); const PointDev pt = point_dev(h);
+  OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
+  h->d_Hdiag.zero(s); h->d_g.zero(s); h->d_rhs.zero(s);
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->m);
+  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get());
+  launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
+  launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
+  launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  const int64_t m = h->m, nt = h->nt;
+  std::vector<double> tiles((size_t)nt * nt * kTile * kTile), hr((size_t)nt * kTile);
+  h->d_S.download(tiles.data(), tiles.size(), s); h->d_rhs.download(hr.data(), hr.size(), s);
+  sync(h);
+  for (int64_t i = 0; i < m; ++i) {
+    rhs[i] = hr[i];
+    for (int64_t j = 0; j <= i; ++j) {
+      const double v = tiles[((i / kTile) * nt + (j / kTile)) * (kTile * kTile) + (i % kTile) * kTile + (j % kTile)];
+      lhs[i * m + j] = v; lhs[j * m + i] = v;
+    }
+  }
+  // tiles outside the structural mask were never zeroed: treat them as zero
+  {
+    std::vector<int32_t> tl((size_t)2 * h->ntiles);
+    h->d_tiles.download(tl.data(), tl.size(), s); sync(h);
+    std::vector<uint8_t> mk((size_t)nt * nt, 0);
+    for (int t = 0; t < h->ntiles; ++t) mk[(size_t)tl[2 * t] * nt + tl[2 * t + 1]] = 1;
+    for (int64_t i = 0; i < m; ++i) for (int64_t j = 0; j <= i; ++j) if (!mk[(i / kTile) * nt + (j / kTile)]) { lhs[i * m + j] = 0.0; lhs[j * m + i] = 0.0; }
+  }
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary* sum) {
+  if (!h || !prm || !sum) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "solve: cameras not set");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  const double t_start = wall_s();
+  std::memset(sum, 0, sizeof(*sum));
+  h->iterations.clear();
+  prepare(h);
+  const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
+                         h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
+  hipStream_t s = h->stream;
+
+  // fixed cost: residual blocks with only constant parameter blocks
+  OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_cost(s, blocks_dev(h), reproj_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
+              h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), 1, h->d_scal.get());
+  OBVI_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.get(), sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+  sync(h);
+  const double fixed_cost = h->h_scal[SC_COST_FIXED];
+  sum->fixed_cost = fixed_cost;
+  sum->num_parameters_reduced = (int32_t)h->num_params;
+  sum->num_residuals_reduced = (int32_t)h->num_residuals;
+  sum->reduced_system_size = (int32_t)h->m;
+
+  auto finish = [&](int term, const char* msg) {
+    sum->termination_type = term;
+    std::snprintf(sum->message, sizeof(sum->message), "%s", msg);
+    sum->num_iterations = (int32_t)h->iterations.size();
+    sum->final_cost = sum->initial_cost;  // min over iterations: non-monotonic steps [Ceres-doc solver.cc]
+    for (const auto& it : h->iterations) sum->final_cost = std::min(sum->final_cost, it.cost);
+    sum->is_solution_usable = (term == OBVI_CONVERGENCE || term == OBVI_NO_CONVERGENCE) ? 1 : 0;
+    sum->total_time_in_seconds = wall_s() - t_start;
+    sum->jacobian_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE] - ms0[0]);
+    sum->linear_solver_time_in_seconds = 1e-3 * (h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY] - ms0[1]);
+    sum->residual_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_COST] - ms0[2]);
+  };
+
+  if (h->num_params == 0) {
+    sum->initial_cost = fixed_cost;
+    obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
+    it.cost = fixed_cost; it.step_is_valid = 1; it.step_is_successful = 1;
+    h->iterations.push_back(it);
+    finish(OBVI_CONVERGENCE, "Function tolerance reached. No non-constant parameter blocks found.");
+    return OBVI_OK;
+  }
+
+  // LevenbergMarquardtStrategy / TrustRegionStepEvaluator state
+  double radius = prm->initial_trust_region_radius;
+  const double max_radius = prm->max_trust_region_radius;
+  double decrease_factor = 2.0;
+  const double kMinRelDecrease = 1e-3, kMinRadius = 1e-32;
+  const int kMaxInvalid = 5, max_nonmono = prm->allow_non_monotonic_steps ? 5 : 0;
+  int num_invalid = 0, num_nonmono = 0;
+  double x_cost = 0, x_norm = 0, minimum_cost = 0, current_cost = 0, reference_cost = 0, candidate_cost_ev = 0, acc_ref_model = 0, acc_cand_model = 0;
+  double best_cost = 0;
+  bool have_best = false;
+
+  obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
+  bool pending_accept = false;   // `it` is an accepted step waiting for the gradient of its new point
+  bool first = true;
+  double iter_t0 = wall_s();
+  submit_step(h, radius, true, true);
+
+  // loop-top checks of TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue
+  auto push_and_check = [&](obvi_iteration_summary& rec) -> bool {
+    rec.trust_region_radius = radius;
+    rec.iteration_time_in_seconds = wall_s() - iter_t0;
+    iter_t0 = wall_s();
+    h->iterations.push_back(rec);
+    if (rec.iteration > 0) { if (rec.step_is_successful) sum->num_successful_steps++; else sum->num_unsuccessful_steps++; }
+    if (rec.iteration >= prm->max_num_iterations) { finish(OBVI_NO_CONVERGENCE, "Maximum number of iterations reached."); return false; }
+    if (rec.step_is_successful && rec.gradient_max_norm <= prm->gradient_tolerance) { finish(OBVI_CONVERGENCE, "Gradient tolerance reached."); return false; }
+    if (radius < kMinRadius) { finish(OBVI_CONVERGENCE, "Minimum trust region radius reached."); return false; }
+    return true;
+  };
+
+  for (;;) {
+    const double* sc = h->h_scal;
+    if (first || pending_accept) {
+      // results of the linearisation at the (new) current point complete the pending record
+      x_cost = sc[SC_COST];
+      x_norm = std::sqrt(sc[SC_XSQ]);
+      it.cost = x_cost + fixed_cost;
+      it.gradient_max_norm = scal_gmax(h);
+      it.gradient_norm = std::sqrt(sc[SC_GSQ]);
+      if (first) {
+        sum->initial_cost = it.cost;
+        it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1;
+        minimum_cost = current_cost = reference_cost = candidate_cost_ev = x_cost;
+        best_cost = x_cost;
+      }
+      if (!have_best || x_cost < best_cost) {
+        // the minimum-cost iterate is what Ceres hands back [Ceres-doc trust_region_minimizer.cc]
+        best_cost = x_cost; have_best = true;
+        copy_current(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
+      }
+      first = false; pending_accept = false;
+      if (!push_and_check(it)) break;
+    }
+    const obvi_iteration_summary prev = h->iterations.back();
+    std::memset(&it, 0, sizeof(it));
+    it.iteration = prev.iteration + 1;
+
+    // ---- ComputeTrustRegionStep outcome ----
+    const double model_cost_change = sc[SC_MODEL_CHANGE];
+    const bool finite = sc[SC_CHOL_FAIL] == 0.0 && sc[SC_NONFINITE] == 0.0 && std::isfinite(model_cost_change) && std::isfinite(sc[SC_STEPSQ]);
+    it.step_is_valid = (finite && model_cost_change > 0.0) ? 1 : 0;
+    if (!it.step_is_valid) {
+      if (++num_invalid >= kMaxInvalid) {
+        h->iterations.push_back(it);
+        finish(OBVI_FAILURE, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps");
+        break;
+      }
+      radius /= decrease_factor; decrease_factor *= 2.0;  // StepIsInvalid
+      it.cost = x_cost + fixed_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      if (!push_and_check(it)) break;
+      submit_step(h, radius, false, true);
+      continue;
+    }
+    num_invalid = 0;
+    double cand_cost = sc[SC_COST_CAND];
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    // ParameterToleranceReached
+    it.step_norm = std::sqrt(sc[SC_STEPSQ]);
+    if (it.step_norm <= prm->parameter_tolerance * (x_norm + prm->parameter_tolerance)) { finish(OBVI_CONVERGENCE, "Parameter tolerance reached."); break; }
+    // FunctionToleranceReached
+    it.cost_change = x_cost - cand_cost;
+    if (std::fabs(it.cost_change) <= prm->function_tolerance * x_cost) { finish(OBVI_CONVERGENCE, "Function tolerance reached."); break; }
+    // TrustRegionStepEvaluator::StepQuality
+    {
+      const double rel = (current_cost - cand_cost) / model_cost_change;
+      const double hist = (reference_cost - cand_cost) / (acc_ref_model + model_cost_change);
+      it.relative_decrease = (cand_cost >= std::numeric_limits<double>::max()) ? -std::numeric_limits<double>::max() : std::max(rel, hist);
+    }
+    if (it.relative_decrease > kMinRelDecrease) {
+      // HandleSuccessfulStep: the candidate becomes the current point
+      h->d_pose.swap(h->d_pose_c); h->d_point.swap(h->d_point_c); h->d_obj.swap(h->d_obj_c);
+      it.step_is_successful = 1;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));  // StepAccepted
+      radius = std::min(max_radius, radius);
+      decrease_factor = 2.0;
+      current_cost = cand_cost; acc_cand_model += model_cost_change; acc_ref_model += model_cost_change;
+      if (cand_cost < minimum_cost) { minimum_cost = cand_cost; num_nonmono = 0; candidate_cost_ev = cand_cost; acc_cand_model = 0.0; }
+      else { ++num_nonmono; if (cand_cost > candidate_cost_ev) { candidate_cost_ev = cand_cost; acc_cand_model = 0.0; } }
+      if (num_nonmono == max_nonmono) { reference_cost = candidate_cost_ev; acc_ref_model = acc_cand_model; }
+      pending_accept = true;
+      // gradient (and the next step) at the new point; at the iteration cap only the linearisation is needed
+      submit_step(h, radius, false, it.iteration < prm->max_num_iterations);
+    } else {
+      it.step_is_successful = 0;
+      it.cost = x_cost + fixed_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      radius /= decrease_factor; decrease_factor *= 2.0;  // StepRejected
+      if (!push_and_check(it)) break;
+      submit_step(h, radius, false, true);
+    }
+  }
+  // hand back the minimum-cost iterate
+  if (have_best) restore_from(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap) {
+  if (!h || !out) return 0;
+  const int n = std::min<int>(cap, (int)h->iterations.size());
+  for (int i = 0; i < n; ++i) out[i] = h->iterations[i];
+  return n;
+}
+
+int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
+  if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  const int64_t nfac = h->n_rp + h->n_bb + h->n_sp + h->n_lt + h->n_rl;
+  std::vector<double> sq((size_t)nfac);
+  const int rc = obvi_ba_evaluate(h, 0, nullptr, nullptr, sq.data());
+  if (rc != OBVI_OK) return rc;
+  int64_t off = 0, n = 0;
+  const std::vector<uint8_t>* act = nullptr;
+  switch (type) {
+    case OBVI_FACTOR_REPROJECTION: off = 0; n = h->n_rp; act = &h->h_rp_active; break;
+    case OBVI_FACTOR_BBOX: off = h->n_rp; n = h->n_bb; act = &h->h_bb_active; break;
+    case OBVI_FACTOR_SHAPE_PRIOR: off = h->n_rp + h->n_bb; n = h->n_sp; act = &h->h_sp_active; break;
+    case OBVI_FACTOR_LTM_PRIOR: off = h->n_rp + h->n_bb + h->n_sp; n = h->n_lt; act = &h->h_lt_active; break;
+    case OBVI_FACTOR_REL_POSE: off = h->n_rp + h->n_bb + h->n_sp + h->n_lt; n = h->n_rl; act = &h->h_rl_active; break;
+    default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "select_outliers: unknown factor type");
+  }
+  // offline_problem_runner.h:769-800: std::map keyed by the squared residual (descending); equal
+  // keys collapse, n_outliers = floor(map.size() * fraction), first n entries excluded.
+  std::vector<std::pair<double, int64_t>> v;
+  v.reserve((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const bool a = type == OBVI_FACTOR_REPROJECTION ? (*act)[h->h_rp_inv[i]] != 0 : (*act)[i] != 0;
+    mask_out[i] = a ? 1 : 0;
+    if (a) v.push_back({sq[(size_t)(off + i)], i});
+  }
+  std::sort(v.begin(), v.end(), [](const std::pair<double, int64_t>& x, const std::pair<double, int64_t>& y) { return x.first > y.first || (x.first == y.first && x.second > y.second); });
+  size_t distinct = 0;
+  for (size_t k = 0; k < v.size(); ++k) if (k == 0 || v[k].first != v[k - 1].first) ++distinct;
+  const size_t n_out = (size_t)(distinct * fraction);
+  size_t taken = 0;
+  for (size_t k = 0; k < v.size() && taken < n_out; ++k) if (k == 0 || v[k].first != v[k - 1].first) { mask_out[v[k].second] = 0; ++taken; }
+  if (num_excluded) *num_excluded = (int64_t)n_out;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_snapshot(obvi_ba_handle* h) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  copy_current(h, h->d_pose_s, h->d_point_s, h->d_obj_s);
+  sync(h);
+  h->have_snapshot = true;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+int obvi_ba_restore(obvi_ba_handle* h) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!h->have_snapshot) return fail(h, OBVI_ERR_NOT_READY, "restore: no snapshot");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  restore_from(h, h->d_pose_s, h->d_point_s, h->d_obj_s);
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+static int get_blocks(obvi_ba_handle* h, const DevBuf<double>& d, int64_t n, int dim, double* out) {
+  if (!h || (n > 0 && !out)) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  d.download(out, (size_t)n * dim, h->stream);
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_pose, h ? h->P : 0, 6, out); }
+int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_point, h ? h->L : 0, 3, out); }
+int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_obj, h ? h->O : 0, 7, out); }
+
+int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  h->allreduce = fn; h->allreduce_user = user;
+  return OBVI_OK;
+}
+
+int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms, int64_t* launches, int32_t cap) {
+  if (!h || !names || !total_ms || !launches) return 0;
+  int n = 0, off = 0;
+  for (int p = 0; p < PH_COUNT && n < cap; ++p) {
+    const int len = (int)std::strlen(kPhaseNames[p]);
+    if (off + len + 1 > names_cap) break;
+    std::memcpy(names + off, kPhaseNames[p], len + 1);
+    off += len + 1;
+    total_ms[n] = h->phase_ms[p]; launches[n] = h->phase_launches[p];
+    ++n;
+  }
+  return n;
+}
+
+}  // extern "C"
