@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- global bundle adjustment on MI355X: LM iterations / second.
+
+One "step" = one Levenberg-Marquardt iteration of the global BA (linearisation of every active
+factor, Schur complement, exact reduced solve, back-substitution, trial-point cost) on the
+synthetic problem of BASELINE.json configs[2]: 2 000 keyframes / 200 ellipsoid objects /
+300 000 features (seed 20241008+3).  Inputs are uploaded through the C ABI
+before the timed region starts, so they are resident in HBM.  Tolerances are set to zero in
+the timed solve so exactly K iterations run.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: a monolithic global BA does not shard without exchanging the reduced system
+ -- each rank solves an independent replica (its own seed), no
+data-path collective; value = total LM iterations of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "obvi-slam_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    2: dict(name="local-BA 500 KF / 50k features, reprojection only", P=500, L=50000, O=0, const_poses=5),
+    3: dict(name="global-BA 2000 KF / 200 objects / 300k features", P=2000, L=300000, O=200, const_poses=1),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MATRIX_PEAK_TF = 78.6   # MI355X datasheet FP64 matrix (== FP64 vector) rate; not in the guide's table
+
+
+def solver_params(obvi_ba, iters):
+    # global_ba_iteration_params of config/base7a_2_fallback.json with zero tolerances
+    return obvi_ba.SolverParams(max_num_iterations=iters, allow_non_monotonic_steps=True, function_tolerance=0.0,
+                                gradient_tolerance=0.0, parameter_tolerance=0.0, initial_trust_region_radius=100.0,
+                                max_trust_region_radius=1e4)
+
+
+def cpu_baseline(prob, budget_iters=2):
+    """Oracle (scalar fp64 CPU restatement, 1 thread) on the same problem, bounded to a few LM iterations."""
+    import obvi_ba
+    import synth
+    lib = os.path.join(ROOT, "oracle", "libobvi_oracle.so")
+    if not os.path.exists(lib):
+        return None
+    o = obvi_ba.BundleAdjuster(library=lib, prefix="oracle_")
+    synth.upload(o, prob)
+    t0 = time.time()
+    s = o.solve(solver_params(obvi_ba, budget_iters))
+    dt = time.time() - t0
+    its = max(1, s.num_iterations - 1)
+    return {"value": its / dt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d LM iterations of the same problem (oracle/libobvi_oracle.so, scalar fp64, %.1f s)" % (its, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import obvi_ba
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=20241008 + args.config + 100 * rank, const_poses=cfg["const_poses"])
+    stats = synth.problem_stats(prob)
+    ba = obvi_ba.BundleAdjuster(device_id=local_rank)
+    synth.upload(ba, prob)          # inputs now resident in HBM
+    ba.evaluate(True, False)        # builds the reduced-program bookkeeping / symbolic plan (not timed: the reference times "build" separately)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        ba.solve(solver_params(obvi_ba, args.warmup))
+    k0 = ba.kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    summ = ba.solve(solver_params(obvi_ba, args.steps))
+    barrier()
+    dt = time.perf_counter() - t0
+    k1 = ba.kernel_times()
+    steps_done = summ.num_iterations - 1
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        sd = torch.tensor([steps_done], dtype=torch.float64, device="cuda")
+        dist.all_reduce(sd, op=dist.ReduceOp.MIN)
+        steps_done = int(sd.item())
+
+    if rank == 0:
+        pst = ba.problem_stats()
+        n_r, n_b = pst["reproj_active"], pst["bbox_active"]
+        # per-launch algorithmic bytes of the HBM-bound kernels (SURVEY 8d split of B_step) and flops of the solve
+        alg = {
+            "point_pass": n_r * (32.0 + 144.0),            # read obs, write Z (6x3 fp64)
+            "schur_blocks": n_r * 144.0 + pst["schur_blocks"] * 288.0,
+            "point_backsub": n_r * 144.0,
+            "cost": n_r * 32.0,
+            "small_factors": n_b * (168.0 + 672.0),
+        }
+        phases = {}
+        for name in k1:
+            ms = k1[name][0] - k0.get(name, (0.0, 0))[0]
+            n = k1[name][1] - k0.get(name, (0.0, 0))[1]
+            phases[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
+        dom = max(phases, key=lambda k: phases[k]["ms_total"])
+        avg_s = phases[dom]["ms_avg"] * 1e-3
+        if dom == "cholesky_solve":
+            ach = pst["chol_flops"] / avg_s / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / FP64_MATRIX_PEAK_TF, "traffic": None,
+                    "note": "whole tile-Cholesky phase (potrf+trsm+update+substitution launches) per LM step; flops = structural tile flops"}
+        else:
+            ach = alg.get(dom, 0.0) / avg_s / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        out = {
+            "metric": "global-BA LM iterations/s", "value": world * steps_done / dt, "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "keyframes": stats["P"], "features": stats["L"], "objects": stats["O"],
+                       "reprojection_obs": stats["N_r"], "bbox_obs": stats["N_b"], "reduced_rows": int(pst["reduced_rows"]),
+                       "parallelism": "replicas" if world > 1 else "single", "steps_done": steps_done,
+                       "final_cost": summ.final_cost, "termination": summ.message.decode()},
+            "roofline": roof,
+            "phases_ms_avg": {k: round(v["ms_avg"], 4) for k, v in phases.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

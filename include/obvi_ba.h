@@ -232,6 +232,12 @@ int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t factor_type, double* r, d
  * lhs [m][m] row-major symmetric, rhs [m]; order = variable poses then variable objects. */
 int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, double* rhs, int32_t m_cap,
                                  int32_t* m_out);
+/* structure of the reduced program after the last evaluate/solve, as doubles:
+ * [0] variable poses [1] variable objects [2] eliminated points [3] reduced rows m [4] tiles per dim
+ * [5] Schur 6x6 blocks [6] Schur observation pairs [7] non-zero tiles after fill [8] trsm tile jobs
+ * [9] update tile jobs [10] flops of one tile-Cholesky factorisation [11] active reprojection obs
+ * [12] active bbox obs.  Returns the number of entries written. */
+int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap);
 /* per-kernel device timings of the last solve (ms, HIP events on the handle's stream):
  * names is a NUL-separated list; returns number of entries. */
 int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms,

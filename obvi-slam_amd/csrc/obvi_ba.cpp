@@ -1016,6 +1016,19 @@ int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user) {
   return OBVI_OK;
 }
 
+int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap) {
+  if (!h || !out) return 0;
+  int64_t act_rp = 0, act_bb = 0;
+  for (uint8_t a : h->h_rp_active) act_rp += a != 0;
+  for (uint8_t a : h->h_bb_active) act_bb += a != 0;
+  const double v[13] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m, (double)h->nt, (double)h->nblk, (double)h->npairs,
+                        (double)h->ntiles, h->h_trsm_ptr.empty() ? 0.0 : (double)h->h_trsm_ptr.back(),
+                        h->h_upd_ptr.empty() ? 0.0 : (double)h->h_upd_ptr.back(), h->chol_flops, (double)act_rp, (double)act_bb};
+  const int n = std::min<int>(cap, 13);
+  for (int i = 0; i < n; ++i) out[i] = v[i];
+  return n;
+}
+
 int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms, int64_t* launches, int32_t cap) {
   if (!h || !names || !total_ms || !launches) return 0;
   int n = 0, off = 0;

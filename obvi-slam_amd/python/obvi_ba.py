@@ -287,6 +287,13 @@ class BundleAdjuster:
         mm = m.value
         return lhs.ravel()[:mm * mm].reshape(mm, mm).copy(), rhs[:mm].copy()
 
+    def problem_stats(self):
+        buf = (C.c_double * 16)()
+        n = self._fn("ba_get_problem_stats")(self._h, buf, C.c_int32(16))
+        names = ["poses_var", "objects_var", "points_var", "reduced_rows", "tiles_per_dim", "schur_blocks", "schur_pairs",
+                 "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active"]
+        return {names[i]: buf[i] for i in range(n)}
+
     def kernel_times(self, cap=64):
         names = C.create_string_buffer(4096)
         ms = (C.c_double * cap)()
