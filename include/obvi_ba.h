@@ -236,7 +236,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
  * [0] variable poses [1] variable objects [2] eliminated points [3] reduced rows m [4] tiles per dim
  * [5] Schur 6x6 blocks [6] Schur observation pairs [7] non-zero tiles after fill [8] trsm tile jobs
  * [9] update tile jobs [10] flops of one tile-Cholesky factorisation [11] active reprojection obs
- * [12] active bbox obs.  Returns the number of entries written. */
+ * [12] active bbox obs [13] levels of the tile elimination tree.  Returns the number of entries written. */
 int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap);
 /* per-kernel device timings of the last solve (ms, HIP events on the handle's stream):
  * names is a NUL-separated list; returns number of entries. */

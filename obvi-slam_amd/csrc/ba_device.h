@@ -45,7 +45,8 @@ struct ReprojDev {          // observations sorted by (point, pose): CSC by poin
 struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   int64_t P, L, O;
   int64_t nPv, nOv;         // variable+used poses / objects
-  int64_t m;                // 6 nPv + 7 nOv
+  int64_t obj_row0;         // first reduced row of the object blocks (6 nPv rounded up to a tile boundary)
+  int64_t m;                // obj_row0 + 7 nOv
   const int32_t* pose_vid;  // [P]  reduced index or -1
   const int32_t* obj_vid;   // [O]
   const uint8_t* point_var; // [L]
@@ -65,7 +66,7 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
 };
 
 struct ReducedDev {         // accumulators of the reduced system
-  double* Hdiag;            // pose v: 36 doubles at 36 v; object w: 49 doubles at 36 nPv + 49 w (row-major, full)
+  double* Hdiag;            // pose v: 36 doubles at 36 v; object w: 49 doubles at 36 nPv + 49 w (row-major, lower part used)
   double* g;                // [m]   gradient J^T r
   double* scale;            // [m]   Jacobi scaling (fixed at iteration 0)
   double* lam;              // [m]   LM damping of the unscaled normal equations
@@ -115,18 +116,28 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
 void launch_fill(hipStream_t s, double* p, int64_t n, double v);
 
 // ---- tile Cholesky (chol_kernels.hip) --------------------------------------------------
-struct CholPlan {           // symbolic factorisation at tile granularity (host-built, device-resident lists)
+// Symbolic factorisation at tile granularity, level-scheduled: tile columns in one level of the
+// tile elimination tree do not depend on each other and are processed by the same launches.
+// *_ptr arrays indexed by level live on the host (they size the launches); the rest is on the device.
+struct CholPlan {
   int32_t nt;
-  // per step k: tiles i > k with L(i,k) != 0  -> trsm jobs; pairs (i >= j > k) -> update jobs
-  const int32_t* trsm_ptr;  // [nt+1] (host)
-  const int32_t* trsm_i;    // device
-  const int32_t* upd_ptr;   // [nt+1] (host)
-  const int32_t* upd_ij;    // device, 2 per job
-  // backward substitution: per step k, tiles j < k with L(k,j) != 0
-  const int32_t* back_ptr;  // [nt+1] (host)
-  const int32_t* back_j;    // device
+  int32_t nlevels;
+  const int32_t* lvl_k_ptr;   // host [nlevels+1]   tile columns of each level
+  const int32_t* lvl_k;       // device
+  const int32_t* trsm_ptr;    // host [nlevels+1]   trsm jobs (i,k), k in the level
+  const int32_t* trsm_ik;     // device, 2 per job
+  const int32_t* upd_ptr;     // host [nlevels+1]   update jobs: one per target tile (i,j) and level
+  const int32_t* upd_ij;      // device, 2 per job
+  const int32_t* upd_kptr;    // device [jobs+1]    the level's columns k contributing to the target
+  const int32_t* upd_k;       // device
+  const int32_t* rh_ptr;      // host [nlevels+1]   right-hand-side jobs: one per target tile row i and level
+  const int32_t* rh_i;        // device
+  const int32_t* rh_kptr;     // device [jobs+1]
+  const int32_t* rh_k;        // device
+  const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
+  const int32_t* col_i;       // device
 };
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t m);
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t pad0a, int64_t pad0b, int64_t pad1);
 void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* scal);
 
 }  // namespace obvi

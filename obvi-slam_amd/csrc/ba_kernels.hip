@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf
       double rho0, w;
       huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
       cost = 0.5 * rho0;
-      const int64_t orow = 6 * b.nPv + 7 * (int64_t)ov, prow = 6 * (int64_t)pv;
+      const int64_t orow = b.obj_row0 + 7 * (int64_t)ov, prow = 6 * (int64_t)pv;
       if (ov >= 0) add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + orow, 7, Je, r, 4, w);
       if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + prow, 6, Jp, r, 4, w);
       if (ov >= 0 && pv >= 0) {
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFact
         double rho0, w;
         huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + b.obj_row0 + 7 * (int64_t)ov, 7, J, r, 3, w);
       }
     }
   } else if (t < sf.n_sp + sf.n_lt) {
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFact
         double rho0, w;
         huber_eval(s, sf.lt_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + b.obj_row0 + 7 * (int64_t)ov, 7, J, r, 7, w);
       }
     }
   }
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
     if (vid >= 0) {
       const int d = is_pose ? 6 : 7;
-      const int64_t row = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;
+      const int64_t row = is_pose ? 6 * (int64_t)vid : b.obj_row0 + 7 * (int64_t)vid;
       const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
       const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
       for (int k = 0; k < d; ++k) {
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
     const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
     double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
-    const int64_t row = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;
+    const int64_t row = is_pose ? 6 * (int64_t)vid : b.obj_row0 + 7 * (int64_t)vid;
     for (int k = 0; k < d; ++k) {
       double v = x[k];
       if (vid >= 0) {

@@ -1,14 +1,16 @@
 // chol_kernels.hip -- K5: exact solve of the reduced camera+object system S y = b by a
-// right-looking tile Cholesky (S = L L^T, 64x64 fp64 tiles) that only visits tiles which are
-// structurally non-zero after symbolic fill (ba_device.h: CholPlan).  This is the role Ceres'
-// sparse Cholesky of the Schur complement plays behind SPARSE_SCHUR
-// (object_pose_graph_optimizer.h:665) [Ceres-doc]; the elimination order (poses in frame
-// order, objects last) keeps the pose part banded and the object part a dense border.
+// level-scheduled tile Cholesky (S = L L^T, 64x64 fp64 tiles).  Only tiles that are structurally
+// non-zero after symbolic fill are visited, and tile columns that do not depend on each other
+// (same level of the tile elimination tree) are processed by the same launch.  This is the role
+// Ceres' sparse Cholesky of the Schur complement plays behind SPARSE_SCHUR
+// (object_pose_graph_optimizer.h:665) [Ceres-doc]; because the factorisation is exact the
+// elimination order (obvi_ba.cpp: nested dissection of the pose chain, objects last) changes the
+// result only by round-off.
 //
-// Per step k:  potrf(k)   L_kk, L_kk^-1, z_k = L_kk^-1 b_k             (1 workgroup)
-//              trsm(k)    L_ik = S_ik L_kk^-T ; b_i -= L_ik z_k        (1 workgroup per tile)
-//              update(k)  S_ij -= L_ik L_jk^T                          (1 workgroup per tile pair)
-// then backward: y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i), right-looking over k descending.
+// Per level:  potrf   L_kk, L_kk^-1, z_k = L_kk^-1 b_k                      (1 workgroup per k)
+//             trsm    L_ik = S_ik L_kk^-T                                   (1 workgroup per tile)
+//             update  S_ij -= sum_k L_ik L_jk^T ; b_i -= sum_k L_ik z_k     (1 workgroup per target)
+// then backward over levels descending: y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i).
 #include "ba_device.h"
 
 namespace obvi {
@@ -20,78 +22,177 @@ constexpr int kThreads = 256;
 
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
-__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int64_t m) {
+// zero the structurally non-zero tiles; identity on padding rows (rows in [pad0a, pad0b) and >= pad1)
+__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int64_t pad0a, int64_t pad0b, int64_t pad1) {
   const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
   double* t = tile_ptr(S, nt, ti, tj);
   for (int e = threadIdx.x; e < T * T; e += kThreads) {
     double v = 0.0;
-    if (ti == tj) { const int r = e / T, c = e % T; if (r == c && (int64_t)ti * T + r >= m) v = 1.0; }  // identity on padding rows
+    if (ti == tj) {
+      const int r = e / T, c = e % T;
+      const int64_t row = (int64_t)ti * T + r;
+      if (r == c && ((row >= pad0a && row < pad0b) || row >= pad1)) v = 1.0;
+    }
     t[e] = v;
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
-  __shared__ double A[T * LD];
-  __shared__ double B[T * LD];
+// ---------------------------------------------------------------------------------------
+// potrf of one 64x64 tile.  256 threads as a 16x16 grid, thread (ty,tx) owns the 4x4 block
+// (rows 4ty.., cols 4tx..) in registers.  Right-looking over 16 panels of 4 columns; then
+// L^-1 by a right-looking blocked forward substitution on the identity (same structure).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
+  __shared__ double Lsh[T * LD];       // L (lower), later L^-1
+  __shared__ double Dsh[16 * 16];      // inverse of the 16 diagonal 4x4 blocks of L
+  __shared__ double Wsh[16 * 16];      // row-block r of L^-1 during the inverse phase
   __shared__ double zsh[T];
+  const int k = klist[blockIdx.x];
   double* tile = tile_ptr(S, nt, k, k);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = tile[e]; }
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[i][j] = tile[(4 * ty + i) * T + 4 * tx + j];
   if (tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
-  bool bad = false;
-  for (int j = 0; j < T; ++j) {
-    __syncthreads();
-    double d = A[j * LD + j];
-    if (!(d > 0.0)) { bad = true; d = 1.0; }
-    const double sq = sqrt(d), inv = 1.0 / sq;
-    __syncthreads();
-    if (tid < T) {
-      if (tid > j) A[tid * LD + j] *= inv;
-      else if (tid == j) A[j * LD + j] = sq;
+  if (ty < tx) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * tx + j] = 0.0;
+  }
+  double bad = 0.0;
+  for (int kb = 0; kb < 16; ++kb) {
+    if (ty == kb && tx == kb) {
+      // 4x4 Cholesky in registers + its inverse
+      double p;
+      p = a[0][0]; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
+      const double l00 = sqrt(p), i00 = 1.0 / l00;
+      const double l10 = a[1][0] * i00, l20 = a[2][0] * i00, l30 = a[3][0] * i00;
+      p = a[1][1] - l10 * l10; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
+      const double l11 = sqrt(p), i11 = 1.0 / l11;
+      const double l21 = (a[2][1] - l20 * l10) * i11, l31 = (a[3][1] - l30 * l10) * i11;
+      p = a[2][2] - l20 * l20 - l21 * l21; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
+      const double l22 = sqrt(p), i22 = 1.0 / l22;
+      const double l32 = (a[3][2] - l30 * l20 - l31 * l21) * i22;
+      p = a[3][3] - l30 * l30 - l31 * l31 - l32 * l32; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
+      const double l33 = sqrt(p), i33 = 1.0 / l33;
+      a[0][0] = l00; a[0][1] = 0; a[0][2] = 0; a[0][3] = 0;
+      a[1][0] = l10; a[1][1] = l11; a[1][2] = 0; a[1][3] = 0;
+      a[2][0] = l20; a[2][1] = l21; a[2][2] = l22; a[2][3] = 0;
+      a[3][0] = l30; a[3][1] = l31; a[3][2] = l32; a[3][3] = l33;
+      const double d10 = -l10 * i00 * i11, d21 = -l21 * i11 * i22, d32 = -l32 * i22 * i33;
+      const double d20 = -(l20 * i00 + l21 * d10) * i22, d31 = -(l31 * i11 + l32 * d21) * i33;
+      const double d30 = -(l30 * i00 + l31 * d10 + l32 * d20) * i33;
+      double* D = Dsh + 16 * kb;
+      D[0] = i00; D[1] = 0; D[2] = 0; D[3] = 0;
+      D[4] = d10; D[5] = i11; D[6] = 0; D[7] = 0;
+      D[8] = d20; D[9] = d21; D[10] = i22; D[11] = 0;
+      D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i33;
     }
     __syncthreads();
-    // trailing update of the lower triangle: (r, c) with j < c <= r
-    const int nrem = T - 1 - j;
-    for (int e = tid; e < nrem * nrem; e += kThreads) {
-      const int r = j + 1 + e / nrem, c = j + 1 + e % nrem;
-      if (c <= r) A[r * LD + c] -= A[r * LD + j] * A[c * LD + j];
+    if (tx == kb && ty >= kb) {
+      if (ty > kb) {
+        // X = A_blk * D^T  (D = inverse of the diagonal block's L)
+        const double* D = Dsh + 16 * kb;
+        double x[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t <= j; ++t) s += a[i][t] * D[4 * j + t];
+            x[i][j] = s;
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[i][j] = x[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * kb + j] = a[i][j];
+    }
+    __syncthreads();
+    if (tx > kb && ty >= tx) {
+      double pr[4][4], pc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { pr[i][t] = Lsh[(4 * ty + i) * LD + 4 * kb + t]; pc[i][t] = Lsh[(4 * tx + i) * LD + 4 * kb + t]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i][j] -= pr[i][0] * pc[j][0] + pr[i][1] * pc[j][1] + pr[i][2] * pc[j][2] + pr[i][3] * pc[j][3];
     }
   }
-  __syncthreads();
-  if (bad && tid == 0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
-  // B = L^-1 (lower): thread c solves L x = e_c
-  for (int e = tid; e < T * LD; e += kThreads) B[e] = 0.0;
-  __syncthreads();
-  if (tid < T) {
-    const int c = tid;
-    for (int i = c; i < T; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int t = c; t < i; ++t) s -= A[i * LD + t] * B[t * LD + c];
-      B[i * LD + c] = s / A[i * LD + i];
+  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  // store L (zeros above the diagonal)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[(4 * ty + i) * T + 4 * tx + j] = (ty >= tx) ? a[i][j] : 0.0;
+  // ---- W = L^-1: acc starts as the identity, row-block r is finished at step r ----
+  double w[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
+  for (int r = 0; r < 16; ++r) {
+    __syncthreads();   // Wsh free (previous step's readers done); Lsh complete on the first pass
+    if (ty == r && tx <= r) {
+      const double* D = Dsh + 16 * r;
+      double x[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t <= i; ++t) s += D[4 * i + t] * w[t][j];
+          x[i][j] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[i][j] = x[i][j]; Wsh[16 * tx + 4 * i + j] = x[i][j]; }
+    }
+    __syncthreads();
+    if (ty > r && tx <= r) {
+      const double* Wr = Wsh + 16 * tx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double l0 = Lsh[(4 * ty + i) * LD + 4 * r], l1 = Lsh[(4 * ty + i) * LD + 4 * r + 1], l2 = Lsh[(4 * ty + i) * LD + 4 * r + 2], l3 = Lsh[(4 * ty + i) * LD + 4 * r + 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[i][j] -= l0 * Wr[j] + l1 * Wr[4 + j] + l2 * Wr[8 + j] + l3 * Wr[12 + j];
+      }
     }
   }
   __syncthreads();
   double* Li = Linv_all + (int64_t)k * (T * T);
-  for (int e = tid; e < T * T; e += kThreads) {
-    const int r = e / T, c = e % T;
-    tile[e] = (c <= r) ? A[r * LD + c] : 0.0;
-    Li[e] = B[r * LD + c];
-  }
-  // z_k = L^-1 b_k
-  if (tid < T) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double v = (ty >= tx) ? w[i][j] : 0.0;
+      Li[(4 * ty + i) * T + 4 * tx + j] = v;
+      Lsh[(4 * ty + i) * LD + 4 * tx + j] = v;
+    }
+  __syncthreads();
+  if (tid < T) {   // z_k = L^-1 b_k
     double s = 0.0;
-    for (int c = 0; c <= tid; ++c) s += B[tid * LD + c] * zsh[c];
+    for (int c = 0; c <= tid; ++c) s += Lsh[tid * LD + c] * zsh[c];
     rhs[(int64_t)k * T + tid] = s;
   }
 }
 
-// out[r][c] = sum_t A[r][t] * B[c][t]   (both operands staged in LDS, 4x4 outputs per thread)
-__device__ __forceinline__ void tile_abt(const double* A, const double* B, double acc[4][4]) {
+// acc[r][c] (+)= sum_t A[r][t] * B[c][t]   (both operands staged in LDS, 4x4 outputs per thread)
+__device__ __forceinline__ void tile_abt_acc(const double* A, const double* B, double acc[4][4]) {
   const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 8
   for (int t = 0; t < T; ++t) {
     double a[4], b[4];
 #pragma unroll
@@ -103,105 +204,119 @@ __device__ __forceinline__ void tile_abt(const double* A, const double* B, doubl
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, int k, const int32_t* __restrict__ rows, const double* __restrict__ Linv_all, double* rhs) {
+__global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int32_t* __restrict__ jobs, const double* __restrict__ Linv_all) {
   __shared__ double A[T * LD];
   __shared__ double B[T * LD];
-  __shared__ double zsh[T];
-  const int i = rows[blockIdx.x];
+  const int i = jobs[2 * blockIdx.x], k = jobs[2 * blockIdx.x + 1];
   double* tile = tile_ptr(S, nt, i, k);
   const double* Li = Linv_all + (int64_t)k * (T * T);
   const int tid = threadIdx.x;
   for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = tile[e]; B[r * LD + c] = Li[e]; }
-  if (tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
   __syncthreads();
-  double acc[4][4];
-  tile_abt(A, B, acc);   // X = S_ik * Linv^T
-  __syncthreads();
+  double acc[4][4] = {};
+  tile_abt_acc(A, B, acc);   // X = S_ik * Linv^T
   const int ty = tid / 16, tx = tid % 16;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { A[(ty * 4 + a) * LD + tx * 4 + b] = acc[a][b]; tile[(ty * 4 + a) * T + tx * 4 + b] = acc[a][b]; }
-  __syncthreads();
-  if (tid < T) {
-    double s = 0.0;
-    for (int c = 0; c < T; ++c) s += A[tid * LD + c] * zsh[c];
-    rhs[(int64_t)i * T + tid] -= s;
-  }
+    for (int b = 0; b < 4; ++b) tile[(ty * 4 + a) * T + tx * 4 + b] = acc[a][b];
 }
 
-__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int k, const int32_t* __restrict__ jobs) {
+// job g < n_upd: tile target (i,j): S_ij -= sum_{k in list} L_ik L_jk^T
+// job g >= n_upd: rhs target i:     b_i  -= sum_{k in list} L_ik z_k
+__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_upd, const int32_t* __restrict__ upd_ij, const int32_t* __restrict__ upd_kptr,
+                                                    const int32_t* __restrict__ upd_k, const int32_t* __restrict__ rh_i, const int32_t* __restrict__ rh_kptr,
+                                                    const int32_t* __restrict__ rh_k, double* rhs) {
   __shared__ double A[T * LD];
   __shared__ double B[T * LD];
-  const int i = jobs[2 * blockIdx.x], j = jobs[2 * blockIdx.x + 1];
-  const double* Xi = tile_ptr(S, nt, i, k);
-  const double* Xj = tile_ptr(S, nt, j, k);
-  double* C = tile_ptr(S, nt, i, j);
   const int tid = threadIdx.x;
-  for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = Xi[e]; B[r * LD + c] = Xj[e]; }
-  __syncthreads();
-  double acc[4][4];
-  tile_abt(A, B, acc);
-  const int ty = tid / 16, tx = tid % 16;
+  const int g = blockIdx.x;
+  if (g < n_upd) {
+    const int i = upd_ij[2 * g], j = upd_ij[2 * g + 1];
+    double acc[4][4] = {};
+    for (int q = upd_kptr[g]; q < upd_kptr[g + 1]; ++q) {
+      const int k = upd_k[q];
+      const double* Xi = tile_ptr(S, nt, i, k);
+      const double* Xj = tile_ptr(S, nt, j, k);
+      __syncthreads();
+      for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = Xi[e]; B[r * LD + c] = Xj[e]; }
+      __syncthreads();
+      tile_abt_acc(A, B, acc);
+    }
+    double* C = tile_ptr(S, nt, i, j);
+    const int ty = tid / 16, tx = tid % 16;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) C[(ty * 4 + a) * T + tx * 4 + b] -= acc[a][b];
+      for (int b = 0; b < 4; ++b) C[(ty * 4 + a) * T + tx * 4 + b] -= acc[a][b];
+  } else {
+    const int h = g - n_upd;
+    const int i = rh_i[h];
+    // thread (r = tid/4, part = tid%4): 16 columns each
+    const int r = tid >> 2, part = tid & 3;
+    double s = 0.0;
+    for (int q = rh_kptr[h]; q < rh_kptr[h + 1]; ++q) {
+      const int k = rh_k[q];
+      const double* X = tile_ptr(S, nt, i, k) + r * T + part * 16;
+      const double* z = rhs + (int64_t)k * T + part * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s += X[c] * z[c];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) rhs[(int64_t)i * T + r] -= s;
+  }
 }
 
-// backward step k: every workgroup recomputes y_k = L_kk^-T z_k (64x64 mat-vec), workgroup g < n
-// applies z_j -= L_kj^T y_k for its tile j, the last workgroup stores y_k.
-__global__ void __launch_bounds__(kThreads) k_backward(const double* S, int nt, int k, const int32_t* __restrict__ cols, int n, const double* __restrict__ Linv_all,
-                                                      double* rhs, double* y) {
-  __shared__ double ysh[T];
+// backward, one workgroup per tile column k of a level:
+//   y_k = L_kk^-T (z_k - sum_{i in col(k)} L_ik^T y_i)
+__global__ void __launch_bounds__(kThreads) k_backward(const double* S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ col_ptr,
+                                                      const int32_t* __restrict__ col_i, const double* __restrict__ Linv_all, const double* rhs, double* y) {
   __shared__ double part[4][T];
-  const int tid = threadIdx.x;
+  __shared__ double tsh[T];
+  const int k = klist[blockIdx.x];
+  const int tid = threadIdx.x, c = tid % T, q = tid / T;
+  double s = 0.0;
+  for (int e = col_ptr[k]; e < col_ptr[k + 1]; ++e) {
+    const int i = col_i[e];
+    const double* X = tile_ptr(const_cast<double*>(S), nt, i, k);
+    const double* yi = y + (int64_t)i * T;
+    for (int r = q * 16; r < q * 16 + 16; ++r) s += X[r * T + c] * yi[r];
+  }
+  part[q][c] = s;
+  __syncthreads();
+  if (tid < T) tsh[tid] = rhs[(int64_t)k * T + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+  __syncthreads();
   const double* Li = Linv_all + (int64_t)k * (T * T);
-  {
-    // y[c] = sum_{i>=c} Linv[i][c] z[i] ; 4 row-slices of 16 rows
-    const int c = tid % T, q = tid / T;
-    double s = 0.0;
-    for (int i = q * 16; i < q * 16 + 16; ++i) if (i >= c) s += Li[i * T + c] * rhs[(int64_t)k * T + i];
-    part[q][c] = s;
-  }
+  s = 0.0;
+  for (int i = q * 16; i < q * 16 + 16; ++i) if (i >= c) s += Li[i * T + c] * tsh[i];
   __syncthreads();
-  if (tid < T) ysh[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  part[q][c] = s;
   __syncthreads();
-  if ((int)blockIdx.x == n) {
-    if (tid < T) y[(int64_t)k * T + tid] = ysh[tid];
-    return;
-  }
-  const int j = cols[blockIdx.x];
-  const double* X = tile_ptr(const_cast<double*>(S), nt, k, j);
-  {
-    const int c = tid % T, q = tid / T;
-    double s = 0.0;
-    for (int r = q * 16; r < q * 16 + 16; ++r) s += X[r * T + c] * ysh[r];
-    __syncthreads();
-    part[q][c] = s;
-  }
-  __syncthreads();
-  if (tid < T) rhs[(int64_t)j * T + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  if (tid < T) y[(int64_t)k * T + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
 }  // namespace
 
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t m) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, m);
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t pad0a, int64_t pad0b, int64_t pad1) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, pad0a, pad0b, pad1);
 }
 
-void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* scal) {
-  const int nt = plan.nt;
-  for (int k = 0; k < nt; ++k) {
-    hipLaunchKernelGGL(k_potrf, dim3(1), dim3(kThreads), 0, s, S, nt, k, Linv, rhs, scal);
-    const int ntr = plan.trsm_ptr[k + 1] - plan.trsm_ptr[k];
-    if (ntr > 0) hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, k, plan.trsm_i + plan.trsm_ptr[k], Linv, rhs);
-    const int nup = plan.upd_ptr[k + 1] - plan.upd_ptr[k];
-    if (nup > 0) hipLaunchKernelGGL(k_update, dim3(nup), dim3(kThreads), 0, s, S, nt, k, plan.upd_ij + 2 * (int64_t)plan.upd_ptr[k]);
+void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* Linv, double* rhs, double* y, double* scal) {
+  const int nt = p.nt;
+  for (int l = 0; l < p.nlevels; ++l) {
+    const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
+    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
+    const int ntr = p.trsm_ptr[l + 1] - p.trsm_ptr[l];
+    if (ntr > 0) hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv);
+    const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
+    if (nup + nrh > 0)
+      hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k,
+                         p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
   }
-  for (int k = nt - 1; k >= 0; --k) {
-    const int nb = plan.back_ptr[k + 1] - plan.back_ptr[k];
-    hipLaunchKernelGGL(k_backward, dim3(nb + 1), dim3(kThreads), 0, s, S, nt, k, plan.back_j + plan.back_ptr[k], nb, Linv, rhs, y);
+  for (int l = p.nlevels - 1; l >= 0; --l) {
+    const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
+    hipLaunchKernelGGL(k_backward, dim3(npk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], p.col_ptr, p.col_i, Linv, rhs, y);
   }
 }
 

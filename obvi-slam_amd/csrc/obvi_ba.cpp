@@ -77,18 +77,21 @@ struct obvi_ba_handle {
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b;
-  DevBuf<int32_t> d_tiles, d_trsm_i, d_upd_ij, d_back_j;
+  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
   double* h_scal = nullptr;  // pinned
 
   // ---- reduced-program bookkeeping (prepare()) ----
   bool dirty = true;
-  int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, num_params = 0, num_residuals = 0;
+  int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, obj_row0 = 0, num_params = 0, num_residuals = 0;
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
-  std::vector<int32_t> h_trsm_ptr, h_upd_ptr, h_back_ptr;
+  int32_t nlevels = 0;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr;
+  std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
   int32_t ntiles = 0;
+  int64_t n_trsm_jobs = 0, n_upd_products = 0;
   double chol_flops = 0.0;
 
   // ---- last solve ----
@@ -140,7 +143,7 @@ void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
 
 BlocksDev blocks_dev(const obvi_ba_handle* h) {
   BlocksDev b;
-  b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.m = h->m;
+  b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.obj_row0 = h->obj_row0; b.m = h->m;
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
   return b;
 }
@@ -177,8 +180,12 @@ PointDev point_dev(const obvi_ba_handle* h) {
 }
 CholPlan chol_plan(const obvi_ba_handle* h) {
   CholPlan c;
-  c.nt = h->nt; c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_i = h->d_trsm_i.get(); c.upd_ptr = h->h_upd_ptr.data();
-  c.upd_ij = h->d_upd_ij.get(); c.back_ptr = h->h_back_ptr.data(); c.back_j = h->d_back_j.get();
+  c.nt = h->nt; c.nlevels = h->nlevels;
+  c.lvl_k_ptr = h->h_lvl_k_ptr.data(); c.lvl_k = h->d_lvl_k.get();
+  c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
+  c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
+  c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
+  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
   return c;
 }
 
@@ -222,11 +229,72 @@ void prepare(obvi_ba_handle* h) {
   std::vector<int32_t> pose_vid(P, -1), obj_vid(O, -1);
   std::vector<uint8_t> point_var(L, 0);
   h->nPv = h->nOv = h->nLv = 0;
-  for (int64_t p = 0; p < P; ++p) if (!h->h_pose_const[p] && pose_used[p]) pose_vid[p] = (int32_t)h->nPv++;
+  std::vector<int32_t> nat(P, -1);     // rank among the variable poses in pose-index (frame) order
+  for (int64_t p = 0; p < P; ++p) if (!h->h_pose_const[p] && pose_used[p]) nat[p] = (int32_t)h->nPv++;
   for (int64_t o = 0; o < O; ++o) if (!h->h_object_const[o] && obj_used[o]) obj_vid[o] = (int32_t)h->nOv++;
   for (int64_t l = 0; l < L; ++l) if (!h->h_point_const[l] && point_used[l]) { point_var[l] = 1; h->nLv++; }
-  h->m = 6 * h->nPv + 7 * h->nOv;
-  h->num_params = h->m + 3 * h->nLv;
+  const int64_t nPv = h->nPv;
+
+  // ---- elimination order of the poses: nested dissection of the frame chain.  reach[f] = largest
+  //      frame rank f couples to through a shared point or an odometry factor; a separator
+  //      [s0, s1) with s1 > reach of everything left of s0 decouples the two sides.  Cut positions
+  //      are multiples of 32 poses (= 3 tiles) so tree nodes never share a tile.
+  {
+    std::vector<int32_t> reach(nPv);
+    for (int64_t f = 0; f < nPv; ++f) reach[f] = (int32_t)f;
+    for (int64_t l = 0; l < L; ++l) {
+      if (!point_var[l]) continue;
+      int32_t lo = INT32_MAX, hi = -1;
+      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
+        if (!h->h_rp_active[a]) continue;
+        const int32_t f = nat[h->h_rp_pose[a]];
+        if (f >= 0) { lo = std::min(lo, f); hi = std::max(hi, f); }
+      }
+      if (hi < 0) continue;
+      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {   // every frame of the track couples to its last one
+        if (!h->h_rp_active[a]) continue;
+        const int32_t f = nat[h->h_rp_pose[a]];
+        if (f >= 0) reach[f] = std::max(reach[f], hi);
+      }
+      (void)lo;
+    }
+    for (int64_t i = 0; i < h->n_rl; ++i) {
+      if (!h->h_rl_active[i]) continue;
+      const int32_t fa = nat[h->h_rl_a[i]], fb = nat[h->h_rl_b[i]];
+      if (fa >= 0 && fb >= 0) reach[std::min(fa, fb)] = std::max(reach[std::min(fa, fb)], std::max(fa, fb));
+    }
+    std::vector<int32_t> order; order.reserve(nPv);
+    const int32_t G = 32, kLeaf = 160;
+    struct Rng { int32_t lo, hi; bool emit; };
+    std::vector<Rng> stack;
+    stack.push_back({0, (int32_t)nPv, false});
+    while (!stack.empty()) {
+      const Rng r = stack.back(); stack.pop_back();
+      if (r.emit || r.hi - r.lo <= kLeaf) { for (int32_t f = r.lo; f < r.hi; ++f) order.push_back(f); continue; }
+      int32_t s0 = ((r.lo + r.hi) / 2 / G) * G;
+      if (s0 <= r.lo) s0 = r.lo + G;
+      int32_t far = s0 - 1;
+      for (int32_t f = r.lo; f < s0; ++f) far = std::max(far, reach[f]);
+      int32_t s1 = std::min<int32_t>(r.hi, ((far + 1 + G - 1) / G) * G);
+      if (s1 <= s0) s1 = std::min<int32_t>(r.hi, s0 + G);
+      if (s1 - s0 > (r.hi - r.lo) / 2 || s1 >= r.hi) { for (int32_t f = r.lo; f < r.hi; ++f) order.push_back(f); continue; }
+      // emitted order: left subtree, right subtree, separator  (stack is LIFO: push in reverse)
+      stack.push_back({s0, s1, true});
+      stack.push_back({s1, r.hi, false});
+      stack.push_back({r.lo, s0, false});
+    }
+    std::vector<int32_t> pos(nPv);
+    for (int64_t k = 0; k < nPv; ++k) pos[order[k]] = (int32_t)k;
+    for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
+  }
+  h->obj_row0 = ((6 * nPv + kTile - 1) / kTile) * kTile;
+  if (h->nOv == 0) h->obj_row0 = 6 * nPv;
+  h->m = h->obj_row0 + 7 * h->nOv;
+  h->m_canon = 6 * nPv + 7 * h->nOv;
+  h->h_canon_row.resize(h->m_canon);
+  for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) for (int k = 0; k < 6; ++k) h->h_canon_row[6 * (int64_t)nat[p] + k] = 6 * (int64_t)pose_vid[p] + k;
+  for (int64_t w = 0; w < 7 * h->nOv; ++w) h->h_canon_row[6 * nPv + w] = h->obj_row0 + w;
+  h->num_params = h->m_canon + 3 * h->nLv;
   h->num_residuals = nres;
   h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
   const int32_t nt = h->nt;
@@ -277,33 +345,83 @@ void prepare(obvi_ba_handle* h) {
   for (int64_t i = 0; i < h->n_bb; ++i) {
     if (!h->h_bb_active[i]) continue;
     const int32_t ov = obj_vid[h->h_bb_obj[i]], pv = pose_vid[h->h_bb_pose[i]];
-    if (ov >= 0 && pv >= 0) mark(6 * h->nPv + 7 * (int64_t)ov, 7, 6 * (int64_t)pv, 6);
+    if (ov >= 0 && pv >= 0) mark(h->obj_row0 + 7 * (int64_t)ov, 7, 6 * (int64_t)pv, 6);
   }
   for (int64_t i = 0; i < h->n_rl; ++i) {
     if (!h->h_rl_active[i]) continue;
     const int32_t va = pose_vid[h->h_rl_a[i]], vb = pose_vid[h->h_rl_b[i]];
     if (va >= 0 && vb >= 0 && va != vb) mark(6 * (int64_t)std::max(va, vb), 6, 6 * (int64_t)std::min(va, vb), 6);
   }
-  std::vector<int32_t> trsm_i, upd_ij, back_j;
-  h->h_trsm_ptr.assign(nt + 1, 0); h->h_upd_ptr.assign(nt + 1, 0); h->h_back_ptr.assign(nt + 1, 0);
-  std::vector<int32_t> rows;
+  // object diagonal blocks may straddle tiles
+  for (int64_t w = 0; w < h->nOv; ++w) mark(h->obj_row0 + 7 * w, 7, h->obj_row0 + 7 * w, 7);
+  for (int64_t v = 0; v < nPv; ++v) mark(6 * v, 6, 6 * v, 6);
+  // symbolic fill (tile columns in increasing order) + column structure of L
+  std::vector<int32_t> col_ptr(nt + 1, 0), col_i;
+  for (int k = 0; k < nt; ++k) {
+    const size_t beg = col_i.size();
+    for (int i = k + 1; i < nt; ++i) if (mask[(size_t)i * nt + k]) col_i.push_back(i);
+    for (size_t x = beg; x < col_i.size(); ++x) for (size_t y = beg; y <= x; ++y) mask[(size_t)col_i[x] * nt + col_i[y]] = 1;
+    col_ptr[k + 1] = (int32_t)col_i.size();
+  }
+  // levels of the tile elimination tree: k depends on every j < k with L(k,j) != 0
+  std::vector<int32_t> level(nt, 0);
+  int32_t nlev = 0;
+  for (int k = 0; k < nt; ++k) {
+    int32_t lv = 0;
+    for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) lv = std::max(lv, level[j] + 1);
+    level[k] = lv; nlev = std::max(nlev, lv + 1);
+  }
+  h->nlevels = nlev;
+  std::vector<std::vector<int32_t>> by_level(nlev);
+  for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
+  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k;
+  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
-  for (int k = 0; k < nt; ++k) {
-    rows.clear();
-    for (int i = k + 1; i < nt; ++i) if (mask[(size_t)i * nt + k]) rows.push_back(i);
-    for (int i : rows) trsm_i.push_back(i);
-    for (size_t x = 0; x < rows.size(); ++x)
-      for (size_t y = 0; y <= x; ++y) { upd_ij.push_back(rows[x]); upd_ij.push_back(rows[y]); mask[(size_t)rows[x] * nt + rows[y]] = 1; }
-    h->h_trsm_ptr[k + 1] = (int32_t)trsm_i.size();
-    h->h_upd_ptr[k + 1] = (int32_t)(upd_ij.size() / 2);
-    flops += t3 / 3.0 + t3 * rows.size() + 2.0 * t3 * (rows.size() * (rows.size() + 1) / 2);
+  struct Trip { int32_t i, j, k; };
+  std::vector<Trip> trips;
+  std::vector<std::pair<int32_t, int32_t>> ik;
+  int64_t n_products = 0;
+  for (int l = 0; l < nlev; ++l) {
+    trips.clear(); ik.clear();
+    for (int32_t k : by_level[l]) {
+      lvl_k.push_back(k);
+      const int32_t b0 = col_ptr[k], b1 = col_ptr[k + 1];
+      for (int32_t x = b0; x < b1; ++x) {
+        trsm_ik.push_back(col_i[x]); trsm_ik.push_back(k);
+        ik.push_back({col_i[x], k});
+        for (int32_t y = b0; y <= x; ++y) trips.push_back({col_i[x], col_i[y], k});
+      }
+      const double nr = (double)(b1 - b0);
+      flops += t3 / 3.0 + t3 * nr + 2.0 * t3 * (nr * (nr + 1) / 2);
+    }
+    std::sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.i != b.i ? a.i < b.i : (a.j != b.j ? a.j < b.j : a.k < b.k); });
+    for (size_t q = 0; q < trips.size(); ++q) {
+      if (q == 0 || trips[q].i != trips[q - 1].i || trips[q].j != trips[q - 1].j) {
+        if (q != 0) upd_kptr.push_back((int32_t)upd_k.size());
+        upd_ij.push_back(trips[q].i); upd_ij.push_back(trips[q].j);
+      }
+      upd_k.push_back(trips[q].k);
+    }
+    if (!trips.empty()) upd_kptr.push_back((int32_t)upd_k.size());
+    n_products += (int64_t)trips.size();
+    std::sort(ik.begin(), ik.end());
+    for (size_t q = 0; q < ik.size(); ++q) {
+      if (q == 0 || ik[q].first != ik[q - 1].first) {
+        if (q != 0) rh_kptr.push_back((int32_t)rh_k.size());
+        rh_i.push_back(ik[q].first);
+      }
+      rh_k.push_back(ik[q].second);
+    }
+    if (!ik.empty()) rh_kptr.push_back((int32_t)rh_k.size());
+    h->h_lvl_k_ptr[l + 1] = (int32_t)lvl_k.size();
+    h->h_trsm_ptr[l + 1] = (int32_t)(trsm_ik.size() / 2);
+    h->h_upd_ptr[l + 1] = (int32_t)(upd_ij.size() / 2);
+    h->h_rh_ptr[l + 1] = (int32_t)rh_i.size();
   }
   h->chol_flops = flops;
-  for (int k = 0; k < nt; ++k) {  // backward: tiles (k, j), j < k, non-zero in L
-    for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) back_j.push_back(j);
-    h->h_back_ptr[k + 1] = (int32_t)back_j.size();
-  }
+  h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
+  h->n_upd_products = n_products;
   std::vector<int32_t> tiles;
   for (int i = 0; i < nt; ++i) for (int j = 0; j <= i; ++j) if (mask[(size_t)i * nt + j]) { tiles.push_back(i); tiles.push_back(j); }
   h->ntiles = (int32_t)(tiles.size() / 2);
@@ -313,7 +431,10 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
   h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
-  h->d_tiles.upload(tiles, s); h->d_trsm_i.upload(trsm_i, s); h->d_upd_ij.upload(upd_ij, s); h->d_back_j.upload(back_j, s);
+  h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
+  h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
+  h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
+  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s);
   h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
   h->d_g.resize((size_t)h->m + 1); h->d_scale.resize((size_t)h->m + 1); h->d_lam.resize((size_t)h->m + 1);
   h->d_S.resize((size_t)nt * nt * kTile * kTile);
@@ -346,7 +467,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   h->d_Hdiag.zero(s); h->d_g.zero(s);
   record(h, PH_POSE_CACHE);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->m);
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, 6 * h->nPv, h->obj_row0, h->m);
   h->d_rhs.zero(s);
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal);
@@ -731,37 +852,38 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   prepare(h);
-  if (m_out) *m_out = (int32_t)h->m;
-  if (h->m > m_cap) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_reduced_system: buffer too small");
+  if (m_out) *m_out = (int32_t)h->m_canon;
+  if (h->m_canon > m_cap) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_reduced_system: buffer too small");
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h); const ReprojDev rp = reproj_dev(h); const SmallFactorsDev sf = small_dev(h);
   const ReducedDev rd = reduced_dev(h); const PointDev pt = point_dev(h);
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
   h->d_Hdiag.zero(s); h->d_g.zero(s); h->d_rhs.zero(s);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->m);
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, 6 * h->nPv, h->obj_row0, h->m);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get());
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
   launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
-  const int64_t m = h->m, nt = h->nt;
+  const int64_t mc = h->m_canon, nt = h->nt;
   std::vector<double> tiles((size_t)nt * nt * kTile * kTile), hr((size_t)nt * kTile);
+  std::vector<int32_t> tl((size_t)2 * h->ntiles);
   h->d_S.download(tiles.data(), tiles.size(), s); h->d_rhs.download(hr.data(), hr.size(), s);
+  h->d_tiles.download(tl.data(), tl.size(), s);
   sync(h);
-  for (int64_t i = 0; i < m; ++i) {
-    rhs[i] = hr[i];
-    for (int64_t j = 0; j <= i; ++j) {
-      const double v = tiles[((i / kTile) * nt + (j / kTile)) * (kTile * kTile) + (i % kTile) * kTile + (j % kTile)];
-      lhs[i * m + j] = v; lhs[j * m + i] = v;
+  // tiles outside the structural mask are never written: read them as zero
+  std::vector<uint8_t> mk((size_t)nt * nt, 0);
+  for (int t = 0; t < h->ntiles; ++t) mk[(size_t)tl[2 * t] * nt + tl[2 * t + 1]] = 1;
+  // canonical order (variable poses by index, then objects) <- rows of the tile grid (elimination order)
+  for (int64_t ci = 0; ci < mc; ++ci) {
+    const int64_t i = h->h_canon_row[ci];
+    rhs[ci] = hr[i];
+    for (int64_t cj = 0; cj < mc; ++cj) {
+      const int64_t j = h->h_canon_row[cj];
+      const int64_t r = std::max(i, j), c = std::min(i, j);
+      const size_t tix = (size_t)(r / kTile) * nt + (c / kTile);
+      lhs[ci * mc + cj] = mk[tix] ? tiles[tix * (kTile * kTile) + (r % kTile) * kTile + (c % kTile)] : 0.0;
     }
-  }
-  // tiles outside the structural mask were never zeroed: treat them as zero
-  {
-    std::vector<int32_t> tl((size_t)2 * h->ntiles);
-    h->d_tiles.download(tl.data(), tl.size(), s); sync(h);
-    std::vector<uint8_t> mk((size_t)nt * nt, 0);
-    for (int t = 0; t < h->ntiles; ++t) mk[(size_t)tl[2 * t] * nt + tl[2 * t + 1]] = 1;
-    for (int64_t i = 0; i < m; ++i) for (int64_t j = 0; j <= i; ++j) if (!mk[(i / kTile) * nt + (j / kTile)]) { lhs[i * m + j] = 0.0; lhs[j * m + i] = 0.0; }
   }
   return OBVI_OK;
   OBVI_API_END(h)
@@ -791,7 +913,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   sum->fixed_cost = fixed_cost;
   sum->num_parameters_reduced = (int32_t)h->num_params;
   sum->num_residuals_reduced = (int32_t)h->num_residuals;
-  sum->reduced_system_size = (int32_t)h->m;
+  sum->reduced_system_size = (int32_t)h->m_canon;
 
   auto finish = [&](int term, const char* msg) {
     sum->termination_type = term;
@@ -1021,10 +1143,10 @@ int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap)
   int64_t act_rp = 0, act_bb = 0;
   for (uint8_t a : h->h_rp_active) act_rp += a != 0;
   for (uint8_t a : h->h_bb_active) act_bb += a != 0;
-  const double v[13] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m, (double)h->nt, (double)h->nblk, (double)h->npairs,
-                        (double)h->ntiles, h->h_trsm_ptr.empty() ? 0.0 : (double)h->h_trsm_ptr.back(),
-                        h->h_upd_ptr.empty() ? 0.0 : (double)h->h_upd_ptr.back(), h->chol_flops, (double)act_rp, (double)act_bb};
-  const int n = std::min<int>(cap, 13);
+  const double v[14] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m_canon, (double)h->nt, (double)h->nblk, (double)h->npairs,
+                        (double)h->ntiles, (double)h->n_trsm_jobs, (double)h->n_upd_products, h->chol_flops, (double)act_rp, (double)act_bb,
+                        (double)h->nlevels};
+  const int n = std::min<int>(cap, 14);
   for (int i = 0; i < n; ++i) out[i] = v[i];
   return n;
 }

@@ -291,7 +291,7 @@ class BundleAdjuster:
         buf = (C.c_double * 16)()
         n = self._fn("ba_get_problem_stats")(self._h, buf, C.c_int32(16))
         names = ["poses_var", "objects_var", "points_var", "reduced_rows", "tiles_per_dim", "schur_blocks", "schur_pairs",
-                 "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active"]
+                 "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active", "chol_levels"]
         return {names[i]: buf[i] for i in range(n)}
 
     def kernel_times(self, cap=64):
