@@ -121,6 +121,7 @@ def main():
         # per-launch algorithmic bytes of the HBM-bound kernels (SURVEY 8d split of B_step) and flops of the solve
         alg = {
             "point_pass": n_r * (32.0 + 144.0),            # read obs, write Z (6x3 fp64)
+            "pose_pass": n_r * 32.0,
             "schur_blocks": n_r * 144.0 + pst["schur_blocks"] * 288.0,
             "point_backsub": n_r * 144.0,
             "cost": n_r * 32.0,

@@ -42,6 +42,17 @@ struct ReprojDev {          // observations sorted by (point, pose): CSC by poin
   double huber;
 };
 
+struct ReprojPoseDev {      // the same observations sorted by (pose, point): CSR by pose, for the pose-side pass
+  int64_t n;
+  const uint32_t* point;    // [n]
+  const uint16_t* cam;      // [n]
+  const double2* pixel;     // [n]
+  const double* sigma;      // [n]
+  const uint8_t* active;    // [n]
+  const uint32_t* pose_ptr; // [P+1]
+  double huber;
+};
+
 struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   int64_t P, L, O;
   int64_t nPv, nOv;         // variable+used poses / objects
@@ -88,6 +99,8 @@ void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache*
 void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc,
                        const double* points, const ReducedDev& rd, const PointDev& pt, double radius, int first_iter,
                        double* scal);
+void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc,
+                      const double* points, const ReducedDev& rd);
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams,
                           const double* poses, const double* objects, const ReducedDev& rd, double* scal);
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects,

@@ -109,16 +109,6 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         h20 += w * (Jl[2] * Jl[0] + Jl[5] * Jl[3]); h21 += w * (Jl[2] * Jl[1] + Jl[5] * Jl[4]); h22 += w * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
         g0 += w * (Jl[0] * r[0] + Jl[3] * r[1]); g1 += w * (Jl[1] * r[0] + Jl[4] * r[1]); g2 += w * (Jl[2] * r[0] + Jl[5] * r[1]);
       }
-      if (vid >= 0) {
-        double* Hd = rd.Hdiag + 36 * (int64_t)vid;
-        double* gd = rd.g + 6 * (int64_t)vid;
-#pragma unroll
-        for (int x = 0; x < 6; ++x) {
-#pragma unroll
-          for (int y = 0; y <= x; ++y) atomic_add_f64(Hd + 6 * x + y, w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]));
-          atomic_add_f64(gd + x, w * (Jp[x] * r[0] + Jp[6 + x] * r[1]));
-        }
-      }
     }
     if (lvar) {
       xsq = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
@@ -171,6 +161,64 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
   block_accumulate(xsq, scal + SC_XSQ);
   block_accumulate(fail, scal + SC_CHOL_FAIL);
   block_accumulate_max(gmax, scal + SC_GMAX_BITS);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1b.  Pose side of the reprojection linearisation: one workgroup per pose, its observations
+// contiguous (CSR by pose copy of the observation arrays).  Each thread accumulates the 21 unique
+// entries of rho' Jp^T Jp and the 6 of rho' Jp^T r over its observations; one deterministic
+// wavefront/LDS reduction per pose, no atomics.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
+                                                     const double* __restrict__ points, ReducedDev rd) {
+  const int64_t p = blockIdx.x;
+  const int32_t vid = b.pose_vid[p];
+  if (vid < 0) return;   // uniform per workgroup
+  __shared__ double red[kBlock / 64][27];
+  const PoseCache cache = pc[p];
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  const uint32_t beg = rq.pose_ptr[p], end = rq.pose_ptr[p + 1];
+  for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
+    if (!rq.active[k]) continue;
+    const uint32_t l = rq.point[k];
+    const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+    const double2 px = rq.pixel[k];
+    double r[2], Jp[12], Jl[6];
+    reproj_eval<true>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, Jp, Jl);
+    double rho0, w;
+    huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+    int e = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+#pragma unroll
+      for (int y = 0; y <= x; ++y) acc[e++] += w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) acc[21 + x] += w * (Jp[x] * r[0] + Jp[6 + x] * r[1]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) t += red[i][threadIdx.x];
+    const int k = threadIdx.x;
+    if (k < 21) {
+      // packed lower-triangular index -> (x, y)
+      int x = 0, base = 0;
+      while (base + x + 1 <= k) { base += x + 1; ++x; }
+      const int y = k - base;
+      rd.Hdiag[36 * (int64_t)vid + 6 * x + y] += t;
+    } else {
+      rd.g[6 * (int64_t)vid + (k - 21)] += t;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -341,32 +389,70 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
                                                         const uint32_t* __restrict__ blk_ptr, const uint32_t* __restrict__ pair_a,
                                                         const uint32_t* __restrict__ pair_b, const uint32_t* __restrict__ obs_point,
                                                         PointDev pt, ReducedDev rd) {
-  const int64_t blk = blockIdx.x * (int64_t)(kBlock / 64) + (threadIdx.x >> 6);
-  if (blk >= nblk) return;
-  const int lane = threadIdx.x & 63;
+  // One workgroup per 6x6 block.  Per pass the 4 wavefronts stage 16 pairs each: the two 6x3 Z
+  // blocks of a pair (36 doubles) are fetched with coalesced 8-byte loads into LDS, then lanes
+  // 0..35 of each wavefront accumulate element (x,y); lanes 36..41 the rhs on diagonal blocks.
+  constexpr int kPairsPerWave = 16;
+  __shared__ double zsh[kBlock / 64][kPairsPerWave * 36];
+  __shared__ double ush[kBlock / 64][kPairsPerWave * 3];
+  __shared__ double red[kBlock / 64][42];
+  const int64_t blk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t row = blk_row[blk], col = blk_col[blk];
   const uint32_t beg = blk_ptr[blk], end = blk_ptr[blk + 1];
   const bool diag = row == col;
-  if (lane < 36) {
-    const int x = lane / 6, y = lane % 6;
-    double acc = 0.0;
-    for (uint32_t k = beg; k < end; ++k) {
-      const double* Za = pt.Z + 18 * (int64_t)pair_a[k] + 3 * x;
-      const double* Zb = pt.Z + 18 * (int64_t)pair_b[k] + 3 * y;
-      acc += Za[0] * Zb[0] + Za[1] * Zb[1] + Za[2] * Zb[2];
+  const int x = lane < 36 ? lane / 6 : lane - 36, y = lane % 6;
+  double acc = 0.0;
+  for (uint32_t base = beg; base < end; base += (kBlock / 64) * kPairsPerWave) {
+    const uint32_t wbeg = base + wv * kPairsPerWave;
+    // pair indices of this wavefront: lanes 0..15 -> a, 16..31 -> b
+    uint32_t idx = 0xffffffffu;
+    if (lane < 32) {
+      const uint32_t k = wbeg + (lane & 15);
+      if (k < end) idx = lane < 16 ? pair_a[k] : pair_b[k];
     }
-    if (!diag || y <= x) *S_at(rd.S, rd.nt, (int64_t)row + x, (int64_t)col + y) -= acc;
-  } else if (diag && lane < 42) {
-    const int x = lane - 36;
-    double acc = 0.0;
-    for (uint32_t k = beg; k < end; ++k) {
-      const uint32_t a = pair_a[k];
-      if (a != pair_b[k]) continue;
-      const double* Za = pt.Z + 18 * (int64_t)a + 3 * x;
-      const double* u = pt.u + 3 * (int64_t)obs_point[a];
-      acc += Za[0] * u[0] + Za[1] * u[1] + Za[2] * u[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int f = i * 64 + lane;             // [0, 576): pair = f / 36, half = (f % 36) / 18, e = f % 18
+      const int pr = f / 36, rem = f - 36 * pr, half = rem >= 18 ? 1 : 0, e = rem - 18 * half;
+      const uint32_t src = __shfl(idx, pr + 16 * half, 64);
+      zsh[wv][f] = (src != 0xffffffffu) ? pt.Z[18 * (int64_t)src + e] : 0.0;
     }
-    rd.rhs[row + x] -= acc;
+    if (diag && lane < 48) {
+      const int pr = lane / 3, e = lane - 3 * pr;
+      const uint32_t sa = __shfl(idx, pr, 64), sb = __shfl(idx, pr + 16, 64);
+      ush[wv][lane] = (sa != 0xffffffffu && sa == sb) ? pt.u[3 * (int64_t)obs_point[sa] + e] : 0.0;
+    }
+    __syncthreads();
+    if (lane < 36) {
+#pragma unroll
+      for (int pr = 0; pr < kPairsPerWave; ++pr) {
+        const double* Za = &zsh[wv][36 * pr + 3 * x];
+        const double* Zb = &zsh[wv][36 * pr + 18 + 3 * y];
+        acc += Za[0] * Zb[0] + Za[1] * Zb[1] + Za[2] * Zb[2];
+      }
+    } else if (diag && lane < 42) {
+#pragma unroll
+      for (int pr = 0; pr < kPairsPerWave; ++pr) {
+        const double* Za = &zsh[wv][36 * pr + 3 * x];
+        const double* u = &ush[wv][3 * pr];
+        acc += Za[0] * u[0] + Za[1] * u[1] + Za[2] * u[2];
+      }
+    }
+    __syncthreads();
+  }
+  if (lane < 42) red[wv][lane] = acc;
+  __syncthreads();
+  if (threadIdx.x < 42) {
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) s += red[i][t];
+    if (t < 36) {
+      const int xx = t / 6, yy = t % 6;
+      if (!diag || yy <= xx) *S_at(rd.S, rd.nt, (int64_t)row + xx, (int64_t)col + yy) -= s;
+    } else if (diag) {
+      rd.rhs[row + (t - 36)] -= s;
+    }
   }
 }
 
@@ -769,6 +855,10 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal) {
   if (b.L > 0 && rp.n > 0) hipLaunchKernelGGL(k_point_pass, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal);
 }
+void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
+                      const ReducedDev& rd) {
+  if (b.P > 0 && rq.n > 0) hipLaunchKernelGGL(k_pose_pass, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd);
+}
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
   if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
@@ -781,7 +871,7 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
-  if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(nblk, kBlock / 64)), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
+  if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nblk), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
 }
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
                           double* points_cand, double* scal) {

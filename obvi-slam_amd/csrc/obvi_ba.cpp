@@ -28,8 +28,8 @@ namespace {
 
 double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
-const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "small_factors", "reduced_diag", "schur_blocks",
+enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_POSE_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "pose_pass", "small_factors", "reduced_diag", "schur_blocks",
                                      "cholesky_solve", "point_backsub", "apply_step", "cost"};
 
 }  // namespace
@@ -47,6 +47,7 @@ struct obvi_ba_handle {
   int64_t n_rp = 0;
   std::vector<uint32_t> h_rp_pose, h_rp_point, h_rp_perm, h_rp_inv, h_point_ptr;
   std::vector<uint8_t> h_rp_active;  // sorted order
+  std::vector<uint32_t> h_rq_src;    // CSR-by-pose copy: position -> index into the CSC-by-point arrays
   double rp_huber = 1.0;
   int64_t n_bb = 0, n_sp = 0, n_lt = 0, n_rl = 0;
   std::vector<uint32_t> h_bb_obj, h_bb_pose, h_sp_obj, h_lt_obj, h_rl_a, h_rl_b;
@@ -69,6 +70,11 @@ struct obvi_ba_handle {
   DevBuf<double2> d_rp_pixel;
   DevBuf<double> d_rp_sigma;
   DevBuf<uint8_t> d_rp_active;
+  DevBuf<uint32_t> d_rq_point, d_rq_pose_ptr;
+  DevBuf<uint16_t> d_rq_cam;
+  DevBuf<double2> d_rq_pixel;
+  DevBuf<double> d_rq_sigma;
+  DevBuf<uint8_t> d_rq_active;
   DevBuf<uint32_t> d_bb_obj, d_bb_pose, d_sp_obj, d_lt_obj, d_rl_a, d_rl_b;
   DevBuf<uint16_t> d_bb_cam;
   DevBuf<double> d_bb_rect, d_bb_sqrt_inf, d_sp_mean, d_sp_sqrt_inf, d_lt_mean, d_lt_sqrt_inf, d_rl_t, d_rl_R, d_rl_sqrt_inf;
@@ -152,6 +158,12 @@ ReprojDev reproj_dev(const obvi_ba_handle* h) {
   r.n = h->n_rp; r.pose = h->d_rp_pose.get(); r.point = h->d_rp_point.get(); r.cam = h->d_rp_cam.get();
   r.pixel = h->d_rp_pixel.get(); r.sigma = h->d_rp_sigma.get(); r.active = h->d_rp_active.get();
   r.point_ptr = h->d_point_ptr.get(); r.huber = h->rp_huber;
+  return r;
+}
+ReprojPoseDev reproj_pose_dev(const obvi_ba_handle* h) {
+  ReprojPoseDev r;
+  r.n = h->n_rp; r.point = h->d_rq_point.get(); r.cam = h->d_rq_cam.get(); r.pixel = h->d_rq_pixel.get(); r.sigma = h->d_rq_sigma.get();
+  r.active = h->d_rq_active.get(); r.pose_ptr = h->d_rq_pose_ptr.get(); r.huber = h->rp_huber;
   return r;
 }
 SmallFactorsDev small_dev(const obvi_ba_handle* h) {
@@ -471,6 +483,8 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   h->d_rhs.zero(s);
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal);
+  record(h, PH_POSE_PASS);
+  launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   record(h, PH_SMALL);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
   record(h, PH_DIAG);
@@ -659,6 +673,24 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   hipStream_t s = h->stream;
   h->d_rp_pose.upload(h->h_rp_pose, s); h->d_rp_point.upload(h->h_rp_point, s); h->d_rp_perm.upload(perm, s); h->d_point_ptr.upload(ptr, s);
   h->d_rp_cam.upload(cam, s); h->d_rp_pixel.upload(pix, s); h->d_rp_sigma.upload(sg, s); h->d_rp_active.upload(h->h_rp_active, s);
+  // CSR-by-pose copy for the pose-side pass (counting sort on the pose index; stable, so points ascend inside a pose)
+  std::vector<uint32_t> pptr(h->P + 1, 0), q_point(n);
+  std::vector<uint16_t> q_cam(n);
+  std::vector<double2> q_pix(n);
+  std::vector<double> q_sg(n);
+  std::vector<uint8_t> q_act(n, 1);
+  h->h_rq_src.resize(n);
+  for (int64_t a = 0; a < n; ++a) pptr[h->h_rp_pose[a] + 1]++;
+  for (int64_t p = 0; p < h->P; ++p) pptr[p + 1] += pptr[p];
+  {
+    std::vector<uint32_t> cur(pptr.begin(), pptr.end() - 1);
+    for (int64_t a = 0; a < n; ++a) {
+      const uint32_t k = cur[h->h_rp_pose[a]]++;
+      h->h_rq_src[k] = (uint32_t)a; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a];
+    }
+  }
+  h->d_rq_point.upload(q_point, s); h->d_rq_cam.upload(q_cam, s); h->d_rq_pixel.upload(q_pix, s); h->d_rq_sigma.upload(q_sg, s);
+  h->d_rq_active.upload(q_act, s); h->d_rq_pose_ptr.upload(pptr, s);
   sync(h);
   h->dirty = true;
   return OBVI_OK;
@@ -772,7 +804,14 @@ int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t type, const uint8_t* mask
   OBVI_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   switch (type) {
-    case OBVI_FACTOR_REPROJECTION: set_mask(h->h_rp_active, h->d_rp_active, mask, h->n_rp, s, h->h_rp_perm.data()); break;
+    case OBVI_FACTOR_REPROJECTION: {
+      set_mask(h->h_rp_active, h->d_rp_active, mask, h->n_rp, s, h->h_rp_perm.data());
+      std::vector<uint8_t> q(h->n_rp);
+      for (int64_t k = 0; k < h->n_rp; ++k) q[k] = h->h_rp_active[h->h_rq_src[k]];
+      h->d_rq_active.upload(q, s);
+      sync(h);
+      break;
+    }
     case OBVI_FACTOR_BBOX: set_mask<uint32_t>(h->h_bb_active, h->d_bb_active, mask, h->n_bb, s, nullptr); break;
     case OBVI_FACTOR_SHAPE_PRIOR: set_mask<uint32_t>(h->h_sp_active, h->d_sp_active, mask, h->n_sp, s, nullptr); break;
     case OBVI_FACTOR_LTM_PRIOR: set_mask<uint32_t>(h->h_lt_active, h->d_lt_active, mask, h->n_lt, s, nullptr); break;
@@ -862,6 +901,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
   launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, 6 * h->nPv, h->obj_row0, h->m);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get());
+  launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
   launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
@@ -898,7 +938,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   std::memset(sum, 0, sizeof(*sum));
   h->iterations.clear();
   prepare(h);
-  const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
+  const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
                          h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
   hipStream_t s = h->stream;
 
@@ -923,7 +963,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     for (const auto& it : h->iterations) sum->final_cost = std::min(sum->final_cost, it.cost);
     sum->is_solution_usable = (term == OBVI_CONVERGENCE || term == OBVI_NO_CONVERGENCE) ? 1 : 0;
     sum->total_time_in_seconds = wall_s() - t_start;
-    sum->jacobian_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE] - ms0[0]);
+    sum->jacobian_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE] - ms0[0]);
     sum->linear_solver_time_in_seconds = 1e-3 * (h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY] - ms0[1]);
     sum->residual_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_COST] - ms0[2]);
   };
