@@ -66,18 +66,19 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
   for (int kb = 0; kb < 16; ++kb) {
     if (ty == kb && tx == kb) {
       // 4x4 Cholesky in registers + its inverse
+      // division-free: i = rsqrt(pivot), l = pivot * i
       double p;
       p = a[0][0]; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double l00 = sqrt(p), i00 = 1.0 / l00;
+      const double i00 = rsqrt(p), l00 = p * i00;
       const double l10 = a[1][0] * i00, l20 = a[2][0] * i00, l30 = a[3][0] * i00;
       p = a[1][1] - l10 * l10; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double l11 = sqrt(p), i11 = 1.0 / l11;
+      const double i11 = rsqrt(p), l11 = p * i11;
       const double l21 = (a[2][1] - l20 * l10) * i11, l31 = (a[3][1] - l30 * l10) * i11;
       p = a[2][2] - l20 * l20 - l21 * l21; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double l22 = sqrt(p), i22 = 1.0 / l22;
+      const double i22 = rsqrt(p), l22 = p * i22;
       const double l32 = (a[3][2] - l30 * l20 - l31 * l21) * i22;
       p = a[3][3] - l30 * l30 - l31 * l31 - l32 * l32; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double l33 = sqrt(p), i33 = 1.0 / l33;
+      const double i33 = rsqrt(p), l33 = p * i33;
       a[0][0] = l00; a[0][1] = 0; a[0][2] = 0; a[0][3] = 0;
       a[1][0] = l10; a[1][1] = l11; a[1][2] = 0; a[1][3] = 0;
       a[2][0] = l20; a[2][1] = l21; a[2][2] = l22; a[2][3] = 0;
@@ -182,44 +183,67 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
       Lsh[(4 * ty + i) * LD + 4 * tx + j] = v;
     }
   __syncthreads();
-  if (tid < T) {   // z_k = L^-1 b_k
+  {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
+    const int r = tid >> 2, part = tid & 3;
     double s = 0.0;
-    for (int c = 0; c <= tid; ++c) s += Lsh[tid * LD + c] * zsh[c];
-    rhs[(int64_t)k * T + tid] = s;
+#pragma unroll
+    for (int c = 16 * part; c < 16 * part + 16; ++c) s += Lsh[r * LD + c] * zsh[c];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) rhs[(int64_t)k * T + r] = s;
   }
 }
 
-// acc[r][c] (+)= sum_t A[r][t] * B[c][t]   (both operands staged in LDS, 4x4 outputs per thread)
-__device__ __forceinline__ void tile_abt_acc(const double* A, const double* B, double acc[4][4]) {
-  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-#pragma unroll 8
-  for (int t = 0; t < T; ++t) {
-    double a[4], b[4];
+// ---------------------------------------------------------------------------------------
+// 64x64x64 fp64 tile product  C += A * B^T  on the matrix cores: v_mfma_f64_16x16x4_f64.
+// Both operands are row-major tiles staged in LDS with leading dimension LDM = 66 doubles
+// (bank = (4 row + 2 col) mod 64 for the 16-row x 2-col footprint of a 32-lane group: conflict-free).
+// Wavefront w owns output columns [16w, 16w+16); acc[rt] is the 16x16 tile of rows [16rt, 16rt+16).
+// Fragment layout (cdna_hip_programming.md 3): A: lane l -> A[l&15][l>>4]; B: lane l -> B[l>>4][l&15];
+// D: lane l, reg r -> D[(l>>4) + 4r][l&15].
+// ---------------------------------------------------------------------------------------
+constexpr int LDM = T + 2;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tile_abt_mfma(const double* A, const double* B, f64x4 acc[4]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const double* Bp = B + (16 * wv + r16) * LDM + kq;
+  const double* Ap = A + r16 * LDM + kq;
+#pragma unroll 4
+  for (int k0 = 0; k0 < T; k0 += 4) {
+    const double bv = Bp[k0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { a[i] = A[(ty * 4 + i) * LD + t]; b[i] = B[(tx * 4 + i) * LD + t]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    for (int rt = 0; rt < 4; ++rt) {
+      const double av = Ap[16 * rt * LDM + k0];
+      acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[rt], 0, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void stage_tile(double* dst, const double* __restrict__ src) {
+  // 64x64 row-major global tile -> LDS with leading dimension LDM; 16-byte global loads
+  for (int e = threadIdx.x; e < T * T / 2; e += kThreads) {
+    const int r = e / (T / 2), c2 = e % (T / 2);
+    const double2 v = reinterpret_cast<const double2*>(src)[e];
+    dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
   }
 }
 
 __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int32_t* __restrict__ jobs, const double* __restrict__ Linv_all) {
-  __shared__ double A[T * LD];
-  __shared__ double B[T * LD];
+  __shared__ double A[T * LDM];
+  __shared__ double B[T * LDM];
   const int i = jobs[2 * blockIdx.x], k = jobs[2 * blockIdx.x + 1];
   double* tile = tile_ptr(S, nt, i, k);
-  const double* Li = Linv_all + (int64_t)k * (T * T);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = tile[e]; B[r * LD + c] = Li[e]; }
+  stage_tile(A, tile);
+  stage_tile(B, Linv_all + (int64_t)k * (T * T));
   __syncthreads();
-  double acc[4][4] = {};
-  tile_abt_acc(A, B, acc);   // X = S_ik * Linv^T
-  const int ty = tid / 16, tx = tid % 16;
+  f64x4 acc[4] = {};
+  tile_abt_mfma(A, B, acc);   // X = S_ik * Linv^T
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) tile[(ty * 4 + a) * T + tx * 4 + b] = acc[a][b];
+    for (int r = 0; r < 4; ++r) tile[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = acc[rt][r];
 }
 
 // job g < n_upd: tile target (i,j): S_ij -= sum_{k in list} L_ik L_jk^T
@@ -227,28 +251,27 @@ __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int3
 __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_upd, const int32_t* __restrict__ upd_ij, const int32_t* __restrict__ upd_kptr,
                                                     const int32_t* __restrict__ upd_k, const int32_t* __restrict__ rh_i, const int32_t* __restrict__ rh_kptr,
                                                     const int32_t* __restrict__ rh_k, double* rhs) {
-  __shared__ double A[T * LD];
-  __shared__ double B[T * LD];
+  __shared__ double A[T * LDM];
+  __shared__ double B[T * LDM];
   const int tid = threadIdx.x;
   const int g = blockIdx.x;
   if (g < n_upd) {
     const int i = upd_ij[2 * g], j = upd_ij[2 * g + 1];
-    double acc[4][4] = {};
+    f64x4 acc[4] = {};
     for (int q = upd_kptr[g]; q < upd_kptr[g + 1]; ++q) {
       const int k = upd_k[q];
-      const double* Xi = tile_ptr(S, nt, i, k);
-      const double* Xj = tile_ptr(S, nt, j, k);
       __syncthreads();
-      for (int e = tid; e < T * T; e += kThreads) { const int r = e / T, c = e % T; A[r * LD + c] = Xi[e]; B[r * LD + c] = Xj[e]; }
+      stage_tile(A, tile_ptr(S, nt, i, k));
+      if (i != j) stage_tile(B, tile_ptr(S, nt, j, k));
       __syncthreads();
-      tile_abt_acc(A, B, acc);
+      tile_abt_mfma(A, i != j ? B : A, acc);
     }
     double* C = tile_ptr(S, nt, i, j);
-    const int ty = tid / 16, tx = tid % 16;
+    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) C[(ty * 4 + a) * T + tx * 4 + b] -= acc[a][b];
+      for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] -= acc[rt][r];
   } else {
     const int h = g - n_upd;
     const int i = rh_i[h];
