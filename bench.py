@@ -73,9 +73,8 @@ def main():
     import obvi_ba
     import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import dist_util
+    rank, local_rank, world = dist_util.rank_info()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -85,7 +84,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
-    prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=20241008 + args.config + 100 * rank, const_poses=cfg["const_poses"])
+    prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(20241008, args.config, rank), const_poses=cfg["const_poses"])
     stats = synth.problem_stats(prob)
     ba = obvi_ba.BundleAdjuster(device_id=local_rank)
     synth.upload(ba, prob)          # inputs now resident in HBM
@@ -107,13 +106,7 @@ def main():
     dt = time.perf_counter() - t0
     k1 = ba.kernel_times()
     steps_done = summ.num_iterations - 1
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        sd = torch.tensor([steps_done], dtype=torch.float64, device="cuda")
-        dist.all_reduce(sd, op=dist.ReduceOp.MIN)
-        steps_done = int(sd.item())
+    dt, steps_done = dist_util.reduce_timing(dist, "cuda", dt, steps_done)
 
     if rank == 0:
         pst = ba.problem_stats()
@@ -143,7 +136,7 @@ def main():
             ach = alg.get(dom, 0.0) / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
         out = {
-            "metric": "global-BA LM iterations/s", "value": world * steps_done / dt, "unit": "LM iterations/s",
+            "metric": "global-BA LM iterations/s", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "keyframes": stats["P"], "features": stats["L"], "objects": stats["O"],

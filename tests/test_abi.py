@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every declared symbol and refuses to run without a GPU."""
+import ctypes as C
+import os
+
+import pytest
+
+import helpers
+import obvi_ba
+
+
+def _abi_symbols():
+    import __graft_entry__ as ge
+    return ge.abi_symbols()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(helpers.PRODUCT_LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    return C.CDLL(helpers.PRODUCT_LIB)
+
+
+def test_exports_every_declared_symbol(lib):
+    syms = _abi_symbols()
+    assert len(syms) >= 30
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_oracle_mirrors_the_abi():
+    o = C.CDLL(helpers.ensure_oracle())
+    skip = {"obvi_ba_last_error", "obvi_ba_version", "obvi_ba_set_allreduce", "obvi_ba_get_kernel_times", "obvi_ba_get_problem_stats"}
+    for s in _abi_symbols():
+        if s not in skip:
+            assert hasattr(o, s.replace("obvi_", "oracle_", 1)), s
+
+
+def test_version_and_struct_sizes(lib):
+    lib.obvi_ba_version.restype = C.c_char_p
+    assert b"gfx950" in lib.obvi_ba_version()
+    assert C.sizeof(obvi_ba.SolverParams) == 48 and C.sizeof(obvi_ba.IterationSummary) == 80 and C.sizeof(obvi_ba.Summary) == 248
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the product refuses to create a handle (OBVI_ERR_NO_DEVICE); it never computes on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    opt = obvi_ba.Options(0, 7)
+    assert lib.obvi_ba_create(C.byref(opt), C.byref(h)) == -2
+    with pytest.raises(obvi_ba.ObviError):
+        obvi_ba.BundleAdjuster(device_id=0)
+    with pytest.raises(obvi_ba.ObviError):
+        obvi_ba.BundleAdjuster(library="/nonexistent/libobvi_ba.so")
+
+
+def test_invalid_arguments(lib):
+    assert lib.obvi_ba_create(None, None) == -1
+    bad = obvi_ba.Options(0, 9)     # the 9-parameter ellipsoid branch does not compile in the reference either
+    h = C.c_void_p()
+    assert lib.obvi_ba_create(C.byref(bad), C.byref(h)) == -1
+    assert lib.obvi_ba_solve(None, None, None) == -1
+
+
+def test_generator_shapes():
+    import numpy as np
+    import synth
+    prob = synth.make_problem(P=40, L=500, O=3, seed=3, min_obj_obs=5)
+    st = synth.problem_stats(prob)
+    assert st["P"] == 40 and st["L"] == 500 and st["O"] == 3 and st["N_rel"] == 39
+    cnt = np.bincount(prob["rp_point"], minlength=500)
+    assert cnt.min() >= 5                                  # min_low_level_feature_observations
+    assert np.all(np.diff(prob["rp_point"].astype(np.int64)) >= 0)
+    assert np.bincount(prob["bb_obj"], minlength=3).min() >= 5
+    px, z = synth.project_points(prob["gt_poses"][prob["rp_pose"]], prob["gt_points"][prob["rp_point"]])
+    inl = ~prob["rp_is_outlier"]
+    assert np.abs(px - prob["rp_pixel"])[inl].std() < 1.2 and z.min() > 0.5

@@ -1,0 +1,159 @@
+"""CPU: the oracle's linear algebra and LM bookkeeping against brute-force numpy on small problems."""
+import numpy as np
+
+import helpers
+import obvi_ba
+import synth
+
+FACTOR_BLOCKS = {0: (("pose", "rp_pose"), ("point", "rp_point")), 2: (("object", "bb_obj"), ("pose", "bb_pose")),
+                 3: (("object", "sp_obj"),), 5: (("pose", "rl_a"), ("pose", "rl_b"))}
+HUBER = {0: "rp_huber", 2: "bb_huber", 3: "sp_huber", 5: "rl_huber"}
+
+
+def dense_normal_equations(ba, prob):
+    """Robustified J and r of the reduced program, dense, columns = [variable poses, objects, points]."""
+    P, L, O = len(prob["poses"]), len(prob["points"]), len(prob["objects"])
+    pc = prob["pose_const"].astype(bool)
+    pv = -np.ones(P, int); pv[~pc] = np.arange((~pc).sum())
+    nPv = int((~pc).sum()); m = 6 * nPv + 7 * O; n = m + 3 * L
+    col = {"pose": lambda i: None if pv[i] < 0 else (6 * pv[i], 6), "object": lambda i: (6 * nPv + 7 * i, 7), "point": lambda i: (m + 3 * i, 3)}
+    rows, rr = [], []
+    for t, blocks in FACTOR_BLOCKS.items():
+        if ba.num_factors(t) == 0:
+            continue
+        r, J0, J1 = ba.debug_linearize(t)
+        a = prob[HUBER[t]]
+        s = (r ** 2).sum(axis=1)
+        w = np.sqrt(np.where(s > a * a, a / np.sqrt(np.maximum(s, 1e-300)), 1.0))
+        for f in range(len(r)):
+            blk = np.zeros((r.shape[1], n)); anyvar = False
+            for bi, (kind, key) in enumerate(blocks):
+                c = col[kind](prob[key][f])
+                if c is None:
+                    continue
+                anyvar = True
+                blk[:, c[0]:c[0] + c[1]] += w[f] * (J0 if bi == 0 else J1)[f]
+            if anyvar:
+                rows.append(blk); rr.append(w[f] * r[f])
+    return np.vstack(rows), np.concatenate(rr), m, pv
+
+
+def lm_system(J, r, radius):
+    H, g = J.T @ J, J.T @ r
+    c = np.diag(H).copy(); sc = 1 / (1 + np.sqrt(c))
+    lam = np.clip(c * sc * sc, 1e-6, 1e32) / radius / (sc * sc)
+    return H + np.diag(lam), g
+
+
+def small_problem(seed=5, const_poses=2):
+    return synth.make_problem(P=12, L=30, O=2, seed=seed, min_obj_obs=4, object_classes=("bench", "chair"), const_poses=const_poses)
+
+
+def test_gradient_matches_finite_differences():
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    x0 = [prob["poses"].copy(), prob["points"].copy(), prob["objects"].copy()]
+
+    def cost_at(x):
+        ba.set_poses(x[0], prob["pose_const"]); ba.set_points(x[1], prob["point_const"]); ba.set_objects(x[2], prob["object_const"])
+        return ba.evaluate(True, False)[0]
+    cost_at(x0)
+    g = [np.zeros_like(a) for a in x0]
+    kind_idx = {"pose": 0, "point": 1, "object": 2}
+    for t, blocks in FACTOR_BLOCKS.items():
+        r, J0, J1 = ba.debug_linearize(t)
+        a = prob[HUBER[t]]; s = (r ** 2).sum(axis=1)
+        w = np.where(s > a * a, a / np.sqrt(np.maximum(s, 1e-300)), 1.0)
+        for bi, (kind, key) in enumerate(blocks):
+            np.add.at(g[kind_idx[kind]], prob[key], np.einsum("n,nmd,nm->nd", w, J0 if bi == 0 else J1, r))
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    for kind in range(3):
+        for _ in range(25):
+            i = rng.integers(x0[kind].shape[0]); k = rng.integers(x0[kind].shape[1])
+            xp = [a.copy() for a in x0]; xm = [a.copy() for a in x0]
+            xp[kind][i, k] += eps; xm[kind][i, k] -= eps
+            gn = (cost_at(xp) - cost_at(xm)) / (2 * eps)
+            assert abs(gn - g[kind][i, k]) <= 2e-5 * (1 + abs(gn))
+
+
+def test_schur_complement_and_step_match_dense_solve():
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    J, r, m, pv = dense_normal_equations(ba, prob)
+    radius = 100.0
+    A, g = lm_system(J, r, radius)
+    S = A[:m, :m] - A[:m, m:] @ np.linalg.solve(A[m:, m:], A[:m, m:].T)
+    b = g[:m] - A[:m, m:] @ np.linalg.solve(A[m:, m:], g[m:])
+    So, bo = ba.debug_reduced_system(radius)
+    assert So.shape == (m, m)
+    assert helpers.rel_err(So, S) < 1e-12 and helpers.rel_err(bo, b) < 1e-11
+    delta = -np.linalg.solve(A, g)
+    before = [ba.get_poses(), ba.get_points(), ba.get_objects()]
+    s = ba.solve(helpers.ba_params(max_it=1, ftol=0, ptol=0, gtol=0, radius=radius))
+    its = ba.iterations()
+    assert s.termination_type == obvi_ba.NO_CONVERGENCE and len(its) == 2 and its[1].step_is_successful
+    d = np.concatenate([(ba.get_poses() - before[0])[pv >= 0].ravel(), (ba.get_objects() - before[2]).ravel(), (ba.get_points() - before[1]).ravel()])
+    assert helpers.rel_err(d, delta) < 1e-11
+    assert abs(its[1].step_norm - np.linalg.norm(delta)) < 1e-10 * np.linalg.norm(delta)
+
+
+def test_fixed_cost_and_constant_blocks():
+    prob = small_problem(const_poses=3)
+    prob["point_const"][:5] = 1
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    s = ba.solve(helpers.ba_params(max_it=3))
+    assert s.fixed_cost > 0.0                       # observations of constant points from constant poses
+    assert np.array_equal(ba.get_poses()[:3], prob["poses"][:3])
+    assert np.array_equal(ba.get_points()[:5], prob["points"][:5])
+    assert s.final_cost < s.initial_cost
+    # everything constant: nothing to optimise
+    ba.set_const_flags(np.ones(12, np.uint8), np.ones(30, np.uint8), np.ones(2, np.uint8))
+    s = ba.solve(helpers.ba_params(max_it=3))
+    assert s.termination_type == obvi_ba.CONVERGENCE and s.num_iterations == 1 and s.num_parameters_reduced == 0
+
+
+def test_noise_free_problem_stays_at_truth():
+    """a BA started from ground truth with noiseless measurements must stay at ~0 cost."""
+    prob = synth.make_problem(P=10, L=60, O=0, seed=9, outlier_frac=0.0, pixel_noise=0.0, point_noise=0.0)
+    prob["poses"] = prob["gt_poses"].copy()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob, relpose=False)
+    assert ba.evaluate(True, False)[0] < 1e-18
+    s = ba.solve(helpers.ba_params(max_it=5))
+    assert s.final_cost < 1e-18 and np.abs(ba.get_poses() - prob["gt_poses"]).max() < 1e-9
+
+
+def test_outlier_selection_semantics():
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    _, _, sq = ba.evaluate(False)
+    n = ba.num_factors(0)
+    mask, nex = ba.select_outliers(0, 0.1)
+    assert nex == int(len(np.unique(sq[:n])) * 0.1) and (mask == 0).sum() == nex
+    assert sq[:n][mask == 0].min() >= np.sort(sq[:n])[-nex]          # the largest residual blocks are the ones dropped
+    # phase II: excluded factors leave the problem
+    c0 = ba.evaluate(False)[0]
+    ba.set_active_mask(0, mask)
+    c1, res, sq1 = ba.evaluate(False)
+    assert c1 < c0 and np.all(sq1[:n][mask == 0] == 0.0)
+    ba.set_active_mask(0, None)
+    assert abs(ba.evaluate(False)[0] - c0) < 1e-9 * c0
+
+
+def test_snapshot_restore():
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    ba.snapshot()
+    ba.solve(helpers.ba_params(max_it=3))
+    assert np.abs(ba.get_points() - prob["points"]).max() > 0
+    ba.restore()
+    assert np.array_equal(ba.get_points(), prob["points"]) and np.array_equal(ba.get_poses(), prob["poses"])
+
+
+def test_nonmonotonic_returns_minimum_cost_iterate():
+    prob = synth.make_problem(P=20, L=150, O=2, seed=2, min_obj_obs=4)
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    s = ba.solve(helpers.ba_params(max_it=25, nonmono=True))
+    costs = [it.cost for it in ba.iterations()]
+    assert abs(s.final_cost - min(costs)) < 1e-12 * min(costs)
+    assert abs(ba.evaluate(True, False)[0] - s.final_cost) < 1e-9 * s.final_cost
