@@ -1,0 +1,477 @@
+// obvi_optimizer.h -- host-side mirror of the reference's optimisation layer on top of the C ABI:
+//   obvi::Problem                    takes the place of ceres::Problem in the signatures (thin: records
+//                                    the flat problem of the last build and owns the device handle)
+//   ObjectPoseGraphOptimizer         buildPoseGraphOptimization / solveOptimization / clearPastOptimizationData
+//                                    (include/refactoring/optimization/object_pose_graph_optimizer.h:93-797)
+//   runPgoPlusEllipsoids             (include/refactoring/optimization/pose_graph_plus_objects_optimizer.h:23-353)
+//   OptimizationLogger               ceres_opt_summary.csv with the reference's columns
+//                                    (include/debugging/optimization_logger.h:166-304)
+// No evaluation happens on the host: everything numeric goes through include/obvi_ba.h.
+#ifndef OBVI_HOST_OPTIMIZER_H_
+#define OBVI_HOST_OPTIMIZER_H_
+
+#include <obvi_ba.h>
+
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+
+#include "obvi_params.h"
+#include "obvi_pose_graph.h"
+
+namespace obvi {
+
+typedef uint64_t ResidualBlockId;   // stands in for ceres::ResidualBlockId
+
+struct IterationSummary { int iteration; double cost, cost_change, step_norm, gradient_max_norm; bool step_is_successful; };
+// the fields of ceres::Solver::Summary the reference consumes (object_pose_graph_optimizer.h:676-706,
+// optimization_logger.h:192-203)
+struct SolverSummary {
+  int termination_type = OBVI_FAILURE;
+  bool usable = false;
+  double initial_cost = 0, final_cost = 0, fixed_cost = 0;
+  double total_time_in_seconds = 0, linear_solver_time_in_seconds = 0, jacobian_evaluation_time_in_seconds = 0, residual_evaluation_time_in_seconds = 0;
+  int num_parameters_reduced = 0, num_residuals_reduced = 0;
+  std::vector<IterationSummary> iterations;
+  std::string message;
+  bool IsSolutionUsable() const { return usable; }
+  std::string FullReport() const {
+    std::ostringstream o;
+    o << "obvi_ba solve: " << message << "  iterations " << iterations.size() << "  cost " << initial_cost << " -> " << final_cost << "  time "
+      << total_time_in_seconds << " s (linear solver " << linear_solver_time_in_seconds << ", jacobian " << jacobian_evaluation_time_in_seconds
+      << ", residual " << residual_evaluation_time_in_seconds << ")";
+    return o.str();
+  }
+};
+
+// Flat problem in the layout of the C ABI plus the ids needed to scatter results back.
+struct FlatProblem {
+  std::vector<vslam_types_refactor::CameraId> cameras;                 // camera index -> CameraId
+  std::vector<double> cam_K, cam_ext;
+  std::vector<vslam_types_refactor::FrameId> frames;                   // pose index -> FrameId (ascending)
+  std::vector<vslam_types_refactor::FeatureId> features;               // point index -> FeatureId (ascending)
+  std::vector<vslam_types_refactor::ObjectId> objects;                 // object index -> ObjectId (ascending)
+  std::vector<double*> pose_ptrs, point_ptrs, object_ptrs;             // the pose graph's parameter blocks
+  std::vector<uint8_t> pose_const, point_const, object_const;
+  std::vector<uint32_t> rp_pose, rp_point; std::vector<uint16_t> rp_cam; std::vector<double> rp_pixel, rp_sigma;
+  std::vector<uint32_t> bb_obj, bb_pose; std::vector<uint16_t> bb_cam; std::vector<double> bb_corners, bb_cov;
+  std::vector<uint32_t> sp_obj; std::vector<double> sp_mean, sp_cov;
+  std::vector<uint32_t> lt_obj; std::vector<double> lt_mean, lt_cov;
+  std::vector<uint32_t> rl_a, rl_b; std::vector<double> rl_t, rl_aa, rl_cov;
+  double rl_huber = 1.0;
+  // residual blocks in Problem::GetResidualBlocks order (= evaluate order of the ABI: types 0,2,3,4,5)
+  std::vector<vslam_types_refactor::FactorInfo> blocks;
+};
+
+class Problem {
+ public:
+  explicit Problem(int device_id = 0, bool dry_run = false) : device_id_(device_id), dry_run_(dry_run) {}
+  Problem(const Problem&) = delete;
+  Problem& operator=(const Problem&) = delete;
+  ~Problem() { if (h_) obvi_ba_destroy(h_); }
+  // residual blocks added outside the factor store: runPgoPlusEllipsoids adds RelativePoseFactor blocks directly
+  // to its ceres::Problem (pose_graph_plus_objects_optimizer.h:129-159); they stay for every later build on it.
+  void AddRelativePoseResidualBlock(const vslam_types_refactor::RelPoseFactor& f, double huber) { extra_relpose_.push_back(f); extra_relpose_huber_ = huber; }
+  const std::vector<vslam_types_refactor::RelPoseFactor>& extraRelativePoseBlocks() const { return extra_relpose_; }
+  double extraRelativePoseHuber() const { return extra_relpose_huber_; }
+  FlatProblem flat;
+  bool dryRun() const { return dry_run_; }
+  obvi_ba_handle* handle() {
+    if (!h_ && !dry_run_) {
+      obvi_ba_options opt{}; opt.device_id = device_id_; opt.object_block_size = 7;
+      const int rc = obvi_ba_create(&opt, &h_);
+      if (rc != OBVI_OK) { std::cerr << "obvi_ba_create failed: status " << rc << " (no HIP device? there is no CPU path)" << std::endl; h_ = nullptr; }
+    }
+    return h_;
+  }
+ private:
+  int device_id_; bool dry_run_;
+  obvi_ba_handle* h_ = nullptr;
+  std::vector<vslam_types_refactor::RelPoseFactor> extra_relpose_;
+  double extra_relpose_huber_ = 1.0;
+};
+
+}  // namespace obvi
+
+namespace vslam_types_refactor {
+
+// include/debugging/optimization_logger.h:151-304
+class OptimizationLogger {
+ public:
+  explicit OptimizationLogger(const std::string& output_file_path) : output_file_path_(output_file_path) {}
+  void setOptimizationTypeParams(const FrameId& max_frame_id, const bool& global_ba, const bool& global_pgo, const bool& outliers_excluded, const size_t& attempt_num = 0) {
+    info_.max_frame_id_ = max_frame_id; info_.global_ba_ = global_ba; info_.global_pgo_ = global_pgo; info_.local_ba_ = !global_ba;
+    info_.outliers_excluded_opt_ = outliers_excluded; info_.attempt_num_ = attempt_num;
+  }
+  void setOptimizationParams(size_t num_objects, size_t num_features, size_t num_frames) { info_.num_objects_ = num_objects; info_.num_visual_features_ = num_features; info_.num_poses_ = num_frames; }
+  void extractOptimizationTimingResults(const obvi::SolverSummary& s) {
+    info_.total_ceres_time_ = s.total_time_in_seconds; info_.linear_solver_time_ = s.linear_solver_time_in_seconds;
+    info_.jacobian_time_ = s.jacobian_evaluation_time_in_seconds; info_.residual_time_ = s.residual_evaluation_time_in_seconds;
+    info_.num_ceres_iterations_ = s.iterations.size();
+  }
+  void writeOptInfoHeader() {
+    if (output_file_path_.empty()) return;
+    std::ofstream f(output_file_path_, std::ios::trunc);
+    f << "max_frame_id,outliers_excluded?,local_ba?,global_ba?,global_pgo?,num_poses,num_objects,num_visual_features,total_ceres_time,"
+         "linear_solver_time,jacobian_time,residual_time,num_ceres_iterations\n";
+  }
+  void writeCurrentOptInfo() {
+    if (!output_file_path_.empty()) {
+      std::ofstream f(output_file_path_, std::ios::app);
+      f << info_.max_frame_id_ << "," << (info_.outliers_excluded_opt_ ? 1 : 0) << "," << (info_.local_ba_ ? 1 : 0) << "," << (info_.global_ba_ ? 1 : 0) << ","
+        << (info_.global_pgo_ ? 1 : 0) << "," << info_.num_poses_ << "," << info_.num_objects_ << "," << info_.num_visual_features_ << ","
+        << std::to_string(info_.total_ceres_time_) << "," << std::to_string(info_.linear_solver_time_) << "," << std::to_string(info_.jacobian_time_) << ","
+        << std::to_string(info_.residual_time_) << "," << info_.num_ceres_iterations_ << "\n";
+    }
+    info_ = Info();
+  }
+ private:
+  struct Info {
+    FrameId max_frame_id_ = 0; bool outliers_excluded_opt_ = false, local_ba_ = false, global_ba_ = false, global_pgo_ = false;
+    size_t num_poses_ = 0, num_objects_ = 0, num_visual_features_ = 0, num_ceres_iterations_ = 0, attempt_num_ = 0;
+    double total_ceres_time_ = 0, linear_solver_time_ = 0, jacobian_time_ = 0, residual_time_ = 0;
+  };
+  std::string output_file_path_;
+  Info info_;
+};
+
+}  // namespace vslam_types_refactor
+
+namespace pose_graph_optimizer {
+using namespace vslam_types_refactor;   // NOLINT (the reference's optimiser header does the same through its includes)
+typedef ObjectAndReprojectionFeaturePoseGraph PoseGraphType;
+
+class ObjectPoseGraphOptimizer {
+ public:
+  ObjectPoseGraphOptimizer() = default;
+
+  // object_pose_graph_optimizer.h:126-632.  Same selection rules; instead of adding Ceres residual and
+  // parameter blocks the selected factors are flattened into problem->flat.
+  std::unordered_map<obvi::ResidualBlockId, FactorInfo> buildPoseGraphOptimization(
+      const OptimizationScopeParams& optimization_scope, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
+      std::shared_ptr<PoseGraphType>& pose_graph, obvi::Problem* problem, std::optional<OptimizationLogger>& opt_logger,
+      const FactorInfoSet& excluded_feature_factor_types_and_ids = {}) {
+    residual_params_ = residual_params;
+    std::set<FrameId> optimized_frames;
+    std::unordered_set<ObjectId> ltm_object_ids;
+    std::map<FeatureId, FactorInfoSet> features_to_include;
+    std::map<ObjectId, FactorInfoSet> objects_to_include;
+    std::map<FactorType, std::set<FeatureFactorId>> required_feature_factors;
+
+    const bool use_object_only_factors = optimization_scope.include_object_factors_ && !optimization_scope.fix_objects_;      // :165-170
+    const bool use_feature_pose_factors = optimization_scope.include_visual_factors_;
+    const bool use_relative_pose_factors = optimization_scope.min_low_level_feature_observations_per_frame_ > 0 && use_feature_pose_factors;
+    const bool use_object_pose_factors = optimization_scope.include_object_factors_;
+    const bool use_object_param_blocks = optimization_scope.include_object_factors_;
+    const bool fix_object_param_blocks = optimization_scope.fix_objects_;
+    const bool fix_ltm_param_blocks = optimization_scope.fix_objects_ || optimization_scope.fix_ltm_objects_;
+    const bool fix_visual_feature_param_blocks = optimization_scope.fix_visual_features_;
+    const bool fix_pose_param_blocks = optimization_scope.fix_poses_;
+
+    for (const FrameId& f : pose_graph->getFrameIds())                                                                       // :196-203
+      if (f >= optimization_scope.min_frame_id_ && f <= optimization_scope.max_frame_id_) optimized_frames.insert(f);
+
+    auto excluded = [&](const FactorInfo& fi) {                                                                              // :886-905
+      if (optimization_scope.factor_types_to_exclude.count(fi.first)) return true;
+      if (excluded_feature_factor_types_and_ids.count(fi) && fi.first != kLongTermMapFactorTypeId && fi.first != kShapeDimPriorFactorTypeId) return true;
+      return false;
+    };
+    if (use_feature_pose_factors) {                                                                                          // :205-238
+      FactorInfoSet matching;
+      pose_graph->getVisualFeatureFactorIdsBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, matching);
+      for (const FactorInfo& fi : matching) {
+        if (excluded(fi)) continue;
+        FeatureId feat;
+        if (pose_graph->getFeatureIdForObservationFactor(fi, feat)) features_to_include[feat].insert(fi);
+      }
+      applyMinObs(optimization_scope.min_low_level_feature_observations_, features_to_include, required_feature_factors, {});
+    }
+    if (use_relative_pose_factors) {                                                                                         // :240-299
+      std::unordered_map<FrameId, size_t> obs_per_frame;
+      for (const auto& feat : features_to_include)
+        for (const FactorInfo& fi : feat.second) { ReprojectionErrorFactor f; if (pose_graph->getVisualFactor(fi.second, f)) obs_per_frame[f.frame_id_]++; }
+      for (const FrameId& f : optimized_frames) {
+        auto it = obs_per_frame.find(f);
+        if (it != obs_per_frame.end() && it->second >= optimization_scope.min_low_level_feature_observations_per_frame_) continue;
+        FactorInfoSet rel;
+        pose_graph->getPoseFactorInfoByFrameId(f, optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, rel);
+        for (const FactorInfo& fi : rel) required_feature_factors[fi.first].insert(fi.second);
+      }
+    }
+    if (use_object_param_blocks) pose_graph->getLongTermMapObjects(ltm_object_ids);                                         // :301-306
+    if (use_object_pose_factors) {                                                                                           // :308-340
+      FactorInfoSet matching;
+      pose_graph->getObservationFactorsBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, matching);
+      for (const FactorInfo& fi : matching) {
+        if (excluded(fi)) continue;
+        ObjectId obj;
+        if (pose_graph->getObjectIdForObjObservationFactor(fi, obj)) objects_to_include[obj].insert(fi);
+      }
+      applyMinObs(optimization_scope.min_object_observations_, objects_to_include, required_feature_factors, ltm_object_ids);
+    }
+    if (use_object_only_factors) {                                                                                           // :342-405
+      std::unordered_set<ObjectId> with_object_only;
+      for (const auto& o : objects_to_include) if (!fix_ltm_param_blocks || !ltm_object_ids.count(o.first)) with_object_only.insert(o.first);
+      if (!fix_ltm_param_blocks && optimization_scope.force_include_ltm_objs_) with_object_only.insert(ltm_object_ids.begin(), ltm_object_ids.end());
+      std::unordered_map<ObjectId, FactorInfoSet> by_obj;
+      pose_graph->getOnlyObjectFactorsForObjects(with_object_only, optimization_scope.use_pom_, true, by_obj);
+      for (const auto& o : by_obj) {
+        objects_to_include[o.first].insert(o.second.begin(), o.second.end());
+        for (const FactorInfo& fi : o.second) required_feature_factors[fi.first].insert(fi.second);
+      }
+    }
+    for (const FactorType& t : optimization_scope.factor_types_to_exclude) required_feature_factors.erase(t);               // :407-410
+
+    // ---- flatten (the part that replaces addOrRefreshResidualBlocksForRequiredFactors, :415, :991-1055) ----
+    obvi::FlatProblem& fp = problem->flat;
+    fp = obvi::FlatProblem();
+    std::map<CameraId, uint16_t> cam_index;
+    for (const auto& c : pose_graph->intrinsics()) {
+      CameraExtrinsics e;
+      if (!pose_graph->getExtrinsicsForCamera(c.first, e)) continue;
+      cam_index[c.first] = (uint16_t)fp.cameras.size();
+      fp.cameras.push_back(c.first);
+      fp.cam_K.insert(fp.cam_K.end(), {c.second.fx, c.second.fy, c.second.cx, c.second.cy});
+      // Pose3D orientation (axis-angle) -> quaternion xyzw
+      const double th = std::sqrt(e.orientation_[0] * e.orientation_[0] + e.orientation_[1] * e.orientation_[1] + e.orientation_[2] * e.orientation_[2]);
+      const double s = th > 0 ? std::sin(th / 2) / th : 0.5;
+      fp.cam_ext.insert(fp.cam_ext.end(), {e.orientation_[0] * s, e.orientation_[1] * s, e.orientation_[2] * s, std::cos(th / 2), e.transl_[0], e.transl_[1], e.transl_[2]});
+    }
+    std::map<FrameId, uint32_t> pose_index;
+    for (const FrameId& f : optimized_frames) {
+      double* p = nullptr;
+      if (!pose_graph->getPosePointers(f, &p)) continue;
+      pose_index[f] = (uint32_t)fp.frames.size(); fp.frames.push_back(f); fp.pose_ptrs.push_back(p);
+    }
+    // constness of poses (:424-472)
+    fp.pose_const.assign(fp.frames.size(), 0);
+    if (fix_pose_param_blocks) {
+      std::fill(fp.pose_const.begin(), fp.pose_const.end(), 1);
+    } else if (optimization_scope.min_frame_id_ == 0) {
+      auto it = pose_index.find(0); if (it != pose_index.end()) fp.pose_const[it->second] = 1;
+    } else {
+      const uint32_t n_const = std::max<uint32_t>(1, optimization_scope.poses_prior_to_window_to_keep_constant_);
+      for (uint32_t k = 0; k < n_const; ++k) {
+        const FrameId f = optimization_scope.min_frame_id_ + k;
+        if (f > optimization_scope.max_frame_id_) break;
+        auto it = pose_index.find(f); if (it != pose_index.end()) fp.pose_const[it->second] = 1;
+      }
+    }
+    std::map<FeatureId, uint32_t> point_index;
+    if (use_feature_pose_factors) {
+      for (const auto& feat : features_to_include) {
+        double* p = nullptr;
+        if (!pose_graph->getFeaturePointers(feat.first, &p)) continue;
+        point_index[feat.first] = (uint32_t)fp.features.size(); fp.features.push_back(feat.first); fp.point_ptrs.push_back(p);
+      }
+    }
+    fp.point_const.assign(fp.features.size(), fix_visual_feature_param_blocks ? 1 : 0);                                     // :488-520
+    std::map<ObjectId, uint32_t> object_index;
+    if (use_object_param_blocks) {                                                                                          // :532-603
+      for (const auto& o : objects_to_include) {
+        double* p = nullptr;
+        if (!pose_graph->getObjectParamPointers(o.first, &p)) continue;
+        object_index[o.first] = (uint32_t)fp.objects.size(); fp.objects.push_back(o.first); fp.object_ptrs.push_back(p);
+        const bool is_ltm = ltm_object_ids.count(o.first) != 0;
+        fp.object_const.push_back((fix_object_param_blocks || (fix_ltm_param_blocks && is_ltm)) ? 1 : 0);
+      }
+    }
+    const auto& rp = residual_params;
+    // residual blocks, type by type in the evaluate order of the ABI; inside a type by factor id
+    for (FeatureFactorId id : required_feature_factors[kReprojectionErrorFactorTypeId]) {                                    // residual_creator.h:168-264
+      ReprojectionErrorFactor f;
+      if (!pose_graph->getVisualFactor(id, f)) continue;
+      auto pi = pose_index.find(f.frame_id_); auto li = point_index.find(f.feature_id_); auto ci = cam_index.find(f.camera_id_);
+      if (pi == pose_index.end() || li == point_index.end() || ci == cam_index.end()) continue;
+      fp.rp_pose.push_back(pi->second); fp.rp_point.push_back(li->second); fp.rp_cam.push_back(ci->second);
+      fp.rp_pixel.push_back(f.feature_pos_[0]); fp.rp_pixel.push_back(f.feature_pos_[1]); fp.rp_sigma.push_back(f.reprojection_error_std_dev_);
+      fp.blocks.push_back({kReprojectionErrorFactorTypeId, id});
+    }
+    for (FeatureFactorId id : required_feature_factors[kObjectObservationFactorTypeId]) {                                    // residual_creator.h:20-117
+      ObjectObservationFactor f;
+      if (!pose_graph->getObjectObservationFactor(id, f)) continue;
+      auto oi = object_index.find(f.object_id_); auto pi = pose_index.find(f.frame_id_); auto ci = cam_index.find(f.camera_id_);
+      if (oi == object_index.end() || pi == pose_index.end() || ci == cam_index.end()) continue;
+      fp.bb_obj.push_back(oi->second); fp.bb_pose.push_back(pi->second); fp.bb_cam.push_back(ci->second);
+      fp.bb_corners.insert(fp.bb_corners.end(), f.bounding_box_corners_.begin(), f.bounding_box_corners_.end());
+      fp.bb_cov.insert(fp.bb_cov.end(), f.bounding_box_corners_covariance_.begin(), f.bounding_box_corners_covariance_.end());
+      fp.blocks.push_back({kObjectObservationFactorTypeId, id});
+    }
+    for (FeatureFactorId id : required_feature_factors[kShapeDimPriorFactorTypeId]) {                                        // residual_creator.h:119-166
+      ShapeDimPriorFactor f;
+      if (!pose_graph->getShapeDimPriorFactor(id, f)) continue;
+      auto oi = object_index.find(f.object_id_); if (oi == object_index.end()) continue;
+      fp.sp_obj.push_back(oi->second); fp.sp_mean.insert(fp.sp_mean.end(), f.mean_shape_dim_.begin(), f.mean_shape_dim_.end());
+      fp.sp_cov.insert(fp.sp_cov.end(), f.shape_dim_cov_.begin(), f.shape_dim_cov_.end());
+      fp.blocks.push_back({kShapeDimPriorFactorTypeId, id});
+    }
+    for (FeatureFactorId id : required_feature_factors[kLongTermMapFactorTypeId]) {                                          // long_term_map_factor_creator.h:265-322
+      LongTermMapObjectPrior f;
+      if (!pose_graph->getLongTermMapFactor(id, f)) continue;
+      auto oi = object_index.find(f.object_id_); if (oi == object_index.end()) continue;
+      fp.lt_obj.push_back(oi->second); fp.lt_mean.insert(fp.lt_mean.end(), f.ellipsoid_mean_.begin(), f.ellipsoid_mean_.end());
+      fp.lt_cov.insert(fp.lt_cov.end(), f.covariance_.begin(), f.covariance_.end());
+      fp.blocks.push_back({kLongTermMapFactorTypeId, id});
+    }
+    auto add_relpose = [&](const RelPoseFactor& f, const FactorInfo& info) {                                                 // residual_creator.h:266-345
+      auto a = pose_index.find(f.frame_id_1_), b = pose_index.find(f.frame_id_2_);
+      if (a == pose_index.end() || b == pose_index.end()) return;
+      fp.rl_a.push_back(a->second); fp.rl_b.push_back(b->second);
+      fp.rl_t.insert(fp.rl_t.end(), f.measured_pose_deviation_.transl_.begin(), f.measured_pose_deviation_.transl_.end());
+      fp.rl_aa.insert(fp.rl_aa.end(), f.measured_pose_deviation_.orientation_.begin(), f.measured_pose_deviation_.orientation_.end());
+      fp.rl_cov.insert(fp.rl_cov.end(), f.pose_deviation_cov_.begin(), f.pose_deviation_cov_.end());
+      fp.blocks.push_back(info);
+    };
+    fp.rl_huber = rp.relative_pose_factor_huber_loss_;
+    for (FeatureFactorId id : required_feature_factors[kPairwiseRobotPoseFactorTypeId]) { RelPoseFactor f; if (pose_graph->getPoseFactor(id, f)) add_relpose(f, {kPairwiseRobotPoseFactorTypeId, id}); }
+    if (!problem->extraRelativePoseBlocks().empty()) {
+      fp.rl_huber = problem->extraRelativePoseHuber();
+      uint64_t k = 0;
+      for (const RelPoseFactor& f : problem->extraRelativePoseBlocks()) add_relpose(f, {kPairwiseRobotPoseFactorTypeId, (FeatureFactorId)(~0ull - k++)});
+    }
+    last_optimized_nodes_ = optimized_frames.size(); last_optimized_features_ = fp.features.size(); last_optimized_objects_ = fp.objects.size();
+    if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);   // :625-629
+    std::unordered_map<obvi::ResidualBlockId, FactorInfo> current_residual_block_info;
+    for (size_t i = 0; i < fp.blocks.size(); ++i) current_residual_block_info[(obvi::ResidualBlockId)i] = fp.blocks[i];
+    return current_residual_block_info;
+  }
+
+  // object_pose_graph_optimizer.h:634-707
+  bool solveOptimization(obvi::Problem* problem, const pose_graph_optimization::OptimizationSolverParams& solver_params,
+                         std::optional<OptimizationLogger>& opt_logger, std::vector<obvi::ResidualBlockId>* residual_block_id_ptrs = nullptr,
+                         std::vector<double>* residual_ptrs = nullptr, std::shared_ptr<obvi::SolverSummary> solver_summary = nullptr) {
+    if (problem == nullptr) return false;
+    obvi_ba_handle* h = problem->handle();
+    if (h == nullptr) { std::cerr << "solveOptimization: no device handle" << std::endl; return false; }
+    const obvi::FlatProblem& fp = problem->flat;
+    const auto& rp = residual_params_;
+    auto gather = [](const std::vector<double*>& ptrs, int dim) { std::vector<double> v(ptrs.size() * dim); for (size_t i = 0; i < ptrs.size(); ++i) std::copy_n(ptrs[i], dim, &v[dim * i]); return v; };
+    std::vector<double> poses = gather(fp.pose_ptrs, 6), points = gather(fp.point_ptrs, 3), objects = gather(fp.object_ptrs, 7);
+    int rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
+    if (!rc) rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
+    if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
+    if (!rc) rc = obvi_ba_set_objects(h, (int64_t)fp.objects.size(), objects.data(), fp.object_const.data());
+    if (!rc) rc = obvi_ba_set_reproj(h, (int64_t)fp.rp_pose.size(), fp.rp_pose.data(), fp.rp_point.data(), fp.rp_cam.data(), fp.rp_pixel.data(), fp.rp_sigma.data(), 0.0,
+                                     rp.visual_residual_params_.reprojection_error_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_bbox(h, (int64_t)fp.bb_obj.size(), fp.bb_obj.data(), fp.bb_pose.data(), fp.bb_cam.data(), fp.bb_corners.data(), fp.bb_cov.data(),
+                                   rp.object_residual_params_.object_observation_huber_loss_param_, rp.object_residual_params_.invalid_ellipsoid_error_val_);
+    if (!rc) rc = obvi_ba_set_shape_priors(h, (int64_t)fp.sp_obj.size(), fp.sp_obj.data(), fp.sp_mean.data(), fp.sp_cov.data(), rp.object_residual_params_.shape_dim_prior_factor_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_ltm_priors(h, (int64_t)fp.lt_obj.size(), fp.lt_obj.data(), fp.lt_mean.data(), fp.lt_cov.data(), rp.long_term_map_params_.pair_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_relpose(h, (int64_t)fp.rl_a.size(), fp.rl_a.data(), fp.rl_b.data(), fp.rl_t.data(), fp.rl_aa.data(), fp.rl_cov.data(), fp.rl_huber);
+    if (rc) { std::cerr << "obvi_ba upload failed: " << obvi_ba_last_error(h) << std::endl; return false; }
+
+    obvi_solver_params p{solver_params.max_num_iterations_, solver_params.allow_non_monotonic_steps_ ? 1 : 0, solver_params.function_tolerance_,
+                         solver_params.gradient_tolerance_, solver_params.parameter_tolerance_, solver_params.initial_trust_region_radius_,
+                         solver_params.max_trust_region_radius_};
+    obvi_summary s;
+    rc = obvi_ba_solve(h, &p, &s);
+    if (rc) { std::cerr << "obvi_ba_solve failed: " << obvi_ba_last_error(h) << std::endl; return false; }
+    obvi::SolverSummary summary;
+    summary.termination_type = s.termination_type; summary.usable = s.is_solution_usable != 0;
+    summary.initial_cost = s.initial_cost; summary.final_cost = s.final_cost; summary.fixed_cost = s.fixed_cost;
+    summary.total_time_in_seconds = s.total_time_in_seconds; summary.linear_solver_time_in_seconds = s.linear_solver_time_in_seconds;
+    summary.jacobian_evaluation_time_in_seconds = s.jacobian_evaluation_time_in_seconds; summary.residual_evaluation_time_in_seconds = s.residual_evaluation_time_in_seconds;
+    summary.num_parameters_reduced = s.num_parameters_reduced; summary.num_residuals_reduced = s.num_residuals_reduced; summary.message = s.message;
+    std::vector<obvi_iteration_summary> its((size_t)std::max(s.num_iterations, 1));
+    const int nit = obvi_ba_get_iterations(h, its.data(), (int32_t)its.size());
+    for (int i = 0; i < nit; ++i) summary.iterations.push_back({its[i].iteration, its[i].cost, its[i].cost_change, its[i].step_norm, its[i].gradient_max_norm, its[i].step_is_successful != 0});
+
+    if (residual_block_id_ptrs != nullptr) { residual_block_id_ptrs->resize(fp.blocks.size()); for (size_t i = 0; i < fp.blocks.size(); ++i) (*residual_block_id_ptrs)[i] = i; }   // :679-681
+    if (residual_ptrs != nullptr) {                                                                                          // :682-693
+      residual_ptrs->assign((size_t)obvi_ba_num_residuals(h), 0.0);
+      if (obvi_ba_evaluate(h, /*apply_loss=*/0, nullptr, residual_ptrs->data(), nullptr)) return false;
+    }
+    if (solver_summary != nullptr) *solver_summary = summary;
+    if (summary.termination_type == OBVI_FAILURE) std::cerr << "obvi_ba optimization failed: " << summary.message << std::endl;
+    if (opt_logger.has_value()) opt_logger->extractOptimizationTimingResults(summary);
+    // Ceres mutates the parameter blocks in place; copy the device state back into the pose graph's blocks
+    if (obvi_ba_get_poses(h, poses.data()) || obvi_ba_get_points(h, points.data()) || obvi_ba_get_objects(h, objects.data())) return false;
+    for (size_t i = 0; i < fp.pose_ptrs.size(); ++i) std::copy_n(&poses[6 * i], 6, fp.pose_ptrs[i]);
+    for (size_t i = 0; i < fp.point_ptrs.size(); ++i) std::copy_n(&points[3 * i], 3, fp.point_ptrs[i]);
+    for (size_t i = 0; i < fp.object_ptrs.size(); ++i) std::copy_n(&objects[7 * i], 7, fp.object_ptrs[i]);
+    last_summary_ = summary;
+    return summary.IsSolutionUsable();
+  }
+
+  void clearPastOptimizationData() { last_optimized_objects_ = last_optimized_features_ = last_optimized_nodes_ = 0; }     // :792-797
+  const obvi::SolverSummary& lastSummary() const { return last_summary_; }
+
+ private:
+  template <class Id>
+  static void applyMinObs(size_t min_obs, std::map<Id, FactorInfoSet>& by_id, std::map<FactorType, std::set<FeatureFactorId>>& required, const std::unordered_set<Id>& ignore) {   // :826-861
+    for (auto it = by_id.begin(); it != by_id.end();) {
+      if (it->second.size() >= min_obs || ignore.count(it->first)) { for (const FactorInfo& fi : it->second) required[fi.first].insert(fi.second); ++it; }
+      else it = by_id.erase(it);
+    }
+  }
+  pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
+  size_t last_optimized_objects_ = 0, last_optimized_features_ = 0, last_optimized_nodes_ = 0;
+  obvi::SolverSummary last_summary_;
+};
+
+// pose_graph_plus_objects_optimizer.h:23-353
+inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const OptimizationScopeParams& optimization_scope_params,
+                                 const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
+                                 const pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams& pgo_solver_params, const bool& final_run,
+                                 std::optional<OptimizationLogger>& opt_logger, std::shared_ptr<PoseGraphType>& pose_graph, int device_id = 0,
+                                 const int& attempt_num = 0) {
+  std::unordered_map<FrameId, RawPose3d> raw;
+  pose_graph->getRobotPoseEstimates(raw);
+  ObjectPoseGraphOptimizer optimizer;
+  obvi::Problem problem(device_id);
+  for (FrameId f = 1; f <= max_frame_id; ++f) {                                                                              // :94-127
+    if (!raw.count(f) || !raw.count(f - 1)) { std::cerr << "Could not find current estimate for frame num " << f << std::endl; return false; }
+    RelPoseFactor rel;
+    rel.frame_id_1_ = f - 1; rel.frame_id_2_ = f;
+    rel.measured_pose_deviation_ = getPose2RelativeToPose1(convertToPose3D(raw.at(f - 1)), convertToPose3D(raw.at(f)));
+    const auto& c = pgo_solver_params.relative_pose_cov_params_;
+    rel.pose_deviation_cov_ = generateOdomCov(rel.measured_pose_deviation_, c.transl_error_mult_for_transl_error_, c.transl_error_mult_for_rot_error_,
+                                              c.rot_error_mult_for_transl_error_, c.rot_error_mult_for_rot_error_);
+    problem.AddRelativePoseResidualBlock(rel, pgo_solver_params.relative_pose_factor_huber_loss_);                           // :129-159
+  }
+  OptimizationScopeParams scope_pgo = optimization_scope_params;                                                              // :161-165
+  scope_pgo.include_visual_factors_ = false;
+  scope_pgo.poses_prior_to_window_to_keep_constant_ = 1;
+  std::unordered_map<FeatureId, std::pair<FrameId, Position3d>> relative_positions_from_first;
+  if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :167-199
+    std::unordered_map<FeatureId, Position3d> feats;
+    pose_graph->getVisualFeatureEstimates(feats);
+    for (const auto& f : feats) {
+      FrameId first;
+      if (pose_graph->getFirstObservedFrameForFeature(f.first, first) && raw.count(first))
+        relative_positions_from_first[f.first] = {first, getPositionRelativeToPose(convertToPose3D(raw.at(first)), f.second)};
+    }
+  }
+  if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(max_frame_id, false, true, true, attempt_num);          // :201-204
+  optimizer.buildPoseGraphOptimization(scope_pgo, residual_params, pose_graph, &problem, opt_logger);
+  if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_pgo_optimization_solver_params_ : pgo_solver_params.pgo_optimization_solver_params_,
+                                   opt_logger)) {                                                                            // :221-232
+    std::cerr << "Pose-graph + object optimization failed at max frame id " << max_frame_id << std::endl;
+    return false;
+  }
+  if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
+  if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :238-283
+    pose_graph->getRobotPoseEstimates(raw);
+    for (const auto& f : relative_positions_from_first)
+      if (raw.count(f.second.first)) pose_graph->updateVisualPositionParams(f.first, combinePoseAndPosition(convertToPose3D(raw.at(f.second.first)), f.second.second));
+  }
+  if (pgo_solver_params.enable_visual_feats_only_opt_post_pgo_) {                                                            // :284-350
+    std::optional<OptimizationLogger> null_logger;
+    OptimizationScopeParams scope_vf = optimization_scope_params;
+    scope_vf.fix_poses_ = true; scope_vf.fix_objects_ = true; scope_vf.include_object_factors_ = false;
+    optimizer.buildPoseGraphOptimization(scope_vf, residual_params, pose_graph, &problem, null_logger);
+    if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_post_pgo_vf_adjustment_solver_params_ : pgo_solver_params.post_pgo_vf_adjustment_solver_params_,
+                                     null_logger)) {
+      std::cerr << "Visual feature adjustment after pose-graph optimization failed at max frame id " << max_frame_id << std::endl;
+      return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace pose_graph_optimizer
+#endif  // OBVI_HOST_OPTIMIZER_H_

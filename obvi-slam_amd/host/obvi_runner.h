@@ -1,0 +1,241 @@
+// obvi_runner.h -- host-side mirror of the session loop and the two-phase controller:
+//   OfflineProblemRunner::runOptimization / runOptimizationIteration
+//       include/refactoring/offline/offline_problem_runner.h:100-274, 376-916
+// The runner is parameterised like the reference's (window provider, GBA checker, iteration-parameter
+// provider, frame data adder); numeric work goes through ObjectPoseGraphOptimizer -> include/obvi_ba.h.
+#ifndef OBVI_HOST_RUNNER_H_
+#define OBVI_HOST_RUNNER_H_
+
+#include <functional>
+
+#include "obvi_optimizer.h"
+
+namespace vslam_types_refactor {
+
+// Input container (the role of UnassociatedBoundingBoxOfflineProblemData, offline_problem_data.h:110-399, reduced
+// to what reaches the optimisation path: associations are given, the front ends are out of scope).
+struct OfflineProblemData {
+  std::unordered_map<CameraId, CameraIntrinsicsMat> camera_intrinsics_by_camera_;
+  std::unordered_map<CameraId, CameraExtrinsics> camera_extrinsics_by_camera_;
+  std::vector<Pose3D> robot_poses_;                         // initial trajectory estimate (odometry), index = FrameId
+  std::unordered_map<FeatureId, Position3d> initial_feature_positions_;
+  struct VisualObs { FeatureId feature_id; CameraId camera_id; PixelCoord pixel; };
+  std::vector<std::vector<VisualObs>> visual_obs_by_frame_;
+  struct BoxObs { ObjectId object_id; CameraId camera_id; BbCorners corners; Covariance<4> cov; };
+  std::vector<std::vector<BoxObs>> box_obs_by_frame_;
+  std::unordered_map<ObjectId, RawEllipsoid> initial_ellipsoids_;
+  std::unordered_map<ObjectId, std::string> object_class_;
+  std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>> shape_priors_by_class_;
+  std::vector<LongTermMapObjectPrior> long_term_map_;       // objects carried over from a previous session
+  double reprojection_error_std_dev_ = 1.5;
+  FrameId getMaxFrameId() const { return robot_poses_.empty() ? 0 : robot_poses_.size() - 1; }
+};
+
+typedef ObjectAndReprojectionFeaturePoseGraph MainPg;
+typedef std::shared_ptr<MainPg> MainPgPtr;
+
+// The frame data adder of the reference (pose_graph_frame_data_adder.h:8-266) minus the front ends: the new
+// frame's pose is the previous *optimised* pose composed with the odometry increment of the initial trajectory;
+// features / objects enter the graph the first time they are observed; a consecutive-frame odometry factor is
+// stored for every frame (used by buildPoseGraphOptimization only for frames with few observations).
+inline void addFrameDataToPoseGraph(const OfflineProblemData& d, MainPgPtr& pg, const FrameId& frame,
+                                    const pose_graph_optimization::RelativePoseCovarianceOdomModelParams& odom) {
+  if (frame == 0) {
+    pg->addFrame(0, d.robot_poses_[0]);
+  } else {
+    const Pose3D rel = getPose2RelativeToPose1(d.robot_poses_[frame - 1], d.robot_poses_[frame]);
+    const Pose3D prev = convertToPose3D(pg->getRobotPose(frame - 1).value());
+    pg->addFrame(frame, combinePoses(prev, rel));
+    RelPoseFactor f;
+    f.frame_id_1_ = frame - 1; f.frame_id_2_ = frame; f.measured_pose_deviation_ = rel;
+    f.pose_deviation_cov_ = generateOdomCov(rel, odom.transl_error_mult_for_transl_error_, odom.transl_error_mult_for_rot_error_,
+                                            odom.rot_error_mult_for_transl_error_, odom.rot_error_mult_for_rot_error_);
+    pg->addPoseFactor(f);
+  }
+  if (frame < d.visual_obs_by_frame_.size())
+    for (const auto& o : d.visual_obs_by_frame_[frame]) {
+      if (!pg->hasFeature(o.feature_id)) pg->addFeature(o.feature_id, d.initial_feature_positions_.at(o.feature_id));
+      pg->addVisualFactor(ReprojectionErrorFactor{frame, o.feature_id, o.camera_id, o.pixel, d.reprojection_error_std_dev_});
+    }
+  if (frame < d.box_obs_by_frame_.size())
+    for (const auto& o : d.box_obs_by_frame_[frame]) {
+      double* p = nullptr;
+      if (!pg->getObjectParamPointers(o.object_id, &p)) {
+        // objects are created with consecutive ids in first-observation order: the scene must be numbered that way
+        const ObjectId id = pg->addNewEllipsoid(d.initial_ellipsoids_.at(o.object_id), d.object_class_.at(o.object_id));
+        if (id != o.object_id) std::cerr << "object id mismatch " << id << " vs " << o.object_id << std::endl;
+        const auto& pr = d.shape_priors_by_class_.at(d.object_class_.at(o.object_id));
+        pg->addShapeDimPrior(ShapeDimPriorFactor{o.object_id, pr.first, pr.second});
+      }
+      pg->addObjectObservation(ObjectObservationFactor{frame, o.camera_id, o.object_id, o.corners, o.cov, 1.0});
+    }
+}
+
+struct OptimizationRecord {   // one row per solve, for tests / logging
+  FrameId min_frame, max_frame; std::string kind; int iterations; double initial_cost, final_cost; size_t n_poses, n_features, n_objects, n_excluded;
+};
+
+class OfflineProblemRunner {
+ public:
+  OfflineProblemRunner(const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
+                       const pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams& pgo_solver_params,
+                       const std::function<FrameId(const FrameId&)>& window_provider_func,
+                       const std::function<bool(const FrameId&)>& gba_checker,
+                       const std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)>& iteration_params_provider_func,
+                       int device_id = 0)
+      : residual_params_(residual_params), pgo_solver_params_(pgo_solver_params), window_provider_func_(window_provider_func), gba_checker_(gba_checker),
+        iteration_params_provider_func_(iteration_params_provider_func), device_id_(device_id) {}
+
+  // offline_problem_runner.h:100-274
+  bool runOptimization(const OfflineProblemData& problem_data, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
+                       std::optional<OptimizationLogger>& opt_logger, MainPgPtr& pose_graph_out, const FrameId& start_at_frame = 0,
+                       const bool& add_data_for_starting_frame = true) {
+    if (opt_logger.has_value()) opt_logger->writeOptInfoHeader();
+    obvi::Problem problem(device_id_);
+    pose_graph_optimizer::OptimizationScopeParams scope;                                                                     // :115-142
+    scope.min_low_level_feature_observations_per_frame_ = enabled.min_low_level_feature_observations_per_frame_;
+    scope.fix_poses_ = enabled.fix_poses_; scope.fix_objects_ = enabled.fix_objects_; scope.fix_visual_features_ = enabled.fix_visual_features_;
+    scope.fix_ltm_objects_ = enabled.fix_ltm_objects_; scope.include_visual_factors_ = enabled.include_visual_factors_;
+    scope.include_object_factors_ = enabled.include_object_factors_; scope.use_pom_ = enabled.use_pom_;
+    scope.poses_prior_to_window_to_keep_constant_ = enabled.poses_prior_to_window_to_keep_constant_;
+    scope.min_low_level_feature_observations_ = enabled.min_low_level_feature_observations_;
+    scope.min_object_observations_ = enabled.min_object_observations_;
+    const FrameId max_frame_id = problem_data.getMaxFrameId();
+    MainPgPtr pose_graph = std::make_shared<MainPg>(problem_data.camera_extrinsics_by_camera_, problem_data.camera_intrinsics_by_camera_);   // pose_graph_creator_
+    for (const auto& ltm : problem_data.long_term_map_)
+      pose_graph->addLongTermMapObject(ltm.object_id_, ltm.ellipsoid_mean_, problem_data.object_class_.count(ltm.object_id_) ? problem_data.object_class_.at(ltm.object_id_) : "", ltm);
+    if (start_at_frame == 0 && add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_);
+    const FrameId first_frame = std::max<FrameId>(1, start_at_frame);
+    for (FrameId next_frame_id = first_frame; next_frame_id <= max_frame_id; ++next_frame_id) {                               // :174-226
+      const FrameId start_opt_with_frame = window_provider_func_(next_frame_id);
+      scope.min_frame_id_ = start_opt_with_frame; scope.max_frame_id_ = next_frame_id;
+      if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_);
+      if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
+    }
+    if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
+    // mergeObjectsAtSessionEnd (:918-958) and the output extractor act on data-association state: out of scope
+    pose_graph_out = pose_graph;
+    return true;
+  }
+  const std::vector<OptimizationRecord>& records() const { return records_; }
+
+ private:
+  // offline_problem_runner.h:337-374
+  static bool isConsecutivePosesStable_(const MainPgPtr& pg, const FrameId& min_f, const FrameId& max_f, const double& transl_tol, const double& orient_tol) {
+    for (FrameId f = min_f + 1; f <= max_f; ++f) {
+      const auto a = pg->getRobotPose(f - 1), b = pg->getRobotPose(f);
+      if (!a.has_value() || !b.has_value()) continue;
+      const Pose3D rel = getPose2RelativeToPose1(convertToPose3D(a.value()), convertToPose3D(b.value()));
+      const double tn = std::sqrt(rel.transl_[0] * rel.transl_[0] + rel.transl_[1] * rel.transl_[1] + rel.transl_[2] * rel.transl_[2]);
+      const double an = std::sqrt(rel.orientation_[0] * rel.orientation_[0] + rel.orientation_[1] * rel.orientation_[1] + rel.orientation_[2] * rel.orientation_[2]);
+      if (tn > transl_tol || std::fabs(an) > orient_tol) return false;
+    }
+    return true;
+  }
+
+  // offline_problem_runner.h:376-916
+  bool runOptimizationIteration(const FrameId& start_opt_with_frame, const FrameId& next_frame_id, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
+                                const pose_graph_optimizer::OptimizationScopeParams& scope, const FrameId& max_frame_id, std::optional<OptimizationLogger>& opt_logger,
+                                MainPgPtr& pose_graph, obvi::Problem& problem, const int& attempt_num = 0) {
+    const pose_graph_optimization::OptimizationIterationParams iteration_params = iteration_params_provider_func_(next_frame_id);
+    if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, false, attempt_num);
+    const bool global_ba = gba_checker_(next_frame_id);                                                                      // :407
+    bool run_visual_feature_opt = true;
+    if (global_ba) {                                                                                                         // :410-520
+      bool run_pgo;
+      if (next_frame_id == max_frame_id && attempt_num > 0) {
+        run_pgo = enabled.use_pose_graph_on_final_global_ba_;
+        if (run_pgo) run_visual_feature_opt = enabled.use_visual_features_on_final_global_ba_;
+      } else {
+        run_pgo = enabled.use_pose_graph_on_global_ba_;
+        if (run_pgo) run_visual_feature_opt = enabled.use_visual_features_on_global_ba_;
+      }
+      if (run_pgo) {
+        pose_graph_optimizer::OptimizationScopeParams tracking = scope;                                                      // :440-496 "tracking before PGO"
+        tracking.min_frame_id_ = next_frame_id - std::min<FrameId>(next_frame_id, tracking.poses_prior_to_window_to_keep_constant_);
+        std::optional<OptimizationLogger> null_logger;
+        optimizer_.buildPoseGraphOptimization(tracking, residual_params_, pose_graph, &problem, null_logger);
+        if (!optimizer_.solveOptimization(&problem, pgo_solver_params_.pre_pgo_tracking_solver_params_, null_logger)) std::cerr << "Tracking failed" << std::endl;
+        record("pre_pgo_track", tracking.min_frame_id_, next_frame_id, problem, 0);
+        if (!pose_graph_optimizer::runPgoPlusEllipsoids(next_frame_id, scope, residual_params_, pgo_solver_params_, next_frame_id == max_frame_id, opt_logger, pose_graph,
+                                                        device_id_, attempt_num))
+          std::cerr << "PGO+objs failed at frame " << next_frame_id << std::endl;
+        records_.push_back({0, next_frame_id, "pgo", 0, 0, 0, (size_t)next_frame_id + 1, 0, 0, 0});
+      }
+    }
+    if (!run_visual_feature_opt) return true;                                                                                // :522
+    bool two_phase = iteration_params.feature_outlier_percentage_ > 0;
+    const std::string kind = global_ba ? "gba" : "lba";
+    // PHASE I  (:541-660)
+    auto block_info = optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger);
+    MainPgPtr pose_graph_copy = pose_graph->makeCopyDeepCopyValues();                                                        // :594
+    std::vector<obvi::ResidualBlockId> residual_block_ids;
+    std::vector<double> residuals;
+    const bool ok1 = two_phase ? optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, &residual_block_ids, &residuals)
+                               : optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger);
+    if (!ok1) { std::cerr << "Phase I Optimization failed at max frame id " << next_frame_id << std::endl; return false; }
+    if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
+    record(kind + "_phase_1", scope.min_frame_id_, next_frame_id, problem, 0);
+    // per-block squared residuals with the hard-coded block sizes (:689-749)
+    std::map<FactorType, std::vector<std::pair<double, obvi::ResidualBlockId>>> by_type;
+    if (two_phase) {
+      size_t idx = 0;
+      for (obvi::ResidualBlockId id : residual_block_ids) {
+        const FactorType t = block_info.at(id).first;
+        size_t n;
+        if (t == kReprojectionErrorFactorTypeId) n = 2; else if (t == kObjectObservationFactorTypeId) n = 4; else if (t == kShapeDimPriorFactorTypeId) n = 3;
+        else if (t == kLongTermMapFactorTypeId) n = kEllipsoidParamterizationSize; else if (t == kPairwiseRobotPoseFactorTypeId) n = 6; else if (t == kPairwiseErrorFactorTypeId) n = 1;
+        else { two_phase = false; break; }
+        double total = 0;
+        for (size_t i = 0; i < n && idx < residuals.size(); ++i, ++idx) total += residuals[idx] * residuals[idx];
+        if (t == kReprojectionErrorFactorTypeId || t == kObjectObservationFactorTypeId) by_type[t].push_back({total, id});
+      }
+      if (idx != residuals.size()) two_phase = false;
+    }
+    FactorInfoSet excluded;
+    if (two_phase) {                                                                                                         // :769-800
+      for (auto& tv : by_type) {
+        // std::map<double, id, greater>: descending by value, equal values collapse into one entry
+        std::map<double, obvi::ResidualBlockId, std::greater<double>> ordered;
+        for (const auto& e : tv.second) ordered[e.first] = e.second;
+        const size_t n_outliers = (size_t)(ordered.size() * iteration_params.feature_outlier_percentage_);
+        auto it = ordered.begin();
+        for (size_t i = 0; i < n_outliers; ++i, ++it) excluded.insert(block_info.at(it->second));
+      }
+    }
+    if (two_phase) {                                                                                                         // PHASE II :803-892
+      if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, true, attempt_num);
+      pose_graph->setValuesFromAnotherPoseGraph(pose_graph_copy);                                                            // :811
+      optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger, excluded);
+      if (!optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger)) {
+        std::cerr << "Phase II Optimization failed at max frame id " << next_frame_id << std::endl;
+        return false;
+      }
+      if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
+      record(kind + "_phase_2", scope.min_frame_id_, next_frame_id, problem, excluded.size());
+    }
+    if (iteration_params.allow_reversion_after_detecting_jumps_ &&                                                           // :895-905
+        !isConsecutivePosesStable_(pose_graph, scope.min_frame_id_, scope.max_frame_id_, iteration_params.consecutive_pose_transl_tol_, iteration_params.consecutive_pose_orient_tol_)) {
+      std::cerr << "Detecting jumps after optimization. Reverting..." << std::endl;
+      pose_graph->setValuesFromAnotherPoseGraph(pose_graph_copy);
+      records_.push_back({scope.min_frame_id_, next_frame_id, "reverted", 0, 0, 0, 0, 0, 0, 0});
+    }
+    return true;
+  }
+  void record(const std::string& kind, FrameId min_f, FrameId max_f, const obvi::Problem& problem, size_t n_excl) {
+    const obvi::SolverSummary& s = optimizer_.lastSummary();
+    records_.push_back({min_f, max_f, kind, (int)s.iterations.size(), s.initial_cost, s.final_cost, problem.flat.frames.size(), problem.flat.features.size(), problem.flat.objects.size(), n_excl});
+  }
+
+  pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
+  pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams pgo_solver_params_;
+  std::function<FrameId(const FrameId&)> window_provider_func_;
+  std::function<bool(const FrameId&)> gba_checker_;
+  std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)> iteration_params_provider_func_;
+  int device_id_;
+  pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
+  std::vector<OptimizationRecord> records_;
+};
+
+}  // namespace vslam_types_refactor
+#endif  // OBVI_HOST_RUNNER_H_

@@ -134,7 +134,7 @@ def odom_cov(t, aa, m_tt, m_tr, m_rt, m_rr):
 
 
 def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pixel_noise=1.0,
-                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0):
+                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0, stereo=False):
     """Returns a dict of flat arrays accepted by upload(); 'gt_*' hold the ground truth."""
     rng = np.random.Generator(np.random.MT19937(seed))
     rp = RESIDUAL_PARAMS
@@ -182,26 +182,36 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
     obs_pose = np.concatenate(obs_pose).astype(np.uint32)
     obs_point = np.concatenate(obs_point).astype(np.uint32)
     obs_pix = np.concatenate(obs_pix)
+    obs_cam = np.zeros(len(obs_pose), np.uint16)
+    K_all, ext_all = K_DEFAULT[None, :].copy(), EXT_DEFAULT[None, :].copy()
+    if stereo:
+        # second camera 0.12 m to the right of the first (robot -y), same orientation and intrinsics
+        ext2 = EXT_DEFAULT.copy(); ext2[5] = -0.12
+        pix2, z2 = project_points(gt_poses[obs_pose], gt_points[obs_point], K_DEFAULT, ext2)
+        vis2 = (z2 > 0.5) & (pix2[:, 0] > 2) & (pix2[:, 0] < IMG_W - 2) & (pix2[:, 1] > 2) & (pix2[:, 1] < IMG_H - 2)
+        obs_pose = np.concatenate([obs_pose, obs_pose[vis2]]); obs_point = np.concatenate([obs_point, obs_point[vis2]])
+        obs_pix = np.concatenate([obs_pix, pix2[vis2]]); obs_cam = np.concatenate([obs_cam, np.ones(int(vis2.sum()), np.uint16)])
+        K_all = np.stack([K_DEFAULT, K_DEFAULT]); ext_all = np.stack([EXT_DEFAULT, ext2])
     n_r = len(obs_pose)
     obs_pix = obs_pix + rng.normal(size=(n_r, 2)) * pixel_noise
     is_out = rng.uniform(size=n_r) < outlier_frac
     obs_pix[is_out] += rng.uniform(-50, 50, size=(int(is_out.sum()), 2))
     points = gt_points + rng.normal(size=gt_points.shape) * point_noise
     # sort observations by (point, pose): CSC-by-point order, the layout the kernels prefer
-    order = np.lexsort((obs_pose, obs_point))
-    obs_pose, obs_point, obs_pix, is_out = obs_pose[order], obs_point[order], obs_pix[order], is_out[order]
+    order = np.lexsort((obs_cam, obs_pose, obs_point))
+    obs_pose, obs_point, obs_pix, is_out, obs_cam = obs_pose[order], obs_point[order], obs_pix[order], is_out[order], obs_cam[order]
 
-    prob = dict(K=K_DEFAULT[None, :].copy(), ext=EXT_DEFAULT[None, :].copy(),
+    prob = dict(K=K_all, ext=ext_all,
                 poses=poses, gt_poses=gt_poses, pose_const=np.zeros(P, np.uint8),
                 points=points, gt_points=gt_points, point_const=np.zeros(len(points), np.uint8),
-                rp_pose=obs_pose, rp_point=obs_point, rp_cam=np.zeros(n_r, np.uint16), rp_pixel=obs_pix,
+                rp_pose=obs_pose, rp_point=obs_point, rp_cam=obs_cam, rp_pixel=obs_pix,
                 rp_sigma=rp["reproj_sigma"], rp_huber=rp["reproj_huber"], rp_is_outlier=is_out)
     prob["pose_const"][:const_poses] = 1
 
     # ---- objects --------------------------------------------------------------------------
     objects = np.zeros((0, 7)); gt_objects = np.zeros((0, 7))
     bb_obj = np.zeros(0, np.uint32); bb_pose = np.zeros(0, np.uint32); bb_corners = np.zeros((0, 4))
-    sp_mean = np.zeros((0, 3)); sp_cov = np.zeros((0, 9))
+    sp_mean = np.zeros((0, 3)); sp_cov = np.zeros((0, 9)); obj_class = []
     if O > 0:
         names = list(object_classes) if object_classes else list(SHAPE_CLASSES.keys())
         cand_o, cand_corners, cand_pose, cand_gt, cand_cls = [], [], [], [], []
@@ -266,13 +276,14 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
         sd = np.array([SHAPE_CLASSES[names[c]][1] for c in cls_all]).reshape(-1, 3)
         sp_cov[:, np.arange(3), np.arange(3)] = sd ** 2
         sp_cov = sp_cov.reshape(-1, 9)
+        obj_class = [names[c] for c in cls_all]
     n_b = len(bb_obj)
     bb_cov = np.zeros((n_b, 4, 4))
     bb_cov[:, np.arange(4), np.arange(4)] = rp["bbox_var"]
     prob.update(objects=objects, gt_objects=gt_objects, object_const=np.zeros(len(objects), np.uint8),
                 bb_obj=bb_obj, bb_pose=bb_pose, bb_cam=np.zeros(n_b, np.uint16), bb_corners=bb_corners,
                 bb_cov=bb_cov.reshape(-1, 16), bb_huber=rp["bbox_huber"], bb_invalid=rp["invalid_ellipsoid_error"],
-                sp_obj=np.arange(len(objects), dtype=np.uint32), sp_mean=sp_mean, sp_cov=sp_cov, sp_huber=rp["shape_huber"])
+                sp_obj=np.arange(len(objects), dtype=np.uint32), sp_mean=sp_mean, sp_cov=sp_cov, sp_huber=rp["shape_huber"], obj_class=obj_class)
 
     # ---- consecutive-frame odometry factors ----------------------------------------------
     if with_relpose and P > 1:

@@ -244,3 +244,18 @@ def test_full_size_invariants():
     assert abs(g.evaluate(True, False)[0] - c_rob) <= 1e-12 * c_rob                    # snapshot/restore round trip
     s2 = g.solve(helpers.ba_params(max_it=8))
     assert abs(s2.final_cost - s.final_cost) <= 1e-6 * s.final_cost                    # re-running reproduces the solve
+
+
+def test_stereo_rig_matches_oracle():
+    """Two cameras: a point is observed twice from the same pose, which exercises the same-pose observation pairs
+    of the Schur complement (diagonal blocks receive both orders of the pair)."""
+    prob = synth.make_problem(P=25, L=300, O=2, seed=12, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0, stereo=True)
+    assert (prob["rp_cam"] == 1).sum() > 1000
+    o, g = pair(prob)
+    So, bo = o.debug_reduced_system(100.0); Sg, bg = g.debug_reduced_system(100.0)
+    assert rel_err(Sg, So) < 1e-11 and rel_err(bg, bo) < 1e-10
+    so, sg = o.solve(helpers.ba_params(max_it=20)), g.solve(helpers.ba_params(max_it=20))
+    assert sg.num_iterations == so.num_iterations and abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-8
+    # stereo fixes the scale: the solution is close to the truth
+    assert np.linalg.norm(g.get_poses()[:, :3] - prob["gt_poses"][:, :3], axis=1).mean() < 0.05
