@@ -143,15 +143,18 @@ struct CholPlan {
   const int32_t* upd_ij;      // device, 2 per job
   const int32_t* upd_kptr;    // device [jobs+1]    the level's columns k contributing to the target
   const int32_t* upd_k;       // device
+  const uint8_t* upd_flag;    // device [jobs]      1: the target's k-list is split over several jobs -> atomic accumulation
   const int32_t* rh_ptr;      // host [nlevels+1]   right-hand-side jobs: one per target tile row i and level
   const int32_t* rh_i;        // device
   const int32_t* rh_kptr;     // device [jobs+1]
   const int32_t* rh_k;        // device
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
+  const int32_t* back_ptr;    // host [nlevels+1]   backward gather jobs (k, e0, e1): a chunk col_i[e0..e1) of column k
+  const int32_t* back_jobs;   // device, 3 per job
 };
 void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t pad0a, int64_t pad0b, int64_t pad1);
-void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* scal);
+void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

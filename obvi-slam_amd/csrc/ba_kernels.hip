@@ -396,7 +396,11 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
   __shared__ double zsh[kBlock / 64][kPairsPerWave * 36];
   __shared__ double ush[kBlock / 64][kPairsPerWave * 3];
   __shared__ double red[kBlock / 64][42];
-  const int64_t blk = blockIdx.x;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give each XCD a contiguous range of
+  // blocks (sorted by row then column) so the Z records of a pose are re-read from that XCD's L2.
+  const int64_t chunk = (nblk + 7) / 8;
+  const int64_t blk = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (blk >= nblk) return;   // uniform per workgroup
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t row = blk_row[blk], col = blk_col[blk];
   const uint32_t beg = blk_ptr[blk], end = blk_ptr[blk + 1];
@@ -871,7 +875,7 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
-  if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nblk), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
+  if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
 }
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
                           double* points_cand, double* scal) {

@@ -248,9 +248,10 @@ __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int3
 
 // job g < n_upd: tile target (i,j): S_ij -= sum_{k in list} L_ik L_jk^T
 // job g >= n_upd: rhs target i:     b_i  -= sum_{k in list} L_ik z_k
+// A target whose k-list was split over several jobs (flag != 0) accumulates with fp64 hardware atomics.
 __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_upd, const int32_t* __restrict__ upd_ij, const int32_t* __restrict__ upd_kptr,
-                                                    const int32_t* __restrict__ upd_k, const int32_t* __restrict__ rh_i, const int32_t* __restrict__ rh_kptr,
-                                                    const int32_t* __restrict__ rh_k, double* rhs) {
+                                                    const int32_t* __restrict__ upd_k, const uint8_t* __restrict__ upd_flag, const int32_t* __restrict__ rh_i,
+                                                    const int32_t* __restrict__ rh_kptr, const int32_t* __restrict__ rh_k, double* rhs) {
   __shared__ double A[T * LDM];
   __shared__ double B[T * LDM];
   const int tid = threadIdx.x;
@@ -268,10 +269,17 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
     }
     double* C = tile_ptr(S, nt, i, j);
     const int lane = tid & 63, wv = tid >> 6;
+    if (upd_flag[g]) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] -= acc[rt][r];
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(&C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)], -acc[rt][r]);
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] -= acc[rt][r];
+    }
   } else {
     const int h = g - n_upd;
     const int i = rh_i[h];
@@ -291,32 +299,41 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
   }
 }
 
-// backward, one workgroup per tile column k of a level:
-//   y_k = L_kk^-T (z_k - sum_{i in col(k)} L_ik^T y_i)
-__global__ void __launch_bounds__(kThreads) k_backward(const double* S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ col_ptr,
-                                                      const int32_t* __restrict__ col_i, const double* __restrict__ Linv_all, const double* rhs, double* y) {
+// backward substitution of a level in two launches:
+//   gather: job (k, chunk of the column's tiles): acc_k += sum_{i in chunk} L_ik^T y_i    (fp64 atomics into acc)
+//   final : y_k = L_kk^-T (z_k - acc_k)
+__global__ void __launch_bounds__(kThreads) k_backward_gather(const double* S, int nt, const int32_t* __restrict__ jobs, const int32_t* __restrict__ col_i,
+                                                             const double* __restrict__ y, double* acc) {
   __shared__ double part[4][T];
-  __shared__ double tsh[T];
-  const int k = klist[blockIdx.x];
+  const int k = jobs[3 * blockIdx.x], e0 = jobs[3 * blockIdx.x + 1], e1 = jobs[3 * blockIdx.x + 2];
   const int tid = threadIdx.x, c = tid % T, q = tid / T;
   double s = 0.0;
-  for (int e = col_ptr[k]; e < col_ptr[k + 1]; ++e) {
+  for (int e = e0; e < e1; ++e) {
     const int i = col_i[e];
     const double* X = tile_ptr(const_cast<double*>(S), nt, i, k);
     const double* yi = y + (int64_t)i * T;
+#pragma unroll 4
     for (int r = q * 16; r < q * 16 + 16; ++r) s += X[r * T + c] * yi[r];
   }
   part[q][c] = s;
   __syncthreads();
-  if (tid < T) tsh[tid] = rhs[(int64_t)k * T + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+  if (tid < T) unsafeAtomicAdd(acc + (int64_t)k * T + tid, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+}
+__global__ void __launch_bounds__(kThreads) k_backward_final(int nt, const int32_t* __restrict__ klist, const double* __restrict__ Linv_all, const double* __restrict__ rhs,
+                                                            const double* __restrict__ acc, double* y) {
+  __shared__ double part[4][T];
+  __shared__ double tsh[T];
+  const int k = klist[blockIdx.x];
+  const int tid = threadIdx.x, c = tid % T, q = tid / T;
+  if (tid < T) tsh[tid] = rhs[(int64_t)k * T + tid] - acc[(int64_t)k * T + tid];
   __syncthreads();
   const double* Li = Linv_all + (int64_t)k * (T * T);
-  s = 0.0;
+  double s = 0.0;
   for (int i = q * 16; i < q * 16 + 16; ++i) if (i >= c) s += Li[i * T + c] * tsh[i];
-  __syncthreads();
   part[q][c] = s;
   __syncthreads();
   if (tid < T) y[(int64_t)k * T + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  (void)nt;
 }
 
 }  // namespace
@@ -325,8 +342,9 @@ void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile
   if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, pad0a, pad0b, pad1);
 }
 
-void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* Linv, double* rhs, double* y, double* scal) {
+void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal) {
   const int nt = p.nt;
+  (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
   for (int l = 0; l < p.nlevels; ++l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
     hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
@@ -335,11 +353,13 @@ void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* 
     const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
     if (nup + nrh > 0)
       hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k,
-                         p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
+                         p.upd_flag + p.upd_ptr[l], p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
   }
   for (int l = p.nlevels - 1; l >= 0; --l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    hipLaunchKernelGGL(k_backward, dim3(npk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], p.col_ptr, p.col_i, Linv, rhs, y);
+    const int nbj = p.back_ptr[l + 1] - p.back_ptr[l];
+    if (nbj > 0) hipLaunchKernelGGL(k_backward_gather, dim3(nbj), dim3(kThreads), 0, s, S, nt, p.back_jobs + 3 * (int64_t)p.back_ptr[l], p.col_i, y, back_acc);
+    hipLaunchKernelGGL(k_backward_final, dim3(npk), dim3(kThreads), 0, s, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, back_acc, y);
   }
 }
 

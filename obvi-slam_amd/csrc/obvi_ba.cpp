@@ -83,7 +83,9 @@ struct obvi_ba_handle {
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b;
-  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i;
+  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_back_jobs;
+  DevBuf<uint8_t> d_upd_flag;
+  DevBuf<double> d_back_acc;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
   double* h_scal = nullptr;  // pinned
@@ -94,7 +96,7 @@ struct obvi_ba_handle {
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
-  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_back_ptr;
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
   int32_t ntiles = 0;
   int64_t n_trsm_jobs = 0, n_upd_products = 0;
@@ -198,6 +200,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
+  c.upd_flag = h->d_upd_flag.get(); c.back_ptr = h->h_back_ptr.data(); c.back_jobs = h->d_back_jobs.get();
   return c;
 }
 
@@ -386,8 +389,10 @@ void prepare(obvi_ba_handle* h) {
   h->nlevels = nlev;
   std::vector<std::vector<int32_t>> by_level(nlev);
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
-  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k;
-  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0);
+  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, back_jobs;
+  std::vector<uint8_t> upd_flag;
+  const int kUpdChunk = 4, kBackChunk = 6;
+  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_back_ptr.assign(nlev + 1, 0);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
   struct Trip { int32_t i, j, k; };
@@ -408,14 +413,19 @@ void prepare(obvi_ba_handle* h) {
       flops += t3 / 3.0 + t3 * nr + 2.0 * t3 * (nr * (nr + 1) / 2);
     }
     std::sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.i != b.i ? a.i < b.i : (a.j != b.j ? a.j < b.j : a.k < b.k); });
-    for (size_t q = 0; q < trips.size(); ++q) {
-      if (q == 0 || trips[q].i != trips[q - 1].i || trips[q].j != trips[q - 1].j) {
-        if (q != 0) upd_kptr.push_back((int32_t)upd_k.size());
-        upd_ij.push_back(trips[q].i); upd_ij.push_back(trips[q].j);
+    // one job per target tile; a k-list longer than kUpdChunk is split over several jobs that accumulate atomically
+    for (size_t q = 0; q < trips.size();) {
+      size_t e = q;
+      while (e < trips.size() && trips[e].i == trips[q].i && trips[e].j == trips[q].j) ++e;
+      const size_t len = e - q;
+      const uint8_t flag = len > (size_t)kUpdChunk ? 1 : 0;
+      for (size_t c0 = q; c0 < e; c0 += kUpdChunk) {
+        upd_ij.push_back(trips[q].i); upd_ij.push_back(trips[q].j); upd_flag.push_back(flag);
+        for (size_t t = c0; t < std::min(e, c0 + (size_t)kUpdChunk); ++t) upd_k.push_back(trips[t].k);
+        upd_kptr.push_back((int32_t)upd_k.size());
       }
-      upd_k.push_back(trips[q].k);
+      q = e;
     }
-    if (!trips.empty()) upd_kptr.push_back((int32_t)upd_k.size());
     n_products += (int64_t)trips.size();
     std::sort(ik.begin(), ik.end());
     for (size_t q = 0; q < ik.size(); ++q) {
@@ -430,6 +440,9 @@ void prepare(obvi_ba_handle* h) {
     h->h_trsm_ptr[l + 1] = (int32_t)(trsm_ik.size() / 2);
     h->h_upd_ptr[l + 1] = (int32_t)(upd_ij.size() / 2);
     h->h_rh_ptr[l + 1] = (int32_t)rh_i.size();
+    for (int32_t k : by_level[l])
+      for (int32_t e0 = col_ptr[k]; e0 < col_ptr[k + 1]; e0 += kBackChunk) { back_jobs.push_back(k); back_jobs.push_back(e0); back_jobs.push_back(std::min(col_ptr[k + 1], e0 + kBackChunk)); }
+    h->h_back_ptr[l + 1] = (int32_t)(back_jobs.size() / 3);
   }
   h->chol_flops = flops;
   h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
@@ -446,7 +459,8 @@ void prepare(obvi_ba_handle* h) {
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
-  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s);
+  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s); h->d_back_jobs.upload(back_jobs, s);
+  h->d_back_acc.resize((size_t)m_pad);
   h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
   h->d_g.resize((size_t)h->m + 1); h->d_scale.resize((size_t)h->m + 1); h->d_lam.resize((size_t)h->m + 1);
   h->d_S.resize((size_t)nt * nt * kTile * kTile);
@@ -492,7 +506,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   record(h, PH_SCHUR);
   if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   record(h, PH_CHOL);
-  if (solve && h->m > 0) launch_cholesky_solve(s, chol_plan(h), rd.S, h->d_Linv.get(), rd.rhs, rd.y, scal);
+  if (solve && h->m > 0) launch_cholesky_solve(s, chol_plan(h), rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get(), scal);
   record(h, PH_BACKSUB);
   if (solve) launch_point_backsub(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), scal);
   record(h, PH_APPLY);
