@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 CONFIGS = {
     2: dict(name="local-BA 500 KF / 50k features, reprojection only", P=500, L=50000, O=0, const_poses=5),
     3: dict(name="global-BA 2000 KF / 200 objects / 300k features", P=2000, L=300000, O=200, const_poses=1),
+    31: dict(name="(diagnostic) config 3 without objects", P=2000, L=300000, O=0, const_poses=1),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MATRIX_PEAK_TF = 78.6   # MI355X datasheet FP64 matrix (== FP64 vector) rate; not in the guide's table

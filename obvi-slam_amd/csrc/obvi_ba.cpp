@@ -246,7 +246,7 @@ void prepare(obvi_ba_handle* h) {
   h->nPv = h->nOv = h->nLv = 0;
   std::vector<int32_t> nat(P, -1);     // rank among the variable poses in pose-index (frame) order
   for (int64_t p = 0; p < P; ++p) if (!h->h_pose_const[p] && pose_used[p]) nat[p] = (int32_t)h->nPv++;
-  for (int64_t o = 0; o < O; ++o) if (!h->h_object_const[o] && obj_used[o]) obj_vid[o] = (int32_t)h->nOv++;
+  for (int64_t o = 0; o < O; ++o) if (!h->h_object_const[o] && obj_used[o]) obj_vid[o] = (int32_t)h->nOv++;   // provisional: index order
   for (int64_t l = 0; l < L; ++l) if (!h->h_point_const[l] && point_used[l]) { point_var[l] = 1; h->nLv++; }
   const int64_t nPv = h->nPv;
 
@@ -302,13 +302,30 @@ void prepare(obvi_ba_handle* h) {
     for (int64_t k = 0; k < nPv; ++k) pos[order[k]] = (int32_t)k;
     for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
   }
+  // ---- order of the objects inside the border: by the earliest frame that observes them, so that the objects of
+  //      one 64-row tile are neighbours along the trajectory and the tile couples to few subtrees of the pose order
+  {
+    std::vector<int64_t> first_frame(O, INT64_MAX);
+    for (int64_t i = 0; i < h->n_bb; ++i) {
+      if (!h->h_bb_active[i]) continue;
+      const int32_t f = nat[h->h_bb_pose[i]];
+      if (f >= 0) first_frame[h->h_bb_obj[i]] = std::min<int64_t>(first_frame[h->h_bb_obj[i]], f);
+    }
+    std::vector<int64_t> objs;
+    for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) objs.push_back(o);
+    std::stable_sort(objs.begin(), objs.end(), [&](int64_t a, int64_t b) { return first_frame[a] < first_frame[b]; });
+    for (size_t k = 0; k < objs.size(); ++k) obj_vid[objs[k]] = (int32_t)k;
+  }
   h->obj_row0 = ((6 * nPv + kTile - 1) / kTile) * kTile;
   if (h->nOv == 0) h->obj_row0 = 6 * nPv;
   h->m = h->obj_row0 + 7 * h->nOv;
   h->m_canon = 6 * nPv + 7 * h->nOv;
   h->h_canon_row.resize(h->m_canon);
   for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) for (int k = 0; k < 6; ++k) h->h_canon_row[6 * (int64_t)nat[p] + k] = 6 * (int64_t)pose_vid[p] + k;
-  for (int64_t w = 0; w < 7 * h->nOv; ++w) h->h_canon_row[6 * nPv + w] = h->obj_row0 + w;
+  {
+    int64_t rank = 0;   // canonical order = object index order
+    for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) { for (int k = 0; k < 7; ++k) h->h_canon_row[6 * nPv + 7 * rank + k] = h->obj_row0 + 7 * (int64_t)obj_vid[o] + k; ++rank; }
+  }
   h->num_params = h->m_canon + 3 * h->nLv;
   h->num_residuals = nres;
   h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
