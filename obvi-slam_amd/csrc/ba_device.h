@@ -56,8 +56,9 @@ struct ReprojPoseDev {      // the same observations sorted by (pose, point): CS
 struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   int64_t P, L, O;
   int64_t nPv, nOv;         // variable+used poses / objects
-  int64_t obj_row0;         // first reduced row of the object blocks (6 nPv rounded up to a tile boundary)
-  int64_t m;                // obj_row0 + 7 nOv
+  int64_t m;                // rows of the tile grid in use (elimination order, nodes padded to tile boundaries)
+  const int32_t* pose_row;  // [nPv] reduced pose index -> first row of its 6x6 diagonal block in the tile grid
+  const int32_t* obj_row;   // [nOv] reduced object index -> first row of its 7x7 diagonal block
   const int32_t* pose_vid;  // [P]  reduced index or -1
   const int32_t* obj_vid;   // [O]
   const uint8_t* point_var; // [L]
@@ -78,9 +79,9 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
 
 struct ReducedDev {         // accumulators of the reduced system
   double* Hdiag;            // pose v: 36 doubles at 36 v; object w: 49 doubles at 36 nPv + 49 w (row-major, lower part used)
-  double* g;                // [m]   gradient J^T r
-  double* scale;            // [m]   Jacobi scaling (fixed at iteration 0)
-  double* lam;              // [m]   LM damping of the unscaled normal equations
+  double* g;                // [6 nPv + 7 nOv] gradient J^T r (compact index: pose v at 6v, object w at 6 nPv + 7w)
+  double* scale;            // same index: Jacobi scaling (fixed at iteration 0)
+  double* lam;              // same index: LM damping of the unscaled normal equations
   double* S;                // tile grid
   double* rhs;              // [m_pad] right-hand side -> forward-substituted z
   double* y;                // [m_pad] solution
@@ -153,7 +154,7 @@ struct CholPlan {
   const int32_t* back_ptr;    // host [nlevels+1]   backward gather jobs (k, e0, e1): a chunk col_i[e0..e1) of column k
   const int32_t* back_jobs;   // device, 3 per job
 };
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t pad0a, int64_t pad0b, int64_t pad1);
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row);
 void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal);
 
 }  // namespace obvi

@@ -256,14 +256,16 @@ __global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf
       double rho0, w;
       huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
       cost = 0.5 * rho0;
-      const int64_t orow = b.obj_row0 + 7 * (int64_t)ov, prow = 6 * (int64_t)pv;
-      if (ov >= 0) add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + orow, 7, Je, r, 4, w);
-      if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + prow, 6, Jp, r, 4, w);
+      if (ov >= 0) add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, Je, r, 4, w);
+      if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + 6 * (int64_t)pv, 6, Jp, r, 4, w);
       if (ov >= 0 && pv >= 0) {
+        // off-diagonal block in the lower triangle of the tile grid: whichever of the two blocks is eliminated later is the row
+        const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
+        const bool obj_low = orow > prow;
         for (int x = 0; x < 7; ++x) for (int y = 0; y < 6; ++y) {
           double acc = 0.0;
           for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Jp[6 * a + y];
-          atomic_add_f64(S_at(rd.S, rd.nt, orow + x, prow + y), w * acc);
+          atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc);
         }
       }
     }
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFact
         double rho0, w;
         huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + b.obj_row0 + 7 * (int64_t)ov, 7, J, r, 3, w);
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
       }
     }
   } else if (t < sf.n_sp + sf.n_lt) {
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFact
         double rho0, w;
         huber_eval(s, sf.lt_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + b.obj_row0 + 7 * (int64_t)ov, 7, J, r, 7, w);
+        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
       }
     }
   }
@@ -331,10 +333,11 @@ __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev
       if (va >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)va, rd.g + 6 * (int64_t)va, 6, Ja, r, 6, w);
       if (vb >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)vb, rd.g + 6 * (int64_t)vb, 6, Jb, r, 6, w);
       if (va >= 0 && vb >= 0 && va != vb) {
-        const bool b_low = vb > va;  // lower triangle: larger reduced row first
+        const int64_t ra = b.pose_row[va], rb = b.pose_row[vb];
+        const bool b_low = rb > ra;  // lower triangle: the later-eliminated block is the row
         const double* Jr_ = b_low ? Jb : Ja;
         const double* Jc_ = b_low ? Ja : Jb;
-        const int64_t row = 6 * (int64_t)(b_low ? vb : va), col = 6 * (int64_t)(b_low ? va : vb);
+        const int64_t row = b_low ? rb : ra, col = b_low ? ra : rb;
         for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
           double acc = 0.0;
           for (int a = 0; a < 6; ++a) acc += Jr_[6 * a + x] * Jc_[6 * a + y];
@@ -359,17 +362,18 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
     if (vid >= 0) {
       const int d = is_pose ? 6 : 7;
-      const int64_t row = is_pose ? 6 * (int64_t)vid : b.obj_row0 + 7 * (int64_t)vid;
+      const int64_t crow = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;   // compact index (g, scale, lam)
+      const int64_t row = is_pose ? b.pose_row[vid] : b.obj_row[vid];                     // row of the tile grid (S, rhs, y)
       const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
       const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
       for (int k = 0; k < d; ++k) {
         const double c = Hd[d * k + k];
         double s;
-        if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[row + k] = s; } else { s = rd.scale[row + k]; }
+        if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[crow + k] = s; } else { s = rd.scale[crow + k]; }
         const double lam = lm_lambda(c, s, radius);
-        rd.lam[row + k] = lam;
+        rd.lam[crow + k] = lam;
         for (int y = 0; y <= k; ++y) *S_at(rd.S, rd.nt, row + k, row + y) += Hd[d * k + y] + (y == k ? lam : 0.0);
-        const double g = rd.g[row + k];
+        const double g = rd.g[crow + k];
         rd.rhs[row + k] = g;
         gsq += g * g; gmax = fmax(gmax, fabs(g)); xsq += x[k] * x[k];
       }
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
         const int32_t vid = b.pose_vid[rp.pose[a]];
         if (vid < 0) continue;
         const double* Z = pt.Z + 18 * (int64_t)a;
-        const double* y = rd.y + 6 * (int64_t)vid;
+        const double* y = rd.y + b.pose_row[vid];
 #pragma unroll
         for (int x = 0; x < 6; ++x) { t0 -= Z[3 * x] * y[x]; t1 -= Z[3 * x + 1] * y[x]; t2 -= Z[3 * x + 2] * y[x]; }
       }
@@ -505,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
     const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
     double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
-    const int64_t row = is_pose ? 6 * (int64_t)vid : b.obj_row0 + 7 * (int64_t)vid;
+    const int64_t row = vid < 0 ? 0 : (is_pose ? b.pose_row[vid] : b.obj_row[vid]);
     for (int k = 0; k < d; ++k) {
       double v = x[k];
       if (vid >= 0) {

@@ -22,16 +22,15 @@ constexpr int kThreads = 256;
 
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
-// zero the structurally non-zero tiles; identity on padding rows (rows in [pad0a, pad0b) and >= pad1)
-__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int64_t pad0a, int64_t pad0b, int64_t pad1) {
+// zero the structurally non-zero tiles; identity on padding rows
+__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, const uint8_t* __restrict__ is_pad_row) {
   const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
   double* t = tile_ptr(S, nt, ti, tj);
   for (int e = threadIdx.x; e < T * T; e += kThreads) {
     double v = 0.0;
     if (ti == tj) {
       const int r = e / T, c = e % T;
-      const int64_t row = (int64_t)ti * T + r;
-      if (r == c && ((row >= pad0a && row < pad0b) || row >= pad1)) v = 1.0;
+      if (r == c && is_pad_row[(int64_t)ti * T + r]) v = 1.0;
     }
     t[e] = v;
   }
@@ -338,8 +337,8 @@ __global__ void __launch_bounds__(kThreads) k_backward_final(int nt, const int32
 
 }  // namespace
 
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, int64_t pad0a, int64_t pad0b, int64_t pad1) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, pad0a, pad0b, pad1);
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, is_pad_row);
 }
 
 void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal) {

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <numeric>
 #include <string>
@@ -84,7 +85,8 @@ struct obvi_ba_handle {
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_back_jobs;
-  DevBuf<uint8_t> d_upd_flag;
+  DevBuf<uint8_t> d_upd_flag, d_is_pad;
+  DevBuf<int32_t> d_pose_row, d_obj_row;
   DevBuf<double> d_back_acc;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
@@ -92,11 +94,13 @@ struct obvi_ba_handle {
 
   // ---- reduced-program bookkeeping (prepare()) ----
   bool dirty = true;
-  int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, obj_row0 = 0, num_params = 0, num_residuals = 0;
+  int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, num_params = 0, num_residuals = 0;
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
   std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_back_ptr;
+  std::vector<int32_t> h_pose_row, h_obj_row;   // reduced pose / object index -> first row of its diagonal block in the tile grid
+  std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
   int32_t ntiles = 0;
   int64_t n_trsm_jobs = 0, n_upd_products = 0;
@@ -151,7 +155,7 @@ void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
 
 BlocksDev blocks_dev(const obvi_ba_handle* h) {
   BlocksDev b;
-  b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.obj_row0 = h->obj_row0; b.m = h->m;
+  b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.m = h->m; b.pose_row = h->d_pose_row.get(); b.obj_row = h->d_obj_row.get();
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
   return b;
 }
@@ -250,7 +254,7 @@ void prepare(obvi_ba_handle* h) {
   for (int64_t l = 0; l < L; ++l) if (!h->h_point_const[l] && point_used[l]) { point_var[l] = 1; h->nLv++; }
   const int64_t nPv = h->nPv;
 
-  // ---- elimination order of the poses: nested dissection of the frame chain.  reach[f] = largest
+  // ---- elimination order: nested dissection of the frame chain, objects inside the tree.  reach[f] = largest
   //      frame rank f couples to through a shared point or an odometry factor; a separator
   //      [s0, s1) with s1 > reach of everything left of s0 decouples the two sides.  Cut positions
   //      are multiples of 32 poses (= 3 tiles) so tree nodes never share a tile.
@@ -278,57 +282,79 @@ void prepare(obvi_ba_handle* h) {
       const int32_t fa = nat[h->h_rl_a[i]], fb = nat[h->h_rl_b[i]];
       if (fa >= 0 && fb >= 0) reach[std::min(fa, fb)] = std::max(reach[std::min(fa, fb)], std::max(fa, fb));
     }
-    std::vector<int32_t> order; order.reserve(nPv);
+    // ---- the tree: nodes in elimination (post-) order; a node owns the frames [p0,p1) (a leaf, or a separator) and
+    //      covers the frame range [lo,hi) of its subtree
+    struct Node { int32_t lo, hi, p0, p1, left, right; };
+    std::vector<Node> nodes;
     const int32_t G = 32, kLeaf = 160;
-    struct Rng { int32_t lo, hi; bool emit; };
-    std::vector<Rng> stack;
-    stack.push_back({0, (int32_t)nPv, false});
-    while (!stack.empty()) {
-      const Rng r = stack.back(); stack.pop_back();
-      if (r.emit || r.hi - r.lo <= kLeaf) { for (int32_t f = r.lo; f < r.hi; ++f) order.push_back(f); continue; }
-      int32_t s0 = ((r.lo + r.hi) / 2 / G) * G;
-      if (s0 <= r.lo) s0 = r.lo + G;
+    std::function<int32_t(int32_t, int32_t)> build = [&](int32_t lo, int32_t hi) -> int32_t {
+      auto leaf = [&]() { nodes.push_back({lo, hi, lo, hi, -1, -1}); return (int32_t)nodes.size() - 1; };
+      if (hi - lo <= kLeaf) return leaf();
+      int32_t s0 = ((lo + hi) / 2 / G) * G;
+      if (s0 <= lo) s0 = lo + G;
       int32_t far = s0 - 1;
-      for (int32_t f = r.lo; f < s0; ++f) far = std::max(far, reach[f]);
-      int32_t s1 = std::min<int32_t>(r.hi, ((far + 1 + G - 1) / G) * G);
-      if (s1 <= s0) s1 = std::min<int32_t>(r.hi, s0 + G);
-      if (s1 - s0 > (r.hi - r.lo) / 2 || s1 >= r.hi) { for (int32_t f = r.lo; f < r.hi; ++f) order.push_back(f); continue; }
-      // emitted order: left subtree, right subtree, separator  (stack is LIFO: push in reverse)
-      stack.push_back({s0, s1, true});
-      stack.push_back({s1, r.hi, false});
-      stack.push_back({r.lo, s0, false});
-    }
-    std::vector<int32_t> pos(nPv);
-    for (int64_t k = 0; k < nPv; ++k) pos[order[k]] = (int32_t)k;
-    for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
-  }
-  // ---- order of the objects inside the border: by the earliest frame that observes them, so that the objects of
-  //      one 64-row tile are neighbours along the trajectory and the tile couples to few subtrees of the pose order
-  {
-    std::vector<int64_t> first_frame(O, INT64_MAX);
+      for (int32_t f = lo; f < s0; ++f) far = std::max(far, reach[f]);
+      int32_t s1 = std::min<int32_t>(hi, ((far + 1 + G - 1) / G) * G);
+      if (s1 <= s0) s1 = std::min<int32_t>(hi, s0 + G);
+      if (s1 - s0 > (hi - lo) / 2 || s1 >= hi) return leaf();
+      const int32_t l = build(lo, s0), r = build(s1, hi);
+      nodes.push_back({lo, hi, s0, s1, l, r});
+      return (int32_t)nodes.size() - 1;
+    };
+    const int32_t root = nPv > 0 ? build(0, (int32_t)nPv) : -1;
+    // ---- objects: each goes to the deepest node whose subtree covers every frame that observes it (it is then
+    //      eliminated together with that node); inside a node by first observing frame
+    std::vector<int32_t> fa(O, INT32_MAX), fb(O, -1);
     for (int64_t i = 0; i < h->n_bb; ++i) {
       if (!h->h_bb_active[i]) continue;
       const int32_t f = nat[h->h_bb_pose[i]];
-      if (f >= 0) first_frame[h->h_bb_obj[i]] = std::min<int64_t>(first_frame[h->h_bb_obj[i]], f);
+      const uint32_t o = h->h_bb_obj[i];
+      if (f >= 0) { fa[o] = std::min(fa[o], f); fb[o] = std::max(fb[o], f); }
     }
-    std::vector<int64_t> objs;
-    for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) objs.push_back(o);
-    std::stable_sort(objs.begin(), objs.end(), [&](int64_t a, int64_t b) { return first_frame[a] < first_frame[b]; });
-    for (size_t k = 0; k < objs.size(); ++k) obj_vid[objs[k]] = (int32_t)k;
+    std::vector<std::vector<int64_t>> node_objs(nodes.size() + 1);   // last slot: no tree (no variable pose)
+    for (int64_t o = 0; o < O; ++o) {
+      if (obj_vid[o] < 0) continue;
+      int32_t n = root;
+      if (n >= 0 && fb[o] >= 0) {
+        for (;;) {
+          const Node& nd = nodes[n];
+          if (nd.left < 0) break;
+          if (fb[o] < nd.p0) n = nd.left; else if (fa[o] >= nd.p1) n = nd.right; else break;
+        }
+      }
+      node_objs[n >= 0 ? n : (int32_t)nodes.size()].push_back(o);
+    }
+    for (auto& v : node_objs) std::stable_sort(v.begin(), v.end(), [&](int64_t x, int64_t y) { return fa[x] < fa[y]; });
+    // ---- rows of the tile grid: node after node, every node starts on a tile boundary
+    std::vector<int32_t> pos(nPv);
+    h->h_pose_row.assign(nPv, 0); h->h_obj_row.assign(h->nOv, 0);
+    int64_t row = 0;
+    int32_t next_pose = 0, next_obj = 0;
+    std::vector<std::pair<int64_t, int64_t>> used;   // row ranges in use (the rest is padding)
+    auto place_node = [&](int32_t p0, int32_t p1, const std::vector<int64_t>& objs) {
+      row = ((row + kTile - 1) / kTile) * kTile;
+      const int64_t start = row;
+      for (int32_t f = p0; f < p1; ++f) { pos[f] = next_pose; h->h_pose_row[next_pose++] = (int32_t)row; row += 6; }
+      for (int64_t o : objs) { obj_vid[o] = next_obj; h->h_obj_row[next_obj++] = (int32_t)row; row += 7; }
+      if (row > start) used.push_back({start, row});
+    };
+    for (size_t n = 0; n < nodes.size(); ++n) place_node(nodes[n].p0, nodes[n].p1, node_objs[n]);
+    place_node(0, 0, node_objs[nodes.size()]);
+    for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
+    h->m = row;
+    h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
+    h->h_is_pad.assign((size_t)h->nt * kTile, 1);
+    for (const auto& u : used) for (int64_t r = u.first; r < u.second; ++r) h->h_is_pad[r] = 0;
   }
-  h->obj_row0 = ((6 * nPv + kTile - 1) / kTile) * kTile;
-  if (h->nOv == 0) h->obj_row0 = 6 * nPv;
-  h->m = h->obj_row0 + 7 * h->nOv;
   h->m_canon = 6 * nPv + 7 * h->nOv;
   h->h_canon_row.resize(h->m_canon);
-  for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) for (int k = 0; k < 6; ++k) h->h_canon_row[6 * (int64_t)nat[p] + k] = 6 * (int64_t)pose_vid[p] + k;
+  for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) for (int k = 0; k < 6; ++k) h->h_canon_row[6 * (int64_t)nat[p] + k] = (int64_t)h->h_pose_row[pose_vid[p]] + k;
   {
     int64_t rank = 0;   // canonical order = object index order
-    for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) { for (int k = 0; k < 7; ++k) h->h_canon_row[6 * nPv + 7 * rank + k] = h->obj_row0 + 7 * (int64_t)obj_vid[o] + k; ++rank; }
+    for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) { for (int k = 0; k < 7; ++k) h->h_canon_row[6 * nPv + 7 * rank + k] = (int64_t)h->h_obj_row[obj_vid[o]] + k; ++rank; }
   }
   h->num_params = h->m_canon + 3 * h->nLv;
   h->num_residuals = nres;
-  h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
   const int32_t nt = h->nt;
   const int64_t m_pad = (int64_t)nt * kTile;
 
@@ -355,8 +381,8 @@ void prepare(obvi_ba_handle* h) {
   std::vector<uint32_t> blk_row, blk_col, blk_ptr, pair_a(pairs.size()), pair_b(pairs.size());
   for (size_t k = 0; k < pairs.size(); ++k) {
     if (k == 0 || pairs[k].key != pairs[k - 1].key) {
-      blk_row.push_back(6u * (uint32_t)(pairs[k].key / (uint64_t)(h->nPv + 1)));
-      blk_col.push_back(6u * (uint32_t)(pairs[k].key % (uint64_t)(h->nPv + 1)));
+      blk_row.push_back((uint32_t)h->h_pose_row[pairs[k].key / (uint64_t)(h->nPv + 1)]);
+      blk_col.push_back((uint32_t)h->h_pose_row[pairs[k].key % (uint64_t)(h->nPv + 1)]);
       blk_ptr.push_back((uint32_t)k);
     }
     pair_a[k] = pairs[k].a; pair_b[k] = pairs[k].b;
@@ -377,16 +403,16 @@ void prepare(obvi_ba_handle* h) {
   for (int64_t i = 0; i < h->n_bb; ++i) {
     if (!h->h_bb_active[i]) continue;
     const int32_t ov = obj_vid[h->h_bb_obj[i]], pv = pose_vid[h->h_bb_pose[i]];
-    if (ov >= 0 && pv >= 0) mark(h->obj_row0 + 7 * (int64_t)ov, 7, 6 * (int64_t)pv, 6);
+    if (ov >= 0 && pv >= 0) { const int64_t ro = h->h_obj_row[ov], rp = h->h_pose_row[pv]; if (ro > rp) mark(ro, 7, rp, 6); else mark(rp, 6, ro, 7); }
   }
   for (int64_t i = 0; i < h->n_rl; ++i) {
     if (!h->h_rl_active[i]) continue;
     const int32_t va = pose_vid[h->h_rl_a[i]], vb = pose_vid[h->h_rl_b[i]];
-    if (va >= 0 && vb >= 0 && va != vb) mark(6 * (int64_t)std::max(va, vb), 6, 6 * (int64_t)std::min(va, vb), 6);
+    if (va >= 0 && vb >= 0 && va != vb) mark(h->h_pose_row[std::max(va, vb)], 6, h->h_pose_row[std::min(va, vb)], 6);
   }
   // object diagonal blocks may straddle tiles
-  for (int64_t w = 0; w < h->nOv; ++w) mark(h->obj_row0 + 7 * w, 7, h->obj_row0 + 7 * w, 7);
-  for (int64_t v = 0; v < nPv; ++v) mark(6 * v, 6, 6 * v, 6);
+  for (int64_t w = 0; w < h->nOv; ++w) mark(h->h_obj_row[w], 7, h->h_obj_row[w], 7);
+  for (int64_t v = 0; v < nPv; ++v) mark(h->h_pose_row[v], 6, h->h_pose_row[v], 6);
   // symbolic fill (tile columns in increasing order) + column structure of L
   std::vector<int32_t> col_ptr(nt + 1, 0), col_i;
   for (int k = 0; k < nt; ++k) {
@@ -478,8 +504,9 @@ void prepare(obvi_ba_handle* h) {
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
   h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s); h->d_back_jobs.upload(back_jobs, s);
   h->d_back_acc.resize((size_t)m_pad);
+  h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
   h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
-  h->d_g.resize((size_t)h->m + 1); h->d_scale.resize((size_t)h->m + 1); h->d_lam.resize((size_t)h->m + 1);
+  h->d_g.resize((size_t)h->m_canon + 1); h->d_scale.resize((size_t)h->m_canon + 1); h->d_lam.resize((size_t)h->m_canon + 1);
   h->d_S.resize((size_t)nt * nt * kTile * kTile);
   h->d_Linv.resize((size_t)nt * kTile * kTile);
   h->d_rhs.resize((size_t)m_pad); h->d_y.resize((size_t)m_pad);
@@ -510,7 +537,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   h->d_Hdiag.zero(s); h->d_g.zero(s);
   record(h, PH_POSE_CACHE);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, 6 * h->nPv, h->obj_row0, h->m);
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
   h->d_rhs.zero(s);
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal);
@@ -930,7 +957,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
   h->d_Hdiag.zero(s); h->d_g.zero(s); h->d_rhs.zero(s);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, 6 * h->nPv, h->obj_row0, h->m);
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get());
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
