@@ -109,6 +109,10 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt,
                          const ReducedDev& rd);
+// window parameters of k_schur_window, shared with the host code that decides which pairs the window covers
+constexpr int kSchurWindowRows = 24, kSchurWindowOffsets = 16, kSchurMaxObsPerPoint = 36, kSchurChunkFrames = 2;
+void launch_schur_window(hipStream_t s, int64_t nchunks, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
+                         const int32_t* nat_of_pose, const int32_t* row_of_nat, const uint32_t* chunk_ptr, const uint32_t* chunk_points, const int32_t* chunk_f0);
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
                           const double* points, double* points_cand, double* scal);
 void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,

@@ -465,6 +465,93 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
 }
 
 // ---------------------------------------------------------------------------------------
+// K4a.  Schur complement, point-centric with an LDS window.  Points are grouped in chunks by the first frame f0
+// that observes them; a workgroup owns one chunk and accumulates every 6x6 block (fp, fq) with fp - f0 < kSW and
+// fp - fq < kSD (frames in trajectory order) in LDS, so each Z record is read from HBM exactly once (coalesced: a
+// point's records are contiguous) and the window is flushed to the tile grid once per workgroup.  Pairs outside
+// the window (long tracks, loop closures: ~8 % in config #3) are left to k_schur_blocks via the host-built list.
+// ---------------------------------------------------------------------------------------
+constexpr int kSW = kSchurWindowRows, kSD = kSchurWindowOffsets, kSK = kSchurMaxObsPerPoint, kSchurThreads = 512;
+constexpr int kSB = 37;   // doubles per 6x6 block in LDS (odd stride: lanes adding to different blocks hit different banks)
+__global__ void __launch_bounds__(kSchurThreads) k_schur_window(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const int32_t* __restrict__ nat_of_pose,
+                                                               const int32_t* __restrict__ row_of_nat, const uint32_t* __restrict__ chunk_ptr,
+                                                               const uint32_t* __restrict__ chunk_points, const int32_t* __restrict__ chunk_f0) {
+  __shared__ double acc[kSW * kSD * kSB];
+  __shared__ double rhsw[kSW * 6];
+  __shared__ double zsh[kSchurThreads / 64][kSK * 18];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t f0 = chunk_f0[blockIdx.x];
+  for (int i = tid; i < kSW * kSD * kSB; i += kSchurThreads) acc[i] = 0.0;
+  for (int i = tid; i < kSW * 6; i += kSchurThreads) rhsw[i] = 0.0;
+  __syncthreads();
+  double* zs = zsh[wv];
+  for (uint32_t pi = chunk_ptr[blockIdx.x] + wv; pi < chunk_ptr[blockIdx.x + 1]; pi += kSchurThreads / 64) {
+    const uint32_t l = chunk_points[pi];
+    const uint32_t beg = rp.point_ptr[l];
+    const int k = (int)(rp.point_ptr[l + 1] - beg);   // <= kSK (host guarantees)
+    int f_mine = -1;
+    if (lane < k && rp.active[beg + lane]) f_mine = nat_of_pose[rp.pose[beg + lane]];
+    const double* Zg = pt.Z + 18 * (int64_t)beg;
+    for (int idx = lane; idx < 18 * k; idx += 64) zs[idx] = Zg[idx];
+    const double u0 = pt.u[3 * (int64_t)l], u1 = pt.u[3 * (int64_t)l + 1], u2 = pt.u[3 * (int64_t)l + 2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // one lane per observation pair (i >= j in pose order => f_i >= f_j); the lane forms the whole 6x6 product
+    const int npairs = k * (k + 1) / 2;
+    for (int base = 0; base < npairs; base += 64) {
+      const int q = base + lane;
+      int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+      while ((i + 1) * (i + 2) / 2 <= q) ++i;
+      while (i * (i + 1) / 2 > q) --i;
+      const int j = q - i * (i + 1) / 2;
+      const int ic = min(i, k - 1), jc = min(j, k - 1);
+      const int fi = __shfl(f_mine, ic, 64), fj = __shfl(f_mine, jc, 64);
+      const int ri = fi - f0, d = fi - fj;
+      if (q < npairs && fi >= 0 && fj >= 0 && ri < kSW && d < kSD) {
+        double zi[18], zj[18];
+#pragma unroll
+        for (int c = 0; c < 18; ++c) { zi[c] = zs[18 * i + c]; zj[c] = zs[18 * j + c]; }
+        double* blk = &acc[(ri * kSD + d) * kSB];
+        const bool twin = (d == 0) && (i != j);   // two observations from one frame (stereo): both orders land in the diagonal block
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y < 6; ++y) {
+            const double v = zi[3 * x] * zj[3 * y] + zi[3 * x + 1] * zj[3 * y + 1] + zi[3 * x + 2] * zj[3 * y + 2];
+            atomicAdd(&blk[6 * x + y], v);
+            if (twin) atomicAdd(&blk[6 * y + x], v);
+          }
+      }
+    }
+    if (lane < k && f_mine >= 0 && f_mine - f0 < kSW) {
+      const double* Zi = zs + 18 * lane;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) atomicAdd(&rhsw[(f_mine - f0) * 6 + x], Zi[3 * x] * u0 + Zi[3 * x + 1] * u1 + Zi[3 * x + 2] * u2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // zs is overwritten by the next point
+  }
+  __syncthreads();
+  // flush the window: element (x,y) of block (fp, fq), lower triangle of the tile grid
+  for (int idx = tid; idx < kSW * kSD * 36; idx += kSchurThreads) {
+    const int e = idx % 36, blkid = idx / 36;
+    const double v = acc[blkid * kSB + e];
+    if (v == 0.0) continue;
+    const int dd = blkid % kSD, ri = blkid / kSD;
+    const int fp = f0 + ri, fq = fp - dd;
+    const int x = e / 6, y = e % 6;
+    const int64_t rp_ = row_of_nat[fp], rq_ = row_of_nat[fq];
+    if (dd == 0) { if (y <= x) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rp_ + y), -v); }
+    else if (rp_ > rq_) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rq_ + y), -v);
+    else atomic_add_f64(S_at(rd.S, rd.nt, rq_ + y, rp_ + x), -v);
+  }
+  for (int idx = tid; idx < kSW * 6; idx += kSchurThreads) {
+    const double v = rhsw[idx];
+    if (v != 0.0) atomic_add_f64(rd.rhs + row_of_nat[f0 + idx / 6] + idx % 6, -v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // K6.  Back-substitution of the eliminated points, candidate point.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points,
@@ -880,6 +967,10 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
   if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
+}
+void launch_schur_window(hipStream_t s, int64_t nchunks, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
+                         const int32_t* nat_of_pose, const int32_t* row_of_nat, const uint32_t* chunk_ptr, const uint32_t* chunk_points, const int32_t* chunk_f0) {
+  if (nchunks > 0) hipLaunchKernelGGL(k_schur_window, dim3((unsigned)nchunks), dim3(kSchurThreads), 0, s, b, rp, pt, rd, nat_of_pose, row_of_nat, chunk_ptr, chunk_points, chunk_f0);
 }
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
                           double* points_cand, double* scal) {

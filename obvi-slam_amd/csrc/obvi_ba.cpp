@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -83,7 +84,9 @@ struct obvi_ba_handle {
   // ---- device: reduced system ----
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
-  DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b;
+  DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b, d_chunk_ptr, d_chunk_points;
+  DevBuf<int32_t> d_nat_of_pose, d_row_of_nat, d_chunk_f0;
+  int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_back_jobs;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
   DevBuf<int32_t> d_pose_row, d_obj_row;
@@ -99,7 +102,7 @@ struct obvi_ba_handle {
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
   std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_back_ptr;
-  std::vector<int32_t> h_pose_row, h_obj_row;   // reduced pose / object index -> first row of its diagonal block in the tile grid
+  std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
   int32_t ntiles = 0;
@@ -286,7 +289,8 @@ void prepare(obvi_ba_handle* h) {
     //      covers the frame range [lo,hi) of its subtree
     struct Node { int32_t lo, hi, p0, p1, left, right; };
     std::vector<Node> nodes;
-    const int32_t G = 32, kLeaf = 160;
+    const int32_t G = 32;
+    const int32_t kLeaf = std::getenv("OBVI_ND_LEAF") ? std::atoi(std::getenv("OBVI_ND_LEAF")) : 160;   // tuning knob (poses per leaf)
     std::function<int32_t(int32_t, int32_t)> build = [&](int32_t lo, int32_t hi) -> int32_t {
       auto leaf = [&]() { nodes.push_back({lo, hi, lo, hi, -1, -1}); return (int32_t)nodes.size() - 1; };
       if (hi - lo <= kLeaf) return leaf();
@@ -341,6 +345,8 @@ void prepare(obvi_ba_handle* h) {
     for (size_t n = 0; n < nodes.size(); ++n) place_node(nodes[n].p0, nodes[n].p1, node_objs[n]);
     place_node(0, 0, node_objs[nodes.size()]);
     for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
+    h->h_row_of_nat.resize(nPv);
+    for (int64_t f = 0; f < nPv; ++f) h->h_row_of_nat[f] = h->h_pose_row[pos[f]];
     h->m = row;
     h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
     h->h_is_pad.assign((size_t)h->nt * kTile, 1);
@@ -358,25 +364,63 @@ void prepare(obvi_ba_handle* h) {
   const int32_t nt = h->nt;
   const int64_t m_pad = (int64_t)nt * kTile;
 
-  // ---- Schur pair lists: per eliminated point, all ordered observation pairs (a, b) with reduced
-  //      row(a) >= row(b); grouped by 6x6 block (row, col) of the Schur complement.
+  // ---- Schur complement work lists.  Points are chunked by the first frame (trajectory order) that observes them;
+  //      k_schur_window accumulates the pairs whose block falls inside the chunk's LDS window, the remaining ordered
+  //      pairs (a, b) with row(a) >= row(b) go to k_schur_blocks grouped by 6x6 block.  The tile mask gets every block.
+  const int32_t nt_ = h->nt;
+  std::vector<uint8_t> mask((size_t)nt_ * nt_, 0);
+  auto mark = [&](int64_t row, int dr, int64_t col, int dc) {
+    const int t0 = (int)(row / kTile), t1 = (int)((row + dr - 1) / kTile), c0 = (int)(col / kTile), c1 = (int)((col + dc - 1) / kTile);
+    for (int ti = t0; ti <= t1; ++ti) for (int tj = c0; tj <= c1; ++tj) if (ti >= tj) mask[(size_t)ti * nt_ + tj] = 1;
+  };
   struct Pair { uint64_t key; uint32_t a, b; };
   std::vector<Pair> pairs;
+  std::vector<uint32_t> chunk_ptr(1, 0), chunk_points;
+  std::vector<int32_t> chunk_f0;
+  int64_t n_window_pairs = 0;
   {
-    std::vector<std::pair<uint32_t, int32_t>> obs;  // (sorted obs index, pose vid)
+    struct Ob { uint32_t a; int32_t vid, f; };
+    std::vector<Ob> obs;
+    std::vector<std::pair<int32_t, int64_t>> by_first;   // (first frame, point) of the points handled by the window kernel
+    std::vector<int32_t> first_of(L, -1);
+    for (int64_t l = 0; l < L; ++l) {
+      if (!point_var[l]) continue;
+      int32_t f1 = INT32_MAX;
+      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a)
+        if (h->h_rp_active[a] && nat[h->h_rp_pose[a]] >= 0) f1 = std::min(f1, nat[h->h_rp_pose[a]]);
+      if (f1 == INT32_MAX) continue;
+      const bool oversized = (int64_t)(h->h_point_ptr[l + 1] - h->h_point_ptr[l]) > kSchurMaxObsPerPoint;
+      if (!oversized) { by_first.push_back({f1, l}); first_of[l] = (f1 / kSchurChunkFrames) * kSchurChunkFrames; }
+    }
+    std::sort(by_first.begin(), by_first.end());
+    for (size_t q = 0; q < by_first.size(); ++q) {
+      const int32_t c0 = (by_first[q].first / kSchurChunkFrames) * kSchurChunkFrames;
+      if (chunk_f0.empty() || chunk_f0.back() != c0) { if (!chunk_f0.empty()) chunk_ptr.push_back((uint32_t)chunk_points.size()); chunk_f0.push_back(c0); }
+      chunk_points.push_back((uint32_t)by_first[q].second);
+    }
+    if (!chunk_f0.empty()) chunk_ptr.push_back((uint32_t)chunk_points.size());
     for (int64_t l = 0; l < L; ++l) {
       if (!point_var[l]) continue;
       obs.clear();
       for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
         if (!h->h_rp_active[a]) continue;
         const int32_t v = pose_vid[h->h_rp_pose[a]];
-        if (v >= 0) obs.push_back({a, v});
+        if (v >= 0) obs.push_back({a, v, nat[h->h_rp_pose[a]]});
       }
-      for (const auto& x : obs)
-        for (const auto& y : obs)
-          if (x.second >= y.second) pairs.push_back({(uint64_t)x.second * (uint64_t)(h->nPv + 1) + (uint64_t)y.second, x.first, y.first});
+      const int32_t f0 = first_of[l];
+      for (const Ob& x : obs)
+        for (const Ob& y : obs) {
+          if (x.vid < y.vid) continue;
+          mark(h->h_pose_row[x.vid], 6, h->h_pose_row[y.vid], 6);
+          // covered by the LDS window?  (the window indexes by trajectory order: the later frame is the window row)
+          const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
+          if (f0 >= 0 && fp - f0 < kSchurWindowRows && fp - fq < kSchurWindowOffsets) { ++n_window_pairs; continue; }
+          pairs.push_back({(uint64_t)x.vid * (uint64_t)(h->nPv + 1) + (uint64_t)y.vid, x.a, y.a});
+        }
     }
   }
+  h->nchunks = (int64_t)chunk_f0.size();
+  h->npairs_window = n_window_pairs;
   std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key || (x.key == y.key && (x.a < y.a || (x.a == y.a && x.b < y.b))); });
   std::vector<uint32_t> blk_row, blk_col, blk_ptr, pair_a(pairs.size()), pair_b(pairs.size());
   for (size_t k = 0; k < pairs.size(); ++k) {
@@ -393,13 +437,7 @@ void prepare(obvi_ba_handle* h) {
   pairs.clear(); pairs.shrink_to_fit();
 
   // ---- tile mask of the reduced matrix (lower triangle) and symbolic fill ----
-  std::vector<uint8_t> mask((size_t)nt * nt, 0);
-  auto mark = [&](int64_t row, int dr, int64_t col, int dc) {
-    const int t0 = (int)(row / kTile), t1 = (int)((row + dr - 1) / kTile), c0 = (int)(col / kTile), c1 = (int)((col + dc - 1) / kTile);
-    for (int ti = t0; ti <= t1; ++ti) for (int tj = c0; tj <= c1; ++tj) if (ti >= tj) mask[(size_t)ti * nt + tj] = 1;
-  };
   for (int k = 0; k < nt; ++k) mask[(size_t)k * nt + k] = 1;
-  for (int64_t b = 0; b < h->nblk; ++b) mark(blk_row[b], 6, blk_col[b], 6);
   for (int64_t i = 0; i < h->n_bb; ++i) {
     if (!h->h_bb_active[i]) continue;
     const int32_t ov = obj_vid[h->h_bb_obj[i]], pv = pose_vid[h->h_bb_pose[i]];
@@ -499,6 +537,8 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
   h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
+  h->d_chunk_ptr.upload(chunk_ptr, s); h->d_chunk_points.upload(chunk_points, s); h->d_chunk_f0.upload(chunk_f0, s);
+  h->d_nat_of_pose.upload(nat, s); h->d_row_of_nat.upload(h->h_row_of_nat, s);
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
@@ -548,7 +588,8 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   record(h, PH_DIAG);
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
   record(h, PH_SCHUR);
-  if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  if (solve) { launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
+    launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd); }
   record(h, PH_CHOL);
   if (solve && h->m > 0) launch_cholesky_solve(s, chol_plan(h), rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get(), scal);
   record(h, PH_BACKSUB);
@@ -962,7 +1003,8 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
-  launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  { launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
+    launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd); }
   const int64_t mc = h->m_canon, nt = h->nt;
   std::vector<double> tiles((size_t)nt * nt * kTile * kTile), hr((size_t)nt * kTile);
   std::vector<int32_t> tl((size_t)2 * h->ntiles);
@@ -1241,7 +1283,7 @@ int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap)
   int64_t act_rp = 0, act_bb = 0;
   for (uint8_t a : h->h_rp_active) act_rp += a != 0;
   for (uint8_t a : h->h_bb_active) act_bb += a != 0;
-  const double v[14] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m_canon, (double)h->nt, (double)h->nblk, (double)h->npairs,
+  const double v[14] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m_canon, (double)h->nt, (double)h->nblk, (double)(h->npairs + h->npairs_window),
                         (double)h->ntiles, (double)h->n_trsm_jobs, (double)h->n_upd_products, h->chol_flops, (double)act_rp, (double)act_bb,
                         (double)h->nlevels};
   const int n = std::min<int>(cap, 14);
