@@ -20,6 +20,15 @@ constexpr int T = kTile;        // 64
 constexpr int LD = T + 1;       // LDS leading dimension (bank-conflict padding)
 constexpr int kThreads = 256;
 
+// 1/sqrt(p): hardware v_rsq_f64 seed + two Newton steps (full fp64 accuracy for normal positive p)
+__device__ __forceinline__ double fast_rsqrt(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  double e = fma(-p * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  e = fma(-p * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  return y;
+}
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
 // zero the structurally non-zero tiles; identity on padding rows
@@ -41,43 +50,63 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 // (rows 4ty.., cols 4tx..) in registers.  Right-looking over 16 panels of 4 columns; then
 // L^-1 by a right-looking blocked forward substitution on the identity (same structure).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
+#ifdef OBVI_POTRF_TIMING
+#define OBVI_TICK(i) if (threadIdx.x == 0 && tdbg) tdbg[8 * blockIdx.x + (i)] = __builtin_readcyclecounter()
+#define OBVI_PH(var) var += __builtin_readcyclecounter() - tph; tph = __builtin_readcyclecounter()
+__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal, unsigned long long* tdbg) {
+#else
+#define OBVI_TICK(i)
+#define OBVI_PH(var)
+__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
+#endif
   __shared__ double Lsh[T * LD];       // L (lower), later L^-1
   __shared__ double Dsh[16 * 16];      // inverse of the 16 diagonal 4x4 blocks of L
   __shared__ double Wsh[16 * 16];      // row-block r of L^-1 during the inverse phase
   __shared__ double zsh[T];
   const int k = klist[blockIdx.x];
   double* tile = tile_ptr(S, nt, k, k);
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  // wavefronts 0-3 factorise, wavefronts 4-7 build L^-1 concurrently (same (ty,tx) block map, same barriers)
+  const int tid = threadIdx.x & 255, ty = tid >> 4, tx = tid & 15;
+  const bool fac = threadIdx.x < 256;
+  OBVI_TICK(0);
   double a[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[i][j] = tile[(4 * ty + i) * T + 4 * tx + j];
-  if (tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
-  if (ty < tx) {
+  if (fac && tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
+  if (fac && ty < tx) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * tx + j] = 0.0;
   }
   double bad = 0.0;
+  // W = L^-1 is built in the same 16 steps by the threads that are idle in the factorisation (blocks left of the
+  // panel): row-block kb of W is finished in step kb, blocks below it receive  w -= L(ty,kb) W(kb,tx).
+  double w[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
+  __syncthreads();
+  OBVI_TICK(1);
+  unsigned long long tph = __builtin_readcyclecounter(), ph1 = 0, ph2 = 0, ph3 = 0; (void)tph; (void)ph1; (void)ph2; (void)ph3;
   for (int kb = 0; kb < 16; ++kb) {
-    if (ty == kb && tx == kb) {
-      // 4x4 Cholesky in registers + its inverse
-      // division-free: i = rsqrt(pivot), l = pivot * i
+    if (fac && ty == kb && tx == kb) {
+      // 4x4 Cholesky in registers + its inverse; division-free: i = rsqrt(pivot), l = pivot * i
       double p;
       p = a[0][0]; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i00 = rsqrt(p), l00 = p * i00;
+      const double i00 = fast_rsqrt(p), l00 = p * i00;
       const double l10 = a[1][0] * i00, l20 = a[2][0] * i00, l30 = a[3][0] * i00;
       p = a[1][1] - l10 * l10; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i11 = rsqrt(p), l11 = p * i11;
+      const double i11 = fast_rsqrt(p), l11 = p * i11;
       const double l21 = (a[2][1] - l20 * l10) * i11, l31 = (a[3][1] - l30 * l10) * i11;
       p = a[2][2] - l20 * l20 - l21 * l21; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i22 = rsqrt(p), l22 = p * i22;
+      const double i22 = fast_rsqrt(p), l22 = p * i22;
       const double l32 = (a[3][2] - l30 * l20 - l31 * l21) * i22;
       p = a[3][3] - l30 * l30 - l31 * l31 - l32 * l32; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i33 = rsqrt(p), l33 = p * i33;
+      const double i33 = fast_rsqrt(p), l33 = p * i33;
       a[0][0] = l00; a[0][1] = 0; a[0][2] = 0; a[0][3] = 0;
       a[1][0] = l10; a[1][1] = l11; a[1][2] = 0; a[1][3] = 0;
       a[2][0] = l20; a[2][1] = l21; a[2][2] = l22; a[2][3] = 0;
@@ -92,7 +121,8 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
       D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i33;
     }
     __syncthreads();
-    if (tx == kb && ty >= kb) {
+    OBVI_PH(ph1);
+    if (fac && tx == kb && ty >= kb) {
       if (ty > kb) {
         // X = A_blk * D^T  (D = inverse of the diagonal block's L)
         const double* D = Dsh + 16 * kb;
@@ -116,35 +146,9 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
 #pragma unroll
         for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * kb + j] = a[i][j];
     }
-    __syncthreads();
-    if (tx > kb && ty >= tx) {
-      double pr[4][4], pc[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { pr[i][t] = Lsh[(4 * ty + i) * LD + 4 * kb + t]; pc[i][t] = Lsh[(4 * tx + i) * LD + 4 * kb + t]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[i][j] -= pr[i][0] * pc[j][0] + pr[i][1] * pc[j][1] + pr[i][2] * pc[j][2] + pr[i][3] * pc[j][3];
-    }
-  }
-  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
-  // store L (zeros above the diagonal)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tile[(4 * ty + i) * T + 4 * tx + j] = (ty >= tx) ? a[i][j] : 0.0;
-  // ---- W = L^-1: acc starts as the identity, row-block r is finished at step r ----
-  double w[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
-  for (int r = 0; r < 16; ++r) {
-    __syncthreads();   // Wsh free (previous step's readers done); Lsh complete on the first pass
-    if (ty == r && tx <= r) {
-      const double* D = Dsh + 16 * r;
+    if (!fac && ty == kb && tx <= kb) {
+      // row-block kb of W:  W(kb,tx) = D * acc
+      const double* D = Dsh + 16 * kb;
       double x[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -161,28 +165,56 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
         for (int j = 0; j < 4; ++j) { w[i][j] = x[i][j]; Wsh[16 * tx + 4 * i + j] = x[i][j]; }
     }
     __syncthreads();
-    if (ty > r && tx <= r) {
+    OBVI_PH(ph2);
+    if (fac && tx > kb && ty >= tx) {
+      double pr[4][4], pc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { pr[i][t] = Lsh[(4 * ty + i) * LD + 4 * kb + t]; pc[i][t] = Lsh[(4 * tx + i) * LD + 4 * kb + t]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i][j] -= pr[i][0] * pc[j][0] + pr[i][1] * pc[j][1] + pr[i][2] * pc[j][2] + pr[i][3] * pc[j][3];
+    } else if (!fac && ty > kb && tx <= kb) {
       const double* Wr = Wsh + 16 * tx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const double l0 = Lsh[(4 * ty + i) * LD + 4 * r], l1 = Lsh[(4 * ty + i) * LD + 4 * r + 1], l2 = Lsh[(4 * ty + i) * LD + 4 * r + 2], l3 = Lsh[(4 * ty + i) * LD + 4 * r + 3];
+        const double l0 = Lsh[(4 * ty + i) * LD + 4 * kb], l1 = Lsh[(4 * ty + i) * LD + 4 * kb + 1], l2 = Lsh[(4 * ty + i) * LD + 4 * kb + 2], l3 = Lsh[(4 * ty + i) * LD + 4 * kb + 3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[i][j] -= l0 * Wr[j] + l1 * Wr[4 + j] + l2 * Wr[8 + j] + l3 * Wr[12 + j];
       }
     }
+    OBVI_PH(ph3);
+  }
+#ifdef OBVI_POTRF_TIMING
+  if (threadIdx.x == 0 && tdbg) { tdbg[8 * blockIdx.x + 6] = ph1; tdbg[8 * blockIdx.x + 7] = ph2; tdbg[8 * blockIdx.x + 5] = ph3; }
+#endif
+  OBVI_TICK(2);
+  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  // store L (zeros above the diagonal)
+  if (fac) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[(4 * ty + i) * T + 4 * tx + j] = (ty >= tx) ? a[i][j] : 0.0;
+  }
+  OBVI_TICK(3);
+  __syncthreads();
+  OBVI_TICK(4);
+  double* Li = Linv_all + (int64_t)k * (T * T);
+  if (!fac) {   // the inverse wavefronts hold W
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = (ty >= tx) ? w[i][j] : 0.0;
+        Li[(4 * ty + i) * T + 4 * tx + j] = v;
+        Lsh[(4 * ty + i) * LD + 4 * tx + j] = v;
+      }
   }
   __syncthreads();
-  double* Li = Linv_all + (int64_t)k * (T * T);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double v = (ty >= tx) ? w[i][j] : 0.0;
-      Li[(4 * ty + i) * T + 4 * tx + j] = v;
-      Lsh[(4 * ty + i) * LD + 4 * tx + j] = v;
-    }
-  __syncthreads();
-  {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
+  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
     const int r = tid >> 2, part = tid & 3;
     double s = 0.0;
 #pragma unroll
@@ -191,6 +223,9 @@ __global__ void __launch_bounds__(kThreads) k_potrf(double* S, int nt, const int
     s += __shfl_xor(s, 2, 64);
     if (part == 0) rhs[(int64_t)k * T + r] = s;
   }
+#ifndef OBVI_POTRF_TIMING
+  OBVI_TICK(5);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -346,7 +381,11 @@ void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* 
   (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
   for (int l = 0; l < p.nlevels; ++l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
+#ifdef OBVI_POTRF_TIMING
+    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal, (unsigned long long*)nullptr);
+#else
+    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
+#endif
     const int ntr = p.trsm_ptr[l + 1] - p.trsm_ptr[l];
     if (ntr > 0) hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv);
     const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
