@@ -133,6 +133,15 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
                                   const double* poses, const double* objects, double* r, double* J0, double* J1);
 void launch_fill(hipStream_t s, double* p, int64_t n, double v);
 
+// ---- outlier selection (select_kernels.hip) ---------------------------------------------
+struct SelectScratch {
+  void *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr, *head = nullptr, *rank = nullptr, *counters = nullptr, *tmp = nullptr;
+  size_t cap_keys_in = 0, cap_keys_out = 0, cap_vals_in = 0, cap_vals_out = 0, cap_head = 0, cap_rank = 0, cap_counters = 0, cap_tmp = 0;
+};
+hipError_t select_outliers_device(hipStream_t s, int64_t n, const double* sq, const uint8_t* active, const uint32_t* inv, double fraction,
+                                  uint8_t* mask_out, int* n_excluded_host, SelectScratch* scratch);
+void select_scratch_free(SelectScratch* sc);
+
 // ---- tile Cholesky (chol_kernels.hip) --------------------------------------------------
 // Symbolic factorisation at tile granularity, level-scheduled: tile columns in one level of the
 // tile elimination tree do not depend on each other and are processed by the same launches.

@@ -93,6 +93,9 @@ struct obvi_ba_handle {
   DevBuf<double> d_back_acc;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
+  DevBuf<uint8_t> d_sel_mask;
+  DevBuf<uint32_t> d_rp_inv;
+  SelectScratch sel_scratch;
   double* h_scal = nullptr;  // pinned
 
   // ---- reduced-program bookkeeping (prepare()) ----
@@ -681,6 +684,7 @@ void obvi_ba_destroy(obvi_ba_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  select_scratch_free(&h->sel_scratch);
   // DevBuf members free in ~obvi_ba_handle
   hipStream_t s = h->stream;
   delete h;
@@ -1204,36 +1208,26 @@ int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out,
 int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
-  const int64_t nfac = h->n_rp + h->n_bb + h->n_sp + h->n_lt + h->n_rl;
-  std::vector<double> sq((size_t)nfac);
-  const int rc = obvi_ba_evaluate(h, 0, nullptr, nullptr, sq.data());
+  // un-robustified per-block squared norms at the current estimate (object_pose_graph_optimizer.h:682-693), kept on the device
+  const int rc = obvi_ba_evaluate(h, 0, nullptr, nullptr, nullptr);
   if (rc != OBVI_OK) return rc;
   int64_t off = 0, n = 0;
-  const std::vector<uint8_t>* act = nullptr;
+  const uint8_t* act = nullptr;
+  const uint32_t* inv = nullptr;
   switch (type) {
-    case OBVI_FACTOR_REPROJECTION: off = 0; n = h->n_rp; act = &h->h_rp_active; break;
-    case OBVI_FACTOR_BBOX: off = h->n_rp; n = h->n_bb; act = &h->h_bb_active; break;
-    case OBVI_FACTOR_SHAPE_PRIOR: off = h->n_rp + h->n_bb; n = h->n_sp; act = &h->h_sp_active; break;
-    case OBVI_FACTOR_LTM_PRIOR: off = h->n_rp + h->n_bb + h->n_sp; n = h->n_lt; act = &h->h_lt_active; break;
-    case OBVI_FACTOR_REL_POSE: off = h->n_rp + h->n_bb + h->n_sp + h->n_lt; n = h->n_rl; act = &h->h_rl_active; break;
+    case OBVI_FACTOR_REPROJECTION: off = 0; n = h->n_rp; act = h->d_rp_active.get(); h->d_rp_inv.upload(h->h_rp_inv, h->stream); inv = h->d_rp_inv.get(); break;
+    case OBVI_FACTOR_BBOX: off = h->n_rp; n = h->n_bb; act = h->d_bb_active.get(); break;
+    case OBVI_FACTOR_SHAPE_PRIOR: off = h->n_rp + h->n_bb; n = h->n_sp; act = h->d_sp_active.get(); break;
+    case OBVI_FACTOR_LTM_PRIOR: off = h->n_rp + h->n_bb + h->n_sp; n = h->n_lt; act = h->d_lt_active.get(); break;
+    case OBVI_FACTOR_REL_POSE: off = h->n_rp + h->n_bb + h->n_sp + h->n_lt; n = h->n_rl; act = h->d_rl_active.get(); break;
     default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "select_outliers: unknown factor type");
   }
-  // offline_problem_runner.h:769-800: std::map keyed by the squared residual (descending); equal
-  // keys collapse, n_outliers = floor(map.size() * fraction), first n entries excluded.
-  std::vector<std::pair<double, int64_t>> v;
-  v.reserve((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    const bool a = type == OBVI_FACTOR_REPROJECTION ? (*act)[h->h_rp_inv[i]] != 0 : (*act)[i] != 0;
-    mask_out[i] = a ? 1 : 0;
-    if (a) v.push_back({sq[(size_t)(off + i)], i});
-  }
-  std::sort(v.begin(), v.end(), [](const std::pair<double, int64_t>& x, const std::pair<double, int64_t>& y) { return x.first > y.first || (x.first == y.first && x.second > y.second); });
-  size_t distinct = 0;
-  for (size_t k = 0; k < v.size(); ++k) if (k == 0 || v[k].first != v[k - 1].first) ++distinct;
-  const size_t n_out = (size_t)(distinct * fraction);
-  size_t taken = 0;
-  for (size_t k = 0; k < v.size() && taken < n_out; ++k) if (k == 0 || v[k].first != v[k - 1].first) { mask_out[v[k].second] = 0; ++taken; }
-  if (num_excluded) *num_excluded = (int64_t)n_out;
+  h->d_sel_mask.resize((size_t)n + 1);
+  int n_out = 0;
+  OBVI_HIP(select_outliers_device(h->stream, n, h->d_eval_sq.get() + off, act, inv, fraction, h->d_sel_mask.get(), &n_out, &h->sel_scratch));
+  h->d_sel_mask.download(mask_out, (size_t)n, h->stream);
+  sync(h);
+  if (num_excluded) *num_excluded = n_out;
   return OBVI_OK;
   OBVI_API_END(h)
 }
