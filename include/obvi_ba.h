@@ -212,13 +212,22 @@ int obvi_ba_get_objects(obvi_ba_handle* h, double* out /*[n][7]*/);
  * pose_graph_plus_objects_optimizer.h:238-283) */
 int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
 
-/* ---- multi-GPU (no reference counterpart) ------------------------------- */
-/* Called on the handle's stream between linearisation and the reduced solve of every LM
- * step with the device buffer of packed shared-object blocks [n_obj][7*7 + 7 + 1]
- * (H_oo, g_o, cost share).  The callee sums it across ranks in place (RCCL all-reduce).
- * stream is a hipStream_t.  Return non-zero to abort the solve with OBVI_FAILURE. */
-typedef int (*obvi_allreduce_fn)(void* user, void* device_buf, int64_t count_f64, void* stream);
+/* ---- multi-GPU (no reference counterpart) -------------------------------
+ * Independent windows / sessions, one per rank, that share object blocks.  Every rank uploads ALL shared objects
+ * (same indices, same initial values) plus its own poses, points and observations; object-only factors (shape / LTM
+ * priors) of a shared object are uploaded by exactly one rank.  Shared objects are eliminated last on every rank; per
+ * LM step the library calls `fn` three times on the handle's stream:
+ *   (1) op SUM  on the packed J^T J diagonal blocks and gradients of the shared objects   (n_shared * 56 doubles)
+ *   (2) op SUM  on the trailing shared-object tiles of the reduced system + right-hand side, after the rank's own
+ *               poses / points / private objects have been eliminated
+ *   (3) op SUM / MAX on the scalar block (costs, model change, step and gradient norms) so that every rank takes the
+ *               same accept / reject decision.
+ * `fn` sums (op 0) or maximises (op 1) `count_f64` doubles in place across ranks -- ncclAllReduce on `stream`
+ * (a hipStream_t) in a C++ host, torch.distributed.all_reduce from Python.  Non-zero return aborts the solve. */
+typedef int (*obvi_allreduce_fn)(void* user, void* device_buf, int64_t count_f64, int32_t op, void* stream);
 int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user);
+/* is_shared[i] != 0: object i is shared across ranks.  rank / world: this handle's position in the job. */
+int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared /*[n objects] or NULL*/, int32_t rank, int32_t world);
 
 /* ---- test / profiling hooks (parity tests call these through the C ABI) ------------ */
 /* raw (un-robustified) residual and Jacobians of every factor of one type at the current

@@ -17,16 +17,18 @@ constexpr int kTile = 64;
 
 // Slots of the device scalar block (fp64 unless noted).  One 256-byte D2H copy per LM step.
 enum Scalar {
+  // slots [SC_COST, SC_SUM_END) are summed across ranks in a multi-GPU solve, SC_GMAX_BITS is maximised
   SC_COST = 0,        // 0.5 sum rho(s) over the reduced program at the linearisation point
   SC_COST_CAND,       // same at the candidate point
-  SC_COST_FIXED,      // residual blocks whose every parameter block is constant
   SC_GSQ,             // |g|^2
-  SC_GMAX_BITS,       // max |g_i| (IEEE bits, via integer atomicMax; non-negative doubles order like u64)
   SC_XSQ,             // |x|^2 over the reduced program
   SC_STEPSQ,          // |delta|^2
   SC_MODEL_CHANGE,    // -(J d)^T (r + J d / 2)
   SC_CHOL_FAIL,       // (as double) count of non-positive pivots
   SC_NONFINITE,       // (as double) count of non-finite step entries
+  SC_SUM_END,
+  SC_GMAX_BITS = SC_SUM_END,  // max |g_i| (IEEE bits, via integer atomicMax; non-negative doubles order like u64)
+  SC_COST_FIXED,      // residual blocks whose every parameter block is constant
   SC_COUNT = 32
 };
 
@@ -59,6 +61,8 @@ struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   int64_t m;                // rows of the tile grid in use (elimination order, nodes padded to tile boundaries)
   const int32_t* pose_row;  // [nPv] reduced pose index -> first row of its 6x6 diagonal block in the tile grid
   const int32_t* obj_row;   // [nOv] reduced object index -> first row of its 7x7 diagonal block
+  const uint8_t* obj_shared; // [nOv] or NULL: object block is shared across ranks (multi-GPU exchange)
+  int32_t shared_owner;     // 1 on the rank that contributes the shared objects' diagonal blocks and scalars
   const int32_t* pose_vid;  // [P]  reduced index or -1
   const int32_t* obj_vid;   // [O]
   const uint8_t* point_var; // [L]
@@ -132,6 +136,9 @@ void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uin
 void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFactorsDev& sf, const DevCam* cams,
                                   const double* poses, const double* objects, double* r, double* J0, double* J1);
 void launch_fill(hipStream_t s, double* p, int64_t n, double v);
+// multi-GPU exchange buffers: shared objects' (Hdiag 49 | g 7) and the trailing tiles [t0, nt) + rhs rows
+void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack);
+void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* buf, int unpack);
 
 // ---- outlier selection (select_kernels.hip) ---------------------------------------------
 struct SelectScratch {
@@ -168,7 +175,8 @@ struct CholPlan {
   const int32_t* back_jobs;   // device, 3 per job
 };
 void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row);
-void launch_cholesky_solve(hipStream_t s, const CholPlan& plan, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal);
+void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int level1, double* S, double* Linv, double* rhs, double* scal);
+void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

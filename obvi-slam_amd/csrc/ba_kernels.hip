@@ -366,12 +366,15 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
       const int64_t row = is_pose ? b.pose_row[vid] : b.obj_row[vid];                     // row of the tile grid (S, rhs, y)
       const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
       const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
+      // a shared object's (already globally summed) diagonal block, gradient and norms are contributed by one rank only
+      const bool contribute = is_pose || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
       for (int k = 0; k < d; ++k) {
         const double c = Hd[d * k + k];
         double s;
         if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[crow + k] = s; } else { s = rd.scale[crow + k]; }
         const double lam = lm_lambda(c, s, radius);
         rd.lam[crow + k] = lam;
+        if (!contribute) continue;
         for (int y = 0; y <= k; ++y) *S_at(rd.S, rd.nt, row + k, row + y) += Hd[d * k + y] + (y == k ? lam : 0.0);
         const double g = rd.g[crow + k];
         rd.rhs[row + k] = g;
@@ -597,12 +600,14 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
     const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
     double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
     const int64_t row = vid < 0 ? 0 : (is_pose ? b.pose_row[vid] : b.obj_row[vid]);
+    const bool count = is_pose || vid < 0 || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
     for (int k = 0; k < d; ++k) {
       double v = x[k];
       if (vid >= 0) {
         const double dlt = -rd.y[row + k];
         if (!isfinite(dlt)) bad = 1.0;
-        v += dlt; stepsq += dlt * dlt;
+        v += dlt;
+        if (count) stepsq += dlt * dlt;
       }
       xc[k] = v;
     }
@@ -938,6 +943,33 @@ __global__ void __launch_bounds__(kBlock) k_fill(double* p, int64_t n, double v)
   for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
 }
 
+// multi-GPU exchange (1): (Hdiag 49 | g 7) of the shared objects <-> contiguous buffer
+__global__ void __launch_bounds__(64) k_pack_shared_blocks(BlocksDev b, ReducedDev rd, const int32_t* __restrict__ shared_ov, int32_t n_shared, double* buf, int unpack) {
+  const int o = blockIdx.x;
+  if (o >= n_shared || threadIdx.x >= 56) return;
+  const int32_t ov = shared_ov[o];
+  double* src = threadIdx.x < 49 ? rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov + threadIdx.x : rd.g + 6 * b.nPv + 7 * (int64_t)ov + (threadIdx.x - 49);
+  if (unpack) *src = buf[56 * (int64_t)o + threadIdx.x]; else buf[56 * (int64_t)o + threadIdx.x] = *src;
+}
+// multi-GPU exchange (2): lower tiles (i >= j >= t0) of the tile grid, then rhs rows [t0*64, nt*64)
+__global__ void __launch_bounds__(kBlock) k_pack_tail(ReducedDev rd, int32_t t0, double* buf, int unpack) {
+  const int nt = rd.nt, ntail = nt - t0;
+  const int ntiles = ntail * (ntail + 1) / 2;
+  const int job = blockIdx.x;
+  if (job < ntiles) {
+    int i = (int)((sqrtf(8.0f * (float)job + 1.0f) - 1.0f) * 0.5f);
+    while ((i + 1) * (i + 2) / 2 <= job) ++i;
+    while (i * (i + 1) / 2 > job) --i;
+    const int j = job - i * (i + 1) / 2;
+    double* tile = rd.S + ((int64_t)(t0 + i) * nt + (t0 + j)) * (kTile * kTile);
+    double* dst = buf + (int64_t)job * (kTile * kTile);
+    for (int e = threadIdx.x; e < kTile * kTile; e += kBlock) { if (unpack) tile[e] = dst[e]; else dst[e] = tile[e]; }
+  } else {
+    double* dst = buf + (int64_t)ntiles * (kTile * kTile);
+    for (int e = threadIdx.x; e < ntail * kTile; e += kBlock) { if (unpack) rd.rhs[(int64_t)t0 * kTile + e] = dst[e]; else dst[e] = rd.rhs[(int64_t)t0 * kTile + e]; }
+  }
+}
+
 inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace
@@ -1013,6 +1045,13 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
                                   const double* objects, double* r, double* J0, double* J1) {
   const int64_t n = factor_type == 2 ? sf.n_bb : factor_type == 3 ? sf.n_sp : factor_type == 4 ? sf.n_lt : sf.n_rl;
   if (n > 0) hipLaunchKernelGGL(k_debug_lin_small, dim3(grid_for(n, 64)), dim3(64), 0, s, factor_type, sf, cams, poses, objects, r, J0, J1);
+}
+void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack) {
+  if (n_shared > 0) hipLaunchKernelGGL(k_pack_shared_blocks, dim3(n_shared), dim3(64), 0, s, b, rd, shared_ov, n_shared, buf, unpack);
+}
+void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* buf, int unpack) {
+  const int ntail = rd.nt - t0;
+  if (ntail > 0) hipLaunchKernelGGL(k_pack_tail, dim3(ntail * (ntail + 1) / 2 + 1), dim3(kBlock), 0, s, rd, t0, buf, unpack);
 }
 void launch_fill(hipStream_t s, double* p, int64_t n, double v) {
   if (n > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, p, n, v);

@@ -376,10 +376,11 @@ void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile
   if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, is_pad_row);
 }
 
-void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* Linv, double* rhs, double* y, double* back_acc, double* scal) {
+// Factorisation of the levels [l0, l1) (forward phase), and the backward substitution over all levels.
+// The multi-GPU exchange sits between the levels of a rank's own blocks and the levels of the shared tail.
+void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, double* S, double* Linv, double* rhs, double* scal) {
   const int nt = p.nt;
-  (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
-  for (int l = 0; l < p.nlevels; ++l) {
+  for (int l = l0; l < l1; ++l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
 #ifdef OBVI_POTRF_TIMING
     hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal, (unsigned long long*)nullptr);
@@ -393,6 +394,10 @@ void launch_cholesky_solve(hipStream_t s, const CholPlan& p, double* S, double* 
       hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k,
                          p.upd_flag + p.upd_ptr[l], p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
   }
+}
+void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc) {
+  const int nt = p.nt;
+  (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
   for (int l = p.nlevels - 1; l >= 0; --l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
     const int nbj = p.back_ptr[l + 1] - p.back_ptr[l];

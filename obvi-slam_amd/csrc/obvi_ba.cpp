@@ -116,6 +116,13 @@ struct obvi_ba_handle {
   std::vector<obvi_iteration_summary> iterations;
   obvi_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  std::vector<uint8_t> h_is_shared;      // per object index (caller order)
+  int32_t rank = 0, world = 1;
+  std::vector<int32_t> h_shared_ov;      // reduced object indices of the shared objects, in object-index order
+  DevBuf<int32_t> d_shared_ov;
+  DevBuf<uint8_t> d_obj_shared;
+  DevBuf<double> d_xbuf;                 // exchange buffer
+  int32_t tail_t0 = -1, tail_level0 = -1;   // first tile / first level of the shared tail (-1: none)
 
   // ---- phase timing ----
   hipEvent_t ev[PH_COUNT + 1] = {};
@@ -162,6 +169,7 @@ void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
 BlocksDev blocks_dev(const obvi_ba_handle* h) {
   BlocksDev b;
   b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.m = h->m; b.pose_row = h->d_pose_row.get(); b.obj_row = h->d_obj_row.get();
+  b.obj_shared = (h->allreduce && !h->h_shared_ov.empty()) ? h->d_obj_shared.get() : nullptr; b.shared_owner = h->rank == 0 ? 1 : 0;
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
   return b;
 }
@@ -251,6 +259,7 @@ void prepare(obvi_ba_handle* h) {
     if (!ca) pose_used[a] = 1;
     if (!cb) pose_used[b] = 1;
   }
+  if (!h->h_is_shared.empty()) for (int64_t o = 0; o < O; ++o) if (h->h_is_shared[o]) obj_used[o] = 1;   // shared objects exist on every rank
   std::vector<int32_t> pose_vid(P, -1), obj_vid(O, -1);
   std::vector<uint8_t> point_var(L, 0);
   h->nPv = h->nOv = h->nLv = 0;
@@ -319,8 +328,10 @@ void prepare(obvi_ba_handle* h) {
       if (f >= 0) { fa[o] = std::min(fa[o], f); fb[o] = std::max(fb[o], f); }
     }
     std::vector<std::vector<int64_t>> node_objs(nodes.size() + 1);   // last slot: no tree (no variable pose)
+    std::vector<int64_t> tail_objs;                                   // shared across ranks: eliminated last, in object-index order
     for (int64_t o = 0; o < O; ++o) {
       if (obj_vid[o] < 0) continue;
+      if (!h->h_is_shared.empty() && h->h_is_shared[o]) { tail_objs.push_back(o); continue; }
       int32_t n = root;
       if (n >= 0 && fb[o] >= 0) {
         for (;;) {
@@ -347,6 +358,14 @@ void prepare(obvi_ba_handle* h) {
     };
     for (size_t n = 0; n < nodes.size(); ++n) place_node(nodes[n].p0, nodes[n].p1, node_objs[n]);
     place_node(0, 0, node_objs[nodes.size()]);
+    h->tail_t0 = -1;
+    h->h_shared_ov.clear();
+    if (!tail_objs.empty()) {
+      row = ((row + kTile - 1) / kTile) * kTile;
+      h->tail_t0 = (int32_t)(row / kTile);
+      place_node(0, 0, tail_objs);
+      for (int64_t o : tail_objs) h->h_shared_ov.push_back(obj_vid[o]);
+    }
     for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
     h->h_row_of_nat.resize(nPv);
     for (int64_t f = 0; f < nPv; ++f) h->h_row_of_nat[f] = h->h_pose_row[pos[f]];
@@ -454,6 +473,8 @@ void prepare(obvi_ba_handle* h) {
   // object diagonal blocks may straddle tiles
   for (int64_t w = 0; w < h->nOv; ++w) mark(h->h_obj_row[w], 7, h->h_obj_row[w], 7);
   for (int64_t v = 0; v < nPv; ++v) mark(h->h_pose_row[v], 6, h->h_pose_row[v], 6);
+  // the shared tail is exchanged across ranks as a dense lower-triangular block of tiles
+  if (h->tail_t0 >= 0) for (int i = h->tail_t0; i < nt; ++i) for (int j = h->tail_t0; j <= i; ++j) mask[(size_t)i * nt + j] = 1;
   // symbolic fill (tile columns in increasing order) + column structure of L
   std::vector<int32_t> col_ptr(nt + 1, 0), col_i;
   for (int k = 0; k < nt; ++k) {
@@ -469,6 +490,15 @@ void prepare(obvi_ba_handle* h) {
     int32_t lv = 0;
     for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) lv = std::max(lv, level[j] + 1);
     level[k] = lv; nlev = std::max(nlev, lv + 1);
+  }
+  h->tail_level0 = -1;
+  if (h->tail_t0 >= 0) {
+    // the shared tail is factorised after the multi-GPU exchange: its tile columns get their own, last levels
+    int32_t base = 0;
+    for (int k = 0; k < h->tail_t0; ++k) base = std::max(base, level[k] + 1);
+    for (int k = h->tail_t0; k < nt; ++k) level[k] = base + (k - h->tail_t0);
+    h->tail_level0 = base;
+    nlev = base + (nt - h->tail_t0);
   }
   h->nlevels = nlev;
   std::vector<std::vector<int32_t>> by_level(nlev);
@@ -548,6 +578,13 @@ void prepare(obvi_ba_handle* h) {
   h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s); h->d_back_jobs.upload(back_jobs, s);
   h->d_back_acc.resize((size_t)m_pad);
   h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
+  {
+    std::vector<uint8_t> sh((size_t)h->nOv + 1, 0);
+    for (int32_t ov : h->h_shared_ov) sh[ov] = 1;
+    h->d_obj_shared.upload(sh, s); h->d_shared_ov.upload(h->h_shared_ov, s);
+    const int64_t ntail = h->tail_t0 >= 0 ? nt - h->tail_t0 : 0;
+    h->d_xbuf.resize((size_t)std::max<int64_t>(56 * (int64_t)h->h_shared_ov.size(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile) + 64);
+  }
   h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
   h->d_g.resize((size_t)h->m_canon + 1); h->d_scale.resize((size_t)h->m_canon + 1); h->d_lam.resize((size_t)h->m_canon + 1);
   h->d_S.resize((size_t)nt * nt * kTile * kTile);
@@ -589,12 +626,33 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   record(h, PH_SMALL);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
   record(h, PH_DIAG);
+  const bool exchange = h->allreduce != nullptr && !h->h_shared_ov.empty();
+  if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
+    const int32_t ns = (int32_t)h->h_shared_ov.size();
+    launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 0);
+    if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), 56 * (int64_t)ns, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
+    launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 1);
+  }
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
   record(h, PH_SCHUR);
   if (solve) { launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
     launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd); }
   record(h, PH_CHOL);
-  if (solve && h->m > 0) launch_cholesky_solve(s, chol_plan(h), rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get(), scal);
+  if (solve && h->m > 0) {
+    const CholPlan plan = chol_plan(h);
+    if (exchange && h->tail_level0 >= 0) {
+      launch_cholesky_factor(s, plan, 0, h->tail_level0, rd.S, h->d_Linv.get(), rd.rhs, scal);
+      // (2) the rank's own blocks are eliminated: sum the Schur complement onto the shared objects
+      const int64_t ntail = h->nt - h->tail_t0;
+      launch_pack_tail(s, rd, h->tail_t0, h->d_xbuf.get(), 0);
+      if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (shared tail)", __FILE__, __LINE__};
+      launch_pack_tail(s, rd, h->tail_t0, h->d_xbuf.get(), 1);
+      launch_cholesky_factor(s, plan, h->tail_level0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal);
+    } else {
+      launch_cholesky_factor(s, plan, 0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal);
+    }
+    launch_cholesky_backward(s, plan, rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get());
+  }
   record(h, PH_BACKSUB);
   if (solve) launch_point_backsub(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), scal);
   record(h, PH_APPLY);
@@ -606,6 +664,10 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   if (solve) launch_cost(s, b, rp, sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
                          h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);
   record(h, PH_COUNT);
+  if (exchange) {   // (3) every rank must take the same decision
+    if (h->allreduce(h->allreduce_user, scal + SC_COST, SC_SUM_END - SC_COST, 0, s) || h->allreduce(h->allreduce_user, scal + SC_GMAX_BITS, 1, 1, s))
+      throw HipError{hipErrorUnknown, "allreduce hook (scalars)", __FILE__, __LINE__};
+  }
   OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   sync(h);
   for (int p = 0; p < PH_COUNT; ++p) {
@@ -1051,6 +1113,8 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
   launch_cost(s, blocks_dev(h), reproj_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
               h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), 1, h->d_scal.get());
+  if (h->allreduce != nullptr && !h->h_shared_ov.empty() &&
+      h->allreduce(h->allreduce_user, h->d_scal.get() + SC_COST_FIXED, 1, 0, s)) return fail(h, OBVI_ERR_HIP, "allreduce hook (fixed cost)");
   OBVI_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.get(), sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   sync(h);
   const double fixed_cost = h->h_scal[SC_COST_FIXED];
@@ -1265,6 +1329,14 @@ static int get_blocks(obvi_ba_handle* h, const DevBuf<double>& d, int64_t n, int
 int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_pose, h ? h->P : 0, 6, out); }
 int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_point, h ? h->L : 0, 3, out); }
 int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_obj, h ? h->O : 0, 7, out); }
+
+int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared, int32_t rank, int32_t world) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return OBVI_ERR_INVALID_ARGUMENT;
+  if (is_shared) h->h_is_shared.assign(is_shared, is_shared + h->O); else h->h_is_shared.clear();
+  h->rank = rank; h->world = world;
+  h->dirty = true;
+  return OBVI_OK;
+}
 
 int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;

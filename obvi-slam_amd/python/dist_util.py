@@ -28,3 +28,26 @@ def reduce_timing(dist, device, seconds, steps_done):
 def aggregate_throughput(world, steps_done, seconds):
     """Whole-job LM iterations per second: every rank completed `steps_done` iterations in `seconds`."""
     return world * steps_done / seconds
+
+
+class _DeviceArray:
+    """Zero-copy view of a device buffer handed out by the C ABI (obvi_ba_set_allreduce callback)."""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(n),), "typestr": "<f8", "version": 2}
+
+
+def device_tensor(ptr, n):
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, n), device="cuda")
+
+
+def torch_allreduce(dist):
+    """obvi_ba all-reduce hook on top of torch.distributed (backend nccl == RCCL over xGMI): the collective is enqueued
+    behind the library's own HIP stream, no host synchronisation."""
+    import torch
+
+    def fn(ptr, count, op, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            dist.all_reduce(device_tensor(ptr, count), op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+        return 0
+    return fn

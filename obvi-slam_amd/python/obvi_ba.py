@@ -60,7 +60,7 @@ class Summary(C.Structure):
                 ("residual_evaluation_time_in_seconds", C.c_double), ("message", C.c_char * 160)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
 
 class ObviError(RuntimeError):
@@ -262,13 +262,17 @@ class BundleAdjuster:
 
     # ---- multi-GPU / test hooks ----------------------------------------------------------
     def set_allreduce(self, pyfunc):
-        """pyfunc(device_ptr:int, count_f64:int, stream:int) -> int (0 = ok)."""
+        """pyfunc(device_ptr:int, count_f64:int, op:int (0 sum, 1 max), stream:int) -> int (0 = ok)."""
         if pyfunc is None:
             cb = C.cast(None, ALLREDUCE_FN)
         else:
-            cb = ALLREDUCE_FN(lambda user, buf, count, stream: int(pyfunc(buf or 0, count, stream or 0)))
+            cb = ALLREDUCE_FN(lambda user, buf, count, op, stream: int(pyfunc(buf or 0, count, op, stream or 0)))
         self._keep.append(cb)
         self._check(self._fn("ba_set_allreduce")(self._h, cb, None), "set_allreduce")
+
+    def set_shared_objects(self, is_shared, rank, world):
+        m = None if is_shared is None else np.ascontiguousarray(is_shared, dtype=np.uint8)
+        self._check(self._fn("ba_set_shared_objects")(self._h, _ptr(m, C.c_uint8), C.c_int32(rank), C.c_int32(world)), "set_shared_objects")
 
     def debug_linearize(self, factor_type):
         n, m = self._n[factor_type], RESIDUAL_DIM[factor_type]
