@@ -32,6 +32,7 @@ CONFIGS = {
     2: dict(name="local-BA 500 KF / 50k features, reprojection only", P=500, L=50000, O=0, const_poses=5),
     3: dict(name="global-BA 2000 KF / 200 objects / 300k features", P=2000, L=300000, O=200, const_poses=1),
     31: dict(name="(diagnostic) config 3 without objects", P=2000, L=300000, O=0, const_poses=1),
+    4: dict(name="500-KF local-BA windows, one per GPU, sharing 25 objects (RCCL all-reduce of the shared object blocks)", P=500, L=50000, O=25, const_poses=5, shared=True),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MATRIX_PEAK_TF = 78.6   # MI355X datasheet FP64 matrix (== FP64 vector) rate; not in the guide's table
@@ -85,10 +86,18 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
-    prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(20241008, args.config, rank), const_poses=cfg["const_poses"])
+    shared = bool(cfg.get("shared")) and world > 1
+    prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(20241008, args.config, rank), const_poses=cfg["const_poses"],
+                              object_seed=(20241008 + args.config) if cfg.get("shared") else None, min_obj_obs=10)
+    if shared and rank != 0:        # object-only factors of a shared object are uploaded by exactly one rank
+        for k in ("sp_obj", "sp_mean", "sp_cov"):
+            prob[k] = prob[k][:0]
     stats = synth.problem_stats(prob)
     ba = obvi_ba.BundleAdjuster(device_id=local_rank)
     synth.upload(ba, prob)          # inputs now resident in HBM
+    if shared:
+        ba.set_shared_objects(np.ones(len(prob["objects"]), np.uint8), rank, world)
+        ba.set_allreduce(dist_util.torch_allreduce(dist))
     ba.evaluate(True, False)        # builds the reduced-program bookkeeping / symbolic plan (not timed: the reference times "build" separately)
 
     def barrier():
@@ -142,7 +151,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "keyframes": stats["P"], "features": stats["L"], "objects": stats["O"],
                        "reprojection_obs": stats["N_r"], "bbox_obs": stats["N_b"], "reduced_rows": int(pst["reduced_rows"]),
-                       "parallelism": "replicas" if world > 1 else "single", "steps_done": steps_done,
+                       "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single", "steps_done": steps_done,
                        "final_cost": summ.final_cost, "termination": summ.message.decode()},
             "roofline": roof,
             "phases_ms_avg": {k: round(v["ms_avg"], 4) for k, v in phases.items()},

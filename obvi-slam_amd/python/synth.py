@@ -134,7 +134,7 @@ def odom_cov(t, aa, m_tt, m_tr, m_rt, m_rr):
 
 
 def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pixel_noise=1.0,
-                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0, stereo=False):
+                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0, stereo=False, object_seed=None):
     """Returns a dict of flat arrays accepted by upload(); 'gt_*' hold the ground truth."""
     rng = np.random.Generator(np.random.MT19937(seed))
     rp = RESIDUAL_PARAMS
@@ -213,6 +213,11 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
     bb_obj = np.zeros(0, np.uint32); bb_pose = np.zeros(0, np.uint32); bb_corners = np.zeros((0, 4))
     sp_mean = np.zeros((0, 3)); sp_cov = np.zeros((0, 9)); obj_class = []
     if O > 0:
+        # object_seed: place the objects (and draw their initial estimates) from a separate stream so that several
+        # windows over the same place -- different `seed`, same `object_seed` -- share one object set (config #4)
+        rng_meas = rng
+        if object_seed is not None:
+            rng = np.random.Generator(np.random.MT19937(object_seed))
         names = list(object_classes) if object_classes else list(SHAPE_CLASSES.keys())
         cand_o, cand_corners, cand_pose, cand_gt, cand_cls = [], [], [], [], []
         tries = 0
@@ -264,7 +269,7 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
         # the functor's corner order is (min_x, max_x, min_y, max_y) in pixels
         bb_corners = np.stack([bb_corners[:, 0:2].min(axis=1), bb_corners[:, 0:2].max(axis=1),
                                bb_corners[:, 2:4].min(axis=1), bb_corners[:, 2:4].max(axis=1)], axis=1)
-        bb_corners = bb_corners + rng.normal(size=bb_corners.shape) * bbox_noise
+        bb_corners = bb_corners + rng_meas.normal(size=bb_corners.shape) * bbox_noise
         order = np.lexsort((bb_pose, bb_obj))
         bb_obj, bb_pose, bb_corners = bb_obj[order], bb_pose[order], bb_corners[order]
         objects = gt_objects.copy()

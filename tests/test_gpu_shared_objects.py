@@ -129,3 +129,25 @@ def test_two_windows_sharing_objects_equal_the_joint_solve(scene):
     for rank, (q, pts, rng) in enumerate(wins):
         idx = np.array([pos[int(p)] for p in pts])
         assert np.abs(handles[rank].get_points() - jpts[idx]).max() < 1e-7
+
+
+def test_rccl_hook_through_torch_distributed(scene):
+    """The production hook (dist_util.torch_allreduce: RCCL via torch.distributed, enqueued on the library's own stream
+    through torch.cuda.ExternalStream) on a one-rank process group: the plumbing must leave the solve unchanged."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        a, b = helpers.product_ba(), helpers.product_ba()
+        for ba in (a, b):
+            synth.upload(ba, scene)
+        b.set_shared_objects(np.ones(len(scene["objects"]), np.uint8), 0, 1)
+        b.set_allreduce(dist_util.torch_allreduce(dist))
+        prm = helpers.ba_params(max_it=10)
+        sa, sb = a.solve(prm), b.solve(prm)
+        assert sb.num_iterations == sa.num_iterations and abs(sb.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
+        assert np.abs(b.get_poses() - a.get_poses()).max() < 1e-9
+    finally:
+        dist.destroy_process_group()
