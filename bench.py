@@ -45,6 +45,18 @@ def solver_params(obvi_ba, iters):
                                 max_trust_region_radius=1e4)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes).  None if not measured."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (ValueError, OSError):
+        return None
+
+
 def cpu_baseline(prob, budget_iters=2):
     """Oracle (scalar fp64 CPU restatement, 1 thread) on the same problem, bounded to a few LM iterations."""
     import obvi_ba
@@ -118,33 +130,62 @@ def main():
     steps_done = summ.num_iterations - 1
     dt, steps_done = dist_util.reduce_timing(dist, "cuda", dt, steps_done)
 
+    # Per-kernel durations: a second solve of the same K steps with an event after every launch of the tile
+    # Cholesky (profiling level 2 costs a few percent, so it is kept out of the timed region above).
+    ba.set_profiling(2)
+    p0 = ba.kernel_times()
+    ba.solve(solver_params(obvi_ba, args.steps))
+    p1 = ba.kernel_times()
+    ba.set_profiling(0)
+
     if rank == 0:
         pst = ba.problem_stats()
         n_r, n_b = pst["reproj_active"], pst["bbox_active"]
-        # per-launch algorithmic bytes of the HBM-bound kernels (SURVEY 8d split of B_step) and flops of the solve
-        alg = {
-            "point_pass": n_r * (32.0 + 144.0),            # read obs, write Z (6x3 fp64)
+        t3 = 64.0 ** 3
+        # algorithmic HBM bytes (SURVEY 8d split of B_step) or flops of ONE launch of each kernel
+        hbm = {
+            "point_pass": n_r * (32.0 + 144.0),            # read observations, write Z (6x3 fp64)
             "pose_pass": n_r * 32.0,
-            "schur_blocks": n_r * 144.0 + pst["schur_blocks"] * 288.0,
+            "schur_window": n_r * 144.0,                   # every Z record once
+            "schur_blocks": None,                          # far pairs only: no per-observation figure
             "point_backsub": n_r * 144.0,
             "cost": n_r * 32.0,
             "small_factors": n_b * (168.0 + 672.0),
         }
-        phases = {}
-        for name in k1:
-            ms = k1[name][0] - k0.get(name, (0.0, 0))[0]
-            n = k1[name][1] - k0.get(name, (0.0, 0))[1]
-            phases[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
-        dom = max(phases, key=lambda k: phases[k]["ms_total"])
-        avg_s = phases[dom]["ms_avg"] * 1e-3
-        if dom == "cholesky_solve":
-            ach = pst["chol_flops"] / avg_s / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / FP64_MATRIX_PEAK_TF, "traffic": None,
-                    "note": "whole tile-Cholesky phase (potrf+trsm+update+substitution launches) per LM step; flops = structural tile flops"}
-        else:
-            ach = alg.get(dom, 0.0) / avg_s / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        nlev = max(pst["chol_levels"], 1.0)
+        flops = {   # per launch = per level of the tile elimination tree
+            "k_potrf": pst["tiles_per_dim"] * (2.0 * t3 / 3.0) / nlev,       # factor + inverse of each diagonal tile
+            "k_trsm": pst["trsm_jobs"] * t3 / nlev,
+            "k_update": pst["update_jobs"] * 2.0 * t3 / nlev,
+        }
+        def delta(k1_, k0_):
+            out = {}
+            for name in k1_:
+                ms = k1_[name][0] - k0_.get(name, (0.0, 0))[0]
+                n = k1_[name][1] - k0_.get(name, (0.0, 0))[1]
+                if n > 0:
+                    out[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
+            return out
+        phases = delta(k1, k0)
+        kern = delta(p1, p0)
+        kern.pop("cholesky_solve", None)           # replaced by its kernels
+        steps_prof = max(1, kern["point_pass"]["launches"])
+        table = {}
+        for name, v in kern.items():
+            row = {"avg_us": round(1e3 * v["ms_avg"], 2), "launches_per_step": round(v["launches"] / steps_prof, 1), "ms_per_step": round(v["ms_total"] / steps_prof, 4)}
+            if hbm.get(name):
+                row.update(bound="hbm", achieved=round(hbm[name] / (v["ms_avg"] * 1e-3) / 1e9, 1), unit="GB/s")
+                row["frac"] = round(row["achieved"] / HBM_PEAK_GBS, 4)
+            elif name in flops:
+                row.update(bound="mfma", achieved=round(flops[name] / (v["ms_avg"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
+                row["frac"] = round(row["achieved"] / FP64_MATRIX_PEAK_TF, 4)
+            table[name] = row
+        dom = max(table, key=lambda k: table[k]["ms_per_step"])
+        d = table[dom]
+        roof = {"kernel": dom, "bound": d.get("bound", "hbm"), "achieved": d.get("achieved"), "peak": HBM_PEAK_GBS if d.get("bound", "hbm") == "hbm" else FP64_MATRIX_PEAK_TF,
+                "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "traffic": pmc_traffic(dom),
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"],
+                "note": "dominant kernel by device time per LM step; durations from HIP events around every launch in a second, instrumented solve of the same steps"}
         out = {
             "metric": "global-BA LM iterations/s", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
@@ -154,6 +195,7 @@ def main():
                        "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single", "steps_done": steps_done,
                        "final_cost": summ.final_cost, "termination": summ.message.decode()},
             "roofline": roof,
+            "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
             "phases_ms_avg": {k: round(v["ms_avg"], 4) for k, v in phases.items()},
         }
         if not args.no_cpu_baseline:

@@ -376,10 +376,19 @@ void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile
   if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, is_pad_row);
 }
 
+static void tick(hipStream_t s, CholTimers* t, int tag) {
+  if (!t) return;
+  if ((size_t)t->used >= t->pool->size()) { hipEvent_t e; (void)hipEventCreate(&e); t->pool->push_back(e); t->tags->push_back(-1); }
+  (*t->tags)[t->used] = tag;
+  (void)hipEventRecord((*t->pool)[t->used], s);
+  t->used++;
+}
+
 // Factorisation of the levels [l0, l1) (forward phase), and the backward substitution over all levels.
 // The multi-GPU exchange sits between the levels of a rank's own blocks and the levels of the shared tail.
-void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, double* S, double* Linv, double* rhs, double* scal) {
+void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers) {
   const int nt = p.nt;
+  tick(s, timers, -1);
   for (int l = l0; l < l1; ++l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
 #ifdef OBVI_POTRF_TIMING
@@ -387,22 +396,27 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
 #else
     hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
 #endif
+    tick(s, timers, CK_POTRF);
     const int ntr = p.trsm_ptr[l + 1] - p.trsm_ptr[l];
-    if (ntr > 0) hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv);
+    if (ntr > 0) { hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv); tick(s, timers, CK_TRSM); }
     const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
-    if (nup + nrh > 0)
+    if (nup + nrh > 0) {
       hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k,
                          p.upd_flag + p.upd_ptr[l], p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
+      tick(s, timers, CK_UPDATE);
+    }
   }
 }
-void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc) {
+void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc, CholTimers* timers) {
   const int nt = p.nt;
   (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
+  tick(s, timers, -1);
   for (int l = p.nlevels - 1; l >= 0; --l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
     const int nbj = p.back_ptr[l + 1] - p.back_ptr[l];
-    if (nbj > 0) hipLaunchKernelGGL(k_backward_gather, dim3(nbj), dim3(kThreads), 0, s, S, nt, p.back_jobs + 3 * (int64_t)p.back_ptr[l], p.col_i, y, back_acc);
+    if (nbj > 0) { hipLaunchKernelGGL(k_backward_gather, dim3(nbj), dim3(kThreads), 0, s, S, nt, p.back_jobs + 3 * (int64_t)p.back_ptr[l], p.col_i, y, back_acc); tick(s, timers, CK_BACK_GATHER); }
     hipLaunchKernelGGL(k_backward_final, dim3(npk), dim3(kThreads), 0, s, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, back_acc, y);
+    tick(s, timers, CK_BACK_FINAL);
   }
 }
 

@@ -30,8 +30,8 @@ namespace {
 
 double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_POSE_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
-const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "pose_pass", "small_factors", "reduced_diag", "schur_blocks",
+enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_POSE_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_SCHUR_BLOCKS, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "pose_pass", "small_factors", "reduced_diag", "schur_window", "schur_blocks",
                                      "cholesky_solve", "point_backsub", "apply_step", "cost"};
 
 }  // namespace
@@ -126,6 +126,10 @@ struct obvi_ba_handle {
 
   // ---- phase timing ----
   hipEvent_t ev[PH_COUNT + 1] = {};
+  int ck_used = 0;
+  int profiling = 0;                       // 2: per-kernel events inside the tile Cholesky
+  std::vector<hipEvent_t> ck_pool; std::vector<int> ck_tags;
+  double ck_ms[CK_COUNT] = {}; int64_t ck_launches[CK_COUNT] = {};
   double phase_ms[PH_COUNT] = {};
   int64_t phase_launches[PH_COUNT] = {};
 };
@@ -635,23 +639,29 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   }
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
   record(h, PH_SCHUR);
-  if (solve) { launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
-    launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd); }
+  if (solve) launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
+  record(h, PH_SCHUR_BLOCKS);
+  if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   record(h, PH_CHOL);
   if (solve && h->m > 0) {
     const CholPlan plan = chol_plan(h);
+    CholTimers timers{&h->ck_pool, &h->ck_tags, 0};
+    CholTimers* tm = h->profiling >= 2 ? &timers : nullptr;
     if (exchange && h->tail_level0 >= 0) {
-      launch_cholesky_factor(s, plan, 0, h->tail_level0, rd.S, h->d_Linv.get(), rd.rhs, scal);
+      launch_cholesky_factor(s, plan, 0, h->tail_level0, rd.S, h->d_Linv.get(), rd.rhs, scal, tm);
       // (2) the rank's own blocks are eliminated: sum the Schur complement onto the shared objects
       const int64_t ntail = h->nt - h->tail_t0;
       launch_pack_tail(s, rd, h->tail_t0, h->d_xbuf.get(), 0);
       if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (shared tail)", __FILE__, __LINE__};
       launch_pack_tail(s, rd, h->tail_t0, h->d_xbuf.get(), 1);
-      launch_cholesky_factor(s, plan, h->tail_level0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal);
+      launch_cholesky_factor(s, plan, h->tail_level0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal, tm);
     } else {
-      launch_cholesky_factor(s, plan, 0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal);
+      launch_cholesky_factor(s, plan, 0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal, tm);
     }
-    launch_cholesky_backward(s, plan, rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get());
+    launch_cholesky_backward(s, plan, rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get(), tm);
+    h->ck_used = tm ? timers.used : 0;
+  } else {
+    h->ck_used = 0;
   }
   record(h, PH_BACKSUB);
   if (solve) launch_point_backsub(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), scal);
@@ -675,6 +685,13 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
     OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev[p + 1]));
     h->phase_ms[p] += ms;
     h->phase_launches[p] += 1;
+  }
+  for (int i = 1; i < h->ck_used; ++i) {   // per-kernel events of the tile Cholesky (profiling level 2)
+    const int tag = h->ck_tags[i];
+    if (tag < 0) continue;
+    float ms = 0.f;
+    OBVI_HIP(hipEventElapsedTime(&ms, h->ck_pool[i - 1], h->ck_pool[i]));
+    h->ck_ms[tag] += ms; h->ck_launches[tag] += 1;
   }
 }
 
@@ -1105,7 +1122,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   h->iterations.clear();
   prepare(h);
   const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
-                         h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
+                         h->phase_ms[PH_SCHUR] + h->phase_ms[PH_SCHUR_BLOCKS] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
   hipStream_t s = h->stream;
 
   // fixed cost: residual blocks with only constant parameter blocks
@@ -1132,7 +1149,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     sum->is_solution_usable = (term == OBVI_CONVERGENCE || term == OBVI_NO_CONVERGENCE) ? 1 : 0;
     sum->total_time_in_seconds = wall_s() - t_start;
     sum->jacobian_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE] - ms0[0]);
-    sum->linear_solver_time_in_seconds = 1e-3 * (h->phase_ms[PH_SCHUR] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY] - ms0[1]);
+    sum->linear_solver_time_in_seconds = 1e-3 * (h->phase_ms[PH_SCHUR] + h->phase_ms[PH_SCHUR_BLOCKS] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY] - ms0[1]);
     sum->residual_evaluation_time_in_seconds = 1e-3 * (h->phase_ms[PH_COST] - ms0[2]);
   };
 
@@ -1344,6 +1361,12 @@ int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user) {
   return OBVI_OK;
 }
 
+int obvi_ba_set_profiling(obvi_ba_handle* h, int32_t level) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  h->profiling = level;
+  return OBVI_OK;
+}
+
 int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap) {
   if (!h || !out) return 0;
   int64_t act_rp = 0, act_bb = 0;
@@ -1360,14 +1383,17 @@ int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap)
 int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms, int64_t* launches, int32_t cap) {
   if (!h || !names || !total_ms || !launches) return 0;
   int n = 0, off = 0;
-  for (int p = 0; p < PH_COUNT && n < cap; ++p) {
-    const int len = (int)std::strlen(kPhaseNames[p]);
-    if (off + len + 1 > names_cap) break;
-    std::memcpy(names + off, kPhaseNames[p], len + 1);
+  auto put = [&](const char* name, double ms, int64_t cnt) {
+    const int len = (int)std::strlen(name);
+    if (n >= cap || off + len + 1 > names_cap) return;
+    std::memcpy(names + off, name, len + 1);
     off += len + 1;
-    total_ms[n] = h->phase_ms[p]; launches[n] = h->phase_launches[p];
+    total_ms[n] = ms; launches[n] = cnt;
     ++n;
-  }
+  };
+  for (int p = 0; p < PH_COUNT; ++p) put(kPhaseNames[p], h->phase_ms[p], h->phase_launches[p]);
+  static const char* kCholNames[CK_COUNT] = {"k_potrf", "k_trsm", "k_update", "k_backward_gather", "k_backward_final"};
+  for (int k = 0; k < CK_COUNT; ++k) if (h->ck_launches[k] > 0) put(kCholNames[k], h->ck_ms[k], h->ck_launches[k]);
   return n;
 }
 

@@ -298,6 +298,9 @@ class BundleAdjuster:
                  "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active", "chol_levels"]
         return {names[i]: buf[i] for i in range(n)}
 
+    def set_profiling(self, level):
+        self._check(self._fn("ba_set_profiling")(self._h, C.c_int32(level)), "set_profiling")
+
     def kernel_times(self, cap=64):
         names = C.create_string_buffer(4096)
         ms = (C.c_double * cap)()
