@@ -305,8 +305,8 @@ void prepare(obvi_ba_handle* h) {
     //      covers the frame range [lo,hi) of its subtree
     struct Node { int32_t lo, hi, p0, p1, left, right; };
     std::vector<Node> nodes;
-    const int32_t G = 32;
-    const int32_t kLeaf = std::getenv("OBVI_ND_LEAF") ? std::atoi(std::getenv("OBVI_ND_LEAF")) : 160;   // tuning knob (poses per leaf)
+    const int32_t G = std::getenv("OBVI_ND_G") ? std::atoi(std::getenv("OBVI_ND_G")) : 4;   // cut granularity in poses (tuning knob)
+    const int32_t kLeaf = std::getenv("OBVI_ND_LEAF") ? std::atoi(std::getenv("OBVI_ND_LEAF")) : 96;   // tuning knob (poses per leaf)
     std::function<int32_t(int32_t, int32_t)> build = [&](int32_t lo, int32_t hi) -> int32_t {
       auto leaf = [&]() { nodes.push_back({lo, hi, lo, hi, -1, -1}); return (int32_t)nodes.size() - 1; };
       if (hi - lo <= kLeaf) return leaf();
