@@ -115,10 +115,14 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt,
                          const ReducedDev& rd);
-// window parameters of k_schur_window, shared with the host code that decides which pairs the window covers
-constexpr int kSchurWindowRows = 24, kSchurWindowOffsets = 16, kSchurMaxObsPerPoint = 36, kSchurChunkFrames = 2;
-void launch_schur_window(hipStream_t s, int64_t nchunks, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
-                         const int32_t* nat_of_pose, const int32_t* row_of_nat, const uint32_t* chunk_ptr, const uint32_t* chunk_points, const int32_t* chunk_f0);
+// strip geometry of k_schur_window, shared with the host code that builds the visit lists and decides which pairs
+// the strip covers: row chunks of kSchurRows frames, columns = the kSchurWindowFrames frames ending with the chunk, cut
+// into groups of kSchurGroupCols 16-wide tile columns; visits are streamed through LDS in batches of at most
+// kSchurBatchVisits visits / kSchurBatchBytes of 144-byte slots
+constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSchurBatchBytes = 32768, kSchurBatchVisits = 128;
+void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
+                         const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
+                         const int32_t* wg_f0, const int32_t* wg_group);
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
                           const double* points, double* points_cand, double* scal);
 void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,

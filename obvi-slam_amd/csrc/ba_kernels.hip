@@ -57,6 +57,10 @@ __device__ __forceinline__ void block_accumulate_max(double v, double* dst_bits)
   }
 }
 
+// Z storage: the 18-double record of observation a of point l sits at 18 a + 4 l, and behind a point's last record come
+// 4 doubles (u_l, 0): one contiguous, 16-byte aligned block per point = everything k_schur_window needs of it.
+__device__ __forceinline__ int64_t z_off(int64_t a, int64_t l) { return 18 * a + 4 * l; }
+__device__ __forceinline__ int64_t z_tail(int64_t end_obs, int64_t l) { return 18 * end_obs + 4 * l; }
 __device__ __forceinline__ double* S_at(double* S, int32_t nt, int64_t i, int64_t j) {
   return S + ((i / kTile) * (int64_t)nt + (j / kTile)) * (kTile * kTile) + (i % kTile) * kTile + (j % kTile);
 }
@@ -133,7 +137,9 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
       const double i10 = -c10 * i00 * i11, i21 = -c21 * i11 * i22, i20 = -(c20 * i00 + c21 * i10) * i22;
       double* Ci = pt.Ci + 6 * l;
       Ci[0] = i00; Ci[1] = i10; Ci[2] = i11; Ci[3] = i20; Ci[4] = i21; Ci[5] = i22;
-      pt.u[3 * l] = i00 * g0; pt.u[3 * l + 1] = i10 * g0 + i11 * g1; pt.u[3 * l + 2] = i20 * g0 + i21 * g1 + i22 * g2;
+      const double ul0 = i00 * g0, ul1 = i10 * g0 + i11 * g1, ul2 = i20 * g0 + i21 * g1 + i22 * g2;
+      pt.u[3 * l] = ul0; pt.u[3 * l + 1] = ul1; pt.u[3 * l + 2] = ul2;
+      { double* ut = pt.Z + z_tail(end, l); ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0; }   // copy behind the point's Z records (k_schur_window)
       // second sweep: Z = rho' Jp^T (Jl Ci^T)
       for (uint32_t a = beg; a < end; ++a) {
         if (!rp.active[a]) continue;
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
         const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
         const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
-        double* Z = pt.Z + 18 * (int64_t)a;
+        double* Z = pt.Z + z_off(a, l);
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
           Z[3 * x] = w * (Jp[x] * m00 + Jp[6 + x] * m10);
@@ -427,7 +433,7 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
       const int f = i * 64 + lane;             // [0, 576): pair = f / 36, half = (f % 36) / 18, e = f % 18
       const int pr = f / 36, rem = f - 36 * pr, half = rem >= 18 ? 1 : 0, e = rem - 18 * half;
       const uint32_t src = __shfl(idx, pr + 16 * half, 64);
-      zsh[wv][f] = (src != 0xffffffffu) ? pt.Z[18 * (int64_t)src + e] : 0.0;
+      zsh[wv][f] = (src != 0xffffffffu) ? pt.Z[z_off(src, obs_point[src]) + e] : 0.0;
     }
     if (diag && lane < 48) {
       const int pr = lane / 3, e = lane - 3 * pr;
@@ -468,89 +474,183 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
 }
 
 // ---------------------------------------------------------------------------------------
-// K4a.  Schur complement, point-centric with an LDS window.  Points are grouped in chunks by the first frame f0
-// that observes them; a workgroup owns one chunk and accumulates every 6x6 block (fp, fq) with fp - f0 < kSW and
-// fp - fq < kSD (frames in trajectory order) in LDS, so each Z record is read from HBM exactly once (coalesced: a
-// point's records are contiguous) and the window is flushed to the tile grid once per workgroup.  Pairs outside
-// the window (long tracks, loop closures: ~8 % in config #3) are left to k_schur_blocks via the host-built list.
+// K4a.  Schur complement on the matrix cores, point-centric, no atomics inside the loop.
+// Geometry.  The variable frames (trajectory order) are cut into row chunks of kSR = 8 frames = 48 rows = 3 MFMA row
+// tiles.  The strip of a chunk is the 48 x 240 part of S whose columns are the kSFr = 40 frames [f0 - 32, f0 + 8):
+// 3 x 15 tiles of v_mfma_f64_16x16x4_f64, cut into 3 column groups of kSGC = 5 tile columns.  A point is "visited" by
+// every (chunk, group) in which it has a row frame and a column frame; with Zrow(i) the 3-vector of matrix row i
+// (row 6 fo + x  <->  Z[obs at frame fo][x][0..2]) a visit adds
+//     strip(i, n) += sum_k Zrow(i)[k] * Zrow(n)[k]          (K = 3, padded to the instruction's 4)
+// for the tiles the point covers (wave-uniform bits of the host-built visit record).
+// Parallelism.  A workgroup owns a slice of the visits of one (chunk, group); each of its 4 wavefronts is an
+// independent stream with a private 3 x 5 tile accumulator in registers (120 VGPRs, two wavefronts per SIMD) and takes
+// every 4th visit.  Nothing in the loop depends on another wavefront, and nothing in it touches global memory:
+// Memory.  The host lays a visit out as consecutive 144-byte slots -- the point's Z record for each strip frame from
+// its first to its last row frame and column frame of the group (zeros for a frame it skips), its (u_l, 0) tail, and
+// for a stereo point the second record of each frame -- and cuts a workgroup's visits into batches of <= 32 KB.  A
+// batch is one gather (slot table entry -> global_load_lds_dwordx4, all 256 lanes) issued while the previous batch is
+// multiplied; the table entries of the batch after that ride in registers.  An operand is then a single ds_read_b64 at
+// (slot + fo - first) * 144 + 8 (3 x + (l>>4)), lanes without an operand read a zero.
+// Every wavefront adds its tiles to the tile grid once, at the end (fp64 hardware atomics; 15 tiles per stream).
+// Pairs whose frames are further apart than the strip (loop closures, very long tracks) go to k_schur_blocks.
 // ---------------------------------------------------------------------------------------
-constexpr int kSW = kSchurWindowRows, kSD = kSchurWindowOffsets, kSK = kSchurMaxObsPerPoint, kSchurThreads = 512;
-constexpr int kSB = 37;   // doubles per 6x6 block in LDS (odd stride: lanes adding to different blocks hit different banks)
-__global__ void __launch_bounds__(kSchurThreads) k_schur_window(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const int32_t* __restrict__ nat_of_pose,
-                                                               const int32_t* __restrict__ row_of_nat, const uint32_t* __restrict__ chunk_ptr,
-                                                               const uint32_t* __restrict__ chunk_points, const int32_t* __restrict__ chunk_f0) {
-  __shared__ double acc[kSW * kSD * kSB];
-  __shared__ double rhsw[kSW * 6];
-  __shared__ double zsh[kSchurThreads / 64][kSK * 18];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int32_t f0 = chunk_f0[blockIdx.x];
-  for (int i = tid; i < kSW * kSD * kSB; i += kSchurThreads) acc[i] = 0.0;
-  for (int i = tid; i < kSW * 6; i += kSchurThreads) rhsw[i] = 0.0;
-  __syncthreads();
-  double* zs = zsh[wv];
-  for (uint32_t pi = chunk_ptr[blockIdx.x] + wv; pi < chunk_ptr[blockIdx.x + 1]; pi += kSchurThreads / 64) {
-    const uint32_t l = chunk_points[pi];
-    const uint32_t beg = rp.point_ptr[l];
-    const int k = (int)(rp.point_ptr[l + 1] - beg);   // <= kSK (host guarantees)
-    int f_mine = -1;
-    if (lane < k && rp.active[beg + lane]) f_mine = nat_of_pose[rp.pose[beg + lane]];
-    const double* Zg = pt.Z + 18 * (int64_t)beg;
-    for (int idx = lane; idx < 18 * k; idx += 64) zs[idx] = Zg[idx];
-    const double u0 = pt.u[3 * (int64_t)l], u1 = pt.u[3 * (int64_t)l + 1], u2 = pt.u[3 * (int64_t)l + 2];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // one lane per observation pair (i >= j in pose order => f_i >= f_j); the lane forms the whole 6x6 product
-    const int npairs = k * (k + 1) / 2;
-    for (int base = 0; base < npairs; base += 64) {
-      const int q = base + lane;
-      int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-      while ((i + 1) * (i + 2) / 2 <= q) ++i;
-      while (i * (i + 1) / 2 > q) --i;
-      const int j = q - i * (i + 1) / 2;
-      const int ic = min(i, k - 1), jc = min(j, k - 1);
-      const int fi = __shfl(f_mine, ic, 64), fj = __shfl(f_mine, jc, 64);
-      const int ri = fi - f0, d = fi - fj;
-      if (q < npairs && fi >= 0 && fj >= 0 && ri < kSW && d < kSD) {
-        double zi[18], zj[18];
+constexpr int kSR = kSchurRows, kSFr = kSchurWindowFrames, kSBack = kSFr - kSR;
+constexpr int kSTR = kSR * 6 / 16, kSTC = kSFr * 6 / 16, kSDiag = kSBack * 6 / 16, kSWv = 4, kSGC = kSchurGroupCols;
+static_assert(kSR * 6 % 16 == 0 && kSFr * 6 % 16 == 0 && kSBack * 6 % 16 == 0 && kSFr <= 64 && kSTC % kSGC == 0, "strip must be whole MFMA tiles");
+static_assert(kSchurBatchBytes % (16 * 64 * kSWv) == 0, "a batch is whole gather instructions");
+typedef double sf64x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void schur_gptr;
+typedef __attribute__((address_space(3))) void schur_lptr;
+typedef __attribute__((address_space(3))) const unsigned char schur_lds8;
+typedef __attribute__((address_space(3))) const double schur_ldsd;
+// Accumulating MFMA with the accumulator tied in place (VGPR form).  Written as asm because the builtin form of a
+// *conditional* MFMA leaves the choice of C/D registers to the allocator across the join.
+// Wait states (cdna_hip_programming.md 5.7 item 2): 2 after a VALU write of an operand (s_nop 1); none between MFMAs
+// chained through C; the write-out below pads the MFMA -> VALU read itself.
+__device__ __forceinline__ void mfma_f64_acc(sf64x4& acc, double a, double bv) {
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bv));
+}
+
+template <bool TWIN>
+__global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDev pt, ReducedDev rd, const int32_t* __restrict__ row_of_nat,
+                                                          const uint32_t* __restrict__ wg_bptr, const uint32_t* __restrict__ bfirst,
+                                                          const uint32_t* __restrict__ bslot, const uint4* __restrict__ visits,
+                                                          const uint32_t* __restrict__ slot_src, const int32_t* __restrict__ wg_f0,
+                                                          const int32_t* __restrict__ wg_group) {
+  __shared__ __attribute__((aligned(16))) unsigned char zbuf[2][kSchurBatchBytes];
+  __shared__ __attribute__((aligned(16))) uint4 recbuf[2][kSchurBatchVisits];
+  __shared__ __attribute__((aligned(16))) double zero2[2];
+  __shared__ int32_t rown[kSFr];
+  constexpr int kIters = kSchurBatchBytes / 16 / (64 * kSWv);   // gather instructions per lane per batch
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int32_t f0 = wg_f0[blockIdx.x], fbase = f0 - kSBack, cbase = kSGC * wg_group[blockIdx.x];
+  const bool with_rhs = cbase + kSGC == kSTC;   // the group holding the chunk's own frames sees every visit of the chunk once
+  if (tid < kSFr) { const int32_t f = fbase + tid; rown[tid] = (f >= 0 && f < b.nPv) ? row_of_nat[f] : -1; }
+  if (tid < 2) zero2[tid] = 0.0;
+  // per-lane operand coordinates: frame offset in the strip and byte offset in the record, of row tile r / column tile cbase + c
+  uint32_t foA[kSTR], offA[kSTR], foB[kSGC], offB[kSGC];
 #pragma unroll
-        for (int c = 0; c < 18; ++c) { zi[c] = zs[18 * i + c]; zj[c] = zs[18 * j + c]; }
-        double* blk = &acc[(ri * kSD + d) * kSB];
-        const bool twin = (d == 0) && (i != j);   // two observations from one frame (stereo): both orders land in the diagonal block
+  for (int r = 0; r < kSTR; ++r) { const int row = 16 * (kSDiag + r) + m; foA[r] = row / 6; offA[r] = 8 * ((row % 6) * 3 + kq); }
 #pragma unroll
-        for (int x = 0; x < 6; ++x)
+  for (int c = 0; c < kSGC; ++c) { const int col = 16 * (cbase + c) + m; foB[c] = col / 6; offB[c] = 8 * ((col % 6) * 3 + kq); }
+  sf64x4 acc[kSGC][kSTR];
 #pragma unroll
-          for (int y = 0; y < 6; ++y) {
-            const double v = zi[3 * x] * zj[3 * y] + zi[3 * x + 1] * zj[3 * y + 1] + zi[3 * x + 2] * zj[3 * y + 2];
-            atomicAdd(&blk[6 * x + y], v);
-            if (twin) atomicAdd(&blk[6 * y + x], v);
-          }
+  for (int c = 0; c < kSGC; ++c)
+#pragma unroll
+    for (int r = 0; r < kSTR; ++r) acc[c][r] = sf64x4{0.0, 0.0, 0.0, 0.0};
+  double racc[kSTR] = {};   // partial of (Z u) for row 16 r + m, component kq
+
+  // ---- batch gather: chunk q (16 bytes) of the batch image comes from slot_src[slot0 + q / 9] + q % 9
+  uint32_t src_next[kIters];   // table entries of the batch to stream next, loaded one batch ahead
+  auto load_table = [&](uint32_t bi) {
+    const uint32_t s0 = bslot[bi], ns = bslot[bi + 1] - s0;
+#pragma unroll
+    for (int i = 0; i < kIters; ++i) {
+      const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid, slot = q / 9u;
+      src_next[i] = slot < ns ? slot_src[s0 + slot] + (q - 9u * slot) : 0xffffffffu;
+    }
+  };
+  auto stream_batch = [&](uint32_t bi, int buf) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
+#pragma unroll
+    for (int i = 0; i < kIters; ++i)
+      if (src_next[i] != 0xffffffffu)
+        __builtin_amdgcn_global_load_lds((schur_gptr*)(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * src_next[i]),
+                                         (schur_lptr*)(&zbuf[buf][16u * (uint32_t)(64 * kSWv * i + 64 * wv)]), 16, 0, 0);
+    const uint32_t vb = bfirst[bi], nv = bfirst[bi + 1] - vb;
+    if (wv == 0)
+      for (uint32_t c0 = 0; c0 < nv; c0 += 64)
+        if (c0 + lane < nv) __builtin_amdgcn_global_load_lds((schur_gptr*)(visits + vb + c0 + lane), (schur_lptr*)(&recbuf[buf][c0]), 16, 0, 0);
+  };
+
+  // ---- one visit.  Record: x = slot | first frame offset << 16 | frames << 22 | twin << 28 of the row frames, y = the same of the
+  //      group's column frames, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r
+  schur_lds8* zero_l = (schur_lds8*)(&zero2[0]);
+  auto visit = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, int buf) {
+    schur_lds8* zimg = (schur_lds8*)(&zbuf[buf][0]);
+    const bool twin = TWIN && ((vx >> 28) & 1u);
+    const uint32_t layer2 = 144u * (vz >> 16);
+    auto operand = [&](uint32_t rec, uint32_t fo, uint32_t off) -> double {
+      const uint32_t d = fo - ((rec >> 16) & 63u);
+      const bool ok = kq < 3 && d < ((rec >> 22) & 63u);
+      const uint32_t at = 144u * ((rec & 0xffffu) + d) + off;
+      schur_lds8* p_ = ok ? zimg + at : zero_l;
+      double val = *reinterpret_cast<schur_ldsd*>(p_);
+      if (TWIN && twin) { schur_lds8* p2 = ok ? zimg + (at + layer2) : zero_l; val += *reinterpret_cast<schur_ldsd*>(p2); }
+      return val;
+    };
+    double a[kSTR];
+#pragma unroll
+    for (int r = 0; r < kSTR; ++r) a[r] = operand(vx, foA[r], offA[r]);
+    if (with_rhs) {
+      const double ul = *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq));   // (u_l, 0)
+#pragma unroll
+      for (int r = 0; r < kSTR; ++r) racc[r] += a[r] * ul;
+    }
+    // column tiles: the operand of the next active column is read while the current one is multiplied
+    auto column_operand = [&](int c) -> double {
+      if (c >= kSGC || !((bits >> (3 * c)) & 7u)) return 0.0;
+      return operand(vy, foB[c], offB[c]);
+    };
+    double bcur = column_operand(0);
+#pragma unroll
+    for (int c = 0; c < kSGC; ++c) {
+      const double bnxt = column_operand(c + 1);
+      const uint32_t t3 = (bits >> (3 * c)) & 7u;
+      if (t3) {
+#pragma unroll
+        for (int r = 0; r < kSTR; ++r)
+          if (t3 & (1u << r)) mfma_f64_acc(acc[c][r], a[r], bcur);
+      }
+      bcur = bnxt;
+    }
+  };
+
+  const uint32_t b0 = wg_bptr[blockIdx.x], b1 = wg_bptr[blockIdx.x + 1];
+  if (b0 < b1) { load_table(b0); stream_batch(b0, 0); }
+  if (b0 + 1 < b1) load_table(b0 + 1);
+  for (uint32_t bi = b0; bi < b1; ++bi) {
+    const int buf = (int)((bi - b0) & 1u);
+    __syncthreads();   // batch bi has landed (vmcnt(0) + barrier), its successor's table entries too; the other buffer is free
+    if (bi + 1 < b1) { stream_batch(bi + 1, buf ^ 1); if (bi + 2 < b1) load_table(bi + 2); }
+    const uint32_t nv = bfirst[bi + 1] - bfirst[bi];
+    for (uint32_t i = (uint32_t)wv; i < nv; i += kSWv) {
+      const uint4 rv = recbuf[buf][i];
+      visit(__builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z),
+            __builtin_amdgcn_readfirstlane(rv.w), buf);
+    }
+  }
+
+  // ---- add this wavefront's tiles to the tile grid: tile (r, cbase + c), lane, register q -> row 16 r + kq + 4 q, column 16 (cbase + c) + m
+#pragma unroll
+  for (int c = 0; c < kSGC; ++c)
+#pragma unroll
+    for (int r = 0; r < kSTR; ++r) {
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[c][r]));   // 16-pass MFMA result -> VALU read: 18 wait states
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double v = acc[c][r][q];
+        if (v == 0.0) continue;
+        const int row = 16 * r + kq + 4 * q, col = 16 * (cbase + c) + m;
+        const int fp = kSBack + row / 6, x = row % 6, fq = col / 6, y = col % 6;
+        if (fq > fp || (fq == fp && y > x)) continue;
+        const int64_t rp_ = rown[fp], rq_ = rown[fq];
+        if (rp_ < 0 || rq_ < 0) continue;
+        if (fq == fp) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rp_ + y), -v);
+        else if (rp_ > rq_) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rq_ + y), -v);
+        else atomic_add_f64(S_at(rd.S, rd.nt, rq_ + y, rp_ + x), -v);
       }
     }
-    if (lane < k && f_mine >= 0 && f_mine - f0 < kSW) {
-      const double* Zi = zs + 18 * lane;
+  if (with_rhs) {
 #pragma unroll
-      for (int x = 0; x < 6; ++x) atomicAdd(&rhsw[(f_mine - f0) * 6 + x], Zi[3 * x] * u0 + Zi[3 * x + 1] * u1 + Zi[3 * x + 2] * u2);
+    for (int r = 0; r < kSTR; ++r) {
+      double tot = racc[r];
+      tot += __shfl_xor(tot, 16, 64);
+      tot += __shfl_xor(tot, 32, 64);
+      const int row = 16 * r + m;
+      const int64_t rp_ = rown[kSBack + row / 6];
+      if (kq == 0 && tot != 0.0 && rp_ >= 0) atomic_add_f64(rd.rhs + rp_ + row % 6, -tot);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();   // zs is overwritten by the next point
-  }
-  __syncthreads();
-  // flush the window: element (x,y) of block (fp, fq), lower triangle of the tile grid
-  for (int idx = tid; idx < kSW * kSD * 36; idx += kSchurThreads) {
-    const int e = idx % 36, blkid = idx / 36;
-    const double v = acc[blkid * kSB + e];
-    if (v == 0.0) continue;
-    const int dd = blkid % kSD, ri = blkid / kSD;
-    const int fp = f0 + ri, fq = fp - dd;
-    const int x = e / 6, y = e % 6;
-    const int64_t rp_ = row_of_nat[fp], rq_ = row_of_nat[fq];
-    if (dd == 0) { if (y <= x) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rp_ + y), -v); }
-    else if (rp_ > rq_) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rq_ + y), -v);
-    else atomic_add_f64(S_at(rd.S, rd.nt, rq_ + y, rp_ + x), -v);
-  }
-  for (int idx = tid; idx < kSW * 6; idx += kSchurThreads) {
-    const double v = rhsw[idx];
-    if (v != 0.0) atomic_add_f64(rd.rhs + row_of_nat[f0 + idx / 6] + idx % 6, -v);
   }
 }
 
@@ -570,7 +670,7 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
         if (!rp.active[a]) continue;
         const int32_t vid = b.pose_vid[rp.pose[a]];
         if (vid < 0) continue;
-        const double* Z = pt.Z + 18 * (int64_t)a;
+        const double* Z = pt.Z + z_off(a, l);
         const double* y = rd.y + b.pose_row[vid];
 #pragma unroll
         for (int x = 0; x < 6; ++x) { t0 -= Z[3 * x] * y[x]; t1 -= Z[3 * x + 1] * y[x]; t2 -= Z[3 * x + 2] * y[x]; }
@@ -1000,9 +1100,13 @@ void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, c
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
   if (nblk > 0) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)(8 * ((nblk + 7) / 8))), dim3(kBlock), 0, s, nblk, blk_row, blk_col, blk_ptr, pair_a, pair_b, obs_point, pt, rd);
 }
-void launch_schur_window(hipStream_t s, int64_t nchunks, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
-                         const int32_t* nat_of_pose, const int32_t* row_of_nat, const uint32_t* chunk_ptr, const uint32_t* chunk_points, const int32_t* chunk_f0) {
-  if (nchunks > 0) hipLaunchKernelGGL(k_schur_window, dim3((unsigned)nchunks), dim3(kSchurThreads), 0, s, b, rp, pt, rd, nat_of_pose, row_of_nat, chunk_ptr, chunk_points, chunk_f0);
+void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
+                         const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
+                         const int32_t* wg_f0, const int32_t* wg_group) {
+  if (nwg <= 0) return;
+  const uint4* v = reinterpret_cast<const uint4*>(visits);
+  if (has_twins) hipLaunchKernelGGL(k_schur_window<true>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
+  else hipLaunchKernelGGL(k_schur_window<false>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
 }
 void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
                           double* points_cand, double* scal) {

@@ -85,7 +85,9 @@ struct obvi_ba_handle {
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b, d_chunk_ptr, d_chunk_points;
-  DevBuf<int32_t> d_nat_of_pose, d_row_of_nat, d_chunk_f0;
+  DevBuf<int32_t> d_row_of_nat, d_chunk_f0, d_chunk_group;
+  DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
+  int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_back_jobs;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
@@ -390,62 +392,167 @@ void prepare(obvi_ba_handle* h) {
   const int32_t nt = h->nt;
   const int64_t m_pad = (int64_t)nt * kTile;
 
-  // ---- Schur complement work lists.  Points are chunked by the first frame (trajectory order) that observes them;
-  //      k_schur_window accumulates the pairs whose block falls inside the chunk's LDS window, the remaining ordered
-  //      pairs (a, b) with row(a) >= row(b) go to k_schur_blocks grouped by 6x6 block.  The tile mask gets every block.
+  // ---- Schur complement work lists.  k_schur_window takes every ordered observation pair (i >= j) of a point whose
+  //      frame distance is below the window's offset count; a point is visited once per row chunk that holds one of
+  //      its observations.  The remaining pairs (a, b) with row(a) >= row(b) go to k_schur_blocks grouped by 6x6
+  //      block.  The tile mask gets every block.
   const int32_t nt_ = h->nt;
   std::vector<uint8_t> mask((size_t)nt_ * nt_, 0);
   auto mark = [&](int64_t row, int dr, int64_t col, int dc) {
     const int t0 = (int)(row / kTile), t1 = (int)((row + dr - 1) / kTile), c0 = (int)(col / kTile), c1 = (int)((col + dc - 1) / kTile);
     for (int ti = t0; ti <= t1; ++ti) for (int tj = c0; tj <= c1; ++tj) if (ti >= tj) mask[(size_t)ti * nt_ + tj] = 1;
   };
+  auto env_int = [](const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; };
+  constexpr int32_t SR = kSchurRows, SBACK = kSchurWindowFrames - kSchurRows;
+  const int64_t max_visits = std::max(8, env_int("OBVI_SCHUR_VISITS", 1 << 20));   // visits per workgroup (tuning knob)
   struct Pair { uint64_t key; uint32_t a, b; };
   std::vector<Pair> pairs;
-  std::vector<uint32_t> chunk_ptr(1, 0), chunk_points;
-  std::vector<int32_t> chunk_f0;
+  struct Visit { int32_t chunk; uint32_t l, beg, k; bool twin; uint64_t tiles; };
+  std::vector<Visit> visit_list;
   int64_t n_window_pairs = 0;
+  bool any_twin = false;
   {
     struct Ob { uint32_t a; int32_t vid, f; };
     std::vector<Ob> obs;
-    std::vector<std::pair<int32_t, int64_t>> by_first;   // (first frame, point) of the points handled by the window kernel
-    std::vector<int32_t> first_of(L, -1);
+    std::vector<int32_t> chunks;
     for (int64_t l = 0; l < L; ++l) {
       if (!point_var[l]) continue;
-      int32_t f1 = INT32_MAX;
-      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a)
-        if (h->h_rp_active[a] && nat[h->h_rp_pose[a]] >= 0) f1 = std::min(f1, nat[h->h_rp_pose[a]]);
-      if (f1 == INT32_MAX) continue;
-      const bool oversized = (int64_t)(h->h_point_ptr[l + 1] - h->h_point_ptr[l]) > kSchurMaxObsPerPoint;
-      if (!oversized) { by_first.push_back({f1, l}); first_of[l] = (f1 / kSchurChunkFrames) * kSchurChunkFrames; }
-    }
-    std::sort(by_first.begin(), by_first.end());
-    for (size_t q = 0; q < by_first.size(); ++q) {
-      const int32_t c0 = (by_first[q].first / kSchurChunkFrames) * kSchurChunkFrames;
-      if (chunk_f0.empty() || chunk_f0.back() != c0) { if (!chunk_f0.empty()) chunk_ptr.push_back((uint32_t)chunk_points.size()); chunk_f0.push_back(c0); }
-      chunk_points.push_back((uint32_t)by_first[q].second);
-    }
-    if (!chunk_f0.empty()) chunk_ptr.push_back((uint32_t)chunk_points.size());
-    for (int64_t l = 0; l < L; ++l) {
-      if (!point_var[l]) continue;
+      const uint32_t beg = h->h_point_ptr[l], end = h->h_point_ptr[l + 1];
       obs.clear();
-      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
+      for (uint32_t a = beg; a < end; ++a) {
         if (!h->h_rp_active[a]) continue;
         const int32_t v = pose_vid[h->h_rp_pose[a]];
         if (v >= 0) obs.push_back({a, v, nat[h->h_rp_pose[a]]});
       }
-      const int32_t f0 = first_of[l];
-      for (const Ob& x : obs)
-        for (const Ob& y : obs) {
-          if (x.vid < y.vid) continue;
-          mark(h->h_pose_row[x.vid], 6, h->h_pose_row[y.vid], 6);
-          // covered by the LDS window?  (the window indexes by trajectory order: the later frame is the window row)
+      // the strip kernel takes a point unless one of its frames holds more than two observations
+      bool windowed = true, twin = false;
+      for (size_t i = 0; i < obs.size() && windowed; ++i) {
+        int same = 0;
+        for (size_t j = 0; j < obs.size(); ++j) same += obs[j].f == obs[i].f;
+        if (same > 2) windowed = false;
+        if (same == 2) twin = true;
+      }
+      if (windowed) {
+        chunks.clear();
+        for (const Ob& x : obs) { if (std::find(chunks.begin(), chunks.end(), x.f / SR) == chunks.end()) chunks.push_back(x.f / SR); }
+        for (int32_t c : chunks) {
+          // frames of the strip [fbase, fbase + 48) the point covers, then the 16x16 tiles (r, c) of the 3 x 18 strip it touches
+          const int32_t fbase = c * SR - SBACK;
+          uint64_t m = 0, tiles = 0;
+          for (const Ob& x : obs) if (x.f >= fbase && x.f < (c + 1) * SR) m |= 1ull << (x.f - fbase);
+          auto frames_of_tile = [](int t0) { return ((2ull << ((16 * t0 + 15) / 6)) - 1) & ~((1ull << ((16 * t0) / 6)) - 1); };
+          for (int tc = 0; tc < kSchurWindowFrames * 6 / 16; ++tc)
+            for (int tr = 0; tr < SR * 6 / 16; ++tr)
+              if (tc <= tr + SBACK * 6 / 16 && (m & frames_of_tile(tc)) && (m & frames_of_tile(tr + SBACK * 6 / 16))) tiles |= 1ull << (3 * tc + tr);
+          visit_list.push_back({c, (uint32_t)l, beg, (uint32_t)(end - beg), twin, tiles});
+        }
+        any_twin = any_twin || twin;
+      }
+      for (size_t i = 0; i < obs.size(); ++i)
+        for (size_t j = 0; j <= i; ++j) {
+          const Ob& x = obs[i]; const Ob& y = obs[j];
+          mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
+          // inside the strip of the later frame's chunk?  (same test as the kernel's inverse map)
           const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
-          if (f0 >= 0 && fp - f0 < kSchurWindowRows && fp - fq < kSchurWindowOffsets) { ++n_window_pairs; continue; }
-          pairs.push_back({(uint64_t)x.vid * (uint64_t)(h->nPv + 1) + (uint64_t)y.vid, x.a, y.a});
+          if (windowed && fq >= (fp / SR) * SR - SBACK) { ++n_window_pairs; continue; }
+          const Ob& hi = x.vid >= y.vid ? x : y; const Ob& lo = x.vid >= y.vid ? y : x;
+          pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, hi.a, lo.a});
+          if (i != j && x.vid == y.vid) pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, lo.a, hi.a});
         }
     }
   }
-  h->nchunks = (int64_t)chunk_f0.size();
+  // one work list per (chunk, column group): the visits with a tile in that group
+  constexpr int kGroups = (kSchurWindowFrames * 6 / 16) / kSchurGroupCols, kGroupBits = 3 * kSchurGroupCols;
+  struct GVisit { int32_t chunk, group; uint32_t l, beg, k; bool twin; uint32_t bits; };
+  std::vector<GVisit> gv;
+  gv.reserve(2 * visit_list.size());
+  for (const Visit& v : visit_list)
+    for (int g = 0; g < kGroups; ++g) {
+      const uint32_t bits = (uint32_t)(v.tiles >> (kGroupBits * g)) & ((1u << kGroupBits) - 1u);
+      if (bits) gv.push_back({v.chunk, g, v.l, v.beg, v.k, v.twin, bits});
+    }
+  std::stable_sort(gv.begin(), gv.end(), [](const GVisit& x, const GVisit& y) { return x.chunk < y.chunk || (x.chunk == y.chunk && x.group > y.group); });
+  // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
+  const int64_t slice = std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1024)));
+  // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
+  // slots: one per strip frame over the range of its row frames and of its column frames in the group (source: the Z
+  // record, or the zero page for a frame the point skips), the point's (u_l, 0) tail, and -- stereo -- a second layer
+  // with the second record of each frame.
+  const uint32_t zero16 = (uint32_t)((18ull * (uint64_t)h->n_rp + 4ull * (uint64_t)L + 4ull) / 2);   // zero page behind the Z blocks
+  std::vector<uint32_t> wg_bptr(1, 0), bfirst(1, 0), bslot(1, 0), visits, slot_src;
+  std::vector<int32_t> wg_f0, wg_group;
+  visits.reserve(4 * gv.size());
+  constexpr uint32_t kBatchSlots = kSchurBatchBytes / 144;
+  uint32_t rec[4];
+  auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out) {
+    const int32_t fbase = v.chunk * SR - SBACK;
+    const int32_t gA0 = SBACK, gA1 = kSchurWindowFrames - 1;                                                     // row frames (strip offsets)
+    const int32_t gB0 = (16 * kSchurGroupCols * v.group) / 6, gB1 = (16 * kSchurGroupCols * (v.group + 1) - 1) / 6;   // column frames of the group
+    int32_t loA = INT32_MAX, hiA = -1, loB = INT32_MAX, hiB = -1;
+    uint32_t prim[kSchurWindowFrames], sec[kSchurWindowFrames];
+    for (int i = 0; i < kSchurWindowFrames; ++i) prim[i] = sec[i] = zero16;
+    for (uint32_t a = v.beg; a < v.beg + v.k; ++a) {
+      if (!h->h_rp_active[a] || pose_vid[h->h_rp_pose[a]] < 0) continue;
+      const int32_t fo = nat[h->h_rp_pose[a]] - fbase;
+      if (fo < 0 || fo >= kSchurWindowFrames) continue;
+      if (fo >= gA0 && fo <= gA1) { loA = std::min(loA, fo); hiA = std::max(hiA, fo); }
+      if (fo >= gB0 && fo <= gB1) { loB = std::min(loB, fo); hiB = std::max(hiB, fo); }
+      const uint32_t src = (uint32_t)((18ull * a + 4ull * v.l) / 2);
+      if (prim[fo] == zero16) prim[fo] = src; else sec[fo] = src;
+    }
+    out.clear();
+    uint32_t slotA, slotB, tail;
+    const bool merged = loB <= hiA + 1 && loA <= hiB + 1;
+    if (merged) {
+      const int32_t lo = std::min(loA, loB), hi = std::max(hiA, hiB);
+      for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(prim[fo]);
+      slotA = base + (uint32_t)(loA - lo); slotB = base + (uint32_t)(loB - lo); tail = base + (uint32_t)(hi - lo + 1);
+      out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));   // z_tail()
+      if (v.twin) for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(sec[fo]);
+    } else {
+      for (int32_t fo = loA; fo <= hiA; ++fo) out.push_back(prim[fo]);
+      slotA = base; tail = base + (uint32_t)(hiA - loA + 1); slotB = tail + 1;
+      out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));
+      for (int32_t fo = loB; fo <= hiB; ++fo) out.push_back(prim[fo]);
+      if (v.twin) {
+        for (int32_t fo = loA; fo <= hiA; ++fo) out.push_back(sec[fo]);
+        out.push_back(zero16);
+        for (int32_t fo = loB; fo <= hiB; ++fo) out.push_back(sec[fo]);
+      }
+    }
+    const uint32_t layer = v.twin ? (uint32_t)out.size() / 2 + (merged ? 1u : 0u) : 0u;   // slots from a record to its second-layer twin
+    rec[0] = slotA | ((uint32_t)loA << 16) | ((uint32_t)(hiA - loA + 1) << 22) | (v.twin ? 1u << 28 : 0u);
+    rec[1] = slotB | ((uint32_t)loB << 16) | ((uint32_t)(hiB - loB + 1) << 22);
+    rec[2] = tail | (layer << 16);
+    rec[3] = v.bits;
+  };
+  std::vector<uint32_t> vs;
+  for (size_t q = 0; q < gv.size();) {
+    size_t e = q;
+    while (e < gv.size() && gv[e].chunk == gv[q].chunk && gv[e].group == gv[q].group) ++e;
+    const int64_t n = (int64_t)(e - q), parts = (n + slice - 1) / slice, per = (n + parts - 1) / parts;
+    for (size_t w = q; w < e; w += (size_t)per) {
+      const size_t we = std::min(e, w + (size_t)per);
+      uint32_t used = 0, count = 0;
+      for (size_t t = w; t < we; ++t) {
+        visit_slots(gv[t], used, vs);
+        if (count == (uint32_t)kSchurBatchVisits || used + (uint32_t)vs.size() > kBatchSlots) {
+          bfirst.push_back((uint32_t)(visits.size() / 4)); bslot.push_back((uint32_t)slot_src.size()); used = 0; count = 0;
+          visit_slots(gv[t], used, vs);
+        }
+        visits.insert(visits.end(), rec, rec + 4);
+        slot_src.insert(slot_src.end(), vs.begin(), vs.end());
+        used += (uint32_t)vs.size(); ++count;
+      }
+      bfirst.push_back((uint32_t)(visits.size() / 4)); bslot.push_back((uint32_t)slot_src.size());
+      wg_bptr.push_back((uint32_t)(bfirst.size() - 1));
+      wg_f0.push_back(gv[q].chunk * SR);
+      wg_group.push_back(gv[q].group);
+    }
+    q = e;
+  }
+  h->schur_twins = any_twin ? 1 : 0;
+  h->nchunks = (int64_t)wg_f0.size();
   h->npairs_window = n_window_pairs;
   std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key || (x.key == y.key && (x.a < y.a || (x.a == y.a && x.b < y.b))); });
   std::vector<uint32_t> blk_row, blk_col, blk_ptr, pair_a(pairs.size()), pair_b(pairs.size());
@@ -574,8 +681,8 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
   h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
-  h->d_chunk_ptr.upload(chunk_ptr, s); h->d_chunk_points.upload(chunk_points, s); h->d_chunk_f0.upload(chunk_f0, s);
-  h->d_nat_of_pose.upload(nat, s); h->d_row_of_nat.upload(h->h_row_of_nat, s);
+  h->d_chunk_ptr.upload(wg_bptr, s); h->d_batch_first.upload(bfirst, s); h->d_batch_slot.upload(bslot, s); h->d_chunk_points.upload(visits, s); h->d_chunk_f0.upload(wg_f0, s); h->d_chunk_group.upload(wg_group, s);
+  h->d_slot_src.upload(slot_src, s); h->d_row_of_nat.upload(h->h_row_of_nat, s);
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
@@ -595,7 +702,11 @@ void prepare(obvi_ba_handle* h) {
   h->d_Linv.resize((size_t)nt * kTile * kTile);
   h->d_rhs.resize((size_t)m_pad); h->d_y.resize((size_t)m_pad);
   h->d_Ci.resize((size_t)6 * L + 1); h->d_u.resize((size_t)3 * L + 1); h->d_scale_l.resize((size_t)3 * L + 1);
-  h->d_Z.resize((size_t)18 * h->n_rp + 1);
+  {   // z_off(): 18 per observation + (u_l, 0) per point, then a zero page (k_schur_window's source for frames a point skips)
+    const size_t zdata = (size_t)18 * h->n_rp + 4 * (size_t)h->L + 4;
+    h->d_Z.resize(zdata + 36);
+    OBVI_HIP(hipMemsetAsync(h->d_Z.get() + zdata, 0, 36 * sizeof(double), s));
+  }
   h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)7 * O + 1);
   h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
   h->d_pc.resize((size_t)P + 1); h->d_pc_c.resize((size_t)P + 1);
@@ -639,7 +750,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   }
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
   record(h, PH_SCHUR);
-  if (solve) launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
+  if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   record(h, PH_SCHUR_BLOCKS);
   if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   record(h, PH_CHOL);
@@ -1086,7 +1197,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
-  { launch_schur_window(s, h->nchunks, b, rp, pt, rd, h->d_nat_of_pose.get(), h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_chunk_points.get(), h->d_chunk_f0.get());
+  { launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
     launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd); }
   const int64_t mc = h->m_canon, nt = h->nt;
   std::vector<double> tiles((size_t)nt * nt * kTile * kTile), hr((size_t)nt * kTile);
