@@ -503,6 +503,15 @@ typedef __attribute__((address_space(1))) const void schur_gptr;
 typedef __attribute__((address_space(3))) void schur_lptr;
 typedef __attribute__((address_space(3))) const unsigned char schur_lds8;
 typedef __attribute__((address_space(3))) const double schur_ldsd;
+// global -> LDS gather of 16 bytes per lane: lane l's bytes land at lds_base + 16 l (lds_base wave-uniform).  Issued as asm so
+// that the compiler does not order every later LDS read of the *other* batch buffer behind it (it would wait vmcnt(0));
+// the batch loop waits for it explicitly before its barrier.  M0 recipe: cdna_hip_programming.md 5.7.
+__device__ __forceinline__ void gather16_to_lds(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(schur_lptr*)p; }
 // Accumulating MFMA with the accumulator tied in place (VGPR form).  Written as asm because the builtin form of a
 // *conditional* MFMA leaves the choice of C/D registers to the allocator across the join.
 // Wait states (cdna_hip_programming.md 5.7 item 2): 2 after a VALU write of an operand (s_nop 1); none between MFMAs
@@ -517,8 +526,10 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
                                                           const uint32_t* __restrict__ bslot, const uint4* __restrict__ visits,
                                                           const uint32_t* __restrict__ slot_src, const int32_t* __restrict__ wg_f0,
                                                           const int32_t* __restrict__ wg_group) {
-  __shared__ __attribute__((aligned(16))) unsigned char zbuf[2][kSchurBatchBytes];
-  __shared__ __attribute__((aligned(16))) uint4 recbuf[2][kSchurBatchVisits];
+  // two batch buffers as separate objects, each addressed statically (the loop below is unrolled by two): the compiler then
+  // knows that the reads of one do not alias the gather in flight into the other and does not wait for it
+  __shared__ __attribute__((aligned(16))) unsigned char zbuf0[kSchurBatchBytes], zbuf1[kSchurBatchBytes];
+  __shared__ __attribute__((aligned(16))) uint4 recbuf0[kSchurBatchVisits], recbuf1[kSchurBatchVisits];
   __shared__ __attribute__((aligned(16))) double zero2[2];
   __shared__ int32_t rown[kSFr];
   constexpr int kIters = kSchurBatchBytes / 16 / (64 * kSWv);   // gather instructions per lane per batch
@@ -547,27 +558,32 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
     const uint32_t s0 = bslot[bi], ns = bslot[bi + 1] - s0;
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
-      const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid, slot = q / 9u;
-      src_next[i] = slot < ns ? slot_src[s0 + slot] + (q - 9u * slot) : 0xffffffffu;
+      const uint32_t slot = ((uint32_t)(64 * kSWv * i) + (uint32_t)tid) / 9u;
+      src_next[i] = slot < ns ? slot_src[s0 + slot] : 0xffffffffu;
     }
   };
-  auto stream_batch = [&](uint32_t bi, int buf) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
+  using Buf0 = std::integral_constant<int, 0>;
+  using Buf1 = std::integral_constant<int, 1>;
+  auto stream_batch = [&](uint32_t bi, auto which) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
+    unsigned char* zb_ = decltype(which)::value ? zbuf1 : zbuf0;
+    uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
 #pragma unroll
     for (int i = 0; i < kIters; ++i)
-      if (src_next[i] != 0xffffffffu)
-        __builtin_amdgcn_global_load_lds((schur_gptr*)(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * src_next[i]),
-                                         (schur_lptr*)(&zbuf[buf][16u * (uint32_t)(64 * kSWv * i + 64 * wv)]), 16, 0, 0);
+      if (src_next[i] != 0xffffffffu) {
+        const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid;
+        gather16_to_lds(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * (src_next[i] + q % 9u), lds_address(zb_) + 16u * (uint32_t)(64 * kSWv * i + 64 * wv));
+      }
     const uint32_t vb = bfirst[bi], nv = bfirst[bi + 1] - vb;
     if (wv == 0)
       for (uint32_t c0 = 0; c0 < nv; c0 += 64)
-        if (c0 + lane < nv) __builtin_amdgcn_global_load_lds((schur_gptr*)(visits + vb + c0 + lane), (schur_lptr*)(&recbuf[buf][c0]), 16, 0, 0);
+        if (c0 + lane < nv) gather16_to_lds(visits + vb + c0 + lane, lds_address(rb_) + 16u * c0);
   };
 
   // ---- one visit.  Record: x = slot | first frame offset << 16 | frames << 22 | twin << 28 of the row frames, y = the same of the
   //      group's column frames, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r
   schur_lds8* zero_l = (schur_lds8*)(&zero2[0]);
-  auto visit = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, int buf) {
-    schur_lds8* zimg = (schur_lds8*)(&zbuf[buf][0]);
+  auto visit = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, auto which) {
+    schur_lds8* zimg = decltype(which)::value ? (schur_lds8*)(&zbuf1[0]) : (schur_lds8*)(&zbuf0[0]);
     const bool twin = TWIN && ((vx >> 28) & 1u);
     const uint32_t layer2 = 144u * (vz >> 16);
     auto operand = [&](uint32_t rec, uint32_t fo, uint32_t off) -> double {
@@ -607,18 +623,23 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
   };
 
   const uint32_t b0 = wg_bptr[blockIdx.x], b1 = wg_bptr[blockIdx.x + 1];
-  if (b0 < b1) { load_table(b0); stream_batch(b0, 0); }
+  if (b0 < b1) { load_table(b0); stream_batch(b0, Buf0{}); }
   if (b0 + 1 < b1) load_table(b0 + 1);
-  for (uint32_t bi = b0; bi < b1; ++bi) {
-    const int buf = (int)((bi - b0) & 1u);
-    __syncthreads();   // batch bi has landed (vmcnt(0) + barrier), its successor's table entries too; the other buffer is free
-    if (bi + 1 < b1) { stream_batch(bi + 1, buf ^ 1); if (bi + 2 < b1) load_table(bi + 2); }
+  auto batch = [&](uint32_t bi, auto which, auto other) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's part of batch bi has landed, its successor's table entries too
+    __syncthreads();                                    // ... everybody's; and the other buffer is free
+    if (bi + 1 < b1) { stream_batch(bi + 1, other); if (bi + 2 < b1) load_table(bi + 2); }
     const uint32_t nv = bfirst[bi + 1] - bfirst[bi];
+    const uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
     for (uint32_t i = (uint32_t)wv; i < nv; i += kSWv) {
-      const uint4 rv = recbuf[buf][i];
+      const uint4 rv = rb_[i];
       visit(__builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z),
-            __builtin_amdgcn_readfirstlane(rv.w), buf);
+            __builtin_amdgcn_readfirstlane(rv.w), which);
     }
+  };
+  for (uint32_t bi = b0; bi < b1; bi += 2) {
+    batch(bi, Buf0{}, Buf1{});
+    if (bi + 1 < b1) batch(bi + 1, Buf1{}, Buf0{});
   }
 
   // ---- add this wavefront's tiles to the tile grid: tile (r, cbase + c), lane, register q -> row 16 r + kq + 4 q, column 16 (cbase + c) + m
