@@ -103,9 +103,9 @@ struct PointDev {           // per eliminated point
 
 // ---- launchers (ba_kernels.hip) --------------------------------------------------------
 void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out);
-void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc,
-                       const double* points, const ReducedDev& rd, const PointDev& pt, double radius, int first_iter,
-                       double* scal);
+void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
+                       const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
+                       const uint32_t* long_points, int64_t n_long);
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc,
                       const double* points, const ReducedDev& rd);
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams,

@@ -85,14 +85,17 @@ __global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* 
 }
 
 // ---------------------------------------------------------------------------------------
-// K1.  One thread per point; the point's observations are contiguous (CSC by point).
+// K1 (long tracks).  One thread per point, for the points with more observations than a wavefront has lanes
+// (list built by the host; usually empty).  Same arithmetic as k_point_pass below.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
-                                                      const PoseCache* __restrict__ pc, const double* __restrict__ points,
-                                                      ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal) {
-  const int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+                                                           const PoseCache* __restrict__ pc, const double* __restrict__ points,
+                                                           ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal,
+                                                           const uint32_t* __restrict__ long_points, int64_t n_long) {
+  const int64_t idx = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
-  if (l < b.L) {
+  if (idx < n_long) {
+    const int64_t l = long_points[idx];
     const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
     const bool lvar = b.point_var[l] != 0;
     const double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
@@ -150,6 +153,122 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
         double rho0, w;
         huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+        const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
+        const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
+        double* Z = pt.Z + z_off(a, l);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          Z[3 * x] = w * (Jp[x] * m00 + Jp[6 + x] * m10);
+          Z[3 * x + 1] = w * (Jp[x] * m01 + Jp[6 + x] * m11);
+          Z[3 * x + 2] = w * (Jp[x] * m02 + Jp[6 + x] * m12);
+        }
+      }
+    }
+  }
+  block_accumulate(cost, scal + SC_COST);
+  block_accumulate(gsq, scal + SC_GSQ);
+  block_accumulate(xsq, scal + SC_XSQ);
+  block_accumulate(fail, scal + SC_CHOL_FAIL);
+  block_accumulate_max(gmax, scal + SC_GMAX_BITS);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1.  Point side of the reprojection linearisation, one lane per observation.  The observations are stored by point
+// (CSC), so the lanes of a wavefront read 64 consecutive records (coalesced) and the observations of a point are a
+// run of consecutive lanes; the host cuts the observation list into wavefront-sized pieces at point boundaries
+// (first observation and count per piece, at most 64, whole points).  Per lane: residual + closed-form Jacobians + Huber once
+// (the one-thread-per-point form evaluated them twice).  Per point: H_ll = sum rho' Jl^T Jl, g_l = sum rho' Jl^T r
+// summed by the run's first lane in observation order through LDS, then broadcast to the run; every lane forms the
+// 3x3 Cholesky of H_ll + lambda and its own Z = rho' Jp^T Jl C^-T.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+                                                      const PoseCache* __restrict__ pc, const double* __restrict__ points,
+                                                      ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal,
+                                                      const uint32_t* __restrict__ wave_obs, int64_t n_waves) {
+  __shared__ double ex[kBlock / 64][10][64];   // per wavefront: 9 sums + spare, [value][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t gw = blockIdx.x * (int64_t)(kBlock / 64) + wv;
+  double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
+  if (gw < n_waves) {
+    const uint32_t a0 = wave_obs[2 * gw], n = wave_obs[2 * gw + 1];
+    const bool have = (uint32_t)lane < n;
+    const uint32_t a = a0 + (have ? (uint32_t)lane : 0u);
+    const uint32_t l = rp.point[a], p = rp.pose[a];
+    const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
+    const bool lvar = b.point_var[l] != 0;
+    const int32_t vid = b.pose_vid[p];
+    const bool live = have && rp.active[a] && (vid >= 0 || lvar);   // else: inactive, or an all-constant residual block (fixed cost)
+    const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+    double r[2] = {0.0, 0.0}, Jp[12], Jl[6], w = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jp[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Jl[i] = 0.0;
+    if (live) {
+      const double2 px = rp.pixel[a];
+      reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
+      double rho0;
+      huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
+      cost = 0.5 * rho0;
+    }
+    const bool sum = live && lvar;
+    double* e = &ex[wv][0][0];
+    e[0 * 64 + lane] = sum ? w * (Jl[0] * Jl[0] + Jl[3] * Jl[3]) : 0.0;
+    e[1 * 64 + lane] = sum ? w * (Jl[1] * Jl[0] + Jl[4] * Jl[3]) : 0.0;
+    e[2 * 64 + lane] = sum ? w * (Jl[1] * Jl[1] + Jl[4] * Jl[4]) : 0.0;
+    e[3 * 64 + lane] = sum ? w * (Jl[2] * Jl[0] + Jl[5] * Jl[3]) : 0.0;
+    e[4 * 64 + lane] = sum ? w * (Jl[2] * Jl[1] + Jl[5] * Jl[4]) : 0.0;
+    e[5 * 64 + lane] = sum ? w * (Jl[2] * Jl[2] + Jl[5] * Jl[5]) : 0.0;
+    e[6 * 64 + lane] = sum ? w * (Jl[0] * r[0] + Jl[3] * r[1]) : 0.0;
+    e[7 * 64 + lane] = sum ? w * (Jl[1] * r[0] + Jl[4] * r[1]) : 0.0;
+    e[8 * 64 + lane] = sum ? w * (Jl[2] * r[0] + Jl[5] * r[1]) : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the first lane of a run adds up its run in observation order (same order as a sequential loop over the point)
+    const int first = (int)(beg - a0), len = (int)(end - beg);
+    const bool head = have && a == beg;
+    double t[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (head && lvar) {
+      for (int i = 0; i < len; ++i)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) t[q] += e[q * 64 + first + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (head) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) e[q * 64 + lane] = t[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (have && lvar) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) t[q] = e[q * 64 + first];
+      const double h00 = t[0], h10 = t[1], h11 = t[2], h20 = t[3], h21 = t[4], h22 = t[5], g0 = t[6], g1 = t[7], g2 = t[8];
+      double s0, s1, s2;
+      if (first_iter) { s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); s2 = 1.0 / (1.0 + sqrt(h22)); }
+      else { s0 = pt.scale[3 * (int64_t)l]; s1 = pt.scale[3 * (int64_t)l + 1]; s2 = pt.scale[3 * (int64_t)l + 2]; }
+      const double a00 = h00 + lm_lambda(h00, s0, radius), a11 = h11 + lm_lambda(h11, s1, radius), a22 = h22 + lm_lambda(h22, s2, radius);
+      // 3x3 Cholesky A = C C^T and Ci = C^-1
+      const double c00 = sqrt(a00), c10 = h10 / c00, c20 = h20 / c00;
+      const double d11 = a11 - c10 * c10;
+      const double c11 = sqrt(d11), c21 = (h21 - c20 * c10) / c11;
+      const double d22 = a22 - c20 * c20 - c21 * c21;
+      const double c22 = sqrt(d22);
+      const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+      const double i10 = -c10 * i00 * i11, i21 = -c21 * i11 * i22, i20 = -(c20 * i00 + c21 * i10) * i22;
+      if (head) {
+        if (!(a00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) fail = 1.0;
+        xsq = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+        gsq = g0 * g0 + g1 * g1 + g2 * g2;
+        gmax = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+        if (first_iter) { pt.scale[3 * (int64_t)l] = s0; pt.scale[3 * (int64_t)l + 1] = s1; pt.scale[3 * (int64_t)l + 2] = s2; }
+        double* Ci = pt.Ci + 6 * (int64_t)l;
+        Ci[0] = i00; Ci[1] = i10; Ci[2] = i11; Ci[3] = i20; Ci[4] = i21; Ci[5] = i22;
+        const double ul0 = i00 * g0, ul1 = i10 * g0 + i11 * g1, ul2 = i20 * g0 + i21 * g1 + i22 * g2;
+        pt.u[3 * (int64_t)l] = ul0; pt.u[3 * (int64_t)l + 1] = ul1; pt.u[3 * (int64_t)l + 2] = ul2;
+        double* ut = pt.Z + z_tail(end, l); ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0;   // copy behind the point's Z records (k_schur_window)
+      }
+      if (live && vid >= 0) {   // Z = rho' Jp^T (Jl Ci^T)
         const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
         const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
         double* Z = pt.Z + z_off(a, l);
@@ -1100,8 +1219,10 @@ void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache*
   if (P > 0) hipLaunchKernelGGL(k_pose_cache, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, P, poses, out);
 }
 void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
-                       const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal) {
-  if (b.L > 0 && rp.n > 0) hipLaunchKernelGGL(k_point_pass, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal);
+                       const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
+                       const uint32_t* long_points, int64_t n_long) {
+  if (n_waves > 0) hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, wave_obs, n_waves);
+  if (n_long > 0) hipLaunchKernelGGL(k_point_pass_long, dim3(grid_for(n_long, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, long_points, n_long);
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
                       const ReducedDev& rd) {

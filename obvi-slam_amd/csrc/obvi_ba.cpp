@@ -67,7 +67,8 @@ struct obvi_ba_handle {
   DevBuf<int32_t> d_pose_vid, d_obj_vid;
   DevBuf<uint8_t> d_point_var;
   // ---- device: factors ----
-  DevBuf<uint32_t> d_rp_pose, d_rp_point, d_rp_perm, d_point_ptr;
+  DevBuf<uint32_t> d_rp_pose, d_rp_point, d_rp_perm, d_point_ptr, d_wave_obs, d_long_points;
+  int64_t n_point_waves = 0, n_long_points = 0;
   DevBuf<uint16_t> d_rp_cam;
   DevBuf<double2> d_rp_pixel;
   DevBuf<double> d_rp_sigma;
@@ -735,7 +736,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
   h->d_rhs.zero(s);
   record(h, PH_POINT_PASS);
-  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal);
+  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   record(h, PH_POSE_PASS);
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   record(h, PH_SMALL);
@@ -964,6 +965,22 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     sg[a] = sigma ? sigma[i] : sigma_scalar;
   }
   hipStream_t s = h->stream;
+  {   // k_point_pass: the observation list cut into wavefront-sized pieces (<= 64 observations, whole points); longer tracks go to the per-point kernel
+    std::vector<uint32_t> wave_obs, long_points;   // wave_obs: (first observation, count) per piece
+    uint32_t start = 0, count = 0;
+    for (int64_t l = 0; l < h->L; ++l) {
+      const uint32_t k = ptr[l + 1] - ptr[l];
+      if (k == 0) continue;
+      if (count > 0 && (k > 64 || count + k > 64)) { wave_obs.push_back(start); wave_obs.push_back(count); count = 0; }
+      if (k > 64) { long_points.push_back((uint32_t)l); continue; }
+      if (count == 0) start = ptr[l];
+      count += k;
+    }
+    if (count > 0) { wave_obs.push_back(start); wave_obs.push_back(count); }
+    h->n_point_waves = (int64_t)wave_obs.size() / 2;
+    h->n_long_points = (int64_t)long_points.size();
+    h->d_wave_obs.upload(wave_obs, s); h->d_long_points.upload(long_points, s);
+  }
   h->d_rp_pose.upload(h->h_rp_pose, s); h->d_rp_point.upload(h->h_rp_point, s); h->d_rp_perm.upload(perm, s); h->d_point_ptr.upload(ptr, s);
   h->d_rp_cam.upload(cam, s); h->d_rp_pixel.upload(pix, s); h->d_rp_sigma.upload(sg, s); h->d_rp_active.upload(h->h_rp_active, s);
   // CSR-by-pose copy for the pose-side pass (counting sort on the pose index; stable, so points ascend inside a pose)
@@ -1193,7 +1210,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   h->d_Hdiag.zero(s); h->d_g.zero(s); h->d_rhs.zero(s);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
   launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
-  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get());
+  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get(), h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
   launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, 1, h->d_scal.get());
