@@ -65,6 +65,32 @@ __device__ __forceinline__ double* S_at(double* S, int32_t nt, int64_t i, int64_
   return S + ((i / kTile) * (int64_t)nt + (j / kTile)) * (kTile * kTile) + (i % kTile) * kTile + (j % kTile);
 }
 
+// 1/sqrt(p): hardware v_rsq_f64 seed + two Newton steps (<= 1-2 ulp for normal positive p; NaN/inf for p <= 0, which the caller flags)
+__device__ __forceinline__ double rsqrt_f64(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  double e = fma(-p * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  e = fma(-p * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  return y;
+}
+// block-wide sums of 4 values and maximum of a 5th with one barrier pair -> one atomic each per block
+__device__ __forceinline__ void block_accumulate5(double v0, double* d0, double v1, double* d1, double v2, double* d2, double v3, double* d3, double vmax, double* dmax_bits) {
+  __shared__ double sm5[kBlock / 64][5];
+  v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); vmax = wave_max(vmax);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sm5[w][0] = v0; sm5[w][1] = v1; sm5[w][2] = v2; sm5[w][3] = v3; sm5[w][4] = vmax; }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) t = threadIdx.x < 4 ? t + sm5[i][threadIdx.x] : fmax(t, sm5[i][4]);
+    double* dst = threadIdx.x == 0 ? d0 : threadIdx.x == 1 ? d1 : threadIdx.x == 2 ? d2 : threadIdx.x == 3 ? d3 : dmax_bits;
+    if (threadIdx.x < 4) { if (t != 0.0) atomic_add_f64(dst, t); }
+    else if (t > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t));
+  }
+}
+
 __device__ __forceinline__ double lm_lambda(double colsq, double scale, double radius) {
   // LevenbergMarquardtStrategy::ComputeStep [Ceres-doc]: D^2 = clamp(diag(Js^T Js), 1e-6, 1e32) / radius on
   // the Jacobi-scaled Jacobian Js = J diag(scale); in unscaled variables the damping is D^2 / scale^2.
@@ -178,19 +204,22 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
 // run of consecutive lanes; the host cuts the observation list into wavefront-sized pieces at point boundaries
 // (first observation and count per piece, at most 64, whole points).  Per lane: residual + closed-form Jacobians + Huber once
 // (the one-thread-per-point form evaluated them twice).  Per point: H_ll = sum rho' Jl^T Jl, g_l = sum rho' Jl^T r
-// summed by the run's first lane in observation order through LDS, then broadcast to the run; every lane forms the
+// by a segmented scan over the run's lanes (shuffles); every lane forms the
 // 3x3 Cholesky of H_ll + lambda and its own Z = rho' Jp^T Jl C^-T.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
                                                       const PoseCache* __restrict__ pc, const double* __restrict__ points,
                                                       ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal,
                                                       const uint32_t* __restrict__ wave_obs, int64_t n_waves) {
-  __shared__ double ex[kBlock / 64][10][64];   // per wavefront: 9 sums + spare, [value][lane]
+  // per wavefront: the image of the wavefront's part of the Z storage (records + tails, 18 n + 4 points <= 18 * 64 + 4 * 64
+  // doubles), written out with coalesced 16-byte stores
+  __shared__ __attribute__((aligned(16))) double ex[kBlock / 64][22 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t gw = blockIdx.x * (int64_t)(kBlock / 64) + wv;
   double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
   if (gw < n_waves) {
     const uint32_t a0 = wave_obs[2 * gw], n = wave_obs[2 * gw + 1];
+    const uint32_t l0 = rp.point[a0], l1 = rp.point[a0 + n - 1];   // first and last point of the piece (host: l1 - l0 < 64)
     const bool have = (uint32_t)lane < n;
     const uint32_t a = a0 + (have ? (uint32_t)lane : 0u);
     const uint32_t l = rp.point[a], p = rp.pose[a];
@@ -212,49 +241,42 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
       cost = 0.5 * rho0;
     }
     const bool sum = live && lvar;
-    double* e = &ex[wv][0][0];
-    e[0 * 64 + lane] = sum ? w * (Jl[0] * Jl[0] + Jl[3] * Jl[3]) : 0.0;
-    e[1 * 64 + lane] = sum ? w * (Jl[1] * Jl[0] + Jl[4] * Jl[3]) : 0.0;
-    e[2 * 64 + lane] = sum ? w * (Jl[1] * Jl[1] + Jl[4] * Jl[4]) : 0.0;
-    e[3 * 64 + lane] = sum ? w * (Jl[2] * Jl[0] + Jl[5] * Jl[3]) : 0.0;
-    e[4 * 64 + lane] = sum ? w * (Jl[2] * Jl[1] + Jl[5] * Jl[4]) : 0.0;
-    e[5 * 64 + lane] = sum ? w * (Jl[2] * Jl[2] + Jl[5] * Jl[5]) : 0.0;
-    e[6 * 64 + lane] = sum ? w * (Jl[0] * r[0] + Jl[3] * r[1]) : 0.0;
-    e[7 * 64 + lane] = sum ? w * (Jl[1] * r[0] + Jl[4] * r[1]) : 0.0;
-    e[8 * 64 + lane] = sum ? w * (Jl[2] * r[0] + Jl[5] * r[1]) : 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // the first lane of a run adds up its run in observation order (same order as a sequential loop over the point)
+    // per point: sums over its run of lanes (segmented inclusive scan, then everybody reads the run's last lane)
     const int first = (int)(beg - a0), len = (int)(end - beg);
     const bool head = have && a == beg;
-    double t[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (head && lvar) {
-      for (int i = 0; i < len; ++i)
+    double t[9];
+    t[0] = sum ? w * (Jl[0] * Jl[0] + Jl[3] * Jl[3]) : 0.0;
+    t[1] = sum ? w * (Jl[1] * Jl[0] + Jl[4] * Jl[3]) : 0.0;
+    t[2] = sum ? w * (Jl[1] * Jl[1] + Jl[4] * Jl[4]) : 0.0;
+    t[3] = sum ? w * (Jl[2] * Jl[0] + Jl[5] * Jl[3]) : 0.0;
+    t[4] = sum ? w * (Jl[2] * Jl[1] + Jl[5] * Jl[4]) : 0.0;
+    t[5] = sum ? w * (Jl[2] * Jl[2] + Jl[5] * Jl[5]) : 0.0;
+    t[6] = sum ? w * (Jl[0] * r[0] + Jl[3] * r[1]) : 0.0;
+    t[7] = sum ? w * (Jl[1] * r[0] + Jl[4] * r[1]) : 0.0;
+    t[8] = sum ? w * (Jl[2] * r[0] + Jl[5] * r[1]) : 0.0;
+    const int seg0 = have ? first : lane;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) t[q] += e[q * 64 + first + i];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (head) {
+    for (int d = 1; d < 64; d <<= 1) {
+      const bool take = lane - d >= seg0;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) e[q * 64 + lane] = t[q];
+      for (int q = 0; q < 9; ++q) { const double up = __shfl_up(t[q], d, 64); t[q] += take ? up : 0.0; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    const int last = have ? min(first + len - 1, 63) : lane;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) t[q] = __shfl(t[q], last, 64);
+    double* img = &ex[wv][0];          // img[18 (a - a0) + 4 (l - l0)] <-> pt.Z[z_off(a, l)]
     if (have && lvar) {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) t[q] = e[q * 64 + first];
       const double h00 = t[0], h10 = t[1], h11 = t[2], h20 = t[3], h21 = t[4], h22 = t[5], g0 = t[6], g1 = t[7], g2 = t[8];
       double s0, s1, s2;
       if (first_iter) { s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); s2 = 1.0 / (1.0 + sqrt(h22)); }
       else { s0 = pt.scale[3 * (int64_t)l]; s1 = pt.scale[3 * (int64_t)l + 1]; s2 = pt.scale[3 * (int64_t)l + 2]; }
       const double a00 = h00 + lm_lambda(h00, s0, radius), a11 = h11 + lm_lambda(h11, s1, radius), a22 = h22 + lm_lambda(h22, s2, radius);
-      // 3x3 Cholesky A = C C^T and Ci = C^-1
-      const double c00 = sqrt(a00), c10 = h10 / c00, c20 = h20 / c00;
+      // 3x3 Cholesky A = C C^T and Ci = C^-1, division-free: i_kk = rsqrt(pivot)
+      const double i00 = rsqrt_f64(a00), c10 = h10 * i00, c20 = h20 * i00;
       const double d11 = a11 - c10 * c10;
-      const double c11 = sqrt(d11), c21 = (h21 - c20 * c10) / c11;
+      const double i11 = rsqrt_f64(d11), c21 = (h21 - c20 * c10) * i11;
       const double d22 = a22 - c20 * c20 - c21 * c21;
-      const double c22 = sqrt(d22);
-      const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+      const double i22 = rsqrt_f64(d22);
       const double i10 = -c10 * i00 * i11, i21 = -c21 * i11 * i22, i20 = -(c20 * i00 + c21 * i10) * i22;
       if (head) {
         if (!(a00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0)) fail = 1.0;
@@ -266,26 +288,30 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         Ci[0] = i00; Ci[1] = i10; Ci[2] = i11; Ci[3] = i20; Ci[4] = i21; Ci[5] = i22;
         const double ul0 = i00 * g0, ul1 = i10 * g0 + i11 * g1, ul2 = i20 * g0 + i21 * g1 + i22 * g2;
         pt.u[3 * (int64_t)l] = ul0; pt.u[3 * (int64_t)l + 1] = ul1; pt.u[3 * (int64_t)l + 2] = ul2;
-        double* ut = pt.Z + z_tail(end, l); ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0;   // copy behind the point's Z records (k_schur_window)
+        double* ut = img + 18 * (first + len) + 4 * (int)(l - l0);   // (u_l, 0) behind the point's Z records (k_schur_window)
+        ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0;
       }
-      if (live && vid >= 0) {   // Z = rho' Jp^T (Jl Ci^T)
-        const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
-        const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
-        double* Z = pt.Z + z_off(a, l);
+      // Z = rho' Jp^T (Jl Ci^T); w = 0 for an observation without a Z record (inactive / constant pose): its slot is never read
+      const double wz = (live && vid >= 0) ? w : 0.0;
+      const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
+      const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
+      double* Z = img + 18 * lane + 4 * (int)(l - l0);
 #pragma unroll
-        for (int x = 0; x < 6; ++x) {
-          Z[3 * x] = w * (Jp[x] * m00 + Jp[6 + x] * m10);
-          Z[3 * x + 1] = w * (Jp[x] * m01 + Jp[6 + x] * m11);
-          Z[3 * x + 2] = w * (Jp[x] * m02 + Jp[6 + x] * m12);
-        }
+      for (int x = 0; x < 6; ++x) {
+        Z[3 * x] = wz * (Jp[x] * m00 + Jp[6 + x] * m10);
+        Z[3 * x + 1] = wz * (Jp[x] * m01 + Jp[6 + x] * m11);
+        Z[3 * x + 2] = wz * (Jp[x] * m02 + Jp[6 + x] * m12);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // write the image: contiguous in global memory, 16 bytes per lane per store (slots of constant points carry stale LDS data: never read)
+    const int total2 = (18 * (int)n + 4 * (int)(l1 - l0 + 1)) / 2;
+    double2* dst = reinterpret_cast<double2*>(pt.Z + z_off(a0, l0));
+    const double2* src = reinterpret_cast<const double2*>(img);
+    for (int i = lane; i < total2; i += 64) dst[i] = src[i];
   }
-  block_accumulate(cost, scal + SC_COST);
-  block_accumulate(gsq, scal + SC_GSQ);
-  block_accumulate(xsq, scal + SC_XSQ);
-  block_accumulate(fail, scal + SC_CHOL_FAIL);
-  block_accumulate_max(gmax, scal + SC_GMAX_BITS);
+  block_accumulate5(cost, scal + SC_COST, gsq, scal + SC_GSQ, xsq, scal + SC_XSQ, fail, scal + SC_CHOL_FAIL, gmax, scal + SC_GMAX_BITS);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -968,12 +968,13 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   {   // k_point_pass: the observation list cut into wavefront-sized pieces (<= 64 observations, whole points); longer tracks go to the per-point kernel
     std::vector<uint32_t> wave_obs, long_points;   // wave_obs: (first observation, count) per piece
     uint32_t start = 0, count = 0;
+    int64_t lfirst = 0;
     for (int64_t l = 0; l < h->L; ++l) {
       const uint32_t k = ptr[l + 1] - ptr[l];
       if (k == 0) continue;
-      if (count > 0 && (k > 64 || count + k > 64)) { wave_obs.push_back(start); wave_obs.push_back(count); count = 0; }
+      if (count > 0 && (k > 64 || count + k > 64 || l - lfirst >= 64)) { wave_obs.push_back(start); wave_obs.push_back(count); count = 0; }
       if (k > 64) { long_points.push_back((uint32_t)l); continue; }
-      if (count == 0) start = ptr[l];
+      if (count == 0) { start = ptr[l]; lfirst = l; }
       count += k;
     }
     if (count > 0) { wave_obs.push_back(start); wave_obs.push_back(count); }
