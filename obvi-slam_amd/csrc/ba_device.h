@@ -97,6 +97,8 @@ struct ReducedDev {         // accumulators of the reduced system
 struct PointDev {           // per eliminated point
   double* Ci;               // [L][6]  inverse Cholesky factor of (Hll + lambda), lower-tri packed (00,10,11,20,21,22)
   double* u;                // [L][3]  Ci * g_l
+  double* gl;               // [L][3]  g_l = sum rho' Jl^T r
+  double* lam;              // [L][3]  LM damping of the point block (unscaled normal equations)
   double* scale;            // [L][3]  Jacobi scaling
   double* Z;                // [N_r][18] 6x3 row-major:  rho' Jp^T Jl Ci^T
 };

@@ -154,7 +154,9 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
       } else {
         s0 = pt.scale[3 * l]; s1 = pt.scale[3 * l + 1]; s2 = pt.scale[3 * l + 2];
       }
-      const double a00 = h00 + lm_lambda(h00, s0, radius), a11 = h11 + lm_lambda(h11, s1, radius), a22 = h22 + lm_lambda(h22, s2, radius);
+      const double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      const double a00 = h00 + lam0, a11 = h11 + lam1, a22 = h22 + lam2;
+      pt.gl[3 * l] = g0; pt.gl[3 * l + 1] = g1; pt.gl[3 * l + 2] = g2; pt.lam[3 * l] = lam0; pt.lam[3 * l + 1] = lam1; pt.lam[3 * l + 2] = lam2;
       // 3x3 Cholesky A = C C^T and Ci = C^-1
       const double c00 = sqrt(a00), c10 = h10 / c00, c20 = h20 / c00;
       const double d11 = a11 - c10 * c10;
@@ -270,7 +272,8 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
       double s0, s1, s2;
       if (first_iter) { s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); s2 = 1.0 / (1.0 + sqrt(h22)); }
       else { s0 = pt.scale[3 * (int64_t)l]; s1 = pt.scale[3 * (int64_t)l + 1]; s2 = pt.scale[3 * (int64_t)l + 2]; }
-      const double a00 = h00 + lm_lambda(h00, s0, radius), a11 = h11 + lm_lambda(h11, s1, radius), a22 = h22 + lm_lambda(h22, s2, radius);
+      const double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      const double a00 = h00 + lam0, a11 = h11 + lam1, a22 = h22 + lam2;
       // 3x3 Cholesky A = C C^T and Ci = C^-1, division-free: i_kk = rsqrt(pivot)
       const double i00 = rsqrt_f64(a00), c10 = h10 * i00, c20 = h20 * i00;
       const double d11 = a11 - c10 * c10;
@@ -284,6 +287,8 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         gsq = g0 * g0 + g1 * g1 + g2 * g2;
         gmax = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
         if (first_iter) { pt.scale[3 * (int64_t)l] = s0; pt.scale[3 * (int64_t)l + 1] = s1; pt.scale[3 * (int64_t)l + 2] = s2; }
+        pt.gl[3 * (int64_t)l] = g0; pt.gl[3 * (int64_t)l + 1] = g1; pt.gl[3 * (int64_t)l + 2] = g2;
+        pt.lam[3 * (int64_t)l] = lam0; pt.lam[3 * (int64_t)l + 1] = lam1; pt.lam[3 * (int64_t)l + 2] = lam2;
         double* Ci = pt.Ci + 6 * (int64_t)l;
         Ci[0] = i00; Ci[1] = i10; Ci[2] = i11; Ci[3] = i20; Ci[4] = i21; Ci[5] = i22;
         const double ul0 = i00 * g0, ul1 = i10 * g0 + i11 * g1, ul2 = i20 * g0 + i21 * g1 + i22 * g2;
@@ -826,7 +831,7 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
 __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points,
                                                          double* __restrict__ points_cand, double* scal) {
   const int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-  double stepsq = 0.0, bad = 0.0;
+  double stepsq = 0.0, bad = 0.0, model = 0.0;
   if (l < b.L) {
     double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
     if (b.point_var[l]) {
@@ -847,17 +852,19 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
       if (!isfinite(d0) || !isfinite(d1) || !isfinite(d2)) bad = 1.0;
       X[0] += d0; X[1] += d1; X[2] += d2;
       stepsq = d0 * d0 + d1 * d1 + d2 * d2;
+      model = 0.5 * (pt.lam[3 * l] * d0 * d0 + pt.lam[3 * l + 1] * d1 * d1 + pt.lam[3 * l + 2] * d2 * d2 - (pt.gl[3 * l] * d0 + pt.gl[3 * l + 1] * d1 + pt.gl[3 * l + 2] * d2));
     }
     points_cand[3 * l] = X[0]; points_cand[3 * l + 1] = X[1]; points_cand[3 * l + 2] = X[2];
   }
   block_accumulate(stepsq, scal + SC_STEPSQ);
   block_accumulate(bad, scal + SC_NONFINITE);
+  block_accumulate(model, scal + SC_MODEL_CHANGE);
 }
 
 __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, ReducedDev rd, const double* __restrict__ poses, const double* __restrict__ objects,
                                                               double* __restrict__ poses_cand, double* __restrict__ objects_cand, double* scal) {
   const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-  double stepsq = 0.0, bad = 0.0;
+  double stepsq = 0.0, bad = 0.0, model = 0.0;
   if (t < b.P + b.O) {
     const bool is_pose = t < b.P;
     const int64_t idx = is_pose ? t : t - b.P;
@@ -866,6 +873,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
     const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
     double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
     const int64_t row = vid < 0 ? 0 : (is_pose ? b.pose_row[vid] : b.obj_row[vid]);
+    const int64_t ci = vid < 0 ? 0 : (is_pose ? 6 * (int64_t)vid : 6 * (int64_t)b.nPv + 7 * (int64_t)vid);   // compact index of g, lam
     const bool count = is_pose || vid < 0 || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
     for (int k = 0; k < d; ++k) {
       double v = x[k];
@@ -873,193 +881,88 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
         const double dlt = -rd.y[row + k];
         if (!isfinite(dlt)) bad = 1.0;
         v += dlt;
-        if (count) stepsq += dlt * dlt;
+        if (count) { stepsq += dlt * dlt; model += 0.5 * dlt * (rd.lam[ci + k] * dlt - rd.g[ci + k]); }
       }
       xc[k] = v;
     }
   }
   block_accumulate(stepsq, scal + SC_STEPSQ);
   block_accumulate(bad, scal + SC_NONFINITE);
+  block_accumulate(model, scal + SC_MODEL_CHANGE);
 }
 
 // ---------------------------------------------------------------------------------------
-// K7.  Trial cost + model cost change  -(J d)^T (r + J d/2)  [Ceres-doc: TrustRegionMinimizer::
-// ComputeTrustRegionStep], with r, J the robustified residual/Jacobian at the current point.
+// K7.  Cost at the trial point (mode 0) / cost of the all-constant residual blocks (mode 1).
+// The model cost change  -(J d)^T (r + J d/2)  of [Ceres-doc: TrustRegionMinimizer::ComputeTrustRegionStep] is not
+// re-derived from the Jacobian here: with d the exact solution of (J^T J + D) d = -g it equals  -d^T g / 2 + d^T D d / 2,
+// which k_point_backsub and k_apply_reduced_step accumulate from quantities they already hold.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
-                                                       const PoseCache* __restrict__ pc_cur, const double* __restrict__ poses_cur, const double* __restrict__ points_cur,
-                                                       const PoseCache* __restrict__ pc_cand, const double* __restrict__ poses_cand, const double* __restrict__ points_cand,
-                                                       int mode, double* scal) {
+                                                       const PoseCache* __restrict__ pc, const double* __restrict__ points, int mode, double* scal) {
   const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-  double cost = 0.0, model = 0.0, fixed = 0.0;
+  double cost = 0.0;
   if (a < rp.n && rp.active[a]) {
     const uint32_t p = rp.pose[a], l = rp.point[a];
     const bool var = b.pose_vid[p] >= 0 || b.point_var[l] != 0;
-    const DevCam cam = cams[rp.cam[a]];
-    const double2 px = rp.pixel[a];
-    const double sigma = rp.sigma[a];
-    if (mode == 1) {
-      if (!var) {
-        const double X[3] = {points_cur[3 * (int64_t)l], points_cur[3 * (int64_t)l + 1], points_cur[3 * (int64_t)l + 2]};
-        double r[2], rho0, w;
-        reproj_eval<false>(pc_cur[p], cam, X, px.x, px.y, sigma, r, nullptr, nullptr);
-        huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
-        fixed = 0.5 * rho0;
-      }
-    } else if (var) {
-      const double Xc[3] = {points_cand[3 * (int64_t)l], points_cand[3 * (int64_t)l + 1], points_cand[3 * (int64_t)l + 2]};
-      double rc[2], rho0, w;
-      reproj_eval<false>(pc_cand[p], cam, Xc, px.x, px.y, sigma, rc, nullptr, nullptr);
-      huber_eval(rc[0] * rc[0] + rc[1] * rc[1], rp.huber, &rho0, &w);
-      cost = 0.5 * rho0;
-      const double X[3] = {points_cur[3 * (int64_t)l], points_cur[3 * (int64_t)l + 1], points_cur[3 * (int64_t)l + 2]};
-      double r[2], Jp[12], Jl[6];
-      reproj_eval<true>(pc_cur[p], cam, X, px.x, px.y, sigma, r, Jp, Jl);
+    if (var == (mode == 0)) {
+      const double2 px = rp.pixel[a];
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      double r[2], rho0, w;
+      reproj_eval<false>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, nullptr, nullptr);
       huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
-      double jd0 = 0.0, jd1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { const double d = poses_cand[6 * (int64_t)p + k] - poses_cur[6 * (int64_t)p + k]; jd0 += Jp[k] * d; jd1 += Jp[6 + k] * d; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = Xc[k] - X[k]; jd0 += Jl[k] * d; jd1 += Jl[3 + k] * d; }
-      model = -w * (jd0 * (r[0] + 0.5 * jd0) + jd1 * (r[1] + 0.5 * jd1));
+      cost = 0.5 * rho0;
     }
   }
-  block_accumulate(cost, scal + SC_COST_CAND);
-  block_accumulate(model, scal + SC_MODEL_CHANGE);
-  block_accumulate(fixed, scal + SC_COST_FIXED);
+  block_accumulate(cost, scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED));
 }
 
 // small factors: one kernel, thread ranges [bbox | shape | ltm | relpose]
-__device__ __forceinline__ double model_term(const double* r, const double* Jd, int m, double w) {
-  double acc = 0.0;
-  for (int a = 0; a < m; ++a) acc += Jd[a] * (r[a] + 0.5 * Jd[a]);
-  return -w * acc;
-}
 __global__ void __launch_bounds__(64) k_cost_small(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams,
-                                                  const double* __restrict__ poses_cur, const double* __restrict__ objects_cur,
-                                                  const double* __restrict__ poses_cand, const double* __restrict__ objects_cand, int mode, double* scal) {
+                                                  const double* __restrict__ poses, const double* __restrict__ objects, int mode, double* scal) {
   int64_t t = blockIdx.x * 64LL + threadIdx.x;
-  double cost = 0.0, model = 0.0, fixed = 0.0;
+  double cost = 0.0, rho0, w;
   if (t < sf.n_bb) {
     const int64_t i = t;
-    if (sf.bb_active[i]) {
-      const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
-      const bool var = b.obj_vid[o] >= 0 || b.pose_vid[p] >= 0;
-      const DevCam cam = cams[sf.bb_cam[i]];
-      D13 res[4];
-      double rho0, w;
-      if (mode == 1) {
-        if (!var) {
-          bbox_eval(objects_cur + 7 * (int64_t)o, poses_cur + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-          huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
-          fixed = 0.5 * rho0;
-        }
-      } else if (var) {
-        bbox_eval(objects_cand + 7 * (int64_t)o, poses_cand + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-        huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
-        cost = 0.5 * rho0;
-        bbox_eval(objects_cur + 7 * (int64_t)o, poses_cur + 6 * (int64_t)p, cam, sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-        double r[4], Jd[4];
-        for (int a = 0; a < 4; ++a) {
-          r[a] = res[a].v;
-          double acc = 0.0;
-          for (int k = 0; k < 7; ++k) acc += res[a].d[k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]);
-          for (int k = 0; k < 6; ++k) acc += res[a].d[7 + k] * (poses_cand[6 * (int64_t)p + k] - poses_cur[6 * (int64_t)p + k]);
-          Jd[a] = acc;
-        }
-        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
-        model = model_term(r, Jd, 4, w);
-      }
+    const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
+    if (sf.bb_active[i] && (b.obj_vid[o] >= 0 || b.pose_vid[p] >= 0) == (mode == 0)) {
+      Dual<1> res[4];
+      bbox_eval_n<1>(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+      huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
+      cost = 0.5 * rho0;
     }
   } else if ((t -= sf.n_bb) < sf.n_sp) {
     const int64_t i = t;
-    if (sf.sp_active[i]) {
-      const uint32_t o = sf.sp_obj[i];
-      const bool var = b.obj_vid[o] >= 0;
-      double r[3], J[21], rho0, w;
-      if (mode == 1) {
-        if (!var) {
-          shape_prior_eval(objects_cur + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
-          huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
-          fixed = 0.5 * rho0;
-        }
-      } else if (var) {
-        shape_prior_eval(objects_cand + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
-        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
-        cost = 0.5 * rho0;
-        shape_prior_eval(objects_cur + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
-        double Jd[3];
-        for (int a = 0; a < 3; ++a) { double acc = 0.0; for (int k = 0; k < 7; ++k) acc += J[7 * a + k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]); Jd[a] = acc; }
-        huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
-        model = model_term(r, Jd, 3, w);
-      }
+    const uint32_t o = sf.sp_obj[i];
+    if (sf.sp_active[i] && (b.obj_vid[o] >= 0) == (mode == 0)) {
+      double r[3];
+      shape_prior_eval(objects + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+      huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
+      cost = 0.5 * rho0;
     }
   } else if ((t -= sf.n_sp) < sf.n_lt) {
     const int64_t i = t;
-    if (sf.lt_active[i]) {
-      const uint32_t o = sf.lt_obj[i];
-      const bool var = b.obj_vid[o] >= 0;
-      double r[7], J[49], rho0, w, s = 0.0;
-      if (mode == 1) {
-        if (!var) {
-          ltm_prior_eval(objects_cur + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
-          for (int a = 0; a < 7; ++a) s += r[a] * r[a];
-          huber_eval(s, sf.lt_huber, &rho0, &w);
-          fixed = 0.5 * rho0;
-        }
-      } else if (var) {
-        ltm_prior_eval(objects_cand + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
-        for (int a = 0; a < 7; ++a) s += r[a] * r[a];
-        huber_eval(s, sf.lt_huber, &rho0, &w);
-        cost = 0.5 * rho0;
-        ltm_prior_eval(objects_cur + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
-        double Jd[7]; s = 0.0;
-        for (int a = 0; a < 7; ++a) { s += r[a] * r[a]; double acc = 0.0; for (int k = 0; k < 7; ++k) acc += J[7 * a + k] * (objects_cand[7 * (int64_t)o + k] - objects_cur[7 * (int64_t)o + k]); Jd[a] = acc; }
-        huber_eval(s, sf.lt_huber, &rho0, &w);
-        model = model_term(r, Jd, 7, w);
-      }
+    const uint32_t o = sf.lt_obj[i];
+    if (sf.lt_active[i] && (b.obj_vid[o] >= 0) == (mode == 0)) {
+      double r[7], s = 0.0;
+      ltm_prior_eval(objects + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
+      for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+      huber_eval(s, sf.lt_huber, &rho0, &w);
+      cost = 0.5 * rho0;
     }
   } else if ((t -= sf.n_lt) < sf.n_rl) {
     const int64_t i = t;
-    if (sf.rl_active[i]) {
-      const uint32_t pa = sf.rl_a[i], pb = sf.rl_b[i];
-      const bool var = b.pose_vid[pa] >= 0 || b.pose_vid[pb] >= 0;
-      D12 res[6];
-      double rho0, w, s = 0.0;
-      if (mode == 1) {
-        if (!var) {
-          relpose_eval(poses_cur + 6 * (int64_t)pa, poses_cur + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
-          for (int a = 0; a < 6; ++a) s += res[a].v * res[a].v;
-          huber_eval(s, sf.rl_huber, &rho0, &w);
-          fixed = 0.5 * rho0;
-        }
-      } else if (var) {
-        relpose_eval(poses_cand + 6 * (int64_t)pa, poses_cand + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
-        for (int a = 0; a < 6; ++a) s += res[a].v * res[a].v;
-        huber_eval(s, sf.rl_huber, &rho0, &w);
-        cost = 0.5 * rho0;
-        relpose_eval(poses_cur + 6 * (int64_t)pa, poses_cur + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
-        double r[6], Jd[6]; s = 0.0;
-        for (int a = 0; a < 6; ++a) {
-          r[a] = res[a].v; s += r[a] * r[a];
-          double acc = 0.0;
-          for (int k = 0; k < 6; ++k) {
-            acc += res[a].d[k] * (poses_cand[6 * (int64_t)pa + k] - poses_cur[6 * (int64_t)pa + k]);
-            acc += res[a].d[6 + k] * (poses_cand[6 * (int64_t)pb + k] - poses_cur[6 * (int64_t)pb + k]);
-          }
-          Jd[a] = acc;
-        }
-        huber_eval(s, sf.rl_huber, &rho0, &w);
-        model = model_term(r, Jd, 6, w);
-      }
+    const uint32_t pa = sf.rl_a[i], pb = sf.rl_b[i];
+    if (sf.rl_active[i] && (b.pose_vid[pa] >= 0 || b.pose_vid[pb] >= 0) == (mode == 0)) {
+      Dual<1> res[6];
+      double s = 0.0;
+      relpose_eval_n<1>(poses + 6 * (int64_t)pa, poses + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
+      for (int a = 0; a < 6; ++a) s += res[a].v * res[a].v;
+      huber_eval(s, sf.rl_huber, &rho0, &w);
+      cost = 0.5 * rho0;
     }
   }
-  cost = wave_sum(cost); model = wave_sum(model); fixed = wave_sum(fixed);
-  if (threadIdx.x == 0) {
-    if (cost != 0.0) atomic_add_f64(scal + SC_COST_CAND, cost);
-    if (model != 0.0) atomic_add_f64(scal + SC_MODEL_CHANGE, model);
-    if (fixed != 0.0) atomic_add_f64(scal + SC_COST_FIXED, fixed);
-  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED), cost);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1287,9 +1190,14 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
                  const double* points_cand, const double* objects_cand, int mode, double* scal) {
-  if (rp.n > 0) hipLaunchKernelGGL(k_cost_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc_cur, poses_cur, points_cur, pc_cand, poses_cand, points_cand, mode, scal);
+  // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
+  const PoseCache* pc = mode == 0 ? pc_cand : pc_cur;
+  const double* poses = mode == 0 ? poses_cand : poses_cur;
+  const double* points = mode == 0 ? points_cand : points_cur;
+  const double* objects = mode == 0 ? objects_cand : objects_cur;
+  if (rp.n > 0) hipLaunchKernelGGL(k_cost_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, mode, scal);
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
-  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses_cur, objects_cur, poses_cand, objects_cand, mode, scal);
+  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
                      const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,

@@ -192,12 +192,15 @@ template <int N> OBVI_HD void dual_inverse_pose(const Dual<N>* pose, Dual<N>* Ri
 // BoundingBoxFactor::operator() (bounding_box_factor.h:68-136) over
 // getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273).  13 directions: ellipsoid 0..6,
 // pose 7..12.  Returns false (constant residual, zero Jacobian) in the invalid-ellipse case.
-typedef Dual<13> D13;
-OBVI_HD bool bbox_eval(const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
-                       const double* sqrt_inf, double invalid_err, D13* res) {
+// N = 13: value + Jacobian; N = 1: value only at about twice the cost of plain doubles (trial-point cost)
+template <int N> OBVI_HD Dual<N> dvar_n(double c, int k) { Dual<N> r(c); if (k < N) r.d[k] = 1.0; return r; }
+template <int N>
+OBVI_HD bool bbox_eval_n(const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
+                         const double* sqrt_inf, double invalid_err, Dual<N>* res) {
+  typedef Dual<N> D13;
   D13 ell[7], pose[6];
-  for (int k = 0; k < 7; ++k) ell[k] = dvar<13>(ell_v[k], k);
-  for (int k = 0; k < 6; ++k) pose[k] = dvar<13>(pose_v[k], 7 + k);
+  for (int k = 0; k < 7; ++k) ell[k] = dvar_n<N>(ell_v[k], k);
+  for (int k = 0; k < 6; ++k) pose[k] = dvar_n<N>(pose_v[k], 7 + k);
   D13 Rinv[9], tinv[3];
   dual_inverse_pose(pose, Rinv, tinv);
   D13 Rcw[9], tcw[3];
@@ -232,21 +235,29 @@ OBVI_HD bool bbox_eval(const double* ell_v, const double* pose_v, const DevCam& 
     res[i] = dev[0] * sqrt_inf[4 * i] + dev[1] * sqrt_inf[4 * i + 1] + dev[2] * sqrt_inf[4 * i + 2] + dev[3] * sqrt_inf[4 * i + 3];
   return true;
 }
+typedef Dual<13> D13;
+OBVI_HD bool bbox_eval(const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
+                       const double* sqrt_inf, double invalid_err, D13* res) {
+  return bbox_eval_n<13>(ell_v, pose_v, cam, rect_corners, sqrt_inf, invalid_err, res);
+}
 
 // RelativePoseFactor::operator() (relative_pose_factor.h:32-61).  12 directions: pose_before
 // 0..5, pose_after 6..11.  Pose rotation: PoseArrayToAffine (vslam_math_util.h:121-141);
 // rotation log: Eigen::AngleAxis(Matrix3) via its quaternion (see oracle/README.md).
-typedef Dual<12> D12;
-OBVI_HD void dual_forward_rotation(const D12* pose, D12* R) {
+template <int N>
+OBVI_HD void dual_forward_rotation(const Dual<N>* pose, Dual<N>* R) {
+  typedef Dual<N> D12;
   const D12 angle = dsqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5]);
   if (!(angle.v > OBVI_SMALL_ANGLE)) { dual_identity(R); return; }
   const D12 axis[3] = {pose[3] / angle, pose[4] / angle, pose[5] / angle};
   dual_rotation(angle, axis, R);
 }
-OBVI_HD void relpose_eval(const double* pa_v, const double* pb_v, const double* t_meas, const double* R_meas,
-                          const double* sqrt_inf, D12* res) {
+template <int N>
+OBVI_HD void relpose_eval_n(const double* pa_v, const double* pb_v, const double* t_meas, const double* R_meas,
+                            const double* sqrt_inf, Dual<N>* res) {
+  typedef Dual<N> D12;
   D12 pa[6], pb[6];
-  for (int k = 0; k < 6; ++k) { pa[k] = dvar<12>(pa_v[k], k); pb[k] = dvar<12>(pb_v[k], 6 + k); }
+  for (int k = 0; k < 6; ++k) { pa[k] = dvar_n<N>(pa_v[k], k); pb[k] = dvar_n<N>(pb_v[k], 6 + k); }
   D12 Rb[9], Ra[9];
   dual_forward_rotation(pa, Rb);   // "before"
   dual_forward_rotation(pb, Ra);   // "after"
@@ -291,6 +302,11 @@ OBVI_HD void relpose_eval(const double* pa_v, const double* pb_v, const double* 
     for (int j = 1; j < 6; ++j) acc = acc + u[j] * sqrt_inf[6 * i + j];
     res[i] = acc;
   }
+}
+typedef Dual<12> D12;
+OBVI_HD void relpose_eval(const double* pa_v, const double* pb_v, const double* t_meas, const double* R_meas,
+                          const double* sqrt_inf, D12* res) {
+  relpose_eval_n<12>(pa_v, pb_v, t_meas, R_meas, sqrt_inf, res);
 }
 
 // ShapePriorFactor (shape_prior_factor.h:46-61) and IndependentObjectMapFactor

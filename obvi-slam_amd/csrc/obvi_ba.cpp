@@ -84,7 +84,7 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_bb_active, d_sp_active, d_lt_active, d_rl_active;
   // ---- device: reduced system ----
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
-  DevBuf<double> d_Ci, d_u, d_scale_l, d_Z;
+  DevBuf<double> d_Ci, d_u, d_scale_l, d_Z, d_gl, d_lam_l;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b, d_chunk_ptr, d_chunk_points;
   DevBuf<int32_t> d_row_of_nat, d_chunk_f0, d_chunk_group;
   DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
@@ -214,7 +214,7 @@ ReducedDev reduced_dev(const obvi_ba_handle* h) {
 }
 PointDev point_dev(const obvi_ba_handle* h) {
   PointDev p;
-  p.Ci = h->d_Ci.get(); p.u = h->d_u.get(); p.scale = h->d_scale_l.get(); p.Z = h->d_Z.get();
+  p.Ci = h->d_Ci.get(); p.u = h->d_u.get(); p.scale = h->d_scale_l.get(); p.Z = h->d_Z.get(); p.gl = h->d_gl.get(); p.lam = h->d_lam_l.get();
   return p;
 }
 CholPlan chol_plan(const obvi_ba_handle* h) {
@@ -702,7 +702,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_S.resize((size_t)nt * nt * kTile * kTile);
   h->d_Linv.resize((size_t)nt * kTile * kTile);
   h->d_rhs.resize((size_t)m_pad); h->d_y.resize((size_t)m_pad);
-  h->d_Ci.resize((size_t)6 * L + 1); h->d_u.resize((size_t)3 * L + 1); h->d_scale_l.resize((size_t)3 * L + 1);
+  h->d_Ci.resize((size_t)6 * L + 1); h->d_u.resize((size_t)3 * L + 1); h->d_scale_l.resize((size_t)3 * L + 1); h->d_gl.resize((size_t)3 * L + 1); h->d_lam_l.resize((size_t)3 * L + 1);
   {   // z_off(): 18 per observation + (u_l, 0) per point, then a zero page (k_schur_window's source for frames a point skips)
     const size_t zdata = (size_t)18 * h->n_rp + 4 * (size_t)h->L + 4;
     h->d_Z.resize(zdata + 36);
