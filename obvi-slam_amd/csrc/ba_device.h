@@ -179,19 +179,17 @@ struct CholPlan {
   const int32_t* rh_k;        // device
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
-  const int32_t* back_ptr;    // host [nlevels+1]   backward gather jobs (k, e0, e1): a chunk col_i[e0..e1) of column k
-  const int32_t* back_jobs;   // device, 3 per job
 };
 void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row);
 // optional per-kernel timing (profiling level 2): an event is recorded after every launch, tagged with the kernel class
-enum CholKernel { CK_POTRF = 0, CK_TRSM, CK_UPDATE, CK_BACK_GATHER, CK_BACK_FINAL, CK_COUNT };
+enum CholKernel { CK_POTRF = 0, CK_TRSM, CK_UPDATE, CK_BACKWARD, CK_COUNT };
 struct CholTimers {
   std::vector<hipEvent_t>* pool;   // grown on demand
   std::vector<int>* tags;          // tag of the kernel that ENDS at event i (event 0 = start, tag -1)
   int used;
 };
 void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int level1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers = nullptr);
-void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc, CholTimers* timers = nullptr);
+void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, const double* rhs, double* y, CholTimers* timers = nullptr);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

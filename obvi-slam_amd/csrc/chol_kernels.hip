@@ -333,41 +333,46 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
   }
 }
 
-// backward substitution of a level in two launches:
-//   gather: job (k, chunk of the column's tiles): acc_k += sum_{i in chunk} L_ik^T y_i    (fp64 atomics into acc)
-//   final : y_k = L_kk^-T (z_k - acc_k)
-__global__ void __launch_bounds__(kThreads) k_backward_gather(const double* S, int nt, const int32_t* __restrict__ jobs, const int32_t* __restrict__ col_i,
-                                                             const double* __restrict__ y, double* acc) {
-  __shared__ double part[4][T];
-  const int k = jobs[3 * blockIdx.x], e0 = jobs[3 * blockIdx.x + 1], e1 = jobs[3 * blockIdx.x + 2];
-  const int tid = threadIdx.x, c = tid % T, q = tid / T;
-  double s = 0.0;
-  for (int e = e0; e < e1; ++e) {
-    const int i = col_i[e];
-    const double* X = tile_ptr(const_cast<double*>(S), nt, i, k);
-    const double* yi = y + (int64_t)i * T;
-#pragma unroll 4
-    for (int r = q * 16; r < q * 16 + 16; ++r) s += X[r * T + c] * yi[r];
-  }
-  part[q][c] = s;
-  __syncthreads();
-  if (tid < T) unsafeAtomicAdd(acc + (int64_t)k * T + tid, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
-}
-__global__ void __launch_bounds__(kThreads) k_backward_final(int nt, const int32_t* __restrict__ klist, const double* __restrict__ Linv_all, const double* __restrict__ rhs,
-                                                            const double* __restrict__ acc, double* y) {
-  __shared__ double part[4][T];
+// backward substitution of a level, one workgroup per tile column k of the level:
+//   t = z_k - sum_{i in column k} L_ik^T y_i   (rows i below k: all of them belong to later levels, already solved)
+//   y_k = L_kk^-T t
+constexpr int kBackThreads = 512;
+__global__ void __launch_bounds__(kBackThreads) k_backward(const double* S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ col_ptr,
+                                                         const int32_t* __restrict__ col_i, const double* __restrict__ Linv_all, const double* __restrict__ rhs, double* y) {
+  constexpr int Q = kBackThreads / T;   // row slices
+  __shared__ double part[Q][T];
   __shared__ double tsh[T];
   const int k = klist[blockIdx.x];
   const int tid = threadIdx.x, c = tid % T, q = tid / T;
-  if (tid < T) tsh[tid] = rhs[(int64_t)k * T + tid] - acc[(int64_t)k * T + tid];
-  __syncthreads();
-  const double* Li = Linv_all + (int64_t)k * (T * T);
   double s = 0.0;
-  for (int i = q * 16; i < q * 16 + 16; ++i) if (i >= c) s += Li[i * T + c] * tsh[i];
+  for (int e = col_ptr[k]; e < col_ptr[k + 1]; ++e) {
+    const int i = col_i[e];
+    const double* X = tile_ptr(const_cast<double*>(S), nt, i, k) + (q * (T / Q)) * T + c;
+    const double* yi = y + (int64_t)i * T + q * (T / Q);
+#pragma unroll
+    for (int r = 0; r < T / Q; ++r) s += X[r * T] * yi[r];
+  }
   part[q][c] = s;
   __syncthreads();
-  if (tid < T) y[(int64_t)k * T + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-  (void)nt;
+  if (tid < T) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) a += part[j][tid];
+    tsh[tid] = rhs[(int64_t)k * T + tid] - a;
+  }
+  __syncthreads();
+  const double* Li = Linv_all + (int64_t)k * (T * T);
+  s = 0.0;
+#pragma unroll
+  for (int r = 0; r < T / Q; ++r) { const int i = q * (T / Q) + r; if (i >= c) s += Li[i * T + c] * tsh[i]; }
+  part[q][c] = s;
+  __syncthreads();
+  if (tid < T) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) a += part[j][tid];
+    y[(int64_t)k * T + tid] = a;
+  }
 }
 
 }  // namespace
@@ -407,16 +412,13 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
     }
   }
 }
-void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, double* back_acc, CholTimers* timers) {
+void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, CholTimers* timers) {
   const int nt = p.nt;
-  (void)hipMemsetAsync(back_acc, 0, sizeof(double) * (size_t)nt * T, s);
   tick(s, timers, -1);
   for (int l = p.nlevels - 1; l >= 0; --l) {
     const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    const int nbj = p.back_ptr[l + 1] - p.back_ptr[l];
-    if (nbj > 0) { hipLaunchKernelGGL(k_backward_gather, dim3(nbj), dim3(kThreads), 0, s, S, nt, p.back_jobs + 3 * (int64_t)p.back_ptr[l], p.col_i, y, back_acc); tick(s, timers, CK_BACK_GATHER); }
-    hipLaunchKernelGGL(k_backward_final, dim3(npk), dim3(kThreads), 0, s, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, back_acc, y);
-    tick(s, timers, CK_BACK_FINAL);
+    hipLaunchKernelGGL(k_backward, dim3(npk), dim3(kBackThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], p.col_ptr, p.col_i, Linv, rhs, y);
+    tick(s, timers, CK_BACKWARD);
   }
 }
 

@@ -90,10 +90,9 @@ struct obvi_ba_handle {
   DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
-  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_back_jobs;
+  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
   DevBuf<int32_t> d_pose_row, d_obj_row;
-  DevBuf<double> d_back_acc;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
   DevBuf<uint8_t> d_sel_mask;
@@ -107,7 +106,7 @@ struct obvi_ba_handle {
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
-  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_back_ptr;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr;
   std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
@@ -225,7 +224,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
-  c.upd_flag = h->d_upd_flag.get(); c.back_ptr = h->h_back_ptr.data(); c.back_jobs = h->d_back_jobs.get();
+  c.upd_flag = h->d_upd_flag.get();
   return c;
 }
 
@@ -615,10 +614,10 @@ void prepare(obvi_ba_handle* h) {
   h->nlevels = nlev;
   std::vector<std::vector<int32_t>> by_level(nlev);
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
-  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, back_jobs;
+  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k;
   std::vector<uint8_t> upd_flag;
-  const int kUpdChunk = 4, kBackChunk = 6;
-  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_back_ptr.assign(nlev + 1, 0);
+  const int kUpdChunk = 4;
+  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
   struct Trip { int32_t i, j, k; };
@@ -666,9 +665,6 @@ void prepare(obvi_ba_handle* h) {
     h->h_trsm_ptr[l + 1] = (int32_t)(trsm_ik.size() / 2);
     h->h_upd_ptr[l + 1] = (int32_t)(upd_ij.size() / 2);
     h->h_rh_ptr[l + 1] = (int32_t)rh_i.size();
-    for (int32_t k : by_level[l])
-      for (int32_t e0 = col_ptr[k]; e0 < col_ptr[k + 1]; e0 += kBackChunk) { back_jobs.push_back(k); back_jobs.push_back(e0); back_jobs.push_back(std::min(col_ptr[k + 1], e0 + kBackChunk)); }
-    h->h_back_ptr[l + 1] = (int32_t)(back_jobs.size() / 3);
   }
   h->chol_flops = flops;
   h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
@@ -687,8 +683,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
-  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s); h->d_back_jobs.upload(back_jobs, s);
-  h->d_back_acc.resize((size_t)m_pad);
+  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s);
   h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
   {
     std::vector<uint8_t> sh((size_t)h->nOv + 1, 0);
@@ -770,7 +765,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
     } else {
       launch_cholesky_factor(s, plan, 0, plan.nlevels, rd.S, h->d_Linv.get(), rd.rhs, scal, tm);
     }
-    launch_cholesky_backward(s, plan, rd.S, h->d_Linv.get(), rd.rhs, rd.y, h->d_back_acc.get(), tm);
+    launch_cholesky_backward(s, plan, rd.S, h->d_Linv.get(), rd.rhs, rd.y, tm);
     h->ck_used = tm ? timers.used : 0;
   } else {
     h->ck_used = 0;
@@ -1521,7 +1516,7 @@ int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names
     ++n;
   };
   for (int p = 0; p < PH_COUNT; ++p) put(kPhaseNames[p], h->phase_ms[p], h->phase_launches[p]);
-  static const char* kCholNames[CK_COUNT] = {"k_potrf", "k_trsm", "k_update", "k_backward_gather", "k_backward_final"};
+  static const char* kCholNames[CK_COUNT] = {"k_potrf", "k_trsm", "k_update", "k_backward"};
   for (int k = 0; k < CK_COUNT; ++k) if (h->ck_launches[k] > 0) put(kCholNames[k], h->ck_ms[k], h->ck_launches[k]);
   return n;
 }
