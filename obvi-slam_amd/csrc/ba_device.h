@@ -177,6 +177,11 @@ struct CholPlan {
   const int32_t* rh_i;        // device
   const int32_t* rh_kptr;     // device [jobs+1]
   const int32_t* rh_k;        // device
+  const int32_t* job_signal;  // device [update jobs + rhs jobs, per level: updates then rhs]  tile column of the next level whose potrf waits for the job, or -1
+  const int32_t* k_need;      // device, parallel to lvl_k: number of jobs of the previous level that column's potrf waits for
+  int32_t* diag_done;         // device [nt] counters
+  const int32_t* crit_upd;    // host [nlevels]     number of signalling update / right-hand-side jobs of the level (first in their lists)
+  const int32_t* crit_rh;     // host [nlevels]
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
 };

@@ -50,20 +50,14 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 // (rows 4ty.., cols 4tx..) in registers.  Right-looking over 16 panels of 4 columns; then
 // L^-1 by a right-looking blocked forward substitution on the identity (same structure).
 // ---------------------------------------------------------------------------------------
-#ifdef OBVI_POTRF_TIMING
-#define OBVI_TICK(i) if (threadIdx.x == 0 && tdbg) tdbg[8 * blockIdx.x + (i)] = __builtin_readcyclecounter()
-#define OBVI_PH(var) var += __builtin_readcyclecounter() - tph; tph = __builtin_readcyclecounter()
-__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal, unsigned long long* tdbg) {
-#else
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
-__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
-#endif
-  __shared__ double Lsh[T * LD];       // L (lower), later L^-1
-  __shared__ double Dsh[16 * 16];      // inverse of the 16 diagonal 4x4 blocks of L
-  __shared__ double Wsh[16 * 16];      // row-block r of L^-1 during the inverse phase
-  __shared__ double zsh[T];
-  const int k = klist[blockIdx.x];
+constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * 16 + T;   // doubles
+__device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
+  double* Lsh = smem;                  // L (lower), later L^-1
+  double* Dsh = Lsh + T * LD;          // inverse of the 16 diagonal 4x4 blocks of L
+  double* Wsh = Dsh + 16 * 16;         // row-block r of L^-1 during the inverse phase
+  double* zsh = Wsh + 16 * 16;
   double* tile = tile_ptr(S, nt, k, k);
   // wavefronts 0-3 factorise, wavefronts 4-7 build L^-1 concurrently (same (ty,tx) block map, same barriers)
   const int tid = threadIdx.x & 255, ty = tid >> 4, tx = tid & 15;
@@ -91,7 +85,6 @@ __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t*
     for (int j = 0; j < 4; ++j) w[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
   __syncthreads();
   OBVI_TICK(1);
-  unsigned long long tph = __builtin_readcyclecounter(), ph1 = 0, ph2 = 0, ph3 = 0; (void)tph; (void)ph1; (void)ph2; (void)ph3;
   for (int kb = 0; kb < 16; ++kb) {
     if (fac && ty == kb && tx == kb) {
       // 4x4 Cholesky in registers + its inverse; division-free: i = rsqrt(pivot), l = pivot * i
@@ -187,9 +180,6 @@ __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t*
     }
     OBVI_PH(ph3);
   }
-#ifdef OBVI_POTRF_TIMING
-  if (threadIdx.x == 0 && tdbg) { tdbg[8 * blockIdx.x + 6] = ph1; tdbg[8 * blockIdx.x + 7] = ph2; tdbg[8 * blockIdx.x + 5] = ph3; }
-#endif
   OBVI_TICK(2);
   if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
   // store L (zeros above the diagonal)
@@ -223,9 +213,10 @@ __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t*
     s += __shfl_xor(s, 2, 64);
     if (part == 0) rhs[(int64_t)k * T + r] = s;
   }
-#ifndef OBVI_POTRF_TIMING
-  OBVI_TICK(5);
-#endif
+}
+__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
+  __shared__ double smem[kPotrfLds];
+  potrf_tile(smem, S, nt, klist[blockIdx.x], Linv_all, rhs, scal);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -283,18 +274,21 @@ __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int3
 // job g < n_upd: tile target (i,j): S_ij -= sum_{k in list} L_ik L_jk^T
 // job g >= n_upd: rhs target i:     b_i  -= sum_{k in list} L_ik z_k
 // A target whose k-list was split over several jobs (flag != 0) accumulates with fp64 hardware atomics.
-__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_upd, const int32_t* __restrict__ upd_ij, const int32_t* __restrict__ upd_kptr,
-                                                    const int32_t* __restrict__ upd_k, const uint8_t* __restrict__ upd_flag, const int32_t* __restrict__ rh_i,
-                                                    const int32_t* __restrict__ rh_kptr, const int32_t* __restrict__ rh_k, double* rhs) {
-  __shared__ double A[T * LDM];
-  __shared__ double B[T * LDM];
+// The first 256 threads of the workgroup work; any others have left before the call.
+struct UpdateJobs {
+  int n_upd;
+  const int32_t* upd_ij; const int32_t* upd_kptr; const int32_t* upd_k; const uint8_t* upd_flag;
+  const int32_t* rh_i; const int32_t* rh_kptr; const int32_t* rh_k;
+};
+__device__ __forceinline__ void update_job(double* smem, double* S, int nt, const UpdateJobs& u, int g, double* rhs) {
+  double* A = smem;
+  double* B = smem + T * LDM;
   const int tid = threadIdx.x;
-  const int g = blockIdx.x;
-  if (g < n_upd) {
-    const int i = upd_ij[2 * g], j = upd_ij[2 * g + 1];
+  if (g < u.n_upd) {
+    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1];
     f64x4 acc[4] = {};
-    for (int q = upd_kptr[g]; q < upd_kptr[g + 1]; ++q) {
-      const int k = upd_k[q];
+    for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
+      const int k = u.upd_k[q];
       __syncthreads();
       stage_tile(A, tile_ptr(S, nt, i, k));
       if (i != j) stage_tile(B, tile_ptr(S, nt, j, k));
@@ -303,7 +297,7 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
     }
     double* C = tile_ptr(S, nt, i, j);
     const int lane = tid & 63, wv = tid >> 6;
-    if (upd_flag[g]) {
+    if (u.upd_flag[g]) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -315,13 +309,13 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
         for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] -= acc[rt][r];
     }
   } else {
-    const int h = g - n_upd;
-    const int i = rh_i[h];
+    const int h = g - u.n_upd;
+    const int i = u.rh_i[h];
     // thread (r = tid/4, part = tid%4): 16 columns each
     const int r = tid >> 2, part = tid & 3;
     double s = 0.0;
-    for (int q = rh_kptr[h]; q < rh_kptr[h + 1]; ++q) {
-      const int k = rh_k[q];
+    for (int q = u.rh_kptr[h]; q < u.rh_kptr[h + 1]; ++q) {
+      const int k = u.rh_k[q];
       const double* X = tile_ptr(S, nt, i, k) + r * T + part * 16;
       const double* z = rhs + (int64_t)k * T + part * 16;
 #pragma unroll
@@ -331,6 +325,55 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, int n_up
     s += __shfl_xor(s, 2, 64);
     if (part == 0) rhs[(int64_t)i * T + r] -= s;
   }
+}
+__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJobs u, double* rhs) {
+  __shared__ double smem[2 * T * LDM];
+  update_job(smem, S, nt, u, blockIdx.x, rhs);
+}
+
+// One launch for the updates of level l and the potrf of level l+1.  Grid order: the update / right-hand-side jobs whose
+// target is the diagonal tile or right-hand-side block of a tile column of level l+1 ("critical": n_crit_upd + n_crit_rh,
+// first in their job lists), then the potrf workgroups of level l+1, then all other jobs of level l.  A critical job bumps
+// its column's counter when its result is out (release); the column's potrf workgroup starts as soon as the counter
+// reaches the number of such jobs (acquire) and runs while the rest of level l is still being updated.
+// No deadlock: the jobs waited for have lower block indices and never wait themselves.  The wait is bounded (a lost
+// signal becomes a failed step).
+__global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJobs u, int n_rh, int n_crit_upd, int n_crit_rh, int n_potrf,
+                                                     const int32_t* __restrict__ job_signal, const int32_t* __restrict__ klist,
+                                                     const int32_t* __restrict__ k_need, int32_t* done, double* Linv_all, double* rhs, double* scal) {
+  __shared__ double smem[2 * T * LDM];
+  static_assert(kPotrfLds <= 2 * T * LDM, "potrf fits the update buffers");
+  const int b = blockIdx.x, n_crit = n_crit_upd + n_crit_rh;
+  if (b >= n_crit && b < n_crit + n_potrf) {
+    const int k = klist[b - n_crit], need = k_need[b - n_crit];
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 22)) { unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0); break; }
+      }
+    }
+    __syncthreads();
+    __threadfence();
+    potrf_tile(smem, S, nt, k, Linv_all, rhs, scal);
+    return;
+  }
+  if (threadIdx.x >= kThreads) return;
+  int g;   // job id: updates [0, n_upd), right-hand sides [n_upd, n_upd + n_rh)
+  if (b < n_crit_upd) g = b;
+  else if (b < n_crit) g = u.n_upd + (b - n_crit_upd);
+  else {
+    const int r = b - n_crit - n_potrf;
+    g = r < u.n_upd - n_crit_upd ? n_crit_upd + r : u.n_upd + n_crit_rh + (r - (u.n_upd - n_crit_upd));
+  }
+  update_job(smem, S, nt, u, g, rhs);
+  const int sig = job_signal[g];
+  if (sig >= 0) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(done + sig, 1);
+  }
+  (void)n_rh;
 }
 
 // backward substitution of a level, one workgroup per tile column k of the level:
@@ -393,21 +436,25 @@ static void tick(hipStream_t s, CholTimers* t, int tag) {
 // The multi-GPU exchange sits between the levels of a rank's own blocks and the levels of the shared tail.
 void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers) {
   const int nt = p.nt;
+  if (l0 >= l1) return;
+  if (l0 == 0) (void)hipMemsetAsync(p.diag_done, 0, sizeof(int32_t) * (size_t)nt, s);
   tick(s, timers, -1);
+  // the first level of the range has nothing to wait for inside a launch
+  hipLaunchKernelGGL(k_potrf, dim3(p.lvl_k_ptr[l0 + 1] - p.lvl_k_ptr[l0]), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l0], Linv, rhs, scal);
+  tick(s, timers, CK_POTRF);
   for (int l = l0; l < l1; ++l) {
-    const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-#ifdef OBVI_POTRF_TIMING
-    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal, (unsigned long long*)nullptr);
-#else
-    hipLaunchKernelGGL(k_potrf, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], Linv, rhs, scal);
-#endif
-    tick(s, timers, CK_POTRF);
     const int ntr = p.trsm_ptr[l + 1] - p.trsm_ptr[l];
     if (ntr > 0) { hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv); tick(s, timers, CK_TRSM); }
     const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
-    if (nup + nrh > 0) {
-      hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k,
-                         p.upd_flag + p.upd_ptr[l], p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k, rhs);
+    const int npk = l + 1 < l1 ? p.lvl_k_ptr[l + 2] - p.lvl_k_ptr[l + 1] : 0;
+    UpdateJobs u{nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k, p.upd_flag + p.upd_ptr[l],
+                 p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k};
+    if (npk > 0) {
+      hipLaunchKernelGGL(k_update_potrf, dim3(nup + nrh + npk), dim3(512), 0, s, S, nt, u, nrh, p.crit_upd[l], p.crit_rh[l], npk,
+                         p.job_signal + p.upd_ptr[l] + p.rh_ptr[l], p.lvl_k + p.lvl_k_ptr[l + 1], p.k_need + p.lvl_k_ptr[l + 1], p.diag_done, Linv, rhs, scal);
+      tick(s, timers, CK_UPDATE);
+    } else if (nup + nrh > 0) {
+      hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs);
       tick(s, timers, CK_UPDATE);
     }
   }

@@ -92,6 +92,7 @@ struct obvi_ba_handle {
   int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
+  DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done;
   DevBuf<int32_t> d_pose_row, d_obj_row;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
@@ -106,7 +107,7 @@ struct obvi_ba_handle {
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
-  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh;
   std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
@@ -224,7 +225,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
-  c.upd_flag = h->d_upd_flag.get();
+  c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data();
   return c;
 }
 
@@ -614,10 +615,10 @@ void prepare(obvi_ba_handle* h) {
   h->nlevels = nlev;
   std::vector<std::vector<int32_t>> by_level(nlev);
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
-  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k;
+  std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, job_signal, k_need_of(nt, 0);
   std::vector<uint8_t> upd_flag;
   const int kUpdChunk = 4;
-  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0);
+  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_crit_upd.assign(nlev + 1, 0); h->h_crit_rh.assign(nlev + 1, 0);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
   struct Trip { int32_t i, j, k; };
@@ -638,25 +639,41 @@ void prepare(obvi_ba_handle* h) {
       flops += t3 / 3.0 + t3 * nr + 2.0 * t3 * (nr * (nr + 1) / 2);
     }
     std::sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.i != b.i ? a.i < b.i : (a.j != b.j ? a.j < b.j : a.k < b.k); });
-    // one job per target tile; a k-list longer than kUpdChunk is split over several jobs that accumulate atomically
+    // one job per target tile; a k-list longer than kUpdChunk is split over several jobs that accumulate atomically.
+    // Jobs that finish the diagonal tile / right-hand-side block of a column of the next level come first and signal it
+    // (k_update_potrf): that column's potrf starts while the rest of this level's updates are still running.
+    struct Job { int32_t i, j; uint8_t flag; size_t t0, t1; bool crit; };
+    std::vector<Job> jobs;
     for (size_t q = 0; q < trips.size();) {
       size_t e = q;
       while (e < trips.size() && trips[e].i == trips[q].i && trips[e].j == trips[q].j) ++e;
       const size_t len = e - q;
-      const uint8_t flag = len > (size_t)kUpdChunk ? 1 : 0;
-      for (size_t c0 = q; c0 < e; c0 += kUpdChunk) {
-        upd_ij.push_back(trips[q].i); upd_ij.push_back(trips[q].j); upd_flag.push_back(flag);
-        for (size_t t = c0; t < std::min(e, c0 + (size_t)kUpdChunk); ++t) upd_k.push_back(trips[t].k);
-        upd_kptr.push_back((int32_t)upd_k.size());
-      }
+      const bool crit = trips[q].i == trips[q].j && level[trips[q].i] == l + 1;
+      const size_t chunk = crit ? 1 : (size_t)kUpdChunk;   // the next level waits for these: one product per job
+      const uint8_t flag = len > chunk ? 1 : 0;
+      for (size_t c0 = q; c0 < e; c0 += chunk) jobs.push_back({trips[q].i, trips[q].j, flag, c0, std::min(e, c0 + chunk), crit});
       q = e;
+    }
+    std::stable_partition(jobs.begin(), jobs.end(), [](const Job& x) { return x.crit; });
+    h->h_crit_upd[l] = (int32_t)std::count_if(jobs.begin(), jobs.end(), [](const Job& x) { return x.crit; });
+    h->h_crit_rh[l] = 0;
+    for (const Job& jb : jobs) {
+      upd_ij.push_back(jb.i); upd_ij.push_back(jb.j); upd_flag.push_back(jb.flag);
+      for (size_t t = jb.t0; t < jb.t1; ++t) upd_k.push_back(trips[t].k);
+      upd_kptr.push_back((int32_t)upd_k.size());
+      job_signal.push_back(jb.crit ? jb.i : -1);
+      if (jb.crit) k_need_of[jb.i]++;
     }
     n_products += (int64_t)trips.size();
     std::sort(ik.begin(), ik.end());
+    std::stable_sort(ik.begin(), ik.end(), [&](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return (level[x.first] == l + 1) > (level[y.first] == l + 1); });
     for (size_t q = 0; q < ik.size(); ++q) {
       if (q == 0 || ik[q].first != ik[q - 1].first) {
         if (q != 0) rh_kptr.push_back((int32_t)rh_k.size());
         rh_i.push_back(ik[q].first);
+        const bool crit = level[ik[q].first] == l + 1;
+        job_signal.push_back(crit ? ik[q].first : -1);
+        if (crit) { k_need_of[ik[q].first]++; h->h_crit_rh[l]++; }
       }
       rh_k.push_back(ik[q].second);
     }
@@ -684,6 +701,11 @@ void prepare(obvi_ba_handle* h) {
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
   h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s);
+  {
+    std::vector<int32_t> k_need(lvl_k.size());
+    for (size_t x = 0; x < lvl_k.size(); ++x) k_need[x] = k_need_of[lvl_k[x]];
+    h->d_job_signal.upload(job_signal, s); h->d_k_need.upload(k_need, s); h->d_diag_done.resize((size_t)nt + 1);
+  }
   h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
   {
     std::vector<uint8_t> sh((size_t)h->nOv + 1, 0);
