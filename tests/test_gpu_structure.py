@@ -1,0 +1,86 @@
+"""Ragged observation structures through the HIP path, checked against the oracle (reduced system + one LM step):
+tracks longer than a wavefront, tracks with gaps, loop closures (pairs far outside the Schur strip), three observations of a
+point from one pose, points and poses without observations."""
+import numpy as np
+import pytest
+
+import helpers
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _extra_observations(prob, point, poses, cam=0, rng=None):
+    """append observations of `point` from `poses` (pixels from the ground truth + noise); pixels far outside the image are fine"""
+    rng = rng or np.random.default_rng(0)
+    poses = np.asarray(poses, dtype=np.int64)
+    px, depth = synth.project_points(prob["gt_poses"][poses], np.repeat(prob["gt_points"][point][None, :], len(poses), axis=0))
+    keep = depth > 0.1
+    poses, px = poses[keep], px[keep] + rng.normal(size=(keep.sum(), 2))
+    n = len(poses)
+    prob["rp_pose"] = np.concatenate([prob["rp_pose"], poses.astype(prob["rp_pose"].dtype)])
+    prob["rp_point"] = np.concatenate([prob["rp_point"], np.full(n, point, dtype=prob["rp_point"].dtype)])
+    prob["rp_cam"] = np.concatenate([prob["rp_cam"], np.full(n, cam, dtype=prob["rp_cam"].dtype)])
+    prob["rp_pixel"] = np.concatenate([prob["rp_pixel"], px])
+    if np.ndim(prob["rp_sigma"]) > 0:
+        prob["rp_sigma"] = np.concatenate([prob["rp_sigma"], np.full(n, prob["rp_sigma"][0])])
+    if "rp_is_outlier" in prob:
+        prob["rp_is_outlier"] = np.concatenate([prob["rp_is_outlier"], np.zeros(n, dtype=prob["rp_is_outlier"].dtype)])
+    return n
+
+
+def _ragged_problem():
+    prob = synth.make_problem(P=120, L=500, O=2, seed=5, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=5, outlier_frac=0.0)
+    P = len(prob["poses"])
+    seen = {(int(p), int(l)) for p, l in zip(prob["rp_pose"], prob["rp_point"])}
+
+    def unseen(point, poses):
+        return [p for p in poses if (p, point) not in seen]
+    added = 0
+    added += _extra_observations(prob, 3, unseen(3, range(1, 100)))                 # > 64 observations: per-point kernel, far pairs
+    added += _extra_observations(prob, 7, unseen(7, [5, 6, 9, 30, 31, 90, 118]))   # gaps + loop closures
+    added += _extra_observations(prob, 11, unseen(11, [2, 119]))                    # a single far pair
+    p0 = int(prob["rp_pose"][prob["rp_point"] == 20][0])
+    added += _extra_observations(prob, 20, [p0, p0])                                # three observations from one pose
+    assert added > 80
+    # a point and a pose nobody observes
+    keep = (prob["rp_point"] != 33) & (prob["rp_pose"] != 60)
+    for k in ("rp_pose", "rp_point", "rp_cam", "rp_pixel", "rp_sigma", "rp_is_outlier"):
+        if k in prob and np.ndim(prob[k]) > 0:
+            prob[k] = prob[k][keep]
+    return prob
+
+
+def test_ragged_structures_match_oracle():
+    prob = _ragged_problem()
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    assert abs(g.evaluate(True, False)[0] - o.evaluate(True, False)[0]) <= 1e-12 * o.evaluate(True, False)[0]
+    for radius in (100.0, 1e4):
+        So, bo = o.debug_reduced_system(radius)
+        Sg, bg = g.debug_reduced_system(radius)
+        assert So.shape == Sg.shape
+        assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
+    prm = helpers.ba_params(max_it=3, ftol=0, ptol=0, gtol=0)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.num_iterations == so.num_iterations
+    for a, b in zip(o.iterations(), g.iterations()):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-9 * a.cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
+    assert np.abs(g.get_points() - o.get_points()).max() < 1e-6
+
+
+def test_ragged_structures_with_a_stereo_rig():
+    """second camera on every frame of a few tracks + gaps: the two-layer (stereo) path of the Schur strip kernel"""
+    prob = synth.make_problem(P=60, L=300, O=0, seed=9, stereo=True, outlier_frac=0.0)
+    keep = ~((prob["rp_point"] % 7 == 0) & (prob["rp_pose"] % 5 == 2))               # punch holes into every 7th track
+    for k in ("rp_pose", "rp_point", "rp_cam", "rp_pixel", "rp_sigma", "rp_is_outlier"):
+        if k in prob and np.ndim(prob[k]) > 0:
+            prob[k] = prob[k][keep]
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    So, bo = o.debug_reduced_system(100.0)
+    Sg, bg = g.debug_reduced_system(100.0)
+    assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
