@@ -154,9 +154,9 @@ def main():
         }
         nlev = max(pst["chol_levels"], 1.0)
         flops = {   # per launch = per level of the tile elimination tree
-            "k_potrf": pst["tiles_per_dim"] * (2.0 * t3 / 3.0) / nlev,       # factor + inverse of each diagonal tile
             "k_trsm": pst["trsm_jobs"] * t3 / nlev,
-            "k_update": pst["update_jobs"] * 2.0 * t3 / nlev,
+            # updates of a level + factor and inverse of the next level's diagonal tiles, one launch
+            "k_update_potrf": (pst["update_jobs"] * 2.0 * t3 + pst["tiles_per_dim"] * (2.0 * t3 / 3.0)) / nlev,
         }
         def delta(k1_, k0_):
             out = {}

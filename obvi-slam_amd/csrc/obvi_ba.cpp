@@ -1538,7 +1538,7 @@ int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names
     ++n;
   };
   for (int p = 0; p < PH_COUNT; ++p) put(kPhaseNames[p], h->phase_ms[p], h->phase_launches[p]);
-  static const char* kCholNames[CK_COUNT] = {"k_potrf", "k_trsm", "k_update", "k_backward"};
+  static const char* kCholNames[CK_COUNT] = {"k_potrf", "k_trsm", "k_update_potrf", "k_backward"};
   for (int k = 0; k < CK_COUNT; ++k) if (h->ck_launches[k] > 0) put(kCholNames[k], h->ck_ms[k], h->ck_launches[k]);
   return n;
 }

@@ -1,5 +1,4 @@
 // micro-benchmark / phase timing of k_potrf (dev tool, not part of the product)
-#define OBVI_POTRF_TIMING 1
 #include "../obvi-slam_amd/csrc/chol_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -16,8 +15,8 @@ int main() {
     double* t = &S[((size_t)k * nt + k) * T * T];
     for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) { double s = 0; for (int q = 0; q < T; ++q) s += A[i * T + q] * A[j * T + q]; t[i * T + j] = s + (i == j ? T : 0); }
   }
-  double *dS, *dL, *dr, *dscal; int32_t* dk; unsigned long long* dt;
-  hipMalloc(&dS, S.size() * 8); hipMalloc(&dL, (size_t)nt * T * T * 8); hipMalloc(&dr, nt * T * 8); hipMalloc(&dscal, 256); hipMalloc(&dk, nt * 4); hipMalloc(&dt, 64 * 8 * nt);
+  double *dS, *dL, *dr, *dscal; int32_t* dk;
+  hipMalloc(&dS, S.size() * 8); hipMalloc(&dL, (size_t)nt * T * T * 8); hipMalloc(&dr, nt * T * 8); hipMalloc(&dscal, 256); hipMalloc(&dk, nt * 4);
   std::vector<int32_t> kl(nt); for (int i = 0; i < nt; ++i) kl[i] = i;
   hipMemcpy(dk, kl.data(), nt * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -26,12 +25,11 @@ int main() {
     for (int rep = 0; rep < 5; ++rep) {
       hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dr, rhs.data(), nt * T * 8, hipMemcpyHostToDevice); hipMemset(dscal, 0, 256);
       hipEventRecord(e0, 0);
-      hipLaunchKernelGGL(k_potrf, dim3(n), dim3(512), 0, 0, dS, nt, dk, dL, dr, dscal, dt);
+      hipLaunchKernelGGL(k_potrf, dim3(n), dim3(512), 0, 0, dS, nt, dk, dL, dr, dscal);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
-    std::vector<unsigned long long> t(8); hipMemcpy(t.data(), dt, 64, hipMemcpyDeviceToHost);
-    printf("n=%2d  %.1f us   cycles: load %llu  factor %llu (ph1 %llu ph2 %llu ph3 %llu) storeL %llu  inverse %llu\n", n, best * 1e3, t[1] - t[0], t[2] - t[1], t[6], t[7], t[5], t[3] - t[2], t[4] - t[3]);
+    printf("n=%2d  %.1f us\n", n, best * 1e3);
   }
   std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost); printf("chol_fail %g\n", sc[SC_CHOL_FAIL]);
   return 0;
