@@ -131,7 +131,7 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
                                double* poses_cand, double* objects_cand, double* scal);
 // trial-point cost + model cost change.  mode 0: cost at (poses,points,objects) into SC_COST_CAND and
 // model change of the step (cand - current); mode 1: cost only, split into SC_COST / SC_COST_FIXED.
-void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const SmallFactorsDev& sf, const DevCam* cams,
+void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams,
                  const PoseCache* pc_cur, const double* poses_cur, const double* points_cur, const double* objects_cur,
                  const PoseCache* pc_cand, const double* poses_cand, const double* points_cand, const double* objects_cand,
                  int mode, double* scal);

@@ -897,21 +897,26 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
 // re-derived from the Jacobian here: with d the exact solution of (J^T J + D) d = -g it equals  -d^T g / 2 + d^T D d / 2,
 // which k_point_backsub and k_apply_reduced_step accumulate from quantities they already hold.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+// One workgroup per pose over the pose-ordered copy of the observations: the pose cache is uniform per workgroup (a gather
+// of it per observation, in point order, costs more L2 bandwidth than everything else the kernel reads).
+__global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams,
                                                        const PoseCache* __restrict__ pc, const double* __restrict__ points, int mode, double* scal) {
-  const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  const int64_t p = blockIdx.x;
+  const bool pose_var = b.pose_vid[p] >= 0;
+  const PoseCache cache = pc[p];
   double cost = 0.0;
-  if (a < rp.n && rp.active[a]) {
-    const uint32_t p = rp.pose[a], l = rp.point[a];
-    const bool var = b.pose_vid[p] >= 0 || b.point_var[l] != 0;
-    if (var == (mode == 0)) {
-      const double2 px = rp.pixel[a];
-      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
-      double r[2], rho0, w;
-      reproj_eval<false>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, nullptr, nullptr);
-      huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
-      cost = 0.5 * rho0;
-    }
+  const uint32_t beg = rq.pose_ptr[p], end = rq.pose_ptr[p + 1];
+  for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
+    if (!rq.active[k]) continue;
+    const uint32_t l = rq.point[k];
+    const bool var = pose_var || b.point_var[l] != 0;
+    if (var != (mode == 0)) continue;
+    const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+    const double2 px = rq.pixel[k];
+    double r[2], rho0, w;
+    reproj_eval<false>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, nullptr, nullptr);
+    huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+    cost += 0.5 * rho0;
   }
   block_accumulate(cost, scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED));
 }
@@ -1187,7 +1192,7 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
                                double* poses_cand, double* objects_cand, double* scal) {
   if (b.P + b.O > 0) hipLaunchKernelGGL(k_apply_reduced_step, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, rd, poses, objects, poses_cand, objects_cand, scal);
 }
-void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
+void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
                  const double* points_cand, const double* objects_cand, int mode, double* scal) {
   // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
@@ -1195,7 +1200,7 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const S
   const double* poses = mode == 0 ? poses_cand : poses_cur;
   const double* points = mode == 0 ? points_cand : points_cur;
   const double* objects = mode == 0 ? objects_cand : objects_cur;
-  if (rp.n > 0) hipLaunchKernelGGL(k_cost_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, mode, scal);
+  if (rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
 }

@@ -800,7 +800,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
     launch_pose_cache(s, h->P, h->d_pose_c.get(), h->d_pc_c.get());
   }
   record(h, PH_COST);
-  if (solve) launch_cost(s, b, rp, sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
+  if (solve) launch_cost(s, b, reproj_pose_dev(h), sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
                          h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);
   record(h, PH_COUNT);
   if (exchange) {   // (3) every rank must take the same decision
@@ -1274,7 +1274,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   // fixed cost: residual blocks with only constant parameter blocks
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_cost(s, blocks_dev(h), reproj_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
+  launch_cost(s, blocks_dev(h), reproj_pose_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
               h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), 1, h->d_scal.get());
   if (h->allreduce != nullptr && !h->h_shared_ov.empty() &&
       h->allreduce(h->allreduce_user, h->d_scal.get() + SC_COST_FIXED, 1, 0, s)) return fail(h, OBVI_ERR_HIP, "allreduce hook (fixed cost)");
