@@ -185,7 +185,18 @@ struct CholPlan {
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
 };
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row);
+void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2);
+// small accumulators cleared at the start of an LM step, together with the tiles (one launch)
+struct StepClear {
+  double* hdiag; int64_t n_hdiag;
+  double* g; int64_t n_g;
+  double* rhs; int64_t n_rhs;
+  int32_t* diag_done; int64_t n_done;   // potrf counters of k_update_potrf
+  double* scal; int64_t n_scal;         // scalar block; scal[fixed_slot] = fixed_cost
+  int64_t fixed_slot; double fixed_cost;
+  int64_t n_max;
+};
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row, const StepClear& c);
 // optional per-kernel timing (profiling level 2): an event is recorded after every launch, tagged with the kernel class
 enum CholKernel { CK_POTRF = 0, CK_TRSM, CK_UPDATE, CK_BACKWARD, CK_COUNT };
 struct CholTimers {

@@ -1238,6 +1238,19 @@ void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* b
   const int ntail = rd.nt - t0;
   if (ntail > 0) hipLaunchKernelGGL(k_pack_tail, dim3(ntail * (ntail + 1) / 2 + 1), dim3(kBlock), 0, s, rd, t0, buf, unpack);
 }
+// three arrays in one launch (the parameter blocks: poses, points, objects)
+__global__ void __launch_bounds__(kBlock) k_copy3(double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n0 + n1 + n2; i += stride) {
+    if (i < n0) d0[i] = s0[i];
+    else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
+    else d2[i - n0 - n1] = s2[i - n0 - n1];
+  }
+}
+void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2) {
+  const int64_t n = n0 + n1 + n2;
+  if (n > 0) hipLaunchKernelGGL(k_copy3, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, s, d0, s0, n0, d1, s1, n1, d2, s2, n2);
+}
 void launch_fill(hipStream_t s, double* p, int64_t n, double v) {
   if (n > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, p, n, v);
 }

@@ -11,6 +11,7 @@
 //             trsm    L_ik = S_ik L_kk^-T                                   (1 workgroup per tile)
 //             update  S_ij -= sum_k L_ik L_jk^T ; b_i -= sum_k L_ik z_k     (1 workgroup per target)
 // then backward over levels descending: y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i).
+#include <algorithm>
 #include "ba_device.h"
 
 namespace obvi {
@@ -31,8 +32,20 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
 }
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
-// zero the structurally non-zero tiles; identity on padding rows
-__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, const uint8_t* __restrict__ is_pad_row) {
+// Start of an LM step, one launch: zero the structurally non-zero tiles (identity on padding rows); the workgroups behind them
+// clear the small accumulators of the step (diagonal blocks, gradient, right-hand side, potrf counters, scalar block).
+__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int ntiles, const uint8_t* __restrict__ is_pad_row, StepClear c) {
+  if ((int)blockIdx.x >= ntiles) {
+    const int64_t stride = (int64_t)(gridDim.x - ntiles) * kThreads;
+    for (int64_t i = (int64_t)(blockIdx.x - ntiles) * kThreads + threadIdx.x; i < c.n_max; i += stride) {
+      if (i < c.n_hdiag) c.hdiag[i] = 0.0;
+      if (i < c.n_g) c.g[i] = 0.0;
+      if (i < c.n_rhs) c.rhs[i] = 0.0;
+      if (i < c.n_done) c.diag_done[i] = 0;
+      if (i < c.n_scal) c.scal[i] = i == c.fixed_slot ? c.fixed_cost : 0.0;
+    }
+    return;
+  }
   const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
   double* t = tile_ptr(S, nt, ti, tj);
   for (int e = threadIdx.x; e < T * T; e += kThreads) {
@@ -420,8 +433,9 @@ __global__ void __launch_bounds__(kBackThreads) k_backward(const double* S, int 
 
 }  // namespace
 
-void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles), dim3(kThreads), 0, s, S, nt, tile_list, is_pad_row);
+void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row, const StepClear& c) {
+  const int extra = (int)std::min<int64_t>(64, (c.n_max + kThreads - 1) / kThreads);
+  if (ntiles + extra > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles + extra), dim3(kThreads), 0, s, S, nt, tile_list, ntiles, is_pad_row, c);
 }
 
 static void tick(hipStream_t s, CholTimers* t, int tag) {
@@ -437,7 +451,6 @@ static void tick(hipStream_t s, CholTimers* t, int tag) {
 void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers) {
   const int nt = p.nt;
   if (l0 >= l1) return;
-  if (l0 == 0) (void)hipMemsetAsync(p.diag_done, 0, sizeof(int32_t) * (size_t)nt, s);
   tick(s, timers, -1);
   // the first level of the range has nothing to wait for inside a launch
   hipLaunchKernelGGL(k_potrf, dim3(p.lvl_k_ptr[l0 + 1] - p.lvl_k_ptr[l0]), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l0], Linv, rhs, scal);

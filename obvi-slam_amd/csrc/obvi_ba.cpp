@@ -732,6 +732,16 @@ void prepare(obvi_ba_handle* h) {
   h->dirty = false;
 }
 
+StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
+  StepClear c;
+  c.hdiag = h->d_Hdiag.get(); c.n_hdiag = (int64_t)h->d_Hdiag.size();
+  c.g = h->d_g.get(); c.n_g = (int64_t)h->d_g.size();
+  c.rhs = h->d_rhs.get(); c.n_rhs = (int64_t)h->d_rhs.size();
+  c.diag_done = h->d_diag_done.get(); c.n_done = (int64_t)h->d_diag_done.size();
+  c.scal = h->d_scal.get(); c.n_scal = SC_COUNT; c.fixed_slot = SC_COST_FIXED; c.fixed_cost = fixed_cost;
+  c.n_max = std::max({c.n_hdiag, c.n_g, c.n_rhs, c.n_done, c.n_scal});
+  return c;
+}
 void record(obvi_ba_handle* h, int idx) { OBVI_HIP(hipEventRecord(h->ev[idx], h->stream)); }
 
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
@@ -745,13 +755,9 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   const PointDev pt = point_dev(h);
   double* scal = h->d_scal.get();
   const double fixed = h->h_scal[SC_COST_FIXED];
-  OBVI_HIP(hipMemsetAsync(scal, 0, sizeof(double) * SC_COUNT, s));
-  OBVI_HIP(hipMemcpyAsync(scal + SC_COST_FIXED, &fixed, sizeof(double), hipMemcpyHostToDevice, s));
-  h->d_Hdiag.zero(s); h->d_g.zero(s);
   record(h, PH_POSE_CACHE);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
-  h->d_rhs.zero(s);
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   record(h, PH_POSE_PASS);
@@ -829,15 +835,11 @@ double scal_gmax(const obvi_ba_handle* h) { double v; std::memcpy(&v, &h->h_scal
 void copy_current(obvi_ba_handle* h, DevBuf<double>& dp, DevBuf<double>& dl, DevBuf<double>& dobj) {
   hipStream_t s = h->stream;
   dp.resize((size_t)6 * h->P + 1); dl.resize((size_t)3 * h->L + 1); dobj.resize((size_t)7 * h->O + 1);
-  if (h->P) OBVI_HIP(hipMemcpyAsync(dp.get(), h->d_pose.get(), sizeof(double) * 6 * h->P, hipMemcpyDeviceToDevice, s));
-  if (h->L) OBVI_HIP(hipMemcpyAsync(dl.get(), h->d_point.get(), sizeof(double) * 3 * h->L, hipMemcpyDeviceToDevice, s));
-  if (h->O) OBVI_HIP(hipMemcpyAsync(dobj.get(), h->d_obj.get(), sizeof(double) * 7 * h->O, hipMemcpyDeviceToDevice, s));
+  launch_copy3(s, dp.get(), h->d_pose.get(), 6 * h->P, dl.get(), h->d_point.get(), 3 * h->L, dobj.get(), h->d_obj.get(), 7 * h->O);
 }
 void restore_from(obvi_ba_handle* h, const DevBuf<double>& dp, const DevBuf<double>& dl, const DevBuf<double>& dobj) {
   hipStream_t s = h->stream;
-  if (h->P) OBVI_HIP(hipMemcpyAsync(h->d_pose.get(), dp.get(), sizeof(double) * 6 * h->P, hipMemcpyDeviceToDevice, s));
-  if (h->L) OBVI_HIP(hipMemcpyAsync(h->d_point.get(), dl.get(), sizeof(double) * 3 * h->L, hipMemcpyDeviceToDevice, s));
-  if (h->O) OBVI_HIP(hipMemcpyAsync(h->d_obj.get(), dobj.get(), sizeof(double) * 7 * h->O, hipMemcpyDeviceToDevice, s));
+  launch_copy3(s, h->d_pose.get(), dp.get(), 6 * h->P, h->d_point.get(), dl.get(), 3 * h->L, h->d_obj.get(), dobj.get(), 7 * h->O);
 }
 
 bool check_ready(obvi_ba_handle* h) {
@@ -1224,10 +1226,8 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h); const ReprojDev rp = reproj_dev(h); const SmallFactorsDev sf = small_dev(h);
   const ReducedDev rd = reduced_dev(h); const PointDev pt = point_dev(h);
-  OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
-  h->d_Hdiag.zero(s); h->d_g.zero(s); h->d_rhs.zero(s);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get());
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, 0.0));
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get(), h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_scal.get());
