@@ -509,32 +509,33 @@ __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
 __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
                                                         ReducedDev rd, double radius, int first_iter, double* scal) {
-  const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  // 8 threads per block: thread k handles row k of the block
+  const int64_t t = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 3;
+  const int k = threadIdx.x & 7;
   double gsq = 0.0, gmax = 0.0, xsq = 0.0;
   const int64_t nblk = b.P + b.O;
   if (t < nblk) {
     const bool is_pose = t < b.P;
     const int64_t idx = is_pose ? t : t - b.P;
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
-    if (vid >= 0) {
-      const int d = is_pose ? 6 : 7;
+    const int d = is_pose ? 6 : 7;
+    if (vid >= 0 && k < d) {
       const int64_t crow = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;   // compact index (g, scale, lam)
       const int64_t row = is_pose ? b.pose_row[vid] : b.obj_row[vid];                     // row of the tile grid (S, rhs, y)
       const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
       const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
       // a shared object's (already globally summed) diagonal block, gradient and norms are contributed by one rank only
       const bool contribute = is_pose || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
-      for (int k = 0; k < d; ++k) {
-        const double c = Hd[d * k + k];
-        double s;
-        if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[crow + k] = s; } else { s = rd.scale[crow + k]; }
-        const double lam = lm_lambda(c, s, radius);
-        rd.lam[crow + k] = lam;
-        if (!contribute) continue;
+      const double c = Hd[d * k + k];
+      double s;
+      if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[crow + k] = s; } else { s = rd.scale[crow + k]; }
+      const double lam = lm_lambda(c, s, radius);
+      rd.lam[crow + k] = lam;
+      if (contribute) {
         for (int y = 0; y <= k; ++y) *S_at(rd.S, rd.nt, row + k, row + y) += Hd[d * k + y] + (y == k ? lam : 0.0);
         const double g = rd.g[crow + k];
         rd.rhs[row + k] = g;
-        gsq += g * g; gmax = fmax(gmax, fabs(g)); xsq += x[k] * x[k];
+        gsq = g * g; gmax = fabs(g); xsq = x[k] * x[k];
       }
     }
   }
@@ -1170,7 +1171,7 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {
-  if (b.P + b.O > 0) hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
+  if (b.P + b.O > 0) hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(8 * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
