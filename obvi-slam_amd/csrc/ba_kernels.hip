@@ -532,9 +532,10 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
       const double lam = lm_lambda(c, s, radius);
       rd.lam[crow + k] = lam;
       if (contribute) {
-        for (int y = 0; y <= k; ++y) *S_at(rd.S, rd.nt, row + k, row + y) += Hd[d * k + y] + (y == k ? lam : 0.0);
+        // atomics: the Schur complement kernels subtract from the same tiles and right-hand side, possibly at the same time (side stream)
+        for (int y = 0; y <= k; ++y) atomic_add_f64(S_at(rd.S, rd.nt, row + k, row + y), Hd[d * k + y] + (y == k ? lam : 0.0));
         const double g = rd.g[crow + k];
-        rd.rhs[row + k] = g;
+        atomic_add_f64(rd.rhs + row + k, g);
         gsq = g * g; gmax = fabs(g); xsq = x[k] * x[k];
       }
     }
@@ -1195,15 +1196,15 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
-                 const double* points_cand, const double* objects_cand, int mode, double* scal) {
-  // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
+                 const double* points_cand, const double* objects_cand, int mode, double* scal, int which) {
+  // which: 1 reprojection factors, 2 the small families, 3 both.  mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
   const PoseCache* pc = mode == 0 ? pc_cand : pc_cur;
   const double* poses = mode == 0 ? poses_cand : poses_cur;
   const double* points = mode == 0 ? points_cand : points_cur;
   const double* objects = mode == 0 ? objects_cand : objects_cur;
-  if (rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
+  if ((which & 1) && rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
-  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
+  if ((which & 2) && ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
                      const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,

@@ -128,7 +128,11 @@ struct obvi_ba_handle {
   int32_t tail_t0 = -1, tail_level0 = -1;   // first tile / first level of the shared tail (-1: none)
 
   // ---- phase timing ----
-  hipEvent_t ev[PH_COUNT + 1] = {};
+  hipEvent_t ev[PH_COUNT + 1] = {};       // start of each phase (+ end of the step) on the main stream
+  hipEvent_t ev_end[PH_COUNT] = {};       // end of a phase that ran on the side stream
+  bool phase_on_side[PH_COUNT] = {};
+  hipStream_t stream2 = nullptr;          // side stream: kernels that do not depend on the point pass / Schur complement run beside them
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int ck_used = 0;
   int profiling = 0;                       // 2: per-kernel events inside the tile Cholesky
   std::vector<hipEvent_t> ck_pool; std::vector<int> ck_tags;
@@ -742,7 +746,11 @@ StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
   c.n_max = std::max({c.n_hdiag, c.n_g, c.n_rhs, c.n_done, c.n_scal});
   return c;
 }
-void record(obvi_ba_handle* h, int idx) { OBVI_HIP(hipEventRecord(h->ev[idx], h->stream)); }
+void record(obvi_ba_handle* h, int idx, hipStream_t on = nullptr) {
+  OBVI_HIP(hipEventRecord(h->ev[idx], on ? on : h->stream));
+  if (idx < PH_COUNT) h->phase_on_side[idx] = on != nullptr && on != h->stream;
+}
+void record_end(obvi_ba_handle* h, int idx, hipStream_t on) { OBVI_HIP(hipEventRecord(h->ev_end[idx], on)); }
 
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
@@ -758,25 +766,42 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   record(h, PH_POSE_CACHE);
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
   launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
-  record(h, PH_POINT_PASS);
-  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
-  record(h, PH_POSE_PASS);
-  launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
-  record(h, PH_SMALL);
-  launch_small_factors(s, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
-  record(h, PH_DIAG);
   const bool exchange = h->allreduce != nullptr && !h->h_shared_ov.empty();
+  // Fork: the pose-side pass, the small factor families and the diagonal blocks do not depend on the point pass or the
+  // Schur complement (everything they share is accumulated with atomics), so they run beside them on the side stream.
+  // Not with a multi-GPU exchange in the chain (its collective is ordered on the main stream) nor in an instrumented solve.
+  const bool side = !exchange && h->profiling < 2;
+  hipStream_t s2 = side ? h->stream2 : s;
+  if (side) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
+  if (!side) {
+    record(h, PH_POINT_PASS);
+    launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
+  }
+  record(h, PH_POSE_PASS, s2);
+  launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
+  if (side) record_end(h, PH_POSE_PASS, s2);
+  record(h, PH_SMALL, s2);
+  launch_small_factors(s2, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
+  if (side) record_end(h, PH_SMALL, s2);
+  record(h, PH_DIAG, s2);
   if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
     const int32_t ns = (int32_t)h->h_shared_ov.size();
     launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 0);
     if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), 56 * (int64_t)ns, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
     launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 1);
   }
-  launch_reduced_diag(s, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
+  launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
+  if (side) {
+    record_end(h, PH_DIAG, s2);
+    OBVI_HIP(hipEventRecord(h->ev_join, s2));
+    record(h, PH_POINT_PASS);
+    launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
+  }
   record(h, PH_SCHUR);
   if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   record(h, PH_SCHUR_BLOCKS);
   if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  if (side) OBVI_HIP(hipStreamWaitEvent(s, h->ev_join, 0));   // join
   record(h, PH_CHOL);
   if (solve && h->m > 0) {
     const CholPlan plan = chol_plan(h);
@@ -817,7 +842,12 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   sync(h);
   for (int p = 0; p < PH_COUNT; ++p) {
     float ms = 0.f;
-    OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev[p + 1]));
+    if (h->phase_on_side[p]) { OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev_end[p])); }
+    else {
+      int q = p + 1;
+      while (q < PH_COUNT && h->phase_on_side[q]) ++q;   // next phase boundary on the main stream
+      OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev[q]));
+    }
     h->phase_ms[p] += ms;
     h->phase_launches[p] += 1;
   }
@@ -879,7 +909,10 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * SC_COUNT, hipHostMallocDefault));
     std::memset(h->h_scal, 0, sizeof(double) * SC_COUNT);
     h->d_scal.resize(SC_COUNT);
+    OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
+    for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
+    OBVI_HIP(hipEventCreate(&h->ev_fork)); OBVI_HIP(hipEventCreate(&h->ev_join));
   } catch (const HipError&) {
     delete h;
     return OBVI_ERR_HIP;
@@ -892,7 +925,11 @@ void obvi_ba_destroy(obvi_ba_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_end) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_fork, h->ev_join}) if (e) (void)hipEventDestroy(e);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   select_scratch_free(&h->sel_scratch);
   // DevBuf members free in ~obvi_ba_handle
