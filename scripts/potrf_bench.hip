@@ -1,8 +1,10 @@
-// micro-benchmark / phase timing of k_potrf (dev tool, not part of the product)
+// micro-benchmark + self-check of k_potrf (dev tool, not part of the product):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics scripts/potrf_bench.hip -o scripts/potrf_bench
 #include "../obvi-slam_amd/csrc/chol_kernels.hip"
 #include <cstdio>
 #include <vector>
 #include <random>
+#include <cmath>
 using namespace obvi;
 int main() {
   const int nt = 32, T = 64;
@@ -31,6 +33,18 @@ int main() {
     }
     printf("n=%2d  %.1f us\n", n, best * 1e3);
   }
-  std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost); printf("chol_fail %g\n", sc[SC_CHOL_FAIL]);
+  std::vector<double> Lh(S.size()), Li((size_t)nt * T * T), z(nt * T);
+  hipMemcpy(Lh.data(), dS, S.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(Li.data(), dL, Li.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(z.data(), dr, z.size() * 8, hipMemcpyDeviceToHost);
+  double e_llt = 0, e_inv = 0, e_z = 0;
+  for (int k = 0; k < nt; ++k) {
+    const double* A = &S[((size_t)k * nt + k) * T * T]; const double* L = &Lh[((size_t)k * nt + k) * T * T]; const double* W = &Li[(size_t)k * T * T];
+    for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) {
+      double s = 0, t = 0; for (int q = 0; q < T; ++q) { s += L[i * T + q] * L[j * T + q]; t += L[i * T + q] * W[q * T + j]; }
+      e_llt = std::max(e_llt, std::fabs(s - A[i * T + j]) / T); e_inv = std::max(e_inv, std::fabs(t - (i == j)));
+    }
+    for (int i = 0; i < T; ++i) { double s = 0; for (int q = 0; q < T; ++q) s += L[i * T + q] * z[k * T + q]; e_z = std::max(e_z, std::fabs(s - 1.0)); }
+  }
+  std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost);
+  printf("chol_fail %g   max |L L^T - A|/64 %.2e   max |L W - I| %.2e   max |L z - b| %.2e\n", sc[SC_CHOL_FAIL], e_llt, e_inv, e_z);
   return 0;
 }
