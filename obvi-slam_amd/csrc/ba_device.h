@@ -134,7 +134,7 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams,
                  const PoseCache* pc_cur, const double* poses_cur, const double* points_cur, const double* objects_cur,
                  const PoseCache* pc_cand, const double* poses_cand, const double* points_cand, const double* objects_cand,
-                 int mode, double* scal, int which = 3);
+                 int mode, double* scal);
 // problem->Evaluate: raw / robustified residuals of every factor in caller order
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf,
                      const DevCam* cams, const PoseCache* pc, const double* poses, const double* points, const double* objects,

@@ -1196,15 +1196,15 @@ void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedD
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
-                 const double* points_cand, const double* objects_cand, int mode, double* scal, int which) {
-  // which: 1 reprojection factors, 2 the small families, 3 both.  mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
+                 const double* points_cand, const double* objects_cand, int mode, double* scal) {
+  // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
   const PoseCache* pc = mode == 0 ? pc_cand : pc_cur;
   const double* poses = mode == 0 ? poses_cand : poses_cur;
   const double* points = mode == 0 ? points_cand : points_cur;
   const double* objects = mode == 0 ? objects_cand : objects_cur;
-  if ((which & 1) && rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
+  if (rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
-  if ((which & 2) && ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
+  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
                      const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,

@@ -73,8 +73,10 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
   double* zsh = Wsh + 16 * 16;
   double* tile = tile_ptr(S, nt, k, k);
   // wavefronts 0-3 factorise, wavefronts 4-7 build L^-1 concurrently (same (ty,tx) block map, same barriers)
-  const int tid = threadIdx.x & 255, ty = tid >> 4, tx = tid & 15;
   const bool fac = threadIdx.x < 256;
+  // the busy rows are the last ones for both halves: rotate the inverse half by two wavefronts so that the wavefront pairs
+  // sharing a SIMD (w, w + 4) do not both hold rows 12-15
+  const int tid = threadIdx.x & 255, ty = fac ? tid >> 4 : ((tid >> 4) + 8) & 15, tx = tid & 15;
   OBVI_TICK(0);
   double a[4][4];
 #pragma unroll
