@@ -182,6 +182,7 @@ struct CholPlan {
   int32_t* diag_done;         // device [nt] counters
   const int32_t* crit_upd;    // host [nlevels]     number of signalling update / right-hand-side jobs of the level (first in their lists)
   const int32_t* crit_rh;     // host [nlevels]
+  const int32_t* slices;      // host [nlevels]     1, or 4 on thin levels (update / trsm tile products split into four row slices)
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
 };

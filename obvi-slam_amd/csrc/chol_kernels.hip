@@ -269,21 +269,51 @@ __device__ __forceinline__ void stage_tile(double* dst, const double* __restrict
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int32_t* __restrict__ jobs, const double* __restrict__ Linv_all) {
+// Row slice q (16 rows) of  C += A * B^T:  As holds rows [16 q, 16 q + 16) of A, B the whole tile; wavefront w computes the
+// 16x16 output tile of columns [16 w, 16 w + 16).  Used on thin levels, where a tile product is latency-critical and the
+// device is mostly idle: four workgroups share one product.
+__device__ __forceinline__ void tile_abt_mfma_rows(const double* As, const double* B, f64x4& acc) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const double* Ap = As + r16 * LDM + kq;
+  const double* Bp = B + (16 * wv + r16) * LDM + kq;
+#pragma unroll 4
+  for (int k0 = 0; k0 < T; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k0], Bp[k0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void stage_rows16(double* dst, const double* __restrict__ src) {   // 16 rows of a row-major tile -> LDS (LDM)
+  for (int e = threadIdx.x; e < 16 * T / 2; e += kThreads) {
+    const int r = e / (T / 2), c2 = e % (T / 2);
+    const double2 v = reinterpret_cast<const double2*>(src)[e];
+    dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int32_t* __restrict__ jobs, const double* __restrict__ Linv_all, int slices) {
   __shared__ double A[T * LDM];
   __shared__ double B[T * LDM];
-  const int i = jobs[2 * blockIdx.x], k = jobs[2 * blockIdx.x + 1];
+  const int job = blockIdx.x / slices, q = blockIdx.x % slices;
+  const int i = jobs[2 * job], k = jobs[2 * job + 1];
   double* tile = tile_ptr(S, nt, i, k);
-  stage_tile(A, tile);
-  stage_tile(B, Linv_all + (int64_t)k * (T * T));
-  __syncthreads();
-  f64x4 acc[4] = {};
-  tile_abt_mfma(A, B, acc);   // X = S_ik * Linv^T
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (slices == 1) {
+    stage_tile(A, tile);
+    stage_tile(B, Linv_all + (int64_t)k * (T * T));
+    __syncthreads();
+    f64x4 acc[4] = {};
+    tile_abt_mfma(A, B, acc);   // X = S_ik * Linv^T
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = acc[rt][r];
+      for (int r = 0; r < 4; ++r) tile[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = acc[rt][r];
+  } else {   // rows [16 q, 16 q + 16) of X: this workgroup reads and writes only these rows of the tile
+    stage_rows16(A, tile + 16 * q * T);
+    stage_tile(B, Linv_all + (int64_t)k * (T * T));
+    __syncthreads();
+    f64x4 acc = {};
+    tile_abt_mfma_rows(A, B, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(16 * q + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = acc[r];
+  }
 }
 
 // job g < n_upd: tile target (i,j): S_ij -= sum_{k in list} L_ik L_jk^T
@@ -295,10 +325,30 @@ struct UpdateJobs {
   const int32_t* upd_ij; const int32_t* upd_kptr; const int32_t* upd_k; const uint8_t* upd_flag;
   const int32_t* rh_i; const int32_t* rh_kptr; const int32_t* rh_k;
 };
-__device__ __forceinline__ void update_job(double* smem, double* S, int nt, const UpdateJobs& u, int g, double* rhs) {
+__device__ __forceinline__ void update_job(double* smem, double* S, int nt, const UpdateJobs& u, int g, double* rhs, int slice = -1) {
   double* A = smem;
   double* B = smem + T * LDM;
   const int tid = threadIdx.x;
+  if (g < u.n_upd && slice >= 0) {   // rows [16 slice, 16 slice + 16) of the target
+    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1];
+    f64x4 acc = {};
+    for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
+      const int k = u.upd_k[q];
+      __syncthreads();
+      stage_rows16(A, tile_ptr(S, nt, i, k) + 16 * slice * T);
+      stage_tile(B, tile_ptr(S, nt, j, k));
+      __syncthreads();
+      tile_abt_mfma_rows(A, B, acc);
+    }
+    double* C = tile_ptr(S, nt, i, j);
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* c = &C[(16 * slice + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)];
+      if (u.upd_flag[g]) unsafeAtomicAdd(c, -acc[r]); else *c -= acc[r];
+    }
+    return;
+  }
   if (g < u.n_upd) {
     const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1];
     f64x4 acc[4] = {};
@@ -341,9 +391,11 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     if (part == 0) rhs[(int64_t)i * T + r] -= s;
   }
 }
-__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJobs u, double* rhs) {
+__global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJobs u, double* rhs, int slices) {
   __shared__ double smem[2 * T * LDM];
-  update_job(smem, S, nt, u, blockIdx.x, rhs);
+  const int b = blockIdx.x, nu = slices * u.n_upd;
+  if (b < nu) update_job(smem, S, nt, u, b / slices, rhs, slices > 1 ? b % slices : -1);
+  else update_job(smem, S, nt, u, u.n_upd + (b - nu), rhs);
 }
 
 // One launch for the updates of level l and the potrf of level l+1.  Grid order: the update / right-hand-side jobs whose
@@ -353,12 +405,12 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJo
 // reaches the number of such jobs (acquire) and runs while the rest of level l is still being updated.
 // No deadlock: the jobs waited for have lower block indices and never wait themselves.  The wait is bounded (a lost
 // signal becomes a failed step).
-__global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJobs u, int n_rh, int n_crit_upd, int n_crit_rh, int n_potrf,
+__global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJobs u, int n_rh, int n_crit_upd, int n_crit_rh, int n_potrf, int slices,
                                                      const int32_t* __restrict__ job_signal, const int32_t* __restrict__ klist,
                                                      const int32_t* __restrict__ k_need, int32_t* done, double* Linv_all, double* rhs, double* scal) {
   __shared__ double smem[2 * T * LDM];
   static_assert(kPotrfLds <= 2 * T * LDM, "potrf fits the update buffers");
-  const int b = blockIdx.x, n_crit = n_crit_upd + n_crit_rh;
+  const int b = blockIdx.x, n_crit = slices * n_crit_upd + n_crit_rh;
   if (b >= n_crit && b < n_crit + n_potrf) {
     const int k = klist[b - n_crit], need = k_need[b - n_crit];
     if (threadIdx.x == 0) {
@@ -374,14 +426,17 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
     return;
   }
   if (threadIdx.x >= kThreads) return;
-  int g;   // job id: updates [0, n_upd), right-hand sides [n_upd, n_upd + n_rh)
-  if (b < n_crit_upd) g = b;
-  else if (b < n_crit) g = u.n_upd + (b - n_crit_upd);
+  // job id g: updates [0, n_upd), right-hand sides [n_upd, n_upd + n_rh); with slices == 4 every update job is four workgroups
+  int g, slice = -1;
+  const int nc = slices * n_crit_upd;
+  if (b < nc) { g = b / slices; if (slices > 1) slice = b % slices; }
+  else if (b < nc + n_crit_rh) g = u.n_upd + (b - nc);
   else {
-    const int r = b - n_crit - n_potrf;
-    g = r < u.n_upd - n_crit_upd ? n_crit_upd + r : u.n_upd + n_crit_rh + (r - (u.n_upd - n_crit_upd));
+    const int r = b - nc - n_crit_rh - n_potrf, nr = slices * (u.n_upd - n_crit_upd);
+    if (r < nr) { g = n_crit_upd + r / slices; if (slices > 1) slice = r % slices; }
+    else g = u.n_upd + n_crit_rh + (r - nr);
   }
-  update_job(smem, S, nt, u, g, rhs);
+  update_job(smem, S, nt, u, g, rhs, slice);
   const int sig = job_signal[g];
   if (sig >= 0) {
     __threadfence();
@@ -459,17 +514,18 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
   tick(s, timers, CK_POTRF);
   for (int l = l0; l < l1; ++l) {
     const int ntr = p.trsm_ptr[l + 1] - p.trsm_ptr[l];
-    if (ntr > 0) { hipLaunchKernelGGL(k_trsm, dim3(ntr), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv); tick(s, timers, CK_TRSM); }
+    const int sl = p.slices[l];   // 4 on thin levels: a tile product is shared by four workgroups
+    if (ntr > 0) { hipLaunchKernelGGL(k_trsm, dim3(ntr * sl), dim3(kThreads), 0, s, S, nt, p.trsm_ik + 2 * (int64_t)p.trsm_ptr[l], Linv, sl); tick(s, timers, CK_TRSM); }
     const int nup = p.upd_ptr[l + 1] - p.upd_ptr[l], nrh = p.rh_ptr[l + 1] - p.rh_ptr[l];
     const int npk = l + 1 < l1 ? p.lvl_k_ptr[l + 2] - p.lvl_k_ptr[l + 1] : 0;
     UpdateJobs u{nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k, p.upd_flag + p.upd_ptr[l],
                  p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k};
     if (npk > 0) {
-      hipLaunchKernelGGL(k_update_potrf, dim3(nup + nrh + npk), dim3(512), 0, s, S, nt, u, nrh, p.crit_upd[l], p.crit_rh[l], npk,
+      hipLaunchKernelGGL(k_update_potrf, dim3(sl * nup + nrh + npk), dim3(512), 0, s, S, nt, u, nrh, p.crit_upd[l], p.crit_rh[l], npk, sl,
                          p.job_signal + p.upd_ptr[l] + p.rh_ptr[l], p.lvl_k + p.lvl_k_ptr[l + 1], p.k_need + p.lvl_k_ptr[l + 1], p.diag_done, Linv, rhs, scal);
       tick(s, timers, CK_UPDATE);
     } else if (nup + nrh > 0) {
-      hipLaunchKernelGGL(k_update, dim3(nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs);
+      hipLaunchKernelGGL(k_update, dim3(sl * nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs, sl);
       tick(s, timers, CK_UPDATE);
     }
   }

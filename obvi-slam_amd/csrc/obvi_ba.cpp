@@ -107,7 +107,7 @@ struct obvi_ba_handle {
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
-  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh, h_slices;
   std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
@@ -229,7 +229,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
-  c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data();
+  c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
 }
 
@@ -622,7 +622,8 @@ void prepare(obvi_ba_handle* h) {
   std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, job_signal, k_need_of(nt, 0);
   std::vector<uint8_t> upd_flag;
   const int kUpdChunk = 4;
-  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_crit_upd.assign(nlev + 1, 0); h->h_crit_rh.assign(nlev + 1, 0);
+  const int64_t env_slice_max = std::getenv("OBVI_SLICE_MAX") ? std::atoi(std::getenv("OBVI_SLICE_MAX")) : 512;   // tuning knob
+  h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_crit_upd.assign(nlev + 1, 0); h->h_crit_rh.assign(nlev + 1, 0); h->h_slices.assign(nlev + 1, 1);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
   struct Trip { int32_t i, j, k; };
@@ -659,6 +660,8 @@ void prepare(obvi_ba_handle* h) {
       q = e;
     }
     std::stable_partition(jobs.begin(), jobs.end(), [](const Job& x) { return x.crit; });
+    const int32_t sl = (int64_t)jobs.size() + (int64_t)ik.size() <= env_slice_max ? 4 : 1;   // thin level: the device is mostly idle, split every tile product
+    h->h_slices[l] = sl;
     h->h_crit_upd[l] = (int32_t)std::count_if(jobs.begin(), jobs.end(), [](const Job& x) { return x.crit; });
     h->h_crit_rh[l] = 0;
     for (const Job& jb : jobs) {
@@ -666,7 +669,7 @@ void prepare(obvi_ba_handle* h) {
       for (size_t t = jb.t0; t < jb.t1; ++t) upd_k.push_back(trips[t].k);
       upd_kptr.push_back((int32_t)upd_k.size());
       job_signal.push_back(jb.crit ? jb.i : -1);
-      if (jb.crit) k_need_of[jb.i]++;
+      if (jb.crit) k_need_of[jb.i] += sl;
     }
     n_products += (int64_t)trips.size();
     std::sort(ik.begin(), ik.end());
