@@ -185,6 +185,8 @@ struct CholPlan {
   const int32_t* slices;      // host [nlevels]     1, or 4 on thin levels (update / trsm tile products split into four row slices)
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
+  const int32_t* bw_ptr;      // host [nlevels+1]   backward substitution workgroups of each level
+  const int32_t* bw_kj;       // device, 2 per workgroup: tile (k,j) of row k, j < k; j = -1: the workgroup that stores y_k
 };
 void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2);
 // small accumulators cleared at the start of an LM step, together with the tiles (one launch)
@@ -206,7 +208,7 @@ struct CholTimers {
   int used;
 };
 void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int level1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers = nullptr);
-void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, const double* rhs, double* y, CholTimers* timers = nullptr);
+void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* rhs /* z in, overwritten */, double* y, CholTimers* timers = nullptr);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

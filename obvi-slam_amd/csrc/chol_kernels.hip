@@ -63,8 +63,15 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 // (rows 4ty.., cols 4tx..) in registers.  Right-looking over 16 panels of 4 columns; then
 // L^-1 by a right-looking blocked forward substitution on the identity (same structure).
 // ---------------------------------------------------------------------------------------
+#ifndef OBVI_TICK
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
+#endif
+#ifndef OBVI_PH8
+#define OBVI_PH8(i)
+#define OBVI_PH8_DECL
+#define OBVI_PH8_END
+#endif
 constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * 16 + T;   // doubles
 __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
   double* Lsh = smem;                  // L (lower), later L^-1
@@ -227,6 +234,153 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (part == 0) rhs[(int64_t)k * T + r] = s;
+  }
+}
+// ---------------------------------------------------------------------------------------
+// potrf of one 64x64 tile, two columns per step, no single-thread phase.  A wavefront issues one fp64 instruction every
+// ~5.5 cycles whether one lane or 64 are active, so the pivot arithmetic is done redundantly by every thread instead of by
+// one thread followed by a barrier:
+//   step k (columns c = 2k, c+1): the owners of those columns have published their current values C[x] = (A[x][c], A[x][c+1])
+//   for all rows x.  Every thread reads the pivot block (p q; q r) and the C rows of its own 4 row and 4 column indices and forms
+//     i0 = rsqrt(p), i1 = rsqrt(p r - q^2) sqrt(p)   (the two rsqrt are independent: 2x2 block pivot)
+//     l0[x] = C[x][0] i0,  l1[x] = (C[x][1] - l0[x] l10) i1     = L[x][c], L[x][c+1]
+//   and updates its 4x4 block  a -= l0 l0^T + l1 l1^T; the owners store l0, l1 as the finished columns and the owners of the next
+//   two columns publish them.  One barrier per step (the C buffers alternate).
+// The inverse wavefronts build W = L^-1 the same way from the published rows c, c+1 of their accumulator.
+// Finished rows are published as zeros, so their l values vanish and no masks are needed; the diagonal blocks are kept
+// symmetric, the strict upper triangle is cleared when L is stored.
+// ---------------------------------------------------------------------------------------
+constexpr int kPotrf2Lds = 2 * T * 2 + 2 * 2 * T + T * LD + T;   // doubles
+__device__ __forceinline__ void potrf2_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
+  double* Csh = smem;                  // [2][64][2]  current values of the two pivot columns, all rows
+  double* Rsh = Csh + 2 * T * 2;       // [2][2][64]  current values of rows c, c+1 of the L^-1 accumulator
+  double* Lsh = Rsh + 2 * 2 * T;       // L^-1 for the right-hand side at the end
+  double* zsh = Lsh + T * LD;
+  double* tile = tile_ptr(S, nt, k, k);
+  const bool fac = threadIdx.x < 256;
+  const int tid = threadIdx.x & 255, ty = fac ? tid >> 4 : ((tid >> 4) + 8) & 15, tx = tid & 15;
+  double a[4][4];   // fac: block (ty,tx) of A -> L;  inverse: block (ty,tx) of the accumulator -> W
+  if (fac) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[i][j] = tile[(4 * ty + i) * T + 4 * tx + j];
+    if (ty == tx) {   // only the lower triangle of the tile is valid
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) a[i][j] = a[j][i];
+    }
+    if (tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
+    if (tx == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { Csh[(4 * ty + i) * 2] = a[i][0]; Csh[(4 * ty + i) * 2 + 1] = a[i][1]; }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
+    if (ty == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { Rsh[4 * tx + j] = a[0][j]; Rsh[T + 4 * tx + j] = a[1][j]; }
+    }
+  }
+  double bad = 0.0;
+  OBVI_PH8_DECL;
+  __syncthreads();
+  OBVI_PH8(0);
+  for (int bc = 0; bc < 16; ++bc)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = 4 * bc + 2 * h;
+    const double* C = Csh + h * (2 * T);
+    const double* R = Rsh + h * (2 * T);
+    double* Cn = Csh + (1 - h) * (2 * T);
+    double* Rn = Rsh + (1 - h) * (2 * T);
+    const bool active = fac ? (ty >= tx && tx >= bc) : (ty >= bc && tx <= bc && ty >= tx);
+    if (active) {
+      const double p = C[2 * c], q = C[2 * c + 2], r = C[2 * c + 3];
+      const double det = fma(p, r, -(q * q));
+      if (!(p > 0.0) || !(det > 0.0)) bad = 1.0;
+      const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
+      const double l10 = q * i0, i1 = id * (p * i0);
+      double l0r[4], l1r[4], u0[4], u1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double c0 = C[(4 * ty + i) * 2], c1 = C[(4 * ty + i) * 2 + 1];
+        l0r[i] = c0 * i0; l1r[i] = fma(-l0r[i], l10, c1) * i1;
+      }
+      if (fac) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double c0 = C[(4 * tx + j) * 2], c1 = C[(4 * tx + j) * 2 + 1];
+          u0[j] = c0 * i0; u1[j] = fma(-u0[j], l10, c1) * i1;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u0[j] = R[4 * tx + j] * i0; u1[j] = fma(-l10, u0[j], R[T + 4 * tx + j]) * i1;   // rows c, c+1 of W
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i][j] = fma(-l1r[i], u1[j], fma(-l0r[i], u0[j], a[i][j]));
+      if (fac) {
+        if (tx == bc) {   // the two finished columns of L
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (h == 0) { a[i][0] = l0r[i]; a[i][1] = l1r[i]; } else { a[i][2] = l0r[i]; a[i][3] = l1r[i]; }
+          }
+        }
+      } else if (ty == bc) {   // the two finished rows of W
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (h == 0) { a[0][j] = u0[j]; a[1][j] = u1[j]; } else { a[2][j] = u0[j]; a[3][j] = u1[j]; }
+        }
+      }
+      // publish the next pair
+      const int cn = c + 2, bn = cn >> 2, hn = 1 - h;
+      if (fac) {
+        if (tx == bn && cn < T) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool done = ty == bn && hn == 1 && i < 2;   // rows above the pivot block: finished
+            const double v0 = hn == 0 ? a[i][0] : a[i][2], v1 = hn == 0 ? a[i][1] : a[i][3];
+            Cn[(4 * ty + i) * 2] = done ? 0.0 : v0; Cn[(4 * ty + i) * 2 + 1] = done ? 0.0 : v1;
+          }
+        }
+      }
+    }
+    if (!fac && ty == ((c + 2) >> 2) && tx <= ty && c + 2 < T) {   // next two rows of the accumulator (its diagonal block has not been active yet)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { Rn[4 * tx + j] = h == 1 ? a[0][j] : a[2][j]; Rn[T + 4 * tx + j] = h == 1 ? a[1][j] : a[3][j]; }
+    }
+    OBVI_PH8(1);
+    __syncthreads();
+    OBVI_PH8(2);
+  }
+  OBVI_PH8_END;
+  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  double* Li = Linv_all + (int64_t)k * (T * T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double v = (ty > tx || (ty == tx && i >= j)) ? a[i][j] : 0.0;
+      if (fac) tile[(4 * ty + i) * T + 4 * tx + j] = v;
+      else { Li[(4 * ty + i) * T + 4 * tx + j] = v; Lsh[(4 * ty + i) * LD + 4 * tx + j] = v; }
+    }
+  __syncthreads();
+  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
+    const int r = tid >> 2, part = tid & 3;
+    double sum = 0.0;
+#pragma unroll
+    for (int cc = 16 * part; cc < 16 * part + 16; ++cc) sum += Lsh[r * LD + cc] * zsh[cc];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (part == 0) rhs[(int64_t)k * T + r] = sum;
   }
 }
 __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
@@ -446,45 +600,53 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
   (void)n_rh;
 }
 
-// backward substitution of a level, one workgroup per tile column k of the level:
-//   t = z_k - sum_{i in column k} L_ik^T y_i   (rows i below k: all of them belong to later levels, already solved)
-//   y_k = L_kk^-T t
-constexpr int kBackThreads = 512;
-__global__ void __launch_bounds__(kBackThreads) k_backward(const double* S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ col_ptr,
-                                                         const int32_t* __restrict__ col_i, const double* __restrict__ Linv_all, const double* __restrict__ rhs, double* y) {
-  constexpr int Q = kBackThreads / T;   // row slices
+// backward substitution of a level (L^T y = z), row oriented, one workgroup per tile of the level's tile rows.  t starts as z
+// and is updated in place:  every workgroup of row k forms y_k = L_kk^-T t_k (t_k is final: rows above it in the elimination
+// tree were solved by earlier launches); the workgroup of tile (k,j) subtracts L_kj^T y_k from t_j, the workgroup with
+// j = -1 stores y_k.  Both tile reads of a workgroup are in flight together, and a level with a single tile column still
+// spreads over as many compute units as the row has tiles.
+constexpr int kBackThreads = 256;
+__global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restrict__ S, int nt, const int32_t* __restrict__ kj, const double* __restrict__ Linv_all,
+                                                         double* t, double* y) {
+  constexpr int Q = kBackThreads / T, R = T / Q;   // row slices, rows per slice
   __shared__ double part[Q][T];
-  __shared__ double tsh[T];
-  const int k = klist[blockIdx.x];
+  __shared__ double ysh[T];
+  const int k = kj[2 * blockIdx.x], j = kj[2 * blockIdx.x + 1];
   const int tid = threadIdx.x, c = tid % T, q = tid / T;
-  double s = 0.0;
-  for (int e = col_ptr[k]; e < col_ptr[k + 1]; ++e) {
-    const int i = col_i[e];
-    const double* X = tile_ptr(const_cast<double*>(S), nt, i, k) + (q * (T / Q)) * T + c;
-    const double* yi = y + (int64_t)i * T + q * (T / Q);
+  const double* Li = Linv_all + (int64_t)k * (T * T) + (q * R) * T + c;
+  const double* X = j >= 0 ? tile_ptr(const_cast<double*>(S), nt, k, j) + (q * R) * T + c : nullptr;
+  double w[R], x[R];
 #pragma unroll
-    for (int r = 0; r < T / Q; ++r) s += X[r * T] * yi[r];
+  for (int r = 0; r < R; ++r) w[r] = Li[r * T];
+  if (j >= 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = X[r * T];
   }
+  const double* tk = t + (int64_t)k * T + q * R;
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s += w[r] * tk[r];   // L^-1 is lower triangular with an explicit zero upper part
   part[q][c] = s;
   __syncthreads();
   if (tid < T) {
     double a = 0.0;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) a += part[j][tid];
-    tsh[tid] = rhs[(int64_t)k * T + tid] - a;
+    for (int i = 0; i < Q; ++i) a += part[i][tid];
+    ysh[tid] = a;
+    if (j < 0) y[(int64_t)k * T + tid] = a;
   }
+  if (j < 0) return;
   __syncthreads();
-  const double* Li = Linv_all + (int64_t)k * (T * T);
   s = 0.0;
 #pragma unroll
-  for (int r = 0; r < T / Q; ++r) { const int i = q * (T / Q) + r; if (i >= c) s += Li[i * T + c] * tsh[i]; }
+  for (int r = 0; r < R; ++r) s += x[r] * ysh[q * R + r];
   part[q][c] = s;
   __syncthreads();
   if (tid < T) {
     double a = 0.0;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) a += part[j][tid];
-    y[(int64_t)k * T + tid] = a;
+    for (int i = 0; i < Q; ++i) a += part[i][tid];
+    unsafeAtomicAdd(t + (int64_t)j * T + tid, -a);
   }
 }
 
@@ -530,12 +692,12 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
     }
   }
 }
-void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, const double* rhs, double* y, CholTimers* timers) {
+void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* rhs, double* y, CholTimers* timers) {
   const int nt = p.nt;
   tick(s, timers, -1);
   for (int l = p.nlevels - 1; l >= 0; --l) {
-    const int npk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    hipLaunchKernelGGL(k_backward, dim3(npk), dim3(kBackThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], p.col_ptr, p.col_i, Linv, rhs, y);
+    const int nwg = p.bw_ptr[l + 1] - p.bw_ptr[l];
+    if (nwg > 0) hipLaunchKernelGGL(k_backward, dim3(nwg), dim3(kBackThreads), 0, s, S, nt, p.bw_kj + 2 * (int64_t)p.bw_ptr[l], Linv, rhs, y);
     tick(s, timers, CK_BACKWARD);
   }
 }

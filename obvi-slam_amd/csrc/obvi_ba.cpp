@@ -90,7 +90,7 @@ struct obvi_ba_handle {
   DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
-  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i;
+  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
   DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done;
   DevBuf<int32_t> d_pose_row, d_obj_row;
@@ -107,7 +107,7 @@ struct obvi_ba_handle {
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
   int32_t nlevels = 0;
-  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh, h_slices;
+  std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh, h_slices, h_bw_ptr;
   std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
   std::vector<int64_t> h_canon_row;   // canonical reduced index (poses by index, then objects) -> row of the tile grid
@@ -228,7 +228,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
-  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get();
+  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
   c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
 }
@@ -689,6 +689,17 @@ void prepare(obvi_ba_handle* h) {
     h->h_trsm_ptr[l + 1] = (int32_t)(trsm_ik.size() / 2);
     h->h_upd_ptr[l + 1] = (int32_t)(upd_ij.size() / 2);
     h->h_rh_ptr[l + 1] = (int32_t)rh_i.size();
+    if (std::getenv("OBVI_DEBUG_PLAN")) std::fprintf(stderr, "level %d: columns %zu (first %d) trsm %zu update jobs %zu (critical %d) products %zu slices %d\n", l, by_level[l].size(), by_level[l].empty() ? -1 : by_level[l][0], ik.size(), jobs.size(), h->h_crit_upd[l], trips.size(), sl);
+  }
+  // backward substitution, row oriented: one workgroup per tile of L
+  std::vector<int32_t> bw_kj;
+  h->h_bw_ptr.assign(nlev + 1, 0);
+  for (int l = 0; l < nlev; ++l) {
+    for (int32_t k : by_level[l]) {
+      bw_kj.push_back(k); bw_kj.push_back(-1);
+      for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) { bw_kj.push_back(k); bw_kj.push_back(j); }
+    }
+    h->h_bw_ptr[l + 1] = (int32_t)(bw_kj.size() / 2);
   }
   h->chol_flops = flops;
   h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
@@ -707,7 +718,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
-  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_upd_flag.upload(upd_flag, s);
+  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_bw_kj.upload(bw_kj, s); h->d_upd_flag.upload(upd_flag, s);
   {
     std::vector<int32_t> k_need(lvl_k.size());
     for (size_t x = 0; x < lvl_k.size(); ++x) k_need[x] = k_need_of[lvl_k[x]];
