@@ -179,6 +179,8 @@ struct CholPlan {
   const int32_t* rh_k;        // device
   const int32_t* job_signal;  // device [update jobs + rhs jobs, per level: updates then rhs]  tile column of the next level whose potrf waits for the job, or -1
   const int32_t* k_need;      // device, parallel to lvl_k: number of jobs of the previous level that column's potrf waits for
+  const int32_t* pre_ptr;     // device, parallel to lvl_k (+1): tile columns j of the previous level whose product L_kj L_kj^T (and L_kj z_j)
+  const int32_t* pre_j;       // device                  the column's potrf workgroup applies itself (no job, no wait)
   int32_t* diag_done;         // device [nt] counters
   const int32_t* crit_upd;    // host [nlevels]     number of signalling update / right-hand-side jobs of the level (first in their lists)
   const int32_t* crit_rh;     // host [nlevels]

@@ -67,13 +67,8 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
 #endif
-#ifndef OBVI_PH8
-#define OBVI_PH8(i)
-#define OBVI_PH8_DECL
-#define OBVI_PH8_END
-#endif
 constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * 16 + T;   // doubles
-__device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
+__device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
   double* Lsh = smem;                  // L (lower), later L^-1
   double* Dsh = Lsh + T * LD;          // inverse of the 16 diagonal 4x4 blocks of L
   double* Wsh = Dsh + 16 * 16;         // row-block r of L^-1 during the inverse phase
@@ -89,8 +84,13 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[i][j] = tile[(4 * ty + i) * T + 4 * tx + j];
-  if (fac && tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
+    for (int j = 0; j < 4; ++j) a[i][j] = pre_tile ? pre_tile[(4 * ty + i) * (T + 2) + 4 * tx + j] : tile[(4 * ty + i) * T + 4 * tx + j];
+  // pre_tile / pre_z: the tile and right-hand-side block already updated by the caller, in LDS (leading dimension T + 2) that
+  // this function's own buffers overlap
+  double zv = 0.0;
+  if (fac && tid < T) zv = pre_z ? pre_z[tid] : rhs[(int64_t)k * T + tid];
+  if (pre_tile) __syncthreads();
+  if (fac && tid < T) zsh[tid] = zv;
   if (fac && ty < tx) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -234,153 +234,6 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (part == 0) rhs[(int64_t)k * T + r] = s;
-  }
-}
-// ---------------------------------------------------------------------------------------
-// potrf of one 64x64 tile, two columns per step, no single-thread phase.  A wavefront issues one fp64 instruction every
-// ~5.5 cycles whether one lane or 64 are active, so the pivot arithmetic is done redundantly by every thread instead of by
-// one thread followed by a barrier:
-//   step k (columns c = 2k, c+1): the owners of those columns have published their current values C[x] = (A[x][c], A[x][c+1])
-//   for all rows x.  Every thread reads the pivot block (p q; q r) and the C rows of its own 4 row and 4 column indices and forms
-//     i0 = rsqrt(p), i1 = rsqrt(p r - q^2) sqrt(p)   (the two rsqrt are independent: 2x2 block pivot)
-//     l0[x] = C[x][0] i0,  l1[x] = (C[x][1] - l0[x] l10) i1     = L[x][c], L[x][c+1]
-//   and updates its 4x4 block  a -= l0 l0^T + l1 l1^T; the owners store l0, l1 as the finished columns and the owners of the next
-//   two columns publish them.  One barrier per step (the C buffers alternate).
-// The inverse wavefronts build W = L^-1 the same way from the published rows c, c+1 of their accumulator.
-// Finished rows are published as zeros, so their l values vanish and no masks are needed; the diagonal blocks are kept
-// symmetric, the strict upper triangle is cleared when L is stored.
-// ---------------------------------------------------------------------------------------
-constexpr int kPotrf2Lds = 2 * T * 2 + 2 * 2 * T + T * LD + T;   // doubles
-__device__ __forceinline__ void potrf2_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal) {
-  double* Csh = smem;                  // [2][64][2]  current values of the two pivot columns, all rows
-  double* Rsh = Csh + 2 * T * 2;       // [2][2][64]  current values of rows c, c+1 of the L^-1 accumulator
-  double* Lsh = Rsh + 2 * 2 * T;       // L^-1 for the right-hand side at the end
-  double* zsh = Lsh + T * LD;
-  double* tile = tile_ptr(S, nt, k, k);
-  const bool fac = threadIdx.x < 256;
-  const int tid = threadIdx.x & 255, ty = fac ? tid >> 4 : ((tid >> 4) + 8) & 15, tx = tid & 15;
-  double a[4][4];   // fac: block (ty,tx) of A -> L;  inverse: block (ty,tx) of the accumulator -> W
-  if (fac) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[i][j] = tile[(4 * ty + i) * T + 4 * tx + j];
-    if (ty == tx) {   // only the lower triangle of the tile is valid
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i + 1; j < 4; ++j) a[i][j] = a[j][i];
-    }
-    if (tid < T) zsh[tid] = rhs[(int64_t)k * T + tid];
-    if (tx == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { Csh[(4 * ty + i) * 2] = a[i][0]; Csh[(4 * ty + i) * 2 + 1] = a[i][1]; }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
-    if (ty == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { Rsh[4 * tx + j] = a[0][j]; Rsh[T + 4 * tx + j] = a[1][j]; }
-    }
-  }
-  double bad = 0.0;
-  OBVI_PH8_DECL;
-  __syncthreads();
-  OBVI_PH8(0);
-  for (int bc = 0; bc < 16; ++bc)
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = 4 * bc + 2 * h;
-    const double* C = Csh + h * (2 * T);
-    const double* R = Rsh + h * (2 * T);
-    double* Cn = Csh + (1 - h) * (2 * T);
-    double* Rn = Rsh + (1 - h) * (2 * T);
-    const bool active = fac ? (ty >= tx && tx >= bc) : (ty >= bc && tx <= bc && ty >= tx);
-    if (active) {
-      const double p = C[2 * c], q = C[2 * c + 2], r = C[2 * c + 3];
-      const double det = fma(p, r, -(q * q));
-      if (!(p > 0.0) || !(det > 0.0)) bad = 1.0;
-      const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
-      const double l10 = q * i0, i1 = id * (p * i0);
-      double l0r[4], l1r[4], u0[4], u1[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const double c0 = C[(4 * ty + i) * 2], c1 = C[(4 * ty + i) * 2 + 1];
-        l0r[i] = c0 * i0; l1r[i] = fma(-l0r[i], l10, c1) * i1;
-      }
-      if (fac) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double c0 = C[(4 * tx + j) * 2], c1 = C[(4 * tx + j) * 2 + 1];
-          u0[j] = c0 * i0; u1[j] = fma(-u0[j], l10, c1) * i1;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          u0[j] = R[4 * tx + j] * i0; u1[j] = fma(-l10, u0[j], R[T + 4 * tx + j]) * i1;   // rows c, c+1 of W
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[i][j] = fma(-l1r[i], u1[j], fma(-l0r[i], u0[j], a[i][j]));
-      if (fac) {
-        if (tx == bc) {   // the two finished columns of L
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (h == 0) { a[i][0] = l0r[i]; a[i][1] = l1r[i]; } else { a[i][2] = l0r[i]; a[i][3] = l1r[i]; }
-          }
-        }
-      } else if (ty == bc) {   // the two finished rows of W
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (h == 0) { a[0][j] = u0[j]; a[1][j] = u1[j]; } else { a[2][j] = u0[j]; a[3][j] = u1[j]; }
-        }
-      }
-      // publish the next pair
-      const int cn = c + 2, bn = cn >> 2, hn = 1 - h;
-      if (fac) {
-        if (tx == bn && cn < T) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool done = ty == bn && hn == 1 && i < 2;   // rows above the pivot block: finished
-            const double v0 = hn == 0 ? a[i][0] : a[i][2], v1 = hn == 0 ? a[i][1] : a[i][3];
-            Cn[(4 * ty + i) * 2] = done ? 0.0 : v0; Cn[(4 * ty + i) * 2 + 1] = done ? 0.0 : v1;
-          }
-        }
-      }
-    }
-    if (!fac && ty == ((c + 2) >> 2) && tx <= ty && c + 2 < T) {   // next two rows of the accumulator (its diagonal block has not been active yet)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { Rn[4 * tx + j] = h == 1 ? a[0][j] : a[2][j]; Rn[T + 4 * tx + j] = h == 1 ? a[1][j] : a[3][j]; }
-    }
-    OBVI_PH8(1);
-    __syncthreads();
-    OBVI_PH8(2);
-  }
-  OBVI_PH8_END;
-  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
-  double* Li = Linv_all + (int64_t)k * (T * T);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double v = (ty > tx || (ty == tx && i >= j)) ? a[i][j] : 0.0;
-      if (fac) tile[(4 * ty + i) * T + 4 * tx + j] = v;
-      else { Li[(4 * ty + i) * T + 4 * tx + j] = v; Lsh[(4 * ty + i) * LD + 4 * tx + j] = v; }
-    }
-  __syncthreads();
-  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
-    const int r = tid >> 2, part = tid & 3;
-    double sum = 0.0;
-#pragma unroll
-    for (int cc = 16 * part; cc < 16 * part + 16; ++cc) sum += Lsh[r * LD + cc] * zsh[cc];
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    if (part == 0) rhs[(int64_t)k * T + r] = sum;
   }
 }
 __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
@@ -561,22 +414,65 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJo
 // signal becomes a failed step).
 __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJobs u, int n_rh, int n_crit_upd, int n_crit_rh, int n_potrf, int slices,
                                                      const int32_t* __restrict__ job_signal, const int32_t* __restrict__ klist,
-                                                     const int32_t* __restrict__ k_need, int32_t* done, double* Linv_all, double* rhs, double* scal) {
-  __shared__ double smem[2 * T * LDM];
+                                                     const int32_t* __restrict__ k_need, const int32_t* __restrict__ pre_ptr, const int32_t* __restrict__ pre_j,
+                                                     int32_t* done, double* Linv_all, double* rhs, double* scal) {
+  __shared__ double smem[2 * T * LDM + T];
   static_assert(kPotrfLds <= 2 * T * LDM, "potrf fits the update buffers");
   const int b = blockIdx.x, n_crit = slices * n_crit_upd + n_crit_rh;
   if (b >= n_crit && b < n_crit + n_potrf) {
     const int k = klist[b - n_crit], need = k_need[b - n_crit];
-    if (threadIdx.x == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 22)) { unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0); break; }
+    if (need > 0) {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 22)) { unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0); break; }
+        }
+      }
+      __syncthreads();
+      __threadfence();
+    }
+    const int pb = pre_ptr[b - n_crit], pe = pre_ptr[b - n_crit + 1];
+    if (pe == pb) { potrf_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
+    // the few products of the previous level that finish this column's diagonal tile and right-hand-side block are applied here
+    // (wavefronts 0-3: A_kk - sum L_kj L_kj^T on the matrix cores; wavefronts 4-7: z_k - sum L_kj z_j), results stay in LDS
+    double* A = smem;
+    double* Ct = smem + T * LDM;
+    double* zpre = smem + 2 * T * LDM;
+    const int tid = threadIdx.x;
+    f64x4 acc[4] = {};
+    double zs = 0.0;
+    for (int q = pb; q < pe; ++q) {
+      const int j = pre_j[q];
+      __syncthreads();
+      if (tid < kThreads) stage_tile(A, tile_ptr(S, nt, k, j));
+      __syncthreads();
+      if (tid < kThreads) tile_abt_mfma(A, A, acc);
+      else {
+        const int r = (tid - kThreads) >> 2, part = tid & 3;
+        const double* z = rhs + (int64_t)j * T + part * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zs += A[r * LDM + part * 16 + c] * z[c];
       }
     }
+    if (tid < kThreads) {
+      const int lane = tid & 63, wv = tid >> 6;
+      const double* C = tile_ptr(S, nt, k, k);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rt + (lane >> 4) + 4 * r, col = 16 * wv + (lane & 15);
+          Ct[row * LDM + col] = C[row * T + col] - acc[rt][r];
+        }
+    } else {
+      const int r = (tid - kThreads) >> 2, part = tid & 3;
+      zs += __shfl_xor(zs, 1, 64);
+      zs += __shfl_xor(zs, 2, 64);
+      if (part == 0) zpre[r] = rhs[(int64_t)k * T + r] - zs;
+    }
     __syncthreads();
-    __threadfence();
-    potrf_tile(smem, S, nt, k, Linv_all, rhs, scal);
+    potrf_tile(smem, S, nt, k, Linv_all, rhs, scal, Ct, zpre);
     return;
   }
   if (threadIdx.x >= kThreads) return;
@@ -684,7 +580,7 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
                  p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k};
     if (npk > 0) {
       hipLaunchKernelGGL(k_update_potrf, dim3(sl * nup + nrh + npk), dim3(512), 0, s, S, nt, u, nrh, p.crit_upd[l], p.crit_rh[l], npk, sl,
-                         p.job_signal + p.upd_ptr[l] + p.rh_ptr[l], p.lvl_k + p.lvl_k_ptr[l + 1], p.k_need + p.lvl_k_ptr[l + 1], p.diag_done, Linv, rhs, scal);
+                         p.job_signal + p.upd_ptr[l] + p.rh_ptr[l], p.lvl_k + p.lvl_k_ptr[l + 1], p.k_need + p.lvl_k_ptr[l + 1], p.pre_ptr + p.lvl_k_ptr[l + 1], p.pre_j, p.diag_done, Linv, rhs, scal);
       tick(s, timers, CK_UPDATE);
     } else if (nup + nrh > 0) {
       hipLaunchKernelGGL(k_update, dim3(sl * nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs, sl);

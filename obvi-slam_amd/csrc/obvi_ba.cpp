@@ -92,7 +92,7 @@ struct obvi_ba_handle {
   int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj;
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
-  DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done;
+  DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done, d_pre_ptr, d_pre_j;
   DevBuf<int32_t> d_pose_row, d_obj_row;
   DevBuf<double> d_scal;
   DevBuf<double> d_eval_res, d_eval_sq;
@@ -229,7 +229,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
-  c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
+  c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.pre_ptr = h->d_pre_ptr.get(); c.pre_j = h->d_pre_j.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
 }
 
@@ -623,6 +623,9 @@ void prepare(obvi_ba_handle* h) {
   std::vector<uint8_t> upd_flag;
   const int kUpdChunk = 4;
   const int64_t env_slice_max = std::getenv("OBVI_SLICE_MAX") ? std::atoi(std::getenv("OBVI_SLICE_MAX")) : 512;   // tuning knob
+  // a potrf workgroup applies up to this many products of the previous level to its own diagonal tile (tuning knob)
+  const size_t pre_max = (size_t)std::max(0, env_int("OBVI_PRE_MAX", 2));
+  std::vector<std::vector<int32_t>> pre_of(nt);
   h->h_lvl_k_ptr.assign(nlev + 1, 0); h->h_trsm_ptr.assign(nlev + 1, 0); h->h_upd_ptr.assign(nlev + 1, 0); h->h_rh_ptr.assign(nlev + 1, 0); h->h_crit_upd.assign(nlev + 1, 0); h->h_crit_rh.assign(nlev + 1, 0); h->h_slices.assign(nlev + 1, 1);
   double flops = 0.0;
   const double t3 = (double)kTile * kTile * kTile;
@@ -654,6 +657,11 @@ void prepare(obvi_ba_handle* h) {
       while (e < trips.size() && trips[e].i == trips[q].i && trips[e].j == trips[q].j) ++e;
       const size_t len = e - q;
       const bool crit = trips[q].i == trips[q].j && level[trips[q].i] == l + 1;
+      if (crit && len <= pre_max && l + 1 != h->tail_level0) {   // applied by the column's potrf workgroup itself (also its right-hand-side block)
+        for (size_t t = q; t < e; ++t) pre_of[trips[q].i].push_back(trips[t].k);
+        q = e;
+        continue;
+      }
       const size_t chunk = crit ? 1 : (size_t)kUpdChunk;   // the next level waits for these: one product per job
       const uint8_t flag = len > chunk ? 1 : 0;
       for (size_t c0 = q; c0 < e; c0 += chunk) jobs.push_back({trips[q].i, trips[q].j, flag, c0, std::min(e, c0 + chunk), crit});
@@ -674,6 +682,7 @@ void prepare(obvi_ba_handle* h) {
     n_products += (int64_t)trips.size();
     std::sort(ik.begin(), ik.end());
     std::stable_sort(ik.begin(), ik.end(), [&](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return (level[x.first] == l + 1) > (level[y.first] == l + 1); });
+    ik.erase(std::remove_if(ik.begin(), ik.end(), [&](const std::pair<int32_t, int32_t>& x) { return level[x.first] == l + 1 && !pre_of[x.first].empty(); }), ik.end());
     for (size_t q = 0; q < ik.size(); ++q) {
       if (q == 0 || ik[q].first != ik[q - 1].first) {
         if (q != 0) rh_kptr.push_back((int32_t)rh_k.size());
@@ -722,6 +731,10 @@ void prepare(obvi_ba_handle* h) {
   {
     std::vector<int32_t> k_need(lvl_k.size());
     for (size_t x = 0; x < lvl_k.size(); ++x) k_need[x] = k_need_of[lvl_k[x]];
+    std::vector<int32_t> pre_ptr(lvl_k.size() + 1, 0), pre_j;
+    for (size_t x = 0; x < lvl_k.size(); ++x) { pre_j.insert(pre_j.end(), pre_of[lvl_k[x]].begin(), pre_of[lvl_k[x]].end()); pre_ptr[x + 1] = (int32_t)pre_j.size(); }
+    if (pre_j.empty()) pre_j.push_back(0);
+    h->d_pre_ptr.upload(pre_ptr, s); h->d_pre_j.upload(pre_j, s);
     h->d_job_signal.upload(job_signal, s); h->d_k_need.upload(k_need, s); h->d_diag_done.resize((size_t)nt + 1);
   }
   h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
