@@ -67,12 +67,13 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
 #endif
-constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * 16 + T;   // doubles
+constexpr int LWB = 16;   // doubles per 4x4 block of Wsh (padding it to 18 against bank conflicts measured slower)
+constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * LWB + T;   // doubles
 __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
   double* Lsh = smem;                  // L (lower), later L^-1
   double* Dsh = Lsh + T * LD;          // inverse of the 16 diagonal 4x4 blocks of L
   double* Wsh = Dsh + 16 * 16;         // row-block r of L^-1 during the inverse phase
-  double* zsh = Wsh + 16 * 16;
+  double* zsh = Wsh + 16 * LWB;
   double* tile = tile_ptr(S, nt, k, k);
   // wavefronts 0-3 factorise, wavefronts 4-7 build L^-1 concurrently (same (ty,tx) block map, same barriers)
   const bool fac = threadIdx.x < 256;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { w[i][j] = x[i][j]; Wsh[16 * tx + 4 * i + j] = x[i][j]; }
+        for (int j = 0; j < 4; ++j) { w[i][j] = x[i][j]; Wsh[LWB * tx + 4 * i + j] = x[i][j]; }
     }
     __syncthreads();
     OBVI_PH(ph2);
@@ -190,14 +191,14 @@ __device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[i][j] -= pr[i][0] * pc[j][0] + pr[i][1] * pc[j][1] + pr[i][2] * pc[j][2] + pr[i][3] * pc[j][3];
+        for (int j = 0; j < 4; ++j) a[i][j] = fma(-pr[i][3], pc[j][3], fma(-pr[i][2], pc[j][2], fma(-pr[i][1], pc[j][1], fma(-pr[i][0], pc[j][0], a[i][j]))));   // 4 dependent fma, not 5 operations
     } else if (!fac && ty > kb && tx <= kb) {
-      const double* Wr = Wsh + 16 * tx;
+      const double* Wr = Wsh + LWB * tx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const double l0 = Lsh[(4 * ty + i) * LD + 4 * kb], l1 = Lsh[(4 * ty + i) * LD + 4 * kb + 1], l2 = Lsh[(4 * ty + i) * LD + 4 * kb + 2], l3 = Lsh[(4 * ty + i) * LD + 4 * kb + 3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[i][j] -= l0 * Wr[j] + l1 * Wr[4 + j] + l2 * Wr[8 + j] + l3 * Wr[12 + j];
+        for (int j = 0; j < 4; ++j) w[i][j] = fma(-l3, Wr[12 + j], fma(-l2, Wr[8 + j], fma(-l1, Wr[4 + j], fma(-l0, Wr[j], w[i][j]))));
       }
     }
     OBVI_PH(ph3);

@@ -1,10 +1,16 @@
 // micro-benchmark + self-check of k_potrf (dev tool, not part of the product):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics scripts/potrf_bench.hip -o scripts/potrf_bench
-// phase clocks of workgroup 0 (thread 0): ticks at fixed points, per-phase sums over the 16 panel steps
-__device__ long long g_tick[8], g_ph[4];
-#define OBVI_TICK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tick[i] = clock64(); } while (0)
-#define OBVI_PH(var) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long now_ = clock64(); if (&var == &ph1) { if (kb == 0) { ph1 = ph2 = ph3 = 0; last_ = g_tick[1]; } } var += now_ - last_; last_ = now_; if (kb == 15 && &var == &ph3) { g_ph[0] = ph1; g_ph[1] = ph2; g_ph[2] = ph3; } } } while (0)
-static __device__ long long ph1, ph2, ph3, last_;
+// phase clocks of one probe thread of workgroup 0, kept in registers: per-phase sums over the 16 panel steps
+__device__ long long g_ph[4];
+__device__ int g_probe;
+enum { idx_ph1 = 0, idx_ph2 = 1, idx_ph3 = 2 };
+#define OBVI_TICK(i) OBVI_TICK_##i
+#define OBVI_TICK_0 long long acc_[3] = {0, 0, 0}, last_ = 0
+#define OBVI_TICK_1 last_ = clock64()
+#define OBVI_TICK_2 do { if ((int)threadIdx.x == g_probe && blockIdx.x == 0) { g_ph[0] = acc_[0]; g_ph[1] = acc_[1]; g_ph[2] = acc_[2]; } } while (0)
+#define OBVI_TICK_3
+#define OBVI_TICK_4
+#define OBVI_PH(var) do { const long long now_ = clock64(); acc_[idx_##var] += now_ - last_; last_ = now_; } while (0)
 #include "../obvi-slam_amd/csrc/chol_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -49,8 +55,15 @@ int main() {
     }
     for (int i = 0; i < T; ++i) { double s = 0; for (int q = 0; q < T; ++q) s += L[i * T + q] * z[k * T + q]; e_z = std::max(e_z, std::fabs(s - 1.0)); }
   }
-  { long long t[8], ph[4]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_tick), sizeof(t)); hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ph), sizeof(ph));
-    printf("clocks: load %lld  loop %lld (diag %lld  panel %lld  trailing %lld)  store %lld  barrier %lld\n", t[1] - t[0], t[2] - t[1], ph[0], ph[1], ph[2], t[3] - t[2], t[4] - t[3]); }
+  for (int probe : {0, 64, 128, 255, 256, 320, 384, 511}) {
+    long long ph[4];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &probe, sizeof(int));
+    hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_potrf, dim3(1), dim3(512), 0, 0, dS, nt, dk, dL, dr, dscal);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ph), sizeof(ph));
+    printf("thread %3d: to barrier 1 (diag) %lld   to barrier 2 (panel) %lld   trailing %lld   (cycles, sum over 16 steps)\n", probe, ph[0], ph[1], ph[2]);
+  }
   std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost);
   printf("chol_fail %g   max |L L^T - A|/64 %.2e   max |L W - I| %.2e   max |L z - b| %.2e\n", sc[SC_CHOL_FAIL], e_llt, e_inv, e_z);
   return 0;
