@@ -843,8 +843,14 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
         if (!rp.active[a]) continue;
         const int32_t vid = b.pose_vid[rp.pose[a]];
         if (vid < 0) continue;
-        const double* Z = pt.Z + z_off(a, l);
-        const double* y = rd.y + b.pose_row[vid];
+        // 16-byte loads: z_off() is even, and a pose's rows start at an even row of the tile grid
+        const double2* Z2 = reinterpret_cast<const double2*>(pt.Z + z_off(a, l));
+        const double2* y2 = reinterpret_cast<const double2*>(rd.y + b.pose_row[vid]);
+        double Z[18], y[6];
+#pragma unroll
+        for (int x = 0; x < 9; ++x) { const double2 v = Z2[x]; Z[2 * x] = v.x; Z[2 * x + 1] = v.y; }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { const double2 v = y2[x]; y[2 * x] = v.x; y[2 * x + 1] = v.y; }
 #pragma unroll
         for (int x = 0; x < 6; ++x) { t0 -= Z[3 * x] * y[x]; t1 -= Z[3 * x + 1] * y[x]; t2 -= Z[3 * x + 2] * y[x]; }
       }
