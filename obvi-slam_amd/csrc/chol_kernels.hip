@@ -58,189 +58,10 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// potrf of one 64x64 tile.  256 threads as a 16x16 grid, thread (ty,tx) owns the 4x4 block
-// (rows 4ty.., cols 4tx..) in registers.  Right-looking over 16 panels of 4 columns; then
-// L^-1 by a right-looking blocked forward substitution on the identity (same structure).
-// ---------------------------------------------------------------------------------------
 #ifndef OBVI_TICK
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
 #endif
-constexpr int LWB = 16;   // doubles per 4x4 block of Wsh (padding it to 18 against bank conflicts measured slower)
-constexpr int kPotrfLds = T * LD + 16 * 16 + 16 * LWB + T;   // doubles
-__device__ __forceinline__ void potrf_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
-  double* Lsh = smem;                  // L (lower), later L^-1
-  double* Dsh = Lsh + T * LD;          // inverse of the 16 diagonal 4x4 blocks of L
-  double* Wsh = Dsh + 16 * 16;         // row-block r of L^-1 during the inverse phase
-  double* zsh = Wsh + 16 * LWB;
-  double* tile = tile_ptr(S, nt, k, k);
-  // wavefronts 0-3 factorise, wavefronts 4-7 build L^-1 concurrently (same (ty,tx) block map, same barriers)
-  const bool fac = threadIdx.x < 256;
-  // the busy rows are the last ones for both halves: rotate the inverse half by two wavefronts so that the wavefront pairs
-  // sharing a SIMD (w, w + 4) do not both hold rows 12-15
-  const int tid = threadIdx.x & 255, ty = fac ? tid >> 4 : ((tid >> 4) + 8) & 15, tx = tid & 15;
-  OBVI_TICK(0);
-  double a[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[i][j] = pre_tile ? pre_tile[(4 * ty + i) * (T + 2) + 4 * tx + j] : tile[(4 * ty + i) * T + 4 * tx + j];
-  // pre_tile / pre_z: the tile and right-hand-side block already updated by the caller, in LDS (leading dimension T + 2) that
-  // this function's own buffers overlap
-  double zv = 0.0;
-  if (fac && tid < T) zv = pre_z ? pre_z[tid] : rhs[(int64_t)k * T + tid];
-  if (pre_tile) __syncthreads();
-  if (fac && tid < T) zsh[tid] = zv;
-  if (fac && ty < tx) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * tx + j] = 0.0;
-  }
-  double bad = 0.0;
-  // W = L^-1 is built in the same 16 steps by the threads that are idle in the factorisation (blocks left of the
-  // panel): row-block kb of W is finished in step kb, blocks below it receive  w -= L(ty,kb) W(kb,tx).
-  double w[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[i][j] = (ty == tx && i == j) ? 1.0 : 0.0;
-  __syncthreads();
-  OBVI_TICK(1);
-  for (int kb = 0; kb < 16; ++kb) {
-    if (fac && ty == kb && tx == kb) {
-      // 4x4 Cholesky in registers + its inverse; division-free: i = rsqrt(pivot), l = pivot * i
-      double p;
-      p = a[0][0]; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i00 = fast_rsqrt(p), l00 = p * i00;
-      const double l10 = a[1][0] * i00, l20 = a[2][0] * i00, l30 = a[3][0] * i00;
-      p = a[1][1] - l10 * l10; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i11 = fast_rsqrt(p), l11 = p * i11;
-      const double l21 = (a[2][1] - l20 * l10) * i11, l31 = (a[3][1] - l30 * l10) * i11;
-      p = a[2][2] - l20 * l20 - l21 * l21; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i22 = fast_rsqrt(p), l22 = p * i22;
-      const double l32 = (a[3][2] - l30 * l20 - l31 * l21) * i22;
-      p = a[3][3] - l30 * l30 - l31 * l31 - l32 * l32; if (!(p > 0.0)) { bad = 1.0; p = 1.0; }
-      const double i33 = fast_rsqrt(p), l33 = p * i33;
-      a[0][0] = l00; a[0][1] = 0; a[0][2] = 0; a[0][3] = 0;
-      a[1][0] = l10; a[1][1] = l11; a[1][2] = 0; a[1][3] = 0;
-      a[2][0] = l20; a[2][1] = l21; a[2][2] = l22; a[2][3] = 0;
-      a[3][0] = l30; a[3][1] = l31; a[3][2] = l32; a[3][3] = l33;
-      const double d10 = -l10 * i00 * i11, d21 = -l21 * i11 * i22, d32 = -l32 * i22 * i33;
-      const double d20 = -(l20 * i00 + l21 * d10) * i22, d31 = -(l31 * i11 + l32 * d21) * i33;
-      const double d30 = -(l30 * i00 + l31 * d10 + l32 * d20) * i33;
-      double* D = Dsh + 16 * kb;
-      D[0] = i00; D[1] = 0; D[2] = 0; D[3] = 0;
-      D[4] = d10; D[5] = i11; D[6] = 0; D[7] = 0;
-      D[8] = d20; D[9] = d21; D[10] = i22; D[11] = 0;
-      D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i33;
-    }
-    __syncthreads();
-    OBVI_PH(ph1);
-    if (fac && tx == kb && ty >= kb) {
-      if (ty > kb) {
-        // X = A_blk * D^T  (D = inverse of the diagonal block's L)
-        const double* D = Dsh + 16 * kb;
-        double x[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int t = 0; t <= j; ++t) s += a[i][t] * D[4 * j + t];
-            x[i][j] = s;
-          }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) a[i][j] = x[i][j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Lsh[(4 * ty + i) * LD + 4 * kb + j] = a[i][j];
-    }
-    if (!fac && ty == kb && tx <= kb) {
-      // row-block kb of W:  W(kb,tx) = D * acc
-      const double* D = Dsh + 16 * kb;
-      double x[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double s = 0.0;
-#pragma unroll
-          for (int t = 0; t <= i; ++t) s += D[4 * i + t] * w[t][j];
-          x[i][j] = s;
-        }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { w[i][j] = x[i][j]; Wsh[LWB * tx + 4 * i + j] = x[i][j]; }
-    }
-    __syncthreads();
-    OBVI_PH(ph2);
-    if (fac && tx > kb && ty >= tx) {
-      double pr[4][4], pc[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { pr[i][t] = Lsh[(4 * ty + i) * LD + 4 * kb + t]; pc[i][t] = Lsh[(4 * tx + i) * LD + 4 * kb + t]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[i][j] = fma(-pr[i][3], pc[j][3], fma(-pr[i][2], pc[j][2], fma(-pr[i][1], pc[j][1], fma(-pr[i][0], pc[j][0], a[i][j]))));   // 4 dependent fma, not 5 operations
-    } else if (!fac && ty > kb && tx <= kb) {
-      const double* Wr = Wsh + LWB * tx;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const double l0 = Lsh[(4 * ty + i) * LD + 4 * kb], l1 = Lsh[(4 * ty + i) * LD + 4 * kb + 1], l2 = Lsh[(4 * ty + i) * LD + 4 * kb + 2], l3 = Lsh[(4 * ty + i) * LD + 4 * kb + 3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[i][j] = fma(-l3, Wr[12 + j], fma(-l2, Wr[8 + j], fma(-l1, Wr[4 + j], fma(-l0, Wr[j], w[i][j]))));
-      }
-    }
-    OBVI_PH(ph3);
-  }
-  OBVI_TICK(2);
-  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
-  // store L (zeros above the diagonal)
-  if (fac) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tile[(4 * ty + i) * T + 4 * tx + j] = (ty >= tx) ? a[i][j] : 0.0;
-  }
-  OBVI_TICK(3);
-  __syncthreads();
-  OBVI_TICK(4);
-  double* Li = Linv_all + (int64_t)k * (T * T);
-  if (!fac) {   // the inverse wavefronts hold W
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double v = (ty >= tx) ? w[i][j] : 0.0;
-        Li[(4 * ty + i) * T + 4 * tx + j] = v;
-        Lsh[(4 * ty + i) * LD + 4 * tx + j] = v;
-      }
-  }
-  __syncthreads();
-  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
-    const int r = tid >> 2, part = tid & 3;
-    double s = 0.0;
-#pragma unroll
-    for (int c = 16 * part; c < 16 * part + 16; ++c) s += Lsh[r * LD + c] * zsh[c];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (part == 0) rhs[(int64_t)k * T + r] = s;
-  }
-}
-__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
-  __shared__ double smem[kPotrfLds];
-  potrf_tile(smem, S, nt, klist[blockIdx.x], Linv_all, rhs, scal);
-}
 
 // ---------------------------------------------------------------------------------------
 // 64x64x64 fp64 tile product  C += A * B^T  on the matrix cores: v_mfma_f64_16x16x4_f64.
@@ -294,6 +115,224 @@ __device__ __forceinline__ void stage_rows16(double* dst, const double* __restri
     const double2 v = reinterpret_cast<const double2*>(src)[e];
     dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// potrf of one 64x64 tile with the panel solve and the trailing updates on the matrix cores.
+// A right-looking panel of 4 columns is exactly the K of v_mfma_f64_16x16x4_f64, so per panel step kb:
+//   (a) one thread factorises the 4x4 diagonal block and inverts it (D)                         [scalar, the serial part]
+//   (b) X = P D^T for the 16-row tiles below (P = current panel columns): one MFMA per tile row;
+//       rows kb of W = L^-1:  W = D Acc (4 x 64), 4 fma per lane
+//   (c) trailing matrix  A -= X X^T  and  Acc -= X W:  one MFMA per 16x16 tile
+// The trailing matrices stay in registers in the MFMA accumulator layout (wavefront I owns tile row I; wavefronts 0-3 A,
+// wavefronts 4-7 the accumulator of L^-1); the 4 columns (rows) the next step needs are published to LDS at the end of (c)
+// in the operand layout (row-major [64][4]: a fragment is 64 consecutive doubles).  Rows / columns that are already finished
+// are masked out of the operands, so finished parts of the register tiles are never touched again.
+// Fragment layout: A: lane l -> A[l&15][l>>4]; B: lane l -> B[l>>4][l&15]; D: lane l, reg r -> D[(l>>4) + 4r][l&15].
+// Defined after the tile-product helpers (needs f64x4).
+// ---------------------------------------------------------------------------------------
+constexpr int kPotrfMfmaLds = T * LD + 5 * (T * 4) + 16 + T;   // doubles
+struct PotrfLds { double *Lsh, *Psh, *Xsh2, *W4, *AR, *Dsh; };
+// 4x4 Cholesky of the diagonal block kb and the inverse of its factor, one thread.  2x2 block pivots: for the pivot block
+// (p q; q r) the reciprocal square roots of p and of p r - q^2 are independent, so two columns cost one rsqrt latency:
+// l00 = p i0, l10 = q i0, 1/l11 = rsqrt(det) l00, l11 = det rsqrt(det) i0  (det has the same cancellation as r - l10^2).
+// A non-positive pivot is flagged and poisons the tile (NaN); the step is then rejected on the host.
+__device__ __forceinline__ void potrf_factor_diag(const PotrfLds& s, int kb, double& bad) {
+  const double* P = s.Psh + (4 * kb) * 4;
+  const double p = P[0], q = P[4], r = P[5];
+  const double det = fma(p, r, -(q * q));
+  const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
+  const double l00 = p * i0, l10 = q * i0, i1 = id * l00, l11 = det * id * i0;
+  const double l20 = P[8] * i0, l30 = P[12] * i0;
+  const double l21 = fma(-l20, l10, P[9]) * i1, l31 = fma(-l30, l10, P[13]) * i1;
+  const double p2 = fma(-l21, l21, fma(-l20, l20, P[10])), q2 = fma(-l31, l21, fma(-l30, l20, P[14])), r2 = fma(-l31, l31, fma(-l30, l30, P[15]));
+  const double det2 = fma(p2, r2, -(q2 * q2));
+  const double i2 = fast_rsqrt(p2), id2 = fast_rsqrt(det2);
+  const double l22 = p2 * i2, l32 = q2 * i2, i3 = id2 * l22, l33 = det2 * id2 * i2;
+  if (!(p > 0.0) || !(det > 0.0) || !(p2 > 0.0) || !(det2 > 0.0)) bad = 1.0;
+  const double d10 = -l10 * i0 * i1, d21 = -l21 * i1 * i2, d32 = -l32 * i2 * i3;
+  const double d20 = -(l20 * i0 + l21 * d10) * i2, d31 = -(l31 * i1 + l32 * d21) * i3;
+  const double d30 = -(l30 * i0 + l31 * d10 + l32 * d20) * i3;
+  double* D = s.Dsh;   // the strict upper part of Dsh and of L stays zero from the start
+  D[0] = i0; D[4] = d10; D[5] = i1; D[8] = d20; D[9] = d21; D[10] = i2; D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i3;
+  double* L = s.Lsh + (4 * kb) * LD + 4 * kb;
+  L[0] = l00; L[LD] = l10; L[LD + 1] = l11; L[2 * LD] = l20; L[2 * LD + 1] = l21; L[2 * LD + 2] = l22;
+  L[3 * LD] = l30; L[3 * LD + 1] = l31; L[3 * LD + 2] = l32; L[3 * LD + 3] = l33;
+}
+// the panel loop of one wavefront: tile row I of A (FAC) or of the accumulator of L^-1
+template <bool FAC>
+__device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, f64x4 (&acc)[4], double& bad) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+  OBVI_TICK(0);
+  OBVI_TICK(1);
+#pragma unroll 1
+  for (int Ik = 0; Ik < 4; ++Ik) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int kb = 4 * Ik + m, done = 4 * kb + 3;   // rows / columns <= done are finished after this panel
+      double* Xsh = s.Xsh2 + (kb & 1) * (T * 4);
+      const bool live = I > Ik || (I == Ik && m < 3);   // the tile row still has rows below the diagonal block
+      // (b) the panel below the diagonal block / rows kb of W
+      if (FAC) {
+        if (live) {
+          const double av = s.Psh[(16 * I + c) * 4 + q];
+          const double bv = c < 4 ? s.Dsh[c * 4 + q] : 0.0;   // B[k][n] = D[n][k]
+          f64x4 x = {};
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+          if (c < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * I + q + 4 * r;
+              if (row > done) { Xsh[row * 4 + c] = x[r]; s.Lsh[row * LD + 4 * kb + c] = x[r]; }
+            }
+          }
+        }
+      } else if (I == Ik) {
+        const double d0 = s.Dsh[q * 4], d1 = s.Dsh[q * 4 + 1], d2 = s.Dsh[q * 4 + 2], d3 = s.Dsh[q * 4 + 3];
+#pragma unroll
+        for (int J = 0; J < 4; ++J) if (J <= I) {
+          const double* a4 = s.AR + (16 * J + c) * 4;
+          const double w = fma(d3, a4[3], fma(d2, a4[2], fma(d1, a4[1], d0 * a4[0])));
+          s.W4[(16 * J + c) * 4 + q] = w;
+          acc[J][m] = w;
+        }
+      }
+      __syncthreads();
+      OBVI_PH(ph1);
+      // (c) trailing updates, then the next panel's columns / rows are published
+      if (live) {
+        const double xa = Xsh[(16 * I + c) * 4 + q];
+        const double an = (16 * I + c > done) ? -xa : 0.0;
+#pragma unroll
+        for (int J = 0; J < 4; ++J) if (J <= I) {
+          if (FAC) {
+            if (J > Ik || (J == Ik && m < 3)) {
+              const double xb = J == I ? xa : Xsh[(16 * J + c) * 4 + q];
+              const double bv = (16 * J + c > done) ? xb : 0.0;
+              acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bv, acc[J], 0, 0, 0);
+            }
+          } else if (J <= Ik) {
+            const double bv = s.W4[(16 * J + c) * 4 + q];
+            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bv, acc[J], 0, 0, 0);
+          }
+        }
+      }
+      OBVI_PH(ph2);
+      if (kb + 1 < 16) {
+        const int Jn = m == 3 ? Ik + 1 : Ik;
+        const int mn = (m + 1) & 3;
+        if (FAC) {
+          if (I >= Jn && (c >> 2) == mn) {
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+              if (J == Jn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s.Psh[(16 * I + q + 4 * r) * 4 + (c & 3)] = acc[J][r];
+              }
+          }
+          if (I == Jn) {   // this wavefront wrote the new diagonal block: no barrier needed before it is factorised
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) potrf_factor_diag(s, kb + 1, bad);
+          }
+        } else if (I == Jn) {
+#pragma unroll
+          for (int J = 0; J < 4; ++J) if (J <= I) s.AR[(16 * J + c) * 4 + q] = acc[J][mn];
+        }
+      }
+      __syncthreads();
+      OBVI_PH(ph3);
+    }
+  }
+  OBVI_TICK(2);
+}
+template <bool FAC>
+__device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile, const double* pre_z) {
+  PotrfLds s;
+  s.Lsh = smem;                 // L, row-major (LD); at the end L^-1 for the right-hand side
+  s.Psh = s.Lsh + T * LD;       // [64][4] current values of the panel columns, all rows
+  s.Xsh2 = s.Psh + T * 4;       // 2 x [64][4] the solved panel, alternating: the next diagonal block is factorised while other
+                                //   wavefronts still read this panel
+  s.W4 = s.Xsh2 + 2 * T * 4;    // [64][4] W4[c][t] = row 4kb+t of W, column c
+  s.AR = s.W4 + T * 4;          // [64][4] AR[c][t] = row 4kb+t of the accumulator of W, column c
+  s.Dsh = s.AR + T * 4;         // 4x4 inverse of L_kk
+  double* zsh = s.Dsh + 16;
+  double* tile = tile_ptr(S, nt, k, k);
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr bool fac = FAC;
+  const int q = lane >> 4, c = lane & 15;
+  f64x4 acc[4];
+#pragma unroll
+  for (int J = 0; J < 4; ++J)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + q + 4 * r, col = 16 * J + c;
+      double v = 0.0;
+      if (fac) {
+        if (J <= I) {
+          const int rr = (J == I && col > row) ? col : row, cc = (J == I && col > row) ? row : col;   // diagonal tiles are kept symmetric
+          v = pre_tile ? pre_tile[rr * (T + 2) + cc] : tile[rr * T + cc];
+        }
+      } else v = row == col ? 1.0 : 0.0;
+      acc[J][r] = v;
+    }
+  double zv = 0.0;
+  if (tid < T) zv = pre_z ? pre_z[tid] : rhs[(int64_t)k * T + tid];
+  if (pre_tile) __syncthreads();
+  if (tid < T) zsh[tid] = zv;
+  for (int e = tid; e < T * LD; e += 512) s.Lsh[e] = 0.0;
+  for (int e = tid; e < T * 4; e += 512) { s.W4[e] = 0.0; s.AR[e] = 0.0; }
+  if (tid < 16) s.Dsh[tid] = 0.0;
+  __syncthreads();
+  if (fac && c < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s.Psh[(16 * I + q + 4 * r) * 4 + c] = acc[0][r];
+  }
+  if (!fac && I == 0) s.AR[c * 4 + q] = acc[0][0];
+  double bad = 0.0;
+  __syncthreads();
+  if (tid == 0) potrf_factor_diag(s, 0, bad);
+  __syncthreads();
+  potrf_mfma_wave<FAC>(s, I, acc, bad);
+  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  for (int e = tid; e < T * T; e += 512) tile[e] = s.Lsh[(e >> 6) * LD + (e & 63)];
+  __syncthreads();
+  double* Li = Linv_all + (int64_t)k * (T * T);
+  if (!fac) {
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + q + 4 * r, col = 16 * J + c;
+        const double v = (col <= row) ? acc[J][r] : 0.0;
+        Li[row * T + col] = v;
+        s.Lsh[row * LD + col] = v;
+      }
+  }
+  __syncthreads();
+  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
+    const int r = tid >> 2, part = tid & 3;
+    double sum = 0.0;
+#pragma unroll
+    for (int cc = 16 * part; cc < 16 * part + 16; ++cc) sum += s.Lsh[r * LD + cc] * zsh[cc];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (part == 0) rhs[(int64_t)k * T + r] = sum;
+  }
+}
+
+__device__ __forceinline__ void potrf_mfma_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
+  // wavefronts 0-3: tile rows 0-3 of A; wavefronts 4-7: tile rows 3-0 of the accumulator of L^-1 (the heavy rows of the two
+  // halves do not share a SIMD).  Two instruction streams (A / accumulator), tile row wave-uniform; both execute the same barriers.
+  const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wvi < 4) potrf_mfma_rows<true>(wvi, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
+  else potrf_mfma_rows<false>(7 - wvi, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
+}
+
+__global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {
+  __shared__ double smem[kPotrfMfmaLds];
+  potrf_mfma_tile(smem, S, nt, klist[blockIdx.x], Linv_all, rhs, scal);
 }
 
 __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int32_t* __restrict__ jobs, const double* __restrict__ Linv_all, int slices) {
@@ -418,7 +457,7 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
                                                      const int32_t* __restrict__ k_need, const int32_t* __restrict__ pre_ptr, const int32_t* __restrict__ pre_j,
                                                      int32_t* done, double* Linv_all, double* rhs, double* scal) {
   __shared__ double smem[2 * T * LDM + T];
-  static_assert(kPotrfLds <= 2 * T * LDM, "potrf fits the update buffers");
+  static_assert(kPotrfMfmaLds <= 2 * T * LDM, "potrf fits the update buffers");
   const int b = blockIdx.x, n_crit = slices * n_crit_upd + n_crit_rh;
   if (b >= n_crit && b < n_crit + n_potrf) {
     const int k = klist[b - n_crit], need = k_need[b - n_crit];
@@ -434,7 +473,7 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
       __threadfence();
     }
     const int pb = pre_ptr[b - n_crit], pe = pre_ptr[b - n_crit + 1];
-    if (pe == pb) { potrf_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
+    if (pe == pb) { potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
     // the few products of the previous level that finish this column's diagonal tile and right-hand-side block are applied here
     // (wavefronts 0-3: A_kk - sum L_kj L_kj^T on the matrix cores; wavefronts 4-7: z_k - sum L_kj z_j), results stay in LDS
     double* A = smem;
@@ -473,7 +512,7 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
       if (part == 0) zpre[r] = rhs[(int64_t)k * T + r] - zs;
     }
     __syncthreads();
-    potrf_tile(smem, S, nt, k, Linv_all, rhs, scal, Ct, zpre);
+    potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal, Ct, zpre);
     return;
   }
   if (threadIdx.x >= kThreads) return;

@@ -62,7 +62,7 @@ int main() {
     hipLaunchKernelGGL(k_potrf, dim3(1), dim3(512), 0, 0, dS, nt, dk, dL, dr, dscal);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ph), sizeof(ph));
-    printf("thread %3d: to barrier 1 (diag) %lld   to barrier 2 (panel) %lld   trailing %lld   (cycles, sum over 16 steps)\n", probe, ph[0], ph[1], ph[2]);
+    printf("thread %3d: phase 1 %lld   phase 2 %lld   phase 3 %lld   (cycles, sum over 16 steps: panel + barrier / trailing / publish + diagonal block + barrier)\n", probe, ph[0], ph[1], ph[2]);
   }
   std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost);
   printf("chol_fail %g   max |L L^T - A|/64 %.2e   max |L W - I| %.2e   max |L z - b| %.2e\n", sc[SC_CHOL_FAIL], e_llt, e_inv, e_z);
