@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
 #define OBVI_TICK(i)
 #define OBVI_PH(var)
 #endif
+#ifndef OBVI_MARK
+#define OBVI_MARK(i)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // 64x64x64 fp64 tile product  C += A * B^T  on the matrix cores: v_mfma_f64_16x16x4_f64.
@@ -250,7 +253,7 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
 template <bool FAC>
 __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile, const double* pre_z) {
   PotrfLds s;
-  s.Lsh = smem;                 // L, row-major (LD); at the end L^-1 for the right-hand side
+  s.Lsh = smem;                 // L, row-major (LD)
   s.Psh = s.Lsh + T * LD;       // [64][4] current values of the panel columns, all rows
   s.Xsh2 = s.Psh + T * 4;       // 2 x [64][4] the solved panel, alternating: the next diagonal block is factorised while other
                                 //   wavefronts still read this panel
@@ -261,6 +264,7 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   double* tile = tile_ptr(S, nt, k, k);
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr bool fac = FAC;
+  OBVI_MARK(0);
   const int q = lane >> 4, c = lane & 15;
   f64x4 acc[4];
 #pragma unroll
@@ -284,42 +288,47 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   for (int e = tid; e < T * LD; e += 512) s.Lsh[e] = 0.0;
   for (int e = tid; e < T * 4; e += 512) { s.W4[e] = 0.0; s.AR[e] = 0.0; }
   if (tid < 16) s.Dsh[tid] = 0.0;
-  __syncthreads();
   if (fac && c < 4) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s.Psh[(16 * I + q + 4 * r) * 4 + c] = acc[0][r];
   }
-  if (!fac && I == 0) s.AR[c * 4 + q] = acc[0][0];
   double bad = 0.0;
   __syncthreads();
   if (tid == 0) potrf_factor_diag(s, 0, bad);
+  if (!fac && I == 0) s.AR[c * 4 + q] = acc[0][0];
   __syncthreads();
+  OBVI_MARK(1);
   potrf_mfma_wave<FAC>(s, I, acc, bad);
+  OBVI_MARK(2);
   if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
-  for (int e = tid; e < T * T; e += 512) tile[e] = s.Lsh[(e >> 6) * LD + (e & 63)];
-  __syncthreads();
-  double* Li = Linv_all + (int64_t)k * (T * T);
-  if (!fac) {
+  OBVI_MARK(3);
+  if (fac) {   // L: coalesced from LDS (the strict upper part was never written: zeros from the start)
+    for (int e = tid; e < T * T; e += 256) tile[e] = s.Lsh[(e >> 6) * LD + (e & 63)];
+  } else {
+    // L^-1 from the accumulator registers, and z_k = L^-1 b_k without staging L^-1: every lane multiplies its elements with
+    // b and the 16 lanes that share a row add up
+    double* Li = Linv_all + (int64_t)k * (T * T);
+    double zp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int J = 0; J < 4; ++J)
+    for (int J = 0; J < 4; ++J) {
+      const double bz = zsh[16 * J + c];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * I + q + 4 * r, col = 16 * J + c;
         const double v = (col <= row) ? acc[J][r] : 0.0;
         Li[row * T + col] = v;
-        s.Lsh[row * LD + col] = v;
+        zp[r] = fma(v, bz, zp[r]);
       }
-  }
-  __syncthreads();
-  if (fac) {   // z_k = L^-1 b_k : 4 threads per row, 16 columns each
-    const int r = tid >> 2, part = tid & 3;
-    double sum = 0.0;
+    }
 #pragma unroll
-    for (int cc = 16 * part; cc < 16 * part + 16; ++cc) sum += s.Lsh[r * LD + cc] * zsh[cc];
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    if (part == 0) rhs[(int64_t)k * T + r] = sum;
+    for (int r = 0; r < 4; ++r) {
+      double v = zp[r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (c == 0) rhs[(int64_t)k * T + 16 * I + q + 4 * r] = v;
+    }
   }
+  OBVI_MARK(4);
+  OBVI_MARK(5);
 }
 
 __device__ __forceinline__ void potrf_mfma_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
