@@ -42,6 +42,7 @@ struct ReprojDev {          // observations sorted by (point, pose): CSC by poin
   const double2* pixel;     // [n]
   const double* sigma;      // [n]
   const uint8_t* active;    // [n]
+  const int32_t* yrow;      // [n] first row of the observing pose in the reduced system, -1 if the observation is inactive or the pose constant
   const uint32_t* point_ptr;  // [L+1] offsets into the arrays above
   double huber;
 };

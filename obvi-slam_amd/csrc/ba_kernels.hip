@@ -840,12 +840,11 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
       double t0 = pt.u[3 * l], t1 = pt.u[3 * l + 1], t2 = pt.u[3 * l + 2];
       const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
       for (uint32_t a = beg; a < end; ++a) {
-        if (!rp.active[a]) continue;
-        const int32_t vid = b.pose_vid[rp.pose[a]];
-        if (vid < 0) continue;
+        const int32_t yr = rp.yrow[a];   // one lookup instead of active -> pose -> variable id -> row
+        if (yr < 0) continue;
         // 16-byte loads: z_off() is even, and a pose's rows start at an even row of the tile grid
         const double2* Z2 = reinterpret_cast<const double2*>(pt.Z + z_off(a, l));
-        const double2* y2 = reinterpret_cast<const double2*>(rd.y + b.pose_row[vid]);
+        const double2* y2 = reinterpret_cast<const double2*>(rd.y + yr);
         double Z[18], y[6];
 #pragma unroll
         for (int x = 0; x < 9; ++x) { const double2 v = Z2[x]; Z[2 * x] = v.x; Z[2 * x + 1] = v.y; }

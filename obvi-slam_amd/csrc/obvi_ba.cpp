@@ -49,6 +49,7 @@ struct obvi_ba_handle {
   int64_t n_rp = 0;
   std::vector<uint32_t> h_rp_pose, h_rp_point, h_rp_perm, h_rp_inv, h_point_ptr;
   std::vector<uint8_t> h_rp_active;  // sorted order
+  std::vector<int32_t> h_rp_yrow;
   std::vector<uint32_t> h_rq_src;    // CSR-by-pose copy: position -> index into the CSC-by-point arrays
   double rp_huber = 1.0;
   int64_t n_bb = 0, n_sp = 0, n_lt = 0, n_rl = 0;
@@ -73,6 +74,7 @@ struct obvi_ba_handle {
   DevBuf<double2> d_rp_pixel;
   DevBuf<double> d_rp_sigma;
   DevBuf<uint8_t> d_rp_active;
+  DevBuf<int32_t> d_rp_yrow;             // per observation: row of its pose in the reduced system (prepare())
   DevBuf<uint32_t> d_rq_point, d_rq_pose_ptr;
   DevBuf<uint16_t> d_rq_cam;
   DevBuf<double2> d_rq_pixel;
@@ -188,7 +190,7 @@ ReprojDev reproj_dev(const obvi_ba_handle* h) {
   ReprojDev r;
   r.n = h->n_rp; r.pose = h->d_rp_pose.get(); r.point = h->d_rp_point.get(); r.cam = h->d_rp_cam.get();
   r.pixel = h->d_rp_pixel.get(); r.sigma = h->d_rp_sigma.get(); r.active = h->d_rp_active.get();
-  r.point_ptr = h->d_point_ptr.get(); r.huber = h->rp_huber;
+  r.point_ptr = h->d_point_ptr.get(); r.huber = h->rp_huber; r.yrow = h->d_rp_yrow.get();
   return r;
 }
 ReprojPoseDev reproj_pose_dev(const obvi_ba_handle* h) {
@@ -367,7 +369,12 @@ void prepare(obvi_ba_handle* h) {
       for (int64_t o : objs) { obj_vid[o] = next_obj; h->h_obj_row[next_obj++] = (int32_t)row; row += 7; }
       if (row > start) used.push_back({start, row});
     };
-    for (size_t n = 0; n < nodes.size(); ++n) place_node(nodes[n].p0, nodes[n].p1, node_objs[n]);
+    for (size_t n = 0; n < nodes.size(); ++n) {
+      const int64_t r0 = row;
+      place_node(nodes[n].p0, nodes[n].p1, node_objs[n]);
+      if (std::getenv("OBVI_DEBUG_PLAN")) std::fprintf(stderr, "node %zu: frames [%d,%d) of subtree [%d,%d) %s objects %zu rows %lld tiles %lld\n", n, nodes[n].p0, nodes[n].p1, nodes[n].lo, nodes[n].hi,
+                                                       nodes[n].left < 0 ? "leaf" : "separator", node_objs[n].size(), (long long)(row - ((r0 + kTile - 1) / kTile) * kTile), (long long)((row + kTile - 1) / kTile - (r0 + kTile - 1) / kTile));
+    }
     place_node(0, 0, node_objs[nodes.size()]);
     h->tail_t0 = -1;
     h->h_shared_ov.clear();
@@ -384,6 +391,15 @@ void prepare(obvi_ba_handle* h) {
     h->nt = (int32_t)std::max<int64_t>(1, (h->m + kTile - 1) / kTile);
     h->h_is_pad.assign((size_t)h->nt * kTile, 1);
     for (const auto& u : used) for (int64_t r = u.first; r < u.second; ++r) h->h_is_pad[r] = 0;
+  }
+  {   // the back-substitution reads the pose step of an observation through one index instead of pose -> variable id -> row
+    std::vector<int32_t>& yrow = h->h_rp_yrow;   // member: stays alive until the copy has been issued and synchronised
+    yrow.resize((size_t)h->n_rp);
+    for (int64_t a = 0; a < h->n_rp; ++a) {
+      const int32_t v = h->h_rp_active[a] ? pose_vid[h->h_rp_pose[a]] : -1;
+      yrow[a] = v >= 0 ? h->h_pose_row[v] : -1;
+    }
+    h->d_rp_yrow.upload(yrow, h->stream);
   }
   h->m_canon = 6 * nPv + 7 * h->nOv;
   h->h_canon_row.resize(h->m_canon);
