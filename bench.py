@@ -120,18 +120,21 @@ def main():
 
     if args.warmup > 0:
         ba.solve(solver_params(obvi_ba, args.warmup))
-    k0 = ba.kernel_times()
     barrier()
     t0 = time.perf_counter()
     summ = ba.solve(solver_params(obvi_ba, args.steps))
     barrier()
     dt = time.perf_counter() - t0
-    k1 = ba.kernel_times()
     steps_done = summ.num_iterations - 1
     dt, steps_done = dist_util.reduce_timing(dist, "cuda", dt, steps_done)
 
-    # Per-kernel durations: a second solve of the same K steps with an event after every launch of the tile
-    # Cholesky (profiling level 2 costs a few percent, so it is kept out of the timed region above).
+    # Device timings come from two more solves of the same K steps, outside the timed region (the timed solve records no
+    # events at all): level 1 = one HIP event pair per phase of an LM step, same schedule as the timed solve (side stream on);
+    # level 2 = additionally an event after every launch of the tile Cholesky (single stream, costs a few percent).
+    ba.set_profiling(1)
+    k0 = ba.kernel_times()
+    ba.solve(solver_params(obvi_ba, args.steps))
+    k1 = ba.kernel_times()
     ba.set_profiling(2)
     p0 = ba.kernel_times()
     ba.solve(solver_params(obvi_ba, args.steps))

@@ -247,9 +247,10 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
  * [9] update tile jobs [10] flops of one tile-Cholesky factorisation [11] active reprojection obs
  * [12] active bbox obs [13] levels of the tile elimination tree.  Returns the number of entries written. */
 int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap);
-/* level 0/1: one HIP event pair per phase of an LM step (always on, negligible cost); level 2: additionally an event
- * after every launch of the tile Cholesky so that obvi_ba_get_kernel_times also lists k_potrf / k_trsm /
- * k_update_potrf / k_backward (costs a few percent: use a separate, un-timed solve). */
+/* level 0 (default): no events; level 1: one HIP event pair per phase of an LM step (about 40 us of host and device time per
+ * iteration: a dozen records and as many elapsed-time queries); level 2: additionally an event after every launch of the
+ * tile Cholesky so that obvi_ba_get_kernel_times also lists k_potrf / k_trsm / k_update_potrf / k_backward, everything on
+ * one stream (costs a few percent: use a separate, un-timed solve). */
 int obvi_ba_set_profiling(obvi_ba_handle* h, int32_t level);
 /* per-kernel device timings of the last solve (ms, HIP events on the handle's stream):
  * names is a NUL-separated list; returns number of entries. */

@@ -790,10 +790,11 @@ StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
   return c;
 }
 void record(obvi_ba_handle* h, int idx, hipStream_t on = nullptr) {
+  if (h->profiling < 1) return;
   OBVI_HIP(hipEventRecord(h->ev[idx], on ? on : h->stream));
   if (idx < PH_COUNT) h->phase_on_side[idx] = on != nullptr && on != h->stream;
 }
-void record_end(obvi_ba_handle* h, int idx, hipStream_t on) { OBVI_HIP(hipEventRecord(h->ev_end[idx], on)); }
+void record_end(obvi_ba_handle* h, int idx, hipStream_t on) { if (h->profiling >= 1) OBVI_HIP(hipEventRecord(h->ev_end[idx], on)); }
 
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
@@ -883,7 +884,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   }
   OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   sync(h);
-  for (int p = 0; p < PH_COUNT; ++p) {
+  for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
     if (h->phase_on_side[p]) { OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev_end[p])); }
     else {

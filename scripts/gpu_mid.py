@@ -14,6 +14,7 @@ if 6*P+7*O < 3000:
     print("S", So.shape, Sg.shape, "err", rel_err(Sg, So), "rhs err", rel_err(bg, bo))
 prm = helpers.ba_params(max_it=iters, ftol=0, ptol=0, gtol=0)
 t = time.time(); so = o.solve(prm); t1 = time.time() - t
+g.set_profiling(1)
 t = time.time(); sg = g.solve(prm); t2 = time.time() - t
 print("oracle", so.termination_type, so.message, so.num_iterations, so.initial_cost, so.final_cost, "%.3fs" % t1)
 print("gpu   ", sg.termination_type, sg.message, sg.num_iterations, sg.initial_cost, sg.final_cost, "%.3fs" % t2)
