@@ -315,17 +315,25 @@ void prepare(obvi_ba_handle* h) {
     struct Node { int32_t lo, hi, p0, p1, left, right; };
     std::vector<Node> nodes;
     const int32_t G = std::getenv("OBVI_ND_G") ? std::atoi(std::getenv("OBVI_ND_G")) : 4;   // cut granularity in poses (tuning knob)
-    const int32_t kLeaf = std::getenv("OBVI_ND_LEAF") ? std::atoi(std::getenv("OBVI_ND_LEAF")) : 96;   // tuning knob (poses per leaf)
+    const int32_t kLeaf = std::getenv("OBVI_ND_LEAF") ? std::atoi(std::getenv("OBVI_ND_LEAF")) : 64;   // tuning knob (poses per leaf)
+    const bool balance = !std::getenv("OBVI_ND_BALANCE") || std::atoi(std::getenv("OBVI_ND_BALANCE")) != 0;   // tuning knob
+    const double sep_frac = std::getenv("OBVI_ND_SEPFRAC") ? std::atof(std::getenv("OBVI_ND_SEPFRAC")) : 0.5;   // tuning knob: a range is cut only if the separator is at most this part of it
     std::function<int32_t(int32_t, int32_t)> build = [&](int32_t lo, int32_t hi) -> int32_t {
       auto leaf = [&]() { nodes.push_back({lo, hi, lo, hi, -1, -1}); return (int32_t)nodes.size() - 1; };
       if (hi - lo <= kLeaf) return leaf();
-      int32_t s0 = ((lo + hi) / 2 / G) * G;
-      if (s0 <= lo) s0 = lo + G;
-      int32_t far = s0 - 1;
-      for (int32_t f = lo; f < s0; ++f) far = std::max(far, reach[f]);
-      int32_t s1 = std::min<int32_t>(hi, ((far + 1 + G - 1) / G) * G);
-      if (s1 <= s0) s1 = std::min<int32_t>(hi, s0 + G);
-      if (s1 - s0 > (hi - lo) / 2 || s1 >= hi) return leaf();
+      // the separator [s0, s1) is placed so that the two sides are equally long (the longer side sets the depth of the
+      // elimination tree): first cut in the middle to learn the separator's width, then shift the cut left by half of it
+      int32_t s0 = 0, s1 = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int32_t width = pass == 0 ? 0 : s1 - s0;
+        s0 = ((lo + hi - (balance ? width : 0)) / 2 / G) * G;
+        if (s0 <= lo) s0 = lo + G;
+        int32_t far = s0 - 1;
+        for (int32_t f = lo; f < s0; ++f) far = std::max(far, reach[f]);
+        s1 = std::min<int32_t>(hi, ((far + 1 + G - 1) / G) * G);
+        if (s1 <= s0) s1 = std::min<int32_t>(hi, s0 + G);
+      }
+      if ((double)(s1 - s0) > sep_frac * (double)(hi - lo) || s1 >= hi) return leaf();
       const int32_t l = build(lo, s0), r = build(s1, hi);
       nodes.push_back({lo, hi, s0, s1, l, r});
       return (int32_t)nodes.size() - 1;
