@@ -65,6 +65,8 @@ struct obvi_ba_handle {
   DevBuf<double> d_pose_s, d_point_s, d_obj_s;     // snapshot
   bool have_snapshot = false;
   DevBuf<PoseCache> d_pc, d_pc_c;
+  bool pc_valid = false;                 // d_pc belongs to the poses in d_pose (an accepted step hands the candidate's cache over)
+  bool tiles_cleared = false;            // the tiles and step accumulators were already cleared behind the previous LM step
   DevBuf<int32_t> d_pose_vid, d_obj_vid;
   DevBuf<uint8_t> d_point_var;
   // ---- device: factors ----
@@ -784,7 +786,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
   h->d_pc.resize((size_t)P + 1); h->d_pc_c.resize((size_t)P + 1);
   sync(h);  // host vectors above go out of scope
-  h->dirty = false;
+  h->dirty = false; h->pc_valid = false; h->tiles_cleared = false;
 }
 
 StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
@@ -816,8 +818,10 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   double* scal = h->d_scal.get();
   const double fixed = h->h_scal[SC_COST_FIXED];
   record(h, PH_POSE_CACHE);
-  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
+  if (!h->pc_valid) launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  h->pc_valid = true;
+  if (!h->tiles_cleared) launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
+  h->tiles_cleared = false;
   const bool exchange = h->allreduce != nullptr && !h->h_shared_ov.empty();
   // Fork: the pose-side pass, the small factor families and the diagonal blocks do not depend on the point pass or the
   // Schur complement (everything they share is accumulated with atomics), so they run beside them on the side stream.
@@ -891,6 +895,9 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
       throw HipError{hipErrorUnknown, "allreduce hook (scalars)", __FILE__, __LINE__};
   }
   OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+  // the clear of the next LM step does not depend on the accept / reject decision: it runs while the host takes it
+  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
+  h->tiles_cleared = true;
   sync(h);
   for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
@@ -922,6 +929,7 @@ void copy_current(obvi_ba_handle* h, DevBuf<double>& dp, DevBuf<double>& dl, Dev
 void restore_from(obvi_ba_handle* h, const DevBuf<double>& dp, const DevBuf<double>& dl, const DevBuf<double>& dobj) {
   hipStream_t s = h->stream;
   launch_copy3(s, h->d_pose.get(), dp.get(), 6 * h->P, h->d_point.get(), dl.get(), 3 * h->L, h->d_obj.get(), dobj.get(), 7 * h->O);
+  h->pc_valid = false;
 }
 
 bool check_ready(obvi_ba_handle* h) {
@@ -1356,6 +1364,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   std::memset(sum, 0, sizeof(*sum));
   h->iterations.clear();
   prepare(h);
+  h->pc_valid = false; h->tiles_cleared = false;
   const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
                          h->phase_ms[PH_SCHUR] + h->phase_ms[PH_SCHUR_BLOCKS] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
   hipStream_t s = h->stream;
@@ -1487,7 +1496,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     }
     if (it.relative_decrease > kMinRelDecrease) {
       // HandleSuccessfulStep: the candidate becomes the current point
-      h->d_pose.swap(h->d_pose_c); h->d_point.swap(h->d_point_c); h->d_obj.swap(h->d_obj_c);
+      h->d_pose.swap(h->d_pose_c); h->d_point.swap(h->d_point_c); h->d_obj.swap(h->d_obj_c); h->d_pc.swap(h->d_pc_c);   // the candidate's pose cache comes along
       it.step_is_successful = 1;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));  // StepAccepted
       radius = std::min(max_radius, radius);
