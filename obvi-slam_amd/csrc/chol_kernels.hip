@@ -124,24 +124,26 @@ __device__ __forceinline__ void stage_rows16(double* dst, const double* __restri
 // potrf of one 64x64 tile with the panel solve and the trailing updates on the matrix cores.
 // A right-looking panel of 4 columns is exactly the K of v_mfma_f64_16x16x4_f64, so per panel step kb:
 //   (a) one thread factorises the 4x4 diagonal block and inverts it (D)                         [scalar, the serial part]
-//   (b) X = P D^T for the 16-row tiles below (P = current panel columns): one MFMA per tile row;
-//       rows kb of W = L^-1:  W = D Acc (4 x 64), 4 fma per lane
-//   (c) trailing matrix  A -= X X^T  and  Acc -= X W:  one MFMA per 16x16 tile
+//   (b) the solved panel X = P D^T (P = current panel columns) is never stored as a matrix: a wavefront that needs the rows of
+//       tile row J as an MFMA operand computes X_J^T = D P_J^T with one MFMA whose first result register IS that operand
+//       (lane (k, n) holds X[16 J + n][k], the A and B fragment layout alike), so nothing goes through LDS in between
+//   (c) trailing matrix  A -= X X^T  and  Acc -= X W  (W rows = D Acc rows, four fma per lane, again directly in B fragment
+//       layout):  one MFMA per 16x16 tile, finished rows / columns masked out of the operands
 // The trailing matrices stay in registers in the MFMA accumulator layout (wavefront I owns tile row I; wavefronts 0-3 A,
-// wavefronts 4-7 the accumulator of L^-1); the 4 columns (rows) the next step needs are published to LDS at the end of (c)
-// in the operand layout (row-major [64][4]: a fragment is 64 consecutive doubles).  Rows / columns that are already finished
-// are masked out of the operands, so finished parts of the register tiles are never touched again.
+// wavefronts 4-7 the accumulator of L^-1).  At the end of a step the 4 columns (rows) the next step needs are published to
+// LDS in operand layout (row-major [64][4]: a fragment is 64 consecutive doubles); the wavefront that owns the next diagonal
+// block has at most two tiles to update, publishes, and factorises the block right away (same wavefront: no barrier).
+// ONE workgroup barrier per panel step; P, D and the published accumulator rows alternate between two buffers.
 // Fragment layout: A: lane l -> A[l&15][l>>4]; B: lane l -> B[l>>4][l&15]; D: lane l, reg r -> D[(l>>4) + 4r][l&15].
-// Defined after the tile-product helpers (needs f64x4).
 // ---------------------------------------------------------------------------------------
-constexpr int kPotrfMfmaLds = T * LD + 5 * (T * 4) + 16 + T;   // doubles
-struct PotrfLds { double *Lsh, *Psh, *Xsh2, *W4, *AR, *Dsh; };
+constexpr int kPotrfMfmaLds = T * LD + 2 * (T * 4) + 2 * (T * 4) + 32 + T;   // doubles
+struct PotrfLds { double *Lsh, *Psh2, *AR2, *Dsh2; };
 // 4x4 Cholesky of the diagonal block kb and the inverse of its factor, one thread.  2x2 block pivots: for the pivot block
 // (p q; q r) the reciprocal square roots of p and of p r - q^2 are independent, so two columns cost one rsqrt latency:
 // l00 = p i0, l10 = q i0, 1/l11 = rsqrt(det) l00, l11 = det rsqrt(det) i0  (det has the same cancellation as r - l10^2).
 // A non-positive pivot is flagged and poisons the tile (NaN); the step is then rejected on the host.
 __device__ __forceinline__ void potrf_factor_diag(const PotrfLds& s, int kb, double& bad) {
-  const double* P = s.Psh + (4 * kb) * 4;
+  const double* P = s.Psh2 + (kb & 1) * (T * 4) + (4 * kb) * 4;
   const double p = P[0], q = P[4], r = P[5];
   const double det = fma(p, r, -(q * q));
   const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
@@ -156,7 +158,7 @@ __device__ __forceinline__ void potrf_factor_diag(const PotrfLds& s, int kb, dou
   const double d10 = -l10 * i0 * i1, d21 = -l21 * i1 * i2, d32 = -l32 * i2 * i3;
   const double d20 = -(l20 * i0 + l21 * d10) * i2, d31 = -(l31 * i1 + l32 * d21) * i3;
   const double d30 = -(l30 * i0 + l31 * d10 + l32 * d20) * i3;
-  double* D = s.Dsh;   // the strict upper part of Dsh and of L stays zero from the start
+  double* D = s.Dsh2 + (kb & 1) * 16;   // the strict upper part of D and of L stays zero from the start
   D[0] = i0; D[4] = d10; D[5] = i1; D[8] = d20; D[9] = d21; D[10] = i2; D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i3;
   double* L = s.Lsh + (4 * kb) * LD + 4 * kb;
   L[0] = l00; L[LD] = l10; L[LD + 1] = l11; L[2 * LD] = l20; L[2 * LD + 1] = l21; L[2 * LD + 2] = l22;
@@ -173,64 +175,40 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int kb = 4 * Ik + m, done = 4 * kb + 3;   // rows / columns <= done are finished after this panel
-      double* Xsh = s.Xsh2 + (kb & 1) * (T * 4);
+      const int par = m & 1;                            // = kb & 1
+      const double* P = s.Psh2 + par * (T * 4);
+      const double* D = s.Dsh2 + par * 16;
+      double* Pn = s.Psh2 + (1 - par) * (T * 4);
       const bool live = I > Ik || (I == Ik && m < 3);   // the tile row still has rows below the diagonal block
-      // (b) the panel below the diagonal block / rows kb of W
+      const int Jn = m == 3 ? Ik + 1 : Ik, mn = (m + 1) & 3;   // tile column / column block of the next panel
+      const double dpad = c < 4 ? D[c * 4 + q] : 0.0;   // A operand of the panel solve: D padded to 16 x 4
+      // operand of tile row J for the trailing updates: lane (q, c) <- X[16 J + c][q], X = P D^T
+      auto solved_rows = [&](int J) -> double {
+        f64x4 x = {};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(dpad, P[(16 * J + c) * 4 + q], x, 0, 0, 0);
+        return x[0];
+      };
+      double xI = 0.0, an = 0.0;
+      if (live) {
+        xI = solved_rows(I);
+        an = (16 * I + c > done) ? -xI : 0.0;
+      }
       if (FAC) {
         if (live) {
-          const double av = s.Psh[(16 * I + c) * 4 + q];
-          const double bv = c < 4 ? s.Dsh[c * 4 + q] : 0.0;   // B[k][n] = D[n][k]
-          f64x4 x = {};
-          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
-          if (c < 4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = 16 * I + q + 4 * r;
-              if (row > done) { Xsh[row * 4 + c] = x[r]; s.Lsh[row * LD + 4 * kb + c] = x[r]; }
-            }
-          }
-        }
-      } else if (I == Ik) {
-        const double d0 = s.Dsh[q * 4], d1 = s.Dsh[q * 4 + 1], d2 = s.Dsh[q * 4 + 2], d3 = s.Dsh[q * 4 + 3];
-#pragma unroll
-        for (int J = 0; J < 4; ++J) if (J <= I) {
-          const double* a4 = s.AR + (16 * J + c) * 4;
-          const double w = fma(d3, a4[3], fma(d2, a4[2], fma(d1, a4[1], d0 * a4[0])));
-          s.W4[(16 * J + c) * 4 + q] = w;
-          acc[J][m] = w;
-        }
-      }
-      __syncthreads();
-      OBVI_PH(ph1);
-      // (c) trailing updates, then the next panel's columns / rows are published
-      if (live) {
-        const double xa = Xsh[(16 * I + c) * 4 + q];
-        const double an = (16 * I + c > done) ? -xa : 0.0;
-#pragma unroll
-        for (int J = 0; J < 4; ++J) if (J <= I) {
-          if (FAC) {
-            if (J > Ik || (J == Ik && m < 3)) {
-              const double xb = J == I ? xa : Xsh[(16 * J + c) * 4 + q];
-              const double bv = (16 * J + c > done) ? xb : 0.0;
-              acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bv, acc[J], 0, 0, 0);
-            }
-          } else if (J <= Ik) {
-            const double bv = s.W4[(16 * J + c) * 4 + q];
+          for (int J = 3; J >= 0; --J) if (J <= I && (J > Ik || (J == Ik && m < 3))) {   // the tile with the next panel's columns is among the first
+            const double xJ = J == I ? xI : solved_rows(J);
+            const double bv = (16 * J + c > done) ? xJ : 0.0;
             acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bv, acc[J], 0, 0, 0);
           }
         }
-      }
-      OBVI_PH(ph2);
-      if (kb + 1 < 16) {
-        const int Jn = m == 3 ? Ik + 1 : Ik;
-        const int mn = (m + 1) & 3;
-        if (FAC) {
+        if (kb + 1 < 16) {
           if (I >= Jn && (c >> 2) == mn) {
 #pragma unroll
             for (int J = 0; J < 4; ++J)
               if (J == Jn) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s.Psh[(16 * I + q + 4 * r) * 4 + (c & 3)] = acc[J][r];
+                for (int r = 0; r < 4; ++r) Pn[(16 * I + q + 4 * r) * 4 + (c & 3)] = acc[J][r];
               }
           }
           if (I == Jn) {   // this wavefront wrote the new diagonal block: no barrier needed before it is factorised
@@ -239,13 +217,29 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane == 0) potrf_factor_diag(s, kb + 1, bad);
           }
-        } else if (I == Jn) {
+        }
+        if (live && 16 * I + c > done) s.Lsh[(16 * I + c) * LD + 4 * kb + q] = xI;   // the panel's part of L (read at the end)
+      } else if (I >= Ik) {
+        // rows kb of W = D Acc(rows kb): lane (q, c) forms W[4 kb + q][16 J + c], the B operand it needs; the wavefront that
+        // owns these rows keeps them
+        const double d0 = D[q * 4], d1 = D[q * 4 + 1], d2 = D[q * 4 + 2], d3 = D[q * 4 + 3];
+        const double* AR = s.AR2 + par * (T * 4);
 #pragma unroll
-          for (int J = 0; J < 4; ++J) if (J <= I) s.AR[(16 * J + c) * 4 + q] = acc[J][mn];
+        for (int J = 0; J < 4; ++J) if (J <= Ik) {
+          const double* a4 = AR + (16 * J + c) * 4;
+          const double w = fma(d3, a4[3], fma(d2, a4[2], fma(d1, a4[1], d0 * a4[0])));
+          if (I == Ik) acc[J][m] = w;
+          if (live) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, w, acc[J], 0, 0, 0);
+        }
+        if (kb + 1 < 16 && I == Jn) {
+          double* ARn = s.AR2 + (1 - par) * (T * 4);
+#pragma unroll
+          for (int J = 0; J < 4; ++J) if (J <= I) ARn[(16 * J + c) * 4 + q] = acc[J][mn];
         }
       }
+      OBVI_PH(ph1);
       __syncthreads();
-      OBVI_PH(ph3);
+      OBVI_PH(ph2);
     }
   }
   OBVI_TICK(2);
@@ -254,13 +248,10 @@ template <bool FAC>
 __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile, const double* pre_z) {
   PotrfLds s;
   s.Lsh = smem;                 // L, row-major (LD)
-  s.Psh = s.Lsh + T * LD;       // [64][4] current values of the panel columns, all rows
-  s.Xsh2 = s.Psh + T * 4;       // 2 x [64][4] the solved panel, alternating: the next diagonal block is factorised while other
-                                //   wavefronts still read this panel
-  s.W4 = s.Xsh2 + 2 * T * 4;    // [64][4] W4[c][t] = row 4kb+t of W, column c
-  s.AR = s.W4 + T * 4;          // [64][4] AR[c][t] = row 4kb+t of the accumulator of W, column c
-  s.Dsh = s.AR + T * 4;         // 4x4 inverse of L_kk
-  double* zsh = s.Dsh + 16;
+  s.Psh2 = s.Lsh + T * LD;      // 2 x [64][4] current values of the panel columns, all rows (alternating with the panel index)
+  s.AR2 = s.Psh2 + 2 * T * 4;   // 2 x [64][4] AR[c][t] = row 4kb+t of the accumulator of W, column c
+  s.Dsh2 = s.AR2 + 2 * T * 4;   // 2 x 4x4 inverse of L_kk
+  double* zsh = s.Dsh2 + 32;
   double* tile = tile_ptr(S, nt, k, k);
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr bool fac = FAC;
@@ -286,16 +277,16 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   if (pre_tile) __syncthreads();
   if (tid < T) zsh[tid] = zv;
   for (int e = tid; e < T * LD; e += 512) s.Lsh[e] = 0.0;
-  for (int e = tid; e < T * 4; e += 512) { s.W4[e] = 0.0; s.AR[e] = 0.0; }
-  if (tid < 16) s.Dsh[tid] = 0.0;
+  for (int e = tid; e < 2 * T * 4; e += 512) s.AR2[e] = 0.0;
+  if (tid < 32) s.Dsh2[tid] = 0.0;
   if (fac && c < 4) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s.Psh[(16 * I + q + 4 * r) * 4 + c] = acc[0][r];
+    for (int r = 0; r < 4; ++r) s.Psh2[(16 * I + q + 4 * r) * 4 + c] = acc[0][r];
   }
   double bad = 0.0;
   __syncthreads();
   if (tid == 0) potrf_factor_diag(s, 0, bad);
-  if (!fac && I == 0) s.AR[c * 4 + q] = acc[0][0];
+  if (!fac && I == 0) s.AR2[c * 4 + q] = acc[0][0];
   __syncthreads();
   OBVI_MARK(1);
   potrf_mfma_wave<FAC>(s, I, acc, bad);
