@@ -504,7 +504,7 @@ void prepare(obvi_ba_handle* h) {
     }
   std::stable_sort(gv.begin(), gv.end(), [](const GVisit& x, const GVisit& y) { return x.chunk < y.chunk || (x.chunk == y.chunk && x.group > y.group); });
   // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
-  const int64_t slice = std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1024)));
+  const int64_t slice = std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
   // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
   // slots: one per strip frame over the range of its row frames and of its column frames in the group (source: the Z
   // record, or the zero page for a frame the point skips), the point's (u_l, 0) tail, and -- stereo -- a second layer
