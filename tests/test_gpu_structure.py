@@ -84,3 +84,28 @@ def test_ragged_structures_with_a_stereo_rig():
     So, bo = o.debug_reduced_system(100.0)
     Sg, bg = g.debug_reduced_system(100.0)
     assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
+
+
+@pytest.mark.parametrize("knobs", [
+    {"OBVI_PRE_MAX": "0"},                                   # every diagonal product is an update job: the signal / wait path of k_update_potrf
+    {"OBVI_PRE_MAX": "8"},                                   # ... all of them applied by the potrf workgroups
+    {"OBVI_SLICE_MAX": "0"},                                 # no level is row-sliced
+    {"OBVI_SLICE_MAX": "1000000"},                           # every level is
+    {"OBVI_ND_BALANCE": "0", "OBVI_ND_LEAF": "96"},          # the unbalanced dissection of the earlier builds
+    {"OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},                # a deep tree of tiny leaves
+    {"OBVI_SCHUR_WGS": "16", "OBVI_UPD_CHUNK": "1"},
+])
+def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
+    """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
+    is the oracle's step."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    prob = synth.make_problem(P=260, L=4000, O=8, seed=11, bbox_noise=5.0, object_classes=("bench",))
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    prm = helpers.ba_params(max_it=2, ftol=0, ptol=0, gtol=0)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.num_iterations == so.num_iterations
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
