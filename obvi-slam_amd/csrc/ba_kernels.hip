@@ -108,6 +108,12 @@ __global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* 
   PoseCache pc;
   make_pose_cache(pose, &pc);
   out[p] = pc;
+  // second copy, field-major, behind the records (out must hold 2 (P + 1) records): k_point_pass gathers the cache per observation,
+  // and the lanes of a point's run look at consecutive poses -- field-major makes those loads coalesce
+  double* soa = reinterpret_cast<double*>(out + P + 1);
+  const double* f = reinterpret_cast<const double*>(&pc);
+#pragma unroll
+  for (int k = 0; k < 21; ++k) soa[k * P + p] = f[k];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,7 +243,14 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
     for (int i = 0; i < 6; ++i) Jl[i] = 0.0;
     if (live) {
       const double2 px = rp.pixel[a];
-      reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
+      PoseCache cache;   // from the field-major copy (k_pose_cache)
+      {
+        const double* soa = reinterpret_cast<const double*>(pc + b.P + 1) + p;
+        double* f = reinterpret_cast<double*>(&cache);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) f[k] = soa[k * b.P];
+      }
+      reproj_eval<true>(cache, cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
       double rho0;
       huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
       cost = 0.5 * rho0;

@@ -784,7 +784,7 @@ void prepare(obvi_ba_handle* h) {
   }
   h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)7 * O + 1);
   h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
-  h->d_pc.resize((size_t)P + 1); h->d_pc_c.resize((size_t)P + 1);
+  h->d_pc.resize(2 * ((size_t)P + 1)); h->d_pc_c.resize(2 * ((size_t)P + 1));   // records, then the field-major copy (k_pose_cache)
   sync(h);  // host vectors above go out of scope
   h->dirty = false; h->pc_valid = false; h->tiles_cleared = false;
 }
