@@ -246,6 +246,31 @@ def test_full_size_invariants():
     assert abs(s2.final_cost - s.final_cost) <= 1e-6 * s.final_cost                    # re-running reproduces the solve
 
 
+def test_bench_workload_invariants():
+    """BASELINE config #3, the bench.py workload (2000 KF / 200 objects / 300k features, ~3 M observations): size-independent
+    properties.  A solve at a tiny trust-region radius makes the quadratic model exact, so relative_decrease -> 1 checks
+    gradient, damped reduced system, factorisation and back-substitution together at full size."""
+    prob = synth.make_problem(P=2000, L=300000, O=200, seed=20241008, const_poses=1, min_obj_obs=10)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    c_rob, res, sq = g.evaluate(True)
+    c_raw = g.evaluate(False, False)[0]
+    assert abs(0.5 * sq.sum() - c_raw) <= 1e-10 * c_raw          # cost == half the sum of block norms
+    g.snapshot()
+    tiny = g.solve(helpers.ba_params(max_it=1, ftol=0, ptol=0, gtol=0, radius=1e-2, max_radius=1e-2))
+    it = g.iterations()[1]
+    assert it.step_is_valid and it.step_is_successful and abs(it.relative_decrease - 1.0) < 5e-2
+    assert tiny.final_cost < tiny.initial_cost
+    g.restore()
+    assert abs(g.evaluate(True, False)[0] - c_rob) <= 1e-12 * c_rob                    # snapshot/restore round trip
+    s = g.solve(helpers.ba_params(max_it=6))
+    costs = [x.cost for x in g.iterations()]
+    assert s.final_cost == min(costs) and s.final_cost < 0.5 * s.initial_cost
+    assert abs(g.evaluate(True, False)[0] - s.final_cost) <= 1e-9 * s.final_cost      # the returned state is the minimum-cost iterate
+    assert np.array_equal(g.get_poses()[:1], prob["poses"][:1])                         # the constant pose is untouched
+    st = g.problem_stats()
+    assert st["reduced_rows"] == 6 * 1999 + 7 * 200 and st["chol_levels"] < 40
+
+
 def test_stereo_rig_matches_oracle():
     """Two cameras: a point is observed twice from the same pose, which exercises the same-pose observation pairs
     of the Schur complement (diagonal blocks receive both orders of the pair)."""
