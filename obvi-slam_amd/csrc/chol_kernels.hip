@@ -4,13 +4,15 @@
 // (same level of the tile elimination tree) are processed by the same launch.  This is the role
 // Ceres' sparse Cholesky of the Schur complement plays behind SPARSE_SCHUR
 // (object_pose_graph_optimizer.h:665) [Ceres-doc]; because the factorisation is exact the
-// elimination order (obvi_ba.cpp: nested dissection of the pose chain, objects last) changes the
+// elimination order (obvi_ba.cpp: nested dissection of the pose chain, objects inside the tree) changes the
 // result only by round-off.
 //
-// Per level:  potrf   L_kk, L_kk^-1, z_k = L_kk^-1 b_k                      (1 workgroup per k)
-//             trsm    L_ik = S_ik L_kk^-T                                   (1 workgroup per tile)
-//             update  S_ij -= sum_k L_ik L_jk^T ; b_i -= sum_k L_ik z_k     (1 workgroup per target)
-// then backward over levels descending: y_k = L_kk^-T (z_k - sum_{i>k} L_ik^T y_i).
+// Per level, two launches:
+//   k_trsm          L_ik = S_ik L_kk^-T                                          (tile product with L_kk^-1, matrix cores)
+//   k_update_potrf  S_ij -= sum_k L_ik L_jk^T ; b_i -= sum_k L_ik z_k            (1 workgroup per target tile / row block)
+//                   and, in the same grid, for the columns of the NEXT level:  L_kk, L_kk^-1, z_k = L_kk^-1 b_k
+//                   (potrf_mfma_tile: 4-column panels on the matrix cores, one workgroup per column)
+// then backward over levels descending, row oriented: y_k = L_kk^-T t_k, t_j -= L_kj^T y_k (k_backward, 1 workgroup per tile).
 #include <algorithm>
 #include "ba_device.h"
 
