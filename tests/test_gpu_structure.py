@@ -109,3 +109,26 @@ def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     assert sg.num_iterations == so.num_iterations
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
+
+
+def test_non_finite_input_is_a_failed_solve_and_the_handle_survives():
+    """A NaN observation poisons cost, gradient and the reduced system: every step is invalid (non-finite step / failed factorisation),
+    the solve stops after max_num_consecutive_invalid_steps like the oracle's, the parameters are left untouched, and the same
+    handle then solves the clean problem to the oracle's result (nothing non-finite survives in the device buffers)."""
+    prob = synth.make_problem(P=40, L=200, O=2, seed=3, outlier_frac=0.0, object_classes=("bench",))
+    bad = dict(prob); bad["rp_pixel"] = prob["rp_pixel"].copy(); bad["rp_pixel"][5, 0] = np.nan
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, bad)
+    prm = helpers.ba_params(max_it=8)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.termination_type == so.termination_type and sg.message == so.message and sg.num_iterations == so.num_iterations
+    assert b"invalid steps" in sg.message
+    assert [it.step_is_valid for it in g.iterations()] == [it.step_is_valid for it in o.iterations()]
+    assert np.array_equal(g.get_poses(), prob["poses"]) and np.array_equal(g.get_points(), prob["points"])
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.num_iterations == so.num_iterations and np.isfinite(sg.final_cost)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-8
