@@ -826,7 +826,8 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   // Fork: the pose-side pass, the small factor families and the diagonal blocks do not depend on the point pass or the
   // Schur complement (everything they share is accumulated with atomics), so they run beside them on the side stream.
   // Not with a multi-GPU exchange in the chain (its collective is ordered on the main stream) nor in an instrumented solve.
-  const bool side = !exchange && h->profiling < 2;
+  static const bool side_ok = !std::getenv("OBVI_SIDE") || std::atoi(std::getenv("OBVI_SIDE")) != 0;   // tuning knob
+  const bool side = !exchange && h->profiling < 2 && side_ok;
   hipStream_t s2 = side ? h->stream2 : s;
   if (side) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
   if (!side) {
@@ -972,7 +973,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
-    OBVI_HIP(hipEventCreate(&h->ev_fork)); OBVI_HIP(hipEventCreate(&h->ev_join));
+    OBVI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); OBVI_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));   // ordering only: no timestamps
   } catch (const HipError&) {
     delete h;
     return OBVI_ERR_HIP;
