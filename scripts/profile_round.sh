@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 python $R/bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o cfg3 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout 300 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o cfg3 -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
 done
