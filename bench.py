@@ -57,6 +57,24 @@ def pmc_traffic(kernel):
         return None
 
 
+def rocprof_avg_us(kernel):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r01_kernel_stats_cfg3.csv); kernel only, without the launch boundary that a HIP-event bracket includes."""
+    path = os.path.join(ROOT, "profiles", "r01_kernel_stats_cfg3.csv")
+    if not os.path.exists(path):
+        return None
+    try:
+        import csv
+        import re
+        pat = re.compile(r"\bk_" + re.escape(kernel[2:] if kernel.startswith("k_") else kernel) + r"[(<]")   # phase names lack the k_ prefix
+        for row in csv.DictReader(open(path)):
+            if pat.search(row["Name"]):
+                return round(float(row["AverageNs"]) / 1e3, 2)
+    except (ValueError, OSError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(prob, budget_iters=2):
     """Oracle (scalar fp64 CPU restatement, 1 thread) on the same problem, bounded to a few LM iterations."""
     import obvi_ba
@@ -187,8 +205,10 @@ def main():
         d = table[dom]
         roof = {"kernel": dom, "bound": d.get("bound", "hbm"), "achieved": d.get("achieved"), "peak": HBM_PEAK_GBS if d.get("bound", "hbm") == "hbm" else FP64_MATRIX_PEAK_TF,
                 "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "traffic": pmc_traffic(dom),
-                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"],
-                "note": "dominant kernel by device time per LM step; durations from HIP events around every launch in a second, instrumented solve of the same steps"}
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "rocprof_avg_us": rocprof_avg_us(dom),
+                "note": "dominant kernel by device time per LM step; durations from HIP events around every launch (they include the launch "
+                        "boundary, about 3 us) in an instrumented solve of the same steps; rocprof_avg_us = kernel-only average of the committed "
+                        "rocprofv3 summary (profiles/)"}
         out = {
             "metric": "global-BA LM iterations/s", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
