@@ -35,3 +35,43 @@ def ba_params(max_it=50, nonmono=True, ftol=1e-6, radius=100.0, max_radius=1e4, 
     return obvi_ba.SolverParams(max_num_iterations=max_it, allow_non_monotonic_steps=nonmono, function_tolerance=ftol,
                                 gradient_tolerance=gtol, parameter_tolerance=ptol, initial_trust_region_radius=radius,
                                 max_trust_region_radius=max_radius)
+
+
+def numpy_robust_residuals(prob):
+    """Independent numpy / scipy restatement of the objective 1/2 sum rho(|r_b|^2) over every factor family of the path
+    (synth.project_points, synth.project_ellipsoids, scipy Rotation, eigen-decomposition square roots; Huber per residual BLOCK,
+    handed out as pre-robustified residuals r~ = r sqrt(rho(s)/s)).  Returns f(poses, points, objects) -> flat r~."""
+    from scipy.spatial.transform import Rotation as Rot
+    import synth
+
+    def inv_sqrt(S):
+        w, V = np.linalg.eigh(S)
+        return (V / np.sqrt(w)) @ V.T
+    W_bb = [inv_sqrt(c.reshape(4, 4)) for c in prob["bb_cov"]]
+    W_sp = [inv_sqrt(c.reshape(3, 3)) for c in prob["sp_cov"]]
+    W_rl = [inv_sqrt(c.reshape(6, 6)) for c in prob.get("rl_cov", [])]
+
+    def robustified(r, delta):
+        if len(r) == 0:
+            return np.zeros(0)
+        sq = (r * r).sum(axis=1)
+        rho = np.where(sq > delta * delta, 2 * delta * np.sqrt(sq) - delta * delta, sq)
+        return (r * np.sqrt(rho / np.maximum(sq, 1e-300))[:, None]).ravel()
+
+    def f(poses, pts, objs):
+        px, _ = synth.project_points(poses[prob["rp_pose"]], pts[prob["rp_point"]], prob["K"][0], prob["ext"][0])
+        out = [robustified((px - prob["rp_pixel"]) / prob["rp_sigma"], prob["rp_huber"])]
+        if len(prob["bb_obj"]):
+            corners, valid, _ = synth.project_ellipsoids(objs[prob["bb_obj"]], poses[prob["bb_pose"]], prob["K"][0], prob["ext"][0])
+            assert valid.all()
+            out.append(robustified(np.stack([W @ d for W, d in zip(W_bb, corners - prob["bb_corners"])]), prob["bb_huber"]))
+        if len(prob["sp_obj"]):
+            out.append(robustified(np.stack([W @ d for W, d in zip(W_sp, objs[prob["sp_obj"], 4:7] - prob["sp_mean"])]), prob["sp_huber"]))
+        if "rl_a" in prob and len(prob["rl_a"]):
+            a, b = prob["rl_a"], prob["rl_b"]
+            Ra = Rot.from_rotvec(poses[a, 3:6])
+            t_rel = Ra.inv().apply(poses[b, :3] - poses[a, :3])
+            rot = ((Ra.inv() * Rot.from_rotvec(poses[b, 3:6])) * Rot.from_rotvec(prob["rl_aa"]).inv()).as_rotvec()
+            out.append(robustified(np.stack([W @ d for W, d in zip(W_rl, np.concatenate([t_rel - prob["rl_t"], rot], axis=1))]), prob["rl_huber"]))
+        return np.concatenate(out)
+    return f

@@ -246,6 +246,22 @@ def test_full_size_invariants():
     assert abs(s2.final_cost - s.final_cost) <= 1e-6 * s.final_cost                    # re-running reproduces the solve
 
 
+def test_cost_equals_the_numpy_restatement_of_every_factor_family():
+    """The HIP path against the independent numpy / scipy restatement directly (not through the oracle): robustified cost at the
+    initial estimate, at the ground truth and at a perturbed state."""
+    prob = synth.make_problem(P=30, L=300, O=3, seed=13, const_poses=1, outlier_frac=0.05, min_obj_obs=4, object_classes=("bench", "chair"), bbox_noise=5.0)
+    objective = helpers.numpy_robust_residuals(prob)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    rng = np.random.default_rng(1)
+    states = [(prob["poses"], prob["points"], prob["objects"]), (prob["gt_poses"], prob["gt_points"], prob["gt_objects"]),
+              (prob["poses"] + 1e-2 * rng.normal(size=prob["poses"].shape), prob["points"] + 5e-2 * rng.normal(size=prob["points"].shape),
+               prob["objects"] + 1e-2 * rng.normal(size=prob["objects"].shape))]
+    for poses, pts, objs in states:
+        g.set_poses(np.ascontiguousarray(poses), prob["pose_const"]); g.set_points(np.ascontiguousarray(pts), prob["point_const"]); g.set_objects(np.ascontiguousarray(objs), prob["object_const"])
+        want = 0.5 * (objective(poses, pts, objs) ** 2).sum()
+        assert abs(g.evaluate(True, False)[0] - want) <= 1e-11 * want
+
+
 def test_bench_workload_invariants():
     """BASELINE config #3, the bench.py workload (2000 KF / 200 objects / 300k features, ~3 M observations): size-independent
     properties.  A solve at a tiny trust-region radius makes the quadratic model exact, so relative_decrease -> 1 checks

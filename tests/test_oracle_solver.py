@@ -204,17 +204,11 @@ def test_all_factor_families_minimum_matches_scipy():
     numpy / scipy (synth.project_points, synth.project_ellipsoids, scipy Rotation, eigen-decomposition square roots): equal
     objective at the start, equal minimum."""
     from scipy.optimize import least_squares
-    from scipy.spatial.transform import Rotation as Rot
     prob = synth.make_problem(P=10, L=40, O=2, seed=11, const_poses=1, outlier_frac=0.05, min_obj_obs=4, object_classes=("bench", "chair"), bbox_noise=5.0)
     ba = helpers.oracle_ba(); synth.upload(ba, prob)
     s = ba.solve(helpers.ba_params(max_it=150, ftol=1e-15, gtol=1e-14, ptol=1e-14, radius=1e4, max_radius=1e12))
 
-    def inv_sqrt(S):
-        w, V = np.linalg.eigh(S)
-        return (V / np.sqrt(w)) @ V.T
-    W_bb = [inv_sqrt(c.reshape(4, 4)) for c in prob["bb_cov"]]
-    W_sp = [inv_sqrt(c.reshape(3, 3)) for c in prob["sp_cov"]]
-    W_rl = [inv_sqrt(c.reshape(6, 6)) for c in prob["rl_cov"]]
+    objective = helpers.numpy_robust_residuals(prob)
     pv = np.flatnonzero(prob["pose_const"] == 0)
     nP, nL, nO = len(pv), len(prob["points"]), len(prob["objects"])
 
@@ -222,25 +216,8 @@ def test_all_factor_families_minimum_matches_scipy():
         poses = prob["poses"].copy(); poses[pv] = x[:6 * nP].reshape(nP, 6)
         return poses, x[6 * nP:6 * nP + 3 * nL].reshape(nL, 3), x[6 * nP + 3 * nL:].reshape(nO, 7)
 
-    def robustified(r, delta):   # block-wise Huber: |r~|^2 = rho(|r|^2)
-        sq = (r * r).sum(axis=1)
-        rho = np.where(sq > delta * delta, 2 * delta * np.sqrt(sq) - delta * delta, sq)
-        return (r * np.sqrt(rho / np.maximum(sq, 1e-300))[:, None]).ravel()
-
     def residuals(x):
-        poses, pts, objs = unpack(x)
-        px, _ = synth.project_points(poses[prob["rp_pose"]], pts[prob["rp_point"]], prob["K"][0], prob["ext"][0])
-        out = [robustified((px - prob["rp_pixel"]) / prob["rp_sigma"], prob["rp_huber"])]
-        corners, valid, _ = synth.project_ellipsoids(objs[prob["bb_obj"]], poses[prob["bb_pose"]], prob["K"][0], prob["ext"][0])
-        assert valid.all()
-        out.append(robustified(np.stack([W @ d for W, d in zip(W_bb, corners - prob["bb_corners"])]), prob["bb_huber"]))
-        out.append(robustified(np.stack([W @ d for W, d in zip(W_sp, objs[prob["sp_obj"], 4:7] - prob["sp_mean"])]), prob["sp_huber"]))
-        a, b = prob["rl_a"], prob["rl_b"]
-        Ra = Rot.from_rotvec(poses[a, 3:6])
-        t_rel = Ra.inv().apply(poses[b, :3] - poses[a, :3])
-        rot = ((Ra.inv() * Rot.from_rotvec(poses[b, 3:6])) * Rot.from_rotvec(prob["rl_aa"]).inv()).as_rotvec()
-        out.append(robustified(np.stack([W @ d for W, d in zip(W_rl, np.concatenate([t_rel - prob["rl_t"], rot], axis=1))]), prob["rl_huber"]))
-        return np.concatenate(out)
+        return objective(*unpack(x))
 
     x0 = np.concatenate([prob["poses"][pv].ravel(), prob["points"].ravel(), prob["objects"].ravel()])
     assert abs(0.5 * (residuals(x0) ** 2).sum() - s.initial_cost) <= 1e-12 * s.initial_cost
