@@ -262,6 +262,27 @@ def test_cost_equals_the_numpy_restatement_of_every_factor_family():
         assert abs(g.evaluate(True, False)[0] - want) <= 1e-11 * want
 
 
+def test_converged_minimum_equals_scipy_on_the_numpy_restatement():
+    """The whole HIP solver against an independent optimiser on independent arithmetic: the minimum obvi_ba_solve converges to is the
+    one scipy.optimize.least_squares finds for the numpy / scipy restatement of the objective (all factor families)."""
+    from scipy.optimize import least_squares
+    prob = synth.make_problem(P=10, L=40, O=2, seed=11, const_poses=1, outlier_frac=0.05, min_obj_obs=4, object_classes=("bench", "chair"), bbox_noise=5.0)
+    objective = helpers.numpy_robust_residuals(prob)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    s = g.solve(helpers.ba_params(max_it=150, ftol=1e-15, gtol=1e-14, ptol=1e-14, radius=1e4, max_radius=1e12))
+    pv = np.flatnonzero(prob["pose_const"] == 0)
+    nP, nL, nO = len(pv), len(prob["points"]), len(prob["objects"])
+
+    def unpack(x):
+        poses = prob["poses"].copy(); poses[pv] = x[:6 * nP].reshape(nP, 6)
+        return poses, x[6 * nP:6 * nP + 3 * nL].reshape(nL, 3), x[6 * nP + 3 * nL:].reshape(nO, 7)
+    x0 = np.concatenate([prob["poses"][pv].ravel(), prob["points"].ravel(), prob["objects"].ravel()])
+    assert abs(0.5 * (objective(*unpack(x0)) ** 2).sum() - s.initial_cost) <= 1e-11 * s.initial_cost
+    ref = least_squares(lambda x: objective(*unpack(x)), x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=3000)
+    assert abs(ref.cost - s.final_cost) <= 1e-6 * s.final_cost          # flat directions keep both from stopping on a tolerance
+    assert np.abs(g.get_poses() - unpack(ref.x)[0]).max() < 1e-4
+
+
 def test_bench_workload_invariants():
     """BASELINE config #3, the bench.py workload (2000 KF / 200 objects / 300k features, ~3 M observations): size-independent
     properties.  A solve at a tiny trust-region radius makes the quadratic model exact, so relative_decrease -> 1 checks
