@@ -142,29 +142,28 @@ constexpr int kPotrfMfmaLds = T * LD + 2 * (T * 4) + 2 * (T * 4) + 32 + T;   // 
 struct PotrfLds { double *Lsh, *Psh2, *AR2, *Dsh2; };
 // 4x4 Cholesky of the diagonal block kb and the inverse of its factor, one thread.  2x2 block pivots: for the pivot block
 // (p q; q r) the reciprocal square roots of p and of p r - q^2 are independent, so two columns cost one rsqrt latency:
-// l00 = p i0, l10 = q i0, 1/l11 = rsqrt(det) l00, l11 = det rsqrt(det) i0  (det has the same cancellation as r - l10^2).
+// l00 = p i0, l10 = q i0, 1/l11 = rsqrt(det) l00  (det has the same cancellation as r - l10^2).
 // A non-positive pivot is flagged and poisons the tile (NaN); the step is then rejected on the host.
 __device__ __forceinline__ void potrf_factor_diag(const PotrfLds& s, int kb, double& bad) {
   const double* P = s.Psh2 + (kb & 1) * (T * 4) + (4 * kb) * 4;
   const double p = P[0], q = P[4], r = P[5];
   const double det = fma(p, r, -(q * q));
   const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
-  const double l00 = p * i0, l10 = q * i0, i1 = id * l00, l11 = det * id * i0;
+  const double l00 = p * i0, l10 = q * i0, i1 = id * l00;
   const double l20 = P[8] * i0, l30 = P[12] * i0;
   const double l21 = fma(-l20, l10, P[9]) * i1, l31 = fma(-l30, l10, P[13]) * i1;
   const double p2 = fma(-l21, l21, fma(-l20, l20, P[10])), q2 = fma(-l31, l21, fma(-l30, l20, P[14])), r2 = fma(-l31, l31, fma(-l30, l30, P[15]));
   const double det2 = fma(p2, r2, -(q2 * q2));
   const double i2 = fast_rsqrt(p2), id2 = fast_rsqrt(det2);
-  const double l22 = p2 * i2, l32 = q2 * i2, i3 = id2 * l22, l33 = det2 * id2 * i2;
+  const double l22 = p2 * i2, l32 = q2 * i2, i3 = id2 * l22;
   if (!(p > 0.0) || !(det > 0.0) || !(p2 > 0.0) || !(det2 > 0.0)) bad = 1.0;
   const double d10 = -l10 * i0 * i1, d21 = -l21 * i1 * i2, d32 = -l32 * i2 * i3;
   const double d20 = -(l20 * i0 + l21 * d10) * i2, d31 = -(l31 * i1 + l32 * d21) * i3;
   const double d30 = -(l30 * i0 + l31 * d10 + l32 * d20) * i3;
-  double* D = s.Dsh2 + (kb & 1) * 16;   // the strict upper part of D and of L stays zero from the start
+  // only the inverse is handed on (its strict upper part stays zero from the start): the block's own factor falls out of the panel
+  // solve, L_kk = A_kk D^T, with the rows below it
+  double* D = s.Dsh2 + (kb & 1) * 16;
   D[0] = i0; D[4] = d10; D[5] = i1; D[8] = d20; D[9] = d21; D[10] = i2; D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i3;
-  double* L = s.Lsh + (4 * kb) * LD + 4 * kb;
-  L[0] = l00; L[LD] = l10; L[LD + 1] = l11; L[2 * LD] = l20; L[2 * LD + 1] = l21; L[2 * LD + 2] = l22;
-  L[3 * LD] = l30; L[3 * LD + 1] = l31; L[3 * LD + 2] = l32; L[3 * LD + 3] = l33;
 }
 // the panel loop of one wavefront: tile row I of A (FAC) or of the accumulator of L^-1
 template <bool FAC>
@@ -190,8 +189,9 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(dpad, P[(16 * J + c) * 4 + q], x, 0, 0, 0);
         return x[0];
       };
+      const bool live2 = I >= Ik;   // ... or the rows of the diagonal block itself (their part of X = P D^T is L_kk)
       double xI = 0.0, an = 0.0;
-      if (live) {
+      if (FAC ? live2 : live) {
         xI = solved_rows(I);
         an = (16 * I + c > done) ? -xI : 0.0;
       }
@@ -220,7 +220,7 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
             if (lane == 0) potrf_factor_diag(s, kb + 1, bad);
           }
         }
-        if (live && 16 * I + c > done) s.Lsh[(16 * I + c) * LD + 4 * kb + q] = xI;   // the panel's part of L (read at the end)
+        if (live2 && 16 * I + c >= 4 * kb) s.Lsh[(16 * I + c) * LD + 4 * kb + q] = xI;   // the panel's part of L incl. the diagonal block (read at the end)
       } else if (I >= Ik) {
         // rows kb of W = D Acc(rows kb): lane (q, c) forms W[4 kb + q][16 J + c], the B operand it needs; the wavefront that
         // owns these rows keeps them
@@ -278,7 +278,6 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   if (tid < T) zv = pre_z ? pre_z[tid] : rhs[(int64_t)k * T + tid];
   if (pre_tile) __syncthreads();
   if (tid < T) zsh[tid] = zv;
-  for (int e = tid; e < T * LD; e += 512) s.Lsh[e] = 0.0;
   for (int e = tid; e < 2 * T * 4; e += 512) s.AR2[e] = 0.0;
   if (tid < 32) s.Dsh2[tid] = 0.0;
   if (fac && c < 4) {
@@ -295,8 +294,8 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   OBVI_MARK(2);
   if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
   OBVI_MARK(3);
-  if (fac) {   // L: coalesced from LDS (the strict upper part was never written: zeros from the start)
-    for (int e = tid; e < T * T; e += 256) tile[e] = s.Lsh[(e >> 6) * LD + (e & 63)];
+  if (fac) {   // L: coalesced from LDS; the strict upper part was never written (or holds round-off of the diagonal blocks): zeros
+    for (int e = tid; e < T * T; e += 256) tile[e] = (e & 63) <= (e >> 6) ? s.Lsh[(e >> 6) * LD + (e & 63)] : 0.0;
   } else {
     // L^-1 from the accumulator registers, and z_k = L^-1 b_k without staging L^-1: every lane multiplies its elements with
     // b and the 16 lanes that share a row add up
