@@ -295,7 +295,11 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
   OBVI_MARK(3);
   if (fac) {   // L: coalesced from LDS; the strict upper part was never written (or holds round-off of the diagonal blocks): zeros
-    for (int e = tid; e < T * T; e += 256) tile[e] = (e & 63) <= (e >> 6) ? s.Lsh[(e >> 6) * LD + (e & 63)] : 0.0;
+    double lv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { const int e = tid + 256 * it; lv[it] = (e & 63) <= (e >> 6) ? s.Lsh[(e >> 6) * LD + (e & 63)] : 0.0; }   // all reads first
+#pragma unroll
+    for (int it = 0; it < 16; ++it) tile[tid + 256 * it] = lv[it];
   } else {
     // L^-1 from the accumulator registers, and z_k = L^-1 b_k without staging L^-1: every lane multiplies its elements with
     // b and the 16 lanes that share a row add up
