@@ -35,7 +35,7 @@ def test_bundle_adjustment_returns_to_ground_truth(name):
     o = helpers.oracle_ba(); synth.upload(o, prob)
     so = o.solve(prm)
     for a, b in list(zip(o.iterations(), g.iterations()))[:8]:           # far from the minimum: the same trajectory
-        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost + 1e-12 * so.initial_cost
     # at the minimum the cost is rounding noise of the text (1e-8 of the start): both land in the same place
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-6
     assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.initial_cost
