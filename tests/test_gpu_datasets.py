@@ -34,7 +34,9 @@ def test_bundle_adjustment_returns_to_ground_truth(name):
     assert np.abs(g.get_poses() - gt["poses"]).max() < GT_POSE_TOL[name]
     o = helpers.oracle_ba(); synth.upload(o, prob)
     so = o.solve(prm)
-    for a, b in list(zip(o.iterations(), g.iterations()))[:8]:           # far from the minimum: the same trajectory
+    for a, b in zip(o.iterations(), g.iterations()):                     # down to the rounding level: the same trajectory
+        if a.cost <= 1e-9 * so.initial_cost:
+            break
         assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost + 1e-12 * so.initial_cost
     # at the minimum the cost is rounding noise of the text (1e-8 of the start): both land in the same place
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-6
