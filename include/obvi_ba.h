@@ -14,6 +14,10 @@
  *     -> obvi_ba_snapshot / obvi_ba_restore
  *   - two-phase outlier selection  include/refactoring/offline/offline_problem_runner.h:689-800
  *     -> obvi_ba_select_outliers
+ *   - long-term-map covariance extraction (ceres::Covariance::Compute + GetCovarianceBlock on object blocks)
+ *       src/refactoring/long_term_map/long_term_object_map_extraction.cpp:419-433,
+ *       include/refactoring/long_term_map/long_term_object_map_extraction.h:318-340, 499-513
+ *     -> obvi_ba_object_covariances
  *
  * Conventions
  *   - every pointer argument is a HOST pointer owned by the caller; set_* copies to
@@ -201,6 +205,16 @@ int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out,
  * (offline_problem_runner.h:769-800).  Runs on the device. */
 int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t factor_type, double fraction,
                             uint8_t* mask_out, int64_t* num_excluded);
+
+/* Covariance blocks of pairs of object (ellipsoid) blocks at the current estimate: cov49[i] = the 7x7 block
+ * (rows: obj_a[i], columns: obj_b[i], row-major) of (J^T J)^-1 over all non-constant parameter blocks, J with the
+ * loss functions applied and no damping -- what ceres::Covariance::Compute(blocks, problem) followed by
+ * GetCovarianceBlock(obj_a, obj_b) returns (long_term_object_map_extraction.cpp:419-433, .h:318-340, 499-513;
+ * the independent-ellipsoids extractor asks for (o, o) pairs only).  Blocks of a constant or unobserved object are zero.
+ * A rank-deficient problem (free gauge, unobserved feature) fails with OBVI_ERR_NUMERICAL, as Covariance::Compute
+ * fails on it.  Computed on the device from the tile Cholesky factor of the undamped reduced system. */
+int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_t* obj_a, const uint32_t* obj_b,
+                               double* cov49 /*[n_pairs][49]*/);
 
 /* ---- state ------------------------------------------------------------------------- */
 int obvi_ba_snapshot(obvi_ba_handle* h);

@@ -190,6 +190,8 @@ struct CholPlan {
   const int32_t* col_i;       // device
   const int32_t* bw_ptr;      // host [nlevels+1]   backward substitution workgroups of each level
   const int32_t* bw_kj;       // device, 2 per workgroup: tile (k,j) of row k, j < k; j = -1: the workgroup that stores y_k
+  const int32_t* row_ptr;     // device [nt+1]      row structure of L: columns j < k with L(k,j) != 0 (forward substitution with many right-hand sides)
+  const int32_t* row_j;       // device
 };
 void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2);
 // small accumulators cleared at the start of an LM step, together with the tiles (one launch)
@@ -212,6 +214,12 @@ struct CholTimers {
 };
 void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int level1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers = nullptr);
 void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* rhs /* z in, overwritten */, double* y, CholTimers* timers = nullptr);
+
+// covariance blocks: Y = L^-1 E for the unit vectors of every variable object's rows (Y row-major [nt*64][ldy], cleared by the
+// caller), then 7x7 blocks Y[:, ca..]^T Y[:, cb..] for pairs of column offsets (cols: 2 per pair, negative: zero block)
+void launch_forward_multi(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* Y, int64_t ldy, int nslabs,
+                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv);
+void launch_cov_pairs(hipStream_t s, const double* Y, int64_t ldy, int64_t nrows, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

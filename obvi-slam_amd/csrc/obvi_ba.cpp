@@ -95,6 +95,9 @@ struct obvi_ba_handle {
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj;
+  DevBuf<int32_t> d_row_ptr, d_row_j, d_cov_slab, d_cov_cols, d_cov_first;   // row structure of L; covariance extraction scratch
+  DevBuf<double> d_cov_Y, d_cov_out;
+  std::vector<int32_t> h_obj_vid;          // object -> reduced object index (elimination order) or -1
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
   DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done, d_pre_ptr, d_pre_j;
   DevBuf<int32_t> d_pose_row, d_obj_row;
@@ -233,6 +236,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
   c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
+  c.row_ptr = h->d_row_ptr.get(); c.row_j = h->d_row_j.get();
   c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.pre_ptr = h->d_pre_ptr.get(); c.pre_j = h->d_pre_j.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
 }
@@ -736,6 +740,15 @@ void prepare(obvi_ba_handle* h) {
     }
     h->h_bw_ptr[l + 1] = (int32_t)(bw_kj.size() / 2);
   }
+  {   // row structure of L (forward substitution with many right-hand sides: covariance extraction)
+    std::vector<int32_t> row_ptr(nt + 1, 0), row_j;
+    for (int k = 0; k < nt; ++k) {
+      for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) row_j.push_back(j);
+      row_ptr[k + 1] = (int32_t)row_j.size();
+    }
+    if (row_j.empty()) row_j.push_back(0);
+    h->d_row_ptr.upload(row_ptr, h->stream); h->d_row_j.upload(row_j, h->stream);
+  }
   h->chol_flops = flops;
   h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
   h->n_upd_products = n_products;
@@ -746,6 +759,7 @@ void prepare(obvi_ba_handle* h) {
   // ---- upload ----
   hipStream_t s = h->stream;
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
+  h->h_obj_vid = obj_vid;
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
   h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
   h->d_chunk_ptr.upload(wg_bptr, s); h->d_batch_first.upload(bfirst, s); h->d_batch_slot.upload(bslot, s); h->d_chunk_points.upload(visits, s); h->d_chunk_f0.upload(wg_f0, s); h->d_chunk_group.upload(wg_group, s);
@@ -808,7 +822,7 @@ void record_end(obvi_ba_handle* h, int idx, hipStream_t on) { if (h->profiling >
 
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
-void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) {
+void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, bool keep_factor = false) {
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h);
   const ReprojDev rp = reproj_dev(h);
@@ -897,8 +911,8 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve) 
   }
   OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   // the clear of the next LM step does not depend on the accept / reject decision: it runs while the host takes it
-  launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
-  h->tiles_cleared = true;
+  // (not when the caller goes on to use the factor that is in the tiles: covariance extraction)
+  if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
   sync(h);
   for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
@@ -1352,6 +1366,53 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
       lhs[ci * mc + cj] = mk[tix] ? tiles[tix * (kTile * kTile) + (r % kTile) * kTile + (c % kTile)] : 0.0;
     }
   }
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_t* obj_a, const uint32_t* obj_b, double* cov49) {
+  if (!h || n_pairs < 0 || (n_pairs > 0 && (!obj_a || !obj_b || !cov49))) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "object_covariances: cameras not set");
+  for (int64_t i = 0; i < n_pairs; ++i) if ((int64_t)obj_a[i] >= h->O || (int64_t)obj_b[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "object_covariances: object index out of range");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  prepare(h);
+  std::fill(cov49, cov49 + 49 * n_pairs, 0.0);
+  if (n_pairs == 0 || h->nOv == 0 || h->m == 0) return OBVI_OK;
+  if (h->allreduce != nullptr && !h->h_shared_ov.empty()) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "object_covariances: not available with objects shared across ranks");
+  // the undamped reduced system S = J_c^T J_c - (Schur complement of the features) at the current point, factorised: one
+  // LM step's linearisation and factorisation with the trust-region radius at infinity (its candidate point is not used)
+  const int profiling = h->profiling;
+  h->profiling = 0; h->pc_valid = false; h->tiles_cleared = false;
+  submit_step(h, 1e300, true, true, /*keep_factor=*/true);
+  h->profiling = profiling; h->pc_valid = false; h->tiles_cleared = false;
+  if (h->h_scal[SC_CHOL_FAIL] != 0.0 || h->h_scal[SC_NONFINITE] != 0.0 || !std::isfinite(h->h_scal[SC_STEPSQ]))
+    return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: the normal equations are rank deficient at the current estimate");
+  hipStream_t s = h->stream;
+  const int nslabs = (int)((7 * h->nOv + kTile - 1) / kTile);
+  const int64_t ldy = (int64_t)nslabs * kTile, nrows = (int64_t)h->nt * kTile;
+  std::vector<int32_t> slab_first(nslabs, h->nt);
+  for (int64_t w = 0; w < h->nOv; ++w) {
+    const int sl0 = (int)(7 * w / kTile), sl1 = (int)((7 * w + 6) / kTile);
+    for (int sl = sl0; sl <= sl1; ++sl) slab_first[sl] = std::min(slab_first[sl], h->h_obj_row[w] / kTile);
+  }
+  std::vector<int32_t> cols(2 * n_pairs), first_row(n_pairs);
+  for (int64_t i = 0; i < n_pairs; ++i) {
+    const int32_t va = h->h_obj_vid[obj_a[i]], vb = h->h_obj_vid[obj_b[i]];
+    cols[2 * i] = va >= 0 && vb >= 0 ? 7 * va : -1; cols[2 * i + 1] = va >= 0 && vb >= 0 ? 7 * vb : -1;
+    first_row[i] = va >= 0 && vb >= 0 ? std::max(h->h_obj_row[va], h->h_obj_row[vb]) / kTile * kTile : 0;   // both columns are zero above
+  }
+  h->d_cov_Y.resize((size_t)(nrows * ldy));
+  OBVI_HIP(hipMemsetAsync(h->d_cov_Y.get(), 0, sizeof(double) * (size_t)(nrows * ldy), s));
+  h->d_cov_slab.upload(slab_first, s); h->d_cov_cols.upload(cols, s); h->d_cov_first.upload(first_row, s);
+  h->d_cov_out.resize((size_t)(49 * n_pairs));
+  const CholPlan plan = chol_plan(h);
+  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldy, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv);
+  launch_cov_pairs(s, h->d_cov_Y.get(), ldy, nrows, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get());
+  OBVI_HIP(hipGetLastError());
+  h->d_cov_out.download(cov49, (size_t)(49 * n_pairs), s);
+  sync(h);
+  for (int64_t i = 0; i < 49 * n_pairs; ++i) if (!std::isfinite(cov49[i])) return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: non-finite covariance");
   return OBVI_OK;
   OBVI_API_END(h)
 }

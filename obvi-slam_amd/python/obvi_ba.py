@@ -235,6 +235,15 @@ class BundleAdjuster:
                                                    _ptr(mask, C.c_uint8), C.byref(nex)), "select_outliers")
         return mask, nex.value
 
+    def object_covariances(self, obj_a, obj_b=None):
+        """7x7 covariance blocks of object pairs (obj_b None: the objects' own blocks)."""
+        a = np.ascontiguousarray(obj_a, dtype=np.uint32)
+        b = a if obj_b is None else np.ascontiguousarray(obj_b, dtype=np.uint32)
+        out = np.zeros((len(a), 7, 7))
+        self._check(self._fn("ba_object_covariances")(self._h, C.c_int64(len(a)), _ptr(a, C.c_uint32), _ptr(b, C.c_uint32),
+                                                      _ptr(out, C.c_double)), "object_covariances")
+        return out
+
     # ---- state ---------------------------------------------------------------------------
     def snapshot(self):
         self._check(self._fn("ba_snapshot")(self._h), "snapshot")

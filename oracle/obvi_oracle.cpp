@@ -457,7 +457,7 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
 
 // In-place envelope (skyline) Cholesky S = L L^T and solve.  [Ceres-doc: the reduced system
 // is factorised exactly by a sparse Cholesky; the elimination order does not change the result.]
-bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
+bool skyline_factor(Workspace* ws, int64_t m) {
   for (int64_t i = 0; i < m; ++i) {
     const int64_t fi = ws->first[i];
     double* Li = &ws->S[ws->rowptr[i]] - fi;
@@ -474,7 +474,9 @@ bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
     if (!(s > 0.0) || !std::isfinite(s)) return false;
     Li[i] = std::sqrt(s);
   }
-  x->assign(ws->rhs.begin(), ws->rhs.end());
+  return true;
+}
+void skyline_solve_inplace(const Workspace* ws, int64_t m, std::vector<double>* x) {
   for (int64_t i = 0; i < m; ++i) {  // L z = b
     const int64_t fi = ws->first[i];
     const double* Li = &ws->S[ws->rowptr[i]] - fi;
@@ -489,6 +491,11 @@ bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
     (*x)[i] = xi;
     for (int64_t k = fi; k < i; ++k) (*x)[k] -= Li[k] * xi;
   }
+}
+bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
+  if (!skyline_factor(ws, m)) return false;
+  x->assign(ws->rhs.begin(), ws->rhs.end());
+  skyline_solve_inplace(ws, m, x);
   return true;
 }
 
@@ -720,6 +727,43 @@ int oracle_ba_debug_reduced_system(oracle_handle* h, double radius, double* lhs,
     rhs[i] = ws.rhs[i];
   }
   for (int64_t i = 0; i < rd.m; ++i) for (int64_t j = ws.first[i]; j <= i; ++j) { lhs[i * rd.m + j] = Sat(&ws, i, j); lhs[j * rd.m + i] = Sat(&ws, i, j); }
+  return OBVI_OK;
+}
+
+// ceres::Covariance::Compute + GetCovarianceBlock for pairs of object blocks, as the long-term-map extraction asks for them
+// (long_term_object_map_extraction.cpp:419-433, long_term_object_map_extraction.h:318-340, 499-513): blocks of (J^T J)^-1 over
+// the variable parameter blocks at the current point, J robustified (Covariance::Options::apply_loss_function defaults to
+// true), no damping.  [Ceres-doc: Covariance; the algorithm (SPARSE_QR / DENSE_SVD) does not change a full-rank result.]
+// Restated through the Schur complement: the (objects, objects) part of (J^T J)^-1 is that part of S^-1.
+// A constant or unused object has no covariance: its blocks are zero.  Rank deficiency -> OBVI_ERR_NUMERICAL.
+int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32_t* obj_a, const uint32_t* obj_b, double* cov49) {
+  if (!h || n_pairs < 0 || (n_pairs > 0 && (!obj_a || !obj_b || !cov49))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n_pairs; ++i) if (obj_a[i] >= (uint64_t)pb.O || obj_b[i] >= (uint64_t)pb.O) return OBVI_ERR_INVALID_ARGUMENT;
+  Reduced rd; build_reduced(pb, &rd);
+  Workspace ws; linearize(pb, rd, &ws); build_envelope(pb, rd, &ws);
+  std::vector<double> lam_c(rd.m, 0.0), lam_l(3 * pb.L, 0.0), Hinv;
+  if (!assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hinv)) return OBVI_ERR_NUMERICAL;
+  if (!skyline_factor(&ws, rd.m)) return OBVI_ERR_NUMERICAL;
+  std::vector<int32_t> solved_for(pb.O, -1);           // object -> slot in `cols`
+  std::vector<std::vector<double>> cols;              // 7 solution vectors per object that occurs as the second of a pair
+  for (int64_t i = 0; i < n_pairs; ++i) {
+    double* out = cov49 + 49 * i;
+    std::fill(out, out + 49, 0.0);
+    const uint32_t a = obj_a[i], b = obj_b[i];
+    if (rd.obj_vid[a] < 0 || rd.obj_vid[b] < 0) continue;
+    if (solved_for[b] < 0) {
+      solved_for[b] = (int32_t)cols.size();
+      for (int k = 0; k < 7; ++k) {
+        std::vector<double> x(rd.m, 0.0);
+        x[obj_row(rd, b) + k] = 1.0;
+        skyline_solve_inplace(&ws, rd.m, &x);
+        if (!std::isfinite(x[obj_row(rd, b) + k])) return OBVI_ERR_NUMERICAL;
+        cols.push_back(std::move(x));
+      }
+    }
+    for (int r = 0; r < 7; ++r) for (int k = 0; k < 7; ++k) out[7 * r + k] = cols[solved_for[b] + k][obj_row(rd, a) + r];
+  }
   return OBVI_OK;
 }
 

@@ -321,3 +321,46 @@ def test_stereo_rig_matches_oracle():
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-8
     # stereo fixes the scale: the solution is close to the truth
     assert np.linalg.norm(g.get_poses()[:, :3] - prob["gt_poses"][:, :3], axis=1).mean() < 0.05
+
+
+def covariance_close(cg, co, tol):
+    """every block to `tol` relative to its own largest entry (a zero block must be exactly zero)"""
+    scale = np.abs(co).max(axis=(1, 2), keepdims=True)
+    return bool(np.all(np.abs(cg - co) <= tol * scale))
+
+
+def test_object_covariances_match_the_oracle(small):
+    """obvi_ba_object_covariances (ceres::Covariance on object blocks, long_term_object_map_extraction.cpp:419-433):
+    blocks of S^-1 from the tile factor against the oracle's skyline solves.  Tolerance 1e-8 relative to the block's
+    largest entry: the blocks are entries of an inverse, round-off is amplified by the condition of S (1e9 here)."""
+    o, g = pair(small)
+    O = len(small["objects"])
+    ids = np.arange(O)
+    co, cg = o.object_covariances(ids), g.object_covariances(ids)
+    assert np.all(np.linalg.eigvalsh(cg) > 0) and covariance_close(cg, co, 1e-8)
+    a, b = np.array([0, 1, 2, 0]), np.array([1, 0, 1, 2])
+    xo, xg = o.object_covariances(a, b), g.object_covariances(a, b)
+    assert float(np.abs(xg - xo).max()) < 1e-8 * float(np.abs(co).max())
+    assert np.abs(xg[0] - xg[1].T).max() < 1e-10 * float(np.abs(co).max())          # C_ab = C_ba^T
+    # the state and a following solve are untouched by the extraction
+    prm = helpers.ba_params(max_it=5)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    # ... and at the new estimate
+    assert covariance_close(g.object_covariances(ids), o.object_covariances(ids), 1e-8)
+
+
+def test_object_covariances_over_a_dissected_factor():
+    """Several dissection levels, objects spread over the tree, a constant object, an object seen by constant poses only."""
+    prob = synth.make_problem(P=260, L=5000, O=24, seed=11, min_obj_obs=5, const_poses=3)
+    prob["object_const"][5] = 1
+    o, g = pair(prob)
+    ids = np.arange(len(prob["objects"]))
+    co, cg = o.object_covariances(ids), g.object_covariances(ids)
+    assert np.all(cg[5] == 0.0) and np.all(co[5] == 0.0)
+    assert covariance_close(cg, co, 1e-7)
+    far = np.array([0, len(ids) - 1]), np.array([len(ids) - 1, 0])
+    xo, xg = o.object_covariances(*far), g.object_covariances(*far)
+    assert float(np.abs(xg - xo).max()) < 1e-7 * float(np.abs(co).max())
+    with pytest.raises(obvi_ba.ObviError):
+        g.object_covariances([len(ids)])

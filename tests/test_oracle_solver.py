@@ -229,3 +229,27 @@ def test_all_factor_families_minimum_matches_scipy():
     assert abs(0.5 * (residuals(x_oracle) ** 2).sum() - s.final_cost) <= 1e-10 * s.final_cost
     poses, _, _ = unpack(ref.x)
     assert np.abs(ba.get_poses() - poses).max() < 1e-4    # points / objects: through the cost (flat directions)
+
+
+def test_object_covariances_are_blocks_of_the_dense_inverse():
+    """ceres::Covariance on object blocks (long_term_object_map_extraction.cpp:419-433): the oracle's Schur-complement route
+    against numpy's inverse of the full J^T J (poses, objects and points, J robustified, no damping)."""
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    J, r, m, pv = dense_normal_equations(ba, prob)
+    C = np.linalg.inv(J.T @ J)
+    nPv, O = int((pv >= 0).sum()), len(prob["objects"])
+    row = lambda o: 6 * nPv + 7 * o
+    own = ba.object_covariances(np.arange(O))
+    for o in range(O):
+        blk = C[row(o):row(o) + 7, row(o):row(o) + 7]
+        assert np.abs(own[o] - blk).max() <= 1e-9 * np.abs(blk).max()
+        assert np.allclose(own[o], own[o].T, rtol=0, atol=1e-12 * np.abs(blk).max()) and np.all(np.linalg.eigvalsh(own[o]) > 0)
+    cross = ba.object_covariances([0, 1], [1, 0])
+    blk = C[row(0):row(0) + 7, row(1):row(1) + 7]
+    assert np.abs(cross[0] - blk).max() <= 1e-9 * np.abs(own).max() and np.abs(cross[1] - blk.T).max() <= 1e-9 * np.abs(own).max()
+    # a constant object has no covariance, and the others no longer share uncertainty with it
+    prob2 = dict(prob); prob2["object_const"] = prob["object_const"].copy(); prob2["object_const"][0] = 1
+    ba2 = helpers.oracle_ba(); synth.upload(ba2, prob2)
+    c2 = ba2.object_covariances(np.arange(O))
+    assert np.all(c2[0] == 0.0) and np.all(np.diag(c2[1]) <= np.diag(own[1]) * (1 + 1e-9))
