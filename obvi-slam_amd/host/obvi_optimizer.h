@@ -95,6 +95,49 @@ class Problem {
   double extra_relpose_huber_ = 1.0;
 };
 
+// ceres::Covariance as the long-term-map extraction uses it (src/refactoring/long_term_map/long_term_object_map_extraction.cpp:419-433,
+// include/refactoring/long_term_map/long_term_object_map_extraction.h:318-340, 499-513): Compute() for a list of pairs of
+// ellipsoid blocks of the problem that is on the device, then GetCovarianceBlock() per pair.  The parameter values are
+// taken from the pose graph's blocks (as Ceres reads them in place), the factors are those of the last build.
+class Covariance {
+ public:
+  bool Compute(const std::vector<std::pair<vslam_types_refactor::ObjectId, vslam_types_refactor::ObjectId>>& covariance_blocks, Problem* problem) {
+    blocks_.clear();
+    if (problem == nullptr) return false;
+    obvi_ba_handle* h = problem->handle();
+    if (h == nullptr) return false;
+    const FlatProblem& fp = problem->flat;
+    auto index_of = [&](vslam_types_refactor::ObjectId id, uint32_t* out) {
+      const auto it = std::lower_bound(fp.objects.begin(), fp.objects.end(), id);
+      if (it == fp.objects.end() || *it != id) return false;
+      *out = (uint32_t)(it - fp.objects.begin());
+      return true;
+    };
+    std::vector<uint32_t> a(covariance_blocks.size()), b(covariance_blocks.size());
+    for (size_t i = 0; i < covariance_blocks.size(); ++i)
+      if (!index_of(covariance_blocks[i].first, &a[i]) || !index_of(covariance_blocks[i].second, &b[i])) { std::cerr << "Covariance::Compute: object is not a parameter block of the problem" << std::endl; return false; }
+    auto gather = [](const std::vector<double*>& ptrs, int dim) { std::vector<double> v(ptrs.size() * dim); for (size_t i = 0; i < ptrs.size(); ++i) std::copy_n(ptrs[i], dim, &v[dim * i]); return v; };
+    const std::vector<double> poses = gather(fp.pose_ptrs, 6), points = gather(fp.point_ptrs, 3), objects = gather(fp.object_ptrs, 7);
+    int rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
+    if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
+    if (!rc) rc = obvi_ba_set_objects(h, (int64_t)fp.objects.size(), objects.data(), fp.object_const.data());
+    std::vector<double> cov(49 * covariance_blocks.size());
+    if (!rc) rc = obvi_ba_object_covariances(h, (int64_t)covariance_blocks.size(), a.data(), b.data(), cov.data());
+    if (rc) { std::cerr << "Covariance computation failed: " << obvi_ba_last_error(h) << std::endl; return false; }      // LOG(WARNING) at :435-437
+    for (size_t i = 0; i < covariance_blocks.size(); ++i) blocks_[covariance_blocks[i]] = std::vector<double>(cov.begin() + 49 * i, cov.begin() + 49 * (i + 1));
+    return true;
+  }
+  // 7x7, row-major (Ceres' convention)
+  bool GetCovarianceBlock(vslam_types_refactor::ObjectId a, vslam_types_refactor::ObjectId b, double* covariance_block) const {
+    const auto it = blocks_.find({a, b});
+    if (it == blocks_.end()) return false;
+    std::copy(it->second.begin(), it->second.end(), covariance_block);
+    return true;
+  }
+ private:
+  std::map<std::pair<vslam_types_refactor::ObjectId, vslam_types_refactor::ObjectId>, std::vector<double>> blocks_;
+};
+
 }  // namespace obvi
 
 namespace vslam_types_refactor {

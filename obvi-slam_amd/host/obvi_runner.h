@@ -113,11 +113,30 @@ class OfflineProblemRunner {
       if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
     }
     if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
-    // mergeObjectsAtSessionEnd (:918-958) and the output extractor act on data-association state: out of scope
+    // mergeObjectsAtSessionEnd (:918-958) acts on data-association state: out of scope.  The output extractor's covariance
+    // step (IndependentEllipsoidsLongTermObjectMapExtractor::extractLongTermObjectMap, long_term_object_map_extraction.h:
+    // 381-527: marginal covariance of every ellipsoid from the final problem) runs on the device.
+    long_term_map_.clear();
+    if (extract_long_term_map_ && !problem.flat.objects.empty()) {
+      std::vector<std::pair<ObjectId, ObjectId>> blocks;
+      for (const ObjectId& o : problem.flat.objects) blocks.push_back({o, o});
+      obvi::Covariance covariance;
+      if (!covariance.Compute(blocks, &problem)) return false;
+      for (size_t i = 0; i < problem.flat.objects.size(); ++i) {
+        LongTermMapEntry e;
+        e.object_id_ = problem.flat.objects[i];
+        std::copy_n(problem.flat.object_ptrs[i], 7, e.ellipsoid_mean_.begin());
+        if (!covariance.GetCovarianceBlock(e.object_id_, e.object_id_, e.covariance_.data())) return false;
+        long_term_map_.push_back(e);
+      }
+    }
     pose_graph_out = pose_graph;
     return true;
   }
   const std::vector<OptimizationRecord>& records() const { return records_; }
+  struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
+  void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
+  const std::vector<LongTermMapEntry>& longTermMap() const { return long_term_map_; }
 
  private:
   // offline_problem_runner.h:337-374
@@ -235,6 +254,8 @@ class OfflineProblemRunner {
   int device_id_;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
+  bool extract_long_term_map_ = false;
+  std::vector<LongTermMapEntry> long_term_map_;
 };
 
 }  // namespace vslam_types_refactor

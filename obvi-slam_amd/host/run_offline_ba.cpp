@@ -1,6 +1,6 @@
 // run_offline_ba.cpp -- driver of the host-side mirror: the shape of the reference's
 // offline_object_visual_slam_main / run_opt_from_pg_state for a scene whose associations are given.
-//   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv]
+//   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv] [--ltm]
 //   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K]   (no GPU: flattening only)
 // Parameter values: config/base7a_2_fallback.json of the reference.
 #include <cstdlib>
@@ -62,12 +62,13 @@ static pose_graph_optimization::OptimizationSolverParams sp(int it, double ftol)
 int main(int argc, char** argv) {
   if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options]" << std::endl; return 2; }
   SlidingWindowParams sw;
-  int device = 0; std::string csv; bool dump = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  int device = 0; std::string csv; bool dump = false, ltm = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
   for (int i = 3; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) csv = argv[++i];
+    else if (!std::strcmp(argv[i], "--ltm")) ltm = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
   }
@@ -136,6 +137,7 @@ int main(int argc, char** argv) {
   std::optional<OptimizationLogger> logger;
   if (!csv.empty()) logger.emplace(csv);
   MainPgPtr pg;
+  runner.setExtractLongTermMap(ltm);
   const bool ok = runner.runOptimization(data, en, logger, pg);
   out << "{\"ok\": " << (ok ? "true" : "false") << ", \"records\": [";
   bool first = true;
@@ -149,6 +151,20 @@ int main(int argc, char** argv) {
   if (pg) for (FrameId f = 0; f <= max_frame_id; ++f) { const RawPose3d p = pg->getRobotPose(f).value(); out << (f ? "," : "") << "[" << p[0] << "," << p[1] << "," << p[2] << "," << p[3] << "," << p[4] << "," << p[5] << "]"; }
   out << "],\n\"objects\": {";
   if (pg) { std::unordered_map<ObjectId, RawEllipsoid> objs; pg->getObjectEstimates(objs); bool f0 = true; for (const auto& o : objs) { out << (f0 ? "" : ",") << "\"" << o.first << "\": ["; for (int k = 0; k < 7; ++k) out << (k ? "," : "") << o.second[k]; out << "]"; f0 = false; } }
-  out << "}}\n";
+  out << "}";
+  if (ltm) {   // long-term map: ellipsoid mean + 7x7 marginal covariance per object (the input of the next session's IndependentObjectMapFactor)
+    out << ",\n\"long_term_map\": {";
+    bool f0 = true;
+    for (const auto& e : runner.longTermMap()) {
+      out << (f0 ? "" : ",") << "\n \"" << e.object_id_ << "\": {\"mean\": [";
+      for (int k = 0; k < 7; ++k) out << (k ? "," : "") << e.ellipsoid_mean_[k];
+      out << "], \"covariance\": [";
+      for (int k = 0; k < 49; ++k) out << (k ? "," : "") << e.covariance_[k];
+      out << "]}";
+      f0 = false;
+    }
+    out << "}";
+  }
+  out << "}\n";
   return ok ? 0 : 1;
 }

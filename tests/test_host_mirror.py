@@ -120,9 +120,17 @@ def test_offline_runner_session(driver, scene, tmp_path):
     frames, final global BA; the CSV has the reference's columns."""
     prob, path, _ = scene
     out, csv = str(tmp_path / "out.json"), str(tmp_path / "ceres_opt_summary.csv")
-    subprocess.check_call([driver, path, out, "--window", "20", "--gba-frequency", "25", "--csv", csv], timeout=600)
+    subprocess.check_call([driver, path, out, "--window", "20", "--gba-frequency", "25", "--csv", csv, "--ltm"], timeout=600)
     res = json.load(open(out))
     assert res["ok"]
+    # long-term map (the output extractor's covariance step, long_term_object_map_extraction.h:381-527): every object of the
+    # final problem with its estimate and a symmetric positive-definite 7x7 marginal covariance
+    ltm = res["long_term_map"]
+    assert ltm and set(ltm) <= set(res["objects"])
+    for oid, e in ltm.items():
+        cov = np.array(e["covariance"]).reshape(7, 7)
+        assert np.allclose(e["mean"], res["objects"][oid], rtol=0, atol=1e-12)
+        assert np.abs(cov - cov.T).max() <= 1e-9 * np.abs(cov).max() and np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
     recs = res["records"]
     kinds = [r["kind"] for r in recs]
     P = len(prob["poses"])
