@@ -21,7 +21,8 @@
 //   select_outliers  -> include/refactoring/offline/offline_problem_runner.h:769-800
 //
 // PARITY STATUS: factor arithmetic is pinned by the two golden tuples the survey derived from
-// the reference's own code (tests/golden/reference_tuples.json) plus independent numpy
+// the reference's own code (tests/golden/reference_tuples.json), the reference's simulated data
+// sets (zero residual at their ground truth, tests/golden/vslam_set*.npz) plus independent numpy
 // fixtures; the solver level is "parity unpinned" -- the reference holds no test or vector
 // for any residual, Jacobian, cost or solve and Ceres is not installed.
 #include "../include/obvi_ba.h"
