@@ -215,11 +215,12 @@ struct CholTimers {
 void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int level1, double* S, double* Linv, double* rhs, double* scal, CholTimers* timers = nullptr);
 void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* rhs /* z in, overwritten */, double* y, CholTimers* timers = nullptr);
 
-// covariance blocks: Y = L^-1 E for the unit vectors of every variable object's rows (Y row-major [nt*64][ldy], cleared by the
-// caller), then 7x7 blocks Y[:, ca..]^T Y[:, cb..] for pairs of column offsets (cols: 2 per pair, negative: zero block)
-void launch_forward_multi(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* Y, int64_t ldy, int nslabs,
+// covariance blocks: Y = L^-1 E for the unit vectors of every variable object's rows, kept transposed (Yt row-major
+// [64 nslabs][ldt = 64 nt], cleared by the caller), then 7x7 blocks Yt[ca..] Yt[cb..]^T for pairs of row offsets (cols: 2 per
+// pair, negative: zero block)
+void launch_forward_multi(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
                           const int32_t* slab_first, const int32_t* obj_row, int32_t nOv);
-void launch_cov_pairs(hipStream_t s, const double* Y, int64_t ldy, int64_t nrows, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out);
+void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

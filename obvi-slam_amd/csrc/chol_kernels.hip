@@ -594,71 +594,73 @@ __global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restr
 // ---------------------------------------------------------------------------------------
 // Covariance blocks (obvi_ba_object_covariances): forward substitution with many right-hand sides on the factor
 // that is already in the tiles, Y = L^-1 E (E: the unit vectors of the object rows), then blocks of S^-1 = Y^T Y.
-// Y is row-major [nt * 64][ldy]; column slab `sl` = columns [64 sl, 64 sl + 64).  Objects are numbered in elimination
-// order, so a slab's columns are zero above the first row of its first object: slab_first[sl] = that tile row; work
-// above it is skipped (Y is cleared beforehand).
-// One workgroup per (tile row k of the level, slab): thread (c, q) owns column c of the slab in rows [16q, 16q + 16).
-//   T_k = E_k - sum_j L_kj Y_j  over the tiles of row k (all of earlier levels),  Y_k = L_kk^-1 T_k.
-// L tiles go through LDS (a wavefront reads one element at a time: broadcast), Y_j is read from global memory:
-// every element once per thread, coalesced along the slab.
+// Y is kept transposed, Yt[64 nslabs][ldt = 64 nt] row-major: right-hand side c of slab `sl` is row 64 sl + c, so the
+// substitution of tile row k has the shape of the factorisation's update,
+//     Yt_k = (E_k - sum_j Yt_j L_kj^T) L_kk^-T          (64x64 blocks, C += A B^T on the matrix cores, tile_abt_mfma)
+// with A = the (slab, j) block of Yt and B = the tile L_kj, both staged in LDS.  One workgroup per (tile row k of the
+// level, slab); the tiles (k, j) of a row belong to earlier levels.  Objects are numbered in elimination order, so a slab
+// is zero left of the first row of its first object: slab_first[sl] = that tile; work left of it is skipped (Yt is
+// cleared beforehand).
 // ---------------------------------------------------------------------------------------
-constexpr int kFwThreads = 256;
-__device__ __forceinline__ void fw_apply_tile(const double (*Lsh)[T], const double* Yj, int64_t ldy, int q, double* acc, double sign) {
-#pragma unroll 4
-  for (int m = 0; m < T; ++m) {
-    const double y = sign * Yj[(int64_t)m * ldy];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = fma(Lsh[16 * q + r][m], y, acc[r]);
+__device__ __forceinline__ void stage_block_ld(double* dst, const double* src, int64_t ld) {   // 64x64 block of a row-major matrix -> LDS (LDM)
+  for (int e = threadIdx.x; e < T * T / 2; e += kThreads) {
+    const int r = e / (T / 2), c2 = e % (T / 2);
+    const double2 v = *reinterpret_cast<const double2*>(src + (int64_t)r * ld + 2 * c2);
+    dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
   }
 }
-__global__ void __launch_bounds__(kFwThreads) k_forward_multi(const double* __restrict__ S, int nt, const int32_t* __restrict__ lvl_k,
-                                                             const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_j,
-                                                             const double* __restrict__ Linv_all, double* Y, int64_t ldy,
-                                                             const int32_t* __restrict__ slab_first) {
-  __shared__ double Lsh[T][T];
+__global__ void __launch_bounds__(kThreads) k_forward_multi(const double* __restrict__ S, int nt, const int32_t* __restrict__ lvl_k,
+                                                           const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_j,
+                                                           const double* __restrict__ Linv_all, double* Yt, int64_t ldt,
+                                                           const int32_t* __restrict__ slab_first) {
+  __shared__ double smem[2 * T * LDM];
+  double* A = smem;
+  double* B = smem + T * LDM;
   const int k = lvl_k[blockIdx.x], sl = blockIdx.y;
   const int first = slab_first[sl];
   if (k < first) return;                          // uniform per workgroup
-  const int tid = threadIdx.x, c = tid % T, q = tid / T;
-  double* Yk = Y + ((int64_t)k * T + 16 * q) * ldy + (int64_t)sl * T + c;
-  double acc[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = Yk[(int64_t)r * ldy];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* Yslab = Yt + (int64_t)sl * T * ldt;
+  f64x4 acc[4] = {};
   for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
     const int j = row_j[e];
-    if (j < first) continue;                      // Y_j is zero in this slab
-    const double* Lt = tile_ptr(const_cast<double*>(S), nt, k, j);
+    if (j < first) continue;                      // Yt_j is zero in this slab
     __syncthreads();
-    for (int x = tid; x < T * T; x += kFwThreads) Lsh[x / T][x % T] = Lt[x];
+    stage_block_ld(A, Yslab + (int64_t)j * T, ldt);
+    stage_tile(B, tile_ptr(const_cast<double*>(S), nt, k, j));
     __syncthreads();
-    fw_apply_tile(Lsh, Y + (int64_t)j * T * ldy + (int64_t)sl * T + c, ldy, q, acc, -1.0);
+    tile_abt_mfma(A, B, acc);
   }
-  // T_k goes through global memory (this workgroup's own rows) so that every thread can read the whole column
-#pragma unroll
-  for (int r = 0; r < 16; ++r) Yk[(int64_t)r * ldy] = acc[r];
-  const double* Li = Linv_all + (int64_t)k * (T * T);
-  __syncthreads();                                // also orders the stores above for the loads below (same workgroup)
-  for (int x = tid; x < T * T; x += kFwThreads) Lsh[x / T][x % T] = Li[x];
-  __threadfence_block();
+  // T = E_k - sum: from the accumulator layout straight into the A operand of the product with L_kk^-T
+  double* Yk = Yslab + (int64_t)k * T;
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0;
-  fw_apply_tile(Lsh, Y + (int64_t)k * T * ldy + (int64_t)sl * T + c, ldy, q, acc, 1.0);   // L^-1 is stored with an explicit zero upper part
-  __syncthreads();                                // every thread has read T_k before it is overwritten
+  for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) Yk[(int64_t)r * ldy] = acc[r];
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rt + (lane >> 4) + 4 * r, col = 16 * wv + (lane & 15);
+      A[row * LDM + col] = Yk[(int64_t)row * ldt + col] - acc[rt][r];
+    }
+  stage_tile(B, Linv_all + (int64_t)k * (T * T));   // L^-1 is stored with an explicit zero upper part
+  __syncthreads();
+  f64x4 out[4] = {};
+  tile_abt_mfma(A, B, out);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Yk[(int64_t)(16 * rt + (lane >> 4) + 4 * r) * ldt + 16 * wv + (lane & 15)] = out[rt][r];
 }
 
-// unit right-hand sides: column 7 ov + a has its one in row obj_row[ov] + a
-__global__ void __launch_bounds__(64) k_cov_seed(double* Y, int64_t ldy, const int32_t* __restrict__ obj_row, int32_t nOv) {
+// unit right-hand sides: right-hand side 7 ov + a has its one in row obj_row[ov] + a
+__global__ void __launch_bounds__(64) k_cov_seed(double* Yt, int64_t ldt, const int32_t* __restrict__ obj_row, int32_t nOv) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= 7 * nOv) return;
-  Y[((int64_t)obj_row[t / 7] + t % 7) * ldy + t] = 1.0;
+  Yt[(int64_t)t * ldt + obj_row[t / 7] + t % 7] = 1.0;
 }
 
-// cov[p][r][k] = sum over rows of Y[row][ca + r] * Y[row][cb + k]; one workgroup per pair; cols[2p] < 0: zero block
+// cov[p][r][k] = Yt[ca + r] . Yt[cb + k] (rows of Yt from first_row on); one workgroup per pair; cols[2p] < 0: zero block
 constexpr int kCovThreads = 256;
-__global__ void __launch_bounds__(kCovThreads) k_cov_pairs(const double* __restrict__ Y, int64_t ldy, int64_t nrows, const int32_t* __restrict__ cols,
+__global__ void __launch_bounds__(kCovThreads) k_cov_pairs(const double* __restrict__ Yt, int64_t ldt, const int32_t* __restrict__ cols,
                                                           const int32_t* __restrict__ first_row, double* __restrict__ out) {
   __shared__ double red[kCovThreads / 64][49];
   const int p = blockIdx.x, ca = cols[2 * p], cb = cols[2 * p + 1];
@@ -666,15 +668,15 @@ __global__ void __launch_bounds__(kCovThreads) k_cov_pairs(const double* __restr
 #pragma unroll
   for (int i = 0; i < 49; ++i) acc[i] = 0.0;
   if (ca >= 0 && cb >= 0) {
-    for (int64_t row = first_row[p] + threadIdx.x; row < nrows; row += kCovThreads) {
-      const double* ya = Y + row * ldy + ca;
-      const double* yb = Y + row * ldy + cb;
+    const double* ya = Yt + (int64_t)ca * ldt;
+    const double* yb = Yt + (int64_t)cb * ldt;
+    for (int64_t x = first_row[p] + threadIdx.x; x < ldt; x += kCovThreads) {
       double b[7];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) b[k] = yb[k];
+      for (int k = 0; k < 7; ++k) b[k] = yb[k * ldt + x];
 #pragma unroll
       for (int r = 0; r < 7; ++r) {
-        const double a = ya[r];
+        const double a = ya[r * ldt + x];
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[7 * r + k] = fma(a, b[k], acc[7 * r + k]);
       }
@@ -747,17 +749,17 @@ void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S,
   }
 }
 
-void launch_forward_multi(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* Y, int64_t ldy, int nslabs,
+void launch_forward_multi(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
                           const int32_t* slab_first, const int32_t* obj_row, int32_t nOv) {
   if (nOv <= 0 || nslabs <= 0) return;
-  hipLaunchKernelGGL(k_cov_seed, dim3((7 * nOv + 63) / 64), dim3(64), 0, s, Y, ldy, obj_row, nOv);
+  hipLaunchKernelGGL(k_cov_seed, dim3((7 * nOv + 63) / 64), dim3(64), 0, s, Yt, ldt, obj_row, nOv);
   for (int l = 0; l < p.nlevels; ++l) {
     const int nk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    if (nk > 0) hipLaunchKernelGGL(k_forward_multi, dim3(nk, nslabs), dim3(kFwThreads), 0, s, S, p.nt, p.lvl_k + p.lvl_k_ptr[l], p.row_ptr, p.row_j, Linv, Y, ldy, slab_first);
+    if (nk > 0) hipLaunchKernelGGL(k_forward_multi, dim3(nk, nslabs), dim3(kThreads), 0, s, S, p.nt, p.lvl_k + p.lvl_k_ptr[l], p.row_ptr, p.row_j, Linv, Yt, ldt, slab_first);
   }
 }
-void launch_cov_pairs(hipStream_t s, const double* Y, int64_t ldy, int64_t nrows, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out) {
-  if (n_pairs > 0) hipLaunchKernelGGL(k_cov_pairs, dim3((unsigned)n_pairs), dim3(kCovThreads), 0, s, Y, ldy, nrows, cols, first_row, out);
+void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out) {
+  if (n_pairs > 0) hipLaunchKernelGGL(k_cov_pairs, dim3((unsigned)n_pairs), dim3(kCovThreads), 0, s, Yt, ldt, cols, first_row, out);
 }
 
 }  // namespace obvi

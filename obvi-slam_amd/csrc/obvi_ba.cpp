@@ -1390,7 +1390,7 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
     return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: the normal equations are rank deficient at the current estimate");
   hipStream_t s = h->stream;
   const int nslabs = (int)((7 * h->nOv + kTile - 1) / kTile);
-  const int64_t ldy = (int64_t)nslabs * kTile, nrows = (int64_t)h->nt * kTile;
+  const int64_t ldt = (int64_t)h->nt * kTile, nrhs = (int64_t)nslabs * kTile;   // Y = L^-1 E transposed: [nrhs][ldt]
   std::vector<int32_t> slab_first(nslabs, h->nt);
   for (int64_t w = 0; w < h->nOv; ++w) {
     const int sl0 = (int)(7 * w / kTile), sl1 = (int)((7 * w + 6) / kTile);
@@ -1402,13 +1402,13 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
     cols[2 * i] = va >= 0 && vb >= 0 ? 7 * va : -1; cols[2 * i + 1] = va >= 0 && vb >= 0 ? 7 * vb : -1;
     first_row[i] = va >= 0 && vb >= 0 ? std::max(h->h_obj_row[va], h->h_obj_row[vb]) / kTile * kTile : 0;   // both columns are zero above
   }
-  h->d_cov_Y.resize((size_t)(nrows * ldy));
-  OBVI_HIP(hipMemsetAsync(h->d_cov_Y.get(), 0, sizeof(double) * (size_t)(nrows * ldy), s));
+  h->d_cov_Y.resize((size_t)(nrhs * ldt));
+  OBVI_HIP(hipMemsetAsync(h->d_cov_Y.get(), 0, sizeof(double) * (size_t)(nrhs * ldt), s));
   h->d_cov_slab.upload(slab_first, s); h->d_cov_cols.upload(cols, s); h->d_cov_first.upload(first_row, s);
   h->d_cov_out.resize((size_t)(49 * n_pairs));
   const CholPlan plan = chol_plan(h);
-  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldy, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv);
-  launch_cov_pairs(s, h->d_cov_Y.get(), ldy, nrows, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get());
+  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldt, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv);
+  launch_cov_pairs(s, h->d_cov_Y.get(), ldt, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get());
   OBVI_HIP(hipGetLastError());
   h->d_cov_out.download(cov49, (size_t)(49 * n_pairs), s);
   sync(h);
