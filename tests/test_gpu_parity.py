@@ -364,3 +364,44 @@ def test_object_covariances_over_a_dissected_factor():
     assert float(np.abs(xg - xo).max()) < 1e-7 * float(np.abs(co).max())
     with pytest.raises(obvi_ba.ObviError):
         g.object_covariances([len(ids)])
+
+
+def test_multi_session_chain_through_the_long_term_map():
+    """BASELINE config #5 in small: session s ends with the long-term map (ellipsoid estimates + their marginal covariances,
+    obvi_ba_object_covariances); session s+1 sees the same objects again and starts from that map as IndependentObjectMapFactor
+    priors (independent_object_map_factor.h:21-33, ltm_trajectory_sequence_executor.py:45-92 chains sessions this way).
+    The chain on the device equals the chain on the oracle, and the map makes a session more certain about every object
+    it holds."""
+    def session(seed):
+        return synth.make_problem(P=60, L=1500, O=6, seed=seed, object_seed=77, min_obj_obs=5, bbox_noise=5.0, object_classes=("bench",))   # the one class whose yaw is observable (dx != dy)
+    prm = helpers.ba_params(max_it=30)
+    maps = {}
+    for name, make in (("oracle", helpers.oracle_ba), ("hip", helpers.product_ba)):
+        s1 = session(101)
+        ba = make(); synth.upload(ba, s1)
+        assert ba.solve(prm).is_solution_usable
+        ids = np.arange(len(s1["objects"]), dtype=np.uint32)
+        mean1, cov1 = ba.get_objects(), ba.object_covariances(ids)
+        seen = np.array([np.any(cov1[o] != 0.0) for o in ids])
+        assert seen.sum() >= 3
+        s2 = session(202)
+        assert np.array_equal(s2["gt_objects"], s1["gt_objects"])               # the same place, another drive
+        s2.update(lt_obj=ids[seen], lt_mean=mean1[seen], lt_cov=cov1[seen].reshape(-1, 49), lt_huber=1.0)
+        ba2 = make(); synth.upload(ba2, s2)
+        s = ba2.solve(prm)
+        assert s.is_solution_usable
+        cov2 = ba2.object_covariances(ids)
+        # information adds up: at the same estimate, the same session without the map is less certain about every mapped object
+        bare = {k: v for k, v in s2.items() if not k.startswith("lt_")}
+        bare.update(poses=ba2.get_poses(), points=ba2.get_points(), objects=ba2.get_objects())
+        free = make(); synth.upload(free, bare)
+        cov_free = free.object_covariances(ids)
+        both = seen & np.array([np.any(cov_free[o] != 0.0) for o in ids])
+        assert both.any()
+        for o in ids[both]:
+            assert np.all(np.diag(cov2[o]) <= np.diag(cov_free[o]) * (1 + 1e-6))
+        maps[name] = (mean1, cov1, ba2.get_objects(), cov2, s.final_cost, seen)
+    (m1o, c1o, m2o, c2o, fo, so), (m1g, c1g, m2g, c2g, fg, sg) = maps["oracle"], maps["hip"]
+    assert np.array_equal(so, sg)
+    assert np.abs(m1g - m1o).max() < 1e-6 and covariance_close(c1g, c1o, 1e-5)
+    assert abs(fg - fo) <= 1e-6 * fo and np.abs(m2g - m2o).max() < 1e-5 and covariance_close(c2g, c2o, 1e-4)
