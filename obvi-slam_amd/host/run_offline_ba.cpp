@@ -2,6 +2,7 @@
 // offline_object_visual_slam_main / run_opt_from_pg_state for a scene whose associations are given.
 //   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv] [--ltm]
 //   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K]   (no GPU: flattening only)
+//   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 // Parameter values: config/base7a_2_fallback.json of the reference.
 #include <cstdlib>
 #include <cstring>
@@ -9,6 +10,7 @@
 #include <iomanip>
 #include <iostream>
 
+#include "obvi_pending_object_estimator.h"
 #include "obvi_runner.h"
 
 using namespace vslam_types_refactor;   // NOLINT
@@ -62,13 +64,14 @@ static pose_graph_optimization::OptimizationSolverParams sp(int it, double ftol)
 int main(int argc, char** argv) {
   if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options]" << std::endl; return 2; }
   SlidingWindowParams sw;
-  int device = 0; std::string csv; bool dump = false, ltm = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  int device = 0; std::string csv; bool dump = false, ltm = false, pending = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
   for (int i = 3; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) csv = argv[++i];
     else if (!std::strcmp(argv[i], "--ltm")) ltm = true;
+    else if (!std::strcmp(argv[i], "--pending-objects")) pending = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
   }
@@ -124,6 +127,33 @@ int main(int argc, char** argv) {
     arr("sp_obj", fp.sp_obj); arr("rl_a", fp.rl_a); arr("rl_b", fp.rl_b);
     out << "\"num_blocks\": " << info.size() << ", \"num_excluded\": " << excluded.size() << "}\n";
     return 0;
+  }
+
+  if (pending) {
+    // every object of the scene as a pending object: rough estimate = the scene's initial ellipsoid, observations = its boxes,
+    // robot poses = the scene's trajectory (constant), pending_object_estimator_params of config/base7a_2_fallback.json
+    MainPgPtr pg = std::make_shared<MainPg>(data.camera_extrinsics_by_camera_, data.camera_intrinsics_by_camera_);
+    for (FrameId f = 0; f <= max_frame_id; ++f) pg->addFrame(f, data.robot_poses_[f]);
+    std::unordered_map<ObjectId, UninitializedEllispoidInfo> info;
+    for (FrameId f = 0; f <= max_frame_id; ++f)
+      for (const auto& b : data.box_obs_by_frame_[f]) {
+        ObjectObservationFactor o; o.frame_id_ = f; o.camera_id_ = b.camera_id; o.object_id_ = b.object_id; o.bounding_box_corners_ = b.corners; o.bounding_box_corners_covariance_ = b.cov;
+        info[b.object_id].observation_factors_.push_back(o);
+      }
+    std::unordered_map<ObjectId, RawEllipsoid> rough;
+    for (auto& i : info) { i.second.semantic_class_ = data.object_class_.at(i.first); rough[i.first] = data.initial_ellipsoids_.at(i.first); }
+    PendingObjectEstimatorParams pe;
+    pe.object_residual_params_ = rp.object_residual_params_;
+    pe.solver_params_ = sp(100, 1e-6);
+    std::unordered_map<ObjectId, RawEllipsoid> refined;
+    obvi_summary summary{};
+    const bool ok = refineInitialEstimateForPendingObjects(rough, info, pg, data.shape_priors_by_class_, pe, device, &refined, &summary);
+    out << "{\"ok\": " << (ok ? "true" : "false") << ", \"iterations\": " << summary.num_iterations << ", \"initial_cost\": " << summary.initial_cost
+        << ", \"final_cost\": " << summary.final_cost << ",\n\"objects\": {";
+    bool f0 = true;
+    for (const auto& o : refined) { out << (f0 ? "" : ",") << "\"" << o.first << "\": ["; for (int k = 0; k < 7; ++k) out << (k ? "," : "") << o.second[k]; out << "]"; f0 = false; }
+    out << "}}\n";
+    return ok ? 0 : 1;
   }
 
   std::function<FrameId(const FrameId&)> window_provider = [&](const FrameId& f) { return provideOptimizationWindow(f, max_frame_id, sw); };

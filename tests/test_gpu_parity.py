@@ -405,3 +405,31 @@ def test_multi_session_chain_through_the_long_term_map():
     assert np.array_equal(so, sg)
     assert np.abs(m1g - m1o).max() < 1e-6 and covariance_close(c1g, c1o, 1e-5)
     assert abs(fg - fo) <= 1e-6 * fo and np.abs(m2g - m2o).max() < 1e-5 and covariance_close(c2g, c2o, 1e-4)
+
+
+def test_pending_object_refinement_configuration():
+    """refineInitialEstimateForPendingObjects (pending_object_estimator.cpp:11-151): one problem over all pending
+    ellipsoids, their bounding-box factors and shape priors, every robot pose constant, no features -- a block-diagonal
+    reduced system with no pose rows.  Rough initial estimates; the device follows the oracle and lands near the truth."""
+    prob = synth.make_problem(P=50, L=200, O=8, seed=9, min_obj_obs=6, bbox_noise=2.0, object_classes=("bench",))   # yaw observable: a well-posed problem
+    rng = np.random.Generator(np.random.MT19937(3))
+    prob["objects"] = prob["gt_objects"].copy()
+    prob["objects"][:, 0:3] += rng.normal(size=(len(prob["objects"]), 3)) * 0.5      # a rough single-view initialisation
+    prob["objects"][:, 4:7] *= np.exp(rng.normal(size=(len(prob["objects"]), 3)) * 0.3)
+    prob["pose_const"][:] = 1
+    prob["poses"] = prob["gt_poses"].copy()
+    o, g = pair(prob, reproj=False, relpose=False)
+    prm = helpers.ba_params(max_it=50, ftol=1e-8)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.is_solution_usable and sg.num_parameters_reduced == so.num_parameters_reduced == 7 * len(prob["objects"])
+    assert sg.num_iterations == so.num_iterations
+    for a, b in zip(o.iterations(), g.iterations()):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost
+    assert np.abs(g.get_objects() - o.get_objects()).max() < 1e-6
+    assert np.array_equal(g.get_poses(), prob["poses"])
+    est = g.get_objects()
+    # started 0.5 m / 30 % off
+    assert np.median(np.linalg.norm(est[:, 0:3] - prob["gt_objects"][:, 0:3], axis=1)) < 0.15
+    assert np.median(np.abs(est[:, 4:7] / prob["gt_objects"][:, 4:7] - 1.0)) < 0.15
+    ids = np.arange(len(est))
+    assert covariance_close(g.object_covariances(ids), o.object_covariances(ids), 1e-6)

@@ -160,3 +160,37 @@ def test_offline_runner_session(driver, scene, tmp_path):
                       "total_ceres_time,linear_solver_time,jacobian_time,residual_time,num_ceres_iterations")
     rows = open(csv).read().strip().split("\n")[1:]
     assert len(rows) >= 2 * len(lba1)
+
+
+@pytest.mark.gpu
+def test_pending_object_estimator_mirror(driver, tmp_path):
+    """refineInitialEstimateForPendingObjects (pending_object_estimator.cpp:11-151) through the C++ mirror against the same
+    problem pushed through the binding: every object of a scene, its boxes, its class prior; poses constant.  Objects of the
+    one class with an observable yaw (dx != dy), so that the minimum is a point and the two runs can be compared digit by digit."""
+    prob = synth.make_problem(P=60, L=300, O=5, seed=33, min_obj_obs=8, bbox_noise=3.0, object_classes=("bench",))
+    path = str(tmp_path / "scene.txt")
+    new_id = scene_io.write_scene(prob, path)
+    out = str(tmp_path / "pending.json")
+    subprocess.check_call([driver, path, out, "--pending-objects"], timeout=300)
+    res = json.load(open(out))
+    assert res["ok"] and res["final_cost"] < res["initial_cost"]
+    # the same problem through the binding: scene objects only (renumbered), poses constant, bounding boxes + shape priors
+    old_of = {v: k for k, v in new_id.items()}
+    keep = np.array([int(o) in new_id for o in prob["bb_obj"]])
+    q = dict(prob)
+    q["objects"] = np.array([prob["objects"][old_of[i]] for i in range(len(new_id))])
+    q["object_const"] = np.zeros(len(new_id), np.uint8)
+    q["bb_obj"] = np.array([new_id[int(o)] for o in prob["bb_obj"][keep]], dtype=np.uint32)
+    for k in ("bb_pose", "bb_cam", "bb_corners", "bb_cov"):
+        q[k] = prob[k][keep]
+    q["sp_obj"] = np.arange(len(new_id), dtype=np.uint32)
+    q["sp_mean"] = np.array([prob["sp_mean"][old_of[i]] for i in range(len(new_id))])
+    q["sp_cov"] = np.array([prob["sp_cov"][old_of[i]] for i in range(len(new_id))])
+    q["pose_const"] = np.ones(len(prob["poses"]), np.uint8)
+    g = helpers.product_ba(); synth.upload(g, q, reproj=False, relpose=False)
+    s = g.solve(helpers.ba_params(max_it=100, ftol=1e-6, radius=1e4, max_radius=1e16))     # the estimator leaves the radii at Ceres' defaults
+    assert s.num_iterations == res["iterations"]
+    assert abs(s.initial_cost - res["initial_cost"]) <= 1e-9 * s.initial_cost and abs(s.final_cost - res["final_cost"]) <= 1e-8 * s.final_cost
+    est = g.get_objects()
+    for i in range(len(new_id)):
+        assert np.abs(np.array(res["objects"][str(i)]) - est[i]).max() < 1e-6
