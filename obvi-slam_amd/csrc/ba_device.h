@@ -219,7 +219,7 @@ void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double*
 // [64 nslabs][ldt = 64 nt], cleared by the caller), then 7x7 blocks Yt[ca..] Yt[cb..]^T for pairs of row offsets (cols: 2 per
 // pair, negative: zero block)
 void launch_forward_multi(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
-                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv);
+                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split /* host [nlevels]: workgroups per row, or null */);
 void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out);
 
 }  // namespace obvi

@@ -609,10 +609,13 @@ __device__ __forceinline__ void stage_block_ld(double* dst, const double* src, i
     dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
   }
 }
+// nsplit = 1: the whole row in one workgroup.  nsplit > 1 (levels with long rows, i.e. the separators near the root, where
+// a level has few rows of 100+ tiles): workgroup z takes every nsplit-th tile of the row and subtracts its partial sum from
+// E_k atomically; k_forward_multi_diag then applies L_kk^-T.
 __global__ void __launch_bounds__(kThreads) k_forward_multi(const double* __restrict__ S, int nt, const int32_t* __restrict__ lvl_k,
                                                            const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_j,
                                                            const double* __restrict__ Linv_all, double* Yt, int64_t ldt,
-                                                           const int32_t* __restrict__ slab_first) {
+                                                           const int32_t* __restrict__ slab_first, int nsplit) {
   __shared__ double smem[2 * T * LDM];
   double* A = smem;
   double* B = smem + T * LDM;
@@ -622,17 +625,27 @@ __global__ void __launch_bounds__(kThreads) k_forward_multi(const double* __rest
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double* Yslab = Yt + (int64_t)sl * T * ldt;
   f64x4 acc[4] = {};
-  for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
+  bool any = false;
+  for (int e = row_ptr[k] + (int)blockIdx.z; e < row_ptr[k + 1]; e += nsplit) {
     const int j = row_j[e];
     if (j < first) continue;                      // Yt_j is zero in this slab
+    any = true;
     __syncthreads();
     stage_block_ld(A, Yslab + (int64_t)j * T, ldt);
     stage_tile(B, tile_ptr(const_cast<double*>(S), nt, k, j));
     __syncthreads();
     tile_abt_mfma(A, B, acc);
   }
-  // T = E_k - sum: from the accumulator layout straight into the A operand of the product with L_kk^-T
   double* Yk = Yslab + (int64_t)k * T;
+  if (nsplit > 1) {
+    if (!any) return;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) unsafeAtomicAdd(&Yk[(int64_t)(16 * rt + (lane >> 4) + 4 * r) * ldt + 16 * wv + (lane & 15)], -acc[rt][r]);
+    return;
+  }
+  // T = E_k - sum: from the accumulator layout straight into the A operand of the product with L_kk^-T
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
@@ -642,6 +655,25 @@ __global__ void __launch_bounds__(kThreads) k_forward_multi(const double* __rest
       A[row * LDM + col] = Yk[(int64_t)row * ldt + col] - acc[rt][r];
     }
   stage_tile(B, Linv_all + (int64_t)k * (T * T));   // L^-1 is stored with an explicit zero upper part
+  __syncthreads();
+  f64x4 out[4] = {};
+  tile_abt_mfma(A, B, out);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Yk[(int64_t)(16 * rt + (lane >> 4) + 4 * r) * ldt + 16 * wv + (lane & 15)] = out[rt][r];
+}
+__global__ void __launch_bounds__(kThreads) k_forward_multi_diag(int nt, const int32_t* __restrict__ lvl_k, const double* __restrict__ Linv_all, double* Yt, int64_t ldt,
+                                                                const int32_t* __restrict__ slab_first) {
+  __shared__ double smem[2 * T * LDM];
+  double* A = smem;
+  double* B = smem + T * LDM;
+  const int k = lvl_k[blockIdx.x], sl = blockIdx.y;
+  if (k < slab_first[sl]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* Yk = Yt + (int64_t)sl * T * ldt + (int64_t)k * T;
+  stage_block_ld(A, Yk, ldt);
+  stage_tile(B, Linv_all + (int64_t)k * (T * T));
   __syncthreads();
   f64x4 out[4] = {};
   tile_abt_mfma(A, B, out);
@@ -750,12 +782,15 @@ void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S,
 }
 
 void launch_forward_multi(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
-                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv) {
+                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split) {
   if (nOv <= 0 || nslabs <= 0) return;
   hipLaunchKernelGGL(k_cov_seed, dim3((7 * nOv + 63) / 64), dim3(64), 0, s, Yt, ldt, obj_row, nOv);
   for (int l = 0; l < p.nlevels; ++l) {
     const int nk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
-    if (nk > 0) hipLaunchKernelGGL(k_forward_multi, dim3(nk, nslabs), dim3(kThreads), 0, s, S, p.nt, p.lvl_k + p.lvl_k_ptr[l], p.row_ptr, p.row_j, Linv, Yt, ldt, slab_first);
+    if (nk <= 0) continue;
+    const int nsplit = row_split ? row_split[l] : 1;
+    hipLaunchKernelGGL(k_forward_multi, dim3(nk, nslabs, nsplit), dim3(kThreads), 0, s, S, p.nt, p.lvl_k + p.lvl_k_ptr[l], p.row_ptr, p.row_j, Linv, Yt, ldt, slab_first, nsplit);
+    if (nsplit > 1) hipLaunchKernelGGL(k_forward_multi_diag, dim3(nk, nslabs), dim3(kThreads), 0, s, p.nt, p.lvl_k + p.lvl_k_ptr[l], Linv, Yt, ldt, slab_first);
   }
 }
 void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out) {

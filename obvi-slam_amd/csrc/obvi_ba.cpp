@@ -98,6 +98,7 @@ struct obvi_ba_handle {
   DevBuf<int32_t> d_row_ptr, d_row_j, d_cov_slab, d_cov_cols, d_cov_first;   // row structure of L; covariance extraction scratch
   DevBuf<double> d_cov_Y, d_cov_out;
   std::vector<int32_t> h_obj_vid;          // object -> reduced object index (elimination order) or -1
+  std::vector<int32_t> h_row_split;        // per level: workgroups per tile row in the multi-right-hand-side forward substitution
   DevBuf<uint8_t> d_upd_flag, d_is_pad;
   DevBuf<int32_t> d_job_signal, d_k_need, d_diag_done, d_pre_ptr, d_pre_j;
   DevBuf<int32_t> d_pose_row, d_obj_row;
@@ -748,6 +749,14 @@ void prepare(obvi_ba_handle* h) {
     }
     if (row_j.empty()) row_j.push_back(0);
     h->d_row_ptr.upload(row_ptr, h->stream); h->d_row_j.upload(row_j, h->stream);
+    // levels whose rows are long (separators near the root) spread a row over several workgroups: about 8 tiles each, at most 16
+    const int row_tiles = std::max(1, std::getenv("OBVI_COV_ROW_TILES") ? std::atoi(std::getenv("OBVI_COV_ROW_TILES")) : 8);   // tuning knob
+    h->h_row_split.assign(nlev, 1);
+    for (int l = 0; l < nlev; ++l) {
+      int longest = 0;
+      for (int32_t k : by_level[l]) longest = std::max(longest, row_ptr[k + 1] - row_ptr[k]);
+      h->h_row_split[l] = std::min(16, std::max(1, longest / row_tiles));
+    }
   }
   h->chol_flops = flops;
   h->n_trsm_jobs = (int64_t)(trsm_ik.size() / 2);
@@ -1407,7 +1416,7 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   h->d_cov_slab.upload(slab_first, s); h->d_cov_cols.upload(cols, s); h->d_cov_first.upload(first_row, s);
   h->d_cov_out.resize((size_t)(49 * n_pairs));
   const CholPlan plan = chol_plan(h);
-  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldt, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv);
+  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldt, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv, h->h_row_split.data());
   launch_cov_pairs(s, h->d_cov_Y.get(), ldt, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get());
   OBVI_HIP(hipGetLastError());
   h->d_cov_out.download(cov49, (size_t)(49 * n_pairs), s);

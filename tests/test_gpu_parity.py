@@ -350,8 +350,13 @@ def test_object_covariances_match_the_oracle(small):
     assert covariance_close(g.object_covariances(ids), o.object_covariances(ids), 1e-8)
 
 
-def test_object_covariances_over_a_dissected_factor():
-    """Several dissection levels, objects spread over the tree, a constant object, an object seen by constant poses only."""
+@pytest.mark.parametrize("row_tiles", [None, "1"])
+def test_object_covariances_over_a_dissected_factor(row_tiles, monkeypatch):
+    """Several dissection levels, objects spread over the tree, a constant object, an object seen by constant poses only.
+    OBVI_COV_ROW_TILES=1 spreads every row of the forward substitution over several workgroups (the path the long rows of a big
+    problem take)."""
+    if row_tiles:
+        monkeypatch.setenv("OBVI_COV_ROW_TILES", row_tiles)
     prob = synth.make_problem(P=260, L=5000, O=24, seed=11, min_obj_obs=5, const_poses=3)
     prob["object_const"][5] = 1
     o, g = pair(prob)
