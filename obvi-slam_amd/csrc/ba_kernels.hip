@@ -409,34 +409,58 @@ __device__ __forceinline__ void add_diag_block(double* Hd, double* gd, int d, co
 __global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                 const double* __restrict__ objects, ReducedDev rd, double* scal) {
   const int64_t i = blockIdx.x * 64LL + threadIdx.x;
-  double cost = 0.0;
+  double cost = 0.0, w = 0.0;
+  double r[4] = {0.0, 0.0, 0.0, 0.0}, Je[28], Jp[24];
+  int32_t ov = -1, pv = -1;
   if (i < sf.n_bb && sf.bb_active[i]) {
     const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
-    const int32_t ov = b.obj_vid[o], pv = b.pose_vid[p];
+    ov = b.obj_vid[o]; pv = b.pose_vid[p];
     if (ov >= 0 || pv >= 0) {
       D13 res[4];
       bbox_eval(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-      double r[4], Je[28], Jp[24];
       for (int a = 0; a < 4; ++a) {
         r[a] = res[a].v;
         for (int k = 0; k < 7; ++k) Je[7 * a + k] = res[a].d[k];
         for (int k = 0; k < 6; ++k) Jp[6 * a + k] = res[a].d[7 + k];
       }
-      double rho0, w;
+      double rho0;
       huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
       cost = 0.5 * rho0;
-      if (ov >= 0) add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, Je, r, 4, w);
-      if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + 6 * (int64_t)pv, 6, Jp, r, 4, w);
-      if (ov >= 0 && pv >= 0) {
-        // off-diagonal block in the lower triangle of the tile grid: whichever of the two blocks is eliminated later is the row
-        const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
-        const bool obj_low = orow > prow;
-        for (int x = 0; x < 7; ++x) for (int y = 0; y < 6; ++y) {
-          double acc = 0.0;
-          for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Jp[6 * a + y];
-          atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc);
-        }
+    } else { ov = pv = -1; }
+  }
+  if (ov < 0) for (int k = 0; k < 28; ++k) Je[k] = 0.0;
+  // Object block.  Factors usually arrive grouped by object, so the lanes of a wavefront would hit the same 35 addresses with
+  // 64 atomics each: when every lane that has an object has the same one, the lanes are summed first and one lane adds.
+  int32_t lo = ov >= 0 ? ov : INT32_MAX, hi = ov;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+  if (hi >= 0 && lo == hi) {
+    double* Hd = rd.Hdiag + 36 * b.nPv + 49 * (int64_t)hi;
+    double* gd = rd.g + 6 * b.nPv + 7 * (int64_t)hi;
+    for (int x = 0; x < 7; ++x) {
+      for (int y = 0; y <= x; ++y) {
+        double acc = 0.0;
+        for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Je[7 * a + y];
+        acc = wave_sum(w * acc);
+        if (threadIdx.x == 0) atomic_add_f64(Hd + 7 * x + y, acc);
       }
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * r[a];
+      acc = wave_sum(w * acc);
+      if (threadIdx.x == 0) atomic_add_f64(gd + x, acc);
+    }
+  } else if (ov >= 0) {
+    add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, Je, r, 4, w);
+  }
+  if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + 6 * (int64_t)pv, 6, Jp, r, 4, w);
+  if (ov >= 0 && pv >= 0) {
+    // off-diagonal block in the lower triangle of the tile grid: whichever of the two blocks is eliminated later is the row
+    const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
+    const bool obj_low = orow > prow;
+    for (int x = 0; x < 7; ++x) for (int y = 0; y < 6; ++y) {
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Jp[6 * a + y];
+      atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc);
     }
   }
   cost = wave_sum(cost);
