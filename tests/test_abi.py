@@ -62,6 +62,7 @@ def test_invalid_arguments(lib):
     h = C.c_void_p()
     assert lib.obvi_ba_create(C.byref(bad), C.byref(h)) == -1
     assert lib.obvi_ba_solve(None, None, None) == -1
+    assert lib.obvi_ba_object_covariances(None, C.c_int64(0), None, None, None) == -1
 
 
 def test_generator_shapes():
