@@ -438,3 +438,14 @@ def test_pending_object_refinement_configuration():
     assert np.median(np.abs(est[:, 4:7] / prob["gt_objects"][:, 4:7] - 1.0)) < 0.15
     ids = np.arange(len(est))
     assert covariance_close(g.object_covariances(ids), o.object_covariances(ids), 1e-6)
+
+
+def test_object_covariances_at_local_ba_size():
+    """500 keyframes / 50 000 features / 50 objects (BASELINE config #2 with objects): ~60 tile columns, rows of the forward
+    substitution long enough to be spread over workgroups with the default setting."""
+    prob = synth.make_problem(P=500, L=50000, O=50, seed=3, const_poses=1, min_obj_obs=10)
+    o, g = pair(prob)
+    ids = np.arange(len(prob["objects"]))
+    co, cg = o.object_covariances(ids), g.object_covariances(ids)
+    assert np.count_nonzero(np.abs(co).max(axis=(1, 2))) >= 40
+    assert covariance_close(cg, co, 1e-8)
