@@ -19,6 +19,7 @@
 #include <limits>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ba_device.h"
@@ -242,11 +243,36 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   return c;
 }
 
+// Host threads of the symbolic phase (OBVI_HOST_THREADS, default: the machine's, at most 16).  fn(part, begin, end) gets
+// contiguous ranges in order, so results concatenated by part are those of the sequential loop.
+int host_threads() {
+  const char* v = std::getenv("OBVI_HOST_THREADS");
+  const int n = v ? std::atoi(v) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  return std::max(1, n);
+}
+template <class F>
+void parallel_ranges(int64_t n, int parts, F&& fn) {
+  parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n));
+  if (parts == 1) { fn(0, (int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < parts; ++t) th.emplace_back([&, t]() { fn(t, n * t / parts, n * (t + 1) / parts); });
+  for (auto& x : th) x.join();
+}
+
 // ---------------------------------------------------------------------------------------
 // Reduced program [Ceres-doc Program::RemoveFixedBlocks], Schur pair lists, tile plan.
 // ---------------------------------------------------------------------------------------
 void prepare(obvi_ba_handle* h) {
   if (!h->dirty) return;
+  // OBVI_DEBUG_PREPARE: stage times of the symbolic phase on stderr
+  const bool stage_times = std::getenv("OBVI_DEBUG_PREPARE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* name) {
+    if (!stage_times) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "prepare: %-28s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   const int64_t P = h->P, L = h->L, O = h->O;
   std::vector<uint8_t> pose_used(P, 0), obj_used(O, 0), point_used(L, 0);
   int64_t nres = 0;
@@ -289,6 +315,7 @@ void prepare(obvi_ba_handle* h) {
   for (int64_t l = 0; l < L; ++l) if (!h->h_point_const[l] && point_used[l]) { point_var[l] = 1; h->nLv++; }
   const int64_t nPv = h->nPv;
 
+  stage("reduced program");
   // ---- elimination order: nested dissection of the frame chain, objects inside the tree.  reach[f] = largest
   //      frame rank f couples to through a shared point or an odometry factor; a separator
   //      [s0, s1) with s1 > reach of everything left of s0 decouples the two sides.  Cut positions
@@ -428,6 +455,7 @@ void prepare(obvi_ba_handle* h) {
   const int32_t nt = h->nt;
   const int64_t m_pad = (int64_t)nt * kTile;
 
+  stage("ordering");
   // ---- Schur complement work lists.  k_schur_window takes every ordered observation pair (i >= j) of a point whose
   //      frame distance is below the window's offset count; a point is visited once per row chunk that holds one of
   //      its observations.  The remaining pairs (a, b) with row(a) >= row(b) go to k_schur_blocks grouped by 6x6
@@ -447,11 +475,27 @@ void prepare(obvi_ba_handle* h) {
   std::vector<Visit> visit_list;
   int64_t n_window_pairs = 0;
   bool any_twin = false;
+  // pose pairs that share a point: collected in a bitmap (one store per pair of sightings) and turned into tile marks once per
+  // pose pair afterwards -- a point contributes k (k + 1) / 2 pairs and most of them repeat
+  const bool pair_bitmap = h->nPv <= 16384;
+  std::vector<uint8_t> pose_pair(pair_bitmap ? (size_t)h->nPv * (size_t)h->nPv : 0, 0);
   {
+    // points are independent: ranges of points on host threads (the bitmap is shared: every writer stores the same 1), lists joined in
+    // point order.  Without the bitmap the tile marks go straight into the mask: one thread.
+    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 4096)) : 1;   // a thread is worth starting for a few thousand points
+    std::vector<std::vector<Pair>> pairs_t(parts);
+    std::vector<std::vector<Visit>> visits_t(parts);
+    std::vector<int64_t> window_pairs_t(parts, 0);
+    std::vector<uint8_t> twin_t(parts, 0);
+    parallel_ranges(L, parts, [&](int part, int64_t l0, int64_t l1) {
     struct Ob { uint32_t a; int32_t vid, f; };
     std::vector<Ob> obs;
     std::vector<int32_t> chunks;
-    for (int64_t l = 0; l < L; ++l) {
+    std::vector<Pair>& pairs = pairs_t[part];
+    std::vector<Visit>& visit_list = visits_t[part];
+    int64_t n_window_pairs = 0;
+    bool any_twin = false;
+    for (int64_t l = l0; l < l1; ++l) {
       if (!point_var[l]) continue;
       const uint32_t beg = h->h_point_ptr[l], end = h->h_point_ptr[l + 1];
       obs.clear();
@@ -487,7 +531,8 @@ void prepare(obvi_ba_handle* h) {
       for (size_t i = 0; i < obs.size(); ++i)
         for (size_t j = 0; j <= i; ++j) {
           const Ob& x = obs[i]; const Ob& y = obs[j];
-          mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
+          if (pair_bitmap) __atomic_store_n(&pose_pair[(size_t)std::max(x.vid, y.vid) * (size_t)h->nPv + (size_t)std::min(x.vid, y.vid)], (uint8_t)1, __ATOMIC_RELAXED);
+          else mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
           // inside the strip of the later frame's chunk?  (same test as the kernel's inverse map)
           const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
           if (windowed && fq >= (fp / SR) * SR - SBACK) { ++n_window_pairs; continue; }
@@ -496,18 +541,42 @@ void prepare(obvi_ba_handle* h) {
           if (i != j && x.vid == y.vid) pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, lo.a, hi.a});
         }
     }
+    window_pairs_t[part] = n_window_pairs; twin_t[part] = any_twin ? 1 : 0;
+    });
+    for (int t = 0; t < parts; ++t) {
+      pairs.insert(pairs.end(), pairs_t[t].begin(), pairs_t[t].end());
+      visit_list.insert(visit_list.end(), visits_t[t].begin(), visits_t[t].end());
+      n_window_pairs += window_pairs_t[t]; any_twin = any_twin || twin_t[t];
+      std::vector<Pair>().swap(pairs_t[t]); std::vector<Visit>().swap(visits_t[t]);
+    }
   }
+  if (pair_bitmap)
+    for (int64_t hi = 0; hi < h->nPv; ++hi) {
+      const uint8_t* row = &pose_pair[(size_t)hi * (size_t)h->nPv];
+      for (int64_t lo = 0; lo <= hi; ++lo) if (row[lo]) mark(h->h_pose_row[hi], 6, h->h_pose_row[lo], 6);
+    }
+  stage("schur pairs / visits");
   // one work list per (chunk, column group): the visits with a tile in that group
   constexpr int kGroups = (kSchurWindowFrames * 6 / 16) / kSchurGroupCols, kGroupBits = 3 * kSchurGroupCols;
   struct GVisit { int32_t chunk, group; uint32_t l, beg, k; bool twin; uint32_t bits; };
   std::vector<GVisit> gv;
-  gv.reserve(2 * visit_list.size());
-  for (const Visit& v : visit_list)
-    for (int g = 0; g < kGroups; ++g) {
-      const uint32_t bits = (uint32_t)(v.tiles >> (kGroupBits * g)) & ((1u << kGroupBits) - 1u);
-      if (bits) gv.push_back({v.chunk, g, v.l, v.beg, v.k, v.twin, bits});
-    }
-  std::stable_sort(gv.begin(), gv.end(), [](const GVisit& x, const GVisit& y) { return x.chunk < y.chunk || (x.chunk == y.chunk && x.group > y.group); });
+  {
+    // ordered by chunk, then by group descending, visits of a list in point order: a counting sort over the (chunk, group) buckets
+    int32_t max_chunk = -1;
+    for (const Visit& v : visit_list) max_chunk = std::max(max_chunk, v.chunk);
+    std::vector<size_t> start((size_t)(max_chunk + 1) * kGroups + 1, 0);
+    auto bucket = [&](int32_t chunk, int g) { return (size_t)chunk * kGroups + (size_t)(kGroups - 1 - g); };
+    auto group_bits = [&](const Visit& v, int g) { return (uint32_t)(v.tiles >> (kGroupBits * g)) & ((1u << kGroupBits) - 1u); };
+    for (const Visit& v : visit_list)
+      for (int g = 0; g < kGroups; ++g) if (group_bits(v, g)) ++start[bucket(v.chunk, g) + 1];
+    for (size_t b2 = 1; b2 < start.size(); ++b2) start[b2] += start[b2 - 1];
+    gv.resize(start.back());
+    for (const Visit& v : visit_list)
+      for (int g = 0; g < kGroups; ++g) {
+        const uint32_t bits = group_bits(v, g);
+        if (bits) gv[start[bucket(v.chunk, g)]++] = {v.chunk, g, v.l, v.beg, v.k, v.twin, bits};
+      }
+  }
   // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
   const int64_t slice = std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
   // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
@@ -519,8 +588,7 @@ void prepare(obvi_ba_handle* h) {
   std::vector<int32_t> wg_f0, wg_group;
   visits.reserve(4 * gv.size());
   constexpr uint32_t kBatchSlots = kSchurBatchBytes / 144;
-  uint32_t rec[4];
-  auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out) {
+  auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) {
     const int32_t fbase = v.chunk * SR - SBACK;
     const int32_t gA0 = SBACK, gA1 = kSchurWindowFrames - 1;                                                     // row frames (strip offsets)
     const int32_t gB0 = (16 * kSchurGroupCols * v.group) / 6, gB1 = (16 * kSchurGroupCols * (v.group + 1) - 1) / 6;   // column frames of the group
@@ -562,31 +630,47 @@ void prepare(obvi_ba_handle* h) {
     rec[2] = tail | (layer << 16);
     rec[3] = v.bits;
   };
-  std::vector<uint32_t> vs;
+  // the workgroups (slices of the work lists) are independent: ranges of them on host threads, joined in order
+  struct WgRange { size_t w, we; int32_t chunk, group; };
+  std::vector<WgRange> wgs;
   for (size_t q = 0; q < gv.size();) {
     size_t e = q;
     while (e < gv.size() && gv[e].chunk == gv[q].chunk && gv[e].group == gv[q].group) ++e;
     const int64_t n = (int64_t)(e - q), parts = (n + slice - 1) / slice, per = (n + parts - 1) / parts;
-    for (size_t w = q; w < e; w += (size_t)per) {
-      const size_t we = std::min(e, w + (size_t)per);
-      uint32_t used = 0, count = 0;
-      for (size_t t = w; t < we; ++t) {
-        visit_slots(gv[t], used, vs);
-        if (count == (uint32_t)kSchurBatchVisits || used + (uint32_t)vs.size() > kBatchSlots) {
-          bfirst.push_back((uint32_t)(visits.size() / 4)); bslot.push_back((uint32_t)slot_src.size()); used = 0; count = 0;
-          visit_slots(gv[t], used, vs);
-        }
-        visits.insert(visits.end(), rec, rec + 4);
-        slot_src.insert(slot_src.end(), vs.begin(), vs.end());
-        used += (uint32_t)vs.size(); ++count;
-      }
-      bfirst.push_back((uint32_t)(visits.size() / 4)); bslot.push_back((uint32_t)slot_src.size());
-      wg_bptr.push_back((uint32_t)(bfirst.size() - 1));
-      wg_f0.push_back(gv[q].chunk * SR);
-      wg_group.push_back(gv[q].group);
-    }
+    for (size_t w = q; w < e; w += (size_t)per) wgs.push_back({w, std::min(e, w + (size_t)per), gv[q].chunk, gv[q].group});
     q = e;
   }
+  struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches; };
+  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 16384));
+  std::vector<BatchLists> lists_t(parts2);
+  parallel_ranges((int64_t)wgs.size(), parts2, [&](int part, int64_t g0, int64_t g1) {
+    BatchLists& o = lists_t[part];
+    std::vector<uint32_t> vs;
+    uint32_t rec[4];
+    for (int64_t g = g0; g < g1; ++g) {
+      uint32_t used = 0, count = 0, nb = 0;
+      for (size_t t = wgs[g].w; t < wgs[g].we; ++t) {
+        visit_slots(gv[t], used, vs, rec);
+        if (count == (uint32_t)kSchurBatchVisits || used + (uint32_t)vs.size() > kBatchSlots) {
+          o.end_visit.push_back((uint32_t)(o.visits.size() / 4)); o.end_slot.push_back((uint32_t)o.slot_src.size()); ++nb; used = 0; count = 0;
+          visit_slots(gv[t], used, vs, rec);
+        }
+        o.visits.insert(o.visits.end(), rec, rec + 4);
+        o.slot_src.insert(o.slot_src.end(), vs.begin(), vs.end());
+        used += (uint32_t)vs.size(); ++count;
+      }
+      o.end_visit.push_back((uint32_t)(o.visits.size() / 4)); o.end_slot.push_back((uint32_t)o.slot_src.size()); ++nb;
+      o.wg_batches.push_back(nb);
+    }
+  });
+  for (const BatchLists& o : lists_t) {
+    const uint32_t voff = (uint32_t)(visits.size() / 4), soff = (uint32_t)slot_src.size();
+    visits.insert(visits.end(), o.visits.begin(), o.visits.end());
+    slot_src.insert(slot_src.end(), o.slot_src.begin(), o.slot_src.end());
+    for (size_t b = 0; b < o.end_visit.size(); ++b) { bfirst.push_back(voff + o.end_visit[b]); bslot.push_back(soff + o.end_slot[b]); }
+    for (uint32_t nb : o.wg_batches) wg_bptr.push_back(wg_bptr.back() + nb);
+  }
+  for (const WgRange& g : wgs) { wg_f0.push_back(g.chunk * SR); wg_group.push_back(g.group); }
   h->schur_twins = any_twin ? 1 : 0;
   h->nchunks = (int64_t)wg_f0.size();
   h->npairs_window = n_window_pairs;
@@ -605,6 +689,7 @@ void prepare(obvi_ba_handle* h) {
   h->npairs = (int64_t)pairs.size();
   pairs.clear(); pairs.shrink_to_fit();
 
+  stage("schur batches");
   // ---- tile mask of the reduced matrix (lower triangle) and symbolic fill ----
   for (int k = 0; k < nt; ++k) mask[(size_t)k * nt + k] = 1;
   for (int64_t i = 0; i < h->n_bb; ++i) {
@@ -630,6 +715,7 @@ void prepare(obvi_ba_handle* h) {
     for (size_t x = beg; x < col_i.size(); ++x) for (size_t y = beg; y <= x; ++y) mask[(size_t)col_i[x] * nt + col_i[y]] = 1;
     col_ptr[k + 1] = (int32_t)col_i.size();
   }
+  stage("tile mask + fill");
   // levels of the tile elimination tree: k depends on every j < k with L(k,j) != 0
   std::vector<int32_t> level(nt, 0);
   int32_t nlev = 0;
@@ -731,6 +817,7 @@ void prepare(obvi_ba_handle* h) {
     h->h_rh_ptr[l + 1] = (int32_t)rh_i.size();
     if (std::getenv("OBVI_DEBUG_PLAN")) std::fprintf(stderr, "level %d: columns %zu (first %d) trsm %zu update jobs %zu (critical %d) products %zu slices %d\n", l, by_level[l].size(), by_level[l].empty() ? -1 : by_level[l][0], ik.size(), jobs.size(), h->h_crit_upd[l], trips.size(), sl);
   }
+  stage("level jobs");
   // backward substitution, row oriented: one workgroup per tile of L
   std::vector<int32_t> bw_kj;
   h->h_bw_ptr.assign(nlev + 1, 0);
@@ -765,6 +852,7 @@ void prepare(obvi_ba_handle* h) {
   for (int i = 0; i < nt; ++i) for (int j = 0; j <= i; ++j) if (mask[(size_t)i * nt + j]) { tiles.push_back(i); tiles.push_back(j); }
   h->ntiles = (int32_t)(tiles.size() / 2);
 
+  stage("lists");
   // ---- upload ----
   hipStream_t s = h->stream;
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
@@ -809,6 +897,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
   h->d_pc.resize(2 * ((size_t)P + 1)); h->d_pc_c.resize(2 * ((size_t)P + 1));   // records, then the field-major copy (k_pose_cache)
   sync(h);  // host vectors above go out of scope
+  stage("upload + allocations");
   h->dirty = false; h->pc_valid = false; h->tiles_cleared = false;
 }
 
