@@ -1178,21 +1178,27 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
   }
-  for (int64_t l = 0; l < h->L; ++l)
-    std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], [&](uint32_t x, uint32_t y) { return pose_idx[x] < pose_idx[y] || (pose_idx[x] == pose_idx[y] && x < y); });
+  const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 65536));   // ranges of points / observations on host threads
+  parallel_ranges(h->L, threads, [&](int, int64_t l0, int64_t l1) {
+    auto before = [&](uint32_t x, uint32_t y) { return pose_idx[x] < pose_idx[y] || (pose_idx[x] == pose_idx[y] && x < y); };
+    for (int64_t l = l0; l < l1; ++l)
+      if (!std::is_sorted(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before)) std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before);
+  });
   h->n_rp = n; h->rp_huber = huber;
   h->h_rp_perm = perm; h->h_point_ptr = ptr;
   h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
   std::vector<uint16_t> cam(n);
   std::vector<double2> pix(n);
   std::vector<double> sg(n);
-  for (int64_t a = 0; a < n; ++a) {
-    const uint32_t i = perm[a];
-    h->h_rp_inv[i] = (uint32_t)a;
-    h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i]; cam[a] = cam_idx ? cam_idx[i] : 0;
-    pix[a] = make_double2(pixel[2 * (int64_t)i], pixel[2 * (int64_t)i + 1]);
-    sg[a] = sigma ? sigma[i] : sigma_scalar;
-  }
+  parallel_ranges(n, threads, [&](int, int64_t a0, int64_t a1) {
+    for (int64_t a = a0; a < a1; ++a) {
+      const uint32_t i = perm[a];
+      h->h_rp_inv[i] = (uint32_t)a;
+      h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i]; cam[a] = cam_idx ? cam_idx[i] : 0;
+      pix[a] = make_double2(pixel[2 * (int64_t)i], pixel[2 * (int64_t)i + 1]);
+      sg[a] = sigma ? sigma[i] : sigma_scalar;
+    }
+  });
   hipStream_t s = h->stream;
   {   // k_point_pass: the observation list cut into wavefront-sized pieces (<= 64 observations, whole points); longer tracks go to the per-point kernel
     std::vector<uint32_t> wave_obs, long_points;   // wave_obs: (first observation, count) per piece
@@ -1224,10 +1230,10 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   for (int64_t p = 0; p < h->P; ++p) pptr[p + 1] += pptr[p];
   {
     std::vector<uint32_t> cur(pptr.begin(), pptr.end() - 1);
-    for (int64_t a = 0; a < n; ++a) {
-      const uint32_t k = cur[h->h_rp_pose[a]]++;
-      h->h_rq_src[k] = (uint32_t)a; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a];
-    }
+    for (int64_t a = 0; a < n; ++a) h->h_rq_src[cur[h->h_rp_pose[a]]++] = (uint32_t)a;
+    parallel_ranges(n, threads, [&](int, int64_t k0, int64_t k1) {
+      for (int64_t k = k0; k < k1; ++k) { const uint32_t a = h->h_rq_src[k]; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a]; }
+    });
   }
   h->d_rq_point.upload(q_point, s); h->d_rq_cam.upload(q_cam, s); h->d_rq_pixel.upload(q_pix, s); h->d_rq_sigma.upload(q_sg, s);
   h->d_rq_active.upload(q_act, s); h->d_rq_pose_ptr.upload(pptr, s);
