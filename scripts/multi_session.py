@@ -38,6 +38,6 @@ for s in range(n_sessions):
     seen = np.abs(cov).max(axis=(1, 2)) > 0
     err = np.linalg.norm(est[seen, :3] - prob["gt_objects"][seen, :3], axis=1)
     sd = np.sqrt(np.einsum("oii->oi", cov[seen])[:, :3]).mean(axis=1)
-    print("session %2d: %3d objects mapped | BA %5.1f ms (%2d + %2d iterations) | map extraction %5.2f ms | upload %4.0f ms | centre error median %.3f m, sigma median %.3f m"
-          % (s, int(seen.sum()), (t2 - t1) * 1e3, s1.num_iterations, s2.num_iterations, (t3 - t2) * 1e3, 0.0 if False else (t1 - t0) * 1e3, np.median(err), np.median(sd)), flush=True)
+    print("session %2d: %3d objects mapped | BA %5.1f ms (%2d + %2d iterations) | map extraction %5.2f ms | problem generation %4.0f ms | centre error median %.3f m, sigma median %.3f m"
+          % (s, int(seen.sum()), (t2 - t1) * 1e3, s1.num_iterations, s2.num_iterations, (t3 - t2) * 1e3, (t1 - t0) * 1e3, np.median(err), np.median(sd)), flush=True)
     ltm = (ids[seen], est[seen], cov[seen])
