@@ -12,6 +12,7 @@
 
 #include <obvi_ba.h>
 
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <functional>
@@ -201,7 +202,6 @@ class ObjectPoseGraphOptimizer {
     residual_params_ = residual_params;
     std::set<FrameId> optimized_frames;
     std::unordered_set<ObjectId> ltm_object_ids;
-    std::map<FeatureId, FactorInfoSet> features_to_include;
     std::map<ObjectId, FactorInfoSet> objects_to_include;
     std::map<FactorType, std::set<FeatureFactorId>> required_feature_factors;
 
@@ -223,20 +223,35 @@ class ObjectPoseGraphOptimizer {
       if (excluded_feature_factor_types_and_ids.count(fi) && fi.first != kLongTermMapFactorTypeId && fi.first != kShapeDimPriorFactorTypeId) return true;
       return false;
     };
-    if (use_feature_pose_factors) {                                                                                          // :205-238
-      FactorInfoSet matching;
-      pose_graph->getVisualFeatureFactorIdsBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, matching);
-      for (const FactorInfo& fi : matching) {
-        if (excluded(fi)) continue;
-        FeatureId feat;
-        if (pose_graph->getFeatureIdForObservationFactor(fi, feat)) features_to_include[feat].insert(fi);
-      }
-      applyMinObs(optimization_scope.min_low_level_feature_observations_, features_to_include, required_feature_factors, {});
+    // Visual factors (:205-238): the reference collects the window's factor ids in a set, groups them per feature in a map of sets,
+    // drops the features with too few sightings (:826-861) and inserts the rest into the set of required factors.  The same selection
+    // on flat arrays (a window holds tens of thousands of sightings and is rebuilt twice per frame): one look-up per factor, a count
+    // per feature, and a sort by id only if the factors did not come out in id order.
+    struct VisualFactorRef { FeatureId feature; FeatureFactorId id; const ReprojectionErrorFactor* factor; int64_t point; };
+    std::vector<VisualFactorRef> visual;             // the required reprojection factors, ascending id
+    std::vector<FeatureId> included_features;        // ascending
+    std::unordered_map<FrameId, size_t> obs_per_frame;
+    if (use_feature_pose_factors) {
+      const bool type_excluded = optimization_scope.factor_types_to_exclude.count(kReprojectionErrorFactorTypeId) != 0;
+      const bool any_excluded = !excluded_feature_factor_types_and_ids.empty();
+      std::vector<VisualFactorRef> all;
+      if (!type_excluded)
+        pose_graph->forEachVisualFactorBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, [&](FeatureFactorId id, const ReprojectionErrorFactor& f) {
+          if (any_excluded && excluded_feature_factor_types_and_ids.count({kReprojectionErrorFactorTypeId, id})) return;
+          all.push_back({f.feature_id_, id, &f, -1});
+        });
+      std::unordered_map<FeatureId, uint32_t> sightings;
+      sightings.reserve(all.size() / 4 + 16);
+      for (const VisualFactorRef& v : all) ++sightings[v.feature];
+      visual.reserve(all.size());
+      for (const VisualFactorRef& v : all)
+        if (sightings[v.feature] >= optimization_scope.min_low_level_feature_observations_) { visual.push_back(v); obs_per_frame[v.factor->frame_id_]++; }
+      for (const auto& f : sightings) if (f.second >= optimization_scope.min_low_level_feature_observations_) included_features.push_back(f.first);
+      std::sort(included_features.begin(), included_features.end());
+      auto by_id = [](const VisualFactorRef& a, const VisualFactorRef& b) { return a.id < b.id; };
+      if (!std::is_sorted(visual.begin(), visual.end(), by_id)) std::sort(visual.begin(), visual.end(), by_id);
     }
     if (use_relative_pose_factors) {                                                                                         // :240-299
-      std::unordered_map<FrameId, size_t> obs_per_frame;
-      for (const auto& feat : features_to_include)
-        for (const FactorInfo& fi : feat.second) { ReprojectionErrorFactor f; if (pose_graph->getVisualFactor(fi.second, f)) obs_per_frame[f.frame_id_]++; }
       for (const FrameId& f : optimized_frames) {
         auto it = obs_per_frame.find(f);
         if (it != obs_per_frame.end() && it->second >= optimization_scope.min_low_level_feature_observations_per_frame_) continue;
@@ -304,12 +319,13 @@ class ObjectPoseGraphOptimizer {
         auto it = pose_index.find(f); if (it != pose_index.end()) fp.pose_const[it->second] = 1;
       }
     }
-    std::map<FeatureId, uint32_t> point_index;
+    std::unordered_map<FeatureId, uint32_t> point_index;
     if (use_feature_pose_factors) {
-      for (const auto& feat : features_to_include) {
+      point_index.reserve(included_features.size());
+      for (const FeatureId& feat : included_features) {
         double* p = nullptr;
-        if (!pose_graph->getFeaturePointers(feat.first, &p)) continue;
-        point_index[feat.first] = (uint32_t)fp.features.size(); fp.features.push_back(feat.first); fp.point_ptrs.push_back(p);
+        if (!pose_graph->getFeaturePointers(feat, &p)) continue;
+        point_index[feat] = (uint32_t)fp.features.size(); fp.features.push_back(feat); fp.point_ptrs.push_back(p);
       }
     }
     fp.point_const.assign(fp.features.size(), fix_visual_feature_param_blocks ? 1 : 0);                                     // :488-520
@@ -325,9 +341,11 @@ class ObjectPoseGraphOptimizer {
     }
     const auto& rp = residual_params;
     // residual blocks, type by type in the evaluate order of the ABI; inside a type by factor id
-    for (FeatureFactorId id : required_feature_factors[kReprojectionErrorFactorTypeId]) {                                    // residual_creator.h:168-264
-      ReprojectionErrorFactor f;
-      if (!pose_graph->getVisualFactor(id, f)) continue;
+    fp.rp_pose.reserve(visual.size()); fp.rp_point.reserve(visual.size()); fp.rp_cam.reserve(visual.size()); fp.rp_pixel.reserve(2 * visual.size());
+    fp.rp_sigma.reserve(visual.size()); fp.blocks.reserve(visual.size() + 64);
+    for (const VisualFactorRef& v : visual) {                                                                                // residual_creator.h:168-264
+      const ReprojectionErrorFactor& f = *v.factor;
+      const FeatureFactorId id = v.id;
       auto pi = pose_index.find(f.frame_id_); auto li = point_index.find(f.feature_id_); auto ci = cam_index.find(f.camera_id_);
       if (pi == pose_index.end() || li == point_index.end() || ci == cam_index.end()) continue;
       fp.rp_pose.push_back(pi->second); fp.rp_point.push_back(li->second); fp.rp_cam.push_back(ci->second);
@@ -394,6 +412,7 @@ class ObjectPoseGraphOptimizer {
     const auto& rp = residual_params_;
     auto gather = [](const std::vector<double*>& ptrs, int dim) { std::vector<double> v(ptrs.size() * dim); for (size_t i = 0; i < ptrs.size(); ++i) std::copy_n(ptrs[i], dim, &v[dim * i]); return v; };
     std::vector<double> poses = gather(fp.pose_ptrs, 6), points = gather(fp.point_ptrs, 3), objects = gather(fp.object_ptrs, 7);
+    const auto t_upload = std::chrono::steady_clock::now();
     int rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
     if (!rc) rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
     if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
@@ -411,7 +430,9 @@ class ObjectPoseGraphOptimizer {
                          solver_params.gradient_tolerance_, solver_params.parameter_tolerance_, solver_params.initial_trust_region_radius_,
                          solver_params.max_trust_region_radius_};
     obvi_summary s;
+    const auto t_solve = std::chrono::steady_clock::now();
     rc = obvi_ba_solve(h, &p, &s);
+    const auto t_solved = std::chrono::steady_clock::now();
     if (rc) { std::cerr << "obvi_ba_solve failed: " << obvi_ba_last_error(h) << std::endl; return false; }
     obvi::SolverSummary summary;
     summary.termination_type = s.termination_type; summary.usable = s.is_solution_usable != 0;
@@ -437,11 +458,20 @@ class ObjectPoseGraphOptimizer {
     for (size_t i = 0; i < fp.point_ptrs.size(); ++i) std::copy_n(&points[3 * i], 3, fp.point_ptrs[i]);
     for (size_t i = 0; i < fp.object_ptrs.size(); ++i) std::copy_n(&objects[7 * i], 7, fp.object_ptrs[i]);
     last_summary_ = summary;
+    const auto t_end = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    time_upload_ms_ += ms(t_upload, t_solve); time_solve_ms_ += ms(t_solve, t_solved); time_readback_ms_ += ms(t_solved, t_end); time_lm_ms_ += 1e3 * s.total_time_in_seconds; ++n_solves_;
     return summary.IsSolutionUsable();
   }
 
   void clearPastOptimizationData() { last_optimized_objects_ = last_optimized_features_ = last_optimized_nodes_ = 0; }     // :792-797
   const obvi::SolverSummary& lastSummary() const { return last_summary_; }
+  // where a solveOptimization call spends its wall time: upload (set_*), obvi_ba_solve (symbolic phase + LM loop), read-back; the LM loop alone
+  void printTiming(std::ostream& os) const {
+    if (n_solves_ == 0) return;
+    os << "solveOptimization x" << n_solves_ << ": upload " << time_upload_ms_ / n_solves_ << " ms, obvi_ba_solve " << time_solve_ms_ / n_solves_ << " ms (LM loop "
+       << time_lm_ms_ / n_solves_ << " ms), evaluate + read-back " << time_readback_ms_ / n_solves_ << " ms per call" << std::endl;
+  }
 
  private:
   template <class Id>
@@ -454,6 +484,7 @@ class ObjectPoseGraphOptimizer {
   pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
   size_t last_optimized_objects_ = 0, last_optimized_features_ = 0, last_optimized_nodes_ = 0;
   obvi::SolverSummary last_summary_;
+  double time_upload_ms_ = 0, time_solve_ms_ = 0, time_readback_ms_ = 0, time_lm_ms_ = 0; size_t n_solves_ = 0;
 };
 
 // pose_graph_plus_objects_optimizer.h:23-353

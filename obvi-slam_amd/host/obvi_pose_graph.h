@@ -74,6 +74,21 @@ class ObjectAndReprojectionFeaturePoseGraph {
     for (const auto& fr : visual_factors_by_frame_)
       if (fr.first >= min_f && fr.first <= max_f) for (FeatureFactorId id : fr.second) out.insert({kReprojectionErrorFactorTypeId, id});
   }
+  // the factors of getVisualFeatureFactorIdsBetweenFrameIdsInclusive handed to `fn(id, factor)` one by one (no id set is built)
+  template <class F>
+  void forEachVisualFactorBetweenFrameIdsInclusive(const FrameId& min_f, const FrameId& max_f, F&& fn) const {
+    if (max_f - min_f < visual_factors_by_frame_.size()) {       // frames in ascending order (ids are then usually ascending as well)
+      for (FrameId f = min_f; f <= max_f; ++f) {
+        const auto fr = visual_factors_by_frame_.find(f);
+        if (fr == visual_factors_by_frame_.end()) continue;
+        for (FeatureFactorId id : fr->second) { const auto it = factors_.find(id); if (it != factors_.end()) fn(id, it->second); }
+      }
+      return;
+    }
+    for (const auto& fr : visual_factors_by_frame_)
+      if (fr.first >= min_f && fr.first <= max_f)
+        for (FeatureFactorId id : fr.second) { const auto it = factors_.find(id); if (it != factors_.end()) fn(id, it->second); }
+  }
   bool getFeatureIdForObservationFactor(const FactorInfo& info, FeatureId& feature_id) const {
     if (info.first != kReprojectionErrorFactorTypeId) return false;
     auto it = factors_.find(info.second); if (it == factors_.end()) return false; feature_id = it->second.feature_id_; return true;

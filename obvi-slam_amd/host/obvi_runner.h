@@ -6,6 +6,7 @@
 #ifndef OBVI_HOST_RUNNER_H_
 #define OBVI_HOST_RUNNER_H_
 
+#include <chrono>
 #include <functional>
 
 #include "obvi_optimizer.h"
@@ -134,6 +135,10 @@ class OfflineProblemRunner {
     return true;
   }
   const std::vector<OptimizationRecord>& records() const { return records_; }
+  void printTiming(std::ostream& os) const {
+    optimizer_.printTiming(os);
+    if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call" << std::endl;
+  }
   struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
   void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
   const std::vector<LongTermMapEntry>& longTermMap() const { return long_term_map_; }
@@ -150,6 +155,24 @@ class OfflineProblemRunner {
       if (tn > transl_tol || std::fabs(an) > orient_tol) return false;
     }
     return true;
+  }
+
+  // values of the parameter blocks of a flattened problem (makeCopyDeepCopyValues / setValuesFromAnotherPoseGraph restricted to them)
+  struct ValueSnapshot { std::vector<double*> ptrs[3]; std::vector<double> values[3]; };
+  static ValueSnapshot snapshotValues(const obvi::FlatProblem& fp) {
+    ValueSnapshot s;
+    const std::vector<double*>* src[3] = {&fp.pose_ptrs, &fp.point_ptrs, &fp.object_ptrs};
+    const int dim[3] = {6, 3, 7};
+    for (int k = 0; k < 3; ++k) {
+      s.ptrs[k] = *src[k];
+      s.values[k].resize(src[k]->size() * dim[k]);
+      for (size_t i = 0; i < src[k]->size(); ++i) std::copy_n((*src[k])[i], dim[k], &s.values[k][dim[k] * i]);
+    }
+    return s;
+  }
+  static void restoreValues(const ValueSnapshot& s) {
+    const int dim[3] = {6, 3, 7};
+    for (int k = 0; k < 3; ++k) for (size_t i = 0; i < s.ptrs[k].size(); ++i) std::copy_n(&s.values[k][dim[k] * i], dim[k], s.ptrs[k][i]);
   }
 
   // offline_problem_runner.h:376-916
@@ -186,8 +209,14 @@ class OfflineProblemRunner {
     bool two_phase = iteration_params.feature_outlier_percentage_ > 0;
     const std::string kind = global_ba ? "gba" : "lba";
     // PHASE I  (:541-660)
+    const auto t_b0 = std::chrono::steady_clock::now();
     auto block_info = optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger);
-    MainPgPtr pose_graph_copy = pose_graph->makeCopyDeepCopyValues();                                                        // :594
+    const auto t_b1 = std::chrono::steady_clock::now();
+    // :594 deep-copies the whole pose graph; all that is ever read back (:811, :903) are the values of the parameter blocks this
+    // optimisation can move, i.e. the blocks of the phase-I problem: those are saved (the device-side equivalent is obvi_ba_snapshot)
+    const ValueSnapshot pose_graph_copy = snapshotValues(problem.flat);
+    const auto t_b2 = std::chrono::steady_clock::now();
+    time_build_ms_ += std::chrono::duration<double, std::milli>(t_b1 - t_b0).count(); time_copy_ms_ += std::chrono::duration<double, std::milli>(t_b2 - t_b1).count(); ++n_iterations_;
     std::vector<obvi::ResidualBlockId> residual_block_ids;
     std::vector<double> residuals;
     const bool ok1 = two_phase ? optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, &residual_block_ids, &residuals)
@@ -200,7 +229,7 @@ class OfflineProblemRunner {
     if (two_phase) {
       size_t idx = 0;
       for (obvi::ResidualBlockId id : residual_block_ids) {
-        const FactorType t = block_info.at(id).first;
+        const FactorType t = id < problem.flat.blocks.size() ? problem.flat.blocks[id].first : block_info.at(id).first;   // block ids index the flat problem's block list
         size_t n;
         if (t == kReprojectionErrorFactorTypeId) n = 2; else if (t == kObjectObservationFactorTypeId) n = 4; else if (t == kShapeDimPriorFactorTypeId) n = 3;
         else if (t == kLongTermMapFactorTypeId) n = kEllipsoidParamterizationSize; else if (t == kPairwiseRobotPoseFactorTypeId) n = 6; else if (t == kPairwiseErrorFactorTypeId) n = 1;
@@ -214,17 +243,19 @@ class OfflineProblemRunner {
     FactorInfoSet excluded;
     if (two_phase) {                                                                                                         // :769-800
       for (auto& tv : by_type) {
-        // std::map<double, id, greater>: descending by value, equal values collapse into one entry
-        std::map<double, obvi::ResidualBlockId, std::greater<double>> ordered;
-        for (const auto& e : tv.second) ordered[e.first] = e.second;
+        // the reference fills a std::map<double, id, greater> (:769-800): descending by value, equal values collapse into one entry
+        // that keeps the id inserted last.  Same list from a stable sort.
+        std::vector<std::pair<double, obvi::ResidualBlockId>>& v = tv.second;
+        std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        std::vector<obvi::ResidualBlockId> ordered;
+        for (size_t i = 0; i < v.size(); ++i) if (i + 1 == v.size() || v[i + 1].first != v[i].first) ordered.push_back(v[i].second);
         const size_t n_outliers = (size_t)(ordered.size() * iteration_params.feature_outlier_percentage_);
-        auto it = ordered.begin();
-        for (size_t i = 0; i < n_outliers; ++i, ++it) excluded.insert(block_info.at(it->second));
+        for (size_t i = 0; i < n_outliers; ++i) excluded.insert(block_info.at(ordered[i]));
       }
     }
     if (two_phase) {                                                                                                         // PHASE II :803-892
       if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, true, attempt_num);
-      pose_graph->setValuesFromAnotherPoseGraph(pose_graph_copy);                                                            // :811
+      restoreValues(pose_graph_copy);                                                            // :811
       optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger, excluded);
       if (!optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger)) {
         std::cerr << "Phase II Optimization failed at max frame id " << next_frame_id << std::endl;
@@ -236,7 +267,7 @@ class OfflineProblemRunner {
     if (iteration_params.allow_reversion_after_detecting_jumps_ &&                                                           // :895-905
         !isConsecutivePosesStable_(pose_graph, scope.min_frame_id_, scope.max_frame_id_, iteration_params.consecutive_pose_transl_tol_, iteration_params.consecutive_pose_orient_tol_)) {
       std::cerr << "Detecting jumps after optimization. Reverting..." << std::endl;
-      pose_graph->setValuesFromAnotherPoseGraph(pose_graph_copy);
+      restoreValues(pose_graph_copy);
       records_.push_back({scope.min_frame_id_, next_frame_id, "reverted", 0, 0, 0, 0, 0, 0, 0});
     }
     return true;
@@ -254,6 +285,7 @@ class OfflineProblemRunner {
   int device_id_;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
+  double time_build_ms_ = 0, time_copy_ms_ = 0; size_t n_iterations_ = 0;
   bool extract_long_term_map_ = false;
   std::vector<LongTermMapEntry> long_term_map_;
 };

@@ -169,6 +169,7 @@ int main(int argc, char** argv) {
   MainPgPtr pg;
   runner.setExtractLongTermMap(ltm);
   const bool ok = runner.runOptimization(data, en, logger, pg);
+  if (std::getenv("OBVI_HOST_TIMING")) runner.printTiming(std::cerr);
   out << "{\"ok\": " << (ok ? "true" : "false") << ", \"records\": [";
   bool first = true;
   for (const auto& r : runner.records()) {
