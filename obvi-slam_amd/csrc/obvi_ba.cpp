@@ -482,7 +482,7 @@ void prepare(obvi_ba_handle* h) {
   {
     // points are independent: ranges of points on host threads (the bitmap is shared: every writer stores the same 1), lists joined in
     // point order.  Without the bitmap the tile marks go straight into the mask: one thread.
-    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 4096)) : 1;   // a thread is worth starting for a few thousand points
+    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 2048)) : 1;   // a thread is worth starting for a couple of thousand points
     std::vector<std::vector<Pair>> pairs_t(parts);
     std::vector<std::vector<Visit>> visits_t(parts);
     std::vector<int64_t> window_pairs_t(parts, 0);
@@ -505,29 +505,48 @@ void prepare(obvi_ba_handle* h) {
         if (v >= 0) obs.push_back({a, v, nat[h->h_rp_pose[a]]});
       }
       // the strip kernel takes a point unless one of its frames holds more than two observations
+      // (the observations of a point are sorted by pose, hence by frame: equal frames are neighbours)
       bool windowed = true, twin = false;
-      for (size_t i = 0; i < obs.size() && windowed; ++i) {
-        int same = 0;
-        for (size_t j = 0; j < obs.size(); ++j) same += obs[j].f == obs[i].f;
-        if (same > 2) windowed = false;
-        if (same == 2) twin = true;
+      for (size_t i = 0; i < obs.size() && windowed;) {
+        size_t e = i + 1;
+        while (e < obs.size() && obs[e].f == obs[i].f) ++e;
+        if (e - i > 2) windowed = false;
+        if (e - i == 2) twin = true;
+        i = e;
       }
       if (windowed) {
         chunks.clear();
-        for (const Ob& x : obs) { if (std::find(chunks.begin(), chunks.end(), x.f / SR) == chunks.end()) chunks.push_back(x.f / SR); }
+        for (const Ob& x : obs) { if (chunks.empty() || chunks.back() != x.f / SR) chunks.push_back(x.f / SR); }
         for (int32_t c : chunks) {
           // frames of the strip [fbase, fbase + 48) the point covers, then the 16x16 tiles (r, c) of the 3 x 18 strip it touches
           const int32_t fbase = c * SR - SBACK;
           uint64_t m = 0, tiles = 0;
           for (const Ob& x : obs) if (x.f >= fbase && x.f < (c + 1) * SR) m |= 1ull << (x.f - fbase);
           auto frames_of_tile = [](int t0) { return ((2ull << ((16 * t0 + 15) / 6)) - 1) & ~((1ull << ((16 * t0) / 6)) - 1); };
-          for (int tc = 0; tc < kSchurWindowFrames * 6 / 16; ++tc)
-            for (int tr = 0; tr < SR * 6 / 16; ++tr)
-              if (tc <= tr + SBACK * 6 / 16 && (m & frames_of_tile(tc)) && (m & frames_of_tile(tr + SBACK * 6 / 16))) tiles |= 1ull << (3 * tc + tr);
+          constexpr int kColTiles = kSchurWindowFrames * 6 / 16, kRowTiles = SR * 6 / 16, kRowTile0 = SBACK * 6 / 16;
+          static_assert(kRowTiles == 3, "three row tiles per chunk (bit 3 tc + tr of a visit's tile word)");
+          uint64_t rows = 0;                                                        // row tiles the point touches
+          for (int tr = 0; tr < kRowTiles; ++tr) if (m & frames_of_tile(tr + kRowTile0)) rows |= 1ull << tr;
+          for (int tc = 0; tc < kColTiles; ++tc) {
+            if (!(m & frames_of_tile(tc))) continue;
+            uint64_t allowed = 0;                                                   // lower triangle: tc <= tr + kRowTile0
+            for (int tr = 0; tr < kRowTiles; ++tr) if (tc <= tr + kRowTile0) allowed |= 1ull << tr;
+            tiles |= (rows & allowed) << (3 * tc);
+          }
           visit_list.push_back({c, (uint32_t)l, beg, (uint32_t)(end - beg), twin, tiles});
         }
         any_twin = any_twin || twin;
       }
+      // every pair lies inside the strip of its later frame's chunk iff the point's first frame lies inside the strip of its last frame
+      const bool all_in_window = windowed && !obs.empty() && obs.front().f >= (obs.back().f / SR) * SR - SBACK;
+      if (all_in_window) n_window_pairs += (int64_t)(obs.size() * (obs.size() + 1) / 2);
+      if (all_in_window && pair_bitmap) {
+        for (size_t i = 0; i < obs.size(); ++i)
+          for (size_t j = 0; j <= i; ++j)
+            __atomic_store_n(&pose_pair[(size_t)std::max(obs[i].vid, obs[j].vid) * (size_t)h->nPv + (size_t)std::min(obs[i].vid, obs[j].vid)], (uint8_t)1, __ATOMIC_RELAXED);
+        continue;
+      }
+      if (all_in_window) n_window_pairs -= (int64_t)(obs.size() * (obs.size() + 1) / 2);   // counted pair by pair below
       for (size_t i = 0; i < obs.size(); ++i)
         for (size_t j = 0; j <= i; ++j) {
           const Ob& x = obs[i]; const Ob& y = obs[j];
@@ -641,7 +660,7 @@ void prepare(obvi_ba_handle* h) {
     q = e;
   }
   struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches; };
-  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 16384));
+  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 8192));
   std::vector<BatchLists> lists_t(parts2);
   parallel_ranges((int64_t)wgs.size(), parts2, [&](int part, int64_t g0, int64_t g1) {
     BatchLists& o = lists_t[part];
