@@ -10,6 +10,7 @@
 // Reference arithmetic: see ba_math.h.  Solver algebra: [Ceres-doc] SchurEliminator / LM strategy.
 #include <algorithm>
 
+#include <cstdlib>
 #include "ba_device.h"
 
 namespace obvi {
@@ -543,6 +544,129 @@ __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev
   if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
 }
 
+// Small problems (a sliding window holds a few hundred of these factors): the thread-per-factor kernels above are then a handful of
+// wavefronts whose single-lane dual arithmetic (13 or 12 directions) is the latency of the whole side stream.  Here a factor takes
+// 16 lanes: lane `dir` evaluates the residual with a one-direction dual, so the Jacobian column of a parameter lives in its lane;
+// rows of J^T J are formed from the group's columns (wave shuffles) and added by the lane that owns the row.  (On big problems the
+// thread-per-factor kernels win: see DESIGN.md.)
+__global__ void __launch_bounds__(64) k_bbox_lin_lanes(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                                      const double* __restrict__ objects, ReducedDev rd, double* scal) {
+  const int64_t i = blockIdx.x * 4LL + (threadIdx.x >> 4);
+  const int dir = threadIdx.x & 15, base = threadIdx.x & 48;
+  uint32_t o = 0, p = 0;
+  int32_t ov = -1, pv = -1;
+  if (i < sf.n_bb && sf.bb_active[i]) { o = sf.bb_obj[i]; p = sf.bb_pose[i]; ov = b.obj_vid[o]; pv = b.pose_vid[p]; }
+  const bool work = ov >= 0 || pv >= 0;
+  double r[4] = {0.0, 0.0, 0.0, 0.0}, J[4] = {0.0, 0.0, 0.0, 0.0}, cost = 0.0, w = 0.0;
+  if (work) {
+    Dual<1> res[4];
+    bbox_eval_n<1>(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res, dir);
+    for (int a = 0; a < 4; ++a) { r[a] = res[a].v; J[a] = res[a].d[0]; }
+    double rho0;
+    huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
+    if (dir == 0) cost = 0.5 * rho0;
+  }
+  double Jk[4][13];                                   // the factor's whole Jacobian, column k from lane base + k
+#pragma unroll
+  for (int k = 0; k < 13; ++k)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Jk[a][k] = __shfl(J[a], base + k, 64);
+  if (work && dir < 7 && ov >= 0) {
+    const int x = dir;
+    double* Hd = rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov;
+#pragma unroll
+    for (int y = 0; y < 7; ++y) {
+      if (y > x) continue;
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][y];
+      atomic_add_f64(Hd + 7 * x + y, w * acc);
+    }
+    double acc = 0.0;
+    for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
+    atomic_add_f64(rd.g + 6 * b.nPv + 7 * (int64_t)ov + x, w * acc);
+    if (pv >= 0) {
+      const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
+      const bool obj_low = orow > prow;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) {
+        double acc2 = 0.0;
+        for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
+        atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc2);
+      }
+    }
+  } else if (work && dir >= 7 && dir < 13 && pv >= 0) {
+    const int x = dir - 7;
+    double* Hd = rd.Hdiag + 36 * (int64_t)pv;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) {
+      if (y > x) continue;
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][7 + y];
+      atomic_add_f64(Hd + 6 * x + y, w * acc);
+    }
+    double acc = 0.0;
+    for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
+    atomic_add_f64(rd.g + 6 * (int64_t)pv + x, w * acc);
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+// lanes 0..5 own the columns of the first pose, 6..11 of the second
+__global__ void __launch_bounds__(64) k_relpose_lin_lanes(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ poses, ReducedDev rd, double* scal) {
+  const int64_t i = blockIdx.x * 4LL + (threadIdx.x >> 4);
+  const int dir = threadIdx.x & 15, base = threadIdx.x & 48;
+  uint32_t pa = 0, pb = 0;
+  int32_t va = -1, vb = -1;
+  if (i < sf.n_rl && sf.rl_active[i]) { pa = sf.rl_a[i]; pb = sf.rl_b[i]; va = b.pose_vid[pa]; vb = b.pose_vid[pb]; }
+  const bool work = va >= 0 || vb >= 0;
+  double r[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cost = 0.0, w = 0.0;
+  if (work) {
+    Dual<1> res[6];
+    relpose_eval_n<1>(poses + 6 * (int64_t)pa, poses + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res, dir);
+    double s = 0.0;
+    for (int a = 0; a < 6; ++a) { r[a] = res[a].v; J[a] = res[a].d[0]; s += r[a] * r[a]; }
+    double rho0;
+    huber_eval(s, sf.rl_huber, &rho0, &w);
+    if (dir == 0) cost = 0.5 * rho0;
+  }
+  double Jk[6][12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) Jk[a][k] = __shfl(J[a], base + k, 64);
+  const bool first = dir < 6;
+  const int32_t vid = first ? va : vb;
+  if (work && dir < 12 && vid >= 0) {
+    const int x = first ? dir : dir - 6;
+    double* Hd = rd.Hdiag + 36 * (int64_t)vid;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) {
+      if (y > x) continue;
+      double acc = 0.0;
+      for (int a = 0; a < 6; ++a) acc += J[a] * (first ? Jk[a][y] : Jk[a][6 + y]);
+      atomic_add_f64(Hd + 6 * x + y, w * acc);
+    }
+    double acc = 0.0;
+    for (int a = 0; a < 6; ++a) acc += J[a] * r[a];
+    atomic_add_f64(rd.g + 6 * (int64_t)vid + x, w * acc);
+    if (va >= 0 && vb >= 0 && va != vb) {
+      const int64_t ra = b.pose_row[va], rb = b.pose_row[vb];
+      const bool b_low = rb > ra;  // lower triangle: the later-eliminated block is the row, and its lanes add the block
+      if (b_low != first) {
+        const int64_t row = b_low ? rb : ra, col = b_low ? ra : rb;
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+          double acc2 = 0.0;
+          for (int a = 0; a < 6; ++a) acc2 += J[a] * (first ? Jk[a][6 + y] : Jk[a][y]);
+          atomic_add_f64(S_at(rd.S, rd.nt, row + x, col + y), w * acc2);
+        }
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
 __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
                                                         ReducedDev rd, double radius, int first_iter, double* scal) {
@@ -655,9 +779,9 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
     for (int i = 0; i < kBlock / 64; ++i) s += red[i][t];
     if (t < 36) {
       const int xx = t / 6, yy = t % 6;
-      if (!diag || yy <= xx) *S_at(rd.S, rd.nt, (int64_t)row + xx, (int64_t)col + yy) -= s;
+      if (!diag || yy <= xx) atomic_add_f64(S_at(rd.S, rd.nt, (int64_t)row + xx, (int64_t)col + yy), -s);   // a block may be spread over several work items
     } else if (diag) {
-      rd.rhs[row + (t - 36)] -= s;
+      atomic_add_f64(rd.rhs + row + (t - 36), -s);
     }
   }
 }
@@ -1208,9 +1332,13 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
-  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
+  // few factors (a sliding window): 16 lanes per factor, the latency of a handful of wavefronts is the whole side stream
+  const int64_t lanes_below = std::getenv("OBVI_SMALL_LANES_BELOW") ? std::atoll(std::getenv("OBVI_SMALL_LANES_BELOW")) : 4096;   // tuning knob
+  if (sf.n_bb > 0 && sf.n_bb < lanes_below) hipLaunchKernelGGL(k_bbox_lin_lanes, dim3(grid_for(sf.n_bb, 4)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
+  else if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
   if (sf.n_sp + sf.n_lt > 0) hipLaunchKernelGGL(k_object_priors_lin, dim3(grid_for(sf.n_sp + sf.n_lt, 64)), dim3(64), 0, s, b, sf, objects, rd, scal);
-  if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
+  if (sf.n_rl > 0 && sf.n_rl < lanes_below) hipLaunchKernelGGL(k_relpose_lin_lanes, dim3(grid_for(sf.n_rl, 4)), dim3(64), 0, s, b, sf, poses, rd, scal);
+  else if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {

@@ -193,14 +193,21 @@ template <int N> OBVI_HD void dual_inverse_pose(const Dual<N>* pose, Dual<N>* Ri
 // getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273).  13 directions: ellipsoid 0..6,
 // pose 7..12.  Returns false (constant residual, zero Jacobian) in the invalid-ellipse case.
 // N = 13: value + Jacobian; N = 1: value only at about twice the cost of plain doubles (trial-point cost)
-template <int N> OBVI_HD Dual<N> dvar_n(double c, int k) { Dual<N> r(c); if (k < N) r.d[k] = 1.0; return r; }
+// dir >= 0 (N = 1): the single slot carries the derivative along parameter `dir` -- the lane-parallel linearisation kernels of small
+// problems give every parameter its own lane, which costs a lane two plain evaluations instead of N + 1
+template <int N> OBVI_HD Dual<N> dvar_n(double c, int k, int dir = -1) {
+  Dual<N> r(c);
+  if (dir >= 0) r.d[0] = (k == dir) ? 1.0 : 0.0;
+  else if (k < N) r.d[k] = 1.0;
+  return r;
+}
 template <int N>
 OBVI_HD bool bbox_eval_n(const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
-                         const double* sqrt_inf, double invalid_err, Dual<N>* res) {
+                         const double* sqrt_inf, double invalid_err, Dual<N>* res, int dir = -1) {
   typedef Dual<N> D13;
   D13 ell[7], pose[6];
-  for (int k = 0; k < 7; ++k) ell[k] = dvar_n<N>(ell_v[k], k);
-  for (int k = 0; k < 6; ++k) pose[k] = dvar_n<N>(pose_v[k], 7 + k);
+  for (int k = 0; k < 7; ++k) ell[k] = dvar_n<N>(ell_v[k], k, dir);
+  for (int k = 0; k < 6; ++k) pose[k] = dvar_n<N>(pose_v[k], 7 + k, dir);
   D13 Rinv[9], tinv[3];
   dual_inverse_pose(pose, Rinv, tinv);
   D13 Rcw[9], tcw[3];
@@ -254,10 +261,10 @@ OBVI_HD void dual_forward_rotation(const Dual<N>* pose, Dual<N>* R) {
 }
 template <int N>
 OBVI_HD void relpose_eval_n(const double* pa_v, const double* pb_v, const double* t_meas, const double* R_meas,
-                            const double* sqrt_inf, Dual<N>* res) {
+                            const double* sqrt_inf, Dual<N>* res, int dir = -1) {
   typedef Dual<N> D12;
   D12 pa[6], pb[6];
-  for (int k = 0; k < 6; ++k) { pa[k] = dvar_n<N>(pa_v[k], k); pb[k] = dvar_n<N>(pb_v[k], 6 + k); }
+  for (int k = 0; k < 6; ++k) { pa[k] = dvar_n<N>(pa_v[k], k, dir); pb[k] = dvar_n<N>(pb_v[k], 6 + k, dir); }
   D12 Rb[9], Ra[9];
   dual_forward_rotation(pa, Rb);   // "before"
   dual_forward_rotation(pb, Ra);   // "after"

@@ -696,7 +696,10 @@ void prepare(obvi_ba_handle* h) {
   std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key || (x.key == y.key && (x.a < y.a || (x.a == y.a && x.b < y.b))); });
   std::vector<uint32_t> blk_row, blk_col, blk_ptr, pair_a(pairs.size()), pair_b(pairs.size());
   for (size_t k = 0; k < pairs.size(); ++k) {
-    if (k == 0 || pairs[k].key != pairs[k - 1].key) {
+    // a block's pairs are cut into work items of at most kPairsPerItem (k_schur_blocks adds its sums atomically): a few long tracks in a
+    // small window would otherwise leave one workgroup with thousands of pairs on the critical path
+    constexpr size_t kPairsPerItem = 256;
+    if (k == 0 || pairs[k].key != pairs[k - 1].key || k - blk_ptr.back() >= kPairsPerItem) {
       blk_row.push_back((uint32_t)h->h_pose_row[pairs[k].key / (uint64_t)(h->nPv + 1)]);
       blk_col.push_back((uint32_t)h->h_pose_row[pairs[k].key % (uint64_t)(h->nPv + 1)]);
       blk_ptr.push_back((uint32_t)k);

@@ -94,6 +94,8 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_ND_BALANCE": "0", "OBVI_ND_LEAF": "96"},          # the unbalanced dissection of the earlier builds
     {"OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},                # a deep tree of tiny leaves
     {"OBVI_SCHUR_WGS": "16", "OBVI_UPD_CHUNK": "1"},
+    {"OBVI_SMALL_LANES_BELOW": "0"},                         # thread-per-factor small-factor kernels (the big-problem path) on a small problem
+    {"OBVI_SMALL_LANES_BELOW": "1000000000", "OBVI_HOST_THREADS": "3"},   # ... 16 lanes per factor; symbolic phase on three host threads
 ])
 def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
