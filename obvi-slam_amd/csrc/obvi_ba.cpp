@@ -477,7 +477,7 @@ void prepare(obvi_ba_handle* h) {
   bool any_twin = false;
   // pose pairs that share a point: collected in a bitmap (one store per pair of sightings) and turned into tile marks once per
   // pose pair afterwards -- a point contributes k (k + 1) / 2 pairs and most of them repeat
-  const bool pair_bitmap = h->nPv <= 16384;
+  const bool pair_bitmap = h->nPv <= env_int("OBVI_PAIR_BITMAP_MAX", 8192);   // 64 MB at most; beyond it the tile marks are made pair by pair (tuning knob)
   std::vector<uint8_t> pose_pair(pair_bitmap ? (size_t)h->nPv * (size_t)h->nPv : 0, 0);
   {
     // points are independent: ranges of points on host threads (the bitmap is shared: every writer stores the same 1), lists joined in
@@ -1508,10 +1508,12 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   if (h->allreduce != nullptr && !h->h_shared_ov.empty()) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "object_covariances: not available with objects shared across ranks");
   // the undamped reduced system S = J_c^T J_c - (Schur complement of the features) at the current point, factorised: one
   // LM step's linearisation and factorisation with the trust-region radius at infinity (its candidate point is not used)
-  const int profiling = h->profiling;
-  h->profiling = 0; h->pc_valid = false; h->tiles_cleared = false;
-  submit_step(h, 1e300, true, true, /*keep_factor=*/true);
-  h->profiling = profiling; h->pc_valid = false; h->tiles_cleared = false;
+  struct QuietStep {   // no phase events for this step; the caches of the LM loop do not survive it (also when a launch throws)
+    obvi_ba_handle* h; int profiling;
+    explicit QuietStep(obvi_ba_handle* hh) : h(hh), profiling(hh->profiling) { h->profiling = 0; h->pc_valid = false; h->tiles_cleared = false; }
+    ~QuietStep() { h->profiling = profiling; h->pc_valid = false; h->tiles_cleared = false; }
+  };
+  { QuietStep quiet(h); submit_step(h, 1e300, true, true, /*keep_factor=*/true); }
   if (h->h_scal[SC_CHOL_FAIL] != 0.0 || h->h_scal[SC_NONFINITE] != 0.0 || !std::isfinite(h->h_scal[SC_STEPSQ]))
     return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: the normal equations are rank deficient at the current estimate");
   hipStream_t s = h->stream;

@@ -94,6 +94,7 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_ND_BALANCE": "0", "OBVI_ND_LEAF": "96"},          # the unbalanced dissection of the earlier builds
     {"OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},                # a deep tree of tiny leaves
     {"OBVI_SCHUR_WGS": "16", "OBVI_UPD_CHUNK": "1"},
+    {"OBVI_PAIR_BITMAP_MAX": "0"},                           # tile marks pair by pair (the path of more than 8192 variable poses)
     {"OBVI_SMALL_LANES_BELOW": "0"},                         # thread-per-factor small-factor kernels (the big-problem path) on a small problem
     {"OBVI_SMALL_LANES_BELOW": "1000000000", "OBVI_HOST_THREADS": "3"},   # ... 16 lanes per factor; symbolic phase on three host threads
 ])
