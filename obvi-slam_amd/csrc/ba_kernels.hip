@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf
   if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
 }
 
-__global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ objects, ReducedDev rd, double* scal) {
-  const int64_t t = blockIdx.x * 64LL + threadIdx.x;
+__device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
+  const int64_t t = block * 64LL + threadIdx.x;
   double cost = 0.0;
   if (t < sf.n_sp) {
     const int64_t i = t;
@@ -504,6 +504,10 @@ __global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFact
   }
   cost = wave_sum(cost);
   if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+__global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ objects, ReducedDev rd, double* scal) {
+  object_priors_lin(blockIdx.x, b, sf, objects, rd, scal);
 }
 
 __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ poses, ReducedDev rd, double* scal) {
@@ -549,9 +553,9 @@ __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev
 // 16 lanes: lane `dir` evaluates the residual with a one-direction dual, so the Jacobian column of a parameter lives in its lane;
 // rows of J^T J are formed from the group's columns (wave shuffles) and added by the lane that owns the row.  (On big problems the
 // thread-per-factor kernels win: see DESIGN.md.)
-__global__ void __launch_bounds__(64) k_bbox_lin_lanes(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
-                                                      const double* __restrict__ objects, ReducedDev rd, double* scal) {
-  const int64_t i = blockIdx.x * 4LL + (threadIdx.x >> 4);
+__device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                               const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
+  const int64_t i = block * 4LL + (threadIdx.x >> 4);
   const int dir = threadIdx.x & 15, base = threadIdx.x & 48;
   uint32_t o = 0, p = 0;
   int32_t ov = -1, pv = -1;
@@ -612,8 +616,8 @@ __global__ void __launch_bounds__(64) k_bbox_lin_lanes(BlocksDev b, SmallFactors
   if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
 }
 // lanes 0..5 own the columns of the first pose, 6..11 of the second
-__global__ void __launch_bounds__(64) k_relpose_lin_lanes(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ poses, ReducedDev rd, double* scal) {
-  const int64_t i = blockIdx.x * 4LL + (threadIdx.x >> 4);
+__device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const double* __restrict__ poses, const ReducedDev& rd, double* scal) {
+  const int64_t i = block * 4LL + (threadIdx.x >> 4);
   const int dir = threadIdx.x & 15, base = threadIdx.x & 48;
   uint32_t pa = 0, pb = 0;
   int32_t va = -1, vb = -1;
@@ -665,6 +669,15 @@ __global__ void __launch_bounds__(64) k_relpose_lin_lanes(BlocksDev b, SmallFact
   }
   cost = wave_sum(cost);
   if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+}
+
+// the three small-factor families of a small problem in one launch (at this size an iteration's first half is bound by the host's launches)
+__global__ void __launch_bounds__(64) k_small_lin_lanes(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
+                                                       const double* __restrict__ objects, ReducedDev rd, double* scal, int nb_bbox, int nb_priors) {
+  const int blk = blockIdx.x;
+  if (blk < nb_bbox) bbox_lin_lanes(blk, b, sf, cams, poses, objects, rd, scal);
+  else if (blk < nb_bbox + nb_priors) object_priors_lin(blk - nb_bbox, b, sf, objects, rd, scal);
+  else relpose_lin_lanes(blk - nb_bbox - nb_priors, b, sf, poses, rd, scal);
 }
 
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
@@ -1332,13 +1345,16 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
-  // few factors (a sliding window): 16 lanes per factor, the latency of a handful of wavefronts is the whole side stream
+  // few factors (a sliding window): 16 lanes per factor, the latency of a handful of wavefronts is the whole side stream; one launch
   const int64_t lanes_below = std::getenv("OBVI_SMALL_LANES_BELOW") ? std::atoll(std::getenv("OBVI_SMALL_LANES_BELOW")) : 4096;   // tuning knob
-  if (sf.n_bb > 0 && sf.n_bb < lanes_below) hipLaunchKernelGGL(k_bbox_lin_lanes, dim3(grid_for(sf.n_bb, 4)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
-  else if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
+  if (sf.n_bb < lanes_below && sf.n_rl < lanes_below) {
+    const int nb_bbox = (int)grid_for(sf.n_bb, 4), nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
+    if (nb_bbox + nb_priors + nb_rel > 0) hipLaunchKernelGGL(k_small_lin_lanes, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+    return;
+  }
+  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
   if (sf.n_sp + sf.n_lt > 0) hipLaunchKernelGGL(k_object_priors_lin, dim3(grid_for(sf.n_sp + sf.n_lt, 64)), dim3(64), 0, s, b, sf, objects, rd, scal);
-  if (sf.n_rl > 0 && sf.n_rl < lanes_below) hipLaunchKernelGGL(k_relpose_lin_lanes, dim3(grid_for(sf.n_rl, 4)), dim3(64), 0, s, b, sf, poses, rd, scal);
-  else if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
+  if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {
