@@ -397,7 +397,8 @@ class ObjectPoseGraphOptimizer {
     last_optimized_nodes_ = optimized_frames.size(); last_optimized_features_ = fp.features.size(); last_optimized_objects_ = fp.objects.size();
     if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);   // :625-629
     std::unordered_map<obvi::ResidualBlockId, FactorInfo> current_residual_block_info;
-    for (size_t i = 0; i < fp.blocks.size(); ++i) current_residual_block_info[(obvi::ResidualBlockId)i] = fp.blocks[i];
+    current_residual_block_info.reserve(fp.blocks.size());
+    for (size_t i = 0; i < fp.blocks.size(); ++i) current_residual_block_info.emplace((obvi::ResidualBlockId)i, fp.blocks[i]);
     return current_residual_block_info;
   }
 

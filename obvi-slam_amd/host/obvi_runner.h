@@ -250,7 +250,8 @@ class OfflineProblemRunner {
         std::vector<obvi::ResidualBlockId> ordered;
         for (size_t i = 0; i < v.size(); ++i) if (i + 1 == v.size() || v[i + 1].first != v[i].first) ordered.push_back(v[i].second);
         const size_t n_outliers = (size_t)(ordered.size() * iteration_params.feature_outlier_percentage_);
-        for (size_t i = 0; i < n_outliers; ++i) excluded.insert(block_info.at(ordered[i]));
+        excluded.reserve(excluded.size() + n_outliers);
+        for (size_t i = 0; i < n_outliers; ++i) excluded.insert(ordered[i] < problem.flat.blocks.size() ? problem.flat.blocks[ordered[i]] : block_info.at(ordered[i]));
       }
     }
     if (two_phase) {                                                                                                         // PHASE II :803-892
