@@ -3,7 +3,7 @@
 ground-truth features, calibration).  Run in the build container, where /root/reference exists; the
 fixtures travel, the reference does not.
 
-  data/vslam_set2, vslam_set4, vslam_set6, vslam_set7   simulated sequences with ground truth (data/vslam_set2/README.md):
+  data/vslam_set2, vslam_set4, vslam_set5, vslam_set6, vslam_set7   simulated sequences with ground truth (data/vslam_set2/README.md):
         pixels are the exact projections of features/features.txt from the frame poses, so the reprojection
         residual of the restated model at ground truth must vanish -- a known answer for the whole convention
         chain (quaternion -> axis-angle pose block, robot <- camera extrinsics, rectification, pixel axes).
@@ -57,7 +57,7 @@ def pack(directory, pattern, out_name, with_features=True, pixel_dtype=np.float6
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
-    for s in ("vslam_set2", "vslam_set4", "vslam_set6", "vslam_set7"):
+    for s in ("vslam_set2", "vslam_set4", "vslam_set5", "vslam_set6", "vslam_set7"):
         pack(os.path.join(REF, s), "[0-9]*.txt", s + ".npz")
     # pixels of the ORB tracks are written with 6 decimals of a float32 detector output: float32 holds them exactly enough
     pack(os.path.join(REF, "TUM_fr2_pioneer_360_consecutive_frame_matching"), "*_curr_*.txt", "tum_fr2_360_tracks.npz",

@@ -1,6 +1,6 @@
 """CPU: the oracle against the known answers the reference's own data sets hold.
 
-data/vslam_set2, 4, 6, 7 are simulated sequences whose pixels are the exact projections of the ground-truth features
+data/vslam_set2, 4, 5, 6, 7 are simulated sequences whose pixels are the exact projections of the ground-truth features
 from the ground-truth frame poses (data/vslam_set2/README.md), written with 6 decimals.  The restated reprojection model
 -- quaternion -> axis-angle pose block, robot <- camera extrinsics, rectified pixel, multiplier f / sigma -- must
 therefore give a zero residual for every observation at ground truth, and bundle adjustment started away from ground
@@ -14,7 +14,7 @@ import helpers
 import synth
 
 # worst projection error the 6-decimal text of each set allows (pixels); set 6 turns the camera, its quaternions' rounding shows
-GT_PIXEL_TOL = {"vslam_set2": 5e-5, "vslam_set4": 3e-4, "vslam_set6": 2e-3, "vslam_set7": 2e-4}
+GT_PIXEL_TOL = {"vslam_set2": 5e-5, "vslam_set4": 3e-4, "vslam_set5": 4e-4, "vslam_set6": 2e-3, "vslam_set7": 2e-4}
 
 
 @pytest.mark.parametrize("name", sorted(GT_PIXEL_TOL))
@@ -43,7 +43,7 @@ def perturbed(prob, seed, pose_sigma=(0.05, 0.01), point_sigma=0.2):
 
 # how far the minimum may sit from ground truth (m / rad): the rounding of the text, amplified by the 0.5 m baseline of the
 # two fixed poses that sets the scale (set 6 rounds its quaternions as well)
-GT_POSE_TOL = {"vslam_set2": 1e-3, "vslam_set4": 1e-4, "vslam_set6": 1e-2, "vslam_set7": 1e-6}
+GT_POSE_TOL = {"vslam_set2": 1e-3, "vslam_set4": 1e-4, "vslam_set5": 1e-2, "vslam_set6": 1e-2, "vslam_set7": 1e-6}
 
 
 @pytest.mark.parametrize("name", sorted(GT_POSE_TOL))
