@@ -488,79 +488,79 @@ void prepare(obvi_ba_handle* h) {
     std::vector<int64_t> window_pairs_t(parts, 0);
     std::vector<uint8_t> twin_t(parts, 0);
     parallel_ranges(L, parts, [&](int part, int64_t l0, int64_t l1) {
-    struct Ob { uint32_t a; int32_t vid, f; };
-    std::vector<Ob> obs;
-    std::vector<int32_t> chunks;
-    std::vector<Pair>& pairs = pairs_t[part];
-    std::vector<Visit>& visit_list = visits_t[part];
-    int64_t n_window_pairs = 0;
-    bool any_twin = false;
-    for (int64_t l = l0; l < l1; ++l) {
-      if (!point_var[l]) continue;
-      const uint32_t beg = h->h_point_ptr[l], end = h->h_point_ptr[l + 1];
-      obs.clear();
-      for (uint32_t a = beg; a < end; ++a) {
-        if (!h->h_rp_active[a]) continue;
-        const int32_t v = pose_vid[h->h_rp_pose[a]];
-        if (v >= 0) obs.push_back({a, v, nat[h->h_rp_pose[a]]});
-      }
-      // the strip kernel takes a point unless one of its frames holds more than two observations
-      // (the observations of a point are sorted by pose, hence by frame: equal frames are neighbours)
-      bool windowed = true, twin = false;
-      for (size_t i = 0; i < obs.size() && windowed;) {
-        size_t e = i + 1;
-        while (e < obs.size() && obs[e].f == obs[i].f) ++e;
-        if (e - i > 2) windowed = false;
-        if (e - i == 2) twin = true;
-        i = e;
-      }
-      if (windowed) {
-        chunks.clear();
-        for (const Ob& x : obs) { if (chunks.empty() || chunks.back() != x.f / SR) chunks.push_back(x.f / SR); }
-        for (int32_t c : chunks) {
-          // frames of the strip [fbase, fbase + 48) the point covers, then the 16x16 tiles (r, c) of the 3 x 18 strip it touches
-          const int32_t fbase = c * SR - SBACK;
-          uint64_t m = 0, tiles = 0;
-          for (const Ob& x : obs) if (x.f >= fbase && x.f < (c + 1) * SR) m |= 1ull << (x.f - fbase);
-          auto frames_of_tile = [](int t0) { return ((2ull << ((16 * t0 + 15) / 6)) - 1) & ~((1ull << ((16 * t0) / 6)) - 1); };
-          constexpr int kColTiles = kSchurWindowFrames * 6 / 16, kRowTiles = SR * 6 / 16, kRowTile0 = SBACK * 6 / 16;
-          static_assert(kRowTiles == 3, "three row tiles per chunk (bit 3 tc + tr of a visit's tile word)");
-          uint64_t rows = 0;                                                        // row tiles the point touches
-          for (int tr = 0; tr < kRowTiles; ++tr) if (m & frames_of_tile(tr + kRowTile0)) rows |= 1ull << tr;
-          for (int tc = 0; tc < kColTiles; ++tc) {
-            if (!(m & frames_of_tile(tc))) continue;
-            uint64_t allowed = 0;                                                   // lower triangle: tc <= tr + kRowTile0
-            for (int tr = 0; tr < kRowTiles; ++tr) if (tc <= tr + kRowTile0) allowed |= 1ull << tr;
-            tiles |= (rows & allowed) << (3 * tc);
+      struct Ob { uint32_t a; int32_t vid, f; };
+      std::vector<Ob> obs;
+      std::vector<int32_t> chunks;
+      std::vector<Pair>& pairs = pairs_t[part];
+      std::vector<Visit>& visit_list = visits_t[part];
+      int64_t n_window_pairs = 0;
+      bool any_twin = false;
+      for (int64_t l = l0; l < l1; ++l) {
+        if (!point_var[l]) continue;
+        const uint32_t beg = h->h_point_ptr[l], end = h->h_point_ptr[l + 1];
+        obs.clear();
+        for (uint32_t a = beg; a < end; ++a) {
+          if (!h->h_rp_active[a]) continue;
+          const int32_t v = pose_vid[h->h_rp_pose[a]];
+          if (v >= 0) obs.push_back({a, v, nat[h->h_rp_pose[a]]});
+        }
+        // the strip kernel takes a point unless one of its frames holds more than two observations
+        // (the observations of a point are sorted by pose, hence by frame: equal frames are neighbours)
+        bool windowed = true, twin = false;
+        for (size_t i = 0; i < obs.size() && windowed;) {
+          size_t e = i + 1;
+          while (e < obs.size() && obs[e].f == obs[i].f) ++e;
+          if (e - i > 2) windowed = false;
+          if (e - i == 2) twin = true;
+          i = e;
+        }
+        if (windowed) {
+          chunks.clear();
+          for (const Ob& x : obs) { if (chunks.empty() || chunks.back() != x.f / SR) chunks.push_back(x.f / SR); }
+          for (int32_t c : chunks) {
+            // frames of the strip [fbase, fbase + 48) the point covers, then the 16x16 tiles (r, c) of the 3 x 18 strip it touches
+            const int32_t fbase = c * SR - SBACK;
+            uint64_t m = 0, tiles = 0;
+            for (const Ob& x : obs) if (x.f >= fbase && x.f < (c + 1) * SR) m |= 1ull << (x.f - fbase);
+            auto frames_of_tile = [](int t0) { return ((2ull << ((16 * t0 + 15) / 6)) - 1) & ~((1ull << ((16 * t0) / 6)) - 1); };
+            constexpr int kColTiles = kSchurWindowFrames * 6 / 16, kRowTiles = SR * 6 / 16, kRowTile0 = SBACK * 6 / 16;
+            static_assert(kRowTiles == 3, "three row tiles per chunk (bit 3 tc + tr of a visit's tile word)");
+            uint64_t rows = 0;                                                        // row tiles the point touches
+            for (int tr = 0; tr < kRowTiles; ++tr) if (m & frames_of_tile(tr + kRowTile0)) rows |= 1ull << tr;
+            for (int tc = 0; tc < kColTiles; ++tc) {
+              if (!(m & frames_of_tile(tc))) continue;
+              uint64_t allowed = 0;                                                   // lower triangle: tc <= tr + kRowTile0
+              for (int tr = 0; tr < kRowTiles; ++tr) if (tc <= tr + kRowTile0) allowed |= 1ull << tr;
+              tiles |= (rows & allowed) << (3 * tc);
+            }
+            visit_list.push_back({c, (uint32_t)l, beg, (uint32_t)(end - beg), twin, tiles});
           }
-          visit_list.push_back({c, (uint32_t)l, beg, (uint32_t)(end - beg), twin, tiles});
+          any_twin = any_twin || twin;
         }
-        any_twin = any_twin || twin;
-      }
-      // every pair lies inside the strip of its later frame's chunk iff the point's first frame lies inside the strip of its last frame
-      const bool all_in_window = windowed && !obs.empty() && obs.front().f >= (obs.back().f / SR) * SR - SBACK;
-      if (all_in_window) n_window_pairs += (int64_t)(obs.size() * (obs.size() + 1) / 2);
-      if (all_in_window && pair_bitmap) {
+        // every pair lies inside the strip of its later frame's chunk iff the point's first frame lies inside the strip of its last frame
+        const bool all_in_window = windowed && !obs.empty() && obs.front().f >= (obs.back().f / SR) * SR - SBACK;
+        if (all_in_window) n_window_pairs += (int64_t)(obs.size() * (obs.size() + 1) / 2);
+        if (all_in_window && pair_bitmap) {
+          for (size_t i = 0; i < obs.size(); ++i)
+            for (size_t j = 0; j <= i; ++j)
+              __atomic_store_n(&pose_pair[(size_t)std::max(obs[i].vid, obs[j].vid) * (size_t)h->nPv + (size_t)std::min(obs[i].vid, obs[j].vid)], (uint8_t)1, __ATOMIC_RELAXED);
+          continue;
+        }
+        if (all_in_window) n_window_pairs -= (int64_t)(obs.size() * (obs.size() + 1) / 2);   // counted pair by pair below
         for (size_t i = 0; i < obs.size(); ++i)
-          for (size_t j = 0; j <= i; ++j)
-            __atomic_store_n(&pose_pair[(size_t)std::max(obs[i].vid, obs[j].vid) * (size_t)h->nPv + (size_t)std::min(obs[i].vid, obs[j].vid)], (uint8_t)1, __ATOMIC_RELAXED);
-        continue;
+          for (size_t j = 0; j <= i; ++j) {
+            const Ob& x = obs[i]; const Ob& y = obs[j];
+            if (pair_bitmap) __atomic_store_n(&pose_pair[(size_t)std::max(x.vid, y.vid) * (size_t)h->nPv + (size_t)std::min(x.vid, y.vid)], (uint8_t)1, __ATOMIC_RELAXED);
+            else mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
+            // inside the strip of the later frame's chunk?  (same test as the kernel's inverse map)
+            const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
+            if (windowed && fq >= (fp / SR) * SR - SBACK) { ++n_window_pairs; continue; }
+            const Ob& hi = x.vid >= y.vid ? x : y; const Ob& lo = x.vid >= y.vid ? y : x;
+            pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, hi.a, lo.a});
+            if (i != j && x.vid == y.vid) pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, lo.a, hi.a});
+          }
       }
-      if (all_in_window) n_window_pairs -= (int64_t)(obs.size() * (obs.size() + 1) / 2);   // counted pair by pair below
-      for (size_t i = 0; i < obs.size(); ++i)
-        for (size_t j = 0; j <= i; ++j) {
-          const Ob& x = obs[i]; const Ob& y = obs[j];
-          if (pair_bitmap) __atomic_store_n(&pose_pair[(size_t)std::max(x.vid, y.vid) * (size_t)h->nPv + (size_t)std::min(x.vid, y.vid)], (uint8_t)1, __ATOMIC_RELAXED);
-          else mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
-          // inside the strip of the later frame's chunk?  (same test as the kernel's inverse map)
-          const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
-          if (windowed && fq >= (fp / SR) * SR - SBACK) { ++n_window_pairs; continue; }
-          const Ob& hi = x.vid >= y.vid ? x : y; const Ob& lo = x.vid >= y.vid ? y : x;
-          pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, hi.a, lo.a});
-          if (i != j && x.vid == y.vid) pairs.push_back({(uint64_t)hi.vid * (uint64_t)(h->nPv + 1) + (uint64_t)lo.vid, lo.a, hi.a});
-        }
-    }
-    window_pairs_t[part] = n_window_pairs; twin_t[part] = any_twin ? 1 : 0;
+      window_pairs_t[part] = n_window_pairs; twin_t[part] = any_twin ? 1 : 0;
     });
     for (int t = 0; t < parts; ++t) {
       pairs.insert(pairs.end(), pairs_t[t].begin(), pairs_t[t].end());
