@@ -1043,7 +1043,7 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
 }
 
 __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, ReducedDev rd, const double* __restrict__ poses, const double* __restrict__ objects,
-                                                              double* __restrict__ poses_cand, double* __restrict__ objects_cand, double* scal) {
+                                                              double* __restrict__ poses_cand, double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, double* scal) {
   const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   double stepsq = 0.0, bad = 0.0, model = 0.0;
   if (t < b.P + b.O) {
@@ -1066,6 +1066,18 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
       }
       xc[k] = v;
     }
+    if (is_pose && pc_cand != nullptr) {   // the candidate's pose cache (what k_pose_cache would write), while the pose is in registers
+      double pose[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pose[k] = xc[k];
+      PoseCache pc;
+      make_pose_cache(pose, &pc);
+      pc_cand[idx] = pc;
+      double* soa = reinterpret_cast<double*>(pc_cand + b.P + 1);
+      const double* f = reinterpret_cast<const double*>(&pc);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) soa[k * b.P + idx] = f[k];
+    }
   }
   block_accumulate(stepsq, scal + SC_STEPSQ);
   block_accumulate(bad, scal + SC_NONFINITE);
@@ -1080,9 +1092,8 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
 // ---------------------------------------------------------------------------------------
 // One workgroup per pose over the pose-ordered copy of the observations: the pose cache is uniform per workgroup (a gather
 // of it per observation, in point order, costs more L2 bandwidth than everything else the kernel reads).
-__global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams,
-                                                       const PoseCache* __restrict__ pc, const double* __restrict__ points, int mode, double* scal) {
-  const int64_t p = blockIdx.x;
+__device__ __forceinline__ void cost_reproj_block(int64_t p, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* __restrict__ cams,
+                                                  const PoseCache* __restrict__ pc, const double* __restrict__ points, int mode, double* scal) {
   const bool pose_var = b.pose_vid[p] >= 0;
   const PoseCache cache = pc[p];
   double cost = 0.0;
@@ -1103,9 +1114,9 @@ __global__ void __launch_bounds__(kBlock) k_cost_reproj(BlocksDev b, ReprojPoseD
 }
 
 // small factors: one kernel, thread ranges [bbox | shape | ltm | relpose]
-__global__ void __launch_bounds__(64) k_cost_small(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams,
-                                                  const double* __restrict__ poses, const double* __restrict__ objects, int mode, double* scal) {
-  int64_t t = blockIdx.x * 64LL + threadIdx.x;
+__device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* __restrict__ cams,
+                                                 const double* __restrict__ poses, const double* __restrict__ objects, int mode, double* scal) {
+  int64_t t = block * (int64_t)kBlock + threadIdx.x;
   double cost = 0.0, rho0, w;
   if (t < sf.n_bb) {
     const int64_t i = t;
@@ -1148,7 +1159,14 @@ __global__ void __launch_bounds__(64) k_cost_small(BlocksDev b, SmallFactorsDev 
     }
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED), cost);
+  if ((threadIdx.x & 63) == 0 && cost != 0.0) atomic_add_f64(scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED), cost);
+}
+// one launch: workgroups [0, n_pose_blocks) take the reprojection factors of a pose, the rest the small factor families
+__global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, SmallFactorsDev sf, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
+                                                const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ objects, int mode,
+                                                int n_pose_blocks, double* scal) {
+  if ((int)blockIdx.x < n_pose_blocks) cost_reproj_block(blockIdx.x, b, rq, cams, pc, points, mode, scal);
+  else cost_small_block((int64_t)blockIdx.x - n_pose_blocks, b, sf, cams, poses, objects, mode, scal);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1377,8 +1395,8 @@ void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
   if (b.L > 0) hipLaunchKernelGGL(k_point_backsub, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, scal);
 }
 void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,
-                               double* poses_cand, double* objects_cand, double* scal) {
-  if (b.P + b.O > 0) hipLaunchKernelGGL(k_apply_reduced_step, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, rd, poses, objects, poses_cand, objects_cand, scal);
+                               double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal) {
+  if (b.P + b.O > 0) hipLaunchKernelGGL(k_apply_reduced_step, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, rd, poses, objects, poses_cand, objects_cand, pc_cand, scal);
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
@@ -1388,9 +1406,10 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   const double* poses = mode == 0 ? poses_cand : poses_cur;
   const double* points = mode == 0 ? points_cand : points_cur;
   const double* objects = mode == 0 ? objects_cand : objects_cur;
-  if (rq.n > 0 && b.P > 0) hipLaunchKernelGGL(k_cost_reproj, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, mode, scal);
+  const int n_pose_blocks = rq.n > 0 && b.P > 0 ? (int)b.P : 0;
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
-  if (ns > 0) hipLaunchKernelGGL(k_cost_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, mode, scal);
+  const unsigned grid = (unsigned)n_pose_blocks + grid_for(ns, kBlock);
+  if (grid > 0) hipLaunchKernelGGL(k_cost, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
                      const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,
