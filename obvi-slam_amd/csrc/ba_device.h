@@ -126,11 +126,9 @@ constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSch
 void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
                          const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
                          const int32_t* wg_f0, const int32_t* wg_group);
-void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
-                          const double* points, double* points_cand, double* scal);
-// also writes the candidate's pose cache (both layouts of launch_pose_cache) when pc_cand is given
-void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,
-                               double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal);
+// point back-substitution and the candidate poses / objects (with the candidate's pose cache, both layouts of launch_pose_cache), one launch
+void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
+                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal);
 // trial-point cost + model cost change.  mode 0: cost at (poses,points,objects) into SC_COST_CAND and
 // model change of the step (cand - current); mode 1: cost only, split into SC_COST / SC_COST_FIXED.
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams,

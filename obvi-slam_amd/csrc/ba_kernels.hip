@@ -1004,9 +1004,9 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
 // ---------------------------------------------------------------------------------------
 // K6.  Back-substitution of the eliminated points, candidate point.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points,
-                                                         double* __restrict__ points_cand, double* scal) {
-  const int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+__device__ __forceinline__ void point_backsub_block(int64_t block, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* __restrict__ points,
+                                                    double* __restrict__ points_cand, double* scal) {
+  const int64_t l = block * (int64_t)kBlock + threadIdx.x;
   double stepsq = 0.0, bad = 0.0, model = 0.0;
   if (l < b.L) {
     double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
@@ -1042,9 +1042,9 @@ __global__ void __launch_bounds__(kBlock) k_point_backsub(BlocksDev b, ReprojDev
   block_accumulate(model, scal + SC_MODEL_CHANGE);
 }
 
-__global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, ReducedDev rd, const double* __restrict__ poses, const double* __restrict__ objects,
-                                                              double* __restrict__ poses_cand, double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, double* scal) {
-  const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+__device__ __forceinline__ void apply_reduced_step_block(int64_t block, const BlocksDev& b, const ReducedDev& rd, const double* __restrict__ poses, const double* __restrict__ objects,
+                                                         double* __restrict__ poses_cand, double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, double* scal) {
+  const int64_t t = block * (int64_t)kBlock + threadIdx.x;
   double stepsq = 0.0, bad = 0.0, model = 0.0;
   if (t < b.P + b.O) {
     const bool is_pose = t < b.P;
@@ -1082,6 +1082,14 @@ __global__ void __launch_bounds__(kBlock) k_apply_reduced_step(BlocksDev b, Redu
   block_accumulate(stepsq, scal + SC_STEPSQ);
   block_accumulate(bad, scal + SC_NONFINITE);
   block_accumulate(model, scal + SC_MODEL_CHANGE);
+}
+
+// K6 + K9 in one launch (both only read y): workgroups [0, n_point_blocks) back-substitute the features, the rest form the candidate poses / objects
+__global__ void __launch_bounds__(kBlock) k_backsub_apply(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points, double* __restrict__ points_cand,
+                                                         const double* __restrict__ poses, const double* __restrict__ objects, double* __restrict__ poses_cand,
+                                                         double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, int n_point_blocks, double* scal) {
+  if ((int)blockIdx.x < n_point_blocks) point_backsub_block(blockIdx.x, b, rp, pt, rd, points, points_cand, scal);
+  else apply_reduced_step_block((int64_t)blockIdx.x - n_point_blocks, b, rd, poses, objects, poses_cand, objects_cand, pc_cand, scal);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1390,13 +1398,11 @@ void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const Blocks
   if (has_twins) hipLaunchKernelGGL(k_schur_window<true>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
   else hipLaunchKernelGGL(k_schur_window<false>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
 }
-void launch_point_backsub(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
-                          double* points_cand, double* scal) {
-  if (b.L > 0) hipLaunchKernelGGL(k_point_backsub, dim3(grid_for(b.L, kBlock)), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, scal);
-}
-void launch_apply_reduced_step(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const double* poses, const double* objects,
-                               double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal) {
-  if (b.P + b.O > 0) hipLaunchKernelGGL(k_apply_reduced_step, dim3(grid_for(b.P + b.O, kBlock)), dim3(kBlock), 0, s, b, rd, poses, objects, poses_cand, objects_cand, pc_cand, scal);
+void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
+                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal) {
+  const int n_point_blocks = (int)grid_for(b.L, kBlock);
+  const unsigned grid = (unsigned)n_point_blocks + grid_for(b.P + b.O, kBlock);
+  if (grid > 0) hipLaunchKernelGGL(k_backsub_apply, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal);
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,

@@ -1015,11 +1015,8 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     h->ck_used = 0;
   }
   record(h, PH_BACKSUB);
-  if (solve) launch_point_backsub(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), scal);
-  record(h, PH_APPLY);
-  if (solve) {
-    launch_apply_reduced_step(s, b, rd, h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), h->d_pc_c.get(), scal);
-  }
+  if (solve) launch_backsub_apply(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), h->d_pc_c.get(), scal);
+  record(h, PH_APPLY);   // (the candidate poses / objects are formed in the same launch)
   record(h, PH_COST);
   if (solve) launch_cost(s, b, reproj_pose_dev(h), sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
                          h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);

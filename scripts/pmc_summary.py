@@ -5,7 +5,7 @@ gfx950 correction: the guide says FETCH_SIZE reports half the bytes of a wide co
 library read a known number of bytes and pin the factor for the two access patterns that occur here:
   * k_copy3 streams 3 arrays with full-line coalesced loads: 7.31 MB read (same as it writes; WRITE_SIZE reports 7.31 MB) and
     raw FETCH_SIZE reports 3.67 MB                      -> factor 2 for full-line streaming reads
-  * k_point_backsub reads every Z record once (2 990 848 x 144 B = 430.7 MB) through per-lane 144-byte-strided loads; with
+  * k_point_backsub (today the point part of k_backsub_apply) reads every Z record once (2 990 848 x 144 B = 430.7 MB) through per-lane 144-byte-strided loads; with
     8-byte loads raw FETCH_SIZE reported 451.8 MB          -> factor 1 for gathers / partial lines
     (the current kernel uses 16-byte loads and reports 322.9 MB for the same >= 430.7 MB: part of its requests are counted at
     half, so for gather kernels with 16-byte loads the factor-1 figure is a LOWER bound, up to 1.4x low)
