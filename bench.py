@@ -11,9 +11,15 @@ the timed solve so exactly K iterations run.
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: a monolithic global BA does not shard without exchanging the reduced system
- -- each rank solves an independent replica (its own seed), no
-data-path collective; value = total LM iterations of all ranks / max-over-ranks time.
+`--gpus N` is honoured: with N > 1 and no launcher environment (WORLD_SIZE unset) the script re-launches itself under
+torch.distributed.run with N ranks; under a launcher it refuses to run if WORLD_SIZE != N.
+
+N > 1 (BASELINE.json configs[3]): the workload that shards is independent 500-keyframe local-BA windows, one per
+GPU, SHARING object blocks: per LM step an RCCL all-reduce of the shared objects' J^T J blocks / gradients, of the trailing
+shared tiles of the reduced system, and of the scalar block (compiled ncclAllReduce forwarder libobvi_rccl.so on the handle's
+own stream; `--hook torch` routes the same callback through torch.distributed instead).  That is the default for N > 1
+(`--config 4`); weak scaling: value = total LM iterations of all ranks / max-over-ranks time.  A monolithic global BA does not
+shard without exchanging the reduced system: `--config 3` with N > 1 runs N independent replicas, no data-path collective.
 
 Prints ONE JSON line on rank 0.
 """
@@ -97,9 +103,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="default: 3 on one GPU, 4 (windows sharing objects, RCCL all-reduce) on several")
+    ap.add_argument("--hook", choices=("rccl", "torch"), default="rccl", help="all-reduce callback of config 4: libobvi_rccl.so (compiled) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one.  One process per GPU, rendezvous on the loopback address.
+        import socket
+        import subprocess
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import obvi_ba
@@ -107,13 +124,19 @@ def main():
 
     import dist_util
     rank, local_rank, world = dist_util.rank_info()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit("bench.py: rank %d needs device %d but only %d visible (one process per GPU)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.config is None:
+        args.config = 3 if world == 1 else 4
 
     cfg = CONFIGS[args.config]
     shared = bool(cfg.get("shared")) and world > 1
@@ -127,9 +150,21 @@ def main():
     t_up = time.perf_counter()
     synth.upload(ba, prob)          # inputs now resident in HBM
     upload_ms = 1e3 * (time.perf_counter() - t_up)
+    rccl_ranks = None
+    comm = None
     if shared:
-        ba.set_shared_objects(np.ones(len(prob["objects"]), np.uint8), rank, world)
-        ba.set_allreduce(dist_util.torch_allreduce(dist))
+        is_shared = np.ones(len(prob["objects"]), np.uint8)
+        if args.hook == "rccl":
+            # the job's ncclUniqueId travels over the launcher's process group; the data path then never touches Python
+            ids = [dist_util.RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
+            comm.attach(ba, is_shared)
+            rccl_ranks = comm.world()
+        else:
+            ba.set_shared_objects(is_shared, rank, world)
+            ba.set_allreduce(dist_util.torch_allreduce(dist))
+            rccl_ranks = dist.get_world_size()
     t_sym = time.perf_counter()
     ba.evaluate(True, False)        # builds the reduced-program bookkeeping / symbolic plan (not timed: the reference times "build" separately)
     t_ev = time.perf_counter()
@@ -216,12 +251,13 @@ def main():
                         "boundary, about 3 us) in an instrumented solve of the same steps; rocprof_avg_us = kernel-only average of the committed "
                         "rocprofv3 summary (profiles/)"}
         out = {
-            "metric": "global-BA LM iterations/s", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
+            "metric": "global-BA LM iterations/s" if not cfg.get("shared") else "local-BA LM iterations/s (windows sharing objects)", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "keyframes": stats["P"], "features": stats["L"], "objects": stats["O"],
                        "reprojection_obs": stats["N_r"], "bbox_obs": stats["N_b"], "reduced_rows": int(pst["reduced_rows"]),
-                       "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single", "steps_done": steps_done,
+                       "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single",
+                       "rccl_ranks": rccl_ranks, "allreduce_hook": (args.hook if shared else None), "steps_done": steps_done,
                        "final_cost": summ.final_cost, "termination": summ.message.decode()},
             "roofline": roof,
             "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
@@ -234,6 +270,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
+        ba.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

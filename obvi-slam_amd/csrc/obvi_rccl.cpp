@@ -1,0 +1,152 @@
+// obvi_rccl.cpp -- libobvi_rccl.so: the compiled RCCL implementation of libobvi_ba's all-reduce callback
+// (include/obvi_rccl.h).  One process per GPU; the collectives are enqueued on the stream the library passes in
+// (the handle's stream), so the exchange is ordered with the kernels around it and the host never waits for it.
+#include "../../include/obvi_rccl.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+
+static_assert(sizeof(ncclUniqueId) == OBVI_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+
+struct obvi_rccl_comm {
+  ncclComm_t comm = nullptr;
+  int32_t rank = 0, world = 1, device = 0;
+  double* bounce = nullptr;     // device buffer for the small host all-reduces
+  hipStream_t stream = nullptr; // their stream
+  std::string err;
+};
+
+namespace {
+constexpr int kBounceDoubles = 256;
+int fail(obvi_rccl_comm* c, int code, const char* what, const char* detail) {
+  if (c) c->err = std::string(what) + ": " + detail;
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+int obvi_rccl_unique_id(char out[OBVI_RCCL_ID_BYTES]) {
+  if (!out) return OBVI_ERR_INVALID_ARGUMENT;
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return OBVI_ERR_HIP;
+  std::memcpy(out, &id, sizeof(id));
+  return OBVI_OK;
+}
+
+int obvi_rccl_comm_create(const char id_bytes[OBVI_RCCL_ID_BYTES], int32_t rank, int32_t world, int32_t device, obvi_rccl_comm** out) {
+  if (!out) return OBVI_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!id_bytes || world < 1 || rank < 0 || rank >= world) return OBVI_ERR_INVALID_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return OBVI_ERR_NO_DEVICE;
+  obvi_rccl_comm* c = new (std::nothrow) obvi_rccl_comm();
+  if (!c) return OBVI_ERR_HIP;
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->bounce), sizeof(double) * kBounceDoubles) != hipSuccess) {
+    obvi_rccl_comm_destroy(c);
+    return OBVI_ERR_HIP;
+  }
+  const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    std::fprintf(stderr, "obvi_rccl: ncclCommInitRank failed: %s\n", ncclGetErrorString(r));
+    c->comm = nullptr;
+    obvi_rccl_comm_destroy(c);
+    return OBVI_ERR_HIP;
+  }
+  *out = c;
+  return OBVI_OK;
+}
+
+int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, double timeout_s, obvi_rccl_comm** out) {
+  if (!path || !out) return OBVI_ERR_INVALID_ARGUMENT;
+  char id[OBVI_RCCL_ID_BYTES];
+  if (rank == 0) {
+    const int rc = obvi_rccl_unique_id(id);
+    if (rc != OBVI_OK) return rc;
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return OBVI_ERR_INVALID_ARGUMENT;
+    const bool ok = std::fwrite(id, 1, sizeof(id), f) == sizeof(id);
+    std::fclose(f);
+    if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return OBVI_ERR_INVALID_ARGUMENT; }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE* f = std::fopen(path, "rb");
+      if (f) {
+        const size_t n = std::fread(id, 1, sizeof(id), f);
+        std::fclose(f);
+        if (n == sizeof(id)) break;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return OBVI_ERR_NOT_READY;
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  }
+  return obvi_rccl_comm_create(id, rank, world, device, out);
+}
+
+void obvi_rccl_comm_destroy(obvi_rccl_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->bounce) (void)hipFree(c->bounce);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int32_t obvi_rccl_comm_rank(const obvi_rccl_comm* c) { return c ? c->rank : -1; }
+int32_t obvi_rccl_comm_world(const obvi_rccl_comm* c) {
+  if (!c || !c->comm) return -1;
+  int n = -1;
+  return ncclCommCount(c->comm, &n) == ncclSuccess ? n : -1;
+}
+const char* obvi_rccl_last_error(const obvi_rccl_comm* c) { return c ? c->err.c_str() : "null communicator"; }
+
+int obvi_rccl_allreduce(void* user, void* device_buf, int64_t count_f64, int32_t op, void* stream) {
+  obvi_rccl_comm* c = static_cast<obvi_rccl_comm*>(user);
+  if (!c || !c->comm || !device_buf || count_f64 < 0) return OBVI_ERR_INVALID_ARGUMENT;
+  if (count_f64 == 0) return 0;
+  const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+  const ncclResult_t r = ncclAllReduce(device_buf, device_buf, (size_t)count_f64, ncclDouble, rop, c->comm, static_cast<hipStream_t>(stream));
+  if (r != ncclSuccess) return fail(c, (int)r, "ncclAllReduce", ncclGetErrorString(r));
+  return 0;
+}
+
+int obvi_rccl_attach(obvi_ba_handle* h, obvi_rccl_comm* c, const uint8_t* is_shared) {
+  if (!h || !c) return OBVI_ERR_INVALID_ARGUMENT;
+  const int rc = obvi_ba_set_shared_objects(h, is_shared, c->rank, c->world);
+  if (rc != OBVI_OK) return rc;
+  return obvi_ba_set_allreduce(h, obvi_rccl_allreduce, c);
+}
+
+int obvi_rccl_host_allreduce(obvi_rccl_comm* c, double* host_buf, int32_t count, int32_t op) {
+  if (!c || !c->comm || !host_buf || count < 0 || count > kBounceDoubles) return OBVI_ERR_INVALID_ARGUMENT;
+  if (count == 0) return OBVI_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return OBVI_ERR_HIP;
+  if (hipMemcpyAsync(c->bounce, host_buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream) != hipSuccess) return OBVI_ERR_HIP;
+  const int rc = obvi_rccl_allreduce(c, c->bounce, count, op, c->stream);
+  if (rc != 0) return OBVI_ERR_HIP;
+  if (hipMemcpyAsync(host_buf, c->bounce, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return OBVI_ERR_HIP;
+  return hipStreamSynchronize(c->stream) == hipSuccess ? OBVI_OK : OBVI_ERR_HIP;
+}
+
+int obvi_rccl_barrier(obvi_rccl_comm* c) {
+  double one = 1.0;
+  return obvi_rccl_host_allreduce(c, &one, 1, 0);
+}
+
+}  // extern "C"

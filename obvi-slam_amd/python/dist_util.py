@@ -1,6 +1,8 @@
-"""Rank plumbing shared by bench.py and the multi-process tests: one process per GPU, independent
-windows (replicas) per rank, no data-path collective -- only the timing reduction of the bench
-contract (max over ranks) and the count of completed LM iterations (min over ranks)."""
+"""Rank plumbing shared by bench.py and the multi-process tests: one process per GPU.  Independent windows per rank;
+either replicas (no data-path collective) or windows that share object blocks, whose per-step all-reduces go
+through libobvi_rccl.so (compiled ncclAllReduce forwarder, RcclComm below), through torch.distributed (torch_allreduce),
+or -- tests without RCCL -- through a host bounce over any torch.distributed backend (staged_allreduce)."""
+import ctypes as C
 import os
 
 
@@ -51,3 +53,82 @@ def torch_allreduce(dist):
             dist.all_reduce(device_tensor(ptr, count), op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
         return 0
     return fn
+
+
+def staged_allreduce(dist):
+    """The same hook over any torch.distributed backend (gloo in the tests: two ranks on ONE GPU, where RCCL refuses to form a
+    communicator): device -> host on the library's stream, all_reduce on the host, host -> device on the same stream."""
+    import torch
+
+    def fn(ptr, count, op, stream):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            d = device_tensor(ptr, count)
+            h = d.cpu()                                     # synchronises the stream: everything before the exchange is done
+            dist.all_reduce(h, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+            d.copy_(h)
+        return 0
+    return fn
+
+
+class RcclComm:
+    """ctypes binding of include/obvi_rccl.h (libobvi_rccl.so): the compiled RCCL all-reduce callback of a C/C++ host."""
+    ID_BYTES = 128
+
+    def __init__(self, rank, world, device, unique_id=None, id_file=None, timeout_s=120.0, library=None):
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = library or os.path.join(os.path.dirname(here), "csrc", "libobvi_rccl.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s not found: build it with __graft_entry__.build()" % path)
+        self._lib = C.CDLL(path)
+        self._c = C.c_void_p()
+        if id_file is not None:
+            rc = self._lib.obvi_rccl_comm_create_from_file(id_file.encode(), C.c_int32(rank), C.c_int32(world), C.c_int32(device), C.c_double(timeout_s), C.byref(self._c))
+        else:
+            if unique_id is None or len(unique_id) != self.ID_BYTES:
+                raise ValueError("unique_id: %d bytes from RcclComm.unique_id() on rank 0" % self.ID_BYTES)
+            rc = self._lib.obvi_rccl_comm_create(C.c_char_p(bytes(unique_id)), C.c_int32(rank), C.c_int32(world), C.c_int32(device), C.byref(self._c))
+        if rc != 0:
+            raise RuntimeError("obvi_rccl_comm_create failed: status %d" % rc)
+        self.rank, self.world_requested = rank, world
+
+    @staticmethod
+    def unique_id(library=None):
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib = C.CDLL(library or os.path.join(os.path.dirname(here), "csrc", "libobvi_rccl.so"))
+        buf = C.create_string_buffer(RcclComm.ID_BYTES)
+        if lib.obvi_rccl_unique_id(buf) != 0:
+            raise RuntimeError("obvi_rccl_unique_id failed")
+        return buf.raw
+
+    def world(self):
+        """ncclCommCount of the live communicator."""
+        self._lib.obvi_rccl_comm_world.restype = C.c_int32
+        return int(self._lib.obvi_rccl_comm_world(self._c))
+
+    def attach(self, ba, is_shared):
+        """obvi_ba_set_shared_objects + obvi_ba_set_allreduce(h, obvi_rccl_allreduce, comm): no Python in the solve's exchange."""
+        import numpy as np
+        m = None if is_shared is None else np.ascontiguousarray(is_shared, dtype=np.uint8)
+        rc = self._lib.obvi_rccl_attach(ba._h, self._c, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            raise RuntimeError("obvi_rccl_attach failed: status %d" % rc)
+        self._keep = m
+
+    def host_allreduce(self, values, op=0):
+        """op 0 sum, 1 max, 2 min over a short list of doubles."""
+        n = len(values)
+        buf = (C.c_double * n)(*values)
+        rc = self._lib.obvi_rccl_host_allreduce(self._c, buf, C.c_int32(n), C.c_int32(op))
+        if rc != 0:
+            raise RuntimeError("obvi_rccl_host_allreduce failed: status %d" % rc)
+        return [buf[i] for i in range(n)]
+
+    def barrier(self):
+        if self._lib.obvi_rccl_barrier(self._c) != 0:
+            raise RuntimeError("obvi_rccl_barrier failed")
+
+    def close(self):
+        if self._c:
+            self._lib.obvi_rccl_comm_destroy.restype = None
+            self._lib.obvi_rccl_comm_destroy(self._c)
+            self._c = C.c_void_p()
