@@ -50,7 +50,7 @@ typedef enum {
   OBVI_OK = 0,
   OBVI_ERR_INVALID_ARGUMENT = -1,
   OBVI_ERR_NO_DEVICE = -2,       /* HIP runtime/device unavailable: the product never falls back to CPU */
-  OBVI_ERR_HIP = -3,             /* a HIP API call failed; see obvi_ba_last_error */
+  OBVI_ERR_HIP = -3,             /* a HIP API call failed, a host exception, or a scheduling time-out inside the tile Cholesky; see obvi_ba_last_error */
   OBVI_ERR_OUT_OF_RANGE = -4,    /* an index array refers to a block that was not uploaded */
   OBVI_ERR_NOT_READY = -5,       /* solve/evaluate before the problem was uploaded */
   OBVI_ERR_NUMERICAL = -6        /* non-finite value / non-SPD matrix in a set_* covariance */
@@ -106,7 +106,7 @@ typedef struct {
   int32_t step_is_valid;
   int32_t step_is_successful;
   int32_t reserved;
-  double cost;
+  double cost;                /* accepted step: cost of the new point; rejected step: cost of the CANDIDATE; invalid step: cost of the current point (+ fixed cost) */
   double cost_change;
   double gradient_max_norm;
   double gradient_norm;
@@ -120,9 +120,9 @@ typedef struct {
  * (include/debugging/optimization_logger.h:192-203) and solveOptimization (:698-706). */
 typedef struct {
   int32_t termination_type;
-  int32_t is_solution_usable;        /* Summary::IsSolutionUsable() */
+  int32_t is_solution_usable;        /* Summary::IsSolutionUsable(); 0 (FAILURE): the parameter blocks are handed back as they were at entry */
   int32_t num_iterations;            /* == iterations.size(): includes the iteration-0 record */
-  int32_t num_successful_steps;
+  int32_t num_successful_steps;      /* iteration 0 counts as a successful step (successful + unsuccessful == num_iterations) */
   int32_t num_unsuccessful_steps;
   int32_t num_parameters_reduced;    /* scalar parameters in non-constant, used blocks */
   int32_t num_residuals_reduced;
@@ -200,9 +200,10 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* params, obvi_summ
 /* copies min(cap, summary.num_iterations) records of the last solve; returns the count */
 int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap);
 
-/* per factor type: mask_out[i]=0 for the floor(n_active*fraction) active factors with the
- * largest un-robustified squared residual at the current estimate, 1 otherwise
- * (offline_problem_runner.h:769-800).  Runs on the device. */
+/* per factor type: mask_out[i]=0 for the active factors that carry the (size_t)(d * fraction) largest DISTINCT values of the
+ * un-robustified squared residual at the current estimate, d = number of distinct values among the active factors, 1 otherwise:
+ * the reference keys a std::map by the residual value, so equal residuals overwrite each other and the count is taken on the
+ * de-duplicated set (offline_problem_runner.h:769-800).  Runs on the device. */
 int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t factor_type, double fraction,
                             uint8_t* mask_out, int64_t* num_excluded);
 

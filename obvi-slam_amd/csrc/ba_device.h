@@ -28,6 +28,8 @@ enum Scalar {
   SC_MODEL_CHANGE,    // -(J d)^T (r + J d / 2)
   SC_CHOL_FAIL,       // (as double) count of non-positive pivots
   SC_NONFINITE,       // (as double) count of non-finite step entries
+  SC_WAIT_TIMEOUT,    // (as double) potrf workgroups of k_update_potrf whose wait for the previous level's jobs timed out: a scheduling
+                      // failure, not a numerical one -- obvi_ba_solve returns OBVI_ERR_HIP (summed across ranks so that every rank does)
   SC_SUM_END,
   SC_GMAX_BITS = SC_SUM_END,  // max |g_i| (IEEE bits, via integer atomicMax; non-negative doubles order like u64)
   SC_COST_FIXED,      // residual blocks whose every parameter block is constant

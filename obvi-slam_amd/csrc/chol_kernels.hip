@@ -14,6 +14,7 @@
 //                   (potrf_mfma_tile: 4-column panels on the matrix cores, one workgroup per column)
 // then backward over levels descending, row oriented: y_k = L_kk^-T t_k, t_j -= L_kj^T y_k (k_backward, 1 workgroup per tile).
 #include <algorithm>
+#include <cstdlib>
 #include "ba_device.h"
 
 namespace obvi {
@@ -450,6 +451,56 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJo
   else update_job(smem, S, nt, u, u.n_upd + (b - nu), rhs);
 }
 
+// potrf of tile column k preceded by the few products of the previous level that finish its diagonal tile and right-hand-side
+// block (pre list, may be empty): wavefronts 0-3 form A_kk - sum L_kj L_kj^T on the matrix cores, wavefronts 4-7 z_k - sum L_kj z_j;
+// the results stay in LDS and the factorisation starts from there.  512 threads, smem = 2 T LDM + T doubles.
+__device__ __forceinline__ void potrf_column(double* smem, double* S, int nt, int k, int pb, int pe, const int32_t* __restrict__ pre_j, double* Linv_all, double* rhs, double* scal) {
+  if (pe == pb) { potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
+  double* A = smem;
+  double* Ct = smem + T * LDM;
+  double* zpre = smem + 2 * T * LDM;
+  const int tid = threadIdx.x;
+  f64x4 acc[4] = {};
+  double zs = 0.0;
+  for (int q = pb; q < pe; ++q) {
+    const int j = pre_j[q];
+    __syncthreads();
+    if (tid < kThreads) stage_tile(A, tile_ptr(S, nt, k, j));
+    __syncthreads();
+    if (tid < kThreads) tile_abt_mfma(A, A, acc);
+    else {
+      const int r = (tid - kThreads) >> 2, part = tid & 3;
+      const double* z = rhs + (int64_t)j * T + part * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) zs += A[r * LDM + part * 16 + c] * z[c];
+    }
+  }
+  if (tid < kThreads) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const double* C = tile_ptr(S, nt, k, k);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + (lane >> 4) + 4 * r, col = 16 * wv + (lane & 15);
+        Ct[row * LDM + col] = C[row * T + col] - acc[rt][r];
+      }
+  } else {
+    const int r = (tid - kThreads) >> 2, part = tid & 3;
+    zs += __shfl_xor(zs, 1, 64);
+    zs += __shfl_xor(zs, 2, 64);
+    if (part == 0) zpre[r] = rhs[(int64_t)k * T + r] - zs;
+  }
+  __syncthreads();
+  potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal, Ct, zpre);
+}
+// the potrf half of k_update_potrf as its own launch (OBVI_FUSED_POTRF=0: update jobs of a level, then this; no waiting inside a launch)
+__global__ void __launch_bounds__(512) k_potrf_pre(double* S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ pre_ptr, const int32_t* __restrict__ pre_j,
+                                                  double* Linv_all, double* rhs, double* scal) {
+  __shared__ double smem[2 * T * LDM + T];
+  potrf_column(smem, S, nt, klist[blockIdx.x], pre_ptr[blockIdx.x], pre_ptr[blockIdx.x + 1], pre_j, Linv_all, rhs, scal);
+}
+
 // One launch for the updates of level l and the potrf of level l+1.  Grid order: the update / right-hand-side jobs whose
 // target is the diagonal tile or right-hand-side block of a tile column of level l+1 ("critical": n_crit_upd + n_crit_rh,
 // first in their job lists), then the potrf workgroups of level l+1, then all other jobs of level l.  A critical job bumps
@@ -471,53 +522,15 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
         int spins = 0;
         while (__hip_atomic_load(done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
           __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1 << 22)) { unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0); break; }
+          // a lost or late signal (the jobs waited for have lower block indices, but HIP does not promise dispatch order) is not a
+          // numerical event: it is reported through its own scalar and obvi_ba_solve returns OBVI_ERR_HIP
+          if (++spins > (1 << 22)) { unsafeAtomicAdd(scal + SC_WAIT_TIMEOUT, 1.0); unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0); break; }
         }
       }
       __syncthreads();
       __threadfence();
     }
-    const int pb = pre_ptr[b - n_crit], pe = pre_ptr[b - n_crit + 1];
-    if (pe == pb) { potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
-    // the few products of the previous level that finish this column's diagonal tile and right-hand-side block are applied here
-    // (wavefronts 0-3: A_kk - sum L_kj L_kj^T on the matrix cores; wavefronts 4-7: z_k - sum L_kj z_j), results stay in LDS
-    double* A = smem;
-    double* Ct = smem + T * LDM;
-    double* zpre = smem + 2 * T * LDM;
-    const int tid = threadIdx.x;
-    f64x4 acc[4] = {};
-    double zs = 0.0;
-    for (int q = pb; q < pe; ++q) {
-      const int j = pre_j[q];
-      __syncthreads();
-      if (tid < kThreads) stage_tile(A, tile_ptr(S, nt, k, j));
-      __syncthreads();
-      if (tid < kThreads) tile_abt_mfma(A, A, acc);
-      else {
-        const int r = (tid - kThreads) >> 2, part = tid & 3;
-        const double* z = rhs + (int64_t)j * T + part * 16;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) zs += A[r * LDM + part * 16 + c] * z[c];
-      }
-    }
-    if (tid < kThreads) {
-      const int lane = tid & 63, wv = tid >> 6;
-      const double* C = tile_ptr(S, nt, k, k);
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * rt + (lane >> 4) + 4 * r, col = 16 * wv + (lane & 15);
-          Ct[row * LDM + col] = C[row * T + col] - acc[rt][r];
-        }
-    } else {
-      const int r = (tid - kThreads) >> 2, part = tid & 3;
-      zs += __shfl_xor(zs, 1, 64);
-      zs += __shfl_xor(zs, 2, 64);
-      if (part == 0) zpre[r] = rhs[(int64_t)k * T + r] - zs;
-    }
-    __syncthreads();
-    potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal, Ct, zpre);
+    potrf_column(smem, S, nt, k, pre_ptr[b - n_crit], pre_ptr[b - n_crit + 1], pre_j, Linv_all, rhs, scal);
     return;
   }
   if (threadIdx.x >= kThreads) return;
@@ -761,7 +774,12 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
     const int npk = l + 1 < l1 ? p.lvl_k_ptr[l + 2] - p.lvl_k_ptr[l + 1] : 0;
     UpdateJobs u{nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k, p.upd_flag + p.upd_ptr[l],
                  p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k};
-    if (npk > 0) {
+    static const bool fused = !std::getenv("OBVI_FUSED_POTRF") || std::atoi(std::getenv("OBVI_FUSED_POTRF")) != 0;   // 0: two launches per level, nothing waits inside a launch (CI parity run)
+    if (npk > 0 && !fused) {
+      if (nup + nrh > 0) { hipLaunchKernelGGL(k_update, dim3(sl * nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs, sl); tick(s, timers, CK_UPDATE); }
+      hipLaunchKernelGGL(k_potrf_pre, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l + 1], p.pre_ptr + p.lvl_k_ptr[l + 1], p.pre_j, Linv, rhs, scal);
+      tick(s, timers, CK_POTRF);
+    } else if (npk > 0) {
       hipLaunchKernelGGL(k_update_potrf, dim3(sl * nup + nrh + npk), dim3(512), 0, s, S, nt, u, nrh, p.crit_upd[l], p.crit_rh[l], npk, sl,
                          p.job_signal + p.upd_ptr[l] + p.rh_ptr[l], p.lvl_k + p.lvl_k_ptr[l + 1], p.k_need + p.lvl_k_ptr[l + 1], p.pre_ptr + p.lvl_k_ptr[l + 1], p.pre_j, p.diag_done, Linv, rhs, scal);
       tick(s, timers, CK_UPDATE);

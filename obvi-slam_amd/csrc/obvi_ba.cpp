@@ -15,10 +15,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -57,6 +60,13 @@ struct obvi_ba_handle {
   std::vector<uint32_t> h_bb_obj, h_bb_pose, h_sp_obj, h_lt_obj, h_rl_a, h_rl_b;
   std::vector<uint8_t> h_bb_active, h_sp_active, h_lt_active, h_rl_active;
   double bb_huber = 1.0, bb_invalid = 1e6, sp_huber = 1.0, lt_huber = 1.0, rl_huber = 1.0;
+  // largest block / camera index each factor family refers to (-1: none): re-checked against the current block counts before every
+  // evaluate / solve, because blocks and cameras may be re-uploaded (with other counts) after the factors
+  int64_t max_rp_pose = -1, max_rp_point = -1, max_rp_cam = -1, max_bb_obj = -1, max_bb_pose = -1, max_bb_cam = -1, max_sp_obj = -1, max_lt_obj = -1, max_rl_pose = -1;
+  // bounding boxes as uploaded (pixels, (cov^-1)^1/2): the rectified corners and sqrt_inf on the device depend on the cameras and
+  // are re-derived when the cameras change
+  std::vector<uint16_t> h_bb_cam;
+  std::vector<double> h_bb_corners, h_bb_m4;
 
   // ---- device: parameters ----
   DevBuf<DevCam> d_cams;
@@ -64,6 +74,7 @@ struct obvi_ba_handle {
   DevBuf<double> d_pose_c, d_point_c, d_obj_c;     // candidate
   DevBuf<double> d_pose_b, d_point_b, d_obj_b;     // best (minimum cost) iterate
   DevBuf<double> d_pose_s, d_point_s, d_obj_s;     // snapshot
+  DevBuf<double> d_pose_e, d_point_e, d_obj_e;     // state at solve entry (handed back after a FAILURE)
   bool have_snapshot = false;
   DevBuf<PoseCache> d_pc, d_pc_c;
   bool pc_valid = false;                 // d_pc belongs to the poses in d_pose (an accepted step hands the candidate's cache over)
@@ -166,7 +177,9 @@ int hip_fail(obvi_ba_handle* h, const HipError& e) {
 #define OBVI_API_END(h)                                           \
   }                                                               \
   catch (const HipError& e) { return hip_fail(h, e); }            \
-  catch (const std::bad_alloc&) { return fail(h, OBVI_ERR_HIP, "host allocation failed"); }
+  catch (const std::bad_alloc&) { return fail(h, OBVI_ERR_HIP, "host allocation failed"); } \
+  catch (const std::exception& e) { return fail(h, OBVI_ERR_HIP, std::string("host exception: ") + e.what()); } \
+  catch (...) { return fail(h, OBVI_ERR_HIP, "unknown host exception"); }
 
 void make_cam(const double* K4, const double* e, DevCam* c) {
   // inverse of the extrinsics T_robot<-camera: cam_to_robot_tf_inv_ (reprojection_cost_functor.cpp:10-13)
@@ -254,9 +267,59 @@ template <class F>
 void parallel_ranges(int64_t n, int parts, F&& fn) {
   parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n));
   if (parts == 1) { fn(0, (int64_t)0, n); return; }
+  // nothing may escape a worker (std::terminate across the C ABI): the first exception is kept and rethrown on the caller's thread
+  // after every worker has been joined; a range whose thread cannot be started runs on the caller's thread
   std::vector<std::thread> th;
-  for (int t = 0; t < parts; ++t) th.emplace_back([&, t]() { fn(t, n * t / parts, n * (t + 1) / parts); });
+  std::exception_ptr first_error;
+  std::mutex error_mutex;
+  auto guarded = [&](int t) {
+    try { fn(t, n * t / parts, n * (t + 1) / parts); }
+    catch (...) { std::lock_guard<std::mutex> lock(error_mutex); if (!first_error) first_error = std::current_exception(); }
+  };
+  th.reserve(parts);
+  for (int t = 0; t < parts; ++t) {
+    try { th.emplace_back(guarded, t); }
+    catch (const std::system_error&) { guarded(t); }
+  }
   for (auto& x : th) x.join();
+  if (first_error) std::rethrow_exception(first_error);
+}
+
+// Every index a factor family holds must refer to a block / camera of the CURRENT upload (set_poses / set_points / set_objects /
+// set_cameras may have been called again, with smaller counts, after the factors).  0, or OBVI_ERR_OUT_OF_RANGE with the message set.
+int validate_indices(obvi_ba_handle* h) {
+  const int64_t ncam = (int64_t)h->h_cams.size();
+  auto bad = [&](const char* what) { return fail(h, OBVI_ERR_OUT_OF_RANGE, std::string(what) + " refer to a block that is not in the current upload (blocks / cameras were re-uploaded after the factors)"); };
+  if (h->n_rp > 0 && (h->max_rp_pose >= h->P || h->max_rp_point >= h->L || h->max_rp_cam >= ncam)) return bad("reprojection factors");
+  if (h->n_rp > 0 && (int64_t)h->h_point_ptr.size() != h->L + 1) return bad("reprojection factors (point count changed)");
+  if (h->n_bb > 0 && (h->max_bb_obj >= h->O || h->max_bb_pose >= h->P || h->max_bb_cam >= ncam)) return bad("bounding-box factors");
+  if (h->n_sp > 0 && h->max_sp_obj >= h->O) return bad("shape priors");
+  if (h->n_lt > 0 && h->max_lt_obj >= h->O) return bad("long-term-map priors");
+  if (h->n_rl > 0 && h->max_rl_pose >= h->P) return bad("relative-pose factors");
+  if (!h->h_is_shared.empty() && (int64_t)h->h_is_shared.size() != h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_shared_objects: flags were given for another object count");
+  if ((int64_t)h->h_pose_const.size() != h->P || (int64_t)h->h_point_const.size() != h->L || (int64_t)h->h_object_const.size() != h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "constness flags do not match the block counts");
+  return OBVI_OK;
+}
+template <class T>
+int64_t max_index(const T* v, int64_t n) { int64_t m = -1; for (int64_t i = 0; i < n; ++i) m = std::max<int64_t>(m, (int64_t)v[i]); return m; }
+
+// rectified corners and sqrt_inf of the bounding-box factors from the caller's corners / (cov^-1)^1/2 and the CURRENT cameras
+// (bounding_box_factor.cpp:26-39: sqrt_inf = (cov^-1)^(1/2) diag(fx,fx,fy,fy); corners rectified)
+void bake_bbox(obvi_ba_handle* h) {
+  const int64_t n = h->n_bb;
+  if (n == 0 || h->max_bb_cam >= (int64_t)h->h_cams.size()) return;   // validate_indices reports the latter
+  std::vector<double> rect(4 * n), si(16 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    const DevCam& c = h->h_cams[h->h_bb_cam[i]];
+    const double sc[4] = {c.fx, c.fx, c.fy, c.fy};
+    const double* m4 = &h->h_bb_m4[16 * i];
+    const double* corners = &h->h_bb_corners[4 * i];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) si[16 * i + 4 * a + b] = m4[4 * a + b] * sc[b];
+    rect[4 * i] = (corners[0] - c.cx) / c.fx; rect[4 * i + 1] = (corners[1] - c.cx) / c.fx;
+    rect[4 * i + 2] = (corners[2] - c.cy) / c.fy; rect[4 * i + 3] = (corners[3] - c.cy) / c.fy;
+  }
+  h->d_bb_rect.upload(rect, h->stream); h->d_bb_sqrt_inf.upload(si, h->stream);
+  OBVI_HIP(hipStreamSynchronize(h->stream));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1030,6 +1093,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // (not when the caller goes on to use the factor that is in the tiles: covariance extraction)
   if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
   sync(h);
+  if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) throw HipError{hipErrorLaunchTimeOut, "tile Cholesky: a potrf workgroup timed out waiting for the previous level's update jobs (set OBVI_FUSED_POTRF=0 for the two-launch schedule)", __FILE__, __LINE__};
   for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
     if (h->phase_on_side[p]) { OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev_end[p])); }
@@ -1137,6 +1201,7 @@ int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const dou
   for (int i = 0; i < n; ++i) make_cam(K + 4 * i, ext + 7 * i, &h->h_cams[i]);
   h->d_cams.upload(h->h_cams, h->stream);
   sync(h);
+  bake_bbox(h);   // the bounding-box factors already uploaded follow the new intrinsics
   return OBVI_OK;
   OBVI_API_END(h)
 }
@@ -1161,11 +1226,13 @@ int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uin
 
 int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pc, const uint8_t* lc, const uint8_t* oc) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
   if (pc) h->h_pose_const.assign(pc, pc + h->P);
   if (lc) h->h_point_const.assign(lc, lc + h->L);
   if (oc) h->h_object_const.assign(oc, oc + h->O);
   h->dirty = true;
   return OBVI_OK;
+  OBVI_API_END(h)
 }
 
 int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz) {
@@ -1203,6 +1270,7 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
       if (!std::is_sorted(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before)) std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before);
   });
   h->n_rp = n; h->rp_huber = huber;
+  h->max_rp_pose = max_index(pose_idx, n); h->max_rp_point = max_index(point_idx, n); h->max_rp_cam = cam_idx ? max_index(cam_idx, n) : (n > 0 ? 0 : -1);
   h->h_rp_perm = perm; h->h_point_ptr = ptr;
   h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
   std::vector<uint16_t> cam(n);
@@ -1267,25 +1335,21 @@ int obvi_ba_set_bbox(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, cons
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   std::vector<uint16_t> cam(n);
-  std::vector<double> rect(4 * n), si(16 * n);
+  std::vector<double> m4all(16 * n);
   for (int64_t i = 0; i < n; ++i) {
     cam[i] = cam_idx ? cam_idx[i] : 0;
     if (obj_idx[i] >= h->O || pose_idx[i] >= h->P || cam[i] >= h->h_cams.size()) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_bbox: index out of range");
-    const DevCam& c = h->h_cams[cam[i]];
-    // bounding_box_factor.cpp:26-39: sqrt_inf = (cov^-1)^(1/2) diag(fx,fx,fy,fy); corners rectified
-    double m4[16];
-    if (!sym_inverse_sqrt(cov + 16 * i, 4, m4)) return fail(h, OBVI_ERR_NUMERICAL, "set_bbox: covariance not SPD");
-    const double sc[4] = {c.fx, c.fx, c.fy, c.fy};
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) si[16 * i + 4 * a + b] = m4[4 * a + b] * sc[b];
-    rect[4 * i] = (corners[4 * i] - c.cx) / c.fx; rect[4 * i + 1] = (corners[4 * i + 1] - c.cx) / c.fx;
-    rect[4 * i + 2] = (corners[4 * i + 2] - c.cy) / c.fy; rect[4 * i + 3] = (corners[4 * i + 3] - c.cy) / c.fy;
+    if (!sym_inverse_sqrt(cov + 16 * i, 4, &m4all[16 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_bbox: covariance not SPD");
   }
   h->n_bb = n; h->bb_huber = huber; h->bb_invalid = invalid_err;
   h->h_bb_obj.assign(obj_idx, obj_idx + n); h->h_bb_pose.assign(pose_idx, pose_idx + n); h->h_bb_active.assign(n, 1);
   hipStream_t s = h->stream;
+  h->max_bb_obj = max_index(obj_idx, n); h->max_bb_pose = max_index(pose_idx, n); h->max_bb_cam = max_index(cam.data(), n);
+  h->h_bb_cam = cam; h->h_bb_corners.assign(corners, corners + 4 * n); h->h_bb_m4.swap(m4all);
   h->d_bb_obj.upload(h->h_bb_obj, s); h->d_bb_pose.upload(h->h_bb_pose, s); h->d_bb_cam.upload(cam, s);
-  h->d_bb_rect.upload(rect, s); h->d_bb_sqrt_inf.upload(si, s); h->d_bb_active.upload(h->h_bb_active, s);
+  h->d_bb_active.upload(h->h_bb_active, s);
   sync(h);
+  bake_bbox(h);
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1300,7 +1364,7 @@ int obvi_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_i
     if (obj_idx[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_shape_priors: index out of range");
     if (!sym_inverse_sqrt(cov9 + 9 * i, 3, &si[9 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_shape_priors: covariance not SPD");
   }
-  h->n_sp = n; h->sp_huber = huber;
+  h->n_sp = n; h->sp_huber = huber; h->max_sp_obj = max_index(obj_idx, n);
   h->h_sp_obj.assign(obj_idx, obj_idx + n); h->h_sp_active.assign(n, 1);
   hipStream_t s = h->stream;
   h->d_sp_obj.upload(h->h_sp_obj, s); h->d_sp_mean.upload(mean3, 3 * n, s); h->d_sp_sqrt_inf.upload(si, s); h->d_sp_active.upload(h->h_sp_active, s);
@@ -1319,7 +1383,7 @@ int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx
     if (obj_idx[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_ltm_priors: index out of range");
     if (!sym_inverse_sqrt(cov49 + 49 * i, 7, &si[49 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_ltm_priors: covariance not SPD");
   }
-  h->n_lt = n; h->lt_huber = huber;
+  h->n_lt = n; h->lt_huber = huber; h->max_lt_obj = max_index(obj_idx, n);
   h->h_lt_obj.assign(obj_idx, obj_idx + n); h->h_lt_active.assign(n, 1);
   hipStream_t s = h->stream;
   h->d_lt_obj.upload(h->h_lt_obj, s); h->d_lt_mean.upload(mean7, 7 * n, s); h->d_lt_sqrt_inf.upload(si, s); h->d_lt_active.upload(h->h_lt_active, s);
@@ -1351,7 +1415,7 @@ int obvi_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* ia, const 
     }
     if (!sym_inverse_sqrt(cov36 + 36 * i, 6, &si[36 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_relpose: covariance not SPD");
   }
-  h->n_rl = n; h->rl_huber = huber;
+  h->n_rl = n; h->rl_huber = huber; h->max_rl_pose = std::max(max_index(ia, n), max_index(ib, n));
   h->h_rl_a.assign(ia, ia + n); h->h_rl_b.assign(ib, ib + n); h->h_rl_active.assign(n, 1);
   hipStream_t s = h->stream;
   h->d_rl_a.upload(h->h_rl_a, s); h->d_rl_b.upload(h->h_rl_b, s); h->d_rl_t.upload(t3, 3 * n, s); h->d_rl_R.upload(R, s);
@@ -1402,6 +1466,7 @@ int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double
   if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "evaluate: cameras not set");
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
   hipStream_t s = h->stream;
   const int64_t nres = obvi_ba_num_residuals(h), nfac = h->n_rp + h->n_bb + h->n_sp + h->n_lt + h->n_rl;
@@ -1424,6 +1489,7 @@ int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t type, double* r, double* 
   if (!h || !r || !J0) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
   hipStream_t s = h->stream;
   int m, d0, d1; int64_t n;
@@ -1454,6 +1520,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   if (!h || !lhs || !rhs) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
   if (m_out) *m_out = (int32_t)h->m_canon;
   if (h->m_canon > m_cap) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_reduced_system: buffer too small");
@@ -1498,6 +1565,7 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   for (int64_t i = 0; i < n_pairs; ++i) if ((int64_t)obj_a[i] >= h->O || (int64_t)obj_b[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "object_covariances: object index out of range");
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
   std::fill(cov49, cov49 + 49 * n_pairs, 0.0);
   if (n_pairs == 0 || h->nOv == 0 || h->m == 0) return OBVI_OK;
@@ -1549,12 +1617,16 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   const double t_start = wall_s();
   std::memset(sum, 0, sizeof(*sum));
   h->iterations.clear();
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
   h->pc_valid = false; h->tiles_cleared = false;
   const double ms0[3] = {h->phase_ms[PH_POINT_PASS] + h->phase_ms[PH_POSE_PASS] + h->phase_ms[PH_SMALL] + h->phase_ms[PH_DIAG] + h->phase_ms[PH_POSE_CACHE],
                          h->phase_ms[PH_SCHUR] + h->phase_ms[PH_SCHUR_BLOCKS] + h->phase_ms[PH_CHOL] + h->phase_ms[PH_BACKSUB] + h->phase_ms[PH_APPLY], h->phase_ms[PH_COST]};
   hipStream_t s = h->stream;
 
+  // the state at entry: what the caller gets back if the solve ends in FAILURE (Ceres leaves the user's parameter blocks alone
+  // when the solution is not usable [Ceres-doc solver.cc])
+  copy_current(h, h->d_pose_e, h->d_point_e, h->d_obj_e);
   // fixed cost: residual blocks with only constant parameter blocks
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
@@ -1615,7 +1687,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     rec.iteration_time_in_seconds = wall_s() - iter_t0;
     iter_t0 = wall_s();
     h->iterations.push_back(rec);
-    if (rec.iteration > 0) { if (rec.step_is_successful) sum->num_successful_steps++; else sum->num_unsuccessful_steps++; }
+    if (rec.step_is_successful) sum->num_successful_steps++; else sum->num_unsuccessful_steps++;   // iteration 0 counts as a successful step [Ceres-doc]
     if (rec.iteration >= prm->max_num_iterations) { finish(OBVI_NO_CONVERGENCE, "Maximum number of iterations reached."); return false; }
     if (rec.step_is_successful && rec.gradient_max_norm <= prm->gradient_tolerance) { finish(OBVI_CONVERGENCE, "Gradient tolerance reached."); return false; }
     if (radius < kMinRadius) { finish(OBVI_CONVERGENCE, "Minimum trust region radius reached."); return false; }
@@ -1696,14 +1768,16 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
       submit_step(h, radius, false, it.iteration < prm->max_num_iterations);
     } else {
       it.step_is_successful = 0;
-      it.cost = x_cost + fixed_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      it.cost = cand_cost + fixed_cost;   // HandleUnsuccessfulStep records the CANDIDATE's cost [Ceres-doc trust_region_minimizer.cc]
+      it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
       radius /= decrease_factor; decrease_factor *= 2.0;  // StepRejected
       if (!push_and_check(it)) break;
       submit_step(h, radius, false, true);
     }
   }
-  // hand back the minimum-cost iterate
-  if (have_best) restore_from(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
+  // hand back the minimum-cost iterate; after a FAILURE the state at entry
+  if (sum->termination_type == OBVI_FAILURE) restore_from(h, h->d_pose_e, h->d_point_e, h->d_obj_e);
+  else if (have_best) restore_from(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
   sync(h);
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1773,16 +1847,18 @@ static int get_blocks(obvi_ba_handle* h, const DevBuf<double>& d, int64_t n, int
   return OBVI_OK;
   OBVI_API_END(h)
 }
-int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_pose, h ? h->P : 0, 6, out); }
-int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_point, h ? h->L : 0, 3, out); }
-int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return get_blocks(h, h->d_obj, h ? h->O : 0, 7, out); }
+int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_pose, h->P, 6, out) : OBVI_ERR_INVALID_ARGUMENT; }
+int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_point, h->L, 3, out) : OBVI_ERR_INVALID_ARGUMENT; }
+int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_obj, h->O, 7, out) : OBVI_ERR_INVALID_ARGUMENT; }
 
 int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared, int32_t rank, int32_t world) {
   if (!h || world < 1 || rank < 0 || rank >= world) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
   if (is_shared) h->h_is_shared.assign(is_shared, is_shared + h->O); else h->h_is_shared.clear();
   h->rank = rank; h->world = world;
   h->dirty = true;
   return OBVI_OK;
+  OBVI_API_END(h)
 }
 
 int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user) {

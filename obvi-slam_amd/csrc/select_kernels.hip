@@ -58,8 +58,12 @@ hipError_t select_outliers_device(hipStream_t s, int64_t n, const double* sq, co
   auto grow = [&](void** p, size_t* cap, size_t bytes) -> hipError_t {
     if (bytes <= *cap) return hipSuccess;
     if (*p) (void)hipFree(*p);
-    *cap = bytes + bytes / 4 + 256;
-    return hipMalloc(p, *cap);
+    *p = nullptr; *cap = 0;                       // a failed allocation must not leave a dangling pointer / stale capacity behind
+    const size_t want = bytes + bytes / 4 + 256;
+    const hipError_t rc = hipMalloc(p, want);
+    if (rc != hipSuccess) { *p = nullptr; return rc; }
+    *cap = want;
+    return hipSuccess;
   };
   if ((e = grow(&scratch->keys_in, &scratch->cap_keys_in, n * 8)) != hipSuccess) return e;
   if ((e = grow(&scratch->keys_out, &scratch->cap_keys_out, n * 8)) != hipSuccess) return e;

@@ -453,11 +453,14 @@ class ObjectPoseGraphOptimizer {
     if (solver_summary != nullptr) *solver_summary = summary;
     if (summary.termination_type == OBVI_FAILURE) std::cerr << "obvi_ba optimization failed: " << summary.message << std::endl;
     if (opt_logger.has_value()) opt_logger->extractOptimizationTimingResults(summary);
-    // Ceres mutates the parameter blocks in place; copy the device state back into the pose graph's blocks
-    if (obvi_ba_get_poses(h, poses.data()) || obvi_ba_get_points(h, points.data()) || obvi_ba_get_objects(h, objects.data())) return false;
-    for (size_t i = 0; i < fp.pose_ptrs.size(); ++i) std::copy_n(&poses[6 * i], 6, fp.pose_ptrs[i]);
-    for (size_t i = 0; i < fp.point_ptrs.size(); ++i) std::copy_n(&points[3 * i], 3, fp.point_ptrs[i]);
-    for (size_t i = 0; i < fp.object_ptrs.size(); ++i) std::copy_n(&objects[7 * i], 7, fp.object_ptrs[i]);
+    // Ceres mutates the parameter blocks in place; copy the device state back into the pose graph's blocks -- unless the solve
+    // failed: Ceres leaves the user's blocks as they were when the solution is not usable (the library hands the entry state back)
+    if (summary.IsSolutionUsable()) {
+      if (obvi_ba_get_poses(h, poses.data()) || obvi_ba_get_points(h, points.data()) || obvi_ba_get_objects(h, objects.data())) return false;
+      for (size_t i = 0; i < fp.pose_ptrs.size(); ++i) std::copy_n(&poses[6 * i], 6, fp.pose_ptrs[i]);
+      for (size_t i = 0; i < fp.point_ptrs.size(); ++i) std::copy_n(&points[3 * i], 3, fp.point_ptrs[i]);
+      for (size_t i = 0; i < fp.object_ptrs.size(); ++i) std::copy_n(&objects[7 * i], 7, fp.object_ptrs[i]);
+    }
     last_summary_ = summary;
     const auto t_end = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -848,6 +848,8 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   std::vector<double> best_poses, best_points, best_objects;
   copy_params(pb, &best_poses, &best_points, &best_objects);
   double best_cost = x_cost;
+  bool failed = false;   // FAILURE: the solution is not usable and Ceres leaves the user's parameter blocks as they were at entry [Ceres-doc solver.cc]
+  const std::vector<double> entry_poses = best_poses, entry_points = best_points, entry_objects = best_objects;
 
   sum->initial_cost = x_cost + rd.fixed_cost;
   obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
@@ -864,7 +866,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     it.trust_region_radius = radius;
     it.iteration_time_in_seconds = now_s() - iter_t0;
     pb.iterations.push_back(it);
-    if (it.step_is_successful) sum->num_successful_steps += (it.iteration > 0); else sum->num_unsuccessful_steps++;
+    if (it.step_is_successful) sum->num_successful_steps++; else sum->num_unsuccessful_steps++;   // iteration 0 counts as a successful step [Ceres-doc]
     if (it.iteration >= prm->max_num_iterations) { finish(OBVI_NO_CONVERGENCE, "Maximum number of iterations reached."); break; }
     if (it.step_is_successful && it.gradient_max_norm <= prm->gradient_tolerance) { finish(OBVI_CONVERGENCE, "Gradient tolerance reached."); break; }
     if (radius < kMinRadius) { finish(OBVI_CONVERGENCE, "Minimum trust region radius reached."); break; }
@@ -938,6 +940,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
       if (++num_invalid >= kMaxInvalid) {
         pb.iterations.push_back(it);
         finish(OBVI_FAILURE, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps");
+        failed = true;
         break;
       }
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;  // StepIsInvalid
@@ -1001,13 +1004,14 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     } else {
       revert();
       it.step_is_successful = 0;
-      it.cost = x_cost + rd.fixed_cost;
+      it.cost = cand_cost + rd.fixed_cost;   // HandleUnsuccessfulStep records the CANDIDATE's cost [Ceres-doc trust_region_minimizer.cc]
       it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;  // StepRejected
     }
   }
-  // write back the minimum-cost iterate
-  pb.poses = best_poses; pb.points = best_points; pb.objects = best_objects;
+  // write back the minimum-cost iterate (the entry state after a FAILURE)
+  if (failed) { pb.poses = entry_poses; pb.points = entry_points; pb.objects = entry_objects; }
+  else { pb.poses = best_poses; pb.points = best_points; pb.objects = best_objects; }
   return OBVI_OK;
 }
 

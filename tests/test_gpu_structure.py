@@ -1,10 +1,13 @@
 """Ragged observation structures through the HIP path, checked against the oracle (reduced system + one LM step):
 tracks longer than a wavefront, tracks with gaps, loop closures (pairs far outside the Schur strip), three observations of a
 point from one pose, points and poses without observations."""
+import os
+
 import numpy as np
 import pytest
 
 import helpers
+import obvi_ba
 import synth
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +117,62 @@ def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
 
 
+def test_blocks_or_cameras_re_uploaded_after_the_factors():
+    """The ABI states no call order, so the library must cope with one: a later set_poses / set_points / set_objects with FEWER
+    blocks than the factors refer to is an error at the next evaluate / solve (OBVI_ERR_OUT_OF_RANGE = -4, nothing read out of
+    bounds), and a later set_cameras re-derives what the bounding-box factors baked from the intrinsics."""
+    prob = synth.make_problem(P=30, L=200, O=2, seed=5, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=5)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    c0 = g.evaluate(True, False)[0]
+    for setter, arr, flags in ((g.set_poses, prob["poses"][:10], prob["pose_const"][:10]), (g.set_points, prob["points"][:50], prob["point_const"][:50]),
+                               (g.set_objects, prob["objects"][:1], prob["object_const"][:1])):
+        setter(np.ascontiguousarray(arr), flags)
+        with pytest.raises(obvi_ba.ObviError, match="status -4"):
+            g.evaluate(True, False)
+        with pytest.raises(obvi_ba.ObviError, match="status -4"):
+            g.solve(helpers.ba_params(max_it=2))
+        g.set_poses(prob["poses"], prob["pose_const"]); g.set_points(prob["points"], prob["point_const"]); g.set_objects(prob["objects"], prob["object_const"])
+        assert abs(g.evaluate(True, False)[0] - c0) <= 1e-13 * c0     # the handle is intact once the blocks are back (sums are atomic: order-dependent round-off)
+    # shared-object flags given for another object count
+    g.set_shared_objects(np.ones(2, np.uint8), 0, 1)
+    g.set_objects(np.concatenate([prob["objects"], prob["objects"][:1]]), np.zeros(3, np.uint8))
+    with pytest.raises(obvi_ba.ObviError, match="status -4"):
+        g.evaluate(True, False)
+    g.set_objects(prob["objects"], prob["object_const"]); g.set_shared_objects(None, 0, 1)
+    # cameras after the bounding boxes: same as a fresh upload with those cameras
+    K2 = prob["K"].copy(); K2[:, 0] *= 1.1; K2[:, 1] *= 0.9; K2[:, 2] += 7.0
+    g.set_cameras(K2, prob["ext"])
+    fresh = helpers.product_ba(); p2 = dict(prob); p2["K"] = K2; synth.upload(fresh, p2)
+    cg, rg, _ = g.evaluate(True); cf, rf, _ = fresh.evaluate(True)
+    assert abs(cg - cf) <= 1e-13 * cf and np.array_equal(rg, rf) and abs(cg - c0) > 1e-3 * c0
+    o = helpers.oracle_ba(); synth.upload(o, p2)
+    assert abs(o.evaluate(True, False)[0] - cg) <= 1e-12 * cg
+
+
+def test_two_launch_schedule_of_the_tile_cholesky(monkeypatch):
+    """OBVI_FUSED_POTRF=0: update jobs of a level and the potrf of the next level as two launches (nothing waits inside a launch);
+    same steps as the fused schedule and as the oracle.  The knob is read once per process, so this runs in a child process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path[:0] = [%r, %r]
+        import helpers, synth
+        prob = synth.make_problem(P=260, L=4000, O=8, seed=11, bbox_noise=5.0, object_classes=("bench",))
+        o, g = helpers.oracle_ba(), helpers.product_ba()
+        for ba in (o, g):
+            synth.upload(ba, prob)
+        prm = helpers.ba_params(max_it=3, ftol=0, ptol=0, gtol=0)
+        so, sg = o.solve(prm), g.solve(prm)
+        assert sg.num_iterations == so.num_iterations and abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost, (sg.final_cost, so.final_cost)
+        assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
+        assert g.problem_stats()["chol_levels"] > 3
+        print("two-launch ok")
+    """) % (os.path.join(helpers.ROOT, "obvi-slam_amd", "python"), os.path.join(helpers.ROOT, "tests"))
+    env = dict(os.environ, OBVI_FUSED_POTRF="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "two-launch ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_non_finite_input_is_a_failed_solve_and_the_handle_survives():
     """A NaN observation poisons cost, gradient and the reduced system: every step is invalid (non-finite step / failed factorisation),
     the solve stops after max_num_consecutive_invalid_steps like the oracle's, the parameters are left untouched, and the same
@@ -129,6 +188,7 @@ def test_non_finite_input_is_a_failed_solve_and_the_handle_survives():
     assert b"invalid steps" in sg.message
     assert [it.step_is_valid for it in g.iterations()] == [it.step_is_valid for it in o.iterations()]
     assert np.array_equal(g.get_poses(), prob["poses"]) and np.array_equal(g.get_points(), prob["points"])
+    assert sg.is_solution_usable == 0 and sg.num_successful_steps == so.num_successful_steps == 1 and sg.num_unsuccessful_steps == so.num_unsuccessful_steps
     for ba in (o, g):
         synth.upload(ba, prob)
     so, sg = o.solve(prm), g.solve(prm)

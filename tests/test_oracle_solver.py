@@ -159,6 +159,25 @@ def test_nonmonotonic_returns_minimum_cost_iterate():
     assert abs(ba.evaluate(True, False)[0] - s.final_cost) < 1e-9 * s.final_cost
 
 
+def test_iteration_log_bookkeeping():
+    """[Ceres-doc trust_region_minimizer.cc] iteration 0 counts as a successful step (successful + unsuccessful == iterations.size());
+    a rejected step records the CANDIDATE's cost (which is why it was rejected: it is above the current one, or barely below it);
+    final_cost is the minimum over the log."""
+    prob = synth.make_problem(P=20, L=150, O=2, seed=2, min_obj_obs=4)
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    s = ba.solve(helpers.ba_params(max_it=40, nonmono=False, radius=1e6, max_radius=1e12, ftol=1e-12))
+    its = ba.iterations()
+    assert s.num_successful_steps + s.num_unsuccessful_steps == s.num_iterations == len(its)
+    assert its[0].step_is_successful and s.num_successful_steps == sum(i.step_is_successful for i in its)
+    rejected = [k for k, i in enumerate(its) if i.step_is_valid and not i.step_is_successful]
+    assert rejected, "the wide initial radius must produce at least one rejected step"
+    for k in rejected:
+        cur = [i.cost for i in its[:k] if i.step_is_successful][-1]
+        assert abs(its[k].cost - (cur - its[k].cost_change)) <= 1e-12 * abs(cur)      # cost = candidate cost = x_cost - cost_change
+        assert its[k].cost != cur
+    assert abs(s.final_cost - min(i.cost for i in its)) <= 1e-15 * s.final_cost
+
+
 def test_converged_minimum_matches_scipy_on_the_numpy_restatement():
     """Solver-level pin that does not involve the oracle's own arithmetic: the minimiser of 1/2 sum rho(|r_b|^2) the oracle's LM loop
     converges to must be the one scipy.optimize.least_squares finds for residuals computed by the independent numpy restatement
