@@ -81,21 +81,58 @@ def rocprof_avg_us(kernel):
     return None
 
 
-def cpu_baseline(prob, budget_iters=2):
-    """Oracle (scalar fp64 CPU restatement, 1 thread) on the same problem, bounded to a few LM iterations."""
+def cpu_baseline(prob, budget_iters=3):
+    """The CPU oracle on the same problem, on the host cores of this box: min(20, hardware threads) threads -- 20 is the reference's
+    own Solver::Options::num_threads (object_pose_graph_optimizer.h:662) -- bounded to a few LM iterations.  The rate is taken
+    from the per-iteration records of iterations 1..K (the initial evaluation, which also first-touches the oracle's
+    linearisation records, is iteration 0 and is reported separately)."""
+    import ctypes
     import obvi_ba
     import synth
     lib = os.path.join(ROOT, "oracle", "libobvi_oracle.so")
     if not os.path.exists(lib):
         return None
+    threads = max(1, min(20, os.cpu_count() or 1))
+    ctypes.CDLL(lib).oracle_set_threads(ctypes.c_int32(threads))
     o = obvi_ba.BundleAdjuster(library=lib, prefix="oracle_")
     synth.upload(o, prob)
     t0 = time.time()
     s = o.solve(solver_params(obvi_ba, budget_iters))
     dt = time.time() - t0
-    its = max(1, s.num_iterations - 1)
-    return {"value": its / dt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d LM iterations of the same problem (oracle/libobvi_oracle.so, scalar fp64, %.1f s)" % (its, dt)}
+    its = o.iterations()
+    steady = sum(i.iteration_time_in_seconds for i in its[1:])
+    n = max(1, len(its) - 1)
+    ceres = ceres_harness(prob, budget_iters, threads)
+    return {"value": n / steady, "unit": "LM iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d LM iterations of the same problem (oracle/libobvi_oracle.so, fp64, %d host threads of %d; %.1f s wall incl. %.1f s "
+                      "initial evaluation)" % (n, threads, os.cpu_count() or 1, dt, dt - steady),
+            "ms_per_step": 1e3 * steady / n, "reference_ceres": ceres}
+
+
+def ceres_harness(prob=None, budget_iters=3, threads=20):
+    """if Ceres is discoverable on this box, __graft_entry__.build() has built oracle/_ref/ceres_harness
+    (oracle/ceres_harness: find_package(Ceres QUIET)); it times ceres::Solve with the reference's option block on the same problem.
+    Otherwise say so."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ceres_harness")
+    if not os.path.exists(exe):
+        return "Ceres unavailable on this box (oracle/ceres_harness: find_package(Ceres QUIET) found nothing) -- CPU oracle used as baseline"
+    if prob is None:
+        return "oracle/_ref/ceres_harness present"
+    import subprocess
+    import tempfile
+    import synth
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "problem.flat")
+            synth.dump_flat(prob, path, max_it=budget_iters)
+            out = subprocess.run([exe, path, str(threads)], capture_output=True, text=True, timeout=900)
+        rep = json.loads(out.stdout)
+        n = max(1, rep["num_iterations"] - 1)
+        steady = sum(i["iteration_time_in_seconds"] for i in rep["iterations"][1:])
+        return {"kind": "reference", "ceres_version": rep["ceres_version"], "threads": threads, "value": n / steady, "unit": "LM iterations/s",
+                "ms_per_step": 1e3 * steady / n, "final_cost": rep["final_cost"]}
+    except Exception as exc:   # the harness is optional: report, never fail the bench
+        return "oracle/_ref/ceres_harness failed: %r" % (exc,)
 
 
 def main():

@@ -318,3 +318,32 @@ def upload(ba, prob, relpose=True, objects=True, reproj=True):
 def problem_stats(prob):
     return dict(P=len(prob["poses"]), L=len(prob["points"]), O=len(prob["objects"]), N_r=len(prob["rp_pose"]),
                 N_b=len(prob["bb_obj"]), N_rel=len(prob.get("rl_a", [])))
+
+
+def dump_flat(prob, path, max_it=3, nonmono=True, ftol=0.0, gtol=0.0, ptol=0.0, radius=100.0, max_radius=1e4):
+    """The flat problem + solver parameters as one little-endian file for the optional Ceres harness
+    (oracle/ceres_harness/ceres_harness.cpp): magic, then arrays as (u64 count, payload) and scalars as f64, in upload() order."""
+    import struct
+
+    def arr(f, a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype).ravel()
+        f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
+
+    def scal(f, v):
+        f.write(struct.pack("<d", float(v)))
+    e = lambda k, shape: prob[k] if k in prob else np.zeros(shape)   # noqa: E731
+    with open(path, "wb") as f:
+        f.write(b"OBVIFLT1")
+        arr(f, prob["K"], "<f8"); arr(f, prob["ext"], "<f8")
+        arr(f, prob["poses"], "<f8"); arr(f, prob["pose_const"], "u1"); arr(f, prob["points"], "<f8"); arr(f, prob["point_const"], "u1")
+        arr(f, prob["objects"], "<f8"); arr(f, prob["object_const"], "u1")
+        arr(f, prob["rp_pose"], "<u4"); arr(f, prob["rp_point"], "<u4"); arr(f, prob["rp_cam"], "<u4"); arr(f, prob["rp_pixel"], "<f8")
+        scal(f, prob["rp_sigma"]); scal(f, prob["rp_huber"])
+        arr(f, prob["bb_obj"], "<u4"); arr(f, prob["bb_pose"], "<u4"); arr(f, prob["bb_cam"], "<u4"); arr(f, prob["bb_corners"], "<f8"); arr(f, prob["bb_cov"], "<f8")
+        scal(f, prob["bb_huber"]); scal(f, prob["bb_invalid"])
+        arr(f, prob["sp_obj"], "<u4"); arr(f, prob["sp_mean"], "<f8"); arr(f, prob["sp_cov"], "<f8"); scal(f, prob["sp_huber"])
+        arr(f, e("lt_obj", 0), "<u4"); arr(f, e("lt_mean", (0, 7)), "<f8"); arr(f, e("lt_cov", (0, 49)), "<f8"); scal(f, prob.get("lt_huber", 1.0))
+        arr(f, e("rl_a", 0), "<u4"); arr(f, e("rl_b", 0), "<u4"); arr(f, e("rl_t", (0, 3)), "<f8"); arr(f, e("rl_aa", (0, 3)), "<f8"); arr(f, e("rl_cov", (0, 36)), "<f8")
+        scal(f, prob.get("rl_huber", 1.0))
+        for v in (max_it, int(nonmono), ftol, gtol, ptol, radius, max_radius):
+            scal(f, v)

@@ -31,10 +31,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "oracle_factors.h"
@@ -44,6 +48,21 @@ using namespace oracle;  // NOLINT
 
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Host threads for the embarrassingly parallel parts (linearisation of the factors, trial-point cost, elimination of the points):
+// bench.py's cpu_baseline leg sets min(20, hardware threads) -- 20 is the reference's own num_threads
+// (object_pose_graph_optimizer.h:662) -- through oracle_set_threads().  The default, and what every parity test runs, is 1: the
+// sequential code below, whose summation order is fixed.  With more threads the factor records are the same and in the same
+// order; only the order in which the points' Schur contributions are added changes (round-off).
+int g_threads = 1;
+template <class F>
+void parallel_ranges(int64_t n, F&& fn) {   // fn(thread, begin, end), contiguous ranges in order
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(g_threads, n));
+  if (parts == 1) { fn(0, (int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < parts; ++t) th.emplace_back([&fn, n, parts, t]() { fn(t, n * t / parts, n * (t + 1) / parts); });
+  for (auto& x : th) x.join();
 }
 
 struct OracleProblem {
@@ -232,6 +251,7 @@ struct Workspace {
   std::vector<double> colsq_c, colsq_l;   // squared column norms: reduced rows / points (3 per point)
   std::vector<double> g_c;                // gradient, reduced rows
   std::vector<std::vector<int64_t>> point_obs;  // per point: indices into lin of its reprojection records
+  int64_t object_row0 = 0;                // first object row of the reduced system (= 6 nPv): rows from here on form the arrow's border
 };
 
 inline int64_t pose_row(const Reduced& rd, int64_t p) { return 6 * (int64_t)rd.pose_vid[p]; }
@@ -284,13 +304,19 @@ int64_t reduced_row(const Reduced& rd, BlockKind k, int64_t i) {
 double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
   double cost = 0.0;
   for (const Family& fam : families(pb)) {
-    for (int64_t i = 0; i < fam.n; ++i) {
-      if (!(*fam.active)[i]) continue;
-      FactorLin f; fam.lin(pb, i, false, &f);
-      if (!is_var(pb, rd, f.k0, f.i0) && !is_var(pb, rd, f.k1, f.i1)) continue;
-      robustify(&f, fam.huber, true);
-      cost += f.cost;
-    }
+    std::vector<double> part((size_t)std::max(1, g_threads), 0.0);
+    parallel_ranges(fam.n, [&](int t, int64_t i0, int64_t i1) {
+      double c = 0.0;
+      for (int64_t i = i0; i < i1; ++i) {
+        if (!(*fam.active)[i]) continue;
+        FactorLin f; fam.lin(pb, i, false, &f);
+        if (!is_var(pb, rd, f.k0, f.i0) && !is_var(pb, rd, f.k1, f.i1)) continue;
+        robustify(&f, fam.huber, true);
+        c += f.cost;
+      }
+      part[t] = c;
+    });
+    for (double c : part) cost += c;   // one thread: the plain running sum
   }
   return cost;
 }
@@ -298,10 +324,45 @@ double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
 // Full linearisation at the current estimate: robustified r, J per residual block;
 // squared column norms, gradient, point blocks; skyline envelope of the reduced system.
 double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
+  const bool timing = std::getenv("OBVI_ORACLE_TIMING") != nullptr;
+  const double t_begin = now_s();
   ws->lin.clear();
   ws->point_obs.assign(pb.L, {});
   double cost = 0.0;
   for (const Family& fam : families(pb)) {
+    if (g_threads > 1 && fam.n >= 1024) {
+      // same records in the same order as the loop below: which factors stay is decided first (values only, cheap), then the
+      // records are filled at their final positions by ranges of factors on host threads
+      std::vector<int64_t> slot((size_t)fam.n, -1);
+      std::vector<uint8_t> keep((size_t)fam.n, 0);
+      parallel_ranges(fam.n, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+          if (!(*fam.active)[i]) continue;
+          FactorLin f; fam.lin(pb, i, false, &f);   // block kinds / indices (and a value that is not used)
+          keep[i] = is_var(pb, rd, f.k0, f.i0) || is_var(pb, rd, f.k1, f.i1);
+        }
+      });
+      int64_t next = (int64_t)ws->lin.size();
+      for (int64_t i = 0; i < fam.n; ++i) if (keep[i]) slot[i] = next++;
+      ws->lin.resize((size_t)next);
+      parallel_ranges(fam.n, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+          if (slot[i] < 0) continue;
+          FactorLin& f = ws->lin[slot[i]];
+          fam.lin(pb, i, true, &f);
+          robustify(&f, fam.huber, true);
+          if (!is_var(pb, rd, f.k0, f.i0)) std::memset(f.J0, 0, sizeof(f.J0));
+          if (!is_var(pb, rd, f.k1, f.i1)) std::memset(f.J1, 0, sizeof(f.J1));
+        }
+      });
+      for (int64_t i = 0; i < fam.n; ++i) {
+        if (slot[i] < 0) continue;
+        const FactorLin& f = ws->lin[slot[i]];
+        cost += f.cost;
+        if (fam.type == OBVI_FACTOR_REPROJECTION && is_var(pb, rd, f.k1, f.i1)) ws->point_obs[f.i1].push_back(slot[i]);
+      }
+      continue;
+    }
     for (int64_t i = 0; i < fam.n; ++i) {
       if (!(*fam.active)[i]) continue;
       FactorLin f; fam.lin(pb, i, true, &f);
@@ -315,6 +376,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
       ws->lin.push_back(f);
     }
   }
+  if (timing) std::fprintf(stderr, "oracle linearize: factor records %.3f s\n", now_s() - t_begin);
   // squared column norms and gradient
   ws->colsq_c.assign(rd.m, 0.0); ws->g_c.assign(rd.m, 0.0);
   ws->colsq_l.assign(3 * pb.L, 0.0); ws->gl.assign(3 * pb.L, 0.0); ws->Hll.assign(9 * pb.L, 0.0);
@@ -339,6 +401,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
       }
     }
   }
+  if (timing) std::fprintf(stderr, "oracle linearize: total %.3f s\n", now_s() - t_begin);
   return cost;
 }
 
@@ -346,6 +409,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
 // residual block (relpose, bbox) or an eliminated point with.
 void build_envelope(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   ws->first.resize(rd.m);
+  ws->object_row0 = 6 * rd.nPv;
   // every row of a diagonal block reaches back to the block's first row
   for (int64_t v = 0; v < rd.nPv; ++v) for (int k = 0; k < 6; ++k) ws->first[6 * v + k] = 6 * v;
   for (int64_t w = 0; w < rd.nOv; ++w) for (int k = 0; k < 7; ++k) ws->first[6 * rd.nPv + 7 * w + k] = 6 * rd.nPv + 7 * w;
@@ -408,7 +472,12 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
   }
   // eliminate points
   Hll_inv->assign(9 * pb.L, 0.0);
-  for (int64_t l = 0; l < pb.L; ++l) {
+  // host threads (g_threads > 1): ranges of points; a point's contributions to a pose's rows (right-hand side and the blocks of
+  // that block row) are added under that pose's lock, so the sums are complete but their order depends on the schedule
+  std::unique_ptr<std::mutex[]> row_lock(g_threads > 1 ? new std::mutex[(size_t)rd.nPv + 1] : nullptr);
+  std::vector<uint8_t> bad_part((size_t)std::max(1, g_threads), 0);
+  parallel_ranges(pb.L, [&](int tid, int64_t l_begin, int64_t l_end) {
+  for (int64_t l = l_begin; l < l_end; ++l) {
     if (!rd.point_var[l]) continue;
     double H[9];
     for (int k = 0; k < 9; ++k) H[k] = ws->Hll[9 * l + k];
@@ -416,7 +485,7 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
     // 3x3 symmetric inverse via cofactors
     const double c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
     const double det = H[0] * c00 + H[1] * c01 + H[2] * c02;
-    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) { bad_part[tid] = 1; return; }
     double* Hi = &(*Hll_inv)[9 * l];
     Hi[0] = c00 / det; Hi[1] = (H[2] * H[7] - H[1] * H[8]) / det; Hi[2] = (H[1] * H[5] - H[2] * H[4]) / det;
     Hi[3] = Hi[1];     Hi[4] = (H[0] * H[8] - H[2] * H[6]) / det; Hi[5] = (H[2] * H[3] - H[0] * H[5]) / det;
@@ -433,6 +502,8 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
       for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
         Ya[3 * x + k] = Wa[3 * x] * Hi[k] + Wa[3 * x + 1] * Hi[3 + k] + Wa[3 * x + 2] * Hi[6 + k];
       const int64_t ra = pose_row(rd, f.i0);
+      std::unique_lock<std::mutex> lock;
+      if (row_lock) lock = std::unique_lock<std::mutex>(row_lock[rd.pose_vid[f.i0]]);
       for (int x = 0; x < 6; ++x)
         ws->rhs[ra + x] -= Ya[3 * x] * ws->gl[3 * l] + Ya[3 * x + 1] * ws->gl[3 * l + 1] + Ya[3 * x + 2] * ws->gl[3 * l + 2];
     }
@@ -440,6 +511,8 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
       const FactorLin& fa = ws->lin[obs[a]];
       if (rd.pose_vid[fa.i0] < 0) continue;
       const int64_t ra = pose_row(rd, fa.i0);
+      std::unique_lock<std::mutex> lock;
+      if (row_lock) lock = std::unique_lock<std::mutex>(row_lock[rd.pose_vid[fa.i0]]);
       for (size_t b = 0; b < obs.size(); ++b) {
         const FactorLin& fb = ws->lin[obs[b]];
         if (rd.pose_vid[fb.i0] < 0) continue;
@@ -453,12 +526,88 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
       }
     }
   }
+  });
+  for (uint8_t b : bad_part) if (b) return false;
   return true;
 }
 
 // In-place envelope (skyline) Cholesky S = L L^T and solve.  [Ceres-doc: the reduced system
 // is factorised exactly by a sparse Cholesky; the elimination order does not change the result.]
+// Host threads (g_threads > 1): the same factorisation with the object rows (the border of the arrow: rows >= object_row0, whose
+// envelopes reach far back into the pose band) split so that their long dot products run in parallel.  Every entry subtracts the
+// same products in the same order as the sequential loop, so the factor is bit-identical:
+//   band   rows < r0, sequential (narrow envelopes: a fraction of a percent of the flops)
+//   (1)    entries (i, j < r0) of the border rows: need band rows only -> parallel over border rows
+//   (2a)   entries (i, j >= r0): the part of the dot product over k < r0 -> parallel over border rows (reads (1) only)
+//   (2b)   the remaining part over k >= r0 and the division: the dense Cholesky of the border block, sequential
+bool skyline_factor_arrow(Workspace* ws, int64_t m) {
+  const int64_t r0 = std::min(ws->object_row0, m);
+  auto row = [&](int64_t i) { return &ws->S[ws->rowptr[i]] - ws->first[i]; };
+  bool ok = true;
+  for (int64_t i = 0; i < r0 && ok; ++i) {
+    const int64_t fi = ws->first[i];
+    double* Li = row(i);
+    for (int64_t j = fi; j < i; ++j) {
+      const int64_t fj = ws->first[j];
+      const double* Lj = row(j);
+      double s = Li[j];
+      for (int64_t k = std::max(fi, fj); k < j; ++k) s -= Li[k] * Lj[k];
+      Li[j] = s / Lj[j];
+    }
+    double s = Li[i];
+    for (int64_t k = fi; k < i; ++k) s -= Li[k] * Li[k];
+    if (!(s > 0.0) || !std::isfinite(s)) ok = false;
+    Li[i] = std::sqrt(s);
+  }
+  if (!ok) return false;
+  const int64_t nb = m - r0;
+  // interleaved assignment of border rows to threads (their costs grow with the row index)
+  auto border_rows = [&](auto&& body) {
+    parallel_ranges(std::min<int64_t>(g_threads, std::max<int64_t>(nb, 1)), [&](int, int64_t t0, int64_t t1) {
+      for (int64_t t = t0; t < t1; ++t) for (int64_t i = r0 + t; i < m; i += std::min<int64_t>(g_threads, std::max<int64_t>(nb, 1))) body(i);
+    });
+  };
+  border_rows([&](int64_t i) {   // (1)
+    const int64_t fi = ws->first[i];
+    double* Li = row(i);
+    for (int64_t j = fi; j < std::min(i, r0); ++j) {
+      const int64_t fj = ws->first[j];
+      const double* Lj = row(j);
+      double s = Li[j];
+      for (int64_t k = std::max(fi, fj); k < j; ++k) s -= Li[k] * Lj[k];
+      Li[j] = s / Lj[j];
+    }
+  });
+  border_rows([&](int64_t i) {   // (2a)
+    const int64_t fi = ws->first[i];
+    double* Li = row(i);
+    for (int64_t j = std::max(fi, r0); j <= i; ++j) {
+      const int64_t fj = ws->first[j];
+      const double* Lj = row(j);
+      double s = Li[j];
+      for (int64_t k = std::max(fi, fj); k < std::min(j, r0); ++k) s -= Li[k] * Lj[k];
+      Li[j] = s;
+    }
+  });
+  for (int64_t i = r0; i < m; ++i) {   // (2b)
+    const int64_t fi = ws->first[i];
+    double* Li = row(i);
+    for (int64_t j = std::max(fi, r0); j < i; ++j) {
+      const int64_t fj = ws->first[j];
+      const double* Lj = row(j);
+      double s = Li[j];
+      for (int64_t k = std::max({fi, fj, r0}); k < j; ++k) s -= Li[k] * Lj[k];
+      Li[j] = s / Lj[j];
+    }
+    double s = Li[i];
+    for (int64_t k = std::max(fi, r0); k < i; ++k) s -= Li[k] * Li[k];
+    if (!(s > 0.0) || !std::isfinite(s)) return false;
+    Li[i] = std::sqrt(s);
+  }
+  return true;
+}
 bool skyline_factor(Workspace* ws, int64_t m) {
+  if (g_threads > 1 && ws->object_row0 < m) return skyline_factor_arrow(ws, m);
   for (int64_t i = 0; i < m; ++i) {
     const int64_t fi = ws->first[i];
     double* Li = &ws->S[ws->rowptr[i]] - fi;
@@ -512,6 +661,10 @@ void copy_params(const OracleProblem& pb, std::vector<double>* a, std::vector<do
 extern "C" {
 
 struct oracle_handle { OracleProblem pb; };
+
+// host threads of the oracle's parallel parts (process-wide; 1 = the sequential reference order)
+void oracle_set_threads(int32_t n) { g_threads = std::max<int32_t>(1, n); }
+int32_t oracle_get_threads(void) { return g_threads; }
 
 int oracle_ba_create(const obvi_ba_options* opt, oracle_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
@@ -889,8 +1042,11 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = diag_c[i] / radius / (scale_c[i] * scale_c[i]);
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k)
       lam_l[3 * l + k] = diag_l[3 * l + k] / radius / (scale_l[3 * l + k] * scale_l[3 * l + k]);
+    const double t_asm = now_s();
     bool ok = assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hll_inv);
+    const double t_fac = now_s();
     if (ok) ok = skyline_cholesky_solve(&ws, rd.m, &y_c);
+    if (std::getenv("OBVI_ORACLE_TIMING")) std::fprintf(stderr, "oracle step: assemble_schur %.3f s, skyline factor + solve %.3f s (envelope %.1f M entries)\n", t_fac - t_asm, now_s() - t_fac, 1e-6 * (double)ws.S.size());
     // back-substitution  y_l = Hll^-1 (g_l - W^T y_c)
     if (ok) {
       for (int64_t l = 0; l < pb.L; ++l) {

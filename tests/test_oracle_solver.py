@@ -178,6 +178,41 @@ def test_iteration_log_bookkeeping():
     assert abs(s.final_cost - min(i.cost for i in its)) <= 1e-15 * s.final_cost
 
 
+def test_host_threads_change_round_off_only():
+    """bench.py's cpu_baseline runs the oracle with min(20, hardware) host threads (the reference's num_threads = 20): same factor
+    records in the same order, bit-identical skyline factor (arrow split), only the order of the points' Schur contributions
+    differs.  The trajectory must be that of the sequential oracle to round-off."""
+    import ctypes
+    lib = ctypes.CDLL(helpers.ensure_oracle())
+    prob = synth.make_problem(P=60, L=2500, O=4, seed=9, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0)
+    out = []
+    try:
+        for threads in (1, 4):
+            lib.oracle_set_threads(ctypes.c_int32(threads))
+            ba = helpers.oracle_ba(); synth.upload(ba, prob)
+            s = ba.solve(helpers.ba_params(max_it=6, ftol=0, gtol=0, ptol=0))
+            out.append((s.num_iterations, [i.cost for i in ba.iterations()], [i.step_is_successful for i in ba.iterations()], ba.get_poses(), ba.get_objects()))
+    finally:
+        lib.oracle_set_threads(ctypes.c_int32(1))
+    (n1, c1, a1, p1, o1), (n4, c4, a4, p4, o4) = out
+    assert n1 == n4 and a1 == a4
+    assert max(abs(x - y) / y for x, y in zip(c4, c1)) < 1e-11
+    assert np.abs(p4 - p1).max() < 1e-9 and np.abs(o4 - o1).max() < 1e-8
+
+
+def test_flat_problem_file_for_the_ceres_harness(tmp_path):
+    """synth.dump_flat writes what oracle/ceres_harness/ceres_harness.cpp reads (the harness itself only builds where Ceres is)."""
+    import struct
+    prob = small_problem()
+    path = tmp_path / "p.flat"
+    synth.dump_flat(prob, str(path), max_it=4)
+    raw = path.read_bytes()
+    assert raw[:8] == b"OBVIFLT1"
+    n_k = struct.unpack_from("<Q", raw, 8)[0]
+    assert n_k == prob["K"].size and struct.unpack_from("<%dd" % n_k, raw, 16) == tuple(prob["K"].ravel())
+    assert struct.unpack_from("<7d", raw, len(raw) - 56)[0] == 4.0
+
+
 def test_converged_minimum_matches_scipy_on_the_numpy_restatement():
     """Solver-level pin that does not involve the oracle's own arithmetic: the minimiser of 1/2 sum rho(|r_b|^2) the oracle's LM loop
     converges to must be the one scipy.optimize.least_squares finds for residuals computed by the independent numpy restatement
