@@ -77,6 +77,10 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
   // bounding boxes
   int64_t n_bb; const uint32_t* bb_obj; const uint32_t* bb_pose; const uint16_t* bb_cam;
   const double* bb_rect; const double* bb_sqrt_inf; const uint8_t* bb_active; double bb_huber, bb_invalid;
+  double* bb_blk;                                       // [n_bb][62] per-factor diagonal blocks (big problems: k_small_lin_lanes<true> / k_bbox_gather)
+  int32_t bb_pairs_unique;                              // no (object, pose) pair occurs twice: the off-diagonal block of a factor is its own
+  const uint32_t* bbo_ptr; const uint32_t* bbo_idx;     // factors by object: [O+1], [n_bb]
+  const uint32_t* bbp_ptr; const uint32_t* bbp_idx;     // factors by pose:   [P+1], [n_bb]
   // shape priors
   int64_t n_sp; const uint32_t* sp_obj; const double* sp_mean; const double* sp_sqrt_inf; const uint8_t* sp_active; double sp_huber;
   // LTM priors

@@ -553,6 +553,12 @@ __global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev
 // 16 lanes: lane `dir` evaluates the residual with a one-direction dual, so the Jacobian column of a parameter lives in its lane;
 // rows of J^T J are formed from the group's columns (wave shuffles) and added by the lane that owns the row.  (On big problems the
 // thread-per-factor kernels win: see DESIGN.md.)
+// STORE (big problems): nothing is added atomically except the cost -- the factor's blocks (w J^T J, w J^T r) go to its slot of the
+// scratch (kBbBlk doubles: H_oo lower-packed 28 | g_o 7 | H_pp lower-packed 21 | g_p 6), and k_bbox_gather sums the slots per
+// object and per pose; the off-diagonal 7x6 block goes straight into its tile.  Tens of thousands of factors would otherwise mean millions of fp64 atomics (32-byte memory-side
+// transactions each): that, not the dual arithmetic, was the duration of the thread-per-factor kernel this replaces.
+constexpr int kBbBlk = 62, kBbHoo = 0, kBbGo = 28, kBbHpp = 35, kBbGp = 56;
+template <bool STORE>
 __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
   const int64_t i = block * 4LL + (threadIdx.x >> 4);
@@ -575,7 +581,47 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
   for (int k = 0; k < 13; ++k)
 #pragma unroll
     for (int a = 0; a < 4; ++a) Jk[a][k] = __shfl(J[a], base + k, 64);
-  if (work && dir < 7 && ov >= 0) {
+  if (STORE) {
+    double* slot = sf.bb_blk + (int64_t)kBbBlk * i;
+    if (work && dir < 7 && ov >= 0) {
+      const int x = dir;
+#pragma unroll
+      for (int y = 0; y < 7; ++y) {
+        if (y > x) continue;
+        double acc = 0.0;
+        for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][y];
+        slot[kBbHoo + x * (x + 1) / 2 + y] = w * acc;
+      }
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
+      slot[kBbGo + x] = w * acc;
+      if (pv >= 0) {
+        // the 7x6 block between the object and the pose belongs to this factor alone when no (object, pose) pair occurs twice
+        // (host: bb_pairs_unique; false only with several cameras seeing the object from one frame): plain stores into the cleared tile
+        const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
+        const bool obj_low = orow > prow;
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+          double acc2 = 0.0;
+          for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
+          double* dst = obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
+          if (sf.bb_pairs_unique) *dst = w * acc2; else atomic_add_f64(dst, w * acc2);
+        }
+      }
+    } else if (work && dir >= 7 && dir < 13 && pv >= 0) {
+      const int x = dir - 7;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) {
+        if (y > x) continue;
+        double acc = 0.0;
+        for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][7 + y];
+        slot[kBbHpp + x * (x + 1) / 2 + y] = w * acc;
+      }
+      double acc = 0.0;
+      for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
+      slot[kBbGp + x] = w * acc;
+    }
+  } else if (work && dir < 7 && ov >= 0) {
     const int x = dir;
     double* Hd = rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov;
 #pragma unroll
@@ -672,12 +718,76 @@ __device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev
 }
 
 // the three small-factor families of a small problem in one launch (at this size an iteration's first half is bound by the host's launches)
+template <bool STORE>
 __global__ void __launch_bounds__(64) k_small_lin_lanes(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                        const double* __restrict__ objects, ReducedDev rd, double* scal, int nb_bbox, int nb_priors) {
   const int blk = blockIdx.x;
-  if (blk < nb_bbox) bbox_lin_lanes(blk, b, sf, cams, poses, objects, rd, scal);
+  if (blk < nb_bbox) bbox_lin_lanes<STORE>(blk, b, sf, cams, poses, objects, rd, scal);
   else if (blk < nb_bbox + nb_priors) object_priors_lin(blk - nb_bbox, b, sf, objects, rd, scal);
   else relpose_lin_lanes(blk - nb_bbox - nb_priors, b, sf, poses, rd, scal);
+}
+
+// The sums behind k_small_lin_lanes<true>: the diagonal blocks.  Workgroups [0, O): one per object, its factors' H_oo | g_o (CSR by
+// object; an object of the global problem has ~100 factors, so the list is cut into 7 slices of 36 lanes and the loop is unrolled:
+// the loads of a slot go through two indirections).  The rest: one wavefront per pose, H_pp | g_p of its ~10 factors (CSR by pose).
+// One writer per block: plain read-modify-write, a fixed summation order.  Runs after the kernels that add to the diagonal blocks
+// atomically (same stream).
+__global__ void __launch_bounds__(kBlock) k_bbox_gather(BlocksDev b, SmallFactorsDev sf, ReducedDev rd) {
+  if ((int64_t)blockIdx.x < b.O) {
+    __shared__ double part[7][36];
+    const int64_t o = blockIdx.x;
+    const int32_t ov = b.obj_vid[o];
+    if (ov < 0) return;   // uniform per workgroup
+    const int slice = threadIdx.x / 36, e = threadIdx.x % 36;
+    const uint32_t q0 = sf.bbo_ptr[o], q1 = sf.bbo_ptr[o + 1];
+    if (threadIdx.x < 252) {
+      double acc = 0.0;
+      if (e < 35) {
+#pragma unroll 4
+        for (uint32_t q = q0 + slice; q < q1; q += 7) {
+          const uint32_t f = sf.bbo_idx[q];
+          const double v = sf.bb_blk[(int64_t)kBbBlk * f + e];
+          acc += sf.bb_active[f] ? v : 0.0;
+        }
+      }
+      part[slice][e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 35) {
+      const int lane = threadIdx.x;
+      double acc = 0.0;
+      for (int i = 0; i < 7; ++i) acc += part[i][lane];
+      if (lane < 28) {
+        int x = 0, base = 0;
+        while (base + x + 1 <= lane) { base += x + 1; ++x; }
+        rd.Hdiag[36 * b.nPv + 49 * (int64_t)ov + 7 * x + (lane - base)] += acc;
+      } else {
+        rd.g[6 * b.nPv + 7 * (int64_t)ov + (lane - 28)] += acc;
+      }
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t p = ((int64_t)blockIdx.x - b.O) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (p >= b.P) return;
+  const int32_t pv = b.pose_vid[p];
+  if (pv < 0 || lane >= 27) return;
+  const uint32_t q0 = sf.bbp_ptr[p], q1 = sf.bbp_ptr[p + 1];
+  if (q1 == q0) return;
+  double acc = 0.0;
+#pragma unroll 4
+  for (uint32_t q = q0; q < q1; ++q) {
+    const uint32_t f = sf.bbp_idx[q];
+    const double v = sf.bb_blk[(int64_t)kBbBlk * f + kBbHpp + lane];
+    acc += sf.bb_active[f] ? v : 0.0;
+  }
+  if (lane < 21) {
+    int x = 0, base = 0;
+    while (base + x + 1 <= lane) { base += x + 1; ++x; }
+    rd.Hdiag[36 * (int64_t)pv + 6 * x + (lane - base)] += acc;
+  } else {
+    rd.g[6 * (int64_t)pv + (lane - 21)] += acc;
+  }
 }
 
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
@@ -1373,14 +1483,17 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
                           const double* objects, const ReducedDev& rd, double* scal) {
   // few factors (a sliding window): 16 lanes per factor, the latency of a handful of wavefronts is the whole side stream; one launch
   const int64_t lanes_below = std::getenv("OBVI_SMALL_LANES_BELOW") ? std::atoll(std::getenv("OBVI_SMALL_LANES_BELOW")) : 4096;   // tuning knob
-  if (sf.n_bb < lanes_below && sf.n_rl < lanes_below) {
-    const int nb_bbox = (int)grid_for(sf.n_bb, 4), nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
-    if (nb_bbox + nb_priors + nb_rel > 0) hipLaunchKernelGGL(k_small_lin_lanes, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+  const int nb_bbox = (int)grid_for(sf.n_bb, 4), nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
+  if (nb_bbox + nb_priors + nb_rel == 0) return;
+  if (sf.n_bb < lanes_below) {
+    hipLaunchKernelGGL(k_small_lin_lanes<false>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
     return;
   }
-  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_lin, dim3(grid_for(sf.n_bb, 64)), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal);
-  if (sf.n_sp + sf.n_lt > 0) hipLaunchKernelGGL(k_object_priors_lin, dim3(grid_for(sf.n_sp + sf.n_lt, 64)), dim3(64), 0, s, b, sf, objects, rd, scal);
-  if (sf.n_rl > 0) hipLaunchKernelGGL(k_relpose_lin, dim3(grid_for(sf.n_rl, 64)), dim3(64), 0, s, b, sf, poses, rd, scal);
+  // many bounding boxes: per-factor blocks into the scratch, then one wavefront per object / pose sums them (no atomics); the priors and
+  // the relative-pose factors ride in the first launch, 16 lanes per factor at every size (a thread per factor left the 2 000 odometry
+  // factors of the global problem as 32 wavefronts dragging a 12-direction dual: 250 us)
+  hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+  hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {

@@ -98,6 +98,9 @@ struct obvi_ba_handle {
   DevBuf<uint16_t> d_bb_cam;
   DevBuf<double> d_bb_rect, d_bb_sqrt_inf, d_sp_mean, d_sp_sqrt_inf, d_lt_mean, d_lt_sqrt_inf, d_rl_t, d_rl_R, d_rl_sqrt_inf;
   DevBuf<uint8_t> d_bb_active, d_sp_active, d_lt_active, d_rl_active;
+  DevBuf<double> d_bb_blk;                                    // per-factor blocks of the bounding-box factors (k_bbox_gather)
+  int32_t bb_pairs_unique = 1;
+  DevBuf<uint32_t> d_bbo_ptr, d_bbo_idx, d_bbp_ptr, d_bbp_idx;   // ... and the factor lists by object / by pose (prepare())
   // ---- device: reduced system ----
   DevBuf<double> d_Hdiag, d_g, d_scale, d_lam, d_S, d_rhs, d_y, d_Linv;
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z, d_gl, d_lam_l;
@@ -224,6 +227,7 @@ SmallFactorsDev small_dev(const obvi_ba_handle* h) {
   s.n_bb = h->n_bb; s.bb_obj = h->d_bb_obj.get(); s.bb_pose = h->d_bb_pose.get(); s.bb_cam = h->d_bb_cam.get();
   s.bb_rect = h->d_bb_rect.get(); s.bb_sqrt_inf = h->d_bb_sqrt_inf.get(); s.bb_active = h->d_bb_active.get();
   s.bb_huber = h->bb_huber; s.bb_invalid = h->bb_invalid;
+  s.bb_pairs_unique = h->bb_pairs_unique; s.bb_blk = h->d_bb_blk.get(); s.bbo_ptr = h->d_bbo_ptr.get(); s.bbo_idx = h->d_bbo_idx.get(); s.bbp_ptr = h->d_bbp_ptr.get(); s.bbp_idx = h->d_bbp_idx.get();
   s.n_sp = h->n_sp; s.sp_obj = h->d_sp_obj.get(); s.sp_mean = h->d_sp_mean.get(); s.sp_sqrt_inf = h->d_sp_sqrt_inf.get();
   s.sp_active = h->d_sp_active.get(); s.sp_huber = h->sp_huber;
   s.n_lt = h->n_lt; s.lt_obj = h->d_lt_obj.get(); s.lt_mean = h->d_lt_mean.get(); s.lt_sqrt_inf = h->d_lt_sqrt_inf.get();
@@ -960,6 +964,25 @@ void prepare(obvi_ba_handle* h) {
     h->d_job_signal.upload(job_signal, s); h->d_k_need.upload(k_need, s); h->d_diag_done.resize((size_t)nt + 1);
   }
   h->d_pose_row.upload(h->h_pose_row, s); h->d_obj_row.upload(h->h_obj_row, s); h->d_is_pad.upload(h->h_is_pad, s);
+  {   // bounding-box factors by object and by pose (counting sorts, caller order inside a list), scratch for their blocks
+    std::vector<uint32_t> optr((size_t)O + 1, 0), pptr((size_t)P + 1, 0), oidx((size_t)h->n_bb), pidx((size_t)h->n_bb);
+    for (int64_t i = 0; i < h->n_bb; ++i) { optr[h->h_bb_obj[i] + 1]++; pptr[h->h_bb_pose[i] + 1]++; }
+    for (int64_t o = 0; o < O; ++o) optr[o + 1] += optr[o];
+    for (int64_t p = 0; p < P; ++p) pptr[p + 1] += pptr[p];
+    std::vector<uint32_t> oc(optr.begin(), optr.end() - 1), pc(pptr.begin(), pptr.end() - 1);
+    for (int64_t i = 0; i < h->n_bb; ++i) { oidx[oc[h->h_bb_obj[i]]++] = (uint32_t)i; pidx[pc[h->h_bb_pose[i]]++] = (uint32_t)i; }
+    h->d_bbo_ptr.upload(optr, s); h->d_bbo_idx.upload(oidx, s); h->d_bbp_ptr.upload(pptr, s); h->d_bbp_idx.upload(pidx, s);
+    h->d_bb_blk.resize((size_t)62 * (size_t)h->n_bb + 1);
+    // does any (object, pose) pair occur twice?  (inside a pose's list: the same object twice)
+    h->bb_pairs_unique = 1;
+    std::vector<uint32_t> objs;
+    for (int64_t p = 0; p < P && h->bb_pairs_unique; ++p) {
+      objs.clear();
+      for (uint32_t q = pptr[p]; q < pptr[p + 1]; ++q) objs.push_back(h->h_bb_obj[pidx[q]]);
+      std::sort(objs.begin(), objs.end());
+      if (std::adjacent_find(objs.begin(), objs.end()) != objs.end()) h->bb_pairs_unique = 0;
+    }
+  }
   {
     std::vector<uint8_t> sh((size_t)h->nOv + 1, 0);
     for (int32_t ov : h->h_shared_ov) sh[ov] = 1;
@@ -1026,11 +1049,12 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   static const bool side_ok = !std::getenv("OBVI_SIDE") || std::atoi(std::getenv("OBVI_SIDE")) != 0;   // tuning knob
   const bool side = !exchange && h->profiling < 2 && side_ok;
   hipStream_t s2 = side ? h->stream2 : s;
+  // the point pass first, alone: it and the pose-side pass stream the same observation arrays and are both HBM-bound (side by side the
+  // point pass took 0.35 ms instead of 0.24); the side stream starts behind it and runs beside the Schur complement, which is bound
+  // by instruction issue and LDS, not by HBM
+  record(h, PH_POINT_PASS);
+  launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   if (side) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
-  if (!side) {
-    record(h, PH_POINT_PASS);
-    launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
-  }
   record(h, PH_POSE_PASS, s2);
   launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   if (side) record_end(h, PH_POSE_PASS, s2);
@@ -1045,12 +1069,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 1);
   }
   launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
-  if (side) {
-    record_end(h, PH_DIAG, s2);
-    OBVI_HIP(hipEventRecord(h->ev_join, s2));
-    record(h, PH_POINT_PASS);
-    launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
-  }
+  if (side) { record_end(h, PH_DIAG, s2); OBVI_HIP(hipEventRecord(h->ev_join, s2)); }
   record(h, PH_SCHUR);
   if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   record(h, PH_SCHUR_BLOCKS);

@@ -97,6 +97,8 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_ND_BALANCE": "0", "OBVI_ND_LEAF": "96"},          # the unbalanced dissection of the earlier builds
     {"OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},                # a deep tree of tiny leaves
     {"OBVI_SCHUR_WGS": "16", "OBVI_UPD_CHUNK": "1"},
+    {"OBVI_SMALL_LANES_BELOW": "0"},                         # bounding boxes through the scratch + gather kernels of big problems (no atomics)
+    {"OBVI_SMALL_LANES_BELOW": "1000000"},                   # ... through the one-launch atomic path of sliding windows
     {"OBVI_PAIR_BITMAP_MAX": "0"},                           # tile marks pair by pair (the path of more than 8192 variable poses)
     {"OBVI_SMALL_LANES_BELOW": "0"},                         # thread-per-factor small-factor kernels (the big-problem path) on a small problem
     {"OBVI_SMALL_LANES_BELOW": "1000000000", "OBVI_HOST_THREADS": "3"},   # ... 16 lanes per factor; symbolic phase on three host threads
@@ -115,6 +117,29 @@ def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     assert sg.num_iterations == so.num_iterations
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
+
+
+@pytest.mark.parametrize("below", ["0", "1000000"])
+def test_an_object_seen_twice_from_one_frame(below, monkeypatch):
+    """Two bounding-box factors on the same (object, pose) pair (two detections / two cameras): their off-diagonal blocks land on
+    the same tile entries.  Both small-factor paths (scratch + gather with plain stores when every pair is unique, atomics
+    otherwise; the one-launch atomic path) must give the oracle's reduced system and step."""
+    monkeypatch.setenv("OBVI_SMALL_LANES_BELOW", below)
+    prob = synth.make_problem(P=40, L=400, O=3, seed=21, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=5)
+    dup = np.arange(0, len(prob["bb_obj"]), 3)
+    rng = np.random.default_rng(3)
+    for k in ("bb_obj", "bb_pose", "bb_cam", "bb_cov"):
+        prob[k] = np.concatenate([prob[k], prob[k][dup]])
+    prob["bb_corners"] = np.concatenate([prob["bb_corners"], prob["bb_corners"][dup] + rng.normal(size=(len(dup), 4)) * 3.0])
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    So, bo = o.debug_reduced_system(100.0)
+    Sg, bg = g.debug_reduced_system(100.0)
+    assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
+    prm = helpers.ba_params(max_it=3, ftol=0, ptol=0, gtol=0)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost and np.abs(g.get_objects() - o.get_objects()).max() < 1e-8
 
 
 def test_blocks_or_cameras_re_uploaded_after_the_factors():
