@@ -180,9 +180,12 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
       { double* ut = pt.Z + z_tail(end, l); ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0; }   // copy behind the point's Z records (k_schur_window)
       // second sweep: Z = rho' Jp^T (Jl Ci^T)
       for (uint32_t a = beg; a < end; ++a) {
-        if (!rp.active[a]) continue;
         const uint32_t p = rp.pose[a];
-        if (b.pose_vid[p] < 0) continue;
+        if (!rp.active[a] || b.pose_vid[p] < 0) {   // no contribution: a zero record (a plan kept across a mask change may still visit it)
+          double* Z0 = pt.Z + z_off(a, l);
+          for (int x = 0; x < 18; ++x) Z0[x] = 0.0;
+          continue;
+        }
         const double2 px = rp.pixel[a];
         double r[2], Jp[12], Jl[6];
         reproj_eval<true>(pc[p], cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
@@ -198,6 +201,10 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
           Z[3 * x + 2] = w * (Jp[x] * m02 + Jp[6 + x] * m12);
         }
       }
+    } else {   // not variable: zero records and tail (see k_point_pass)
+      for (uint32_t a = beg; a < end; ++a) { double* Z = pt.Z + z_off(a, l); for (int x = 0; x < 18; ++x) Z[x] = 0.0; }
+      double* ut = pt.Z + z_tail(end, l); ut[0] = ut[1] = ut[2] = ut[3] = 0.0;
+      pt.u[3 * l] = 0.0; pt.u[3 * l + 1] = 0.0; pt.u[3 * l + 2] = 0.0;
     }
   }
   block_accumulate(cost, scal + SC_COST);
@@ -321,10 +328,20 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
         Z[3 * x + 1] = wz * (Jp[x] * m01 + Jp[6 + x] * m11);
         Z[3 * x + 2] = wz * (Jp[x] * m02 + Jp[6 + x] * m12);
       }
+    } else if (have) {
+      // a point that is not variable (constant, or -- under a plan kept across a mask change -- one that lost all its factors): zero
+      // records and a zero tail, because the plan's Schur work lists may still visit it
+      double* Z = img + 18 * lane + 4 * (int)(l - l0);
+#pragma unroll
+      for (int x = 0; x < 18; ++x) Z[x] = 0.0;
+      if (head) {
+        double* ut = img + 18 * (first + len) + 4 * (int)(l - l0); ut[0] = ut[1] = ut[2] = ut[3] = 0.0;
+        pt.u[3 * (int64_t)l] = 0.0; pt.u[3 * (int64_t)l + 1] = 0.0; pt.u[3 * (int64_t)l + 2] = 0.0;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // write the image: contiguous in global memory, 16 bytes per lane per store (slots of constant points carry stale LDS data: never read)
+    // write the image: contiguous in global memory, 16 bytes per lane per store
     const int total2 = (18 * (int)n + 4 * (int)(l1 - l0 + 1)) / 2;
     double2* dst = reinterpret_cast<double2*>(pt.Z + z_off(a0, l0));
     const double2* src = reinterpret_cast<const double2*>(img);

@@ -125,7 +125,13 @@ struct obvi_ba_handle {
   double* h_scal = nullptr;  // pinned
 
   // ---- reduced-program bookkeeping (prepare()) ----
-  bool dirty = true;
+  bool dirty = true;                     // the symbolic plan must be rebuilt (blocks / factors / constness changed)
+  bool mask_dirty = false;               // only factor masks changed since the plan was built: prepare_masks() may keep the plan
+  // what the plan was built for: variable blocks and active factors.  A later state whose variable blocks and active factors are
+  // subsets of these runs on the same plan (rows of dropped blocks become padding, masked observations contribute zeros)
+  std::vector<int32_t> plan_pose_vid, plan_obj_vid;
+  std::vector<uint8_t> plan_point_var, plan_is_pad, plan_rp_active, plan_bb_active, plan_sp_active, plan_lt_active, plan_rl_active;
+  int64_t live_rows = 0;                 // 6 (variable poses) + 7 (variable objects) of the current state (== m_canon right after a full plan)
   int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, num_params = 0, num_residuals = 0;
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
@@ -329,8 +335,10 @@ void bake_bbox(obvi_ba_handle* h) {
 // ---------------------------------------------------------------------------------------
 // Reduced program [Ceres-doc Program::RemoveFixedBlocks], Schur pair lists, tile plan.
 // ---------------------------------------------------------------------------------------
+bool prepare_masks(obvi_ba_handle* h);
 void prepare(obvi_ba_handle* h) {
-  if (!h->dirty) return;
+  if (!h->dirty && h->mask_dirty && prepare_masks(h)) return;
+  if (!h->dirty && !h->mask_dirty) return;
   // OBVI_DEBUG_PREPARE: stage times of the symbolic phase on stderr
   const bool stage_times = std::getenv("OBVI_DEBUG_PREPARE") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
@@ -1006,7 +1014,98 @@ void prepare(obvi_ba_handle* h) {
   h->d_pc.resize(2 * ((size_t)P + 1)); h->d_pc_c.resize(2 * ((size_t)P + 1));   // records, then the field-major copy (k_pose_cache)
   sync(h);  // host vectors above go out of scope
   stage("upload + allocations");
-  h->dirty = false; h->pc_valid = false; h->tiles_cleared = false;
+  h->dirty = false; h->mask_dirty = false; h->pc_valid = false; h->tiles_cleared = false;
+  h->plan_pose_vid = pose_vid; h->plan_obj_vid = obj_vid; h->plan_point_var = point_var; h->plan_is_pad = h->h_is_pad;
+  h->plan_rp_active = h->h_rp_active; h->plan_bb_active = h->h_bb_active; h->plan_sp_active = h->h_sp_active; h->plan_lt_active = h->h_lt_active; h->plan_rl_active = h->h_rl_active;
+  h->live_rows = h->m_canon;
+}
+
+// Factor masks changed and nothing else (phase II of a window: offline_problem_runner.h:803-892 re-solves the phase-I problem minus
+// the excluded factors).  If the active factors and the blocks they leave variable are subsets of what the plan was built for, the
+// plan stays: elimination order, Schur work lists, tile structure and level jobs are those of a superset problem, masked
+// observations write zero Z records, points that lost all their factors are skipped (their records are zeroed too), and the rows
+// of a pose / object that dropped out become padding rows (identity).  Only the reduced-program bookkeeping is redone: O(factors).
+// Returns false when the new state is not a subset (the caller then rebuilds the plan).
+bool prepare_masks(obvi_ba_handle* h) {
+  static const bool keep = !std::getenv("OBVI_KEEP_PLAN") || std::atoi(std::getenv("OBVI_KEEP_PLAN")) != 0;   // 0: always rebuild (parity runs)
+  if (!keep) return false;
+  const int64_t P = h->P, L = h->L, O = h->O;
+  if ((int64_t)h->plan_pose_vid.size() != P || (int64_t)h->plan_obj_vid.size() != O || (int64_t)h->plan_point_var.size() != L) return false;
+  auto subset = [](const std::vector<uint8_t>& now, const std::vector<uint8_t>& plan) {
+    if (now.size() != plan.size()) return false;
+    for (size_t i = 0; i < now.size(); ++i) if (now[i] && !plan[i]) return false;
+    return true;
+  };
+  if (!subset(h->h_rp_active, h->plan_rp_active) || !subset(h->h_bb_active, h->plan_bb_active) || !subset(h->h_sp_active, h->plan_sp_active) ||
+      !subset(h->h_lt_active, h->plan_lt_active) || !subset(h->h_rl_active, h->plan_rl_active)) return false;
+  std::vector<uint8_t> pose_used(P, 0), obj_used(O, 0), point_used(L, 0);
+  int64_t nres = 0;
+  for (int64_t a = 0; a < h->n_rp; ++a) {
+    if (!h->h_rp_active[a]) continue;
+    const uint32_t p = h->h_rp_pose[a], l = h->h_rp_point[a];
+    const bool cp = h->h_pose_const[p], cl = h->h_point_const[l];
+    if (cp && cl) continue;
+    nres += 2;
+    if (!cp) pose_used[p] = 1;
+    if (!cl) point_used[l] = 1;
+  }
+  for (int64_t i = 0; i < h->n_bb; ++i) {
+    if (!h->h_bb_active[i]) continue;
+    const uint32_t o = h->h_bb_obj[i], p = h->h_bb_pose[i];
+    const bool co = h->h_object_const[o], cp = h->h_pose_const[p];
+    if (co && cp) continue;
+    nres += 4;
+    if (!co) obj_used[o] = 1;
+    if (!cp) pose_used[p] = 1;
+  }
+  for (int64_t i = 0; i < h->n_sp; ++i) if (h->h_sp_active[i] && !h->h_object_const[h->h_sp_obj[i]]) { nres += 3; obj_used[h->h_sp_obj[i]] = 1; }
+  for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += 7; obj_used[h->h_lt_obj[i]] = 1; }
+  for (int64_t i = 0; i < h->n_rl; ++i) {
+    if (!h->h_rl_active[i]) continue;
+    const uint32_t a = h->h_rl_a[i], b = h->h_rl_b[i];
+    const bool ca = h->h_pose_const[a], cb = h->h_pose_const[b];
+    if (ca && cb) continue;
+    nres += 6;
+    if (!ca) pose_used[a] = 1;
+    if (!cb) pose_used[b] = 1;
+  }
+  if (!h->h_is_shared.empty()) for (int64_t o = 0; o < O; ++o) if (h->h_is_shared[o]) obj_used[o] = 1;
+  std::vector<int32_t> pose_vid(P, -1), obj_vid(O, -1);
+  std::vector<uint8_t> point_var(L, 0), is_pad = h->plan_is_pad;
+  int64_t nP = 0, nO = 0, nL = 0;
+  for (int64_t p = 0; p < P; ++p) {
+    const bool var = !h->h_pose_const[p] && pose_used[p];
+    if (var && h->plan_pose_vid[p] < 0) return false;
+    if (var) { pose_vid[p] = h->plan_pose_vid[p]; ++nP; }
+    else if (h->plan_pose_vid[p] >= 0) { const int64_t r = h->h_pose_row[h->plan_pose_vid[p]]; for (int k = 0; k < 6; ++k) is_pad[r + k] = 1; }
+  }
+  for (int64_t o = 0; o < O; ++o) {
+    const bool var = !h->h_object_const[o] && obj_used[o];
+    if (var && h->plan_obj_vid[o] < 0) return false;
+    if (var) { obj_vid[o] = h->plan_obj_vid[o]; ++nO; }
+    else if (h->plan_obj_vid[o] >= 0) { const int64_t r = h->h_obj_row[h->plan_obj_vid[o]]; for (int k = 0; k < 7; ++k) is_pad[r + k] = 1; }
+  }
+  for (int64_t l = 0; l < L; ++l) {
+    const bool var = !h->h_point_const[l] && point_used[l];
+    if (var && !h->plan_point_var[l]) return false;
+    if (var) { point_var[l] = 1; ++nL; }
+  }
+  std::vector<int32_t>& yrow = h->h_rp_yrow;
+  yrow.resize((size_t)h->n_rp);
+  for (int64_t a = 0; a < h->n_rp; ++a) {
+    const int32_t v = h->h_rp_active[a] ? pose_vid[h->h_rp_pose[a]] : -1;
+    yrow[a] = v >= 0 ? h->h_pose_row[v] : -1;
+  }
+  hipStream_t s = h->stream;
+  h->d_rp_yrow.upload(yrow, s);
+  h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s); h->d_is_pad.upload(is_pad, s);
+  h->h_obj_vid = obj_vid; h->h_is_pad = is_pad;
+  h->nLv = nL; h->live_rows = 6 * nP + 7 * nO;
+  h->num_params = h->live_rows + 3 * nL;
+  h->num_residuals = nres;
+  sync(h);
+  h->mask_dirty = false; h->pc_valid = false; h->tiles_cleared = false;
+  return true;
 }
 
 StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
@@ -1466,7 +1565,7 @@ int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t type, const uint8_t* mask
     default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_active_mask: unknown factor type");
   }
   sync(h);
-  h->dirty = true;
+  h->mask_dirty = true;   // prepare() keeps the symbolic plan if the new masks select a subset of what it was built for
   return OBVI_OK;
   OBVI_API_END(h)
 }
@@ -1540,6 +1639,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
+  if (h->mask_dirty) h->dirty = true;   // the canonical (caller-order) view below is that of a plan built for exactly the current masks
   prepare(h);
   if (m_out) *m_out = (int32_t)h->m_canon;
   if (h->m_canon > m_cap) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_reduced_system: buffer too small");
@@ -1659,7 +1759,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   sum->fixed_cost = fixed_cost;
   sum->num_parameters_reduced = (int32_t)h->num_params;
   sum->num_residuals_reduced = (int32_t)h->num_residuals;
-  sum->reduced_system_size = (int32_t)h->m_canon;
+  sum->reduced_system_size = (int32_t)h->live_rows;
 
   auto finish = [&](int term, const char* msg) {
     sum->termination_type = term;

@@ -142,6 +142,53 @@ def test_an_object_seen_twice_from_one_frame(below, monkeypatch):
     assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost and np.abs(g.get_objects() - o.get_objects()).max() < 1e-8
 
 
+def test_symbolic_plan_survives_a_mask_change():
+    """Phase II of a window re-solves the phase-I problem minus the excluded factors (offline_problem_runner.h:803-892).  The library
+    keeps the symbolic plan when the new masks select a subset of what it was built for: masked observations contribute zero
+    records, features that lose all their sightings drop out, the rows of an object that loses all its boxes become padding.  Same
+    result as a handle whose plan was built for the masked problem, and as the oracle; re-enabling everything rebuilds the plan."""
+    prob = synth.make_problem(P=130, L=3000, O=6, seed=17, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=6)
+    rng = np.random.default_rng(4)
+    m_rp = (rng.uniform(size=len(prob["rp_pose"])) > 0.12).astype(np.uint8)
+    gone = rng.choice(len(prob["points"]), 40, replace=False)
+    m_rp[np.isin(prob["rp_point"], gone)] = 0                       # these features lose every sighting
+    left = np.bincount(prob["rp_point"], weights=m_rp, minlength=len(prob["points"]))
+    m_rp[left[prob["rp_point"]] < 3] = 0                            # ... and so do features left with fewer than 3 (as the min-observation filter would)
+    gone = np.flatnonzero(np.bincount(prob["rp_point"], weights=m_rp, minlength=len(prob["points"])) == 0)
+    m_bb = (rng.uniform(size=len(prob["bb_obj"])) > 0.1).astype(np.uint8)
+    m_bb[prob["bb_obj"] == 2] = 0                                   # object 2 loses every box ...
+    m_sp = np.ones(len(prob["sp_obj"]), np.uint8); m_sp[prob["sp_obj"] == 2] = 0   # ... and its shape prior: it drops out of the problem
+    prm = helpers.ba_params(max_it=6, ftol=0, gtol=0, ptol=0)
+
+    def masked(ba, build_plan_first):
+        synth.upload(ba, prob)
+        if build_plan_first:
+            ba.snapshot(); ba.solve(helpers.ba_params(max_it=2)); ba.restore()       # a full plan and a solve on it, as phase I does
+        ba.set_active_mask(0, m_rp); ba.set_active_mask(2, m_bb); ba.set_active_mask(3, m_sp)
+        s = ba.solve(prm)
+        return s, ba.get_poses(), ba.get_objects(), ba.get_points()
+    g1, g2, o = helpers.product_ba(), helpers.product_ba(), helpers.oracle_ba()
+    (s1, p1, o1, x1), (s2, p2, o2, x2), (so, po, oo, xo) = masked(g1, True), masked(g2, False), masked(o, False)
+    assert s1.num_parameters_reduced == s2.num_parameters_reduced == so.num_parameters_reduced
+    assert s1.num_residuals_reduced == s2.num_residuals_reduced == so.num_residuals_reduced and s1.reduced_system_size == s2.reduced_system_size
+    assert g1.problem_stats()["chol_levels"] >= g2.problem_stats()["chol_levels"]       # g1 still runs the plan of the full problem
+    for s, p, ob, x in ((s1, p1, o1, x1), (s2, p2, o2, x2)):
+        assert s.num_iterations == so.num_iterations and abs(s.initial_cost - so.initial_cost) <= 1e-11 * so.initial_cost
+        assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+        assert np.abs(p - po).max() < 1e-7 and np.abs(ob - oo).max() < 1e-7 and np.abs(x - xo).max() < 1e-6
+    assert np.array_equal(o1[2], prob["objects"][2]) and np.array_equal(x1[gone], prob["points"][gone])     # dropped blocks do not move
+    # covariance blocks on the kept plan: the dropped object's block is zero, the others equal the rebuilt plan's
+    c1, c2 = g1.object_covariances(np.arange(6)), g2.object_covariances(np.arange(6))
+    assert np.all(c1[2] == 0.0) and np.abs(c1 - c2).max() <= 1e-7 * np.abs(c2).max()
+    # back to all factors: not a subset of the masked state's plan for g2 -> rebuilt; g1's plan still fits
+    for ba in (g1, g2, o):
+        ba.set_poses(prob["poses"], prob["pose_const"]); ba.set_points(prob["points"], prob["point_const"]); ba.set_objects(prob["objects"], prob["object_const"])
+        for t in (0, 2, 3):
+            ba.set_active_mask(t, None)
+    sa, sb, sc = g1.solve(prm), g2.solve(prm), o.solve(prm)
+    assert abs(sa.final_cost - sc.final_cost) <= 1e-8 * sc.final_cost and abs(sb.final_cost - sc.final_cost) <= 1e-8 * sc.final_cost
+
+
 def test_blocks_or_cameras_re_uploaded_after_the_factors():
     """The ABI states no call order, so the library must cope with one: a later set_poses / set_points / set_objects with FEWER
     blocks than the factors refer to is an error at the next evaluate / solve (OBVI_ERR_OUT_OF_RANGE = -4, nothing read out of
