@@ -402,10 +402,69 @@ class ObjectPoseGraphOptimizer {
     return current_residual_block_info;
   }
 
+  // Phase II of a two-phase optimisation (offline_problem_runner.h:803-892) re-runs buildPoseGraphOptimization with the excluded
+  // factors.  What that rebuild selects can be stated on the flat problem phase I already built: an excluded visual / bounding-box
+  // factor is masked; a feature left with fewer than min_low_level_feature_observations sightings, or an object left with fewer
+  // than min_object_observations boxes (long-term-map objects excepted, :826-861), loses all its factors and so drops out; the
+  // object-only factors follow the objects (:342-405).  Returns false when the rebuild would ADD something the phase-I problem does
+  // not hold (relative-pose factors for a frame that fell below min_low_level_feature_observations_per_frame_, :240-299): the caller
+  // then rebuilds as the reference does.
+  struct PhaseTwoMasks { std::vector<uint8_t> rp, bb, sp, lt; size_t n_features = 0, n_objects = 0; };
+  template <class PoseGraphPtr>
+  bool excludeFromBuiltProblem(const OptimizationScopeParams& scope, const PoseGraphPtr& pose_graph, const FactorInfoSet& excluded, const obvi::Problem& problem,
+                               PhaseTwoMasks* out) const {
+    const obvi::FlatProblem& fp = problem.flat;
+    const size_t n_rp = fp.rp_pose.size(), n_bb = fp.bb_obj.size(), n_sp = fp.sp_obj.size(), n_lt = fp.lt_obj.size();
+    if (fp.blocks.size() < n_rp + n_bb + n_sp + n_lt) return false;
+    auto is_excluded = [&](size_t block) { return excluded.count(fp.blocks[block]) != 0; };
+    out->rp.assign(n_rp, 1); out->bb.assign(n_bb, 1); out->sp.assign(n_sp, 1); out->lt.assign(n_lt, 1);
+    // visual factors
+    std::vector<uint32_t> sightings(fp.features.size(), 0), per_frame_before(fp.frames.size(), 0), per_frame_after(fp.frames.size(), 0);
+    for (size_t i = 0; i < n_rp; ++i) {
+      ++per_frame_before[fp.rp_pose[i]];
+      if (is_excluded(i)) out->rp[i] = 0; else ++sightings[fp.rp_point[i]];
+    }
+    out->n_features = 0;
+    for (uint32_t c : sightings) if (c >= scope.min_low_level_feature_observations_) ++out->n_features;
+    for (size_t i = 0; i < n_rp; ++i) {
+      if (out->rp[i] && sightings[fp.rp_point[i]] < scope.min_low_level_feature_observations_) out->rp[i] = 0;
+      if (out->rp[i]) ++per_frame_after[fp.rp_pose[i]];
+    }
+    if (scope.include_visual_factors_ && scope.min_low_level_feature_observations_per_frame_ > 0) {   // (use_relative_pose_factors of the build) a frame that newly falls below the per-frame minimum would get odometry factors
+      for (size_t f = 0; f < fp.frames.size(); ++f) {
+        const bool below_before = per_frame_before[f] < scope.min_low_level_feature_observations_per_frame_, below_after = per_frame_after[f] < scope.min_low_level_feature_observations_per_frame_;
+        if (below_after != below_before) return false;
+      }
+    }
+    // objects
+    std::unordered_set<ObjectId> ltm_object_ids;
+    pose_graph->getLongTermMapObjects(ltm_object_ids);
+    const bool fix_ltm = scope.fix_objects_ || scope.fix_ltm_objects_;
+    std::vector<uint32_t> boxes(fp.objects.size(), 0);
+    for (size_t i = 0; i < n_bb; ++i) { if (is_excluded(n_rp + i)) out->bb[i] = 0; else ++boxes[fp.bb_obj[i]]; }
+    std::vector<uint8_t> included(fp.objects.size(), 0), object_only(fp.objects.size(), 0);
+    out->n_objects = 0;
+    for (size_t o = 0; o < fp.objects.size(); ++o) {
+      const bool is_ltm = ltm_object_ids.count(fp.objects[o]) != 0;
+      included[o] = boxes[o] >= scope.min_object_observations_ || (boxes[o] > 0 && is_ltm);
+      object_only[o] = (included[o] && (!fix_ltm || !is_ltm)) || (!fix_ltm && scope.force_include_ltm_objs_ && is_ltm);
+      if (included[o] || object_only[o]) ++out->n_objects;
+    }
+    for (size_t i = 0; i < n_bb; ++i) if (!included[fp.bb_obj[i]]) out->bb[i] = 0;
+    for (size_t i = 0; i < n_sp; ++i) if (!object_only[fp.sp_obj[i]]) out->sp[i] = 0;
+    for (size_t i = 0; i < n_lt; ++i) if (!object_only[fp.lt_obj[i]]) out->lt[i] = 0;
+    return true;
+  }
+  void setPhaseTwoLogCounts(const PhaseTwoMasks& m, std::optional<OptimizationLogger>& opt_logger) {
+    last_optimized_features_ = m.n_features; last_optimized_objects_ = m.n_objects;
+    if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);
+  }
+
   // object_pose_graph_optimizer.h:634-707
   bool solveOptimization(obvi::Problem* problem, const pose_graph_optimization::OptimizationSolverParams& solver_params,
                          std::optional<OptimizationLogger>& opt_logger, std::vector<obvi::ResidualBlockId>* residual_block_id_ptrs = nullptr,
-                         std::vector<double>* residual_ptrs = nullptr, std::shared_ptr<obvi::SolverSummary> solver_summary = nullptr) {
+                         std::vector<double>* residual_ptrs = nullptr, std::shared_ptr<obvi::SolverSummary> solver_summary = nullptr,
+                         const PhaseTwoMasks* phase_two_masks = nullptr) {
     if (problem == nullptr) return false;
     obvi_ba_handle* h = problem->handle();
     if (h == nullptr) { std::cerr << "solveOptimization: no device handle" << std::endl; return false; }
@@ -414,7 +473,20 @@ class ObjectPoseGraphOptimizer {
     auto gather = [](const std::vector<double*>& ptrs, int dim) { std::vector<double> v(ptrs.size() * dim); for (size_t i = 0; i < ptrs.size(); ++i) std::copy_n(ptrs[i], dim, &v[dim * i]); return v; };
     std::vector<double> poses = gather(fp.pose_ptrs, 6), points = gather(fp.point_ptrs, 3), objects = gather(fp.object_ptrs, 7);
     const auto t_upload = std::chrono::steady_clock::now();
-    int rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
+    int rc = 0;
+    if (phase_two_masks != nullptr) {
+      // phase II on the problem phase I left on the device: the values go back to the snapshot taken behind phase I's upload (the
+      // host side was restored by the caller, :811), the excluded factors are masked; no flattening, no upload, and the library
+      // keeps its symbolic plan (the masks select a subset of what it was built for)
+      rc = obvi_ba_restore(h);
+      if (!rc) rc = obvi_ba_set_active_mask(h, OBVI_FACTOR_REPROJECTION, phase_two_masks->rp.data());
+      if (!rc) rc = obvi_ba_set_active_mask(h, OBVI_FACTOR_BBOX, phase_two_masks->bb.data());
+      if (!rc) rc = obvi_ba_set_active_mask(h, OBVI_FACTOR_SHAPE_PRIOR, phase_two_masks->sp.data());
+      if (!rc) rc = obvi_ba_set_active_mask(h, OBVI_FACTOR_LTM_PRIOR, phase_two_masks->lt.data());
+      if (rc) { std::cerr << "obvi_ba phase-II masks failed: " << obvi_ba_last_error(h) << std::endl; return false; }
+    }
+    if (phase_two_masks == nullptr) {
+    rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
     if (!rc) rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
     if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
     if (!rc) rc = obvi_ba_set_objects(h, (int64_t)fp.objects.size(), objects.data(), fp.object_const.data());
@@ -426,7 +498,8 @@ class ObjectPoseGraphOptimizer {
     if (!rc) rc = obvi_ba_set_ltm_priors(h, (int64_t)fp.lt_obj.size(), fp.lt_obj.data(), fp.lt_mean.data(), fp.lt_cov.data(), rp.long_term_map_params_.pair_huber_loss_param_);
     if (!rc) rc = obvi_ba_set_relpose(h, (int64_t)fp.rl_a.size(), fp.rl_a.data(), fp.rl_b.data(), fp.rl_t.data(), fp.rl_aa.data(), fp.rl_cov.data(), fp.rl_huber);
     if (rc) { std::cerr << "obvi_ba upload failed: " << obvi_ba_last_error(h) << std::endl; return false; }
-
+    if (residual_ptrs != nullptr && obvi_ba_snapshot(h)) return false;   // phase I of a two-phase optimisation: phase II starts from these values
+    }
     obvi_solver_params p{solver_params.max_num_iterations_, solver_params.allow_non_monotonic_steps_ ? 1 : 0, solver_params.function_tolerance_,
                          solver_params.gradient_tolerance_, solver_params.parameter_tolerance_, solver_params.initial_trust_region_radius_,
                          solver_params.max_trust_region_radius_};

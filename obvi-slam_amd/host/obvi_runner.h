@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <functional>
+#include <memory>
 
 #include "obvi_optimizer.h"
 
@@ -137,7 +138,11 @@ class OfflineProblemRunner {
   const std::vector<OptimizationRecord>& records() const { return records_; }
   void printTiming(std::ostream& os) const {
     optimizer_.printTiming(os);
-    if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call" << std::endl;
+    if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call; phase II on the phase-I problem (masks) x"
+                          << n_phase_two_masked_ << ", rebuilt x" << n_phase_two_rebuilt_ << std::endl;
+    if (check_.windows) os << "phase2_check windows " << check_.windows << " failures " << check_.failures << " iteration_mismatches " << check_.iteration_mismatches << " size_mismatches "
+                           << check_.size_mismatches << " max_initial_cost_rel " << check_.max_initial_cost_rel << " max_final_cost_rel " << check_.max_final_cost_rel << " max_value_diff "
+                           << check_.max_value_diff << " points " << check_.points << " points_apart " << check_.points_apart << " objects " << check_.objects << " objects_apart " << check_.objects_apart << std::endl;
   }
   struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
   void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
@@ -257,8 +262,58 @@ class OfflineProblemRunner {
     if (two_phase) {                                                                                                         // PHASE II :803-892
       if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, true, attempt_num);
       restoreValues(pose_graph_copy);                                                            // :811
-      optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger, excluded);
-      if (!optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger)) {
+      // :812-:830 rebuild the problem with the excluded factors.  The same selection is made on the problem phase I left on the device
+      // whenever the rebuild would only remove things (OBVI_HOST_PHASE2_REBUILD=1: always rebuild, as the reference does)
+      static const bool always_rebuild = std::getenv("OBVI_HOST_PHASE2_REBUILD") && std::atoi(std::getenv("OBVI_HOST_PHASE2_REBUILD")) != 0;
+      pose_graph_optimizer::ObjectPoseGraphOptimizer::PhaseTwoMasks masks;
+      bool ok2;
+      if (!always_rebuild && optimizer_.excludeFromBuiltProblem(scope, pose_graph, excluded, problem, &masks)) {
+        optimizer_.setPhaseTwoLogCounts(masks, opt_logger);
+        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger, nullptr, nullptr, nullptr, &masks);
+        ++n_phase_two_masked_;
+        // OBVI_HOST_PHASE2_CHECK=1 (tests): the same phase II the reference's way -- rebuild with the excluded set, upload, solve -- on a
+        // scratch handle from the same start values, window by window; the session goes on with the masked result
+        static const bool check = std::getenv("OBVI_HOST_PHASE2_CHECK") && std::atoi(std::getenv("OBVI_HOST_PHASE2_CHECK")) != 0;
+        if (check && ok2) {
+          const obvi::SolverSummary fast = optimizer_.lastSummary();
+          const ValueSnapshot fast_values = snapshotValues(problem.flat);
+          restoreValues(pose_graph_copy);
+          if (!check_problem_) check_problem_ = std::make_unique<obvi::Problem>(device_id_);
+          pose_graph_optimizer::ObjectPoseGraphOptimizer ref_optimizer;
+          std::optional<OptimizationLogger> null_logger;
+          ref_optimizer.buildPoseGraphOptimization(scope, residual_params_, pose_graph, check_problem_.get(), null_logger, excluded);
+          const bool ok_ref = ref_optimizer.solveOptimization(check_problem_.get(), iteration_params.phase_two_opt_params_, null_logger);
+          const obvi::SolverSummary& ref = ref_optimizer.lastSummary();
+          check_.windows++;
+          if (!ok_ref) check_.failures++;
+          check_.max_initial_cost_rel = std::max(check_.max_initial_cost_rel, std::fabs(fast.initial_cost - ref.initial_cost) / std::max(1e-300, std::fabs(ref.initial_cost)));
+          check_.max_final_cost_rel = std::max(check_.max_final_cost_rel, std::fabs(fast.final_cost - ref.final_cost) / std::max(1e-300, std::fabs(ref.final_cost)));
+          if (fast.iterations.size() != ref.iterations.size()) check_.iteration_mismatches++;
+          if (fast.num_parameters_reduced != ref.num_parameters_reduced || fast.num_residuals_reduced != ref.num_residuals_reduced) check_.size_mismatches++;
+          // rebuilt-problem values vs the masked run's values of the same blocks
+          const ValueSnapshot ref_values = snapshotValues(check_problem_->flat);
+          std::unordered_map<const double*, const double*> fast_of;
+          const int dim[3] = {6, 3, 7};
+          for (int k = 0; k < 3; ++k) for (size_t i = 0; i < fast_values.ptrs[k].size(); ++i) fast_of[fast_values.ptrs[k][i]] = &fast_values.values[k][dim[k] * i];
+          for (int k = 0; k < 3; ++k)
+            for (size_t i = 0; i < ref_values.ptrs[k].size(); ++i) {
+              const auto it = fast_of.find(ref_values.ptrs[k][i]);
+              if (it == fast_of.end()) { check_.size_mismatches++; continue; }
+              double d = 0.0;
+              for (int c = 0; c < dim[k]; ++c) d = std::max(d, std::fabs(it->second[c] - ref_values.values[k][dim[k] * i + c]));
+              if (k == 0) check_.max_value_diff = std::max(check_.max_value_diff, d);   // poses
+              else if (k == 1) { check_.points++; if (d > 1e-2) check_.points_apart++; }   // features: a few are barely constrained in depth and amplify any flipped iteration
+              else { check_.objects++; if (d > 1e-2) check_.objects_apart++; }             // objects: one whose boxes are (nearly) all in the constant invalid-ellipse branch floats
+            }
+          restoreValues(pose_graph_copy);   // blocks the rebuilt problem does not hold keep their start values in both routes
+          restoreValues(fast_values);
+        }
+      } else {
+        optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger, excluded);
+        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger);
+        ++n_phase_two_rebuilt_;
+      }
+      if (!ok2) {
         std::cerr << "Phase II Optimization failed at max frame id " << next_frame_id << std::endl;
         return false;
       }
@@ -286,7 +341,9 @@ class OfflineProblemRunner {
   int device_id_;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
-  double time_build_ms_ = 0, time_copy_ms_ = 0; size_t n_iterations_ = 0;
+  double time_build_ms_ = 0, time_copy_ms_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
+  struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;
+  std::unique_ptr<obvi::Problem> check_problem_;
   bool extract_long_term_map_ = false;
   std::vector<LongTermMapEntry> long_term_map_;
 };

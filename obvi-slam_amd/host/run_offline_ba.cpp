@@ -1,7 +1,7 @@
 // run_offline_ba.cpp -- driver of the host-side mirror: the shape of the reference's
 // offline_object_visual_slam_main / run_opt_from_pg_state for a scene whose associations are given.
 //   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv] [--ltm]
-//   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K]   (no GPU: flattening only)
+//   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K] [--phase-two-masks]   (no GPU: flattening only)
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 // Parameter values: config/base7a_2_fallback.json of the reference.
 #include <cstdlib>
@@ -64,7 +64,7 @@ static pose_graph_optimization::OptimizationSolverParams sp(int it, double ftol)
 int main(int argc, char** argv) {
   if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options]" << std::endl; return 2; }
   SlidingWindowParams sw;
-  int device = 0; std::string csv; bool dump = false, ltm = false, pending = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  int device = 0; std::string csv; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
   for (int i = 3; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--pending-objects")) pending = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
   }
   OfflineProblemData data;
   if (!loadScene(argv[1], &data)) { std::cerr << "could not read scene " << argv[1] << std::endl; return 2; }
@@ -114,7 +115,12 @@ int main(int argc, char** argv) {
       FactorInfoSet all;
       pg->getVisualFeatureFactorIdsBetweenFrameIdsInclusive(dump_min, dump_max, all);
       for (const auto& fi : all) if (fi.second % excluded_every == 0) excluded.insert(fi);
+      FactorInfoSet boxes;
+      pg->getObservationFactorsBetweenFrameIdsInclusive(dump_min, dump_max, boxes);
+      for (const auto& fi : boxes) if (fi.second % excluded_every == 0) excluded.insert(fi);
     }
+    const FactorInfoSet excluded_for_masks = excluded;
+    if (masks_of_unexcluded_build) excluded.clear();
     obvi::Problem problem(0, /*dry_run=*/true);
     pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer;
     std::optional<OptimizationLogger> no_logger;
@@ -125,6 +131,23 @@ int main(int argc, char** argv) {
     arr("frames", fp.frames); arr("features", fp.features); arr("objects", fp.objects); arr("pose_const", fp.pose_const); arr("point_const", fp.point_const);
     arr("object_const", fp.object_const); arr("rp_pose", fp.rp_pose); arr("rp_point", fp.rp_point); arr("rp_pixel", fp.rp_pixel); arr("bb_obj", fp.bb_obj); arr("bb_pose", fp.bb_pose);
     arr("sp_obj", fp.sp_obj); arr("rl_a", fp.rl_a); arr("rl_b", fp.rl_b);
+    {   // factor ids of the residual blocks, family by family (blocks are ordered reprojection, bounding box, shape prior, LTM prior, relative pose)
+      std::vector<double> ids[5];
+      for (const auto& b : fp.blocks) {
+        const int fam = b.first == kReprojectionErrorFactorTypeId ? 0 : b.first == kObjectObservationFactorTypeId ? 1 : b.first == kShapeDimPriorFactorTypeId ? 2 : b.first == kLongTermMapFactorTypeId ? 3 : 4;
+        ids[fam].push_back((double)b.second);
+      }
+      arr("rp_id", ids[0]); arr("bb_id", ids[1]); arr("sp_id", ids[2]); arr("rl_id", ids[4]);
+    }
+    if (masks_of_unexcluded_build) {
+      // --phase-two-masks: the problem above was built WITHOUT the excluded set; these are the masks excludeFromBuiltProblem derives
+      // for it (what phase II applies on the device instead of rebuilding)
+      pose_graph_optimizer::ObjectPoseGraphOptimizer::PhaseTwoMasks m;
+      const bool ok = optimizer.excludeFromBuiltProblem(scope, pg, excluded_for_masks, problem, &m);
+      out << "\"masks_ok\": " << (ok ? 1 : 0) << ",\n";
+      arr("mask_rp", m.rp); arr("mask_bb", m.bb); arr("mask_sp", m.sp);
+      out << "\"mask_n_features\": " << m.n_features << ", \"mask_n_objects\": " << m.n_objects << ",\n";
+    }
     out << "\"num_blocks\": " << info.size() << ", \"num_excluded\": " << excluded.size() << "}\n";
     return 0;
   }
