@@ -412,11 +412,16 @@ class ObjectPoseGraphOptimizer {
   struct PhaseTwoMasks { std::vector<uint8_t> rp, bb, sp, lt; size_t n_features = 0, n_objects = 0; };
   template <class PoseGraphPtr>
   bool excludeFromBuiltProblem(const OptimizationScopeParams& scope, const PoseGraphPtr& pose_graph, const FactorInfoSet& excluded, const obvi::Problem& problem,
-                               PhaseTwoMasks* out) const {
+                               PhaseTwoMasks* out, const std::vector<uint8_t>* rp_keep = nullptr, const std::vector<uint8_t>* bb_keep = nullptr) const {
+    // rp_keep / bb_keep: the exclusion already as one byte per factor of the flat problem (obvi_ba_select_outliers), instead of the set
     const obvi::FlatProblem& fp = problem.flat;
     const size_t n_rp = fp.rp_pose.size(), n_bb = fp.bb_obj.size(), n_sp = fp.sp_obj.size(), n_lt = fp.lt_obj.size();
     if (fp.blocks.size() < n_rp + n_bb + n_sp + n_lt) return false;
-    auto is_excluded = [&](size_t block) { return excluded.count(fp.blocks[block]) != 0; };
+    auto is_excluded = [&](size_t block) {
+      if (block < n_rp && rp_keep != nullptr) return (*rp_keep)[block] == 0;
+      if (block >= n_rp && block < n_rp + n_bb && bb_keep != nullptr) return (*bb_keep)[block - n_rp] == 0;
+      return excluded.count(fp.blocks[block]) != 0;
+    };
     out->rp.assign(n_rp, 1); out->bb.assign(n_bb, 1); out->sp.assign(n_sp, 1); out->lt.assign(n_lt, 1);
     // visual factors
     std::vector<uint32_t> sightings(fp.features.size(), 0), per_frame_before(fp.frames.size(), 0), per_frame_after(fp.frames.size(), 0);
@@ -464,7 +469,7 @@ class ObjectPoseGraphOptimizer {
   bool solveOptimization(obvi::Problem* problem, const pose_graph_optimization::OptimizationSolverParams& solver_params,
                          std::optional<OptimizationLogger>& opt_logger, std::vector<obvi::ResidualBlockId>* residual_block_id_ptrs = nullptr,
                          std::vector<double>* residual_ptrs = nullptr, std::shared_ptr<obvi::SolverSummary> solver_summary = nullptr,
-                         const PhaseTwoMasks* phase_two_masks = nullptr) {
+                         const PhaseTwoMasks* phase_two_masks = nullptr, bool keep_for_phase_two = false) {
     if (problem == nullptr) return false;
     obvi_ba_handle* h = problem->handle();
     if (h == nullptr) { std::cerr << "solveOptimization: no device handle" << std::endl; return false; }
@@ -498,7 +503,7 @@ class ObjectPoseGraphOptimizer {
     if (!rc) rc = obvi_ba_set_ltm_priors(h, (int64_t)fp.lt_obj.size(), fp.lt_obj.data(), fp.lt_mean.data(), fp.lt_cov.data(), rp.long_term_map_params_.pair_huber_loss_param_);
     if (!rc) rc = obvi_ba_set_relpose(h, (int64_t)fp.rl_a.size(), fp.rl_a.data(), fp.rl_b.data(), fp.rl_t.data(), fp.rl_aa.data(), fp.rl_cov.data(), fp.rl_huber);
     if (rc) { std::cerr << "obvi_ba upload failed: " << obvi_ba_last_error(h) << std::endl; return false; }
-    if (residual_ptrs != nullptr && obvi_ba_snapshot(h)) return false;   // phase I of a two-phase optimisation: phase II starts from these values
+    if ((residual_ptrs != nullptr || keep_for_phase_two) && obvi_ba_snapshot(h)) return false;   // phase I of a two-phase optimisation: phase II starts from these values
     }
     obvi_solver_params p{solver_params.max_num_iterations_, solver_params.allow_non_monotonic_steps_ ? 1 : 0, solver_params.function_tolerance_,
                          solver_params.gradient_tolerance_, solver_params.parameter_tolerance_, solver_params.initial_trust_region_radius_,

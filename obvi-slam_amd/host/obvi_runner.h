@@ -111,7 +111,9 @@ class OfflineProblemRunner {
     for (FrameId next_frame_id = first_frame; next_frame_id <= max_frame_id; ++next_frame_id) {                               // :174-226
       const FrameId start_opt_with_frame = window_provider_func_(next_frame_id);
       scope.min_frame_id_ = start_opt_with_frame; scope.max_frame_id_ = next_frame_id;
+      const auto t_add0 = std::chrono::steady_clock::now();
       if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_);
+      time_add_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_add0).count();
       if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
     }
     if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
@@ -140,6 +142,7 @@ class OfflineProblemRunner {
     optimizer_.printTiming(os);
     if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call; phase II on the phase-I problem (masks) x"
                           << n_phase_two_masked_ << ", rebuilt x" << n_phase_two_rebuilt_ << std::endl;
+    if (n_iterations_) os << "frame data adder " << time_add_ms_ / n_iterations_ << " ms, outlier selection on the host " << time_select_ms_ / n_iterations_ << " ms per frame" << std::endl;
     if (check_.windows) os << "phase2_check windows " << check_.windows << " failures " << check_.failures << " iteration_mismatches " << check_.iteration_mismatches << " size_mismatches "
                            << check_.size_mismatches << " max_initial_cost_rel " << check_.max_initial_cost_rel << " max_final_cost_rel " << check_.max_final_cost_rel << " max_value_diff "
                            << check_.max_value_diff << " points " << check_.points << " points_apart " << check_.points_apart << " objects " << check_.objects << " objects_apart " << check_.objects_apart << std::endl;
@@ -224,14 +227,40 @@ class OfflineProblemRunner {
     time_build_ms_ += std::chrono::duration<double, std::milli>(t_b1 - t_b0).count(); time_copy_ms_ += std::chrono::duration<double, std::milli>(t_b2 - t_b1).count(); ++n_iterations_;
     std::vector<obvi::ResidualBlockId> residual_block_ids;
     std::vector<double> residuals;
-    const bool ok1 = two_phase ? optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, &residual_block_ids, &residuals)
-                               : optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger);
+    // :689-800 read every residual back, square-sum them per block and pick the top fraction per factor type through a std::map keyed
+    // by the value.  obvi_ba_select_outliers makes the same selection on the device (K8; same de-duplication of equal values,
+    // tests/test_gpu_parity.py::test_two_phase_outlier_rejection) and hands back one byte per factor instead of every residual.
+    // OBVI_HOST_SELECT_ON_HOST=1: the literal host route.
+    static const bool select_on_host = std::getenv("OBVI_HOST_SELECT_ON_HOST") && std::atoi(std::getenv("OBVI_HOST_SELECT_ON_HOST")) != 0;
+    const bool device_selection = two_phase && !select_on_host;
+    const bool ok1 = (two_phase && !device_selection) ? optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, &residual_block_ids, &residuals)
+                                                      : optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, nullptr, nullptr, nullptr, nullptr, /*keep_for_phase_two=*/two_phase);
     if (!ok1) { std::cerr << "Phase I Optimization failed at max frame id " << next_frame_id << std::endl; return false; }
     if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
     record(kind + "_phase_1", scope.min_frame_id_, next_frame_id, problem, 0);
+    const auto t_sel0 = std::chrono::steady_clock::now();
+    FactorInfoSet excluded;                       // the literal route's set; with the device selection it is only materialised when the rebuild needs it
+    std::vector<uint8_t> keep_rp, keep_bb;        // device selection: one byte per factor of the flat problem
+    size_t n_excluded_device = 0;
+    auto materialise_excluded = [&]() {
+      const obvi::FlatProblem& fp = problem.flat;
+      for (size_t i = 0; i < keep_rp.size(); ++i) if (!keep_rp[i]) excluded.insert(fp.blocks[i]);
+      for (size_t i = 0; i < keep_bb.size(); ++i) if (!keep_bb[i]) excluded.insert(fp.blocks[keep_rp.size() + i]);
+    };
+    if (device_selection) {
+      const obvi::FlatProblem& fp = problem.flat;
+      keep_rp.assign(fp.rp_pose.size(), 1); keep_bb.assign(fp.bb_obj.size(), 1);
+      const struct { int32_t type; std::vector<uint8_t>* keep; } fams[2] = {{OBVI_FACTOR_REPROJECTION, &keep_rp}, {OBVI_FACTOR_BBOX, &keep_bb}};
+      for (const auto& fam : fams) {
+        if (fam.keep->empty()) continue;
+        int64_t n_out = 0;
+        if (obvi_ba_select_outliers(problem.handle(), fam.type, iteration_params.feature_outlier_percentage_, fam.keep->data(), &n_out)) { std::cerr << "outlier selection failed: " << obvi_ba_last_error(problem.handle()) << std::endl; return false; }
+        n_excluded_device += (size_t)n_out;
+      }
+    }
     // per-block squared residuals with the hard-coded block sizes (:689-749)
     std::map<FactorType, std::vector<std::pair<double, obvi::ResidualBlockId>>> by_type;
-    if (two_phase) {
+    if (two_phase && !device_selection) {
       size_t idx = 0;
       for (obvi::ResidualBlockId id : residual_block_ids) {
         const FactorType t = id < problem.flat.blocks.size() ? problem.flat.blocks[id].first : block_info.at(id).first;   // block ids index the flat problem's block list
@@ -245,8 +274,7 @@ class OfflineProblemRunner {
       }
       if (idx != residuals.size()) two_phase = false;
     }
-    FactorInfoSet excluded;
-    if (two_phase) {                                                                                                         // :769-800
+    if (two_phase && !device_selection) {                                                                                    // :769-800
       for (auto& tv : by_type) {
         // the reference fills a std::map<double, id, greater> (:769-800): descending by value, equal values collapse into one entry
         // that keeps the id inserted last.  Same list from a stable sort.
@@ -259,6 +287,7 @@ class OfflineProblemRunner {
         for (size_t i = 0; i < n_outliers; ++i) excluded.insert(ordered[i] < problem.flat.blocks.size() ? problem.flat.blocks[ordered[i]] : block_info.at(ordered[i]));
       }
     }
+    time_select_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sel0).count();
     if (two_phase) {                                                                                                         // PHASE II :803-892
       if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, true, attempt_num);
       restoreValues(pose_graph_copy);                                                            // :811
@@ -267,7 +296,10 @@ class OfflineProblemRunner {
       static const bool always_rebuild = std::getenv("OBVI_HOST_PHASE2_REBUILD") && std::atoi(std::getenv("OBVI_HOST_PHASE2_REBUILD")) != 0;
       pose_graph_optimizer::ObjectPoseGraphOptimizer::PhaseTwoMasks masks;
       bool ok2;
-      if (!always_rebuild && optimizer_.excludeFromBuiltProblem(scope, pose_graph, excluded, problem, &masks)) {
+      const bool have_masks = !always_rebuild && optimizer_.excludeFromBuiltProblem(scope, pose_graph, excluded, problem, &masks, device_selection ? &keep_rp : nullptr, device_selection ? &keep_bb : nullptr);
+      static const bool check_rebuild = std::getenv("OBVI_HOST_PHASE2_CHECK") && std::atoi(std::getenv("OBVI_HOST_PHASE2_CHECK")) != 0;
+      if (device_selection && (!have_masks || check_rebuild)) materialise_excluded();
+      if (have_masks) {
         optimizer_.setPhaseTwoLogCounts(masks, opt_logger);
         ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger, nullptr, nullptr, nullptr, &masks);
         ++n_phase_two_masked_;
@@ -322,7 +354,7 @@ class OfflineProblemRunner {
         return false;
       }
       if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
-      record(kind + "_phase_2", scope.min_frame_id_, next_frame_id, problem, excluded.size());
+      record(kind + "_phase_2", scope.min_frame_id_, next_frame_id, problem, device_selection ? n_excluded_device : excluded.size());
     }
     if (iteration_params.allow_reversion_after_detecting_jumps_ &&                                                           // :895-905
         !isConsecutivePosesStable_(pose_graph, scope.min_frame_id_, scope.max_frame_id_, iteration_params.consecutive_pose_transl_tol_, iteration_params.consecutive_pose_orient_tol_)) {
@@ -345,7 +377,7 @@ class OfflineProblemRunner {
   int device_id_;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
-  double time_build_ms_ = 0, time_copy_ms_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
+  double time_build_ms_ = 0, time_copy_ms_ = 0, time_add_ms_ = 0, time_select_ms_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
   struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;
   std::unique_ptr<obvi::Problem> check_problem_;
   bool extract_long_term_map_ = false;

@@ -4,6 +4,7 @@
 //   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K] [--phase-two-masks]   (no GPU: flattening only)
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 // Parameter values: config/base7a_2_fallback.json of the reference.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -76,6 +77,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
   }
+  const auto t_main0 = std::chrono::steady_clock::now();
   OfflineProblemData data;
   if (!loadScene(argv[1], &data)) { std::cerr << "could not read scene " << argv[1] << std::endl; return 2; }
   const FrameId max_frame_id = data.getMaxFrameId();
@@ -191,8 +193,14 @@ int main(int argc, char** argv) {
   if (!csv.empty()) logger.emplace(csv);
   MainPgPtr pg;
   runner.setExtractLongTermMap(ltm);
+  const auto t_run0 = std::chrono::steady_clock::now();
   const bool ok = runner.runOptimization(data, en, logger, pg);
-  if (std::getenv("OBVI_HOST_TIMING")) runner.printTiming(std::cerr);
+  const auto t_run1 = std::chrono::steady_clock::now();
+  if (std::getenv("OBVI_HOST_TIMING")) {
+    runner.printTiming(std::cerr);
+    std::cerr << "driver: scene load + setup " << std::chrono::duration<double, std::milli>(t_run0 - t_main0).count() << " ms, runOptimization "
+              << std::chrono::duration<double, std::milli>(t_run1 - t_run0).count() << " ms" << std::endl;
+  }
   out << "{\"ok\": " << (ok ? "true" : "false") << ", \"records\": [";
   bool first = true;
   for (const auto& r : runner.records()) {
