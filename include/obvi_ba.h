@@ -217,6 +217,19 @@ int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t factor_type, double fract
 int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_t* obj_a, const uint32_t* obj_b,
                                double* cov49 /*[n_pairs][49]*/);
 
+/* ParameterPrior (include/refactoring/factors/parameter_prior.h:17-50): residual (block[param_idx] - mean) / std_dev, no loss
+ * function.  The reference adds such factors in one place only -- to the problem the long-term-map covariance is extracted from,
+ * for parameters whose Jacobian columns are numerically zero, with mean = the current estimate
+ * (src/refactoring/long_term_map/long_term_object_map_extraction.cpp:764-927).  Accordingly they take part in
+ * obvi_ba_object_covariances and obvi_ba_column_sqnorms (their Jacobian 1 / std_dev in the parameter's column; the residual is zero
+ * at the mean) and NOT in obvi_ba_solve / obvi_ba_evaluate.  block_kind: 0 pose, 1 point, 2 object.  n = 0 clears them. */
+int obvi_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* block_kind, const uint32_t* block_idx,
+                                 const uint8_t* param_idx, const double* mean, const double* std_dev);
+/* Squared column norms of the robustified Jacobian at the current estimate, one per scalar parameter (what findRankDeficiencies
+ * accumulates from the CRS Jacobian, long_term_object_map_extraction.cpp:585-608; parameter priors included); -1 for the parameters
+ * of a block that is constant or touched by no active factor.  Any output may be NULL. */
+int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6 /*[P][6]*/, double* point3 /*[L][3]*/, double* object7 /*[O][7]*/);
+
 /* ---- state ------------------------------------------------------------------------- */
 int obvi_ba_snapshot(obvi_ba_handle* h);
 int obvi_ba_restore(obvi_ba_handle* h);

@@ -99,6 +99,7 @@ struct ReducedDev {         // accumulators of the reduced system
   double* rhs;              // [m_pad] right-hand side -> forward-substituted z
   double* y;                // [m_pad] solution
   int32_t nt;               // tiles per dimension
+  const double* extra;      // NULL, or (same compact index as g) an addition to the diagonal of the normal equations: parameter priors of the covariance extraction
 };
 
 struct PointDev {           // per eliminated point
@@ -108,6 +109,7 @@ struct PointDev {           // per eliminated point
   double* lam;              // [L][3]  LM damping of the point block (unscaled normal equations)
   double* scale;            // [L][3]  Jacobi scaling
   double* Z;                // [N_r][18] 6x3 row-major:  rho' Jp^T Jl Ci^T
+  const double* extra;      // NULL, or [L][3] addition to the diagonal of H_ll (parameter priors of the covariance extraction)
 };
 
 // ---- launchers (ba_kernels.hip) --------------------------------------------------------

@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
       } else {
         s0 = pt.scale[3 * l]; s1 = pt.scale[3 * l + 1]; s2 = pt.scale[3 * l + 2];
       }
-      const double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      if (pt.extra) { lam0 += pt.extra[3 * l]; lam1 += pt.extra[3 * l + 1]; lam2 += pt.extra[3 * l + 2]; }
       const double a00 = h00 + lam0, a11 = h11 + lam1, a22 = h22 + lam2;
       pt.gl[3 * l] = g0; pt.gl[3 * l + 1] = g1; pt.gl[3 * l + 2] = g2; pt.lam[3 * l] = lam0; pt.lam[3 * l + 1] = lam1; pt.lam[3 * l + 2] = lam2;
       // 3x3 Cholesky A = C C^T and Ci = C^-1
@@ -293,7 +294,8 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
       double s0, s1, s2;
       if (first_iter) { s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); s2 = 1.0 / (1.0 + sqrt(h22)); }
       else { s0 = pt.scale[3 * (int64_t)l]; s1 = pt.scale[3 * (int64_t)l + 1]; s2 = pt.scale[3 * (int64_t)l + 2]; }
-      const double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      double lam0 = lm_lambda(h00, s0, radius), lam1 = lm_lambda(h11, s1, radius), lam2 = lm_lambda(h22, s2, radius);
+      if (pt.extra) { lam0 += pt.extra[3 * (int64_t)l]; lam1 += pt.extra[3 * (int64_t)l + 1]; lam2 += pt.extra[3 * (int64_t)l + 2]; }
       const double a00 = h00 + lam0, a11 = h11 + lam1, a22 = h22 + lam2;
       // 3x3 Cholesky A = C C^T and Ci = C^-1, division-free: i_kk = rsqrt(pivot)
       const double i00 = rsqrt_f64(a00), c10 = h10 * i00, c20 = h20 * i00;
@@ -830,7 +832,7 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
       const double c = Hd[d * k + k];
       double s;
       if (first_iter) { s = 1.0 / (1.0 + sqrt(c)); rd.scale[crow + k] = s; } else { s = rd.scale[crow + k]; }
-      const double lam = lm_lambda(c, s, radius);
+      const double lam = lm_lambda(c, s, radius) + (rd.extra ? rd.extra[crow + k] : 0.0);
       rd.lam[crow + k] = lam;
       if (contribute) {
         // atomics: the Schur complement kernels subtract from the same tiles and right-hand side, possibly at the same time (side stream)

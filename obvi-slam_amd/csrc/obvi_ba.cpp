@@ -144,6 +144,10 @@ struct obvi_ba_handle {
   int64_t n_trsm_jobs = 0, n_upd_products = 0;
   double chol_flops = 0.0;
 
+  // ---- parameter priors (covariance extraction only) ----
+  std::vector<uint8_t> h_pp_kind, h_pp_param; std::vector<uint32_t> h_pp_block; std::vector<double> h_pp_mean, h_pp_std;
+  DevBuf<double> d_extra_c, d_extra_l;
+  bool use_extra = false;                // the next submit_step adds d_extra_c / d_extra_l to the diagonal (obvi_ba_object_covariances)
   // ---- last solve ----
   std::vector<obvi_iteration_summary> iterations;
   obvi_allreduce_fn allreduce = nullptr;
@@ -246,11 +250,13 @@ ReducedDev reduced_dev(const obvi_ba_handle* h) {
   ReducedDev r;
   r.Hdiag = h->d_Hdiag.get(); r.g = h->d_g.get(); r.scale = h->d_scale.get(); r.lam = h->d_lam.get();
   r.S = h->d_S.get(); r.rhs = h->d_rhs.get(); r.y = h->d_y.get(); r.nt = h->nt;
+  r.extra = h->use_extra ? h->d_extra_c.get() : nullptr;
   return r;
 }
 PointDev point_dev(const obvi_ba_handle* h) {
   PointDev p;
   p.Ci = h->d_Ci.get(); p.u = h->d_u.get(); p.scale = h->d_scale_l.get(); p.Z = h->d_Z.get(); p.gl = h->d_gl.get(); p.lam = h->d_lam_l.get();
+  p.extra = h->use_extra ? h->d_extra_l.get() : nullptr;
   return p;
 }
 CholPlan chol_plan(const obvi_ba_handle* h) {
@@ -306,6 +312,10 @@ int validate_indices(obvi_ba_handle* h) {
   if (h->n_sp > 0 && h->max_sp_obj >= h->O) return bad("shape priors");
   if (h->n_lt > 0 && h->max_lt_obj >= h->O) return bad("long-term-map priors");
   if (h->n_rl > 0 && h->max_rl_pose >= h->P) return bad("relative-pose factors");
+  for (size_t i = 0; i < h->h_pp_kind.size(); ++i) {
+    const int64_t cnt = h->h_pp_kind[i] == 0 ? h->P : h->h_pp_kind[i] == 1 ? h->L : h->O;
+    if ((int64_t)h->h_pp_block[i] >= cnt) return bad("parameter priors");
+  }
   if (!h->h_is_shared.empty() && (int64_t)h->h_is_shared.size() != h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_shared_objects: flags were given for another object count");
   if ((int64_t)h->h_pose_const.size() != h->P || (int64_t)h->h_point_const.size() != h->L || (int64_t)h->h_object_const.size() != h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "constness flags do not match the block counts");
   return OBVI_OK;
@@ -1250,6 +1260,25 @@ bool check_ready(obvi_ba_handle* h) {
   return true;
 }
 
+// 1 / std_dev^2 of every parameter prior at its parameter's place: compact reduced index for poses / objects, [L][3] for points
+void upload_parameter_prior_diagonals(obvi_ba_handle* h) {
+  if (h->h_pp_kind.empty()) return;
+  std::vector<double> ec((size_t)h->m_canon + 1, 0.0), el((size_t)3 * h->L + 1, 0.0);
+  std::vector<int32_t> pose_vid((size_t)h->P + 1), obj_vid((size_t)h->O + 1);
+  if (h->P) h->d_pose_vid.download(pose_vid.data(), (size_t)h->P, h->stream);
+  if (h->O) h->d_obj_vid.download(obj_vid.data(), (size_t)h->O, h->stream);
+  sync(h);
+  for (size_t i = 0; i < h->h_pp_kind.size(); ++i) {
+    const double w = 1.0 / (h->h_pp_std[i] * h->h_pp_std[i]);
+    const int64_t b = h->h_pp_block[i];
+    if (h->h_pp_kind[i] == 0) { if (pose_vid[b] >= 0) ec[6 * (int64_t)pose_vid[b] + h->h_pp_param[i]] += w; }
+    else if (h->h_pp_kind[i] == 1) el[3 * b + h->h_pp_param[i]] += w;
+    else if (obj_vid[b] >= 0) ec[6 * h->nPv + 7 * (int64_t)obj_vid[b] + h->h_pp_param[i]] += w;
+  }
+  h->d_extra_c.upload(ec, h->stream); h->d_extra_l.upload(el, h->stream);
+  sync(h);
+}
+
 template <class T>
 void set_mask(std::vector<uint8_t>& host, DevBuf<uint8_t>& dev, const uint8_t* mask, int64_t n, hipStream_t s, const T* perm_sorted_to_orig) {
   host.resize(n);
@@ -1696,7 +1725,8 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
     explicit QuietStep(obvi_ba_handle* hh) : h(hh), profiling(hh->profiling) { h->profiling = 0; h->pc_valid = false; h->tiles_cleared = false; }
     ~QuietStep() { h->profiling = profiling; h->pc_valid = false; h->tiles_cleared = false; }
   };
-  { QuietStep quiet(h); submit_step(h, 1e300, true, true, /*keep_factor=*/true); }
+  upload_parameter_prior_diagonals(h);
+  { QuietStep quiet(h); h->use_extra = !h->h_pp_kind.empty(); try { submit_step(h, 1e300, true, true, /*keep_factor=*/true); } catch (...) { h->use_extra = false; throw; } h->use_extra = false; }
   if (h->h_scal[SC_CHOL_FAIL] != 0.0 || h->h_scal[SC_NONFINITE] != 0.0 || !std::isfinite(h->h_scal[SC_STEPSQ]))
     return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: the normal equations are rank deficient at the current estimate");
   hipStream_t s = h->stream;
@@ -1724,6 +1754,59 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   h->d_cov_out.download(cov49, (size_t)(49 * n_pairs), s);
   sync(h);
   for (int64_t i = 0; i < 49 * n_pairs; ++i) if (!std::isfinite(cov49[i])) return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: non-finite covariance");
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* kind, const uint32_t* block, const uint8_t* param, const double* mean, const double* std_dev) {
+  if (!h || n < 0 || (n > 0 && (!kind || !block || !param || !mean || !std_dev))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_parameter_priors: bad arguments");
+  OBVI_API_BEGIN
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t cnt = kind[i] == 0 ? h->P : kind[i] == 1 ? h->L : kind[i] == 2 ? h->O : -1;
+    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : 7;
+    if (cnt < 0 || param[i] >= dim) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_parameter_priors: unknown block kind or parameter index");
+    if ((int64_t)block[i] >= cnt) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_parameter_priors: index out of range");
+    if (!(std_dev[i] > 0.0) || !std::isfinite(std_dev[i]) || !std::isfinite(mean[i])) return fail(h, OBVI_ERR_NUMERICAL, "set_parameter_priors: standard deviation must be positive and finite");
+  }
+  h->h_pp_kind.assign(kind, kind + n); h->h_pp_block.assign(block, block + n); h->h_pp_param.assign(param, param + n);
+  h->h_pp_mean.assign(mean, mean + n); h->h_pp_std.assign(std_dev, std_dev + n);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6, double* point3, double* object7) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "column_sqnorms: cameras not set");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
+  prepare(h);
+  // one linearisation as at iteration 0: the Jacobi scale it stores is s = 1 / (1 + sqrt(c)), c the squared column norm
+  {
+    struct Quiet { obvi_ba_handle* h; int profiling; explicit Quiet(obvi_ba_handle* hh) : h(hh), profiling(hh->profiling) { h->profiling = 0; h->pc_valid = false; h->tiles_cleared = false; }
+                   ~Quiet() { h->profiling = profiling; h->pc_valid = false; h->tiles_cleared = false; } } quiet(h);
+    if (h->num_params > 0) submit_step(h, 1e300, true, false);
+  }
+  std::vector<double> sc((size_t)h->m_canon + 1), sl((size_t)3 * h->L + 1);
+  std::vector<int32_t> pose_vid((size_t)h->P + 1), obj_vid((size_t)h->O + 1);
+  std::vector<uint8_t> point_var((size_t)h->L + 1);
+  hipStream_t s = h->stream;
+  if (h->m_canon) h->d_scale.download(sc.data(), (size_t)h->m_canon, s);
+  if (h->L) { h->d_scale_l.download(sl.data(), (size_t)3 * h->L, s); h->d_point_var.download(point_var.data(), (size_t)h->L, s); }
+  if (h->P) h->d_pose_vid.download(pose_vid.data(), (size_t)h->P, s);
+  if (h->O) h->d_obj_vid.download(obj_vid.data(), (size_t)h->O, s);
+  sync(h);
+  auto colsq = [](double scale) { const double r = 1.0 / scale - 1.0; return r * r; };
+  if (pose6) for (int64_t p = 0; p < h->P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = pose_vid[p] >= 0 ? colsq(sc[6 * (int64_t)pose_vid[p] + k]) : -1.0;
+  if (point3) for (int64_t l = 0; l < h->L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = point_var[l] ? colsq(sl[3 * l + k]) : -1.0;
+  if (object7) for (int64_t o = 0; o < h->O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = obj_vid[o] >= 0 ? colsq(sc[6 * h->nPv + 7 * (int64_t)obj_vid[o] + k]) : -1.0;
+  for (size_t i = 0; i < h->h_pp_kind.size(); ++i) {
+    const double w = 1.0 / (h->h_pp_std[i] * h->h_pp_std[i]);
+    const int64_t b = h->h_pp_block[i];
+    if (h->h_pp_kind[i] == 0 && pose6 && pose_vid[b] >= 0) pose6[6 * b + h->h_pp_param[i]] += w;
+    else if (h->h_pp_kind[i] == 1 && point3 && point_var[b]) point3[3 * b + h->h_pp_param[i]] += w;
+    else if (h->h_pp_kind[i] == 2 && object7 && obj_vid[b] >= 0) object7[7 * b + h->h_pp_param[i]] += w;
+  }
   return OBVI_OK;
   OBVI_API_END(h)
 }

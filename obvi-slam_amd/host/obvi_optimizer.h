@@ -139,11 +139,141 @@ class Covariance {
   std::map<std::pair<vslam_types_refactor::ObjectId, vslam_types_refactor::ObjectId>, std::vector<double>> blocks_;
 };
 
+
+// ---- covariance extraction with rank-deficiency handling (long_term_object_map_extraction.cpp:507-760, 764-927, 929-1062) --------
+// When Covariance::Compute fails (rank-deficient Jacobian), the reference finds the Jacobian columns with the smallest squared
+// norms -- (rank deficiency + kRankDeficiencyColsBuffer) of them -- and gives each of those parameters a ParameterPrior
+// (parameter_prior.h:17-50) centred on its current estimate with std_dev = 1 / sqrt(n* - n_col), n* the smallest norm NOT selected:
+// every selected column is lifted to n*.  Then it retries, up to kMaxJacobianExtractionRetries times.
+struct CovarianceRankRepair { int block_kind; uint64_t block_id; int param_idx; double col_sqnorm, prior_std_dev; int retry; };   // kind 0 frame, 1 feature, 2 object
+constexpr int kMaxJacobianExtractionRetries = 5, kRankDeficiencyColsBuffer = 50;   // long_term_object_map_extraction.h:20-21
+// findRankDeficiencies (:610-660) + the prior parameters of addPriorToProblemParams (:764-927) on the column norms as the device
+// reports them (obvi_ba_column_sqnorms; -1 = not a parameter of the problem).  The reference takes the rank deficiency from a sparse
+// QR of the Jacobian; here it is the number of columns below min_col_norm (at least one): with the buffer of 50 the selection is
+// dominated by the buffer either way.  Pure function: CPU-testable.
+struct ColumnNormView { const std::vector<double>* sqnorms; int block_dim; int block_kind; const std::vector<uint64_t>* ids; };
+inline std::vector<CovarianceRankRepair> selectParameterPriors(const std::vector<ColumnNormView>& views, double min_col_norm, int retry, double* min_non_prob_col_norm_out = nullptr) {
+  struct Col { double n; int view; size_t block; int param; };
+  std::vector<Col> cols;
+  for (size_t v = 0; v < views.size(); ++v)
+    for (size_t i = 0; i < views[v].sqnorms->size(); ++i) {
+      const double n = (*views[v].sqnorms)[i];
+      if (n >= 0.0) cols.push_back({n, (int)v, i / views[v].block_dim, (int)(i % views[v].block_dim)});
+    }
+  std::vector<CovarianceRankRepair> out;
+  if (cols.empty()) return out;
+  size_t rank_deficiency = 0;
+  for (const Col& c : cols) if (c.n < min_col_norm) ++rank_deficiency;
+  rank_deficiency = std::max<size_t>(rank_deficiency, 1);
+  const size_t count = std::min(rank_deficiency + (size_t)kRankDeficiencyColsBuffer + 1, cols.size());   // :623-624
+  std::partial_sort(cols.begin(), cols.begin() + count, cols.end(), [](const Col& a, const Col& b) { return a.n < b.n; });
+  const double min_non_prob = cols[count - 1].n;                                                           // smallest_n.back() :656
+  if (min_non_prob_col_norm_out) *min_non_prob_col_norm_out = min_non_prob;
+  for (size_t k = 0; k + 1 < count; ++k) {
+    const Col& c = cols[k];
+    const double gap = min_non_prob - c.n;
+    if (!(gap > 0.0)) continue;   // equal to the first non-problem column: 1 / sqrt(0) in the reference; nothing to lift
+    out.push_back({views[c.view].block_kind, (*views[c.view].ids)[c.block], c.param, c.n, 1.0 / std::sqrt(gap), retry});
+  }
+  return out;
+}
+
+// extractCovarianceWithRankDeficiencyHandling (:929-1062) for the object blocks of the problem on the device
+inline bool extractCovarianceWithRankDeficiencyHandling(const std::vector<std::pair<vslam_types_refactor::ObjectId, vslam_types_refactor::ObjectId>>& covariance_blocks, Problem* problem,
+                                                        double min_col_norm, Covariance* covariance, std::vector<CovarianceRankRepair>* repairs) {
+  obvi_ba_handle* h = problem ? problem->handle() : nullptr;
+  if (h == nullptr) return false;
+  const FlatProblem& fp = problem->flat;
+  std::vector<uint8_t> kind, param; std::vector<uint32_t> block; std::vector<double> mean, stddev;
+  obvi_ba_set_parameter_priors(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  bool ok = covariance->Compute(covariance_blocks, problem);
+  for (int retry_count = 1; !ok && retry_count <= kMaxJacobianExtractionRetries; ++retry_count) {
+    std::cerr << "Retrying rank deficient jacobian, retry num " << retry_count << std::endl;
+    std::vector<double> np(6 * fp.frames.size()), nl(3 * fp.features.size()), no(7 * fp.objects.size());
+    if (obvi_ba_column_sqnorms(h, np.data(), nl.data(), no.data())) { std::cerr << "column norms failed: " << obvi_ba_last_error(h) << std::endl; return false; }
+    std::vector<uint64_t> frames(fp.frames.begin(), fp.frames.end()), feats(fp.features.begin(), fp.features.end()), objs(fp.objects.begin(), fp.objects.end());
+    const std::vector<CovarianceRankRepair> sel = selectParameterPriors({{&nl, 3, 1, &feats}, {&np, 6, 0, &frames}, {&no, 7, 2, &objs}}, min_col_norm, retry_count);
+    if (sel.empty()) { std::cerr << "No rank deficient columns identified" << std::endl; break; }
+    for (const CovarianceRankRepair& r : sel) {
+      // the flat problem's lists are in ascending id order
+      const std::vector<uint64_t>& ids = r.block_kind == 0 ? frames : r.block_kind == 1 ? feats : objs;
+      const uint32_t idx = (uint32_t)(std::lower_bound(ids.begin(), ids.end(), r.block_id) - ids.begin());
+      const double* values = r.block_kind == 0 ? fp.pose_ptrs[idx] : r.block_kind == 1 ? fp.point_ptrs[idx] : fp.object_ptrs[idx];
+      kind.push_back((uint8_t)(r.block_kind == 0 ? 0 : r.block_kind == 1 ? 1 : 2)); block.push_back(idx); param.push_back((uint8_t)r.param_idx);
+      mean.push_back(values[r.param_idx]); stddev.push_back(r.prior_std_dev);
+      if (repairs) repairs->push_back(r);
+    }
+    if (obvi_ba_set_parameter_priors(h, (int64_t)kind.size(), kind.data(), block.data(), param.data(), mean.data(), stddev.data())) { std::cerr << "parameter priors rejected: " << obvi_ba_last_error(h) << std::endl; return false; }
+    ok = covariance->Compute(covariance_blocks, problem);
+    if (!ok) std::cerr << "Covariance extraction failed on retry " << retry_count << " with additional priors; consider revising buffer " << kRankDeficiencyColsBuffer << std::endl;
+  }
+  obvi_ba_set_parameter_priors(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return ok;
+}
+
 }  // namespace obvi
 
 namespace vslam_types_refactor {
 
 // include/debugging/optimization_logger.h:151-304
+// IterationLogger / IterationLoggerFactory (include/debugging/optimization_logger.h:29-147): one CSV per optimisation type,
+// "ceres_iterations_<type>.csv", a row per LM iteration -- the reference's own definition of what an iteration is.
+class IterationLogger {
+ public:
+  IterationLogger(const std::string& logging_directory, const std::string& logging_type)
+      : output_file_path_((logging_directory.empty() || logging_directory.back() == '/' ? logging_directory : logging_directory + "/") + "ceres_iterations_" + logging_type + ".csv") {
+    std::ofstream csv_file(output_file_path_, std::ios::trunc);
+    csv_file << "optimization_id,iteration_num,cost,cost_change,step_norm,step_norm_per_param,is_successful\n";
+  }
+  void logIterations(const std::string& optimization_identifier, const obvi::SolverSummary& solver_summary) {
+    iteration_info_.push_back({optimization_identifier, solver_summary.num_parameters_reduced, solver_summary.iterations});
+  }
+  void writeLatestData() {
+    if (iteration_info_.empty()) return;
+    std::ofstream csv_file(output_file_path_, std::ios::app);
+    for (const Entry& e : iteration_info_)
+      for (const obvi::IterationSummary& it : e.iterations)
+        csv_file << e.id << "," << std::to_string(it.iteration) << "," << std::to_string(it.cost) << "," << std::to_string(it.cost_change) << "," << std::to_string(it.step_norm) << ","
+                 << std::to_string(it.step_norm / e.num_parameters_reduced) << "," << (it.step_is_successful ? 1 : 0) << "\n";
+    iteration_info_.clear();
+  }
+  const std::string& path() const { return output_file_path_; }
+
+ private:
+  struct Entry { std::string id; int num_parameters_reduced; std::vector<obvi::IterationSummary> iterations; };
+  std::string output_file_path_;
+  std::vector<Entry> iteration_info_;
+};
+class IterationLoggerFactory {
+ public:
+  inline const static std::string kPendingEstimatorOptimizationType = "pending_obj_est";
+  inline const static std::string kVfAdjustOptimizationType = "vf_adjust";
+  inline const static std::string kPrePgoTrackOptimizationType = "pre_pgo_track";
+  inline const static std::string kPGOOptimizationType = "pgo";
+  inline const static std::string kLBAPhase1OptimizationType = "lba_phase_1";
+  inline const static std::string kLBAPhase2OptimizationType = "lba_phase_2";
+  inline const static std::string kGBAPhase1OptimizationType = "gba_phase_1";
+  inline const static std::string kGBAPhase2OptimizationType = "gba_phase_2";
+  static IterationLoggerFactory& getInstance() { static IterationLoggerFactory factory_instance; return factory_instance; }
+  static void setLoggingDirectory(const std::string& logging_directory) {
+    IterationLoggerFactory& f = getInstance();
+    f.logging_directory_ = logging_directory; f.initialized_ = true; f.iteration_loggers_by_type_.clear();
+  }
+  std::shared_ptr<IterationLogger> getOrCreateLoggerOfType(const std::string& logger_type) {
+    if (!initialized_) return nullptr;   // the reference logs "Not initialized with target directory" and returns null: callers skip
+    auto it = iteration_loggers_by_type_.find(logger_type);
+    if (it == iteration_loggers_by_type_.end()) it = iteration_loggers_by_type_.emplace(logger_type, std::make_shared<IterationLogger>(logging_directory_, logger_type)).first;
+    return it->second;
+  }
+  void writeAllIterationLoggerStates() { for (const auto& l : iteration_loggers_by_type_) if (l.second) l.second->writeLatestData(); }
+
+ private:
+  IterationLoggerFactory() = default;
+  bool initialized_ = false;
+  std::string logging_directory_;
+  std::unordered_map<std::string, std::shared_ptr<IterationLogger>> iteration_loggers_by_type_;
+};
+
 class OptimizationLogger {
  public:
   explicit OptimizationLogger(const std::string& output_file_path) : output_file_path_(output_file_path) {}
@@ -156,6 +286,14 @@ class OptimizationLogger {
     info_.total_ceres_time_ = s.total_time_in_seconds; info_.linear_solver_time_ = s.linear_solver_time_in_seconds;
     info_.jacobian_time_ = s.jacobian_evaluation_time_in_seconds; info_.residual_time_ = s.residual_evaluation_time_in_seconds;
     info_.num_ceres_iterations_ = s.iterations.size();
+    // :205-236 the per-iteration rows go to the logger of the optimisation's type, identified by "<max frame>_<attempt>"
+    std::string opt_type;
+    if (info_.global_pgo_) opt_type = IterationLoggerFactory::kPGOOptimizationType;
+    else if (info_.global_ba_) opt_type = info_.outliers_excluded_opt_ ? IterationLoggerFactory::kGBAPhase2OptimizationType : IterationLoggerFactory::kGBAPhase1OptimizationType;
+    else if (info_.local_ba_) opt_type = info_.outliers_excluded_opt_ ? IterationLoggerFactory::kLBAPhase2OptimizationType : IterationLoggerFactory::kLBAPhase1OptimizationType;
+    else return;
+    const std::shared_ptr<IterationLogger> iteration_logger = IterationLoggerFactory::getInstance().getOrCreateLoggerOfType(opt_type);
+    if (iteration_logger != nullptr) iteration_logger->logIterations(std::to_string(info_.max_frame_id_) + "_" + std::to_string(info_.attempt_num_), s);
   }
   void writeOptInfoHeader() {
     if (output_file_path_.empty()) return;
@@ -625,6 +763,9 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
       std::cerr << "Visual feature adjustment after pose-graph optimization failed at max frame id " << max_frame_id << std::endl;
       return false;
     }
+    // :338-345
+    const std::shared_ptr<IterationLogger> vf_adjust_logger = IterationLoggerFactory::getInstance().getOrCreateLoggerOfType(IterationLoggerFactory::kVfAdjustOptimizationType);
+    if (vf_adjust_logger != nullptr) vf_adjust_logger->logIterations(std::to_string(max_frame_id) + "_" + std::to_string(attempt_num), optimizer.lastSummary());
   }
   return true;
 }

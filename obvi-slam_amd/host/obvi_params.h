@@ -107,6 +107,8 @@ struct OptimizationScopeParams {
 }  // namespace pose_graph_optimizer
 
 namespace vslam_types_refactor {
+// long_term_map_extraction_tunable_params.h:11-17
+struct LongTermMapExtractionTunableParams { double far_feature_threshold_ = 75; double min_col_norm_ = 5e-9; bool fallback_to_prev_for_failed_extraction_ = true; };
 struct SlidingWindowParams {   // full_ov_slam_config.h; values of config/base7a_2_fallback.json
   FrameId global_ba_frequency_ = 30;
   FrameId local_ba_window_size_ = 50;

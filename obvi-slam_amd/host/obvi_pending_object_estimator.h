@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "obvi_optimizer.h"
 #include "obvi_params.h"
 #include "obvi_pose_graph.h"
 
@@ -37,7 +38,8 @@ inline bool refineInitialEstimateForPendingObjects(const std::unordered_map<Obje
                                                    const PoseGraphPtr& pose_graph,
                                                    const std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>>& mean_and_cov_by_semantic_class,
                                                    const PendingObjectEstimatorParams& estimator_params, int device_id,
-                                                   std::unordered_map<ObjectId, RawEllipsoid>* updated_estimates, obvi_summary* summary_out = nullptr) {
+                                                   std::unordered_map<ObjectId, RawEllipsoid>* updated_estimates, obvi_summary* summary_out = nullptr,
+                                                   const std::string& optimization_identifier = "" /* "<frame id>_<camera id>" of the triggering observation (.cpp:134-135) */) {
   std::unordered_map<FrameId, RawPose3d> robot_pose_estimates;
   pose_graph->getRobotPoseEstimates(robot_pose_estimates);
   // flat problem: objects in id order, the frames that carry an observation, the cameras of the pose graph
@@ -99,6 +101,17 @@ inline bool refineInitialEstimateForPendingObjects(const std::unordered_map<Obje
   if (!rc) rc = obvi_ba_solve(h, &p, &s);
   if (!rc) rc = obvi_ba_get_objects(h, objects.data());
   if (rc) std::cerr << "pending object estimation: " << obvi_ba_last_error(h) << std::endl;
+  if (!rc) {   // pending_object_estimator.cpp:134-143: the iteration rows of this solve
+    const std::shared_ptr<IterationLogger> logger = IterationLoggerFactory::getInstance().getOrCreateLoggerOfType(IterationLoggerFactory::kPendingEstimatorOptimizationType);
+    if (logger != nullptr) {
+      obvi::SolverSummary summary;
+      summary.num_parameters_reduced = s.num_parameters_reduced;
+      std::vector<obvi_iteration_summary> its((size_t)std::max(s.num_iterations, 1));
+      const int nit = obvi_ba_get_iterations(h, its.data(), (int32_t)its.size());
+      for (int i = 0; i < nit; ++i) summary.iterations.push_back({its[i].iteration, its[i].cost, its[i].cost_change, its[i].step_norm, its[i].gradient_max_norm, its[i].step_is_successful != 0});
+      logger->logIterations(optimization_identifier, summary);
+    }
+  }
   obvi_ba_destroy(h);
   if (rc) return false;
   if (summary_out) *summary_out = s;

@@ -8,12 +8,15 @@
 #define OBVI_HOST_POSE_GRAPH_H_
 
 #include <algorithm>
+#include <iostream>
 #include <map>
+#include <memory>
 #include <optional>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
+#include <vector>
 
 #include "obvi_types.h"
 
@@ -22,6 +25,44 @@ namespace vslam_types_refactor {
 typedef std::pair<FactorType, FeatureFactorId> FactorInfo;
 struct FactorInfoHash { size_t operator()(const FactorInfo& f) const { return std::hash<uint64_t>()((uint64_t)f.first << 56 ^ f.second); } };
 typedef std::unordered_set<FactorInfo, FactorInfoHash> FactorInfoSet;   // util::BoostHashSet<pair<FactorType, FeatureFactorId>>
+
+// ---- state structs: the reference's (low_level_feature_pose_graph.h:25-65, object_pose_graph.h:22-86), same member names ----------
+struct LowLevelFeaturePoseGraphState {
+  std::unordered_map<CameraId, CameraExtrinsics> camera_extrinsics_by_camera_;
+  std::unordered_map<CameraId, CameraIntrinsicsMat> camera_intrinsics_by_camera_;
+  FactorType visual_factor_type_ = kReprojectionErrorFactorTypeId;
+  FrameId min_frame_id_ = 0, max_frame_id_ = 0;
+  FeatureFactorId max_feature_factor_id_ = 0, max_pose_factor_id_ = 0;
+  std::unordered_map<FrameId, RawPose3d> robot_poses_;
+  std::unordered_map<FrameId, FactorInfoSet> pose_factors_by_frame_;
+  std::unordered_map<FrameId, std::vector<FactorInfo>> visual_feature_factors_by_frame_;
+  std::unordered_map<FeatureId, FactorInfoSet> visual_factors_by_feature_;
+  std::unordered_map<FeatureFactorId, RelPoseFactor> pose_factors_;
+  std::unordered_map<FeatureFactorId, ReprojectionErrorFactor> factors_;
+  std::unordered_map<FeatureId, FrameId> last_observed_frame_by_feature_, first_observed_frame_by_feature_;
+};
+struct ReprojectionLowLevelFeaturePoseGraphState {
+  LowLevelFeaturePoseGraphState low_level_pg_state_;
+  FeatureId min_feature_id_ = 0, max_feature_id_ = 0;
+  std::unordered_map<FeatureId, Position3d> feature_positions_;
+};
+struct ObjOnlyPoseGraphState {
+  std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>> mean_and_cov_by_semantic_class_;
+  ObjectId min_object_id_ = 0, max_object_id_ = 0;
+  std::unordered_map<ObjectId, RawEllipsoid> ellipsoid_estimates_;
+  std::unordered_map<ObjectId, std::string> semantic_class_for_object_;
+  std::unordered_map<ObjectId, FrameId> last_observed_frame_by_object_, first_observed_frame_by_object_;
+  FeatureFactorId min_object_observation_factor_ = 0, max_object_observation_factor_ = 0, min_obj_specific_factor_ = 0, max_obj_specific_factor_ = 0;
+  std::unordered_set<ObjectId> long_term_map_object_ids_;
+  std::unordered_map<FeatureFactorId, ObjectObservationFactor> object_observation_factors_;
+  std::unordered_map<FeatureFactorId, ShapeDimPriorFactor> shape_dim_prior_factors_;
+  std::unordered_map<FrameId, FactorInfoSet> observation_factors_by_frame_;
+  std::unordered_map<ObjectId, FactorInfoSet> observation_factors_by_object_, object_only_factors_by_object_;
+};
+struct ObjectAndReprojectionFeaturePoseGraphState {
+  ReprojectionLowLevelFeaturePoseGraphState reprojection_low_level_feature_pose_graph_state_;
+  ObjOnlyPoseGraphState obj_only_pose_graph_state_;
+};
 
 class ObjectAndReprojectionFeaturePoseGraph {
  public:
@@ -170,6 +211,123 @@ class ObjectAndReprojectionFeaturePoseGraph {
     }
   }
 
+  void getObjectEstimates(std::unordered_map<ObjectId, std::pair<std::string, RawEllipsoid>>& out) const {                // object_pose_graph.h:505-520
+    out.clear();
+    for (const auto& p : ellipsoid_estimates_) { auto c = semantic_class_for_object_.find(p.first); out[p.first] = {c == semantic_class_for_object_.end() ? std::string() : c->second, *p.second}; }
+  }
+  // mergeObjects (object_pose_graph.h:739-830): the observation factors of the merged objects are re-pointed at the object they are
+  // merged into; the merged objects, their estimates, classes and object-only factors (shape priors) are removed.
+  bool mergeObjects(const std::unordered_map<ObjectId, std::unordered_set<ObjectId>>& objects_to_merge) {
+    std::unordered_set<ObjectId> objects_to_remove;
+    for (const auto& merge_group : objects_to_merge) {
+      for (const ObjectId& merge_obj : merge_group.second) {
+        if (objects_to_remove.count(merge_obj)) std::cerr << "Object " << merge_obj << " expected to be merged into multiple objects (second was " << merge_group.first << "). This will cause unexpected behavior." << std::endl;
+        if (objects_to_merge.count(merge_obj)) std::cerr << "Object " << merge_obj << " is supposed to be merged into " << merge_group.first << " and have other objects merged into it. This will cause unexpected behavior." << std::endl;
+        const auto src = observation_factors_by_object_.find(merge_obj);
+        if (src == observation_factors_by_object_.end()) continue;
+        const std::vector<FeatureFactorId> moved = src->second;
+        for (FeatureFactorId id : moved) {
+          auto f = object_observation_factors_.find(id);
+          if (f == object_observation_factors_.end()) { std::cerr << "Could not find object observation factor with id " << id << " skipping" << std::endl; continue; }
+          f->second.object_id_ = merge_group.first;
+          observation_factors_by_object_[merge_group.first].push_back(id);
+        }
+      }
+      objects_to_remove.insert(merge_group.second.begin(), merge_group.second.end());
+      auto& v = observation_factors_by_object_[merge_group.first];
+      std::sort(v.begin(), v.end());
+    }
+    for (const ObjectId& o : objects_to_remove) {
+      ellipsoid_estimates_.erase(o); semantic_class_for_object_.erase(o); long_term_map_object_ids_.erase(o);
+      auto sp = shape_dim_factor_for_object_.find(o);
+      if (sp != shape_dim_factor_for_object_.end()) { shape_dim_prior_factors_.erase(sp->second); shape_dim_factor_for_object_.erase(sp); }
+      auto lt = ltm_factor_for_object_.find(o);
+      if (lt != ltm_factor_for_object_.end()) { ltm_factors_.erase(lt->second); ltm_factor_for_object_.erase(lt); }
+      observation_factors_by_object_.erase(o);
+    }
+    return true;
+  }
+
+  // ---- state (checkpoints): getState / createObjectAndReprojectionFeaturePoseGraphFromState (object_pose_graph.h:1185-1212) -------
+  void setShapePriorsBySemanticClass(const std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>>& m) { mean_and_cov_by_semantic_class_ = m; }
+  const std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>>& shapePriorsBySemanticClass() const { return mean_and_cov_by_semantic_class_; }
+  void getState(ObjectAndReprojectionFeaturePoseGraphState& pose_graph_state) const {
+    pose_graph_state = ObjectAndReprojectionFeaturePoseGraphState();
+    ReprojectionLowLevelFeaturePoseGraphState& R = pose_graph_state.reprojection_low_level_feature_pose_graph_state_;
+    LowLevelFeaturePoseGraphState& L = R.low_level_pg_state_;
+    ObjOnlyPoseGraphState& O = pose_graph_state.obj_only_pose_graph_state_;
+    L.camera_extrinsics_by_camera_ = camera_extrinsics_by_camera_; L.camera_intrinsics_by_camera_ = camera_intrinsics_by_camera_;
+    L.visual_factor_type_ = kReprojectionErrorFactorTypeId;
+    L.min_frame_id_ = min_frame_id_; L.max_frame_id_ = max_frame_id_;
+    L.max_feature_factor_id_ = next_visual_factor_id_; L.max_pose_factor_id_ = next_pose_factor_id_;
+    for (const auto& p : robot_poses_) L.robot_poses_[p.first] = *p.second;
+    for (const auto& f : pose_factors_by_frame_) for (FeatureFactorId id : f.second) L.pose_factors_by_frame_[f.first].insert({kPairwiseRobotPoseFactorTypeId, id});
+    for (const auto& f : visual_factors_by_frame_) for (FeatureFactorId id : f.second) L.visual_feature_factors_by_frame_[f.first].push_back({kReprojectionErrorFactorTypeId, id});
+    for (const auto& f : visual_factors_by_feature_) for (FeatureFactorId id : f.second) L.visual_factors_by_feature_[f.first].insert({kReprojectionErrorFactorTypeId, id});
+    L.pose_factors_ = pose_factors_; L.factors_ = factors_;
+    L.first_observed_frame_by_feature_ = first_observed_frame_by_feature_;
+    for (const auto& f : factors_) { auto it = L.last_observed_frame_by_feature_.find(f.second.feature_id_); if (it == L.last_observed_frame_by_feature_.end() || it->second < f.second.frame_id_) L.last_observed_frame_by_feature_[f.second.feature_id_] = f.second.frame_id_; }
+    bool first = true;
+    for (const auto& p : feature_positions_) {
+      R.feature_positions_[p.first] = *p.second;
+      R.min_feature_id_ = first ? p.first : std::min(R.min_feature_id_, p.first); R.max_feature_id_ = first ? p.first : std::max(R.max_feature_id_, p.first); first = false;
+    }
+    O.mean_and_cov_by_semantic_class_ = mean_and_cov_by_semantic_class_;
+    O.min_object_id_ = 0; O.max_object_id_ = next_object_id_;
+    for (const auto& p : ellipsoid_estimates_) O.ellipsoid_estimates_[p.first] = *p.second;
+    O.semantic_class_for_object_ = semantic_class_for_object_;
+    O.long_term_map_object_ids_ = long_term_map_object_ids_;
+    O.object_observation_factors_ = object_observation_factors_; O.shape_dim_prior_factors_ = shape_dim_prior_factors_;
+    O.min_object_observation_factor_ = 0; O.max_object_observation_factor_ = next_obj_factor_id_; O.min_obj_specific_factor_ = 0; O.max_obj_specific_factor_ = next_obj_factor_id_;
+    for (const auto& f : object_observation_factors_) {
+      auto lo = O.first_observed_frame_by_object_.find(f.second.object_id_);
+      if (lo == O.first_observed_frame_by_object_.end() || f.second.frame_id_ < lo->second) O.first_observed_frame_by_object_[f.second.object_id_] = f.second.frame_id_;
+      auto hi = O.last_observed_frame_by_object_.find(f.second.object_id_);
+      if (hi == O.last_observed_frame_by_object_.end() || f.second.frame_id_ > hi->second) O.last_observed_frame_by_object_[f.second.object_id_] = f.second.frame_id_;
+    }
+    for (const auto& f : observation_factors_by_frame_) for (FeatureFactorId id : f.second) O.observation_factors_by_frame_[f.first].insert({kObjectObservationFactorTypeId, id});
+    for (const auto& f : observation_factors_by_object_) for (FeatureFactorId id : f.second) O.observation_factors_by_object_[f.first].insert({kObjectObservationFactorTypeId, id});
+    for (const auto& f : shape_dim_factor_for_object_) O.object_only_factors_by_object_[f.first].insert({kShapeDimPriorFactorTypeId, f.second});
+  }
+  // The long-term-map priors are not part of a checkpoint (the reference re-creates them from the long-term map file through its
+  // long_term_map_factor_provider): attach them afterwards with addLongTermMapObject.
+  static std::shared_ptr<ObjectAndReprojectionFeaturePoseGraph> createObjectAndReprojectionFeaturePoseGraphFromState(const ObjectAndReprojectionFeaturePoseGraphState& st) {
+    const ReprojectionLowLevelFeaturePoseGraphState& R = st.reprojection_low_level_feature_pose_graph_state_;
+    const LowLevelFeaturePoseGraphState& L = R.low_level_pg_state_;
+    const ObjOnlyPoseGraphState& O = st.obj_only_pose_graph_state_;
+    auto pg = std::make_shared<ObjectAndReprojectionFeaturePoseGraph>(L.camera_extrinsics_by_camera_, L.camera_intrinsics_by_camera_);
+    for (const auto& p : L.robot_poses_) pg->robot_poses_[p.first] = std::make_shared<RawPose3d>(p.second);
+    pg->min_frame_id_ = L.min_frame_id_; pg->max_frame_id_ = L.max_frame_id_;
+    for (const auto& p : R.feature_positions_) pg->feature_positions_[p.first] = std::make_shared<Position3d>(p.second);
+    pg->factors_ = L.factors_;
+    // per-frame lists keep the file's order; per-feature sets are stored in ascending id order
+    for (const auto& f : L.visual_feature_factors_by_frame_) for (const FactorInfo& fi : f.second) pg->visual_factors_by_frame_[f.first].push_back(fi.second);
+    for (const auto& f : L.visual_factors_by_feature_) { auto& v = pg->visual_factors_by_feature_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
+    pg->first_observed_frame_by_feature_ = L.first_observed_frame_by_feature_;
+    pg->pose_factors_ = L.pose_factors_;
+    for (const auto& f : L.pose_factors_by_frame_) { auto& v = pg->pose_factors_by_frame_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
+    FeatureFactorId next_v = L.max_feature_factor_id_, next_p = L.max_pose_factor_id_;
+    for (const auto& f : L.factors_) next_v = std::max(next_v, f.first + 1);
+    for (const auto& f : L.pose_factors_) next_p = std::max(next_p, f.first + 1);
+    pg->next_visual_factor_id_ = next_v; pg->next_pose_factor_id_ = next_p;
+    pg->mean_and_cov_by_semantic_class_ = O.mean_and_cov_by_semantic_class_;
+    for (const auto& p : O.ellipsoid_estimates_) pg->ellipsoid_estimates_[p.first] = std::make_shared<RawEllipsoid>(p.second);
+    pg->semantic_class_for_object_ = O.semantic_class_for_object_;
+    pg->long_term_map_object_ids_ = O.long_term_map_object_ids_;
+    pg->object_observation_factors_ = O.object_observation_factors_; pg->shape_dim_prior_factors_ = O.shape_dim_prior_factors_;
+    for (const auto& f : O.shape_dim_prior_factors_) pg->shape_dim_factor_for_object_[f.second.object_id_] = f.first;
+    for (const auto& f : O.observation_factors_by_frame_) { auto& v = pg->observation_factors_by_frame_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
+    for (const auto& f : O.observation_factors_by_object_) { auto& v = pg->observation_factors_by_object_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
+    ObjectId next_o = O.max_object_id_;
+    for (const auto& p : O.ellipsoid_estimates_) next_o = std::max(next_o, p.first + 1);
+    pg->next_object_id_ = next_o;
+    FeatureFactorId next_f = std::max(O.max_object_observation_factor_, O.max_obj_specific_factor_);
+    for (const auto& f : O.object_observation_factors_) next_f = std::max(next_f, f.first + 1);
+    for (const auto& f : O.shape_dim_prior_factors_) next_f = std::max(next_f, f.first + 1);
+    pg->next_obj_factor_id_ = next_f;
+    return pg;
+  }
+
   // ---- value copy / restore (object_pose_graph.h:1025-1121) ---------------------------------
   std::shared_ptr<ObjectAndReprojectionFeaturePoseGraph> makeCopyDeepCopyValues() const {
     auto c = std::make_shared<ObjectAndReprojectionFeaturePoseGraph>(*this);
@@ -198,6 +356,7 @@ class ObjectAndReprojectionFeaturePoseGraph {
   std::unordered_map<FrameId, std::vector<FeatureFactorId>> pose_factors_by_frame_;
   std::unordered_map<ObjectId, RawEllipsoidPtr> ellipsoid_estimates_;
   std::unordered_map<ObjectId, std::string> semantic_class_for_object_;
+  std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>> mean_and_cov_by_semantic_class_;
   std::unordered_set<ObjectId> long_term_map_object_ids_;
   std::unordered_map<FeatureFactorId, ObjectObservationFactor> object_observation_factors_;
   std::unordered_map<FeatureFactorId, ShapeDimPriorFactor> shape_dim_prior_factors_;

@@ -73,6 +73,40 @@ inline void addFrameDataToPoseGraph(const OfflineProblemData& d, MainPgPtr& pg, 
     }
 }
 
+// identifyMergeObjectsBasedOnCenterProximity (bounding_box_front_end_helpers.h:266-356): objects of one semantic class whose centres
+// are at most max_distance_for_merge apart are merged pairwise, closest pairs first, every object in at most one merge; a
+// long-term-map object is the one merged into (two long-term-map objects are never merged); otherwise the second of the pair.
+inline void identifyMergeObjectsBasedOnCenterProximity(const MainPgPtr& pose_graph, const double& max_distance_for_merge, const bool& x_y_only_merge,
+                                                       std::unordered_map<ObjectId, std::unordered_set<ObjectId>>& merge_results) {
+  if (max_distance_for_merge < 0) return;
+  std::unordered_set<ObjectId> long_term_map_objects, involved_in_merge;
+  pose_graph->getLongTermMapObjects(long_term_map_objects);
+  std::unordered_map<ObjectId, std::pair<std::string, RawEllipsoid>> object_estimates_raw;
+  pose_graph->getObjectEstimates(object_estimates_raw);
+  std::map<std::string, std::vector<std::pair<ObjectId, Position3d>>> object_centers_by_semantic_class;
+  std::vector<ObjectId> ids;
+  for (const auto& e : object_estimates_raw) ids.push_back(e.first);
+  std::sort(ids.begin(), ids.end());   // the reference walks an unordered_map; ascending ids make the pairing reproducible
+  for (ObjectId id : ids) { const auto& e = object_estimates_raw.at(id); object_centers_by_semantic_class[e.first].push_back({id, Position3d{{e.second[0], e.second[1], e.second[2]}}}); }
+  std::vector<std::pair<double, std::pair<ObjectId, ObjectId>>> possible_merge_objs_with_dist;
+  for (const auto& cls : object_centers_by_semantic_class)
+    for (size_t i = 0; i < cls.second.size(); ++i)
+      for (size_t j = i + 1; j < cls.second.size(); ++j) {
+        const Position3d &a = cls.second[i].second, &b = cls.second[j].second;
+        const double dz = x_y_only_merge ? 0.0 : a[2] - b[2];
+        const double dist = std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + dz * dz);
+        if (dist <= max_distance_for_merge && (!long_term_map_objects.count(cls.second[i].first) || !long_term_map_objects.count(cls.second[j].first)))
+          possible_merge_objs_with_dist.push_back({dist, {cls.second[i].first, cls.second[j].first}});
+      }
+  std::stable_sort(possible_merge_objs_with_dist.begin(), possible_merge_objs_with_dist.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  for (const auto& c : possible_merge_objs_with_dist) {
+    if (involved_in_merge.count(c.second.first) || involved_in_merge.count(c.second.second)) continue;
+    involved_in_merge.insert(c.second.first); involved_in_merge.insert(c.second.second);
+    if (long_term_map_objects.count(c.second.first)) merge_results[c.second.first] = {c.second.second};
+    else merge_results[c.second.second] = {c.second.first};
+  }
+}
+
 struct OptimizationRecord {   // one row per solve, for tests / logging
   FrameId min_frame, max_frame; std::string kind; int iterations; double initial_cost, final_cost; size_t n_poses, n_features, n_objects, n_excluded;
 };
@@ -103,7 +137,10 @@ class OfflineProblemRunner {
     scope.min_low_level_feature_observations_ = enabled.min_low_level_feature_observations_;
     scope.min_object_observations_ = enabled.min_object_observations_;
     const FrameId max_frame_id = problem_data.getMaxFrameId();
-    MainPgPtr pose_graph = std::make_shared<MainPg>(problem_data.camera_extrinsics_by_camera_, problem_data.camera_intrinsics_by_camera_);   // pose_graph_creator_
+    MainPgPtr pose_graph;
+    if (pose_graph_creator_) pose_graph_creator_(problem_data, pose_graph);                                                  // :149-150 (a checkpoint's graph: run_opt_from_pg_state.cpp:182-185)
+    else pose_graph = std::make_shared<MainPg>(problem_data.camera_extrinsics_by_camera_, problem_data.camera_intrinsics_by_camera_);
+    if (!pose_graph) return false;
     for (const auto& ltm : problem_data.long_term_map_)
       pose_graph->addLongTermMapObject(ltm.object_id_, ltm.ellipsoid_mean_, problem_data.object_class_.count(ltm.object_id_) ? problem_data.object_class_.at(ltm.object_id_) : "", ltm);
     if (start_at_frame == 0 && add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_);
@@ -115,9 +152,12 @@ class OfflineProblemRunner {
       if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_);
       time_add_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_add0).count();
       if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
+      IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                 // :219
     }
     if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
-    // mergeObjectsAtSessionEnd (:918-958) acts on data-association state: out of scope.  The output extractor's covariance
+    if (!mergeObjectsAtSessionEnd(max_frame_id, enabled, scope, opt_logger, pose_graph, problem)) return false;              // :254-262
+    IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();
+    // The output extractor's covariance
     // step (IndependentEllipsoidsLongTermObjectMapExtractor::extractLongTermObjectMap, long_term_object_map_extraction.h:
     // 381-527: marginal covariance of every ellipsoid from the final problem) runs on the device.
     long_term_map_.clear();
@@ -125,7 +165,8 @@ class OfflineProblemRunner {
       std::vector<std::pair<ObjectId, ObjectId>> blocks;
       for (const ObjectId& o : problem.flat.objects) blocks.push_back({o, o});
       obvi::Covariance covariance;
-      if (!covariance.Compute(blocks, &problem)) return false;
+      covariance_rank_repairs_.clear();
+      if (!obvi::extractCovarianceWithRankDeficiencyHandling(blocks, &problem, ltm_tunable_params_.min_col_norm_, &covariance, &covariance_rank_repairs_)) return false;
       for (size_t i = 0; i < problem.flat.objects.size(); ++i) {
         LongTermMapEntry e;
         e.object_id_ = problem.flat.objects[i];
@@ -137,6 +178,26 @@ class OfflineProblemRunner {
     pose_graph_out = pose_graph;
     return true;
   }
+  // :918-958 until there are no more objects to merge, merge and re-run the final optimisation (attempt numbers 2, 3, ...)
+  bool mergeObjectsAtSessionEnd(const FrameId& max_frame_id, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
+                                const pose_graph_optimizer::OptimizationScopeParams& scope, std::optional<OptimizationLogger>& opt_logger, MainPgPtr& pose_graph,
+                                obvi::Problem& merged_problem /* the reference builds a fresh ceres::Problem per round (:935); here the session's problem object is rebuilt
+                                                                 in place, so that the long-term-map extraction afterwards sees the merged problem */) {
+    if (!object_merger_) return true;
+    int post_process_round = 2;
+    while (object_merger_(pose_graph)) {
+      optimizer_.clearPastOptimizationData();
+      pose_graph_optimizer::OptimizationScopeParams merged_scope = scope;
+      merged_scope.min_frame_id_ = 0; merged_scope.max_frame_id_ = max_frame_id;
+      if (!runOptimizationIteration(0, max_frame_id, enabled, merged_scope, max_frame_id, opt_logger, pose_graph, merged_problem, post_process_round)) return false;
+      ++n_merge_rounds_;
+      post_process_round++;
+    }
+    return true;
+  }
+  void setPoseGraphCreator(const std::function<void(const OfflineProblemData&, MainPgPtr&)>& creator) { pose_graph_creator_ = creator; }
+  void setObjectMerger(const std::function<bool(const MainPgPtr&)>& merger) { object_merger_ = merger; }
+  size_t mergeRounds() const { return n_merge_rounds_; }
   const std::vector<OptimizationRecord>& records() const { return records_; }
   void printTiming(std::ostream& os) const {
     optimizer_.printTiming(os);
@@ -149,6 +210,8 @@ class OfflineProblemRunner {
   }
   struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
   void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
+  void setLongTermMapTunableParams(const LongTermMapExtractionTunableParams& p) { ltm_tunable_params_ = p; }
+  const std::vector<obvi::CovarianceRankRepair>& covarianceRankRepairs() const { return covariance_rank_repairs_; }
   const std::vector<LongTermMapEntry>& longTermMap() const { return long_term_map_; }
 
  private:
@@ -206,6 +269,10 @@ class OfflineProblemRunner {
         std::optional<OptimizationLogger> null_logger;
         optimizer_.buildPoseGraphOptimization(tracking, residual_params_, pose_graph, &problem, null_logger);
         if (!optimizer_.solveOptimization(&problem, pgo_solver_params_.pre_pgo_tracking_solver_params_, null_logger)) std::cerr << "Tracking failed" << std::endl;
+        {   // :486-496
+          const std::shared_ptr<IterationLogger> tracking_logger = IterationLoggerFactory::getInstance().getOrCreateLoggerOfType(IterationLoggerFactory::kPrePgoTrackOptimizationType);
+          if (tracking_logger != nullptr) tracking_logger->logIterations(std::to_string(next_frame_id), optimizer_.lastSummary());
+        }
         record("pre_pgo_track", tracking.min_frame_id_, next_frame_id, problem, 0);
         if (!pose_graph_optimizer::runPgoPlusEllipsoids(next_frame_id, scope, residual_params_, pgo_solver_params_, next_frame_id == max_frame_id, opt_logger, pose_graph,
                                                         device_id_, attempt_num))
@@ -375,12 +442,17 @@ class OfflineProblemRunner {
   std::function<bool(const FrameId&)> gba_checker_;
   std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)> iteration_params_provider_func_;
   int device_id_;
+  std::function<void(const OfflineProblemData&, MainPgPtr&)> pose_graph_creator_;
+  std::function<bool(const MainPgPtr&)> object_merger_;
+  size_t n_merge_rounds_ = 0;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
   double time_build_ms_ = 0, time_copy_ms_ = 0, time_add_ms_ = 0, time_select_ms_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
   struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;
   std::unique_ptr<obvi::Problem> check_problem_;
   bool extract_long_term_map_ = false;
+  LongTermMapExtractionTunableParams ltm_tunable_params_;
+  std::vector<obvi::CovarianceRankRepair> covariance_rank_repairs_;
   std::vector<LongTermMapEntry> long_term_map_;
 };
 

@@ -2,6 +2,9 @@
 // offline_object_visual_slam_main / run_opt_from_pg_state for a scene whose associations are given.
 //   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv] [--ltm]
 //   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K] [--phase-two-masks]   (no GPU: flattening only)
+//   run_offline_ba <scene.txt> <out.json> ... [--save-checkpoint DIR] [--iteration-log-dir DIR] [--merge-distance M]
+//   run_offline_ba --from-checkpoint <pose_graph_state.json> <out.json> [--ltm] [--device D]   the shape of run_opt_from_pg_state: final global BA (+ long-term map) from a checkpoint
+//   run_offline_ba --checkpoint-roundtrip <in.json> <out.json>                                  (no GPU) read a pose-graph state and write it back
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 // Parameter values: config/base7a_2_fallback.json of the reference.
 #include <chrono>
@@ -11,8 +14,8 @@
 #include <iomanip>
 #include <iostream>
 
+#include "obvi_optimization_runner.h"
 #include "obvi_pending_object_estimator.h"
-#include "obvi_runner.h"
 
 using namespace vslam_types_refactor;   // NOLINT
 
@@ -55,58 +58,104 @@ static bool loadScene(const std::string& path, OfflineProblemData* d) {
   return (bool)in;
 }
 
-static pose_graph_optimization::OptimizationSolverParams sp(int it, double ftol) {
-  pose_graph_optimization::OptimizationSolverParams p;
-  p.max_num_iterations_ = it; p.allow_non_monotonic_steps_ = true; p.function_tolerance_ = ftol; p.gradient_tolerance_ = 1e-10; p.parameter_tolerance_ = 1e-8;
-  p.initial_trust_region_radius_ = 100; p.max_trust_region_radius_ = 1e4;
-  return p;
+static void writeResults(std::ostream& out, bool ok, const LongTermObjectMapAndResults& res, FrameId max_frame_id, bool ltm) {
+  out << "{\"ok\": " << (ok ? "true" : "false") << ", \"records\": [";
+  bool first = true;
+  for (const auto& r : res.records_) {
+    out << (first ? "" : ",") << "\n {\"min_frame\": " << r.min_frame << ", \"max_frame\": " << r.max_frame << ", \"kind\": \"" << r.kind << "\", \"iterations\": " << r.iterations
+        << ", \"initial_cost\": " << r.initial_cost << ", \"final_cost\": " << r.final_cost << ", \"n_poses\": " << r.n_poses << ", \"n_features\": " << r.n_features
+        << ", \"n_objects\": " << r.n_objects << ", \"n_excluded\": " << r.n_excluded << "}";
+    first = false;
+  }
+  out << "],\n\"merge_rounds\": " << res.post_session_merge_rounds_ << ",\n\"poses\": [";
+  for (FrameId f = 0; f <= max_frame_id && !res.robot_pose_results_.empty(); ++f) {
+    const auto it = res.robot_pose_results_.find(f);
+    if (it == res.robot_pose_results_.end()) { out << (f ? "," : "") << "null"; continue; }
+    const RawPose3d& p = it->second;
+    out << (f ? "," : "") << "[" << p[0] << "," << p[1] << "," << p[2] << "," << p[3] << "," << p[4] << "," << p[5] << "]";
+  }
+  out << "],\n\"objects\": {";
+  { bool f0 = true; for (const auto& o : res.ellipsoid_results_) { out << (f0 ? "" : ",") << "\"" << o.first << "\": ["; for (int k = 0; k < 7; ++k) out << (k ? "," : "") << o.second[k]; out << "]"; f0 = false; } }
+  out << "},\n\"covariance_rank_repairs\": [";
+  for (size_t i = 0; i < res.covariance_rank_repairs_.size(); ++i) {
+    const auto& r = res.covariance_rank_repairs_[i];
+    out << (i ? "," : "") << "\n {\"block_kind\": " << r.block_kind << ", \"block_id\": " << r.block_id << ", \"param_idx\": " << r.param_idx << ", \"col_sqnorm\": " << r.col_sqnorm
+        << ", \"prior_std_dev\": " << r.prior_std_dev << ", \"retry\": " << r.retry << "}";
+  }
+  out << "]";
+  if (ltm) {   // long-term map: ellipsoid mean + 7x7 marginal covariance per object (the input of the next session's IndependentObjectMapFactor)
+    out << ",\n\"long_term_map\": {";
+    bool f0 = true;
+    for (const auto& e : res.long_term_map_) {
+      out << (f0 ? "" : ",") << "\n \"" << e.object_id_ << "\": {\"mean\": [";
+      for (int k = 0; k < 7; ++k) out << (k ? "," : "") << e.ellipsoid_mean_[k];
+      out << "], \"covariance\": [";
+      for (int k = 0; k < 49; ++k) out << (k ? "," : "") << e.covariance_[k];
+      out << "]}";
+      f0 = false;
+    }
+    out << "}";
+  }
+  out << "}\n";
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options]" << std::endl; return 2; }
-  SlidingWindowParams sw;
-  int device = 0; std::string csv; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
-  for (int i = 3; i < argc; ++i) {
+  if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options] | --from-checkpoint state.json out.json | --checkpoint-roundtrip in.json out.json" << std::endl; return 2; }
+  if (!std::strcmp(argv[1], "--checkpoint-roundtrip")) {   // no GPU: the reader and the writer of obvi_checkpoint_io.h
+    if (argc < 4) return 2;
+    ObjectAndReprojectionFeaturePoseGraphState st;
+    if (!readPoseGraphStateFromFile(argv[2], st)) return 1;
+    return outputPoseGraphStateToFile(st, argv[3]) ? 0 : 1;
+  }
+  const bool from_checkpoint = !std::strcmp(argv[1], "--from-checkpoint");
+  if (from_checkpoint && argc < 4) return 2;
+  const int first_opt = from_checkpoint ? 4 : 3;
+  const char* scene_path = from_checkpoint ? nullptr : argv[1];
+  const char* out_path = from_checkpoint ? argv[3] : argv[2];
+  FullOVSLAMConfig config = FullOVSLAMConfig::base7a2Fallback();   // config/base7a_2_fallback.json
+  SlidingWindowParams& sw = config.sliding_window_params_;
+  int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  for (int i = first_opt; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) csv = argv[++i];
     else if (!std::strcmp(argv[i], "--ltm")) ltm = true;
+    else if (!std::strcmp(argv[i], "--save-checkpoint") && i + 1 < argc) checkpoint_dir = argv[++i];
+    else if (!std::strcmp(argv[i], "--iteration-log-dir") && i + 1 < argc) iteration_log_dir = argv[++i];
+    else if (!std::strcmp(argv[i], "--merge-distance") && i + 1 < argc) config.post_session_object_merge_params_.max_merge_distance_ = std::atof(argv[++i]);
     else if (!std::strcmp(argv[i], "--pending-objects")) pending = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
   }
+  if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
   OfflineProblemData data;
-  if (!loadScene(argv[1], &data)) { std::cerr << "could not read scene " << argv[1] << std::endl; return 2; }
+  MainPgPtr checkpoint_graph;
+  if (from_checkpoint) {
+    // run_opt_from_pg_state.cpp:160-312: the checkpoint's pose graph is handed out by the pose_graph_creator, no frame data is added,
+    // the optimisation starts at (and consists of) the last frame: final global BA, then the long-term map
+    ObjectAndReprojectionFeaturePoseGraphState st;
+    if (!readPoseGraphStateFromFile(argv[2], st)) return 2;
+    checkpoint_graph = MainPg::createObjectAndReprojectionFeaturePoseGraphFromState(st);
+    const auto& L = st.reprojection_low_level_feature_pose_graph_state_.low_level_pg_state_;
+    data.camera_intrinsics_by_camera_ = L.camera_intrinsics_by_camera_; data.camera_extrinsics_by_camera_ = L.camera_extrinsics_by_camera_;
+    data.robot_poses_.resize(L.max_frame_id_ + 1);
+    for (const auto& p : L.robot_poses_) if (p.first < data.robot_poses_.size()) data.robot_poses_[p.first] = convertToPose3D(p.second);
+    data.visual_obs_by_frame_.resize(data.robot_poses_.size()); data.box_obs_by_frame_.resize(data.robot_poses_.size());
+    data.shape_priors_by_class_ = st.obj_only_pose_graph_state_.mean_and_cov_by_semantic_class_;
+  } else if (!loadScene(scene_path, &data)) { std::cerr << "could not read scene " << scene_path << std::endl; return 2; }
   const FrameId max_frame_id = data.getMaxFrameId();
+  const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& rp = config.object_visual_pose_graph_residual_params_;
+  const pose_graph_optimizer::OptimizationFactorsEnabledParams& en = config.optimization_factors_enabled_params_;
 
-  // config/base7a_2_fallback.json
-  pose_graph_optimization::ObjectVisualPoseGraphResidualParams rp;
-  rp.object_residual_params_.object_observation_huber_loss_param_ = 0.5; rp.object_residual_params_.shape_dim_prior_factor_huber_loss_param_ = 10;
-  rp.object_residual_params_.invalid_ellipsoid_error_val_ = 1000; rp.visual_residual_params_.reprojection_error_huber_loss_param_ = 1.0;
-  rp.long_term_map_params_.pair_huber_loss_param_ = 1.0; rp.relative_pose_factor_huber_loss_ = 1.0;
-  pose_graph_optimizer::OptimizationFactorsEnabledParams en;
-  en.include_object_factors_ = true; en.include_visual_factors_ = true; en.fix_poses_ = en.fix_objects_ = en.fix_visual_features_ = en.fix_ltm_objects_ = false;
-  en.poses_prior_to_window_to_keep_constant_ = 5; en.min_object_observations_ = 10; en.min_low_level_feature_observations_ = 5; en.min_low_level_feature_observations_per_frame_ = 50;
-  en.use_pose_graph_on_global_ba_ = true; en.use_visual_features_on_global_ba_ = false; en.use_pose_graph_on_final_global_ba_ = true; en.use_visual_features_on_final_global_ba_ = true;
-  pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams pgo;
-  pgo.relative_pose_factor_huber_loss_ = 5.0; pgo.enable_visual_feats_only_opt_post_pgo_ = true; pgo.enable_visual_non_opt_feature_adjustment_post_pgo_ = true;
-  pgo.relative_pose_cov_params_ = {0.1, 0.1, 0.1, 0.1};
-  pgo.pgo_optimization_solver_params_ = sp(250, 1e-6); pgo.final_pgo_optimization_solver_params_ = sp(300, 1e-6);
-  pgo.post_pgo_vf_adjustment_solver_params_ = sp(250, 1e-6); pgo.final_post_pgo_vf_adjustment_solver_params_ = sp(300, 1e-6); pgo.pre_pgo_tracking_solver_params_ = sp(50, 1e-3);
-  pose_graph_optimization::OptimizationIterationParams local_ba, global_ba, final_ba;
-  local_ba.phase_one_opt_params_ = sp(50, 1e-3); local_ba.phase_two_opt_params_ = sp(100, 1e-4);
-  global_ba.phase_one_opt_params_ = sp(250, 1e-6); global_ba.phase_two_opt_params_ = sp(250, 1e-6);
-  final_ba.phase_one_opt_params_ = sp(300, 1e-6); final_ba.phase_two_opt_params_ = sp(300, 1e-6);
-
-  std::ofstream out(argv[2]);
+  std::ofstream out(out_path);
   out << std::setprecision(17);
   if (dump) {
     // flattening only: every frame's data goes into the pose graph, then one build for [min, max]
-    MainPgPtr pg = std::make_shared<MainPg>(data.camera_extrinsics_by_camera_, data.camera_intrinsics_by_camera_);
-    for (FrameId f = 0; f <= max_frame_id; ++f) addFrameDataToPoseGraph(data, pg, f, rp.relative_pose_cov_params_);
+    MainPgPtr pg = checkpoint_graph ? checkpoint_graph : std::make_shared<MainPg>(data.camera_extrinsics_by_camera_, data.camera_intrinsics_by_camera_);
+    if (!checkpoint_graph) for (FrameId f = 0; f <= max_frame_id; ++f) addFrameDataToPoseGraph(data, pg, f, rp.relative_pose_cov_params_);
     pose_graph_optimizer::OptimizationScopeParams scope;
     scope.min_low_level_feature_observations_per_frame_ = en.min_low_level_feature_observations_per_frame_;
     scope.poses_prior_to_window_to_keep_constant_ = en.poses_prior_to_window_to_keep_constant_;
@@ -133,6 +182,15 @@ int main(int argc, char** argv) {
     arr("frames", fp.frames); arr("features", fp.features); arr("objects", fp.objects); arr("pose_const", fp.pose_const); arr("point_const", fp.point_const);
     arr("object_const", fp.object_const); arr("rp_pose", fp.rp_pose); arr("rp_point", fp.rp_point); arr("rp_pixel", fp.rp_pixel); arr("bb_obj", fp.bb_obj); arr("bb_pose", fp.bb_pose);
     arr("sp_obj", fp.sp_obj); arr("rl_a", fp.rl_a); arr("rl_b", fp.rl_b);
+    {   // the whole flat problem: values of the parameter blocks and the measurement data (what solveOptimization uploads)
+      std::vector<double> poses, points, objects;
+      for (const double* q : fp.pose_ptrs) poses.insert(poses.end(), q, q + 6);
+      for (const double* q : fp.point_ptrs) points.insert(points.end(), q, q + 3);
+      for (const double* q : fp.object_ptrs) objects.insert(objects.end(), q, q + 7);
+      arr("poses", poses); arr("points", points); arr("object_values", objects); arr("cam_K", fp.cam_K); arr("cam_ext", fp.cam_ext);
+      arr("rp_cam", fp.rp_cam); arr("rp_sigma", fp.rp_sigma); arr("bb_cam", fp.bb_cam); arr("bb_corners", fp.bb_corners); arr("bb_cov", fp.bb_cov);
+      arr("sp_mean", fp.sp_mean); arr("sp_cov", fp.sp_cov); arr("rl_t", fp.rl_t); arr("rl_aa", fp.rl_aa); arr("rl_cov", fp.rl_cov);
+    }
     {   // factor ids of the residual blocks, family by family (blocks are ordered reprojection, bounding box, shape prior, LTM prior, relative pose)
       std::vector<double> ids[5];
       for (const auto& b : fp.blocks) {
@@ -169,7 +227,7 @@ int main(int argc, char** argv) {
     for (auto& i : info) { i.second.semantic_class_ = data.object_class_.at(i.first); rough[i.first] = data.initial_ellipsoids_.at(i.first); }
     PendingObjectEstimatorParams pe;
     pe.object_residual_params_ = rp.object_residual_params_;
-    pe.solver_params_ = sp(100, 1e-6);
+    pe.solver_params_ = FullOVSLAMConfig::solverParams(100, 1e-6);
     std::unordered_map<ObjectId, RawEllipsoid> refined;
     obvi_summary summary{};
     const bool ok = refineInitialEstimateForPendingObjects(rough, info, pg, data.shape_priors_by_class_, pe, device, &refined, &summary);
@@ -181,52 +239,20 @@ int main(int argc, char** argv) {
     return ok ? 0 : 1;
   }
 
-  std::function<FrameId(const FrameId&)> window_provider = [&](const FrameId& f) { return provideOptimizationWindow(f, max_frame_id, sw); };
-  std::function<bool(const FrameId&)> gba_checker = [&](const FrameId& f) { return f - window_provider(f) > sw.local_ba_window_size_; };   // optimization_runner.h:195-203
-  std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)> params_provider = [&](const FrameId& f) {              // :204-216
-    if (f == max_frame_id) return final_ba;
-    if (f % sw.global_ba_frequency_ == 0) return global_ba;
-    return local_ba;
-  };
-  OfflineProblemRunner runner(rp, pgo, window_provider, gba_checker, params_provider, device);
   std::optional<OptimizationLogger> logger;
+  // offline_object_visual_slam_main.cpp:672-681: the summary CSV lives in the logging directory, next to the per-iteration CSVs
+  if (csv.empty() && !iteration_log_dir.empty()) csv = (iteration_log_dir.back() == '/' ? iteration_log_dir : iteration_log_dir + "/") + "ceres_opt_summary.csv";
   if (!csv.empty()) logger.emplace(csv);
-  MainPgPtr pg;
-  runner.setExtractLongTermMap(ltm);
+  std::function<void(const OfflineProblemData&, MainPgPtr&)> creator;
+  if (from_checkpoint) creator = [&](const OfflineProblemData&, MainPgPtr& pg) { pg = checkpoint_graph; };
+  LongTermObjectMapAndResults results;
   const auto t_run0 = std::chrono::steady_clock::now();
-  const bool ok = runner.runOptimization(data, en, logger, pg);
+  const bool ok = runFullOptimization(logger, config, data, creator, checkpoint_dir, results, from_checkpoint ? max_frame_id : 0, !from_checkpoint, device, ltm);
   const auto t_run1 = std::chrono::steady_clock::now();
-  if (std::getenv("OBVI_HOST_TIMING")) {
-    runner.printTiming(std::cerr);
-    std::cerr << "driver: scene load + setup " << std::chrono::duration<double, std::milli>(t_run0 - t_main0).count() << " ms, runOptimization "
+  IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                     // offline_object_visual_slam_main.cpp:1108
+  if (std::getenv("OBVI_HOST_TIMING"))
+    std::cerr << "driver: scene load + setup " << std::chrono::duration<double, std::milli>(t_run0 - t_main0).count() << " ms, runFullOptimization "
               << std::chrono::duration<double, std::milli>(t_run1 - t_run0).count() << " ms" << std::endl;
-  }
-  out << "{\"ok\": " << (ok ? "true" : "false") << ", \"records\": [";
-  bool first = true;
-  for (const auto& r : runner.records()) {
-    out << (first ? "" : ",") << "\n {\"min_frame\": " << r.min_frame << ", \"max_frame\": " << r.max_frame << ", \"kind\": \"" << r.kind << "\", \"iterations\": " << r.iterations
-        << ", \"initial_cost\": " << r.initial_cost << ", \"final_cost\": " << r.final_cost << ", \"n_poses\": " << r.n_poses << ", \"n_features\": " << r.n_features
-        << ", \"n_objects\": " << r.n_objects << ", \"n_excluded\": " << r.n_excluded << "}";
-    first = false;
-  }
-  out << "],\n\"poses\": [";
-  if (pg) for (FrameId f = 0; f <= max_frame_id; ++f) { const RawPose3d p = pg->getRobotPose(f).value(); out << (f ? "," : "") << "[" << p[0] << "," << p[1] << "," << p[2] << "," << p[3] << "," << p[4] << "," << p[5] << "]"; }
-  out << "],\n\"objects\": {";
-  if (pg) { std::unordered_map<ObjectId, RawEllipsoid> objs; pg->getObjectEstimates(objs); bool f0 = true; for (const auto& o : objs) { out << (f0 ? "" : ",") << "\"" << o.first << "\": ["; for (int k = 0; k < 7; ++k) out << (k ? "," : "") << o.second[k]; out << "]"; f0 = false; } }
-  out << "}";
-  if (ltm) {   // long-term map: ellipsoid mean + 7x7 marginal covariance per object (the input of the next session's IndependentObjectMapFactor)
-    out << ",\n\"long_term_map\": {";
-    bool f0 = true;
-    for (const auto& e : runner.longTermMap()) {
-      out << (f0 ? "" : ",") << "\n \"" << e.object_id_ << "\": {\"mean\": [";
-      for (int k = 0; k < 7; ++k) out << (k ? "," : "") << e.ellipsoid_mean_[k];
-      out << "], \"covariance\": [";
-      for (int k = 0; k < 49; ++k) out << (k ? "," : "") << e.covariance_[k];
-      out << "]}";
-      f0 = false;
-    }
-    out << "}";
-  }
-  out << "}\n";
+  writeResults(out, ok, results, max_frame_id, ltm);
   return ok ? 0 : 1;
 }

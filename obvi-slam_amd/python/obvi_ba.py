@@ -244,6 +244,19 @@ class BundleAdjuster:
                                                       _ptr(out, C.c_double)), "object_covariances")
         return out
 
+    def set_parameter_priors(self, block_kind, block_idx, param_idx, mean, std_dev):
+        """ParameterPrior factors for the covariance extraction: kind 0 pose / 1 point / 2 object; empty arrays clear them."""
+        k = np.ascontiguousarray(block_kind, dtype=np.uint8); b = np.ascontiguousarray(block_idx, dtype=np.uint32)
+        q = np.ascontiguousarray(param_idx, dtype=np.uint8); m, sd = _f64(mean), _f64(std_dev)
+        self._check(self._fn("ba_set_parameter_priors")(self._h, C.c_int64(len(k)), _ptr(k, C.c_uint8), _ptr(b, C.c_uint32), _ptr(q, C.c_uint8),
+                                                        _ptr(m, C.c_double), _ptr(sd, C.c_double)), "set_parameter_priors")
+
+    def column_sqnorms(self):
+        """squared column norms of the robustified Jacobian per scalar parameter: (poses [P,6], points [L,3], objects [O,7]); -1 = not a parameter of the problem"""
+        p, l, o = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, 7))
+        self._check(self._fn("ba_column_sqnorms")(self._h, _ptr(p, C.c_double), _ptr(l, C.c_double), _ptr(o, C.c_double)), "column_sqnorms")
+        return p, l, o
+
     # ---- state ---------------------------------------------------------------------------
     def snapshot(self):
         self._check(self._fn("ba_snapshot")(self._h), "snapshot")

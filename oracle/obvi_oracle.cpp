@@ -87,6 +87,8 @@ struct OracleProblem {
   // relative pose
   int64_t n_rl = 0;
   std::vector<uint32_t> rl_a, rl_b; std::vector<double> rl_t, rl_R, rl_sqrt_inf; double rl_huber = 1.0; std::vector<uint8_t> rl_active;
+  // parameter priors (parameter_prior.h:17-50), used by the covariance extraction only: kind 0 pose / 1 point / 2 object
+  std::vector<uint8_t> pp_kind, pp_param; std::vector<uint32_t> pp_block; std::vector<double> pp_mean, pp_std;
   // snapshot
   std::vector<double> snap_poses, snap_points, snap_objects;
   // last solve
@@ -897,6 +899,14 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
   Reduced rd; build_reduced(pb, &rd);
   Workspace ws; linearize(pb, rd, &ws); build_envelope(pb, rd, &ws);
   std::vector<double> lam_c(rd.m, 0.0), lam_l(3 * pb.L, 0.0), Hinv;
+  // a ParameterPrior's Jacobian is 1 / std_dev in its parameter's column (its residual is zero at mean = estimate): 1 / std_dev^2 on the diagonal
+  for (size_t i = 0; i < pb.pp_kind.size(); ++i) {
+    const double w = 1.0 / (pb.pp_std[i] * pb.pp_std[i]);
+    const int64_t b = pb.pp_block[i];
+    if (pb.pp_kind[i] == 0 && rd.pose_vid[b] >= 0) lam_c[pose_row(rd, b) + pb.pp_param[i]] += w;
+    else if (pb.pp_kind[i] == 1 && rd.point_var[b]) lam_l[3 * b + pb.pp_param[i]] += w;
+    else if (pb.pp_kind[i] == 2 && rd.obj_vid[b] >= 0) lam_c[obj_row(rd, b) + pb.pp_param[i]] += w;
+  }
   if (!assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hinv)) return OBVI_ERR_NUMERICAL;
   if (!skyline_factor(&ws, rd.m)) return OBVI_ERR_NUMERICAL;
   std::vector<int32_t> solved_for(pb.O, -1);           // object -> slot in `cols`
@@ -917,6 +927,39 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
       }
     }
     for (int r = 0; r < 7; ++r) for (int k = 0; k < 7; ++k) out[7 * r + k] = cols[solved_for[b] + k][obj_row(rd, a) + r];
+  }
+  return OBVI_OK;
+}
+
+// ParameterPrior factors for the covariance extraction (long_term_object_map_extraction.cpp:764-927) and the squared column norms of
+// the robustified Jacobian they are chosen from (:585-608).
+int oracle_ba_set_parameter_priors(oracle_handle* h, int64_t n, const uint8_t* kind, const uint32_t* block, const uint8_t* param, const double* mean, const double* std_dev) {
+  if (!h || n < 0 || (n > 0 && (!kind || !block || !param || !mean || !std_dev))) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t cnt = kind[i] == 0 ? pb.P : kind[i] == 1 ? pb.L : kind[i] == 2 ? pb.O : -1;
+    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : 7;
+    if (cnt < 0 || param[i] >= dim) return OBVI_ERR_INVALID_ARGUMENT;
+    if ((int64_t)block[i] >= cnt) return OBVI_ERR_OUT_OF_RANGE;
+    if (!(std_dev[i] > 0.0) || !std::isfinite(std_dev[i]) || !std::isfinite(mean[i])) return OBVI_ERR_NUMERICAL;
+  }
+  pb.pp_kind.assign(kind, kind + n); pb.pp_block.assign(block, block + n); pb.pp_param.assign(param, param + n); pb.pp_mean.assign(mean, mean + n); pb.pp_std.assign(std_dev, std_dev + n);
+  return OBVI_OK;
+}
+int oracle_ba_column_sqnorms(oracle_handle* h, double* pose6, double* point3, double* object7) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OracleProblem& pb = h->pb;
+  Reduced rd; build_reduced(pb, &rd);
+  Workspace ws; linearize(pb, rd, &ws);
+  if (pose6) for (int64_t p = 0; p < pb.P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = rd.pose_vid[p] >= 0 ? ws.colsq_c[pose_row(rd, p) + k] : -1.0;
+  if (point3) for (int64_t l = 0; l < pb.L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = rd.point_var[l] ? ws.colsq_l[3 * l + k] : -1.0;
+  if (object7) for (int64_t o = 0; o < pb.O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = rd.obj_vid[o] >= 0 ? ws.colsq_c[obj_row(rd, o) + k] : -1.0;
+  for (size_t i = 0; i < pb.pp_kind.size(); ++i) {
+    const double w = 1.0 / (pb.pp_std[i] * pb.pp_std[i]);
+    const int64_t b = pb.pp_block[i];
+    if (pb.pp_kind[i] == 0 && pose6 && rd.pose_vid[b] >= 0) pose6[6 * b + pb.pp_param[i]] += w;
+    else if (pb.pp_kind[i] == 1 && point3 && rd.point_var[b]) point3[3 * b + pb.pp_param[i]] += w;
+    else if (pb.pp_kind[i] == 2 && object7 && rd.obj_vid[b] >= 0) object7[7 * b + pb.pp_param[i]] += w;
   }
   return OBVI_OK;
 }

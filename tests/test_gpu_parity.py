@@ -449,3 +449,43 @@ def test_object_covariances_at_local_ba_size():
     co, cg = o.object_covariances(ids), g.object_covariances(ids)
     assert np.count_nonzero(np.abs(co).max(axis=(1, 2))) >= 40
     assert covariance_close(cg, co, 1e-8)
+
+
+def test_column_norms_and_parameter_priors_of_the_covariance_extraction():
+    """long_term_object_map_extraction.cpp:585-608 (squared column norms of the robustified Jacobian), :764-927 (ParameterPrior
+    factors on the weakest columns) and the covariance with them.  A problem whose object 1 has lost every bounding box keeps that
+    object through its shape prior only: its position and yaw columns are exactly zero, Covariance::Compute fails (rank deficient),
+    and with priors on those four parameters it succeeds; HIP == oracle throughout, and the repaired block is what the priors say."""
+    prob = synth.make_problem(P=40, L=500, O=3, seed=19, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=6)
+    m_bb = (prob["bb_obj"] != 1).astype(np.uint8)
+    o, g = helpers.oracle_ba(), helpers.product_ba()
+    for ba in (o, g):
+        synth.upload(ba, prob)
+        ba.set_active_mask(2, m_bb)
+    (po, lo, oo), (pg, lg, og) = o.column_sqnorms(), g.column_sqnorms()
+    for a, b in ((pg, po), (lg, lo), (og, oo)):
+        assert np.array_equal(a < 0, b < 0)
+        live = b >= 0
+        assert np.abs(a[live] - b[live]).max() <= 1e-9 * b[live].max() and np.all(np.abs(a[live] - b[live]) <= 1e-7 * b[live] + 1e-12)
+    assert np.all(po[0] == -1) and np.all(og[1, :4] == 0.0) and np.all(og[1, 4:] > 0) and np.all(og[[0, 2]] > 0)
+    for ba in (o, g):
+        with pytest.raises(obvi_ba.ObviError, match="status -6"):
+            ba.object_covariances(np.arange(3))
+    sd = np.array([0.5, 0.25, 2.0, 0.1])
+    for ba in (o, g):
+        ba.set_parameter_priors(np.full(4, 2), np.full(4, 1), np.arange(4), prob["objects"][1, :4], sd)
+    co, cg = o.object_covariances(np.arange(3)), g.object_covariances(np.arange(3))
+    assert np.abs(cg - co).max() <= 1e-8 * np.abs(co).max()
+    assert np.allclose(np.diag(cg[1])[:4], sd ** 2, rtol=1e-9)          # nothing but the prior informs these four parameters
+    assert np.abs(cg[1][:4, 4:]).max() <= 1e-12 and np.all(np.linalg.eigvalsh(cg[1]) > 0)
+    (_, _, og2) = g.column_sqnorms()
+    assert np.allclose(og2[1, :4], 1.0 / sd ** 2, rtol=1e-12)           # the priors are columns of the Jacobian now
+    # the priors belong to the covariance extraction: the solve does not see them
+    s_with = g.solve(helpers.ba_params(max_it=3))
+    g2 = helpers.product_ba(); synth.upload(g2, prob); g2.set_active_mask(2, m_bb)
+    s_without = g2.solve(helpers.ba_params(max_it=3))
+    assert s_with.initial_cost == pytest.approx(s_without.initial_cost, rel=1e-13) and s_with.num_iterations == s_without.num_iterations
+    for ba in (o, g):
+        ba.set_parameter_priors([], [], [], [], [])
+    with pytest.raises(obvi_ba.ObviError, match="status -6"):
+        g.object_covariances(np.arange(3))

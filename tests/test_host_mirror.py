@@ -265,3 +265,92 @@ def test_pending_object_estimator_mirror(driver, tmp_path):
     est = g.get_objects()
     for i in range(len(new_id)):
         assert np.abs(np.array(res["objects"][str(i)]) - est[i]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_session_end_merge_rank_repair_and_iteration_logs(driver, tmp_path, monkeypatch):
+    """The rest of runFullOptimization's session end (optimization_runner.h:545-640, offline_problem_runner.h:254-262, 918-958,
+    long_term_object_map_extraction.cpp:929-1062) and the per-iteration CSVs (optimization_logger.h:29-147):
+      * an object that the front end split in two (same place, same class) is merged after the final global BA, which is re-run;
+      * an object whose every box falls in the constant invalid-ellipse branch (the camera is inside it) has zero Jacobian columns
+        for its pose: the covariance extraction fails, ParameterPriors are put on the weakest columns, and the retry succeeds;
+      * ceres_iterations_<type>.csv holds one row per LM iteration of every optimisation of that type."""
+    monkeypatch.setitem(synth.SHAPE_CLASSES, "hangar", ((300.0, 300.0, 300.0), (1.0, 1.0, 1.0)))
+    prob = synth.make_problem(P=80, L=1500, O=2, seed=21, min_obj_obs=30, bbox_noise=5.0, object_classes=("bench",), stereo=True)
+    n0 = len(prob["objects"])
+    assert n0 == 2
+    # split object 0: its later observations go to a new object 2 that starts 20 cm away
+    mine = np.flatnonzero(prob["bb_obj"] == 0)
+    later = mine[len(mine) // 2:]
+    assert len(mine) - len(later) >= 12 and len(later) >= 12
+    bb_obj = prob["bb_obj"].copy(); bb_obj[later] = n0
+    dup = prob["objects"][0].copy(); dup[0] += 0.2
+    # a degenerate object 3: the robot drives around inside it
+    frames = np.arange(10, 26)
+    hangar = np.array([0.0, 0.0, 0.0, 0.3, 300.0, 300.0, 300.0])
+    prob["objects"] = np.concatenate([prob["objects"], dup[None], hangar[None]])
+    prob["obj_class"] = list(prob["obj_class"]) + [prob["obj_class"][0], "hangar"]
+    prob["bb_obj"] = np.concatenate([bb_obj, np.full(len(frames), n0 + 1, np.uint32)]).astype(np.uint32)
+    prob["bb_pose"] = np.concatenate([prob["bb_pose"], frames]).astype(np.uint32)
+    prob["bb_cam"] = np.concatenate([prob["bb_cam"], np.zeros(len(frames), np.uint16)])
+    prob["bb_corners"] = np.concatenate([prob["bb_corners"], np.tile([100.0, 300.0, 80.0, 260.0], (len(frames), 1))])
+    prob["bb_cov"] = np.concatenate([prob["bb_cov"], np.tile(prob["bb_cov"][0], (len(frames), 1))])
+    scene = str(tmp_path / "scene.txt")
+    new_id = scene_io.write_scene(prob, scene)
+    logs = tmp_path / "logs"; logs.mkdir()
+    out = str(tmp_path / "out.json")
+    p = subprocess.run([driver, scene, out, "--window", "20", "--gba-frequency", "25", "--ltm", "--merge-distance", "1.0", "--iteration-log-dir", str(logs)],
+                       timeout=900, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["ok"]
+    # ---- merge: one of the two halves is gone, its boxes live on in the other, and the final BA ran once more (attempt 2) ----
+    a, b = str(new_id[0]), str(new_id[n0])
+    assert res["merge_rounds"] == 1 and (a in res["objects"]) != (b in res["objects"])
+    kinds = [r["kind"] for r in res["records"]]
+    assert kinds.count("gba_phase_1") == 2                                  # the final global BA and its re-run after the merge
+    survivor = res["objects"][a] if a in res["objects"] else res["objects"][b]
+    assert np.linalg.norm(np.array(survivor[:3]) - prob["gt_objects"][0][:3]) < 1.0
+    # ---- rank repair ----
+    g = new_id[n0 + 1]
+    rep = res["covariance_rank_repairs"]
+    mine = sorted(r["param_idx"] for r in rep if r["block_kind"] == 2 and r["block_id"] == g and r["retry"] == 1)
+    assert mine[:4] == [0, 1, 2, 3]                                         # x, y, z, yaw of the hangar: zero columns
+    assert all(r["col_sqnorm"] == 0.0 for r in rep if r["block_kind"] == 2 and r["block_id"] == g and r["param_idx"] < 4)
+    assert 4 <= len(rep) <= 4 + 51 and all(r["prior_std_dev"] > 0 and np.isfinite(r["prior_std_dev"]) for r in rep)
+    assert "Retrying rank deficient jacobian, retry num 1" in p.stderr
+    ltm = res["long_term_map"]
+    assert set(ltm) == set(res["objects"])
+    for oid, e in ltm.items():
+        cov = np.array(e["covariance"]).reshape(7, 7)
+        assert np.all(np.isfinite(cov)) and np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
+    sd = {r["param_idx"]: r["prior_std_dev"] for r in rep if r["block_kind"] == 2 and r["block_id"] == g}
+    cov_g = np.array(ltm[str(g)]["covariance"]).reshape(7, 7)
+    assert np.allclose(np.diag(cov_g)[:4], [sd[k] ** 2 for k in range(4)], rtol=1e-6)     # only the priors inform the hangar's pose
+    # ---- iteration logs ----
+    header = "optimization_id,iteration_num,cost,cost_change,step_norm,step_norm_per_param,is_successful"
+    rows = {}
+    for kind in ("lba_phase_1", "lba_phase_2", "gba_phase_1", "gba_phase_2", "pgo", "pre_pgo_track", "vf_adjust"):
+        lines = open(logs / ("ceres_iterations_%s.csv" % kind)).read().strip().split("\n")
+        assert lines[0] == header and len(lines) > 1
+        rows[kind] = [ln.split(",") for ln in lines[1:]]
+    # the logger calls an optimisation "global" when its window starts at frame 0 (offline_problem_runner.h:403-404, 808-809), whatever the
+    # runner's own local / global decision was: the first frames of a session land in the gba files
+    # ... and phase I of a visual BA that follows a PGO stage in the same iteration is not logged at all: the PGO stage's
+    # writeCurrentOptInfo() resets the logger's type flags (optimization_logger.h:283) and nothing sets them again before phase I
+    # (offline_problem_runner.h:403 comes before the PGO stage), so extractOptimizationTimingResults finds no type (:221-224).  Phase II
+    # sets them again (:808).  The mirror keeps the reference's behaviour.
+    n_iter = {k: 0 for k in ("lba_phase_1", "lba_phase_2", "gba_phase_1", "gba_phase_2")}
+    recs = res["records"]
+    for i, r in enumerate(recs):
+        if r["kind"][4:] not in ("phase_1", "phase_2"):
+            continue
+        if r["kind"][4:] == "phase_1" and i > 0 and recs[i - 1]["kind"] == "pgo" and recs[i - 1]["max_frame"] == r["max_frame"]:
+            continue
+        n_iter[("gba_" if r["min_frame"] == 0 else "lba_") + r["kind"][4:]] += r["iterations"]
+    assert {k: len(rows[k]) for k in n_iter} == n_iter                       # iterations.size() rows per optimisation, the iteration-0 record included
+    assert {"79_1", "79_2"} <= {r[0] for r in rows["gba_phase_2"]} and "1_0" in {r[0] for r in rows["gba_phase_1"]}   # "<max frame>_<attempt>"
+    assert {"79_1", "79_2"} <= {r[0] for r in rows["pgo"]}
+    assert all(r[0] == "%d_0" % int(r[0].split("_")[0]) for r in rows["lba_phase_1"])
+    first = [r for r in rows["lba_phase_1"] if r[0] == rows["lba_phase_1"][0][0]]
+    assert [int(r[1]) for r in first] == list(range(len(first))) and first[0][6] == "1"

@@ -178,6 +178,33 @@ def test_iteration_log_bookkeeping():
     assert abs(s.final_cost - min(i.cost for i in its)) <= 1e-15 * s.final_cost
 
 
+def test_parameter_priors_enter_the_covariance_as_jacobian_rows():
+    """oracle_ba_object_covariances with ParameterPrior factors == the blocks of the dense inverse of J^T J + diag(1 / std^2)."""
+    prob = small_problem()
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    base = ba.object_covariances(np.arange(len(prob["objects"])))
+    kind, blk, par, sd = [2, 2, 0, 1], [0, 1, 3, 5], [0, 3, 2, 1], [0.05, 0.02, 0.01, 0.03]
+    mean = [prob["objects"][0, 0], prob["objects"][1, 3], prob["poses"][3, 2], prob["points"][5, 1]]
+    ba.set_parameter_priors(kind, blk, par, mean, sd)
+    with_pr = ba.object_covariances(np.arange(len(prob["objects"])))
+    assert with_pr[0][0, 0] < base[0][0, 0] and with_pr[1][3, 3] < base[1][3, 3]        # information was added
+    assert with_pr[0][0, 0] <= sd[0] ** 2 and with_pr[1][3, 3] <= sd[1] ** 2
+    # dense check: H = J^T J from the reduced system at radius -> infinity, objects last; a prior on an object parameter is a diagonal term
+    S0, _ = ba.debug_reduced_system(1e300)
+    ba2 = helpers.oracle_ba(); synth.upload(ba2, prob)
+    only_obj = ([2, 2], [0, 1], [0, 3], mean[:2], sd[:2])
+    ba2.set_parameter_priors(*only_obj)
+    got = ba2.object_covariances(np.arange(len(prob["objects"])))
+    m = S0.shape[0]; nO = len(prob["objects"]); r0 = m - 7 * nO
+    S1 = S0.copy(); S1[r0 + 0, r0 + 0] += 1 / sd[0] ** 2; S1[r0 + 7 + 3, r0 + 7 + 3] += 1 / sd[1] ** 2
+    inv = np.linalg.inv(S1)
+    for k in range(nO):
+        blk_ = inv[r0 + 7 * k:r0 + 7 * k + 7, r0 + 7 * k:r0 + 7 * k + 7]
+        assert np.abs(got[k] - blk_).max() <= 1e-8 * np.abs(blk_).max()
+    p6, l3, o7 = ba.column_sqnorms()
+    assert np.all(p6[prob["pose_const"] == 1] == -1) and np.all(o7 > 0) and o7[0, 0] > 1 / sd[0] ** 2
+
+
 def test_host_threads_change_round_off_only():
     """bench.py's cpu_baseline runs the oracle with min(20, hardware) host threads (the reference's num_threads = 20): same factor
     records in the same order, bit-identical skyline factor (arrow split), only the order of the points' Schur contributions
