@@ -10,7 +10,13 @@
 
 #include "ba_math.h"
 
+struct obvi_ba_handle;
 namespace obvi {
+// what the front-end gating calls (frontend_kernels.hip) need of a handle: its device, its stream, its error slot
+hipStream_t handle_stream(obvi_ba_handle* h);
+int handle_device(const obvi_ba_handle* h);
+int handle_fail(obvi_ba_handle* h, int code, const char* msg);
+void make_dev_cam(const double* K4, const double* ext7, DevCam* out);
 
 // Tile edge of the reduced (Schur) system.  The reduced matrix is stored as a grid of
 // kTile x kTile fp64 tiles (row-major inside a tile, tiles row-major in the grid); only tiles

@@ -1288,6 +1288,13 @@ void set_mask(std::vector<uint8_t>& host, DevBuf<uint8_t>& dev, const uint8_t* m
 
 }  // namespace
 
+namespace obvi {
+hipStream_t handle_stream(obvi_ba_handle* h) { return h->stream; }
+int handle_device(const obvi_ba_handle* h) { return h->device; }
+int handle_fail(obvi_ba_handle* h, int code, const char* msg) { return fail(h, code, msg); }
+void make_dev_cam(const double* K4, const double* ext7, DevCam* out) { make_cam(K4, ext7, out); }
+}  // namespace obvi
+
 // =========================================================================================
 extern "C" {
 

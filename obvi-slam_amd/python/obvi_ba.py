@@ -63,6 +63,22 @@ class Summary(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
 
+class EpipolarParams(C.Structure):
+    """obvi_epipolar_params (include/obvi_frontend.h)."""
+    _fields_ = [("inlier_epipolar_err_thresh", C.c_double), ("inlier_majority_percentage", C.c_double), ("early_votes_return", C.c_int32), ("reserved", C.c_int32)]
+
+    def __init__(self, thresh=8.0, majority=0.5, early_return=True):
+        super().__init__(thresh, majority, int(early_return), 0)
+
+
+class ParallaxParams(C.Structure):
+    """obvi_parallax_params (include/obvi_frontend.h); defaults: config/base7a_2_fallback.json visual_feature_params."""
+    _fields_ = [("min_pixel", C.c_double), ("min_transl", C.c_double), ("min_orient", C.c_double), ("enforce_pixel", C.c_int32), ("enforce_pose", C.c_int32)]
+
+    def __init__(self, min_pixel=5.0, min_transl=0.1, min_orient=0.05, enforce_pixel=True, enforce_pose=False):
+        super().__init__(min_pixel, min_transl, min_orient, int(enforce_pixel), int(enforce_pose))
+
+
 class ObviError(RuntimeError):
     pass
 
@@ -256,6 +272,46 @@ class BundleAdjuster:
         p, l, o = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, 7))
         self._check(self._fn("ba_column_sqnorms")(self._h, _ptr(p, C.c_double), _ptr(l, C.c_double), _ptr(o, C.c_double)), "column_sqnorms")
         return p, l, o
+
+    # ---- visual-feature front-end gating (include/obvi_frontend.h) --------------------------
+    def _frontend_fn(self, name):
+        f = getattr(self._lib, self._pre + name)      # obvi_frontend_* / oracle_frontend_*
+        f.restype = C.c_int
+        return f
+
+    def epipolar_votes(self, K, ext, poses, cand_pose, cand_cam, cand_pixel, ref_ptr, ref_pose, ref_cam, ref_pixel, ref_frame, ref_skip, params=None):
+        K, ext, poses = _f64(K, (-1, 4)), _f64(ext, (-1, 7)), _f64(poses, (-1, 6))
+        cp = np.ascontiguousarray(cand_pose, dtype=np.uint32); cc = np.ascontiguousarray(cand_cam, dtype=np.uint16); cx = _f64(cand_pixel, (-1, 2))
+        rp = np.ascontiguousarray(ref_ptr, dtype=np.uint64); ro = np.ascontiguousarray(ref_pose, dtype=np.uint32); rc = np.ascontiguousarray(ref_cam, dtype=np.uint16)
+        rx = _f64(ref_pixel, (-1, 2)); rf = np.ascontiguousarray(ref_frame, dtype=np.uint32); rs = np.ascontiguousarray(ref_skip, dtype=np.uint8)
+        prm = params or EpipolarParams()
+        n = len(cp)
+        votes, voters, inl = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self._check(self._frontend_fn("frontend_epipolar_votes")(self._h, C.c_int32(len(K)), _ptr(K, C.c_double), _ptr(ext, C.c_double), C.c_int64(len(poses)), _ptr(poses, C.c_double),
+                                                                C.c_int64(n), _ptr(cp, C.c_uint32), _ptr(cc, C.c_uint16), _ptr(cx, C.c_double), _ptr(rp, C.c_uint64), _ptr(ro, C.c_uint32),
+                                                                _ptr(rc, C.c_uint16), _ptr(rx, C.c_double), _ptr(rf, C.c_uint32), _ptr(rs, C.c_uint8), C.byref(prm),
+                                                                _ptr(votes, C.c_uint32), _ptr(voters, C.c_uint32), _ptr(inl, C.c_uint8)), "frontend_epipolar_votes")
+        return votes, voters, inl
+
+    def epipolar_errors(self, K, ext, poses, cand_pose, cand_cam, cand_pixel, ref_ptr, ref_pose, ref_cam, ref_pixel):
+        K, ext, poses = _f64(K, (-1, 4)), _f64(ext, (-1, 7)), _f64(poses, (-1, 6))
+        cp = np.ascontiguousarray(cand_pose, dtype=np.uint32); cc = np.ascontiguousarray(cand_cam, dtype=np.uint16); cx = _f64(cand_pixel, (-1, 2))
+        rp = np.ascontiguousarray(ref_ptr, dtype=np.uint64); ro = np.ascontiguousarray(ref_pose, dtype=np.uint32); rc = np.ascontiguousarray(ref_cam, dtype=np.uint16)
+        rx = _f64(ref_pixel, (-1, 2))
+        err = np.zeros((len(ro), 2))
+        self._check(self._frontend_fn("frontend_epipolar_errors")(self._h, C.c_int32(len(K)), _ptr(K, C.c_double), _ptr(ext, C.c_double), C.c_int64(len(poses)), _ptr(poses, C.c_double),
+                                                                 C.c_int64(len(cp)), _ptr(cp, C.c_uint32), _ptr(cc, C.c_uint16), _ptr(cx, C.c_double), _ptr(rp, C.c_uint64), _ptr(ro, C.c_uint32),
+                                                                 _ptr(rc, C.c_uint16), _ptr(rx, C.c_double), _ptr(err, C.c_double)), "frontend_epipolar_errors")
+        return err
+
+    def parallax(self, frame_ptr, has_pose, poses, obs_ptr, pixels, params=None):
+        fp = np.ascontiguousarray(frame_ptr, dtype=np.uint64); hp = np.ascontiguousarray(has_pose, dtype=np.uint8); po = _f64(poses, (-1, 6))
+        op = np.ascontiguousarray(obs_ptr, dtype=np.uint64); px = _f64(pixels, (-1, 2))
+        prm = params or ParallaxParams()
+        out = np.zeros(len(fp) - 1, np.uint8)
+        self._check(self._frontend_fn("frontend_parallax")(self._h, C.c_int64(len(fp) - 1), _ptr(fp, C.c_uint64), _ptr(hp, C.c_uint8), _ptr(po, C.c_double), _ptr(op, C.c_uint64),
+                                                          _ptr(px, C.c_double), C.byref(prm), _ptr(out, C.c_uint8)), "frontend_parallax")
+        return out
 
     # ---- state ---------------------------------------------------------------------------
     def snapshot(self):

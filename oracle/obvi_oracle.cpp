@@ -41,7 +41,9 @@
 #include <thread>
 #include <vector>
 
+#include "../include/obvi_frontend.h"
 #include "oracle_factors.h"
+#include "oracle_frontend.h"
 
 namespace {
 using namespace oracle;  // NOLINT
@@ -1285,4 +1287,86 @@ int oracle_ellipsoid_corners(const double* ell7, const double* pose6, const doub
 int oracle_spd_inverse_sqrt(const double* cov, int n, double* out) { return spd_inverse_sqrt(cov, n, out) ? 1 : 0; }
 void oracle_huber(double s, double a, double* rho3) { huber(s, a, rho3); }
 
-}  // extern "C"
+
+// ---- visual-feature front-end gating (include/obvi_frontend.h; oracle_frontend.h restates the arithmetic) -------------------------
+static int oracle_epipolar(int32_t n_cams, const double* K4, const double* ext7, int64_t n_poses, const double* pose6, int64_t n_cand, const uint32_t* cand_pose,
+                           const uint16_t* cand_cam, const double* cand_pixel, const uint64_t* ref_ptr, const uint32_t* ref_pose, const uint16_t* ref_cam,
+                           const double* ref_pixel, const uint32_t* ref_frame, const uint8_t* ref_skip, const obvi_epipolar_params* prm, uint32_t* votes,
+                           uint32_t* voters, uint8_t* inlier, double* err) {
+  if (n_cand < 0 || n_cams < 0 || n_poses < 0) return OBVI_ERR_INVALID_ARGUMENT;
+  std::vector<oracle::Affine> cam_to_robot((size_t)n_cams), robot_to_world((size_t)n_poses);
+  for (int c = 0; c < n_cams; ++c) cam_to_robot[c] = oracle::affine_from_quat_translation(ext7 + 7 * c, ext7 + 7 * c + 4);
+  for (int64_t p = 0; p < n_poses; ++p) robot_to_world[p] = oracle::affine_from_pose6(pose6 + 6 * p);
+  for (int64_t i = 0; i < n_cand; ++i) {
+    const int c2 = cand_cam ? cand_cam[i] : 0;
+    if (cand_pose[i] >= (uint64_t)n_poses || c2 >= n_cams) return OBVI_ERR_OUT_OF_RANGE;
+    uint64_t v = 0, n = 0;
+    for (uint64_t k = ref_ptr[i]; k < ref_ptr[i + 1]; ++k) {
+      const int c1 = ref_cam ? ref_cam[k] : 0;
+      if (ref_pose[k] >= (uint64_t)n_poses || c1 >= n_cams) return OBVI_ERR_OUT_OF_RANGE;
+      if (!err) {
+        if (prm->early_votes_return && k > ref_ptr[i] && ref_frame[k] != ref_frame[ref_ptr[i]]) break;   // :596-599
+        if (ref_skip && ref_skip[k]) continue;                                                            // :551-553
+      }
+      double e[2];
+      oracle::epipolar_error_vec(K4 + 4 * c1, K4 + 4 * c2, cam_to_robot[c1], cam_to_robot[c2], ref_pixel + 2 * k, cand_pixel + 2 * i, robot_to_world[ref_pose[k]],
+                                 robot_to_world[cand_pose[i]], e);
+      if (err) { err[2 * k] = e[0]; err[2 * k + 1] = e[1]; continue; }
+      if (std::sqrt(e[0] * e[0] + e[1] * e[1]) < prm->inlier_epipolar_err_thresh) ++v;
+      ++n;
+    }
+    if (err) continue;
+    if (votes) votes[i] = (uint32_t)v;
+    if (voters) voters[i] = (uint32_t)n;
+    if (inlier) inlier[i] = (((double)v) / n) > prm->inlier_majority_percentage ? 1 : 0;
+  }
+  return OBVI_OK;
+}
+int oracle_frontend_epipolar_votes(oracle_handle*, int32_t n_cams, const double* K4, const double* ext7, int64_t n_poses, const double* pose6, int64_t n_cand,
+                                   const uint32_t* cand_pose, const uint16_t* cand_cam, const double* cand_pixel, const uint64_t* ref_ptr, const uint32_t* ref_pose,
+                                   const uint16_t* ref_cam, const double* ref_pixel, const uint32_t* ref_frame, const uint8_t* ref_skip, const obvi_epipolar_params* prm,
+                                   uint32_t* votes, uint32_t* voters, uint8_t* inlier) {
+  if (!prm) return OBVI_ERR_INVALID_ARGUMENT;
+  return oracle_epipolar(n_cams, K4, ext7, n_poses, pose6, n_cand, cand_pose, cand_cam, cand_pixel, ref_ptr, ref_pose, ref_cam, ref_pixel, ref_frame, ref_skip, prm, votes, voters, inlier, nullptr);
+}
+int oracle_frontend_epipolar_errors(oracle_handle*, int32_t n_cams, const double* K4, const double* ext7, int64_t n_poses, const double* pose6, int64_t n_cand,
+                                    const uint32_t* cand_pose, const uint16_t* cand_cam, const double* cand_pixel, const uint64_t* ref_ptr, const uint32_t* ref_pose,
+                                    const uint16_t* ref_cam, const double* ref_pixel, double* err) {
+  if (!err) return OBVI_ERR_INVALID_ARGUMENT;
+  return oracle_epipolar(n_cams, K4, ext7, n_poses, pose6, n_cand, cand_pose, cand_cam, cand_pixel, ref_ptr, ref_pose, ref_cam, ref_pixel, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, err);
+}
+int oracle_frontend_parallax(oracle_handle*, int64_t n_feat, const uint64_t* frame_ptr, const uint8_t* has_pose, const double* pose6, const uint64_t* obs_ptr,
+                             const double* pixel, const obvi_parallax_params* prm, uint8_t* satisfied) {
+  if (n_feat < 0 || !prm) return OBVI_ERR_INVALID_ARGUMENT;
+  for (int64_t f = 0; f < n_feat; ++f) {
+    const uint64_t k0 = frame_ptr[f], k1 = frame_ptr[f + 1];
+    bool found = false;
+    if (k1 - k0 > 1)
+      for (uint64_t i = k0; i + 1 < k1 && !found; ++i)
+        for (uint64_t j = i + 1; j < k1 && !found; ++j) {
+          bool pixel_req = false, pose_req = false;
+          if (prm->enforce_min_robot_pose_parallax_requirement && has_pose[i] && has_pose[j]) {
+            double tn, ang;
+            oracle::relative_motion(pose6 + 6 * i, pose6 + 6 * j, &tn, &ang);
+            if (tn >= prm->min_visual_feature_parallax_robot_transl_requirement || ang >= prm->min_visual_feature_parallax_robot_orient_requirement) pose_req = true;
+          }
+          if (prm->enforce_min_pixel_parallax_requirement)
+            for (uint64_t a = obs_ptr[i]; a < obs_ptr[i + 1]; ++a)
+              for (uint64_t c = obs_ptr[j]; c < obs_ptr[j + 1]; ++c) {
+                const double dx = pixel[2 * a] - pixel[2 * c], dy = pixel[2 * a + 1] - pixel[2 * c + 1];
+                if (std::sqrt(dx * dx + dy * dy) >= prm->min_visual_feature_parallax_pixel_requirement) pixel_req = true;
+              }
+          bool req;
+          if (prm->enforce_min_robot_pose_parallax_requirement && !prm->enforce_min_pixel_parallax_requirement) req = pose_req;
+          else if (!prm->enforce_min_robot_pose_parallax_requirement && prm->enforce_min_pixel_parallax_requirement) req = pixel_req;
+          else if (prm->enforce_min_robot_pose_parallax_requirement && prm->enforce_min_pixel_parallax_requirement) req = pose_req && pixel_req;
+          else req = true;
+          if (req) found = true;
+        }
+    satisfied[f] = found ? 1 : 0;
+  }
+  return OBVI_OK;
+}
+
+}
+
