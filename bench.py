@@ -51,34 +51,52 @@ def solver_params(obvi_ba, iters):
                                 max_trust_region_radius=1e4)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes).  None if not measured."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+def profile_manifest():
+    """profiles/manifest.json (scripts/profile_round.sh): which build the committed profiles measured.  Returns (manifest, stale):
+    stale is a reason string when the kernel sources this run uses are not the ones the profiles were taken on."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from source_sha import kernel_source_sha
+    path = os.path.join(ROOT, "profiles", "manifest.json")
     try:
-        return json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
-    except (ValueError, OSError):
+        man = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "profiles/manifest.json missing"
+    now = kernel_source_sha()
+    if man.get("kernel_source_sha") != now:
+        return man, "profiles/ were measured on kernel sources %s, this run uses %s: re-run scripts/profile_round.sh" % (man.get("kernel_source_sha"), now)
+    return man, None
+
+
+def pmc_traffic(kernel, man):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    --pmc runs, corrected as MI355X_MICROARCH.md prescribes; scripts/pmc_summary.py).  None if not measured."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", man["files"]["pmc_traffic"]))).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (ValueError, OSError, KeyError, TypeError):
         return None
 
 
-def rocprof_avg_us(kernel):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r01_kernel_stats_cfg3.csv); kernel only, without the launch boundary that a HIP-event bracket includes."""
-    path = os.path.join(ROOT, "profiles", "r01_kernel_stats_cfg3.csv")
-    if not os.path.exists(path):
-        return None
+def rocprof_avg_us(kernel, man):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command; kernel only,
+    without the launch boundary that a HIP-event bracket includes."""
     try:
         import csv
         import re
         pat = re.compile(r"\bk_" + re.escape(kernel[2:] if kernel.startswith("k_") else kernel) + r"[(<]")   # phase names lack the k_ prefix
-        for row in csv.DictReader(open(path)):
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", man["files"]["kernel_stats"]))):
             if pat.search(row["Name"]):
                 return round(float(row["AverageNs"]) / 1e3, 2)
-    except (ValueError, OSError, KeyError):
+    except (ValueError, OSError, KeyError, TypeError):
         pass
     return None
+
+
+def sq_counters(kernel, man):
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", man["files"]["sq_counters"])))["kernels"].get(kernel if kernel.startswith("k_") else "k_" + kernel)
+        return {k: round(e[k], 4) for k in ("mfma_busy_frac", "active_frac", "wait_frac", "issue_stall_frac") if k in e} if e else None
+    except (ValueError, OSError, KeyError, TypeError):
+        return None
 
 
 def cpu_baseline(prob, budget_iters=3):
@@ -281,12 +299,16 @@ def main():
             table[name] = row
         dom = max(table, key=lambda k: table[k]["ms_per_step"])
         d = table[dom]
+        man, stale = profile_manifest()
+        fresh = man if stale is None else None
         roof = {"kernel": dom, "bound": d.get("bound", "hbm"), "achieved": d.get("achieved"), "peak": HBM_PEAK_GBS if d.get("bound", "hbm") == "hbm" else FP64_MATRIX_PEAK_TF,
-                "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "traffic": pmc_traffic(dom),
-                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "rocprof_avg_us": rocprof_avg_us(dom),
-                "note": "dominant kernel by device time per LM step; durations from HIP events around every launch (they include the launch "
-                        "boundary, about 3 us) in an instrumented solve of the same steps; rocprof_avg_us = kernel-only average of the committed "
-                        "rocprofv3 summary (profiles/)"}
+                "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "traffic": pmc_traffic(dom, fresh),
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "rocprof_avg_us": rocprof_avg_us(dom, fresh), "sq": sq_counters(dom, fresh),
+                "profiles": {"tag": man.get("tag") if man else None, "kernel_source_sha": man.get("kernel_source_sha") if man else None, "stale": stale},
+                "note": "dominant kernel by device time per LM step; achieved / frac from HIP events around every launch (they include the launch "
+                        "boundary, about 3 us) in an instrumented solve of the same steps in THIS run; traffic, rocprof_avg_us and sq come from the "
+                        "rocprofv3 passes committed under profiles/ and are null when profiles/manifest.json was not measured on the kernel sources "
+                        "this run uses (profiles.stale says why)"}
         out = {
             "metric": "global-BA LM iterations/s" if not cfg.get("shared") else "local-BA LM iterations/s (windows sharing objects)", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),

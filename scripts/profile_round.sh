@@ -1,16 +1,63 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): scripts/profile_round.sh <tag>
-# Writes under gpurun_out/<tag>/: the bench JSON line, the rocprofv3 kernel stats of the same command, and HBM read / write
-# bytes per kernel from two separate counter-only passes (FETCH_SIZE, WRITE_SIZE).  Copy what should be kept to profiles/.
+# Everything the judge needs to recompute the bench line's roofline from files: written under gpurun_out/<tag>/ (copy to profiles/):
+#   <tag>_bench_cfg3.json            the bench line (python bench.py, defaults)
+#   <tag>_kernel_stats_cfg3.csv      rocprofv3 --kernel-trace --stats of the same command
+#   <tag>_pmc_fetch.csv / _write.csv FETCH_SIZE and WRITE_SIZE, separate counter-only passes (MI355X_MICROARCH.md "HBM")
+#   <tag>_pmc_traffic.json           per-kernel HBM bytes per launch (scripts/pmc_summary.py: corrections documented there)
+#   <tag>_sq_counters.json           SQ / GRBM counters per kernel: MFMA busy, wave cycles, issue / wait split
+#   manifest.json                    tag, git HEAD, kernel_source_sha (scripts/source_sha.py): bench.py checks it
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+SHA=$(python3 $R/scripts/source_sha.py)
 cd /tmp && export TMPDIR=/tmp
-timeout 300 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o cfg3 -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout 600 python $R/bench.py > $OUT/${TAG}_bench_cfg3.json 2> $OUT/bench.err
+rm -rf /tmp/pr_trace; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_trace -o cfg3 -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_cfg3_under_rocprof.json 2> $OUT/rocprof.err
+cp $(find /tmp/pr_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_cfg3.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
+  rm -rf /tmp/pr_$C
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pr_$C -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
 done
-ls $OUT $OUT/trace | head -30
-grep -h metric $OUT/bench.json | cut -c1-400
+F=$(find /tmp/pr_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/pr_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 $R/scripts/pmc_summary.py "$F" "$W" $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic_cfg3.txt
+rm -rf /tmp/pr_sq
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+  --output-format csv -d /tmp/pr_sq -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
+python3 - "$(find /tmp/pr_sq -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_sq_counters.json <<'PY'
+import collections, csv, json, re, sys
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
+try:
+    rows = list(csv.DictReader(open(sys.argv[1])))
+except OSError:
+    rows = []
+for r in rows:
+    m = re.search(r"(k_\w+)", r["Kernel_Name"]); k = m.group(1) if m else r["Kernel_Name"][:40]
+    tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+out = {"_method": "rocprofv3 --pmc (one counter-only pass, 8 SQ slots + GRBM) of `bench.py --steps 4 --warmup 1 --no-cpu-baseline`; per launch averages. "
+                  "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts, SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs "
+                  "(MI355X_MICROARCH.md); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) -- the gfx94x MfmaUtil formula", "kernels": {}}
+for k in tot:
+    e = {c: tot[k][c] / max(1, n[k][c]) for c in tot[k]}
+    e["launches"] = max(n[k].values())
+    if e.get("GRBM_GUI_ACTIVE"):
+        e["mfma_busy_frac"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (e["GRBM_GUI_ACTIVE"] * 256 * 4)
+    if e.get("SQ_WAVE_CYCLES"):
+        e["wait_frac"] = e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"]; e["issue_stall_frac"] = e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
+        e["active_frac"] = e.get("SQ_ACTIVE_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
+    out["kernels"][k] = e
+json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1]["launches"])[:12]:
+    print("%-22s launches %5d  mfma_busy %6.3f  active %5.2f  wait %5.2f  issue-stall %5.2f" % (k, e["launches"], e.get("mfma_busy_frac", float("nan")), e.get("active_frac", float("nan")), e.get("wait_frac", float("nan")), e.get("issue_stall_frac", float("nan"))))
+PY
+python3 - $OUT $TAG $SHA <<'PY'
+import json, os, subprocess, sys
+out, tag, sha = sys.argv[1:4]
+json.dump({"tag": tag, "kernel_source_sha": sha, "files": {"bench": tag + "_bench_cfg3.json", "kernel_stats": tag + "_kernel_stats_cfg3.csv", "pmc_traffic": tag + "_pmc_traffic.json",
+                                                              "sq_counters": tag + "_sq_counters.json"},
+           "note": "measured by scripts/profile_round.sh on one MI355X; kernel_source_sha = scripts/source_sha.py over obvi-slam_amd/csrc at measurement time"},
+          open(os.path.join(out, "manifest.json"), "w"), indent=1)
+PY
+ls $OUT | head -30
+grep -h metric $OUT/${TAG}_bench_cfg3.json | cut -c1-300

@@ -28,6 +28,24 @@ def test_exports_every_declared_symbol(lib):
     assert not missing, missing
 
 
+def test_frontend_and_rccl_libraries_export_their_headers(lib):
+    import __graft_entry__ as ge
+    front = ge.abi_symbols("obvi_frontend.h", "obvi_frontend_")
+    assert set(front) == {"obvi_frontend_epipolar_votes", "obvi_frontend_epipolar_errors", "obvi_frontend_parallax"}
+    assert not [s for s in front if not hasattr(lib, s)]
+    o = C.CDLL(helpers.ensure_oracle())
+    assert all(hasattr(o, s.replace("obvi_", "oracle_", 1)) for s in front)
+    rccl_path = os.path.join(os.path.dirname(helpers.PRODUCT_LIB), "libobvi_rccl.so")
+    syms = ge.abi_symbols("obvi_rccl.h", "obvi_rccl_")
+    assert len(syms) >= 10 and "obvi_rccl_allreduce" in syms
+    rccl = C.CDLL(rccl_path)                       # links librccl: loads without a GPU; communicators need one
+    assert not [s for s in syms if not hasattr(rccl, s)]
+    # libobvi_ba.so itself must not depend on RCCL (the collective is a callback)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", helpers.PRODUCT_LIB], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+
+
 def test_oracle_mirrors_the_abi():
     o = C.CDLL(helpers.ensure_oracle())
     skip = {"obvi_ba_last_error", "obvi_ba_version", "obvi_ba_set_allreduce", "obvi_ba_get_kernel_times", "obvi_ba_get_problem_stats", "obvi_ba_set_shared_objects", "obvi_ba_set_profiling"}
