@@ -206,6 +206,7 @@ struct CholPlan {
   const int32_t* row_ptr;     // device [nt+1]      row structure of L: columns j < k with L(k,j) != 0 (forward substitution with many right-hand sides)
   const int32_t* row_j;       // device
 };
+void launch_publish_scalars(hipStream_t s, const double* scal, double* host_pinned, int n, double seq);   // n <= 64
 void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2);
 // small accumulators cleared at the start of an LM step, together with the tiles (one launch)
 struct StepClear {

@@ -11,6 +11,7 @@
 #include "../../include/obvi_ba.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -122,7 +123,8 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_sel_mask;
   DevBuf<uint32_t> d_rp_inv;
   SelectScratch sel_scratch;
-  double* h_scal = nullptr;  // pinned
+  double* h_scal = nullptr;  // pinned; [SC_COUNT] is the sequence number k_publish_scalars writes last
+  double scal_seq = 0.0;
 
   // ---- reduced-program bookkeeping (prepare()) ----
   bool dirty = true;                     // the symbolic plan must be rebuilt (blocks / factors / constness changed)
@@ -211,6 +213,21 @@ void make_cam(const double* K4, const double* e, DevCam* c) {
 }
 
 void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
+
+// Waits for the scalar block of the step just submitted: polls the sequence number the device writes behind the block, and asks the
+// stream now and then so that a failed launch surfaces as an error instead of a hang.
+void wait_scalars(obvi_ba_handle* h) {
+  volatile const double* seq = h->h_scal + SC_COUNT;
+  for (;;) {
+    for (int spin = 0; spin < 4096; ++spin) {
+      if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+      __builtin_ia32_pause();
+    }
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) { if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; } sync(h); if (*seq != h->scal_seq) throw HipError{hipErrorUnknown, "the step's scalar block never arrived", __FILE__, __LINE__}; return; }
+    if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery", __FILE__, __LINE__};
+  }
+}
 
 BlocksDev blocks_dev(const obvi_ba_handle* h) {
   BlocksDev b;
@@ -1216,11 +1233,14 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     if (h->allreduce(h->allreduce_user, scal + SC_COST, SC_SUM_END - SC_COST, 0, s) || h->allreduce(h->allreduce_user, scal + SC_GMAX_BITS, 1, 1, s))
       throw HipError{hipErrorUnknown, "allreduce hook (scalars)", __FILE__, __LINE__};
   }
-  OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+  static const bool poll_ok = !std::getenv("OBVI_POLL_SCALARS") || std::atoi(std::getenv("OBVI_POLL_SCALARS")) != 0;   // tuning knob
+  const bool poll = poll_ok && h->profiling < 1 && !keep_factor;
+  if (poll) { h->scal_seq += 1.0; launch_publish_scalars(s, scal, h->h_scal, SC_COUNT, h->scal_seq); }
+  else OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   // the clear of the next LM step does not depend on the accept / reject decision: it runs while the host takes it
   // (not when the caller goes on to use the factor that is in the tiles: covariance extraction)
   if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
-  sync(h);
+  if (poll) wait_scalars(h); else sync(h);
   if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) throw HipError{hipErrorLaunchTimeOut, "tile Cholesky: a potrf workgroup timed out waiting for the previous level's update jobs (set OBVI_FUSED_POTRF=0 for the two-launch schedule)", __FILE__, __LINE__};
   for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
@@ -1315,8 +1335,8 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   try {
     OBVI_HIP(hipSetDevice(dev));
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * SC_COUNT, hipHostMallocDefault));
-    std::memset(h->h_scal, 0, sizeof(double) * SC_COUNT);
+    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocDefault));
+    std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
     h->d_scal.resize(SC_COUNT);
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
@@ -1883,6 +1903,9 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   double x_cost = 0, x_norm = 0, minimum_cost = 0, current_cost = 0, reference_cost = 0, candidate_cost_ev = 0, acc_ref_model = 0, acc_cand_model = 0;
   double best_cost = 0;
   bool have_best = false;
+  // The minimum-cost iterate is kept by buffer rotation, not by copying: while it IS the current point (`best_is_current`) an accepted
+  // step parks the old current buffers as `best` and takes the superseded best buffers for the next candidate.
+  bool best_is_current = false;
 
   obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
   bool pending_accept = false;   // `it` is an accepted step waiting for the gradient of its new point
@@ -1921,7 +1944,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
       if (!have_best || x_cost < best_cost) {
         // the minimum-cost iterate is what Ceres hands back [Ceres-doc trust_region_minimizer.cc]
         best_cost = x_cost; have_best = true;
-        copy_current(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
+        best_is_current = true;
       }
       first = false; pending_accept = false;
       if (!push_and_check(it)) break;
@@ -1964,6 +1987,10 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     if (it.relative_decrease > kMinRelDecrease) {
       // HandleSuccessfulStep: the candidate becomes the current point
       h->d_pose.swap(h->d_pose_c); h->d_point.swap(h->d_point_c); h->d_obj.swap(h->d_obj_c); h->d_pc.swap(h->d_pc_c);   // the candidate's pose cache comes along
+      if (best_is_current) {   // the point just left is the best so far: it stays where it is, the old best buffers take the next candidate
+        h->d_pose_c.swap(h->d_pose_b); h->d_point_c.swap(h->d_point_b); h->d_obj_c.swap(h->d_obj_b);
+        best_is_current = false;
+      }
       it.step_is_successful = 1;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));  // StepAccepted
       radius = std::min(max_radius, radius);
@@ -1986,7 +2013,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   }
   // hand back the minimum-cost iterate; after a FAILURE the state at entry
   if (sum->termination_type == OBVI_FAILURE) restore_from(h, h->d_pose_e, h->d_point_e, h->d_obj_e);
-  else if (have_best) restore_from(h, h->d_pose_b, h->d_point_b, h->d_obj_b);
+  else if (have_best && !best_is_current) { restore_from(h, h->d_pose_b, h->d_point_b, h->d_obj_b); h->pc_valid = false; }
   sync(h);
   return OBVI_OK;
   OBVI_API_END(h)
