@@ -946,7 +946,8 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
 // batch is one gather (slot table entry -> global_load_lds_dwordx4, all 256 lanes) issued while the previous batch is
 // multiplied; the table entries of the batch after that ride in registers.  An operand is then a single ds_read_b64 at
 // (slot + fo - first) * 144 + 8 (3 x + (l>>4)), lanes without an operand read a zero.
-// Every wavefront adds its tiles to the tile grid once, at the end (fp64 hardware atomics; 15 tiles per stream).
+// The workgroup adds its tiles to the tile grid once, at the end: the four streams' accumulators are summed through LDS, then fp64
+// hardware atomics (15 tiles per workgroup).
 // Pairs whose frames are further apart than the strip (loop closures, very long tracks) go to k_schur_blocks.
 // ---------------------------------------------------------------------------------------
 constexpr int kSR = kSchurRows, kSFr = kSchurWindowFrames, kSBack = kSFr - kSR;
@@ -1097,26 +1098,42 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
     if (bi + 1 < b1) batch(bi + 1, Buf1{}, Buf0{});
   }
 
-  // ---- add this wavefront's tiles to the tile grid: tile (r, cbase + c), lane, register q -> row 16 r + kq + 4 q, column 16 (cbase + c) + m
+  // ---- add the workgroup's tiles to the tile grid: tile (r, cbase + c), lane, register q -> row 16 r + kq + 4 q, column 16 (cbase + c) + m.
+  //      The four wavefronts hold private accumulators of the same strip: they are summed through LDS first (the batch buffers are free),
+  //      tile column by tile column, so that the strip costs one set of atomics instead of four.
+  static_assert(kSWv * kSTR * 4 * 64 * sizeof(double) <= kSchurBatchBytes && (kSTR * 4) % kSWv == 0, "one tile column of every wavefront fits a batch buffer");
+  double* red = reinterpret_cast<double*>(&zbuf0[0]);   // [wavefront][r][q][lane]
+  __syncthreads();
 #pragma unroll
-  for (int c = 0; c < kSGC; ++c)
+  for (int c = 0; c < kSGC; ++c) {
 #pragma unroll
     for (int r = 0; r < kSTR; ++r) {
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[c][r]));   // 16-pass MFMA result -> VALU read: 18 wait states
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double v = acc[c][r][q];
-        if (v == 0.0) continue;
+      for (int q = 0; q < 4; ++q) red[((wv * kSTR + r) * 4 + q) * 64 + lane] = acc[c][r][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSTR * 4 / kSWv; ++i) {
+      const int pq = (kSTR * 4 / kSWv) * wv + i, r = pq >> 2, q = pq & 3;   // wave-uniform
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kSWv; ++w) v += red[((w * kSTR + r) * 4 + q) * 64 + lane];
+      if (v != 0.0) {
         const int row = 16 * r + kq + 4 * q, col = 16 * (cbase + c) + m;
         const int fp = kSBack + row / 6, x = row % 6, fq = col / 6, y = col % 6;
-        if (fq > fp || (fq == fp && y > x)) continue;
-        const int64_t rp_ = rown[fp], rq_ = rown[fq];
-        if (rp_ < 0 || rq_ < 0) continue;
-        if (fq == fp) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rp_ + y), -v);
-        else if (rp_ > rq_) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rq_ + y), -v);
-        else atomic_add_f64(S_at(rd.S, rd.nt, rq_ + y, rp_ + x), -v);
+        if (!(fq > fp || (fq == fp && y > x))) {
+          const int64_t rp_ = rown[fp], rq_ = rown[fq];
+          if (rp_ >= 0 && rq_ >= 0) {
+            if (fq == fp) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rp_ + y), -v);
+            else if (rp_ > rq_) atomic_add_f64(S_at(rd.S, rd.nt, rp_ + x, rq_ + y), -v);
+            else atomic_add_f64(S_at(rd.S, rd.nt, rq_ + y, rp_ + x), -v);
+          }
+        }
       }
     }
+    __syncthreads();
+  }
   if (with_rhs) {
 #pragma unroll
     for (int r = 0; r < kSTR; ++r) {
