@@ -137,7 +137,7 @@ struct obvi_ba_handle {
   int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, num_params = 0, num_residuals = 0;
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
-  int32_t nlevels = 0;
+  int32_t nlevels = 0, nbw = 0;
   std::vector<int32_t> h_lvl_k_ptr, h_trsm_ptr, h_upd_ptr, h_rh_ptr, h_crit_upd, h_crit_rh, h_slices, h_bw_ptr;
   std::vector<int32_t> h_pose_row, h_obj_row, h_row_of_nat;   // reduced pose / object index -> first row of its diagonal block in the tile grid
   std::vector<uint8_t> h_is_pad;                // rows of the tile grid that belong to no block (identity)
@@ -283,7 +283,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
-  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
+  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.nbw = h->nbw; c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
   c.row_ptr = h->d_row_ptr.get(); c.row_j = h->d_row_j.get();
   c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.pre_ptr = h->d_pre_ptr.get(); c.pre_j = h->d_pre_j.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
@@ -942,15 +942,32 @@ void prepare(obvi_ba_handle* h) {
     if (std::getenv("OBVI_DEBUG_PLAN")) std::fprintf(stderr, "level %d: columns %zu (first %d) trsm %zu update jobs %zu (critical %d) products %zu slices %d\n", l, by_level[l].size(), by_level[l].empty() ? -1 : by_level[l][0], ik.size(), jobs.size(), h->h_crit_upd[l], trips.size(), sl);
   }
   stage("level jobs");
-  // backward substitution, row oriented: one workgroup per tile of L
+  // backward substitution, row oriented: one workgroup per tile of L.  A launch takes two levels (l + 1, l): a row of level l whose
+  // parent column is at level l + 1 forms the parent's y itself (k_backward) and the tile between the two gets no workgroup.
+  // The launches are listed in the order of the forward levels and run last to first.
   std::vector<int32_t> bw_kj;
-  h->h_bw_ptr.assign(nlev + 1, 0);
-  for (int l = 0; l < nlev; ++l) {
-    for (int32_t k : by_level[l]) {
-      bw_kj.push_back(k); bw_kj.push_back(-1);
-      for (int j = 0; j < k; ++j) if (mask[(size_t)k * nt + j]) { bw_kj.push_back(k); bw_kj.push_back(j); }
+  const int bw_levels = std::max(1, std::min(2, env_int("OBVI_BACKWARD_LEVELS", 2)));   // tuning knob: levels per launch (1: one level per launch)
+  h->h_bw_ptr.assign(1, 0);
+  {
+    int top = nlev - 1;             // the levels are grouped from the top: (nlev-1, nlev-2), (nlev-3, nlev-4), ...
+    std::vector<std::pair<int, int>> groups;   // (lower level, upper level)
+    while (top >= 0) { const int lo = std::max(0, top - (bw_levels - 1)); groups.push_back({lo, top}); top = lo - 1; }
+    std::reverse(groups.begin(), groups.end());
+    for (const auto& g : groups) {
+      for (int l = g.first; l <= g.second; ++l)
+        for (int32_t k : by_level[l]) {
+          int32_t k1 = -1;   // the parent (first row of the column) if it belongs to the launch's upper level
+          if (l < g.second && col_ptr[k] < col_ptr[k + 1] && level[col_i[col_ptr[k]]] == g.second && l + 1 == g.second) k1 = col_i[col_ptr[k]];
+          bw_kj.push_back(k); bw_kj.push_back(-1); bw_kj.push_back(k1);
+          for (int j = 0; j < k; ++j) {
+            if (!mask[(size_t)k * nt + j]) continue;
+            if (l == g.second && g.first < g.second && level[j] == g.first && col_ptr[j] < col_ptr[j + 1] && col_i[col_ptr[j]] == k) continue;   // tile (k1, k0): folded into row k0
+            bw_kj.push_back(k); bw_kj.push_back(j); bw_kj.push_back(k1);
+          }
+        }
+      h->h_bw_ptr.push_back((int32_t)(bw_kj.size() / 3));
     }
-    h->h_bw_ptr[l + 1] = (int32_t)(bw_kj.size() / 2);
+    h->nbw = (int32_t)groups.size();
   }
   {   // row structure of L (forward substitution with many right-hand sides: covariance extraction)
     std::vector<int32_t> row_ptr(nt + 1, 0), row_j;
