@@ -201,10 +201,10 @@ struct CholPlan {
   const int32_t* slices;      // host [nlevels]     1, or 4 on thin levels (update / trsm tile products split into four row slices)
   const int32_t* col_ptr;     // device [nt+1]      column structure of L: rows i > k with L(i,k) != 0
   const int32_t* col_i;       // device
-  int32_t nbw;                // launches of the backward substitution (two levels each)
+  int32_t nbw;                // launches of the backward substitution (several levels each)
   const int32_t* bw_ptr;      // host [nbw+1]       backward substitution workgroups of each launch, in the order of the forward levels
-  const int32_t* bw_kj;       // device, 3 per workgroup: tile (k,j) of row k, j < k (j = -1: the workgroup that stores y_k), and k1 >= 0: the
-                              //                    parent column of k in the same launch (its y is formed by the workgroup itself)
+  const int32_t* bw_kj;       // device, 3 per workgroup: tile (k,j) of row k, j < k (j = -1: the workgroup that stores y_k), offset of row k's chain record
+  const int32_t* bw_chains;   // device             chain records: n, the n ancestors of the row inside the launch (top first), 2 words of tile presence bits
   const int32_t* row_ptr;     // device [nt+1]      row structure of L: columns j < k with L(k,j) != 0 (forward substitution with many right-hand sides)
   const int32_t* row_j;       // device
 };

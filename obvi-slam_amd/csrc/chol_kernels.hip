@@ -556,77 +556,81 @@ __global__ void __launch_bounds__(512) k_update_potrf(double* S, int nt, UpdateJ
 
 // backward substitution (L^T y = z), row oriented, one workgroup per tile of the launch's tile rows.  t starts as z and is updated
 // in place:  every workgroup of row k forms y_k = L_kk^-T t_k; the workgroup of tile (k,j) subtracts L_kj^T y_k from t_j, the
-// workgroup with j = -1 stores y_k.  Both tile reads of a workgroup are in flight together, and a launch with a single tile column
-// still spreads over as many compute units as the row has tiles.
-// A launch covers TWO levels of the elimination tree: a row k of the lower level whose parent column k1 sits in the upper one does
-// not wait for a launch boundary to receive L_k1,k^T y_k1 -- its workgroups form y_k1 = L_k1k1^-T t_k1 themselves (t_k1 is final when
-// the launch starts), then v = t_k - L_k1,k^T y_k1 and y_k = L_kk^-T v; the tile (k1,k) gets no workgroup.  All four tiles are
-// loaded up front, so the second level costs three more reductions instead of a kernel launch.
-constexpr int kBackThreads = 256;
-__global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restrict__ S, int nt, const int32_t* __restrict__ kj, const double* __restrict__ Linv_all,
-                                                         double* t, double* y) {
+// workgroup with j = -1 stores y_k.
+// A launch covers SEVERAL levels of the elimination tree (a separator's chain of tile columns is one launch instead of 4-6): a row k
+// whose ancestors a_0 > ... > a_{n-1} (top first, a_{n-1} its parent) sit in the same launch does not wait for launch boundaries to
+// receive their contributions -- its workgroups walk the chain themselves from values that are final when the launch starts:
+//     y_a0 = L^-T t_a0,   y_as = L^-T (t_as - sum_{u<s} L_{au,as}^T y_au),   ...,   y_k = L^-T (t_k - sum_u L_{au,k}^T y_au)
+// (the work is redundant across the workgroups of a row and across rows; the device is idle at this point and a step is two
+// reductions, a launch boundary is several microseconds).  Tiles between two rows of one launch get no workgroup.
+// Chain record: n, a_0 .. a_{n-1}, then the presence bits of the tiles (a_u, a_s) / (a_u, k) (bit 8 s + u, step n = row k), 2 words.
+constexpr int kBackThreads = 512, kBackChain = 7;
+__global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restrict__ S, int nt, const int32_t* __restrict__ kj, const int32_t* __restrict__ chains,
+                                                         const double* __restrict__ Linv_all, double* t, double* y) {
   constexpr int Q = kBackThreads / T, R = T / Q;   // row slices, rows per slice
   __shared__ double part[Q][T];
-  __shared__ double ysh[T], vsh[T];
-  const int k = kj[3 * blockIdx.x], j = kj[3 * blockIdx.x + 1], k1 = kj[3 * blockIdx.x + 2];
+  __shared__ double ych[kBackChain + 1][T], vsh[T];
+  const int k = kj[3 * blockIdx.x], j = kj[3 * blockIdx.x + 1];
+  const int32_t* ch = chains + kj[3 * blockIdx.x + 2];
+  const int n = ch[0];
+  const uint64_t bits = (uint64_t)(uint32_t)ch[1 + n] | ((uint64_t)(uint32_t)ch[2 + n] << 32);
   const int tid = threadIdx.x, c = tid % T, q = tid / T;
-  const double* Li = Linv_all + (int64_t)k * (T * T) + (q * R) * T + c;
-  const double* X = j >= 0 ? tile_ptr(const_cast<double*>(S), nt, k, j) + (q * R) * T + c : nullptr;
-  double w[R], x[R], w1[R], x1[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) w[r] = Li[r * T];
-  if (k1 >= 0) {
-    const double* Li1 = Linv_all + (int64_t)k1 * (T * T) + (q * R) * T + c;
-    const double* X1 = tile_ptr(const_cast<double*>(S), nt, k1, k) + (q * R) * T + c;
-#pragma unroll
-    for (int r = 0; r < R; ++r) { w1[r] = Li1[r * T]; x1[r] = X1[r * T]; }
-  }
-  if (j >= 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = X[r * T];
-  }
-  auto reduce_to = [&](double s, double* out) {   // sum over the row slices; result for column tid < T
+  auto reduce = [&](double s) -> double {   // sum over the row slices; valid for tid < T (column tid)
     part[q][c] = s;
     __syncthreads();
     double a = 0.0;
     if (tid < T) {
 #pragma unroll
       for (int i = 0; i < Q; ++i) a += part[i][tid];
-      if (out) out[tid] = a;
     }
     return a;
   };
-  double s = 0.0;
-  if (k1 >= 0) {
-    const double* tk1 = t + (int64_t)k1 * T + q * R;
+  // the tile of the workgroup itself: in flight from the start
+  double x[R];
+  if (j >= 0) {
+    const double* X = tile_ptr(const_cast<double*>(S), nt, k, j) + (q * R) * T + c;
 #pragma unroll
-    for (int r = 0; r < R; ++r) s += w1[r] * tk1[r];
-    reduce_to(s, ysh);                     // y_k1
-    __syncthreads();
-    s = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) s += x1[r] * ysh[q * R + r];
-    const double a = reduce_to(s, nullptr);   // L_k1,k^T y_k1
-    if (tid < T) vsh[tid] = t[(int64_t)k * T + tid] - a;
-    __syncthreads();
-    s = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) s += w[r] * vsh[q * R + r];
-  } else {
-    const double* tk = t + (int64_t)k * T + q * R;
-#pragma unroll
-    for (int r = 0; r < R; ++r) s += w[r] * tk[r];   // L^-1 is lower triangular with an explicit zero upper part
+    for (int r = 0; r < R; ++r) x[r] = X[r * T];
   }
-  {
-    const double a = reduce_to(s, ysh);    // y_k
-    if (tid < T && j < 0) y[(int64_t)k * T + tid] = a;
+  for (int st = 0; st <= n; ++st) {
+    const int m = st < n ? ch[1 + st] : k;
+    // all tiles of the step are loaded before the first is used
+    double w[R], xu[kBackChain][R];
+    const double* Li = Linv_all + (int64_t)m * (T * T) + (q * R) * T + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = Li[r * T];
+#pragma unroll
+    for (int u = 0; u < kBackChain; ++u)
+      if (u < st && ((bits >> (8 * st + u)) & 1ull)) {
+        const double* Xu = tile_ptr(const_cast<double*>(S), nt, ch[1 + u], m) + (q * R) * T + c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) xu[u][r] = Xu[r * T];
+      }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < kBackChain; ++u)
+      if (u < st && ((bits >> (8 * st + u)) & 1ull)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s += xu[u][r] * ych[u][q * R + r];
+      }
+    if (st > 0) {
+      const double a = reduce(s);
+      if (tid < T) vsh[tid] = t[(int64_t)m * T + tid] - a;
+      __syncthreads();
+    }
+    s = 0.0;
+    const double* vm = st > 0 ? &vsh[q * R] : t + (int64_t)m * T + q * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += w[r] * vm[r];   // L^-1 is lower triangular with an explicit zero upper part
+    const double a = reduce(s);
+    if (tid < T) { ych[st][tid] = a; if (st == n && j < 0) y[(int64_t)k * T + tid] = a; }
+    __syncthreads();
   }
   if (j < 0) return;
-  __syncthreads();
-  s = 0.0;
+  double s = 0.0;
 #pragma unroll
-  for (int r = 0; r < R; ++r) s += x[r] * ysh[q * R + r];
-  const double a = reduce_to(s, nullptr);
+  for (int r = 0; r < R; ++r) s += x[r] * ych[n][q * R + r];
+  const double a = reduce(s);
   if (tid < T) unsafeAtomicAdd(t + (int64_t)j * T + tid, -a);
 }
 
@@ -820,7 +824,7 @@ void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S,
   tick(s, timers, -1);
   for (int l = p.nbw - 1; l >= 0; --l) {
     const int nwg = p.bw_ptr[l + 1] - p.bw_ptr[l];
-    if (nwg > 0) hipLaunchKernelGGL(k_backward, dim3(nwg), dim3(kBackThreads), 0, s, S, nt, p.bw_kj + 3 * (int64_t)p.bw_ptr[l], Linv, rhs, y);
+    if (nwg > 0) hipLaunchKernelGGL(k_backward, dim3(nwg), dim3(kBackThreads), 0, s, S, nt, p.bw_kj + 3 * (int64_t)p.bw_ptr[l], p.bw_chains, Linv, rhs, y);
     tick(s, timers, CK_BACKWARD);
   }
 }

@@ -110,7 +110,7 @@ struct obvi_ba_handle {
   DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
-  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj;
+  DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj, d_bw_chains;
   DevBuf<int32_t> d_row_ptr, d_row_j, d_cov_slab, d_cov_cols, d_cov_first;   // row structure of L; covariance extraction scratch
   DevBuf<double> d_cov_Y, d_cov_out;
   std::vector<int32_t> h_obj_vid;          // object -> reduced object index (elimination order) or -1
@@ -283,7 +283,7 @@ CholPlan chol_plan(const obvi_ba_handle* h) {
   c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
   c.rh_ptr = h->h_rh_ptr.data(); c.rh_i = h->d_rh_i.get(); c.rh_kptr = h->d_rh_kptr.get(); c.rh_k = h->d_rh_k.get();
-  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.nbw = h->nbw; c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get();
+  c.col_ptr = h->d_col_ptr.get(); c.col_i = h->d_col_i.get(); c.nbw = h->nbw; c.bw_ptr = h->h_bw_ptr.data(); c.bw_kj = h->d_bw_kj.get(); c.bw_chains = h->d_bw_chains.get();
   c.row_ptr = h->d_row_ptr.get(); c.row_j = h->d_row_j.get();
   c.upd_flag = h->d_upd_flag.get(); c.job_signal = h->d_job_signal.get(); c.k_need = h->d_k_need.get(); c.pre_ptr = h->d_pre_ptr.get(); c.pre_j = h->d_pre_j.get(); c.diag_done = h->d_diag_done.get(); c.crit_upd = h->h_crit_upd.data(); c.crit_rh = h->h_crit_rh.data(); c.slices = h->h_slices.data();
   return c;
@@ -942,27 +942,37 @@ void prepare(obvi_ba_handle* h) {
     if (std::getenv("OBVI_DEBUG_PLAN")) std::fprintf(stderr, "level %d: columns %zu (first %d) trsm %zu update jobs %zu (critical %d) products %zu slices %d\n", l, by_level[l].size(), by_level[l].empty() ? -1 : by_level[l][0], ik.size(), jobs.size(), h->h_crit_upd[l], trips.size(), sl);
   }
   stage("level jobs");
-  // backward substitution, row oriented: one workgroup per tile of L.  A launch takes two levels (l + 1, l): a row of level l whose
-  // parent column is at level l + 1 forms the parent's y itself (k_backward) and the tile between the two gets no workgroup.
-  // The launches are listed in the order of the forward levels and run last to first.
-  std::vector<int32_t> bw_kj;
-  const int bw_levels = std::max(1, std::min(2, env_int("OBVI_BACKWARD_LEVELS", 2)));   // tuning knob: levels per launch (1: one level per launch)
+  // backward substitution, row oriented: one workgroup per tile of L.  A launch takes kBwLevels consecutive levels: a row forms the
+  // y of its ancestors inside the launch itself (k_backward; chain record per row) and tiles between two rows of a launch get no
+  // workgroup.  The launches are listed in the order of the forward levels and run last to first.
+  std::vector<int32_t> bw_kj, bw_chains;
+  const int bw_levels = std::max(1, std::min(8, env_int("OBVI_BACKWARD_LEVELS", 4)));   // tuning knob: levels per launch (1: one level per launch; chains of at most 7)
   h->h_bw_ptr.assign(1, 0);
   {
-    int top = nlev - 1;             // the levels are grouped from the top: (nlev-1, nlev-2), (nlev-3, nlev-4), ...
-    std::vector<std::pair<int, int>> groups;   // (lower level, upper level)
+    int top = nlev - 1;             // the levels are grouped from the top
+    std::vector<std::pair<int, int>> groups;   // (lowest level, highest level)
     while (top >= 0) { const int lo = std::max(0, top - (bw_levels - 1)); groups.push_back({lo, top}); top = lo - 1; }
     std::reverse(groups.begin(), groups.end());
+    std::vector<int32_t> chain;
     for (const auto& g : groups) {
       for (int l = g.first; l <= g.second; ++l)
         for (int32_t k : by_level[l]) {
-          int32_t k1 = -1;   // the parent (first row of the column) if it belongs to the launch's upper level
-          if (l < g.second && col_ptr[k] < col_ptr[k + 1] && level[col_i[col_ptr[k]]] == g.second && l + 1 == g.second) k1 = col_i[col_ptr[k]];
-          bw_kj.push_back(k); bw_kj.push_back(-1); bw_kj.push_back(k1);
+          chain.clear();   // ancestors of k in the elimination tree (parent = first row of the column) that belong to the launch
+          for (int32_t a = k; col_ptr[a] < col_ptr[a + 1] && level[col_i[col_ptr[a]]] <= g.second;) { a = col_i[col_ptr[a]]; chain.push_back(a); }
+          std::reverse(chain.begin(), chain.end());   // top first
+          const int32_t off = (int32_t)bw_chains.size(), n = (int32_t)chain.size();
+          uint64_t bits = 0;
+          for (int st = 1; st <= n; ++st) {
+            const int32_t m = st < n ? chain[st] : k;
+            for (int u = 0; u < st; ++u) if (mask[(size_t)chain[u] * nt + m]) bits |= 1ull << (8 * st + u);
+          }
+          bw_chains.push_back(n);
+          bw_chains.insert(bw_chains.end(), chain.begin(), chain.end());
+          bw_chains.push_back((int32_t)(uint32_t)(bits & 0xffffffffull)); bw_chains.push_back((int32_t)(uint32_t)(bits >> 32));
+          bw_kj.push_back(k); bw_kj.push_back(-1); bw_kj.push_back(off);
           for (int j = 0; j < k; ++j) {
-            if (!mask[(size_t)k * nt + j]) continue;
-            if (l == g.second && g.first < g.second && level[j] == g.first && col_ptr[j] < col_ptr[j + 1] && col_i[col_ptr[j]] == k) continue;   // tile (k1, k0): folded into row k0
-            bw_kj.push_back(k); bw_kj.push_back(j); bw_kj.push_back(k1);
+            if (!mask[(size_t)k * nt + j] || level[j] >= g.first) continue;   // a row of the same launch takes this tile's contribution itself
+            bw_kj.push_back(k); bw_kj.push_back(j); bw_kj.push_back(off);
           }
         }
       h->h_bw_ptr.push_back((int32_t)(bw_kj.size() / 3));
@@ -1005,7 +1015,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);
-  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_bw_kj.upload(bw_kj, s); h->d_upd_flag.upload(upd_flag, s);
+  h->d_col_ptr.upload(col_ptr, s); h->d_col_i.upload(col_i, s); h->d_bw_kj.upload(bw_kj, s); h->d_bw_chains.upload(bw_chains, s); h->d_upd_flag.upload(upd_flag, s);
   {
     std::vector<int32_t> k_need(lvl_k.size());
     for (size_t x = 0; x < lvl_k.size(); ++x) k_need[x] = k_need_of[lvl_k[x]];
