@@ -102,6 +102,9 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_PAIR_BITMAP_MAX": "0"},                           # tile marks pair by pair (the path of more than 8192 variable poses)
     {"OBVI_SMALL_LANES_BELOW": "0"},                         # thread-per-factor small-factor kernels (the big-problem path) on a small problem
     {"OBVI_SMALL_LANES_BELOW": "1000000000", "OBVI_HOST_THREADS": "3"},   # ... 16 lanes per factor; symbolic phase on three host threads
+    {"OBVI_BACKWARD_LEVELS": "1"},                           # backward substitution: one level per launch, nobody walks a chain
+    {"OBVI_BACKWARD_LEVELS": "8", "OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},   # ... chains of seven ancestors in a deep tree (ragged: not every ancestor tile exists)
+    {"OBVI_BACKWARD_LEVELS": "3", "OBVI_FUSED_POTRF": "0"},  # ... and the two-launch forward schedule
 ])
 def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
