@@ -1222,11 +1222,15 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 1);
   }
   launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
-  if (side) { record_end(h, PH_DIAG, s2); OBVI_HIP(hipEventRecord(h->ev_join, s2)); }
+  if (side) record_end(h, PH_DIAG, s2);
+  // the pairs outside every strip (loop closures, very long tracks) only need the point pass: beside the strip kernel as well (both add
+  // to the tile grid with atomics)
+  if (side && solve) launch_schur_blocks(s2, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  if (side) OBVI_HIP(hipEventRecord(h->ev_join, s2));
   record(h, PH_SCHUR);
   if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   record(h, PH_SCHUR_BLOCKS);
-  if (solve) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  if (solve && !side) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   if (side) OBVI_HIP(hipStreamWaitEvent(s, h->ev_join, 0));   // join
   record(h, PH_CHOL);
   if (solve && h->m > 0) {

@@ -247,24 +247,24 @@ def test_hip_session_against_the_oracle_session(driver, oracle_session, scene, t
     # factor), same LM iteration counts in most windows, costs within the solves' own tolerances
     same_size = sum((a["n_poses"], a["n_features"]) == (b["n_poses"], b["n_features"]) for a, b in zip(rh, ro))
     same_its = sum(a["iterations"] == b["iterations"] for a, b in zip(rh, ro))
-    assert same_size >= 0.9 * len(ro) and same_its >= 0.75 * len(ro), (same_size, same_its, len(ro))
+    assert same_size >= 0.95 * len(ro) and same_its >= 0.8 * len(ro), (same_size, same_its, len(ro))   # measured over repeated runs: 162 / 162, 151-153 / 162
     rel = [abs(a["final_cost"] - b["final_cost"]) / max(b["final_cost"], 1e-12) for a, b in zip(rh, ro) if a["kind"].endswith(("phase_1", "phase_2"))]
-    assert np.median(rel) <= 1e-3 and max(rel) <= 0.2, (np.median(rel), max(rel))
+    assert np.median(rel) <= 1e-3 and max(rel) <= 5e-2, (np.median(rel), max(rel))   # measured: 1e-5, 1.6e-3
     # the outcome: trajectory, objects and long-term map
     ph, po = np.array(hip["poses"]), np.array(ora["poses"])
-    assert np.abs(ph[:, :3] - po[:, :3]).max() <= 2e-2 and np.abs(ph[:, 3:] - po[:, 3:]).max() <= 1e-2
+    assert np.abs(ph[:, :3] - po[:, :3]).max() <= 2e-2 and np.abs(ph[:, 3:] - po[:, 3:]).max() <= 2e-3   # measured: 2e-3 m, 1e-4 rad
     err = [np.linalg.norm(x[:, :3] - prob["gt_poses"][:, :3], axis=1).mean() for x in (ph, po)]
     assert abs(err[0] - err[1]) <= 0.1 * err[1]
     assert set(hip["objects"]) == set(ora["objects"]) and set(hip["long_term_map"]) == set(ora["long_term_map"])
     for oid in ora["objects"]:
         a, b = np.array(hip["objects"][oid]), np.array(ora["objects"][oid])
-        assert np.abs(np.delete(a - b, 3)).max() <= 5e-2
+        assert np.abs(np.delete(a - b, 3)).max() <= 0.15   # measured: up to 4 cm (the fp64 atomics make the HIP session differ from run to run in the last digits)
         if abs(b[4] - b[5]) > 0.1:   # the yaw of an ellipsoid with equal horizontal axes is not observable (and drifts freely in both runs)
             assert abs(np.sin(a[3] - b[3])) <= 5e-2
     for oid, e in ora["long_term_map"].items():
         ch, co = np.array(hip["long_term_map"][oid]["covariance"]).reshape(7, 7), np.array(e["covariance"]).reshape(7, 7)
         keep = [0, 1, 2, 4, 5, 6]   # without the yaw (above)
-        assert np.abs(np.sqrt(np.diag(ch)[keep]) - np.sqrt(np.diag(co)[keep])).max() <= 0.1 * np.sqrt(np.diag(co)[keep]).max()
+        assert np.abs(np.sqrt(np.diag(ch)[keep]) - np.sqrt(np.diag(co)[keep])).max() <= 0.2 * np.sqrt(np.diag(co)[keep]).max()
 
 
 @pytest.mark.gpu
