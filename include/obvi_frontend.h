@@ -8,8 +8,9 @@
  *   isReprojectionErrorFactorInlier          :511-602  votes of the reference observations of the same feature, majority rule,
  *                                                      early return after the earliest reference frame
  *   checkMinParallaxRequirements_            :726-800  any pair of cached frames with enough robot motion / pixel displacement
- * The stateful part (caches of pending features, what is added when: addVisualFeatureObservations :262-450) is host logic: the
- * caller batches a frame's questions into these two calls (the host mirror of that class is not written yet).
+ * The stateful part (caches of pending features, what is added when: addVisualFeatureObservations :262-450) is host logic and is
+ * mirrored in obvi-slam_amd/host/obvi_visual_feature_front_end.h, which runs a frame's features in lock step and batches their
+ * questions into these two calls.
  *
  * Conventions as in obvi_ba.h: host pointers owned by the caller, fp64, 0 / negative obvi_status, nothing throws.  The handle
  * supplies the device and the stream; the calls do not touch the bundle-adjustment state.

@@ -77,7 +77,8 @@ struct LongTermObjectMapAndResults {
 inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, const FullOVSLAMConfig& config, const OfflineProblemData& problem_data,
                                 const std::function<void(const OfflineProblemData&, MainPgPtr&)>& pose_graph_creator, const std::string& output_checkpoints_dir,
                                 LongTermObjectMapAndResults& output_results, const FrameId& start_at_frame = 0, const bool& add_data_for_starting_frame = true,
-                                int device_id = 0, bool extract_long_term_map = true, MainPgPtr* pose_graph_out = nullptr) {
+                                int device_id = 0, bool extract_long_term_map = true, MainPgPtr* pose_graph_out = nullptr,
+                                const VisualFeatureAdder& visual_feature_adder = nullptr) {
   const FrameId max_frame_id = problem_data.getMaxFrameId();                                                                 // :186-189
   std::function<FrameId(const FrameId&)> window_provider_func = [&](const FrameId& f) { return provideOptimizationWindow(f, max_frame_id, config.sliding_window_params_); };
   std::function<bool(const FrameId&)> gba_checker = [&](const FrameId& max_frame_to_opt) {                                  // :195-203
@@ -98,6 +99,7 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
     if (merge_results.empty()) return false;
     return pose_graph->mergeObjects(merge_results);
   });
+  if (visual_feature_adder) runner.setVisualFeatureAdder(visual_feature_adder);   // the visual front end decides what enters the graph (obvi_visual_feature_front_end.h)
   runner.setExtractLongTermMap(extract_long_term_map);
   runner.setLongTermMapTunableParams(config.ltm_tunable_params_);
   MainPgPtr pose_graph;

@@ -109,6 +109,8 @@ class ObjectAndReprojectionFeaturePoseGraph {
     if (it == first_observed_frame_by_feature_.end() || factor.frame_id_ < it->second) first_observed_frame_by_feature_[factor.feature_id_] = factor.frame_id_;
     return id;
   }
+  // the reprojection factors of a feature (getFactorsForFeature, low_level_feature_pose_graph.h, restricted to the visual ones)
+  const std::vector<FeatureFactorId>& visualFactorIdsOfFeature(const FeatureId& id) const { static const std::vector<FeatureFactorId> none; auto it = visual_factors_by_feature_.find(id); return it == visual_factors_by_feature_.end() ? none : it->second; }
   bool getVisualFactor(const FeatureFactorId& id, ReprojectionErrorFactor& f) const { auto it = factors_.find(id); if (it == factors_.end()) return false; f = it->second; return true; }
   bool getFeaturePointers(const FeatureId& id, double** ptr) { auto it = feature_positions_.find(id); if (it == feature_positions_.end()) return false; *ptr = it->second->data(); return true; }
   void getVisualFeatureFactorIdsBetweenFrameIdsInclusive(const FrameId& min_f, const FrameId& max_f, FactorInfoSet& out) const {   // :390-415

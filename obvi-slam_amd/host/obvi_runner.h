@@ -40,8 +40,12 @@ typedef std::shared_ptr<MainPg> MainPgPtr;
 // frame's pose is the previous *optimised* pose composed with the odometry increment of the initial trajectory;
 // features / objects enter the graph the first time they are observed; a consecutive-frame odometry factor is
 // stored for every frame (used by buildPoseGraphOptimization only for frames with few observations).
+// `visual_feature_adder` (optional): the visual-feature front end (obvi_visual_feature_front_end.h) decides which of the frame's
+// observations and features enter the graph (pose_graph_frame_data_adder.h:75-82); without it every observation is added.
+typedef std::function<bool(const OfflineProblemData&, const MainPgPtr&, const FrameId& /*min_frame_id*/, const FrameId& /*max_frame_id*/)> VisualFeatureAdder;
 inline void addFrameDataToPoseGraph(const OfflineProblemData& d, MainPgPtr& pg, const FrameId& frame,
-                                    const pose_graph_optimization::RelativePoseCovarianceOdomModelParams& odom) {
+                                    const pose_graph_optimization::RelativePoseCovarianceOdomModelParams& odom,
+                                    const VisualFeatureAdder& visual_feature_adder = nullptr, const FrameId& min_frame_id = 0) {
   if (frame == 0) {
     pg->addFrame(0, d.robot_poses_[0]);
   } else {
@@ -54,7 +58,9 @@ inline void addFrameDataToPoseGraph(const OfflineProblemData& d, MainPgPtr& pg, 
                                             odom.rot_error_mult_for_transl_error_, odom.rot_error_mult_for_rot_error_);
     pg->addPoseFactor(f);
   }
-  if (frame < d.visual_obs_by_frame_.size())
+  if (visual_feature_adder) {
+    if (!visual_feature_adder(d, pg, min_frame_id, frame)) std::cerr << "visual feature front end failed at frame " << frame << std::endl;
+  } else if (frame < d.visual_obs_by_frame_.size())
     for (const auto& o : d.visual_obs_by_frame_[frame]) {
       if (!pg->hasFeature(o.feature_id)) pg->addFeature(o.feature_id, d.initial_feature_positions_.at(o.feature_id));
       pg->addVisualFactor(ReprojectionErrorFactor{frame, o.feature_id, o.camera_id, o.pixel, d.reprojection_error_std_dev_});
@@ -143,13 +149,13 @@ class OfflineProblemRunner {
     if (!pose_graph) return false;
     for (const auto& ltm : problem_data.long_term_map_)
       pose_graph->addLongTermMapObject(ltm.object_id_, ltm.ellipsoid_mean_, problem_data.object_class_.count(ltm.object_id_) ? problem_data.object_class_.at(ltm.object_id_) : "", ltm);
-    if (start_at_frame == 0 && add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_);
+    if (start_at_frame == 0 && add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_, visual_feature_adder_, 0);
     const FrameId first_frame = std::max<FrameId>(1, start_at_frame);
     for (FrameId next_frame_id = first_frame; next_frame_id <= max_frame_id; ++next_frame_id) {                               // :174-226
       const FrameId start_opt_with_frame = window_provider_func_(next_frame_id);
       scope.min_frame_id_ = start_opt_with_frame; scope.max_frame_id_ = next_frame_id;
       const auto t_add0 = std::chrono::steady_clock::now();
-      if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_);
+      if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_, visual_feature_adder_, start_opt_with_frame);
       time_add_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_add0).count();
       if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
       IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                 // :219
@@ -209,6 +215,7 @@ class OfflineProblemRunner {
                            << check_.max_value_diff << " points " << check_.points << " points_apart " << check_.points_apart << " objects " << check_.objects << " objects_apart " << check_.objects_apart << std::endl;
   }
   struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
+  void setVisualFeatureAdder(const VisualFeatureAdder& adder) { visual_feature_adder_ = adder; }
   void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
   void setLongTermMapTunableParams(const LongTermMapExtractionTunableParams& p) { ltm_tunable_params_ = p; }
   const std::vector<obvi::CovarianceRankRepair>& covarianceRankRepairs() const { return covariance_rank_repairs_; }
@@ -451,6 +458,7 @@ class OfflineProblemRunner {
   struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;
   std::unique_ptr<obvi::Problem> check_problem_;
   bool extract_long_term_map_ = false;
+  VisualFeatureAdder visual_feature_adder_;
   LongTermMapExtractionTunableParams ltm_tunable_params_;
   std::vector<obvi::CovarianceRankRepair> covariance_rank_repairs_;
   std::vector<LongTermMapEntry> long_term_map_;

@@ -15,6 +15,7 @@
 #include <iostream>
 
 #include "obvi_optimization_runner.h"
+#include "obvi_visual_feature_front_end.h"
 #include "obvi_pending_object_estimator.h"
 
 using namespace vslam_types_refactor;   // NOLINT
@@ -114,7 +115,9 @@ int main(int argc, char** argv) {
   const char* out_path = from_checkpoint ? argv[3] : argv[2];
   FullOVSLAMConfig config = FullOVSLAMConfig::base7a2Fallback();   // config/base7a_2_fallback.json
   SlidingWindowParams& sw = config.sliding_window_params_;
-  int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
+  VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
+  front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
   for (int i = first_opt; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
@@ -125,6 +128,10 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--iteration-log-dir") && i + 1 < argc) iteration_log_dir = argv[++i];
     else if (!std::strcmp(argv[i], "--merge-distance") && i + 1 < argc) config.post_session_object_merge_params_.max_merge_distance_ = std::atof(argv[++i]);
     else if (!std::strcmp(argv[i], "--pending-objects")) pending = true;
+    else if (!std::strcmp(argv[i], "--visual-front-end")) visual_front_end = true;
+    else if (!std::strcmp(argv[i], "--front-end-only")) { visual_front_end = true; front_end_only = true; }
+    else if (!std::strcmp(argv[i], "--no-epipolar")) front_end_params.enforce_epipolar_error_requirement_ = false;
+    else if (!std::strcmp(argv[i], "--pose-parallax")) front_end_params.enforce_min_robot_pose_parallax_requirement_ = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
@@ -239,6 +246,46 @@ int main(int argc, char** argv) {
     return ok ? 0 : 1;
   }
 
+  // --visual-front-end: the frame's visual observations go through VisualFeatureFrontend (epipolar votes, parallax) instead of straight
+  // into the pose graph; --front-end-only: no optimisation, the frames are added one after the other and the decisions are reported
+  obvi_ba_handle* front_end_handle = nullptr;
+  std::unique_ptr<VisualFeatureFrontend> front_end;
+  VisualFeatureAdder visual_adder;
+  if (visual_front_end) {
+    obvi_ba_options opt{}; opt.device_id = device;
+    if (obvi_ba_create(&opt, &front_end_handle) != 0) { std::cerr << "no device handle for the visual front end" << std::endl; return 1; }
+    const SlidingWindowParams sw2 = config.sliding_window_params_;
+    front_end = std::make_unique<VisualFeatureFrontend>(front_end_handle, [sw2, max_frame_id](const FrameId& f) { return f - provideOptimizationWindow(f, max_frame_id, sw2) > sw2.local_ba_window_size_; },
+                                                        front_end_params);
+    visual_adder = [&](const OfflineProblemData& d, const MainPgPtr& pg, const FrameId& mn, const FrameId& mx) { return front_end->addVisualFeatureObservations(d, pg, mn, mx); };
+  }
+  auto front_end_report = [&](std::ostream& o) {
+    o << "{\"added\": " << front_end->numAddedFeatures() << ", \"pending\": " << front_end->numPendingFeatures() << ", \"pending_initialized\": " << front_end->numPendingInitializedFeatures()
+      << ", \"rejected_factors\": " << front_end->numRejectedFactors() << ", \"vote_questions\": " << front_end->numVoteQuestions() << ", \"vote_calls\": " << front_end->numVoteCalls() << "}";
+  };
+  if (front_end_only) {
+    MainPgPtr pg = std::make_shared<MainPg>(data.camera_extrinsics_by_camera_, data.camera_intrinsics_by_camera_);
+    std::vector<size_t> feats_after, factors_after;
+    for (FrameId f = 0; f <= max_frame_id; ++f) {
+      addFrameDataToPoseGraph(data, pg, f, rp.relative_pose_cov_params_, visual_adder, f == 0 ? 0 : provideOptimizationWindow(f, max_frame_id, config.sliding_window_params_));
+      FactorInfoSet all;
+      pg->getVisualFeatureFactorIdsBetweenFrameIdsInclusive(0, f, all);
+      feats_after.push_back(pg->featurePositions().size()); factors_after.push_back(all.size());
+    }
+    out << "{\"front_end\": "; front_end_report(out);
+    out << ",\n\"features_after_frame\": ["; for (size_t i = 0; i < feats_after.size(); ++i) out << (i ? "," : "") << feats_after[i];
+    out << "],\n\"factors_after_frame\": ["; for (size_t i = 0; i < factors_after.size(); ++i) out << (i ? "," : "") << factors_after[i];
+    // every reprojection factor that entered the graph: frame, feature, camera
+    out << "],\n\"factors\": [";
+    std::vector<std::array<uint64_t, 3>> fs;
+    pg->forEachVisualFactorBetweenFrameIdsInclusive(0, max_frame_id, [&](FeatureFactorId, const ReprojectionErrorFactor& f) { fs.push_back({{f.frame_id_, f.feature_id_, f.camera_id_}}); });
+    std::sort(fs.begin(), fs.end());
+    for (size_t i = 0; i < fs.size(); ++i) out << (i ? "," : "") << "[" << fs[i][0] << "," << fs[i][1] << "," << fs[i][2] << "]";
+    out << "]}\n";
+    front_end.reset(); obvi_ba_destroy(front_end_handle);
+    return 0;
+  }
+
   std::optional<OptimizationLogger> logger;
   // offline_object_visual_slam_main.cpp:672-681: the summary CSV lives in the logging directory, next to the per-iteration CSVs
   if (csv.empty() && !iteration_log_dir.empty()) csv = (iteration_log_dir.back() == '/' ? iteration_log_dir : iteration_log_dir + "/") + "ceres_opt_summary.csv";
@@ -247,7 +294,8 @@ int main(int argc, char** argv) {
   if (from_checkpoint) creator = [&](const OfflineProblemData&, MainPgPtr& pg) { pg = checkpoint_graph; };
   LongTermObjectMapAndResults results;
   const auto t_run0 = std::chrono::steady_clock::now();
-  const bool ok = runFullOptimization(logger, config, data, creator, checkpoint_dir, results, from_checkpoint ? max_frame_id : 0, !from_checkpoint, device, ltm);
+  const bool ok = runFullOptimization(logger, config, data, creator, checkpoint_dir, results, from_checkpoint ? max_frame_id : 0, !from_checkpoint, device, ltm, nullptr, visual_adder);
+  if (front_end) { std::cerr << "front_end "; front_end_report(std::cerr); std::cerr << std::endl; front_end.reset(); obvi_ba_destroy(front_end_handle); }
   const auto t_run1 = std::chrono::steady_clock::now();
   IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                     // offline_object_visual_slam_main.cpp:1108
   if (std::getenv("OBVI_HOST_TIMING"))

@@ -33,4 +33,7 @@
 #define obvi_ba_update_points oracle_ba_update_points
 #define obvi_ba_num_residuals oracle_ba_num_residuals
 #define obvi_ba_num_factors oracle_ba_num_factors
+#define obvi_frontend_epipolar_votes oracle_frontend_epipolar_votes
+#define obvi_frontend_epipolar_errors oracle_frontend_epipolar_errors
+#define obvi_frontend_parallax oracle_frontend_parallax
 #endif
