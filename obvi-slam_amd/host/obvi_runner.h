@@ -209,6 +209,7 @@ class OfflineProblemRunner {
     optimizer_.printTiming(os);
     if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call; phase II on the phase-I problem (masks) x"
                           << n_phase_two_masked_ << ", rebuilt x" << n_phase_two_rebuilt_ << std::endl;
+    if (n_pgo_) os << "pose-graph + object stages at the global-BA frames x" << n_pgo_ << ": " << time_pgo_ms_ / n_pgo_ << " ms per call (own problem: handle, build, solves)" << std::endl;
     if (n_iterations_) os << "frame data adder " << time_add_ms_ / n_iterations_ << " ms, outlier selection on the host " << time_select_ms_ / n_iterations_ << " ms per frame" << std::endl;
     if (check_.windows) os << "phase2_check windows " << check_.windows << " failures " << check_.failures << " iteration_mismatches " << check_.iteration_mismatches << " size_mismatches "
                            << check_.size_mismatches << " max_initial_cost_rel " << check_.max_initial_cost_rel << " max_final_cost_rel " << check_.max_final_cost_rel << " max_value_diff "
@@ -281,9 +282,11 @@ class OfflineProblemRunner {
           if (tracking_logger != nullptr) tracking_logger->logIterations(std::to_string(next_frame_id), optimizer_.lastSummary());
         }
         record("pre_pgo_track", tracking.min_frame_id_, next_frame_id, problem, 0);
+        const auto t_pgo0 = std::chrono::steady_clock::now();
         if (!pose_graph_optimizer::runPgoPlusEllipsoids(next_frame_id, scope, residual_params_, pgo_solver_params_, next_frame_id == max_frame_id, opt_logger, pose_graph,
                                                         device_id_, attempt_num))
           std::cerr << "PGO+objs failed at frame " << next_frame_id << std::endl;
+        time_pgo_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pgo0).count(); ++n_pgo_;
         records_.push_back({0, next_frame_id, "pgo", 0, 0, 0, (size_t)next_frame_id + 1, 0, 0, 0});
       }
     }
@@ -454,7 +457,7 @@ class OfflineProblemRunner {
   size_t n_merge_rounds_ = 0;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
   std::vector<OptimizationRecord> records_;
-  double time_build_ms_ = 0, time_copy_ms_ = 0, time_add_ms_ = 0, time_select_ms_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
+  double time_build_ms_ = 0, time_copy_ms_ = 0, time_add_ms_ = 0, time_select_ms_ = 0, time_pgo_ms_ = 0; size_t n_pgo_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
   struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;
   std::unique_ptr<obvi::Problem> check_problem_;
   bool extract_long_term_map_ = false;
