@@ -874,8 +874,10 @@ void prepare(obvi_ba_handle* h) {
   std::vector<Trip> trips;
   std::vector<std::pair<int32_t, int32_t>> ik;
   int64_t n_products = 0;
+  std::vector<size_t> trsm_level_begin;
   for (int l = 0; l < nlev; ++l) {
     trips.clear(); ik.clear();
+    const size_t trsm_begin_of_level = trsm_ik.size() / 2;
     for (int32_t k : by_level[l]) {
       lvl_k.push_back(k);
       const int32_t b0 = col_ptr[k], b1 = col_ptr[k + 1];
@@ -887,6 +889,7 @@ void prepare(obvi_ba_handle* h) {
       const double nr = (double)(b1 - b0);
       flops += t3 / 3.0 + t3 * nr + 2.0 * t3 * (nr * (nr + 1) / 2);
     }
+    trsm_level_begin.push_back(trsm_begin_of_level);
     std::sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.i != b.i ? a.i < b.i : (a.j != b.j ? a.j < b.j : a.k < b.k); });
     // one job per target tile; a k-list longer than kUpdChunk is split over several jobs that accumulate atomically.
     // Jobs that finish the diagonal tile / right-hand-side block of a column of the next level come first and signal it
@@ -912,6 +915,40 @@ void prepare(obvi_ba_handle* h) {
     const int32_t sl = (int64_t)jobs.size() + (int64_t)ik.size() <= env_slice_max ? 4 : 1;   // thin level: the device is mostly idle, split every tile product
     h->h_slices[l] = sl;
     h->h_crit_upd[l] = (int32_t)std::count_if(jobs.begin(), jobs.end(), [](const Job& x) { return x.crit; });
+    // XCD placement on the wide levels.  Block b is observed to run on XCD b % 8, each XCD with its own L2; the tiles L_ik of a column
+    // are written by the level's trsm jobs and read by its update jobs a launch later, and across XCDs such a read goes through the
+    // fabric.  Columns of one level are independent, so every column gets the XCD its own potrf ran on (which wrote L_kk^-1), its trsm jobs take
+    // block indices with that residue and so do its update jobs (after the launch's leading critical jobs and potrf workgroups):
+    // operands then come out of the L2 they were written to.  Queues that run dry are filled from the others (a speed matter only).
+    static const bool xcd_place = env_int("OBVI_CHOL_XCD", 1) != 0;   // tuning knob
+    std::vector<int32_t> xcd_of(nt, 0);
+    {   // ... the XCD its potrf ran on: workgroup (leading critical jobs of the previous level's launch + rank) of that launch
+      int32_t r = l > 0 ? h->h_slices[l - 1] * h->h_crit_upd[l - 1] + h->h_crit_rh[l - 1] : 0;
+      for (int32_t k : by_level[l]) xcd_of[k] = (r++) % 8;
+    }
+    auto interleave = [&](auto& items, size_t first, int start_residue, auto&& xcd_of_item) {
+      if (!xcd_place || sl != 1 || items.size() - first < 64) return;
+      typedef typename std::decay<decltype(items)>::type Vec;
+      std::vector<Vec> q(8);
+      for (size_t x = first; x < items.size(); ++x) q[xcd_of_item(items[x])].push_back(items[x]);
+      size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, out = first;
+      int res = start_residue;
+      while (out < items.size()) {
+        int pick = res;
+        for (int t = 0; t < 8 && pos[pick] >= q[pick].size(); ++t) pick = (pick + 1) % 8;   // a dry queue: the next one that still has jobs
+        items[out++] = q[pick][pos[pick]++];
+        res = (res + 1) % 8;
+      }
+    };
+    {
+      const int32_t npk_next = l + 1 < nlev ? (int32_t)by_level[l + 1].size() : 0;
+      // crit jobs come first, crit right-hand sides are not known yet at this point: they are few (<= columns of the next level) and only shift the residue on levels that have them
+      interleave(jobs, (size_t)h->h_crit_upd[l], (int)((h->h_crit_upd[l] + npk_next) % 8), [&](const Job& jb) { return xcd_of[trips[jb.t0].k]; });
+      std::vector<std::pair<int32_t, int32_t>> tj;
+      for (size_t x = trsm_level_begin.back(); x < trsm_ik.size() / 2; ++x) tj.push_back({trsm_ik[2 * x], trsm_ik[2 * x + 1]});
+      interleave(tj, 0, 0, [&](const std::pair<int32_t, int32_t>& e) { return xcd_of[e.second]; });
+      for (size_t x = 0; x < tj.size(); ++x) { trsm_ik[2 * (trsm_level_begin.back() + x)] = tj[x].first; trsm_ik[2 * (trsm_level_begin.back() + x) + 1] = tj[x].second; }
+    }
     h->h_crit_rh[l] = 0;
     for (const Job& jb : jobs) {
       upd_ij.push_back(jb.i); upd_ij.push_back(jb.j); upd_flag.push_back(jb.flag);

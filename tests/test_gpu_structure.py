@@ -105,6 +105,8 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_BACKWARD_LEVELS": "1"},                           # backward substitution: one level per launch, nobody walks a chain
     {"OBVI_BACKWARD_LEVELS": "8", "OBVI_ND_LEAF": "16", "OBVI_ND_G": "1"},   # ... chains of seven ancestors in a deep tree (ragged: not every ancestor tile exists)
     {"OBVI_BACKWARD_LEVELS": "3", "OBVI_FUSED_POTRF": "0"},  # ... and the two-launch forward schedule
+    {"OBVI_CHOL_XCD": "0", "OBVI_SLICE_MAX": "0"},           # no XCD placement of the wide levels' jobs (with every level wide)
+    {"OBVI_CHOL_XCD": "1", "OBVI_SLICE_MAX": "0"},           # ... with it
 ])
 def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
