@@ -976,6 +976,9 @@ __device__ __forceinline__ void mfma_f64_acc(sf64x4& acc, double a, double bv) {
   asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bv));
 }
 
+#ifndef OBVI_SCHUR_VISIT_GROUP
+#define OBVI_SCHUR_VISIT_GROUP 2
+#endif
 template <bool TWIN>
 __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDev pt, ReducedDev rd, const int32_t* __restrict__ row_of_nat,
                                                           const uint32_t* __restrict__ wg_bptr, const uint32_t* __restrict__ bfirst,
@@ -1038,7 +1041,11 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
   // ---- one visit.  Record: x = slot | first frame offset << 16 | frames << 22 | twin << 28 of the row frames, y = the same of the
   //      group's column frames, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r
   schur_lds8* zero_l = (schur_lds8*)(&zero2[0]);
-  auto visit = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, auto which) {
+  // A visit in two halves -- load_ops issues every LDS read of the visit (row operands, the operands of the active column tiles,
+  // (u_l, 0)), multiply does the rest -- so that a wavefront can take its visits two at a time: both records, then both sets of
+  // operands, are read together and the read latency (exposed at two wavefronts per SIMD) is paid once per pair.
+  struct Ops { double a[kSTR]; double b[kSGC]; double ul; uint32_t bits; };
+  auto load_ops = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, auto which) -> Ops {
     schur_lds8* zimg = decltype(which)::value ? (schur_lds8*)(&zbuf1[0]) : (schur_lds8*)(&zbuf0[0]);
     const bool twin = TWIN && ((vx >> 28) & 1u);
     const uint32_t layer2 = 144u * (vz >> 16);
@@ -1051,30 +1058,28 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
       if (TWIN && twin) { schur_lds8* p2 = ok ? zimg + (at + layer2) : zero_l; val += *reinterpret_cast<schur_ldsd*>(p2); }
       return val;
     };
-    double a[kSTR];
+    Ops o;
+    o.bits = bits;
 #pragma unroll
-    for (int r = 0; r < kSTR; ++r) a[r] = operand(vx, foA[r], offA[r]);
+    for (int r = 0; r < kSTR; ++r) o.a[r] = operand(vx, foA[r], offA[r]);
+    o.ul = with_rhs ? *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq)) : 0.0;   // (u_l, 0)
+#pragma unroll
+    for (int c = 0; c < kSGC; ++c) o.b[c] = ((bits >> (3 * c)) & 7u) ? operand(vy, foB[c], offB[c]) : 0.0;
+    return o;
+  };
+  auto multiply = [&](const Ops& o) {
     if (with_rhs) {
-      const double ul = *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq));   // (u_l, 0)
 #pragma unroll
-      for (int r = 0; r < kSTR; ++r) racc[r] += a[r] * ul;
+      for (int r = 0; r < kSTR; ++r) racc[r] += o.a[r] * o.ul;
     }
-    // column tiles: the operand of the next active column is read while the current one is multiplied
-    auto column_operand = [&](int c) -> double {
-      if (c >= kSGC || !((bits >> (3 * c)) & 7u)) return 0.0;
-      return operand(vy, foB[c], offB[c]);
-    };
-    double bcur = column_operand(0);
 #pragma unroll
     for (int c = 0; c < kSGC; ++c) {
-      const double bnxt = column_operand(c + 1);
-      const uint32_t t3 = (bits >> (3 * c)) & 7u;
+      const uint32_t t3 = (o.bits >> (3 * c)) & 7u;
       if (t3) {
 #pragma unroll
         for (int r = 0; r < kSTR; ++r)
-          if (t3 & (1u << r)) mfma_f64_acc(acc[c][r], a[r], bcur);
+          if (t3 & (1u << r)) mfma_f64_acc(acc[c][r], o.a[r], o.b[c]);
       }
-      bcur = bnxt;
     }
   };
 
@@ -1087,11 +1092,20 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
     if (bi + 1 < b1) { stream_batch(bi + 1, other); if (bi + 2 < b1) load_table(bi + 2); }
     const uint32_t nv = bfirst[bi + 1] - bfirst[bi];
     const uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
-    for (uint32_t i = (uint32_t)wv; i < nv; i += kSWv) {
-      const uint4 rv = rb_[i];
-      visit(__builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z),
-            __builtin_amdgcn_readfirstlane(rv.w), which);
+    auto ops_of = [&](uint32_t x) {
+      const uint4 rv = rb_[x];
+      return load_ops(__builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z), __builtin_amdgcn_readfirstlane(rv.w), which);
+    };
+    constexpr int kVisitGroup = OBVI_SCHUR_VISIT_GROUP;   // visits a wavefront takes together
+    uint32_t i = (uint32_t)wv;
+    for (; i + (kVisitGroup - 1) * kSWv < nv; i += kVisitGroup * kSWv) {
+      Ops o[kVisitGroup];
+#pragma unroll
+      for (int v = 0; v < kVisitGroup; ++v) o[v] = ops_of(i + v * kSWv);
+#pragma unroll
+      for (int v = 0; v < kVisitGroup; ++v) multiply(o[v]);
     }
+    for (; i < nv; i += kSWv) multiply(ops_of(i));
   };
   for (uint32_t bi = b0; bi < b1; bi += 2) {
     batch(bi, Buf0{}, Buf1{});
