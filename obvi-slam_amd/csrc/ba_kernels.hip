@@ -1164,38 +1164,50 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
 // ---------------------------------------------------------------------------------------
 // K6.  Back-substitution of the eliminated points, candidate point.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void point_backsub_block(int64_t block, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* __restrict__ points,
-                                                    double* __restrict__ points_cand, double* scal) {
-  const int64_t l = block * (int64_t)kBlock + threadIdx.x;
+// G lanes share a feature: lane g takes its sightings beg + g, beg + g + G, ... and the G partial sums meet in a butterfly: a lane per
+// feature walks all of a feature's records one dependent round trip after the other (300 k features x 10 sightings: 169 us with one
+// lane, 116 us with eight).  A workgroup takes feature groups block, block + stride, ... and adds its three sums to the step's scalars
+// once: they are single addresses of one cache line, and a same-line atomic costs ~40 ns (12 500 workgroups were measured at 1.5 ms).
+template <int G>
+__device__ __forceinline__ void point_backsub_block(int64_t block, int64_t stride, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
+                                                    const double* __restrict__ points, double* __restrict__ points_cand, double* scal) {
+  const uint32_t g = threadIdx.x % G;
   double stepsq = 0.0, bad = 0.0, model = 0.0;
-  if (l < b.L) {
-    double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
+  for (int64_t l = (block * (int64_t)kBlock + threadIdx.x) / G; l < b.L; l += stride * (kBlock / G)) {   // uniform over the G lanes of a feature
     if (b.point_var[l]) {
-      double t0 = pt.u[3 * l], t1 = pt.u[3 * l + 1], t2 = pt.u[3 * l + 2];
-      const uint32_t beg = rp.point_ptr[l], end = rp.point_ptr[l + 1];
-      for (uint32_t a = beg; a < end; ++a) {
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+      const uint32_t end = rp.point_ptr[l + 1];
+      // Branch-free: an observation of a constant pose (yr < 0) reads y[0..5] and multiplies by zero instead of skipping, so that the row
+      // lookup and the record (whose address does not depend on it) are requested together: one exposed latency less per observation.
+      // 16-byte loads: z_off() is even, and a pose's rows start at an even row of the tile grid.
+      for (uint32_t a = rp.point_ptr[l] + g; a < end; a += G) {
         const int32_t yr = rp.yrow[a];   // one lookup instead of active -> pose -> variable id -> row
-        if (yr < 0) continue;
-        // 16-byte loads: z_off() is even, and a pose's rows start at an even row of the tile grid
         const double2* Z2 = reinterpret_cast<const double2*>(pt.Z + z_off(a, l));
-        const double2* y2 = reinterpret_cast<const double2*>(rd.y + yr);
+        const double2* y2 = reinterpret_cast<const double2*>(rd.y + (yr < 0 ? 0 : yr));
         double Z[18], y[6];
 #pragma unroll
         for (int x = 0; x < 9; ++x) { const double2 v = Z2[x]; Z[2 * x] = v.x; Z[2 * x + 1] = v.y; }
 #pragma unroll
         for (int x = 0; x < 3; ++x) { const double2 v = y2[x]; y[2 * x] = v.x; y[2 * x + 1] = v.y; }
+        const double on = yr < 0 ? 0.0 : 1.0;
 #pragma unroll
-        for (int x = 0; x < 6; ++x) { t0 -= Z[3 * x] * y[x]; t1 -= Z[3 * x + 1] * y[x]; t2 -= Z[3 * x + 2] * y[x]; }
+        for (int x = 0; x < 6; ++x) { const double yx = on * y[x]; t0 -= Z[3 * x] * yx; t1 -= Z[3 * x + 1] * yx; t2 -= Z[3 * x + 2] * yx; }
       }
-      const double* Ci = pt.Ci + 6 * l;
-      // y_l = Ci^T t ; delta = -y_l
-      const double d0 = -(Ci[0] * t0 + Ci[1] * t1 + Ci[3] * t2), d1 = -(Ci[2] * t1 + Ci[4] * t2), d2 = -(Ci[5] * t2);
-      if (!isfinite(d0) || !isfinite(d1) || !isfinite(d2)) bad = 1.0;
-      X[0] += d0; X[1] += d1; X[2] += d2;
-      stepsq = d0 * d0 + d1 * d1 + d2 * d2;
-      model = 0.5 * (pt.lam[3 * l] * d0 * d0 + pt.lam[3 * l + 1] * d1 * d1 + pt.lam[3 * l + 2] * d2 * d2 - (pt.gl[3 * l] * d0 + pt.gl[3 * l + 1] * d1 + pt.gl[3 * l + 2] * d2));
+#pragma unroll
+      for (int m = 1; m < G; m <<= 1) { t0 += __shfl_xor(t0, m); t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
+      if (g == 0) {
+        t0 += pt.u[3 * l]; t1 += pt.u[3 * l + 1]; t2 += pt.u[3 * l + 2];
+        const double* Ci = pt.Ci + 6 * l;
+        // y_l = Ci^T t ; delta = -y_l
+        const double d0 = -(Ci[0] * t0 + Ci[1] * t1 + Ci[3] * t2), d1 = -(Ci[2] * t1 + Ci[4] * t2), d2 = -(Ci[5] * t2);
+        if (!isfinite(d0) || !isfinite(d1) || !isfinite(d2)) bad = 1.0;
+        points_cand[3 * l] = points[3 * l] + d0; points_cand[3 * l + 1] = points[3 * l + 1] + d1; points_cand[3 * l + 2] = points[3 * l + 2] + d2;
+        stepsq += d0 * d0 + d1 * d1 + d2 * d2;
+        model += 0.5 * (pt.lam[3 * l] * d0 * d0 + pt.lam[3 * l + 1] * d1 * d1 + pt.lam[3 * l + 2] * d2 * d2 - (pt.gl[3 * l] * d0 + pt.gl[3 * l + 1] * d1 + pt.gl[3 * l + 2] * d2));
+      }
+    } else if (g == 0) {
+      points_cand[3 * l] = points[3 * l]; points_cand[3 * l + 1] = points[3 * l + 1]; points_cand[3 * l + 2] = points[3 * l + 2];
     }
-    points_cand[3 * l] = X[0]; points_cand[3 * l + 1] = X[1]; points_cand[3 * l + 2] = X[2];
   }
   block_accumulate(stepsq, scal + SC_STEPSQ);
   block_accumulate(bad, scal + SC_NONFINITE);
@@ -1245,10 +1257,11 @@ __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const Bl
 }
 
 // K6 + K9 in one launch (both only read y): workgroups [0, n_point_blocks) back-substitute the features, the rest form the candidate poses / objects
+template <int G>
 __global__ void __launch_bounds__(kBlock) k_backsub_apply(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points, double* __restrict__ points_cand,
                                                          const double* __restrict__ poses, const double* __restrict__ objects, double* __restrict__ poses_cand,
                                                          double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, int n_point_blocks, double* scal) {
-  if ((int)blockIdx.x < n_point_blocks) point_backsub_block(blockIdx.x, b, rp, pt, rd, points, points_cand, scal);
+  if ((int)blockIdx.x < n_point_blocks) point_backsub_block<G>(blockIdx.x, n_point_blocks, b, rp, pt, rd, points, points_cand, scal);
   else apply_reduced_step_block((int64_t)blockIdx.x - n_point_blocks, b, rd, poses, objects, poses_cand, objects_cand, pc_cand, scal);
 }
 
@@ -1563,9 +1576,20 @@ void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const Blocks
 }
 void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
                           double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal) {
-  const int n_point_blocks = (int)grid_for(b.L, kBlock);
+  // lanes per feature: enough that the features' sightings spread over the chip, no more than a feature has sightings to hand out.
+  // Measured on 300 k features x 10 sightings (us): 1 lane 169, 2 133, 4 120, 8 116, 16 146, 32 156 -- past 8 the wavefronts' record lines
+  // push each other out of the 32 KB vector cache between the nine loads of a record.
+  const char* env = getenv("OBVI_BACKSUB_LANES");   // per launch: the tests flip it inside one process
+  const int forced = env ? atoi(env) : 0;
+  const int64_t per = b.L > 0 ? rp.n / b.L : 0;
+  int G = per >= 32 ? 8 : per >= 8 ? 4 : per >= 4 ? 2 : 1;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32) G = forced;
+  const int n_point_blocks = (int)std::min<int64_t>(grid_for(b.L * G, kBlock), 2048);   // 8 per CU, each walks its share (flat between 512 and 2048)
   const unsigned grid = (unsigned)n_point_blocks + grid_for(b.P + b.O, kBlock);
-  if (grid > 0) hipLaunchKernelGGL(k_backsub_apply, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal);
+  if (grid == 0) return;
+#define OBVI_BACKSUB(GG) hipLaunchKernelGGL(k_backsub_apply<GG>, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal)
+  switch (G) { case 32: OBVI_BACKSUB(32); break; case 16: OBVI_BACKSUB(16); break; case 8: OBVI_BACKSUB(8); break; case 4: OBVI_BACKSUB(4); break; case 2: OBVI_BACKSUB(2); break; default: OBVI_BACKSUB(1); }
+#undef OBVI_BACKSUB
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,

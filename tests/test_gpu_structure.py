@@ -107,6 +107,8 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_BACKWARD_LEVELS": "3", "OBVI_FUSED_POTRF": "0"},  # ... and the two-launch forward schedule
     {"OBVI_CHOL_XCD": "0", "OBVI_SLICE_MAX": "0"},           # no XCD placement of the wide levels' jobs (with every level wide)
     {"OBVI_CHOL_XCD": "1", "OBVI_SLICE_MAX": "0"},           # ... with it
+    {"OBVI_BACKSUB_LANES": "1"},                             # back-substitution: a lane per feature
+    {"OBVI_BACKSUB_LANES": "32"},                            # ... 32 lanes per feature (most of them beyond the feature's last sighting)
 ])
 def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
