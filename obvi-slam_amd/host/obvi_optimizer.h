@@ -66,6 +66,13 @@ struct FlatProblem {
   double rl_huber = 1.0;
   // residual blocks in Problem::GetResidualBlocks order (= evaluate order of the ABI: types 0,2,3,4,5)
   std::vector<vslam_types_refactor::FactorInfo> blocks;
+  // empty, capacity kept: a sliding window rebuilds a problem of the same size for every frame
+  void reset() {
+    cameras.clear(); cam_K.clear(); cam_ext.clear(); frames.clear(); features.clear(); objects.clear(); pose_ptrs.clear(); point_ptrs.clear(); object_ptrs.clear();
+    pose_const.clear(); point_const.clear(); object_const.clear(); rp_pose.clear(); rp_point.clear(); rp_cam.clear(); rp_pixel.clear(); rp_sigma.clear();
+    bb_obj.clear(); bb_pose.clear(); bb_cam.clear(); bb_corners.clear(); bb_cov.clear(); sp_obj.clear(); sp_mean.clear(); sp_cov.clear();
+    lt_obj.clear(); lt_mean.clear(); lt_cov.clear(); rl_a.clear(); rl_b.clear(); rl_t.clear(); rl_aa.clear(); rl_cov.clear(); rl_huber = 1.0; blocks.clear();
+  }
 };
 
 class Problem {
@@ -327,13 +334,29 @@ namespace pose_graph_optimizer {
 using namespace vslam_types_refactor;   // NOLINT (the reference's optimiser header does the same through its includes)
 typedef ObjectAndReprojectionFeaturePoseGraph PoseGraphType;
 
+// What buildPoseGraphOptimization returns: the reference hands back std::unordered_map<ceres::ResidualBlockId, FactorInfo>
+// (object_pose_graph_optimizer.h:126, :631).  Residual block ids here are the positions in the flat problem's block list, so the map is
+// that list; building a hash map of tens of thousands of entries per window cost as much as selecting the factors.
+class ResidualBlockInfoMap {
+ public:
+  ResidualBlockInfoMap() = default;
+  explicit ResidualBlockInfoMap(const std::vector<FactorInfo>& blocks) : blocks_(blocks) {}
+  size_t size() const { return blocks_.size(); }
+  bool empty() const { return blocks_.empty(); }
+  size_t count(const obvi::ResidualBlockId& id) const { return (size_t)id < blocks_.size() ? 1 : 0; }
+  const FactorInfo& at(const obvi::ResidualBlockId& id) const { if ((size_t)id >= blocks_.size()) throw std::out_of_range("ResidualBlockInfoMap::at"); return blocks_[(size_t)id]; }
+  const std::vector<FactorInfo>& blocks() const { return blocks_; }   // position = residual block id
+ private:
+  std::vector<FactorInfo> blocks_;
+};
+
 class ObjectPoseGraphOptimizer {
  public:
   ObjectPoseGraphOptimizer() = default;
 
   // object_pose_graph_optimizer.h:126-632.  Same selection rules; instead of adding Ceres residual and
   // parameter blocks the selected factors are flattened into problem->flat.
-  std::unordered_map<obvi::ResidualBlockId, FactorInfo> buildPoseGraphOptimization(
+  ResidualBlockInfoMap buildPoseGraphOptimization(
       const OptimizationScopeParams& optimization_scope, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
       std::shared_ptr<PoseGraphType>& pose_graph, obvi::Problem* problem, std::optional<OptimizationLogger>& opt_logger,
       const FactorInfoSet& excluded_feature_factor_types_and_ids = {}) {
@@ -363,40 +386,33 @@ class ObjectPoseGraphOptimizer {
     };
     // Visual factors (:205-238): the reference collects the window's factor ids in a set, groups them per feature in a map of sets,
     // drops the features with too few sightings (:826-861) and inserts the rest into the set of required factors.  The same selection
-    // on flat arrays (a window holds tens of thousands of sightings and is rebuilt twice per frame): one look-up per factor, a count
-    // per feature, and a sort by id only if the factors did not come out in id order.
-    struct VisualFactorRef { FeatureId feature; FeatureFactorId id; const ReprojectionErrorFactor* factor; int64_t point; };
-    std::vector<VisualFactorRef> visual;             // the required reprojection factors, ascending id
-    std::vector<FeatureId> included_features;        // ascending
-    std::unordered_map<FrameId, size_t> obs_per_frame;
+    // on flat arrays (a window holds tens of thousands of sightings and is rebuilt for every frame): the pose graph's per-frame factor
+    // records, a sighting count per feature slot; the required factors are then flattened straight from the records (below), and the
+    // frames that need a relative-pose factor (:240-299) are known once that pass has counted the sightings each frame keeps.
+    typedef PoseGraphType::VisualFactorRecord VisualRecord;
+    std::vector<std::pair<const VisualRecord*, size_t>> spans;   // the window's records, frame by frame
+    std::vector<uint32_t> included_slots;            // feature slots of the included features, ascending feature id
+    uint32_t min_obs = 0;
+    const bool any_excluded = !excluded_feature_factor_types_and_ids.empty();
+    auto visual_excluded = [&](const VisualRecord& r) { return any_excluded && excluded_feature_factor_types_and_ids.count({kReprojectionErrorFactorTypeId, r.id}) != 0; };
     if (use_feature_pose_factors) {
-      const bool type_excluded = optimization_scope.factor_types_to_exclude.count(kReprojectionErrorFactorTypeId) != 0;
-      const bool any_excluded = !excluded_feature_factor_types_and_ids.empty();
-      std::vector<VisualFactorRef> all;
-      if (!type_excluded)
-        pose_graph->forEachVisualFactorBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, [&](FeatureFactorId id, const ReprojectionErrorFactor& f) {
-          if (any_excluded && excluded_feature_factor_types_and_ids.count({kReprojectionErrorFactorTypeId, id})) return;
-          all.push_back({f.feature_id_, id, &f, -1});
+      min_obs = (uint32_t)optimization_scope.min_low_level_feature_observations_;
+      const uint32_t first_count = std::max<uint32_t>(min_obs, 1);
+      sightings_.assign(pose_graph->numFeatureSlots(), 0);
+      if (optimization_scope.factor_types_to_exclude.count(kReprojectionErrorFactorTypeId) == 0)
+        pose_graph->forEachVisualRecordSpanBetweenFrameIdsInclusive(optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, [&](const VisualRecord* r, size_t n) {
+          spans.emplace_back(r, n);
+          for (const VisualRecord* e = r + n; r != e; ++r) {
+            if (visual_excluded(*r)) continue;
+            if (++sightings_[r->feature_slot] == first_count) included_slots.push_back(r->feature_slot);
+          }
         });
-      std::unordered_map<FeatureId, uint32_t> sightings;
-      sightings.reserve(all.size() / 4 + 16);
-      for (const VisualFactorRef& v : all) ++sightings[v.feature];
-      visual.reserve(all.size());
-      for (const VisualFactorRef& v : all)
-        if (sightings[v.feature] >= optimization_scope.min_low_level_feature_observations_) { visual.push_back(v); obs_per_frame[v.factor->frame_id_]++; }
-      for (const auto& f : sightings) if (f.second >= optimization_scope.min_low_level_feature_observations_) included_features.push_back(f.first);
-      std::sort(included_features.begin(), included_features.end());
-      auto by_id = [](const VisualFactorRef& a, const VisualFactorRef& b) { return a.id < b.id; };
-      if (!std::is_sorted(visual.begin(), visual.end(), by_id)) std::sort(visual.begin(), visual.end(), by_id);
-    }
-    if (use_relative_pose_factors) {                                                                                         // :240-299
-      for (const FrameId& f : optimized_frames) {
-        auto it = obs_per_frame.find(f);
-        if (it != obs_per_frame.end() && it->second >= optimization_scope.min_low_level_feature_observations_per_frame_) continue;
-        FactorInfoSet rel;
-        pose_graph->getPoseFactorInfoByFrameId(f, optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, rel);
-        for (const FactorInfo& fi : rel) required_feature_factors[fi.first].insert(fi.second);
-      }
+      // ascending feature id (the keys beside the slots: a sort through featureIdOfSlot is twice as slow)
+      std::vector<std::pair<FeatureId, uint32_t>>& keyed = scratch_keyed_;
+      keyed.clear();
+      for (const uint32_t slot : included_slots) keyed.emplace_back(pose_graph->featureIdOfSlot(slot), slot);
+      if (!std::is_sorted(keyed.begin(), keyed.end())) std::sort(keyed.begin(), keyed.end());
+      for (size_t i = 0; i < keyed.size(); ++i) included_slots[i] = keyed[i].second;
     }
     if (use_object_param_blocks) pose_graph->getLongTermMapObjects(ltm_object_ids);                                         // :301-306
     if (use_object_pose_factors) {                                                                                           // :308-340
@@ -420,11 +436,10 @@ class ObjectPoseGraphOptimizer {
         for (const FactorInfo& fi : o.second) required_feature_factors[fi.first].insert(fi.second);
       }
     }
-    for (const FactorType& t : optimization_scope.factor_types_to_exclude) required_feature_factors.erase(t);               // :407-410
 
     // ---- flatten (the part that replaces addOrRefreshResidualBlocksForRequiredFactors, :415, :991-1055) ----
     obvi::FlatProblem& fp = problem->flat;
-    fp = obvi::FlatProblem();
+    fp.reset();
     std::map<CameraId, uint16_t> cam_index;
     for (const auto& c : pose_graph->intrinsics()) {
       CameraExtrinsics e;
@@ -457,13 +472,14 @@ class ObjectPoseGraphOptimizer {
         auto it = pose_index.find(f); if (it != pose_index.end()) fp.pose_const[it->second] = 1;
       }
     }
-    std::unordered_map<FeatureId, uint32_t> point_index;
+    std::vector<int32_t>& point_of_slot = point_of_slot_;   // feature slot -> point of the flat problem (valid for the included slots)
     if (use_feature_pose_factors) {
-      point_index.reserve(included_features.size());
-      for (const FeatureId& feat : included_features) {
-        double* p = nullptr;
-        if (!pose_graph->getFeaturePointers(feat, &p)) continue;
-        point_index[feat] = (uint32_t)fp.features.size(); fp.features.push_back(feat); fp.point_ptrs.push_back(p);
+      point_of_slot.resize(pose_graph->numFeatureSlots());
+      fp.features.reserve(included_slots.size()); fp.point_ptrs.reserve(included_slots.size());
+      for (const uint32_t slot : included_slots) {
+        double* p = pose_graph->featurePointerOfSlot(slot);
+        point_of_slot[slot] = p ? (int32_t)fp.features.size() : -1;
+        if (p) { fp.features.push_back(pose_graph->featureIdOfSlot(slot)); fp.point_ptrs.push_back(p); }
       }
     }
     fp.point_const.assign(fp.features.size(), fix_visual_feature_param_blocks ? 1 : 0);                                     // :488-520
@@ -479,17 +495,62 @@ class ObjectPoseGraphOptimizer {
     }
     const auto& rp = residual_params;
     // residual blocks, type by type in the evaluate order of the ABI; inside a type by factor id
-    fp.rp_pose.reserve(visual.size()); fp.rp_point.reserve(visual.size()); fp.rp_cam.reserve(visual.size()); fp.rp_pixel.reserve(2 * visual.size());
-    fp.rp_sigma.reserve(visual.size()); fp.blocks.reserve(visual.size() + 64);
-    for (const VisualFactorRef& v : visual) {                                                                                // residual_creator.h:168-264
-      const ReprojectionErrorFactor& f = *v.factor;
-      const FeatureFactorId id = v.id;
-      auto pi = pose_index.find(f.frame_id_); auto li = point_index.find(f.feature_id_); auto ci = cam_index.find(f.camera_id_);
-      if (pi == pose_index.end() || li == point_index.end() || ci == cam_index.end()) continue;
-      fp.rp_pose.push_back(pi->second); fp.rp_point.push_back(li->second); fp.rp_cam.push_back(ci->second);
-      fp.rp_pixel.push_back(f.feature_pos_[0]); fp.rp_pixel.push_back(f.feature_pos_[1]); fp.rp_sigma.push_back(f.reprojection_error_std_dev_);
-      fp.blocks.push_back({kReprojectionErrorFactorTypeId, id});
+    std::unordered_map<FrameId, size_t> obs_per_frame;
+    {                                                                                                                        // residual_creator.h:168-264
+      // Residual blocks go by factor id, and the records come frame by frame in id order unless frames were filled out of order: the
+      // first pass writes them as they come and notices a descent; only then the required records are sorted and written again.
+      std::vector<const VisualRecord*>& sorted = scratch_records_;
+      sorted.clear();
+      size_t n = 0;
+      auto put = [&](const VisualRecord& v, int64_t pose, int32_t cam) {
+        const int32_t point = point_of_slot[v.feature_slot];
+        if (pose < 0 || point < 0 || cam < 0) return;
+        fp.rp_pose[n] = (uint32_t)pose; fp.rp_point[n] = (uint32_t)point; fp.rp_cam[n] = (uint16_t)cam;
+        fp.rp_pixel[2 * n] = v.px; fp.rp_pixel[2 * n + 1] = v.py; fp.rp_sigma[n] = v.sigma;
+        fp.blocks[n] = {kReprojectionErrorFactorTypeId, v.id};
+        ++n;
+      };
+      auto pose_of = [&](const FrameId& f) { const auto pi = pose_index.find(f); return pi == pose_index.end() ? (int64_t)-1 : (int64_t)pi->second; };
+      auto cam_of = [&](const CameraId& c) { const auto ci = cam_index.find(c); return ci == cam_index.end() ? (int32_t)-1 : (int32_t)ci->second; };
+      size_t total = 0;
+      for (const auto& sp : spans) total += sp.second;
+      fp.rp_pose.resize(total); fp.rp_point.resize(total); fp.rp_cam.resize(total); fp.rp_pixel.resize(2 * total); fp.rp_sigma.resize(total); fp.blocks.resize(total);
+      bool ascending = true, first = true; FeatureFactorId last_id = 0;
+      for (const auto& sp : spans) {
+        if (sp.second == 0) continue;
+        const int64_t pose = pose_of(sp.first->frame_id);
+        CameraId last_cam = sp.first->camera_id; int32_t cam = cam_of(last_cam);
+        size_t kept = 0;
+        for (const VisualRecord* v = sp.first, *e = sp.first + sp.second; v != e; ++v) {
+          if (sightings_[v->feature_slot] < min_obs || visual_excluded(*v)) continue;
+          ++kept;
+          if (!first && v->id < last_id) ascending = false;
+          last_id = v->id; first = false;
+          if (v->camera_id != last_cam) { last_cam = v->camera_id; cam = cam_of(last_cam); }
+          put(*v, pose, cam);
+        }
+        if (kept) obs_per_frame[sp.first->frame_id] += kept;
+      }
+      if (!ascending) {
+        for (const auto& sp : spans)
+          for (const VisualRecord* v = sp.first, *e = sp.first + sp.second; v != e; ++v)
+            if (sightings_[v->feature_slot] >= min_obs && !visual_excluded(*v)) sorted.push_back(v);
+        std::sort(sorted.begin(), sorted.end(), [](const VisualRecord* a, const VisualRecord* b) { return a->id < b->id; });
+        n = 0;
+        for (const VisualRecord* v : sorted) put(*v, pose_of(v->frame_id), cam_of(v->camera_id));
+      }
+      fp.rp_pose.resize(n); fp.rp_point.resize(n); fp.rp_cam.resize(n); fp.rp_pixel.resize(2 * n); fp.rp_sigma.resize(n); fp.blocks.resize(n);
     }
+    if (use_relative_pose_factors) {                                                                                         // :240-299
+      for (const FrameId& f : optimized_frames) {
+        auto it = obs_per_frame.find(f);
+        if (it != obs_per_frame.end() && it->second >= optimization_scope.min_low_level_feature_observations_per_frame_) continue;
+        FactorInfoSet rel;
+        pose_graph->getPoseFactorInfoByFrameId(f, optimization_scope.min_frame_id_, optimization_scope.max_frame_id_, rel);
+        for (const FactorInfo& fi : rel) required_feature_factors[fi.first].insert(fi.second);
+      }
+    }
+    for (const FactorType& t : optimization_scope.factor_types_to_exclude) required_feature_factors.erase(t);               // :407-410
     for (FeatureFactorId id : required_feature_factors[kObjectObservationFactorTypeId]) {                                    // residual_creator.h:20-117
       ObjectObservationFactor f;
       if (!pose_graph->getObjectObservationFactor(id, f)) continue;
@@ -534,10 +595,7 @@ class ObjectPoseGraphOptimizer {
     }
     last_optimized_nodes_ = optimized_frames.size(); last_optimized_features_ = fp.features.size(); last_optimized_objects_ = fp.objects.size();
     if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);   // :625-629
-    std::unordered_map<obvi::ResidualBlockId, FactorInfo> current_residual_block_info;
-    current_residual_block_info.reserve(fp.blocks.size());
-    for (size_t i = 0; i < fp.blocks.size(); ++i) current_residual_block_info.emplace((obvi::ResidualBlockId)i, fp.blocks[i]);
-    return current_residual_block_info;
+    return ResidualBlockInfoMap(fp.blocks);
   }
 
   // Phase II of a two-phase optimisation (offline_problem_runner.h:803-892) re-runs buildPoseGraphOptimization with the excluded
@@ -703,6 +761,11 @@ class ObjectPoseGraphOptimizer {
   }
   pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
   size_t last_optimized_objects_ = 0, last_optimized_features_ = 0, last_optimized_nodes_ = 0;
+  // scratch of buildPoseGraphOptimization, kept between calls (a window is built for every frame)
+  std::vector<const PoseGraphType::VisualFactorRecord*> scratch_records_;
+  std::vector<uint32_t> sightings_;
+  std::vector<int32_t> point_of_slot_;
+  std::vector<std::pair<FeatureId, uint32_t>> scratch_keyed_;
   obvi::SolverSummary last_summary_;
   double time_upload_ms_ = 0, time_solve_ms_ = 0, time_readback_ms_ = 0, time_lm_ms_ = 0; size_t n_solves_ = 0;
 };

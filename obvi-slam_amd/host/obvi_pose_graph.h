@@ -98,11 +98,17 @@ class ObjectAndReprojectionFeaturePoseGraph {
   const std::unordered_map<CameraId, CameraIntrinsicsMat>& intrinsics() const { return camera_intrinsics_by_camera_; }
 
   // ---- visual features ---------------------------------------------------------------------
-  void addFeature(const FeatureId& feature_id, const Position3d& position) { feature_positions_[feature_id] = std::make_shared<Position3d>(position); }
+  void addFeature(const FeatureId& feature_id, const Position3d& position) {
+    Position3dPtr& p = feature_positions_[feature_id];
+    p = std::make_shared<Position3d>(position);
+    slot_position_[featureSlot_(feature_id)] = p->data();
+  }
   bool hasFeature(const FeatureId& id) const { return feature_positions_.count(id) != 0; }
   FeatureFactorId addVisualFactor(const ReprojectionErrorFactor& factor) {               // low_level...h:341-369
     const FeatureFactorId id = next_visual_factor_id_++;
     factors_[id] = factor;
+    visual_records_by_frame_[factor.frame_id_].push_back({id, factor.feature_id_, factor.frame_id_, factor.camera_id_, featureSlot_(factor.feature_id_),
+                                                          factor.feature_pos_[0], factor.feature_pos_[1], factor.reprojection_error_std_dev_});
     visual_factors_by_frame_[factor.frame_id_].push_back(id);
     visual_factors_by_feature_[factor.feature_id_].push_back(id);
     auto it = first_observed_frame_by_feature_.find(factor.feature_id_);
@@ -132,6 +138,39 @@ class ObjectAndReprojectionFeaturePoseGraph {
       if (fr.first >= min_f && fr.first <= max_f)
         for (FeatureFactorId id : fr.second) { const auto it = factors_.find(id); if (it != factors_.end()) fn(id, it->second); }
   }
+  // The same walk over a flat copy of the factors (one record per factor, per frame in the order of visual_factors_by_frame_; kept by
+  // addVisualFactor): a sliding window looks at every visual factor of its frames twice per frame of the trajectory, and a hash lookup
+  // per factor is most of what building the window's problem costs.  A feature's slot is a dense index (featureIdOfSlot,
+  // featurePointerOfSlot, numFeatureSlots) for per-feature scratch arrays in place of maps keyed by the feature id.
+  struct VisualFactorRecord { FeatureFactorId id; FeatureId feature_id; FrameId frame_id; CameraId camera_id; uint32_t feature_slot; double px, py, sigma; };
+  template <class F>
+  void forEachVisualRecordBetweenFrameIdsInclusive(const FrameId& min_f, const FrameId& max_f, F&& fn) const {
+    if (max_f - min_f < visual_records_by_frame_.size()) {
+      for (FrameId f = min_f; f <= max_f; ++f) {
+        const auto fr = visual_records_by_frame_.find(f);
+        if (fr != visual_records_by_frame_.end()) for (const VisualFactorRecord& r : fr->second) fn(r);
+      }
+      return;
+    }
+    for (const auto& fr : visual_records_by_frame_)
+      if (fr.first >= min_f && fr.first <= max_f) for (const VisualFactorRecord& r : fr.second) fn(r);
+  }
+  // ... a frame's records at once: fn(first record, count)
+  template <class F>
+  void forEachVisualRecordSpanBetweenFrameIdsInclusive(const FrameId& min_f, const FrameId& max_f, F&& fn) const {
+    if (max_f - min_f < visual_records_by_frame_.size()) {
+      for (FrameId f = min_f; f <= max_f; ++f) {
+        const auto fr = visual_records_by_frame_.find(f);
+        if (fr != visual_records_by_frame_.end() && !fr->second.empty()) fn(fr->second.data(), fr->second.size());
+      }
+      return;
+    }
+    for (const auto& fr : visual_records_by_frame_)
+      if (fr.first >= min_f && fr.first <= max_f && !fr.second.empty()) fn(fr.second.data(), fr.second.size());
+  }
+  size_t numFeatureSlots() const { return slot_feature_.size(); }
+  FeatureId featureIdOfSlot(uint32_t slot) const { return slot_feature_[slot]; }
+  double* featurePointerOfSlot(uint32_t slot) const { return slot_position_[slot]; }   // nullptr: factors seen, feature not added (yet)
   bool getFeatureIdForObservationFactor(const FactorInfo& info, FeatureId& feature_id) const {
     if (info.first != kReprojectionErrorFactorTypeId) return false;
     auto it = factors_.find(info.second); if (it == factors_.end()) return false; feature_id = it->second.feature_id_; return true;
@@ -327,6 +366,7 @@ class ObjectAndReprojectionFeaturePoseGraph {
     for (const auto& f : O.object_observation_factors_) next_f = std::max(next_f, f.first + 1);
     for (const auto& f : O.shape_dim_prior_factors_) next_f = std::max(next_f, f.first + 1);
     pg->next_obj_factor_id_ = next_f;
+    pg->rebuildVisualIndex_();
     return pg;
   }
 
@@ -336,6 +376,7 @@ class ObjectAndReprojectionFeaturePoseGraph {
     for (auto& p : c->robot_poses_) p.second = std::make_shared<RawPose3d>(*p.second);
     for (auto& p : c->feature_positions_) p.second = std::make_shared<Position3d>(*p.second);
     for (auto& p : c->ellipsoid_estimates_) p.second = std::make_shared<RawEllipsoid>(*p.second);
+    for (const auto& p : c->feature_positions_) c->slot_position_[c->feature_slot_.at(p.first)] = p.second->data();   // the copy's own values
     return c;
   }
   void setValuesFromAnotherPoseGraph(const std::shared_ptr<ObjectAndReprojectionFeaturePoseGraph>& other) {
@@ -345,6 +386,36 @@ class ObjectAndReprojectionFeaturePoseGraph {
   }
 
  private:
+  uint32_t featureSlot_(const FeatureId& id) {
+    const auto it = feature_slot_.find(id);
+    if (it != feature_slot_.end()) return it->second;
+    const uint32_t slot = (uint32_t)slot_feature_.size();
+    feature_slot_.emplace(id, slot); slot_feature_.push_back(id); slot_position_.push_back(nullptr);
+    return slot;
+  }
+  void rebuildVisualIndex_() {   // from factors_ / visual_factors_by_frame_ / feature_positions_ (a graph made from a state)
+    feature_slot_.clear(); slot_feature_.clear(); slot_position_.clear(); visual_records_by_frame_.clear();
+    std::vector<FeatureId> ids;
+    for (const auto& p : feature_positions_) ids.push_back(p.first);
+    for (const auto& f : factors_) ids.push_back(f.second.feature_id_);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    for (const FeatureId& id : ids) featureSlot_(id);
+    for (const auto& p : feature_positions_) slot_position_[feature_slot_.at(p.first)] = p.second->data();
+    for (const auto& fr : visual_factors_by_frame_) {
+      auto& v = visual_records_by_frame_[fr.first];
+      for (FeatureFactorId id : fr.second) {
+        const auto it = factors_.find(id);
+        if (it == factors_.end()) continue;
+        const ReprojectionErrorFactor& f = it->second;
+        v.push_back({id, f.feature_id_, f.frame_id_, f.camera_id_, feature_slot_.at(f.feature_id_), f.feature_pos_[0], f.feature_pos_[1], f.reprojection_error_std_dev_});
+      }
+    }
+  }
+  std::unordered_map<FrameId, std::vector<VisualFactorRecord>> visual_records_by_frame_;
+  std::unordered_map<FeatureId, uint32_t> feature_slot_;
+  std::vector<FeatureId> slot_feature_;
+  std::vector<double*> slot_position_;
   std::unordered_map<CameraId, CameraExtrinsics> camera_extrinsics_by_camera_;
   std::unordered_map<CameraId, CameraIntrinsicsMat> camera_intrinsics_by_camera_;
   std::unordered_map<FrameId, RawPose3dPtr> robot_poses_;
