@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,40 @@ struct HipError { hipError_t code; const char* what; const char* file; int line;
     hipError_t e__ = (expr);                                                   \
     if (e__ != hipSuccess) throw ::obvi::HipError{e__, #expr, __FILE__, __LINE__}; \
   } while (0)
+
+// Host -> device copies of an upload go through a pinned arena of the handle: the bytes are copied into it and the transfer is
+// enqueued from there, so that it neither waits on a pageable staging copy inside the runtime (15-30 us per call, and an upload is
+// some forty of them) nor needs the stream synchronised before the caller's buffer or a local vector may go away.  The arena is
+// rewound whenever the stream is known to be idle (sync()); a copy that does not fit, or is too long to be worth a second pass
+// over its bytes, goes the plain way and marks the arena `spilled`: the function that issued it must synchronise before it returns.
+struct StagingArena {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  bool spilled = false;
+  void* take(size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (base == nullptr || at + bytes > cap) return nullptr;
+    used = at + bytes;
+    return base + at;
+  }
+  void rewind() { used = 0; spilled = false; }
+};
+inline thread_local StagingArena* tl_staging = nullptr;   // the arena of the handle whose API call runs on this thread
+constexpr size_t kStagedCopyMaxBytes = (size_t)4 << 20;
+
+inline void h2d_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return;
+  StagingArena* a = tl_staging;
+  if (a != nullptr && bytes <= kStagedCopyMaxBytes) {
+    if (void* p = a->take(bytes)) {
+      std::memcpy(p, src, bytes);
+      OBVI_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s));
+      return;
+    }
+  }
+  if (a != nullptr) a->spilled = true;
+  OBVI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+}
 
 template <class T>
 class DevBuf {
@@ -43,7 +78,7 @@ class DevBuf {
   }
   void upload(const T* h, size_t n, hipStream_t s) {
     resize(n);
-    if (n) OBVI_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+    h2d_async(p_, h, n * sizeof(T), s);
   }
   void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
   void download(T* h, size_t n, hipStream_t s) const {

@@ -44,6 +44,7 @@ const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "pose_pass", "s
 struct obvi_ba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  obvi::StagingArena staging;   // pinned; the uploads of an API call are copied through it (host_util.h)
   std::string err;
 
   // ---- host mirrors ----
@@ -188,7 +189,14 @@ int hip_fail(obvi_ba_handle* h, const HipError& e) {
   return fail(h, OBVI_ERR_HIP, buf);
 }
 
-#define OBVI_API_BEGIN try {
+constexpr size_t kStagingBytes = (size_t)16 << 20;   // a sliding window's upload is ~5 MB, its plan ~2 MB; what does not fit is copied the plain way
+// every API call runs with its handle's staging arena as the destination of DevBuf::upload / h2d_async (host_util.h)
+struct StagingScope {
+  StagingArena* prev;
+  explicit StagingScope(const obvi_ba_handle* h) : prev(tl_staging) { tl_staging = h ? const_cast<StagingArena*>(&h->staging) : nullptr; }
+  ~StagingScope() { tl_staging = prev; }
+};
+#define OBVI_API_BEGIN try { StagingScope staging_scope_(h);
 #define OBVI_API_END(h)                                           \
   }                                                               \
   catch (const HipError& e) { return hip_fail(h, e); }            \
@@ -212,7 +220,10 @@ void make_cam(const double* K4, const double* e, DevCam* c) {
   c->fx = K4[0]; c->fy = K4[1]; c->cx = K4[2]; c->cy = K4[3];
 }
 
-void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); }
+void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); h->staging.rewind(); }
+// End of a function that uploaded from its caller's buffers or from local vectors: everything that went through the arena is safe
+// without waiting; a copy that went straight from pageable memory is not.
+void finish_upload(obvi_ba_handle* h) { if (h->staging.spilled || tl_staging != &h->staging) sync(h); }
 
 // Waits for the scalar block of the step just submitted: polls the sequence number the device writes behind the block, and asks the
 // stream now and then so that a failed launch surfaces as an error instead of a hang.
@@ -1103,7 +1114,7 @@ void prepare(obvi_ba_handle* h) {
   h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)7 * O + 1);
   h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
   h->d_pc.resize(2 * ((size_t)P + 1)); h->d_pc_c.resize(2 * ((size_t)P + 1));   // records, then the field-major copy (k_pose_cache)
-  sync(h);  // host vectors above go out of scope
+  finish_upload(h);  // host vectors above go out of scope
   stage("upload + allocations");
   h->dirty = false; h->mask_dirty = false; h->pc_valid = false; h->tiles_cleared = false;
   h->plan_pose_vid = pose_vid; h->plan_obj_vid = obj_vid; h->plan_point_var = point_var; h->plan_is_pad = h->h_is_pad;
@@ -1405,6 +1416,8 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocDefault));
     std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
+    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
+    h->staging.cap = kStagingBytes;
     h->d_scal.resize(SC_COUNT);
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
@@ -1428,6 +1441,7 @@ void obvi_ba_destroy(obvi_ba_handle* h) {
   for (hipEvent_t e : {h->ev_fork, h->ev_join}) if (e) (void)hipEventDestroy(e);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->staging.base) (void)hipHostFree(h->staging.base);
   select_scratch_free(&h->sel_scratch);
   // DevBuf members free in ~obvi_ba_handle
   hipStream_t s = h->stream;
@@ -1442,7 +1456,7 @@ int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const dou
   h->h_cams.resize(n);
   for (int i = 0; i < n; ++i) make_cam(K + 4 * i, ext + 7 * i, &h->h_cams[i]);
   h->d_cams.upload(h->h_cams, h->stream);
-  sync(h);
+  finish_upload(h);
   bake_bbox(h);   // the bounding-box factors already uploaded follow the new intrinsics
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1455,8 +1469,8 @@ static int set_blocks(obvi_ba_handle* h, int64_t n, int dim, const double* v, co
   *count = n;
   if (c) hc->assign(c, c + n); else hc->assign(n, 0);
   dv->resize((size_t)n * dim + 1);
-  if (n) OBVI_HIP(hipMemcpyAsync(dv->get(), v, sizeof(double) * n * dim, hipMemcpyHostToDevice, h->stream));
-  sync(h);
+  h2d_async(dv->get(), v, sizeof(double) * n * dim, h->stream);
+  finish_upload(h);
   h->dirty = true;
   h->have_snapshot = false;
   return OBVI_OK;
@@ -1481,8 +1495,8 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz) {
   if (!h || n != h->L || (n > 0 && !xyz)) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "update_points: size mismatch");
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
-  if (n) OBVI_HIP(hipMemcpyAsync(h->d_point.get(), xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
-  sync(h);
+  h2d_async(h->d_point.get(), xyz, sizeof(double) * 3 * n, h->stream);
+  finish_upload(h);
   return OBVI_OK;
   OBVI_API_END(h)
 }
@@ -1565,7 +1579,7 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   }
   h->d_rq_point.upload(q_point, s); h->d_rq_cam.upload(q_cam, s); h->d_rq_pixel.upload(q_pix, s); h->d_rq_sigma.upload(q_sg, s);
   h->d_rq_active.upload(q_act, s); h->d_rq_pose_ptr.upload(pptr, s);
-  sync(h);
+  finish_upload(h);
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1590,7 +1604,7 @@ int obvi_ba_set_bbox(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx, cons
   h->h_bb_cam = cam; h->h_bb_corners.assign(corners, corners + 4 * n); h->h_bb_m4.swap(m4all);
   h->d_bb_obj.upload(h->h_bb_obj, s); h->d_bb_pose.upload(h->h_bb_pose, s); h->d_bb_cam.upload(cam, s);
   h->d_bb_active.upload(h->h_bb_active, s);
-  sync(h);
+  finish_upload(h);
   bake_bbox(h);
   h->dirty = true;
   return OBVI_OK;
@@ -1610,7 +1624,7 @@ int obvi_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_i
   h->h_sp_obj.assign(obj_idx, obj_idx + n); h->h_sp_active.assign(n, 1);
   hipStream_t s = h->stream;
   h->d_sp_obj.upload(h->h_sp_obj, s); h->d_sp_mean.upload(mean3, 3 * n, s); h->d_sp_sqrt_inf.upload(si, s); h->d_sp_active.upload(h->h_sp_active, s);
-  sync(h);
+  finish_upload(h);
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1629,7 +1643,7 @@ int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx
   h->h_lt_obj.assign(obj_idx, obj_idx + n); h->h_lt_active.assign(n, 1);
   hipStream_t s = h->stream;
   h->d_lt_obj.upload(h->h_lt_obj, s); h->d_lt_mean.upload(mean7, 7 * n, s); h->d_lt_sqrt_inf.upload(si, s); h->d_lt_active.upload(h->h_lt_active, s);
-  sync(h);
+  finish_upload(h);
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1662,7 +1676,7 @@ int obvi_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* ia, const 
   hipStream_t s = h->stream;
   h->d_rl_a.upload(h->h_rl_a, s); h->d_rl_b.upload(h->h_rl_b, s); h->d_rl_t.upload(t3, 3 * n, s); h->d_rl_R.upload(R, s);
   h->d_rl_sqrt_inf.upload(si, s); h->d_rl_active.upload(h->h_rl_active, s);
-  sync(h);
+  finish_upload(h);
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)
@@ -1679,7 +1693,7 @@ int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t type, const uint8_t* mask
       std::vector<uint8_t> q(h->n_rp);
       for (int64_t k = 0; k < h->n_rp; ++k) q[k] = h->h_rp_active[h->h_rq_src[k]];
       h->d_rq_active.upload(q, s);
-      sync(h);
+      finish_upload(h);
       break;
     }
     case OBVI_FACTOR_BBOX: set_mask<uint32_t>(h->h_bb_active, h->d_bb_active, mask, h->n_bb, s, nullptr); break;
@@ -1688,7 +1702,7 @@ int obvi_ba_set_active_mask(obvi_ba_handle* h, int32_t type, const uint8_t* mask
     case OBVI_FACTOR_REL_POSE: set_mask<uint32_t>(h->h_rl_active, h->d_rl_active, mask, h->n_rl, s, nullptr); break;
     default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_active_mask: unknown factor type");
   }
-  sync(h);
+  finish_upload(h);
   h->mask_dirty = true;   // prepare() keeps the symbolic plan if the new masks select a subset of what it was built for
   return OBVI_OK;
   OBVI_API_END(h)
