@@ -228,6 +228,28 @@ def test_blocks_or_cameras_re_uploaded_after_the_factors():
     assert abs(o.evaluate(True, False)[0] - cg) <= 1e-12 * cg
 
 
+def test_uploads_outlive_their_source_buffers_and_the_staging_arena_wraps():
+    """Uploads are copied through a pinned arena of the handle and enqueued from there without waiting (host_util.h: StagingArena), so
+    (1) the caller may overwrite its buffer the moment a set_* call returns, and (2) a long run of uploads with no solve in between
+    fills the 16 MB arena: the copy that no longer fits goes the plain way, the call synchronises, the arena starts over.  Each
+    upload here carries its own serial number; whatever is read back must be the last one."""
+    g = helpers.product_ba()
+    n = 40000                                           # 0.96 MB per upload: the arena is full after 17 of them
+    buf = np.empty((n, 3))
+    for k in range(60):
+        buf[:] = k                                      # same buffer, new contents: the previous upload must not see them
+        g.set_points(buf, None)
+    assert np.array_equal(g.get_points(), np.full((n, 3), 59.0))
+    for k in range(60, 100):                            # update_points: the other raw copy of the ABI
+        buf[:] = k
+        g.update_points(buf)
+    assert np.array_equal(g.get_points(), np.full((n, 3), 99.0))
+    big = np.arange(3 * 400000, dtype=np.float64).reshape(-1, 3)   # 9.6 MB: above the per-copy limit of the arena, straight from the caller
+    g.set_points(big, None)
+    big_copy = big.copy(); big[:] = -1.0
+    assert np.array_equal(g.get_points(), big_copy)
+
+
 def test_two_launch_schedule_of_the_tile_cholesky(monkeypatch):
     """OBVI_FUSED_POTRF=0: update jobs of a level and the potrf of the next level as two launches (nothing waits inside a launch);
     same steps as the fused schedule and as the oracle.  The knob is read once per process, so this runs in a child process."""
