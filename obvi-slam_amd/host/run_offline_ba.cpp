@@ -1,7 +1,7 @@
 // run_offline_ba.cpp -- driver of the host-side mirror: the shape of the reference's
 // offline_object_visual_slam_main / run_opt_from_pg_state for a scene whose associations are given.
 //   run_offline_ba <scene.txt> <out.json> [--window W] [--gba-frequency F] [--device D] [--csv ceres_opt_summary.csv] [--ltm]
-//   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K] [--phase-two-masks]   (no GPU: flattening only)
+//   run_offline_ba <scene.txt> <out.json> --dump-build MIN MAX [--excluded-every K] [--phase-two-masks] [--frames-reversed]   (no GPU: flattening only)
 //   run_offline_ba <scene.txt> <out.json> ... [--save-checkpoint DIR] [--iteration-log-dir DIR] [--merge-distance M]
 //   run_offline_ba --from-checkpoint <pose_graph_state.json> <out.json> [--ltm] [--device D]   the shape of run_opt_from_pg_state: final global BA (+ long-term map) from a checkpoint
 //   run_offline_ba --checkpoint-roundtrip <in.json> <out.json>                                  (no GPU) read a pose-graph state and write it back
@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
-  front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0;
+  front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window") && i + 1 < argc) sw.local_ba_window_size_ = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "--gba-frequency") && i + 1 < argc) sw.global_ba_frequency_ = std::strtoull(argv[++i], nullptr, 10);
@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--pose-parallax")) front_end_params.enforce_min_robot_pose_parallax_requirement_ = true;
     else if (!std::strcmp(argv[i], "--dump-build") && i + 2 < argc) { dump = true; dump_min = std::strtoull(argv[++i], nullptr, 10); dump_max = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--frames-reversed")) frames_reversed = true;   // --dump-build: the frames' sightings enter the pose graph last frame first (factor ids descend with the frame)
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
   }
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
@@ -162,7 +163,19 @@ int main(int argc, char** argv) {
   if (dump) {
     // flattening only: every frame's data goes into the pose graph, then one build for [min, max]
     MainPgPtr pg = checkpoint_graph ? checkpoint_graph : std::make_shared<MainPg>(data.camera_extrinsics_by_camera_, data.camera_intrinsics_by_camera_);
-    if (!checkpoint_graph) for (FrameId f = 0; f <= max_frame_id; ++f) addFrameDataToPoseGraph(data, pg, f, rp.relative_pose_cov_params_);
+    if (!checkpoint_graph) {
+      const VisualFeatureAdder none = [](const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&) { return true; };
+      for (FrameId f = 0; f <= max_frame_id; ++f) addFrameDataToPoseGraph(data, pg, f, rp.relative_pose_cov_params_, frames_reversed ? none : VisualFeatureAdder(nullptr));
+      if (frames_reversed)   // the sightings enter last frame first, as when a front end initialises a feature late and adds its earlier sightings then
+        for (FrameId k = 0; k <= max_frame_id; ++k) {
+          const FrameId f = max_frame_id - k;
+          if (f >= data.visual_obs_by_frame_.size()) continue;
+          for (const auto& o : data.visual_obs_by_frame_[f]) {
+            if (!pg->hasFeature(o.feature_id)) pg->addFeature(o.feature_id, data.initial_feature_positions_.at(o.feature_id));
+            pg->addVisualFactor(ReprojectionErrorFactor{f, o.feature_id, o.camera_id, o.pixel, data.reprojection_error_std_dev_});
+          }
+        }
+    }
     pose_graph_optimizer::OptimizationScopeParams scope;
     scope.min_low_level_feature_observations_per_frame_ = en.min_low_level_feature_observations_per_frame_;
     scope.poses_prior_to_window_to_keep_constant_ = en.poses_prior_to_window_to_keep_constant_;
@@ -215,6 +228,7 @@ int main(int argc, char** argv) {
       arr("mask_rp", m.rp); arr("mask_bb", m.bb); arr("mask_sp", m.sp);
       out << "\"mask_n_features\": " << m.n_features << ", \"mask_n_objects\": " << m.n_objects << ",\n";
     }
+    { std::vector<double> ids; for (size_t i = 0; i < fp.rp_pose.size(); ++i) ids.push_back((double)info.at((obvi::ResidualBlockId)i).second); arr("rp_factor_ids", ids); }
     out << "\"num_blocks\": " << info.size() << ", \"num_excluded\": " << excluded.size() << "}\n";
     return 0;
   }

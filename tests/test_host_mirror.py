@@ -108,6 +108,29 @@ def test_build_flattening_matches_selection_rules(driver, scene, tmp_path, windo
     assert key_got == key_exp
 
 
+def test_build_orders_residual_blocks_by_factor_id_whatever_the_insertion_order(driver, scene, tmp_path):
+    """Residual blocks go by factor id (the reference walks an ordered set of ids).  The build flattens the pose graph's per-frame records
+    as they come and only sorts when the ids do not ascend: with the frames entered last frame first they descend from frame to frame,
+    and the result must be the same selection in ascending id order."""
+    prob, path, new_id = scene
+    outs = []
+    for extra in ([], ["--frames-reversed"]):
+        out = str(tmp_path / ("build%d.json" % len(outs)))
+        subprocess.check_call([driver, path, out, "--dump-build", "20", "70"] + extra)
+        outs.append(json.load(open(out)))
+    exp = expected_build(prob, new_id, 20, 70)
+    for got in outs:
+        ids = np.array(got["rp_factor_ids"], dtype=np.int64)
+        assert len(ids) == exp["n_rp"] and np.all(np.diff(ids) > 0)
+        assert np.array_equal(np.array(got["features"], dtype=np.int64), exp["features"])
+    fwd, rev = outs
+    frames_f = np.array(fwd["frames"], dtype=np.int64)[np.array(fwd["rp_pose"], dtype=np.int64)]
+    frames_r = np.array(rev["frames"], dtype=np.int64)[np.array(rev["rp_pose"], dtype=np.int64)]
+    assert np.all(np.diff(frames_f) >= 0) and np.all(np.diff(frames_r) <= 0) and frames_r[0] > frames_r[-1]
+    key = lambda g, fr: sorted(zip(fr.tolist(), np.array(g["features"], dtype=np.int64)[np.array(g["rp_point"], dtype=np.int64)].tolist(), np.array(g["rp_pixel"]).reshape(-1, 2)[:, 0].tolist()))
+    assert key(fwd, frames_f) == key(rev, frames_r)
+
+
 def test_build_honours_excluded_factors(driver, scene, tmp_path):
     """Phase II: excluded_feature_factor_types_and_ids drop factors *before* the min-observation filter (:886-905, :826-861)."""
     prob, path, new_id = scene
