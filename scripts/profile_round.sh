@@ -37,12 +37,14 @@ for r in rows:
     tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 out = {"_method": "rocprofv3 --pmc (one counter-only pass, 8 SQ slots + GRBM) of `bench.py --steps 4 --warmup 1 --no-cpu-baseline`; per launch averages. "
                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts, SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs "
-                  "(MI355X_MICROARCH.md); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) -- the gfx94x MfmaUtil formula", "kernels": {}}
+                  "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE comes out summed over the 8 XCDs (k_schur_window: 9.12 M per launch of 460 us = 8 x 2.48 GHz x 460 us), "
+                  "so mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): busy cycles of the matrix pipes over the SIMD cycles of the launch "
+                  "(sets up to r02g divided by GRBM_GUI_ACTIVE * 1024 and read 8 x too low)", "kernels": {}}
 for k in tot:
     e = {c: tot[k][c] / max(1, n[k][c]) for c in tot[k]}
     e["launches"] = max(n[k].values())
     if e.get("GRBM_GUI_ACTIVE"):
-        e["mfma_busy_frac"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (e["GRBM_GUI_ACTIVE"] * 256 * 4)
+        e["mfma_busy_frac"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (e["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
     if e.get("SQ_WAVE_CYCLES"):
         e["wait_frac"] = e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"]; e["issue_stall_frac"] = e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
         e["active_frac"] = e.get("SQ_ACTIVE_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
