@@ -793,14 +793,17 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
   OptimizationScopeParams scope_pgo = optimization_scope_params;                                                              // :161-165
   scope_pgo.include_visual_factors_ = false;
   scope_pgo.poses_prior_to_window_to_keep_constant_ = 1;
-  std::unordered_map<FeatureId, std::pair<FrameId, Position3d>> relative_positions_from_first;
+  // (the reference keys this by feature id in a map filled from a copy of all feature estimates; a flat list over the graph's own
+  // feature table holds the same entries -- tens of thousands at a global-BA frame)
+  struct RelativeToFirst { FeatureId feature; FrameId first; Position3d relative; };
+  std::vector<RelativeToFirst> relative_positions_from_first;
   if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :167-199
-    std::unordered_map<FeatureId, Position3d> feats;
-    pose_graph->getVisualFeatureEstimates(feats);
-    for (const auto& f : feats) {
+    relative_positions_from_first.reserve(pose_graph->featurePositions().size());
+    for (const auto& f : pose_graph->featurePositions()) {
       FrameId first;
-      if (pose_graph->getFirstObservedFrameForFeature(f.first, first) && raw.count(first))
-        relative_positions_from_first[f.first] = {first, getPositionRelativeToPose(convertToPose3D(raw.at(first)), f.second)};
+      if (!pose_graph->getFirstObservedFrameForFeature(f.first, first)) continue;
+      const auto pose_of_first = raw.find(first);
+      if (pose_of_first != raw.end()) relative_positions_from_first.push_back({f.first, first, getPositionRelativeToPose(convertToPose3D(pose_of_first->second), *f.second)});
     }
   }
   if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(max_frame_id, false, true, true, attempt_num);          // :201-204
@@ -813,8 +816,10 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
   if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
   if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :238-283
     pose_graph->getRobotPoseEstimates(raw);
-    for (const auto& f : relative_positions_from_first)
-      if (raw.count(f.second.first)) pose_graph->updateVisualPositionParams(f.first, combinePoseAndPosition(convertToPose3D(raw.at(f.second.first)), f.second.second));
+    for (const RelativeToFirst& f : relative_positions_from_first) {
+      const auto pose_of_first = raw.find(f.first);
+      if (pose_of_first != raw.end()) pose_graph->updateVisualPositionParams(f.feature, combinePoseAndPosition(convertToPose3D(pose_of_first->second), f.relative));
+    }
   }
   if (pgo_solver_params.enable_visual_feats_only_opt_post_pgo_) {                                                            // :284-350
     std::optional<OptimizationLogger> null_logger;
