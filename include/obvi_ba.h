@@ -75,10 +75,24 @@ enum {
   OBVI_RESIDUAL_DIM_REL_POSE = 6
 };
 
+/* Which of the reference's two reprojection functors the handle evaluates (residual_creator.h:251-264 instantiates the first;
+ * the second is the symforce-generated one north_star names). */
+enum {
+  OBVI_REPROJECTION_AUTODIFF = 0,  /* ReprojectionCostFunctor (reprojection_cost_functor.h:56-93, vslam_math_util.h:347-394): no depth clamp,
+                                      constant rotation (zero d/d aa) below |aa| = 1e-8 -- what the reference binary runs */
+  OBVI_REPROJECTION_ANALYTIC = 1   /* ReprojectionCostFunctorAnalyticJacobian::Evaluate (reprojection_cost_functor_analytic_jacobian.h:59-566 ==
+                                      symforce/reprojectionResidual_with_jacobians012.h:37-521): depth z <- max(z, 1e-15) (:160) with the sign-gated
+                                      derivative of the clamp (:289-292), rotation smooth through aa = 0 (epsilon inside the norm, :63-70) */
+};
+
 typedef struct {
-  int32_t device_id;          /* HIP device ordinal (LOCAL_RANK for one-process-per-GPU) */
-  int32_t object_block_size;  /* 7 = yaw-only ellipsoid (the only variant the reference compiles) */
-  int32_t reserved[6];
+  int32_t device_id;             /* HIP device ordinal (LOCAL_RANK for one-process-per-GPU) */
+  int32_t object_block_size;     /* 7 = yaw-only ellipsoid (the only variant the reference compiles) */
+  int32_t reprojection_variant;  /* OBVI_REPROJECTION_* (0 = the production functor) */
+  int32_t deterministic;         /* != 0: every cross-workgroup accumulation of a solve runs in a fixed order (no floating-point atomics whose
+                                    order can change between runs): two solves of the same problem are bit-identical, as Ceres is at a fixed
+                                    num_threads (object_pose_graph_optimizer.h:664).  Slower; for parity and regression runs. */
+  int32_t reserved[4];
 } obvi_ba_options;
 
 /* Mirrors pose_graph_optimization::OptimizationSolverParams

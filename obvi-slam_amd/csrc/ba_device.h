@@ -42,6 +42,21 @@ enum Scalar {
   SC_COUNT = 32
 };
 
+// Deterministic mode (obvi_ba_options.deterministic).  The sums a solve's decisions are taken from -- costs, |g|^2, |x|^2, |delta|^2, the
+// model cost change -- are then not added to the scalar block with fp64 atomics (whose order changes from run to run): workgroup b of
+// a kernel stores its partial sum at scal[SC_COUNT + slot * kDetStride + b], and a one-workgroup-per-slot kernel behind it adds them up
+// in a fixed order (launch_det_reduce).  The scalar block of a deterministic handle is allocated with that tail.  Counters (failed
+// pivots, non-finite entries: small integers, exact in any order) and the gradient maximum stay atomic.
+constexpr int kDetSlots = 7;
+constexpr int64_t kDetStride = 1 << 20;   // workgroups per kernel (a launcher refuses a larger grid in deterministic mode)
+inline __host__ __device__ int det_slot_of(int sc) {
+  return sc == SC_COST ? 0 : sc == SC_COST_CAND ? 1 : sc == SC_GSQ ? 2 : sc == SC_XSQ ? 3 : sc == SC_STEPSQ ? 4 : sc == SC_MODEL_CHANGE ? 5 : sc == SC_COST_FIXED ? 6 : -1;
+}
+inline __host__ __device__ int det_scalar_of(int slot) {
+  return slot == 0 ? SC_COST : slot == 1 ? SC_COST_CAND : slot == 2 ? SC_GSQ : slot == 3 ? SC_XSQ : slot == 4 ? SC_STEPSQ : slot == 5 ? SC_MODEL_CHANGE : SC_COST_FIXED;
+}
+void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask /* bit sc: scalar sc was written by the kernel */);
+
 struct ReprojDev {          // observations sorted by (point, pose): CSC by point
   int64_t n;
   const uint32_t* pose;     // [n]
@@ -77,6 +92,8 @@ struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   const int32_t* pose_vid;  // [P]  reduced index or -1
   const int32_t* obj_vid;   // [O]
   const uint8_t* point_var; // [L]
+  int32_t analytic_rotation; // the pose caches follow the analytic-Jacobian functor (make_pose_cache, ba_math.h)
+  int32_t deterministic;     // obvi_ba_options.deterministic: per-workgroup partial sums behind the scalar block instead of fp64 atomics (kDetStride)
 };
 
 struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
@@ -87,6 +104,10 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
   int32_t bb_pairs_unique;                              // no (object, pose) pair occurs twice: the off-diagonal block of a factor is its own
   const uint32_t* bbo_ptr; const uint32_t* bbo_idx;     // factors by object: [O+1], [n_bb]
   const uint32_t* bbp_ptr; const uint32_t* bbp_idx;     // factors by pose:   [P+1], [n_bb]
+  // deterministic mode: the priors and the relative-pose factors go the same way -- per-factor blocks into a scratch (slot = shape prior i,
+  // then n_sp + LTM prior i, then n_sp + n_lt + relative-pose factor i; kBbBlk doubles: first block | second block), summed per target
+  // block in list order by k_small_gather.  Targets: objects [0, O), then poses [O, O + P); entry = 2 slot + side (1: the slot's second block)
+  double* sm_blk; const uint32_t* smt_ptr; const uint32_t* smt_idx;
   // shape priors
   int64_t n_sp; const uint32_t* sp_obj; const double* sp_mean; const double* sp_sqrt_inf; const uint8_t* sp_active; double sp_huber;
   // LTM priors
@@ -119,7 +140,7 @@ struct PointDev {           // per eliminated point
 };
 
 // ---- launchers (ba_kernels.hip) --------------------------------------------------------
-void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out);
+void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out, int analytic /* obvi_ba_options.reprojection_variant == OBVI_REPROJECTION_ANALYTIC */);
 void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
                        const uint32_t* long_points, int64_t n_long);
@@ -178,6 +199,7 @@ void select_scratch_free(SelectScratch* sc);
 struct CholPlan {
   int32_t nt;
   int32_t nlevels;
+  int32_t deterministic;      // column-oriented backward substitution without atomics (one launch per level)
   const int32_t* lvl_k_ptr;   // host [nlevels+1]   tile columns of each level
   const int32_t* lvl_k;       // device
   const int32_t* trsm_ptr;    // host [nlevels+1]   trsm jobs (i,k), k in the level

@@ -30,8 +30,14 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// block-wide sum -> one atomic per block
-__device__ __forceinline__ void block_accumulate(double v, double* dst) {
+// a workgroup's total for scalar `sc`, one thread per workgroup: an fp64 atomic, or -- deterministic mode, ba_device.h -- the
+// workgroup's slot of the partial sums behind the scalar block (every workgroup of the grid must get here: the slots are not cleared)
+__device__ __forceinline__ void scal_add(double* scal, int det, int sc, double t) {
+  if (det) scal[SC_COUNT + (int64_t)det_slot_of(sc) * kDetStride + blockIdx.x] = t;
+  else if (t != 0.0) atomic_add_f64(scal + sc, t);
+}
+// block-wide sum -> one atomic (or one partial-sum slot) per block
+__device__ __forceinline__ void block_accumulate(double v, double* scal, int sc, int det = 0) {
   __shared__ double sm[kBlock / 64];
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -41,7 +47,7 @@ __device__ __forceinline__ void block_accumulate(double v, double* dst) {
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < kBlock / 64; ++i) t += sm[i];
-    if (t != 0.0) atomic_add_f64(dst, t);
+    scal_add(scal, det, sc, t);
   }
 }
 __device__ __forceinline__ void block_accumulate_max(double v, double* dst_bits) {
@@ -76,7 +82,8 @@ __device__ __forceinline__ double rsqrt_f64(double p) {
   return y;
 }
 // block-wide sums of 4 values and maximum of a 5th with one barrier pair -> one atomic each per block
-__device__ __forceinline__ void block_accumulate5(double v0, double* d0, double v1, double* d1, double v2, double* d2, double v3, double* d3, double vmax, double* dmax_bits) {
+// (deterministic mode: the three sums go to the partial-sum slots; the failure count and the maximum are exact in any order)
+__device__ __forceinline__ void block_accumulate5(double* scal, int det, double v0, int s0, double v1, int s1, double v2, int s2, double v3, double* d3, double vmax, double* dmax_bits) {
   __shared__ double sm5[kBlock / 64][5];
   v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); vmax = wave_max(vmax);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -86,9 +93,9 @@ __device__ __forceinline__ void block_accumulate5(double v0, double* d0, double 
   if (threadIdx.x < 5) {
     double t = 0.0;
     for (int i = 0; i < kBlock / 64; ++i) t = threadIdx.x < 4 ? t + sm5[i][threadIdx.x] : fmax(t, sm5[i][4]);
-    double* dst = threadIdx.x == 0 ? d0 : threadIdx.x == 1 ? d1 : threadIdx.x == 2 ? d2 : threadIdx.x == 3 ? d3 : dmax_bits;
-    if (threadIdx.x < 4) { if (t != 0.0) atomic_add_f64(dst, t); }
-    else if (t > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t));
+    if (threadIdx.x < 3) scal_add(scal, det, threadIdx.x == 0 ? s0 : threadIdx.x == 1 ? s1 : s2, t);
+    else if (threadIdx.x == 3) { if (t != 0.0) atomic_add_f64(d3, t); }
+    else if (t > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(dmax_bits), (unsigned long long)__double_as_longlong(t));
   }
 }
 
@@ -100,14 +107,14 @@ __device__ __forceinline__ double lm_lambda(double colsq, double scale, double r
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* __restrict__ poses, PoseCache* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* __restrict__ poses, PoseCache* __restrict__ out, int analytic) {
   const int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   if (p >= P) return;
   double pose[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) pose[k] = poses[6 * p + k];
   PoseCache pc;
-  make_pose_cache(pose, &pc);
+  make_pose_cache(pose, &pc, analytic != 0);
   out[p] = pc;
   // second copy, field-major, behind the records (out must hold 2 (P + 1) records): k_point_pass gathers the cache per observation,
   // and the lanes of a point's run look at consecutive poses -- field-major makes those loads coalesce
@@ -208,10 +215,10 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
       pt.u[3 * l] = 0.0; pt.u[3 * l + 1] = 0.0; pt.u[3 * l + 2] = 0.0;
     }
   }
-  block_accumulate(cost, scal + SC_COST);
-  block_accumulate(gsq, scal + SC_GSQ);
-  block_accumulate(xsq, scal + SC_XSQ);
-  block_accumulate(fail, scal + SC_CHOL_FAIL);
+  block_accumulate(cost, scal, SC_COST, b.deterministic);
+  block_accumulate(gsq, scal, SC_GSQ, b.deterministic);
+  block_accumulate(xsq, scal, SC_XSQ, b.deterministic);
+  block_accumulate(fail, scal, SC_CHOL_FAIL);
   block_accumulate_max(gmax, scal + SC_GMAX_BITS);
 }
 
@@ -349,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
     const double2* src = reinterpret_cast<const double2*>(img);
     for (int i = lane; i < total2; i += 64) dst[i] = src[i];
   }
-  block_accumulate5(cost, scal + SC_COST, gsq, scal + SC_GSQ, xsq, scal + SC_XSQ, fail, scal + SC_CHOL_FAIL, gmax, scal + SC_GMAX_BITS);
+  block_accumulate5(scal, b.deterministic, cost, SC_COST, gsq, SC_GSQ, xsq, SC_XSQ, fail, scal + SC_CHOL_FAIL, gmax, scal + SC_GMAX_BITS);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -411,7 +418,7 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
 }
 
 // ---------------------------------------------------------------------------------------
-// K2/K3.  Small factor families: thread per factor, atomics into the reduced accumulators.
+// K2/K3.  Small factor families (k_small_lin_lanes below): 16 lanes per bounding-box / relative-pose factor, a lane per prior.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void add_diag_block(double* Hd, double* gd, int d, const double* J, const double* r, int m, double w) {
   for (int x = 0; x < d; ++x) {
@@ -426,70 +433,27 @@ __device__ __forceinline__ void add_diag_block(double* Hd, double* gd, int d, co
   }
 }
 
-__global__ void __launch_bounds__(64) k_bbox_lin(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
-                                                const double* __restrict__ objects, ReducedDev rd, double* scal) {
-  const int64_t i = blockIdx.x * 64LL + threadIdx.x;
-  double cost = 0.0, w = 0.0;
-  double r[4] = {0.0, 0.0, 0.0, 0.0}, Je[28], Jp[24];
-  int32_t ov = -1, pv = -1;
-  if (i < sf.n_bb && sf.bb_active[i]) {
-    const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
-    ov = b.obj_vid[o]; pv = b.pose_vid[p];
-    if (ov >= 0 || pv >= 0) {
-      D13 res[4];
-      bbox_eval(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-      for (int a = 0; a < 4; ++a) {
-        r[a] = res[a].v;
-        for (int k = 0; k < 7; ++k) Je[7 * a + k] = res[a].d[k];
-        for (int k = 0; k < 6; ++k) Jp[6 * a + k] = res[a].d[7 + k];
-      }
-      double rho0;
-      huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
-      cost = 0.5 * rho0;
-    } else { ov = pv = -1; }
-  }
-  if (ov < 0) for (int k = 0; k < 28; ++k) Je[k] = 0.0;
-  // Object block.  Factors usually arrive grouped by object, so the lanes of a wavefront would hit the same 35 addresses with
-  // 64 atomics each: when every lane that has an object has the same one, the lanes are summed first and one lane adds.
-  int32_t lo = ov >= 0 ? ov : INT32_MAX, hi = ov;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
-  if (hi >= 0 && lo == hi) {
-    double* Hd = rd.Hdiag + 36 * b.nPv + 49 * (int64_t)hi;
-    double* gd = rd.g + 6 * b.nPv + 7 * (int64_t)hi;
-    for (int x = 0; x < 7; ++x) {
-      for (int y = 0; y <= x; ++y) {
-        double acc = 0.0;
-        for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Je[7 * a + y];
-        acc = wave_sum(w * acc);
-        if (threadIdx.x == 0) atomic_add_f64(Hd + 7 * x + y, acc);
-      }
+// deterministic mode: the same block, lower-packed (H: d (d + 1) / 2 entries, then g: d) into the factor's scratch slot, no atomics
+__device__ __forceinline__ void store_diag_block(double* slot, int d, const double* J, const double* r, int m, double w) {
+  int e = 0;
+  for (int x = 0; x < d; ++x)
+    for (int y = 0; y <= x; ++y) {
       double acc = 0.0;
-      for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * r[a];
-      acc = wave_sum(w * acc);
-      if (threadIdx.x == 0) atomic_add_f64(gd + x, acc);
+      for (int a = 0; a < m; ++a) acc += J[d * a + x] * J[d * a + y];
+      slot[e++] = w * acc;
     }
-  } else if (ov >= 0) {
-    add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, Je, r, 4, w);
+  for (int x = 0; x < d; ++x) {
+    double acc = 0.0;
+    for (int a = 0; a < m; ++a) acc += J[d * a + x] * r[a];
+    slot[e++] = w * acc;
   }
-  if (pv >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)pv, rd.g + 6 * (int64_t)pv, 6, Jp, r, 4, w);
-  if (ov >= 0 && pv >= 0) {
-    // off-diagonal block in the lower triangle of the tile grid: whichever of the two blocks is eliminated later is the row
-    const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
-    const bool obj_low = orow > prow;
-    for (int x = 0; x < 7; ++x) for (int y = 0; y < 6; ++y) {
-      double acc = 0.0;
-      for (int a = 0; a < 4; ++a) acc += Je[7 * a + x] * Jp[6 * a + y];
-      atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc);
-    }
-  }
-  cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
 }
+constexpr int kSmBlk = 62, kSmSecond = 35;   // scratch slot of a prior / relative-pose factor: first block at 0, second at 35 (the layout of kBbBlk)
 
 __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
   const int64_t t = block * 64LL + threadIdx.x;
   double cost = 0.0;
+  bool stored = false;
   if (t < sf.n_sp) {
     const int64_t i = t;
     if (sf.sp_active[i]) {
@@ -501,7 +465,8 @@ __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev
         double rho0, w;
         huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
+        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, 7, J, r, 3, w); stored = true; }
+        else add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
       }
     }
   } else if (t < sf.n_sp + sf.n_lt) {
@@ -517,54 +482,17 @@ __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev
         double rho0, w;
         huber_eval(s, sf.lt_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
+        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, 7, J, r, 7, w); stored = true; }
+        else add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
       }
     }
   }
-  cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
-}
-
-__global__ void __launch_bounds__(64) k_object_priors_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ objects, ReducedDev rd, double* scal) {
-  object_priors_lin(blockIdx.x, b, sf, objects, rd, scal);
-}
-
-__global__ void __launch_bounds__(64) k_relpose_lin(BlocksDev b, SmallFactorsDev sf, const double* __restrict__ poses, ReducedDev rd, double* scal) {
-  const int64_t i = blockIdx.x * 64LL + threadIdx.x;
-  double cost = 0.0;
-  if (i < sf.n_rl && sf.rl_active[i]) {
-    const uint32_t pa = sf.rl_a[i], pb = sf.rl_b[i];
-    const int32_t va = b.pose_vid[pa], vb = b.pose_vid[pb];
-    if (va >= 0 || vb >= 0) {
-      D12 res[6];
-      relpose_eval(poses + 6 * (int64_t)pa, poses + 6 * (int64_t)pb, sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
-      double r[6], Ja[36], Jb[36];
-      double s = 0.0;
-      for (int a = 0; a < 6; ++a) {
-        r[a] = res[a].v; s += r[a] * r[a];
-        for (int k = 0; k < 6; ++k) { Ja[6 * a + k] = res[a].d[k]; Jb[6 * a + k] = res[a].d[6 + k]; }
-      }
-      double rho0, w;
-      huber_eval(s, sf.rl_huber, &rho0, &w);
-      cost = 0.5 * rho0;
-      if (va >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)va, rd.g + 6 * (int64_t)va, 6, Ja, r, 6, w);
-      if (vb >= 0) add_diag_block(rd.Hdiag + 36 * (int64_t)vb, rd.g + 6 * (int64_t)vb, 6, Jb, r, 6, w);
-      if (va >= 0 && vb >= 0 && va != vb) {
-        const int64_t ra = b.pose_row[va], rb = b.pose_row[vb];
-        const bool b_low = rb > ra;  // lower triangle: the later-eliminated block is the row
-        const double* Jr_ = b_low ? Jb : Ja;
-        const double* Jc_ = b_low ? Ja : Jb;
-        const int64_t row = b_low ? rb : ra, col = b_low ? ra : rb;
-        for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
-          double acc = 0.0;
-          for (int a = 0; a < 6; ++a) acc += Jr_[6 * a + x] * Jc_[6 * a + y];
-          atomic_add_f64(S_at(rd.S, rd.nt, row + x, col + y), w * acc);
-        }
-      }
-    }
+  if (b.deterministic && !stored && t < sf.n_sp + sf.n_lt) {   // an inactive factor / a constant object: a zero block (k_small_gather reads every slot of its lists)
+    double* slot = sf.sm_blk + (int64_t)kSmBlk * t;
+    for (int e = 0; e < 35; ++e) slot[e] = 0.0;
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+  if (threadIdx.x == 0) scal_add(scal, b.deterministic, SC_COST, cost);
 }
 
 // Small problems (a sliding window holds a few hundred of these factors): the thread-per-factor kernels above are then a handful of
@@ -678,7 +606,7 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
     atomic_add_f64(rd.g + 6 * (int64_t)pv + x, w * acc);
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+  if (threadIdx.x == 0) scal_add(scal, b.deterministic, SC_COST, cost);
 }
 // lanes 0..5 own the columns of the first pose, 6..11 of the second
 __device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const double* __restrict__ poses, const ReducedDev& rd, double* scal) {
@@ -705,19 +633,38 @@ __device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev
     for (int a = 0; a < 6; ++a) Jk[a][k] = __shfl(J[a], base + k, 64);
   const bool first = dir < 6;
   const int32_t vid = first ? va : vb;
-  if (work && dir < 12 && vid >= 0) {
+  if (b.deterministic && i < sf.n_rl && dir < 12) {
+    // row x of the lane's diagonal block into the factor's scratch slot (lower-packed 21 | g 6; second pose at kSmSecond); zeros when the
+    // factor is inactive or that pose is constant: k_small_gather reads every slot of its lists
     const int x = first ? dir : dir - 6;
-    double* Hd = rd.Hdiag + 36 * (int64_t)vid;
+    double* slot = sf.sm_blk + (int64_t)kSmBlk * (sf.n_sp + sf.n_lt + i) + (first ? 0 : kSmSecond);
+    const double on = (work && vid >= 0) ? w : 0.0;
 #pragma unroll
     for (int y = 0; y < 6; ++y) {
       if (y > x) continue;
       double acc = 0.0;
       for (int a = 0; a < 6; ++a) acc += J[a] * (first ? Jk[a][y] : Jk[a][6 + y]);
-      atomic_add_f64(Hd + 6 * x + y, w * acc);
+      slot[x * (x + 1) / 2 + y] = on * acc;
     }
     double acc = 0.0;
     for (int a = 0; a < 6; ++a) acc += J[a] * r[a];
-    atomic_add_f64(rd.g + 6 * (int64_t)vid + x, w * acc);
+    slot[21 + x] = on * acc;
+  }
+  if (work && dir < 12 && vid >= 0) {
+    const int x = first ? dir : dir - 6;
+    if (!b.deterministic) {
+      double* Hd = rd.Hdiag + 36 * (int64_t)vid;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) {
+        if (y > x) continue;
+        double acc = 0.0;
+        for (int a = 0; a < 6; ++a) acc += J[a] * (first ? Jk[a][y] : Jk[a][6 + y]);
+        atomic_add_f64(Hd + 6 * x + y, w * acc);
+      }
+      double acc = 0.0;
+      for (int a = 0; a < 6; ++a) acc += J[a] * r[a];
+      atomic_add_f64(rd.g + 6 * (int64_t)vid + x, w * acc);
+    }
     if (va >= 0 && vb >= 0 && va != vb) {
       const int64_t ra = b.pose_row[va], rb = b.pose_row[vb];
       const bool b_low = rb > ra;  // lower triangle: the later-eliminated block is the row, and its lanes add the block
@@ -733,7 +680,7 @@ __device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev
     }
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+  if (threadIdx.x == 0) scal_add(scal, b.deterministic, SC_COST, cost);
 }
 
 // the three small-factor families of a small problem in one launch (at this size an iteration's first half is bound by the host's launches)
@@ -809,6 +756,35 @@ __global__ void __launch_bounds__(kBlock) k_bbox_gather(BlocksDev b, SmallFactor
   }
 }
 
+// deterministic mode: the sums behind the priors' and relative-pose factors' scratch slots.  One wavefront per target block (objects,
+// then poses), lane e = entry e of the lower-packed block | gradient; the target's list is walked in order: a fixed summation order,
+// one writer per block (plain read-modify-write behind the kernels that ran before on the stream).
+__global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFactorsDev sf, ReducedDev rd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (t >= b.O + b.P) return;
+  const bool is_obj = t < b.O;
+  const int32_t vid = is_obj ? b.obj_vid[t] : b.pose_vid[t - b.O];
+  const int d = is_obj ? 7 : 6, nh = d * (d + 1) / 2;
+  if (vid < 0 || lane >= nh + d) return;
+  const uint32_t q0 = sf.smt_ptr[t], q1 = sf.smt_ptr[t + 1];
+  if (q1 == q0) return;
+  double acc = 0.0;
+  for (uint32_t q = q0; q < q1; ++q) {
+    const uint32_t e = sf.smt_idx[q];
+    acc += sf.sm_blk[(int64_t)kSmBlk * (e >> 1) + ((e & 1u) ? kSmSecond : 0) + lane];
+  }
+  double* Hd = is_obj ? rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid : rd.Hdiag + 36 * (int64_t)vid;
+  double* gd = is_obj ? rd.g + 6 * b.nPv + 7 * (int64_t)vid : rd.g + 6 * (int64_t)vid;
+  if (lane < nh) {
+    int x = 0, base = 0;
+    while (base + x + 1 <= lane) { base += x + 1; ++x; }
+    Hd[d * x + (lane - base)] += acc;
+  } else {
+    gd[lane - nh] += acc;
+  }
+}
+
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
 __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
                                                         ReducedDev rd, double radius, int first_iter, double* scal) {
@@ -843,8 +819,8 @@ __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const doub
       }
     }
   }
-  block_accumulate(gsq, scal + SC_GSQ);
-  block_accumulate(xsq, scal + SC_XSQ);
+  block_accumulate(gsq, scal, SC_GSQ, b.deterministic);
+  block_accumulate(xsq, scal, SC_XSQ, b.deterministic);
   block_accumulate_max(gmax, scal + SC_GMAX_BITS);
 }
 
@@ -1209,9 +1185,9 @@ __device__ __forceinline__ void point_backsub_block(int64_t block, int64_t strid
       points_cand[3 * l] = points[3 * l]; points_cand[3 * l + 1] = points[3 * l + 1]; points_cand[3 * l + 2] = points[3 * l + 2];
     }
   }
-  block_accumulate(stepsq, scal + SC_STEPSQ);
-  block_accumulate(bad, scal + SC_NONFINITE);
-  block_accumulate(model, scal + SC_MODEL_CHANGE);
+  block_accumulate(stepsq, scal, SC_STEPSQ, b.deterministic);
+  block_accumulate(bad, scal, SC_NONFINITE);
+  block_accumulate(model, scal, SC_MODEL_CHANGE, b.deterministic);
 }
 
 __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const BlocksDev& b, const ReducedDev& rd, const double* __restrict__ poses, const double* __restrict__ objects,
@@ -1243,7 +1219,7 @@ __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const Bl
 #pragma unroll
       for (int k = 0; k < 6; ++k) pose[k] = xc[k];
       PoseCache pc;
-      make_pose_cache(pose, &pc);
+      make_pose_cache(pose, &pc, b.analytic_rotation != 0);
       pc_cand[idx] = pc;
       double* soa = reinterpret_cast<double*>(pc_cand + b.P + 1);
       const double* f = reinterpret_cast<const double*>(&pc);
@@ -1251,9 +1227,9 @@ __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const Bl
       for (int k = 0; k < 21; ++k) soa[k * b.P + idx] = f[k];
     }
   }
-  block_accumulate(stepsq, scal + SC_STEPSQ);
-  block_accumulate(bad, scal + SC_NONFINITE);
-  block_accumulate(model, scal + SC_MODEL_CHANGE);
+  block_accumulate(stepsq, scal, SC_STEPSQ, b.deterministic);
+  block_accumulate(bad, scal, SC_NONFINITE);
+  block_accumulate(model, scal, SC_MODEL_CHANGE, b.deterministic);
 }
 
 // K6 + K9 in one launch (both only read y): workgroups [0, n_point_blocks) back-substitute the features, the rest form the candidate poses / objects
@@ -1291,7 +1267,7 @@ __device__ __forceinline__ void cost_reproj_block(int64_t p, const BlocksDev& b,
     huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
     cost += 0.5 * rho0;
   }
-  block_accumulate(cost, scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED));
+  block_accumulate(cost, scal, mode == 0 ? SC_COST_CAND : SC_COST_FIXED, b.deterministic);
 }
 
 // small factors: one kernel, thread ranges [bbox | shape | ltm | relpose]
@@ -1339,8 +1315,7 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
       cost = 0.5 * rho0;
     }
   }
-  cost = wave_sum(cost);
-  if ((threadIdx.x & 63) == 0 && cost != 0.0) atomic_add_f64(scal + (mode == 0 ? SC_COST_CAND : SC_COST_FIXED), cost);
+  block_accumulate(cost, scal, mode == 0 ? SC_COST_CAND : SC_COST_FIXED, b.deterministic);
 }
 // one launch: workgroups [0, n_pose_blocks) take the reprojection factors of a pose, the rest the small factor families
 __global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, SmallFactorsDev sf, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
@@ -1355,7 +1330,7 @@ __global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, 
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_eval_reproj(ReprojDev rp, const uint32_t* __restrict__ perm, const DevCam* __restrict__ cams,
                                                        const PoseCache* __restrict__ pc, const double* __restrict__ points, int apply_loss,
-                                                       double* residuals, double* sqnorm, double* scal) {
+                                                       double* residuals, double* sqnorm, double* scal, int det) {
   const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   double cost = 0.0;
   if (a < rp.n) {
@@ -1380,7 +1355,7 @@ __global__ void __launch_bounds__(kBlock) k_eval_reproj(ReprojDev rp, const uint
     if (residuals) { residuals[2 * (int64_t)orig] = r[0]; residuals[2 * (int64_t)orig + 1] = r[1]; }
     if (sqnorm) sqnorm[orig] = s;
   }
-  block_accumulate(cost, scal + SC_COST);
+  block_accumulate(cost, scal, SC_COST, det);
 }
 
 template <int M>
@@ -1407,7 +1382,7 @@ __device__ __forceinline__ double finish_eval(double* r, double huber, int apply
 
 __global__ void __launch_bounds__(64) k_eval_small(SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                   const double* __restrict__ objects, int apply_loss, double* res_bb, double* sq_bb,
-                                                  double* res_sp, double* sq_sp, double* res_lt, double* sq_lt, double* res_rl, double* sq_rl, double* scal) {
+                                                  double* res_sp, double* sq_sp, double* res_lt, double* sq_lt, double* res_rl, double* sq_rl, double* scal, int det) {
   int64_t t = blockIdx.x * 64LL + threadIdx.x;
   double cost = 0.0;
   if (t < sf.n_bb) {
@@ -1444,7 +1419,25 @@ __global__ void __launch_bounds__(64) k_eval_small(SmallFactorsDev sf, const Dev
     cost = finish_eval<6>(r, sf.rl_huber, apply_loss, res_rl, sq_rl, i, act);
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0 && cost != 0.0) atomic_add_f64(scal + SC_COST, cost);
+  if (threadIdx.x == 0) scal_add(scal, det, SC_COST, cost);
+}
+
+// deterministic mode: the partial sums the workgroups of the previous kernel left behind the scalar block, added up in a fixed order (one
+// workgroup per scalar: strided per-thread sums, then a fixed tree) and added to the scalar -- plain read-modify-write, stream order
+__global__ void __launch_bounds__(kBlock) k_det_reduce(double* scal, int64_t nblocks, uint32_t scalar_mask) {
+  const int slot = blockIdx.x, sc = det_scalar_of(slot);
+  if (!((scalar_mask >> sc) & 1u)) return;
+  __shared__ double sm[kBlock];
+  const double* part = scal + SC_COUNT + (int64_t)slot * kDetStride;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < nblocks; i += kBlock) acc += part[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scal[sc] += sm[0];
 }
 
 __global__ void __launch_bounds__(kBlock) k_debug_lin_reproj(ReprojDev rp, const uint32_t* __restrict__ perm, const DevCam* __restrict__ cams,
@@ -1529,14 +1522,24 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 }  // namespace
 
 // =========================================================================================
-void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out) {
-  if (P > 0) hipLaunchKernelGGL(k_pose_cache, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, P, poses, out);
+void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask) {
+  if (nblocks > 0) hipLaunchKernelGGL(k_det_reduce, dim3(kDetSlots), dim3(kBlock), 0, s, scal, nblocks, scalar_mask);
+}
+#define OBVI_SC(x) (1u << (x))
+void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out, int analytic) {
+  if (P > 0) hipLaunchKernelGGL(k_pose_cache, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, P, poses, out, analytic);
 }
 void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
                        const uint32_t* long_points, int64_t n_long) {
-  if (n_waves > 0) hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, wave_obs, n_waves);
-  if (n_long > 0) hipLaunchKernelGGL(k_point_pass_long, dim3(grid_for(n_long, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, long_points, n_long);
+  if (n_waves > 0) {
+    hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, wave_obs, n_waves);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_waves, kBlock / 64), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+  }
+  if (n_long > 0) {
+    hipLaunchKernelGGL(k_point_pass_long, dim3(grid_for(n_long, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, long_points, n_long);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_long, kBlock), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+  }
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
                       const ReducedDev& rd) {
@@ -1548,6 +1551,14 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
   const int64_t lanes_below = std::getenv("OBVI_SMALL_LANES_BELOW") ? std::atoll(std::getenv("OBVI_SMALL_LANES_BELOW")) : 4096;   // tuning knob
   const int nb_bbox = (int)grid_for(sf.n_bb, 4), nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
   if (nb_bbox + nb_priors + nb_rel == 0) return;
+  if (b.deterministic) {
+    // no fp64 atomics on the diagonal blocks: every factor leaves its blocks in a scratch slot, the gathers add them per target in list order
+    hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+    launch_det_reduce(s, scal, nb_bbox + nb_priors + nb_rel, OBVI_SC(SC_COST));
+    if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
+    if (sf.n_sp + sf.n_lt + sf.n_rl > 0) hipLaunchKernelGGL(k_small_gather, dim3(grid_for(b.O + b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
+    return;
+  }
   if (sf.n_bb < lanes_below) {
     hipLaunchKernelGGL(k_small_lin_lanes<false>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
     return;
@@ -1560,7 +1571,10 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {
-  if (b.P + b.O > 0) hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(8 * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
+  if (b.P + b.O > 0) {
+    hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(8 * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(8 * (b.P + b.O), kBlock), OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+  }
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
                          const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* obs_point, const PointDev& pt, const ReducedDev& rd) {
@@ -1590,6 +1604,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
 #define OBVI_BACKSUB(GG) hipLaunchKernelGGL(k_backsub_apply<GG>, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal)
   switch (G) { case 32: OBVI_BACKSUB(32); break; case 16: OBVI_BACKSUB(16); break; case 8: OBVI_BACKSUB(8); break; case 4: OBVI_BACKSUB(4); break; case 2: OBVI_BACKSUB(2); break; default: OBVI_BACKSUB(1); }
 #undef OBVI_BACKSUB
+  if (b.deterministic) launch_det_reduce(s, scal, grid, OBVI_SC(SC_STEPSQ) | OBVI_SC(SC_MODEL_CHANGE));
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
@@ -1602,12 +1617,18 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   const int n_pose_blocks = rq.n > 0 && b.P > 0 ? (int)b.P : 0;
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   const unsigned grid = (unsigned)n_pose_blocks + grid_for(ns, kBlock);
-  if (grid > 0) hipLaunchKernelGGL(k_cost, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
+  if (grid > 0) {
+    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
+    if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED));
+  }
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
                      const PoseCache* pc, const double* poses, const double* points, const double* objects, int apply_loss, double* residuals,
                      double* sqnorm, double* scal) {
-  if (rp.n > 0) hipLaunchKernelGGL(k_eval_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, rp, rp_perm, cams, pc, points, apply_loss, residuals, sqnorm, scal);
+  if (rp.n > 0) {
+    hipLaunchKernelGGL(k_eval_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, rp, rp_perm, cams, pc, points, apply_loss, residuals, sqnorm, scal, b.deterministic);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(rp.n, kBlock), OBVI_SC(SC_COST));
+  }
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   if (ns > 0) {
     double* r_bb = residuals ? residuals + 2 * rp.n : nullptr;
@@ -1618,9 +1639,9 @@ void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, con
     double* q_sp = sqnorm ? q_bb + sf.n_bb : nullptr;
     double* q_lt = sqnorm ? q_sp + sf.n_sp : nullptr;
     double* q_rl = sqnorm ? q_lt + sf.n_lt : nullptr;
-    hipLaunchKernelGGL(k_eval_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, sf, cams, poses, objects, apply_loss, r_bb, q_bb, r_sp, q_sp, r_lt, q_lt, r_rl, q_rl, scal);
+    hipLaunchKernelGGL(k_eval_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, sf, cams, poses, objects, apply_loss, r_bb, q_bb, r_sp, q_sp, r_lt, q_lt, r_rl, q_rl, scal, b.deterministic);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(ns, 64), OBVI_SC(SC_COST));
   }
-  (void)b;
 }
 void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uint32_t* rp_perm, const DevCam* cams, const PoseCache* pc,
                                    const double* points, double* r, double* J0, double* J1) {

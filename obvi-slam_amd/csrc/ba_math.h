@@ -32,7 +32,11 @@ struct DevCam {        // inverse extrinsics + intrinsics, one per camera
   double Rinv[9];      // R_e^T           (reprojection_cost_functor.cpp:10-13)
   double tinv[3];      // -R_e^T t_e
   double fx, fy, cx, cy;
+  double depth_min;    // -inf: no depth clamp (the production functor a3); 1e-15: z <- max(z, depth_min) with the gated derivative of the
+                       // analytic-Jacobian functor a2 (reprojection_cost_functor_analytic_jacobian.h:160, 289-292, 591)
 };
+// reprojection_cost_functor_analytic_jacobian.h:591
+#define OBVI_ANALYTIC_EPSILON 1e-15
 
 struct PoseCache {     // per robot pose, recomputed whenever poses change
   double Rinv[9];      // R(aa)^T
@@ -46,12 +50,27 @@ struct PoseCache {     // per robot pose, recomputed whenever poses change
 // aa/angle), else AngleAxis(0, e_x) -- a constant, so autodiff sees a zero derivative w.r.t.
 // aa there; Jr = 0 reproduces that.
 // d(R^T v)/d(aa) = [R^T v]x Jr(aa),  Jr = I - (1-cos t)/t^2 [aa]x + (t - sin t)/t^3 [aa]x^2.
+//
+// analytic = true (the analytic-Jacobian functor a2, reprojection_cost_functor_analytic_jacobian.h:63-70): the rotation is a smooth
+// function of aa through aa = 0 -- symforce builds it from the quaternion (aa sin(th/2)/th, cos(th/2)) with th = sqrt(|aa|^2 + 1e-15),
+// i.e. R = I + (sin th/th) [aa]x + ((1-cos th)/th^2) [aa]x^2, which differs from the exponential map by less than 1e-15 absolute in R
+// and in dR/daa at every aa -- so below the threshold the series of the exponential map and of its right Jacobian take the place
+// of the production functor's constant branch.
 // ---------------------------------------------------------------------------------------
-OBVI_HD void make_pose_cache(const double* pose, PoseCache* pc) {
+OBVI_HD void make_pose_cache(const double* pose, PoseCache* pc, bool analytic = false) {
   const double ax = pose[3], ay = pose[4], az = pose[5];
   const double t2 = ax * ax + ay * ay + az * az;
   const double t = sqrt(t2);
-  if (t > OBVI_SMALL_ANGLE) {
+  if (analytic && !(t > OBVI_SMALL_ANGLE)) {
+    // R^T = I - [aa]x + (1/2) [aa]x^2 ;  Jr = I - (1/2) [aa]x + (1/6) [aa]x^2   (next terms are O(t^3) < 1e-24)
+    pc->Rinv[0] = 1.0 + 0.5 * (ax * ax - t2); pc->Rinv[1] = az + 0.5 * ax * ay;         pc->Rinv[2] = -ay + 0.5 * ax * az;
+    pc->Rinv[3] = -az + 0.5 * ax * ay;        pc->Rinv[4] = 1.0 + 0.5 * (ay * ay - t2); pc->Rinv[5] = ax + 0.5 * ay * az;
+    pc->Rinv[6] = ay + 0.5 * ax * az;         pc->Rinv[7] = -ax + 0.5 * ay * az;        pc->Rinv[8] = 1.0 + 0.5 * (az * az - t2);
+    const double a = 0.5, b = 1.0 / 6.0;
+    pc->Jr[0] = 1.0 + b * (ax * ax - t2); pc->Jr[1] = a * az + b * ax * ay;     pc->Jr[2] = -a * ay + b * ax * az;
+    pc->Jr[3] = -a * az + b * ax * ay;    pc->Jr[4] = 1.0 + b * (ay * ay - t2); pc->Jr[5] = a * ax + b * ay * az;
+    pc->Jr[6] = a * ay + b * ax * az;     pc->Jr[7] = -a * ax + b * ay * az;    pc->Jr[8] = 1.0 + b * (az * az - t2);
+  } else if (t > OBVI_SMALL_ANGLE) {
     const double s = sin(t), c = cos(t);
     const double ux = ax / t, uy = ay / t, uz = az / t;
     const double oc = 1.0 - c;
@@ -95,16 +114,22 @@ OBVI_HD void reproj_eval(const PoseCache& pc, const DevCam& cam, const double* X
   const double prz = pc.Rinv[6] * X[0] + pc.Rinv[7] * X[1] + pc.Rinv[8] * X[2] + pc.tinv[2];
   const double x = cam.Rinv[0] * prx + cam.Rinv[1] * pry + cam.Rinv[2] * prz + cam.tinv[0];
   const double y = cam.Rinv[3] * prx + cam.Rinv[4] * pry + cam.Rinv[5] * prz + cam.tinv[1];
-  const double z = cam.Rinv[6] * prx + cam.Rinv[7] * pry + cam.Rinv[8] * prz + cam.tinv[2];
+  const double zraw = cam.Rinv[6] * prx + cam.Rinv[7] * pry + cam.Rinv[8] * prz + cam.tinv[2];
+  // depth clamp of the analytic-Jacobian functor (depth_min = 1e-15; reprojection_cost_functor_analytic_jacobian.h:160); depth_min = -inf
+  // leaves z alone (the production functor has no clamp, vslam_math_util.h:376-394)
+  const double z = zraw < cam.depth_min ? cam.depth_min : zraw;
   const double mx = cam.fx / sigma, my = cam.fy / sigma;
   const double u = x / z, v = y / z;
   r[0] = mx * (u - (px - cam.cx) / cam.fx);
   r[1] = my * (v - (py - cam.cy) / cam.fy);
   if (JAC) {
     const double iz = 1.0 / z;
+    // derivative of the clamp (:289-292): ((z - eps > 0) - (z - eps < 0) + 1) / 2 = 1 above eps, 1/2 at it, 0 below; 1 without a clamp
+    const double dz = zraw - cam.depth_min;
+    const double gate = 0.5 * ((double)((dz > 0.0) - (dz < 0.0)) + 1.0);
     // rows of d r / d p_cam
-    const double p00 = mx * iz, p02 = -mx * u * iz;
-    const double p11 = my * iz, p12 = -my * v * iz;
+    const double p00 = mx * iz, p02 = -mx * u * iz * gate;
+    const double p11 = my * iz, p12 = -my * v * iz * gate;
     // A = Pj * R_e^T  (2x3)
     const double a00 = p00 * cam.Rinv[0] + p02 * cam.Rinv[6], a01 = p00 * cam.Rinv[1] + p02 * cam.Rinv[7], a02 = p00 * cam.Rinv[2] + p02 * cam.Rinv[8];
     const double a10 = p11 * cam.Rinv[3] + p12 * cam.Rinv[6], a11 = p11 * cam.Rinv[4] + p12 * cam.Rinv[7], a12 = p11 * cam.Rinv[5] + p12 * cam.Rinv[8];

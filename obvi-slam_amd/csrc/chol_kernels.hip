@@ -634,6 +634,48 @@ __global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restr
   if (tid < T) unsafeAtomicAdd(t + (int64_t)j * T + tid, -a);
 }
 
+// Deterministic mode (obvi_ba_options.deterministic): column-oriented backward substitution, one workgroup per tile column k of a level,
+// levels descending:  y_k = L_kk^-T (z_k - sum_{i in col(k)} L_ik^T y_i)  with the column's tiles walked in list order -- every y_i
+// belongs to a higher level and is final.  One writer per block of y, no atomics (k_backward above lets the rows of a launch subtract
+// from t_j atomically, in whatever order they finish); a launch per level instead of one per four.
+__global__ void __launch_bounds__(kThreads) k_backward_det(const double* __restrict__ S, int nt, const int32_t* __restrict__ klist, const int32_t* __restrict__ col_ptr,
+                                                         const int32_t* __restrict__ col_i, const double* __restrict__ Linv_all, const double* __restrict__ z, double* y) {
+  constexpr int Q = kThreads / T, R = T / Q;   // row slices, rows per slice
+  __shared__ double part[Q][T];
+  __shared__ double v[T];
+  const int k = klist[blockIdx.x];
+  const int tid = threadIdx.x, c = tid % T, q = tid / T;
+  double s = 0.0;
+  for (int e = col_ptr[k]; e < col_ptr[k + 1]; ++e) {
+    const int i = col_i[e];
+    const double* X = tile_ptr(const_cast<double*>(S), nt, i, k) + (q * R) * T + c;
+    const double* yi = y + (int64_t)i * T + q * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += X[r * T] * yi[r];
+  }
+  part[q][c] = s;
+  __syncthreads();
+  if (tid < T) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) a += part[i][tid];
+    v[tid] = z[(int64_t)k * T + tid] - a;
+  }
+  __syncthreads();
+  const double* Li = Linv_all + (int64_t)k * (T * T) + (q * R) * T + c;
+  s = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s += Li[r * T] * v[q * R + r];   // L^-1 carries an explicit zero upper part
+  part[q][c] = s;
+  __syncthreads();
+  if (tid < T) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) a += part[i][tid];
+    y[(int64_t)k * T + tid] = a;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Covariance blocks (obvi_ba_object_covariances): forward substitution with many right-hand sides on the factor
 // that is already in the tiles, Y = L^-1 E (E: the unit vectors of the object rows), then blocks of S^-1 = Y^T Y.
@@ -822,6 +864,14 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
 void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* rhs, double* y, CholTimers* timers) {
   const int nt = p.nt;
   tick(s, timers, -1);
+  if (p.deterministic) {
+    for (int l = p.nlevels - 1; l >= 0; --l) {
+      const int nk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
+      if (nk > 0) hipLaunchKernelGGL(k_backward_det, dim3(nk), dim3(kThreads), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l], p.col_ptr, p.col_i, Linv, rhs, y);
+      tick(s, timers, CK_BACKWARD);
+    }
+    return;
+  }
   for (int l = p.nbw - 1; l >= 0; --l) {
     const int nwg = p.bw_ptr[l + 1] - p.bw_ptr[l];
     if (nwg > 0) hipLaunchKernelGGL(k_backward, dim3(nwg), dim3(kBackThreads), 0, s, S, nt, p.bw_kj + 3 * (int64_t)p.bw_ptr[l], p.bw_chains, Linv, rhs, y);

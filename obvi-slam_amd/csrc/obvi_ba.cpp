@@ -43,6 +43,8 @@ const char* kPhaseNames[PH_COUNT] = {"pose_cache", "point_pass", "pose_pass", "s
 
 struct obvi_ba_handle {
   int device = 0;
+  int reproj_variant = OBVI_REPROJECTION_AUTODIFF;   // obvi_ba_options.reprojection_variant
+  bool deterministic = false;                        // obvi_ba_options.deterministic
   hipStream_t stream = nullptr;
   obvi::StagingArena staging;   // pinned; the uploads of an API call are copied through it (host_util.h)
   std::string err;
@@ -101,6 +103,7 @@ struct obvi_ba_handle {
   DevBuf<double> d_bb_rect, d_bb_sqrt_inf, d_sp_mean, d_sp_sqrt_inf, d_lt_mean, d_lt_sqrt_inf, d_rl_t, d_rl_R, d_rl_sqrt_inf;
   DevBuf<uint8_t> d_bb_active, d_sp_active, d_lt_active, d_rl_active;
   DevBuf<double> d_bb_blk;                                    // per-factor blocks of the bounding-box factors (k_bbox_gather)
+  DevBuf<double> d_sm_blk; DevBuf<uint32_t> d_smt_ptr, d_smt_idx;   // deterministic mode: the same for the priors and relative-pose factors (k_small_gather)
   int32_t bb_pairs_unique = 1;
   DevBuf<uint32_t> d_bbo_ptr, d_bbo_idx, d_bbp_ptr, d_bbp_idx;   // ... and the factor lists by object / by pose (prepare())
   // ---- device: reduced system ----
@@ -218,6 +221,7 @@ void make_cam(const double* K4, const double* e, DevCam* c) {
     c->tinv[i] = -(R[0][i] * e[4] + R[1][i] * e[5] + R[2][i] * e[6]);
   }
   c->fx = K4[0]; c->fy = K4[1]; c->cx = K4[2]; c->cy = K4[3];
+  c->depth_min = -std::numeric_limits<double>::infinity();   // the production functor: no clamp (set_cameras sets it for the analytic variant)
 }
 
 void sync(obvi_ba_handle* h) { OBVI_HIP(hipStreamSynchronize(h->stream)); h->staging.rewind(); }
@@ -245,6 +249,8 @@ BlocksDev blocks_dev(const obvi_ba_handle* h) {
   b.P = h->P; b.L = h->L; b.O = h->O; b.nPv = h->nPv; b.nOv = h->nOv; b.m = h->m; b.pose_row = h->d_pose_row.get(); b.obj_row = h->d_obj_row.get();
   b.obj_shared = (h->allreduce && !h->h_shared_ov.empty()) ? h->d_obj_shared.get() : nullptr; b.shared_owner = h->rank == 0 ? 1 : 0;
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
+  b.analytic_rotation = h->reproj_variant == OBVI_REPROJECTION_ANALYTIC ? 1 : 0;
+  b.deterministic = h->deterministic ? 1 : 0;
   return b;
 }
 ReprojDev reproj_dev(const obvi_ba_handle* h) {
@@ -265,6 +271,7 @@ SmallFactorsDev small_dev(const obvi_ba_handle* h) {
   s.n_bb = h->n_bb; s.bb_obj = h->d_bb_obj.get(); s.bb_pose = h->d_bb_pose.get(); s.bb_cam = h->d_bb_cam.get();
   s.bb_rect = h->d_bb_rect.get(); s.bb_sqrt_inf = h->d_bb_sqrt_inf.get(); s.bb_active = h->d_bb_active.get();
   s.bb_huber = h->bb_huber; s.bb_invalid = h->bb_invalid;
+  s.sm_blk = h->d_sm_blk.get(); s.smt_ptr = h->d_smt_ptr.get(); s.smt_idx = h->d_smt_idx.get();
   s.bb_pairs_unique = h->bb_pairs_unique; s.bb_blk = h->d_bb_blk.get(); s.bbo_ptr = h->d_bbo_ptr.get(); s.bbo_idx = h->d_bbo_idx.get(); s.bbp_ptr = h->d_bbp_ptr.get(); s.bbp_idx = h->d_bbp_idx.get();
   s.n_sp = h->n_sp; s.sp_obj = h->d_sp_obj.get(); s.sp_mean = h->d_sp_mean.get(); s.sp_sqrt_inf = h->d_sp_sqrt_inf.get();
   s.sp_active = h->d_sp_active.get(); s.sp_huber = h->sp_huber;
@@ -289,7 +296,7 @@ PointDev point_dev(const obvi_ba_handle* h) {
 }
 CholPlan chol_plan(const obvi_ba_handle* h) {
   CholPlan c;
-  c.nt = h->nt; c.nlevels = h->nlevels;
+  c.nt = h->nt; c.nlevels = h->nlevels; c.deterministic = h->deterministic ? 1 : 0;
   c.lvl_k_ptr = h->h_lvl_k_ptr.data(); c.lvl_k = h->d_lvl_k.get();
   c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
@@ -710,7 +717,8 @@ void prepare(obvi_ba_handle* h) {
       }
   }
   // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
-  const int64_t slice = std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
+  // (deterministic mode: a work list is never cut -- one workgroup, hence one writer, per strip)
+  const int64_t slice = h->deterministic ? std::numeric_limits<int64_t>::max() : std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
   // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
   // slots: one per strip frame over the range of its row frames and of its column frames in the group (source: the Z
   // record, or the zero page for a frame the point skips), the point's (u_l, 0) tail, and -- stereo -- a second layer
@@ -811,7 +819,7 @@ void prepare(obvi_ba_handle* h) {
   for (size_t k = 0; k < pairs.size(); ++k) {
     // a block's pairs are cut into work items of at most kPairsPerItem (k_schur_blocks adds its sums atomically): a few long tracks in a
     // small window would otherwise leave one workgroup with thousands of pairs on the critical path
-    constexpr size_t kPairsPerItem = 256;
+    const size_t kPairsPerItem = h->deterministic ? std::numeric_limits<size_t>::max() : 256;   // deterministic mode: one work item, hence one writer, per block
     if (k == 0 || pairs[k].key != pairs[k - 1].key || k - blk_ptr.back() >= kPairsPerItem) {
       blk_row.push_back((uint32_t)h->h_pose_row[pairs[k].key / (uint64_t)(h->nPv + 1)]);
       blk_col.push_back((uint32_t)h->h_pose_row[pairs[k].key % (uint64_t)(h->nPv + 1)]);
@@ -873,7 +881,7 @@ void prepare(obvi_ba_handle* h) {
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
   std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, job_signal, k_need_of(nt, 0);
   std::vector<uint8_t> upd_flag;
-  const int kUpdChunk = std::max(1, env_int("OBVI_UPD_CHUNK", 4));   // products per update job (tuning knob)
+  const int kUpdChunk = h->deterministic ? std::numeric_limits<int>::max() : std::max(1, env_int("OBVI_UPD_CHUNK", 4));   // products per update job (tuning knob; deterministic mode: a target's products are never split over jobs that would meet in atomics)
   const int64_t env_slice_max = std::getenv("OBVI_SLICE_MAX") ? std::atoi(std::getenv("OBVI_SLICE_MAX")) : 512;   // tuning knob
   // a potrf workgroup applies up to this many products of the previous level to its own diagonal tile (tuning knob)
   const size_t pre_max = (size_t)std::max(0, env_int("OBVI_PRE_MAX", 2));
@@ -917,7 +925,7 @@ void prepare(obvi_ba_handle* h) {
         q = e;
         continue;
       }
-      const size_t chunk = crit ? 1 : (size_t)kUpdChunk;   // the next level waits for these: one product per job
+      const size_t chunk = h->deterministic ? len : crit ? 1 : (size_t)kUpdChunk;   // the next level waits for the critical ones: one product per job
       const uint8_t flag = len > chunk ? 1 : 0;
       for (size_t c0 = q; c0 < e; c0 += chunk) jobs.push_back({trips[q].i, trips[q].j, flag, c0, std::min(e, c0 + chunk), crit});
       q = e;
@@ -1041,7 +1049,7 @@ void prepare(obvi_ba_handle* h) {
     for (int l = 0; l < nlev; ++l) {
       int longest = 0;
       for (int32_t k : by_level[l]) longest = std::max(longest, row_ptr[k + 1] - row_ptr[k]);
-      h->h_row_split[l] = std::min(16, std::max(1, longest / row_tiles));
+      h->h_row_split[l] = h->deterministic ? 1 : std::min(16, std::max(1, longest / row_tiles));   // (split rows meet in atomics)
     }
   }
   h->chol_flops = flops;
@@ -1083,6 +1091,25 @@ void prepare(obvi_ba_handle* h) {
     for (int64_t i = 0; i < h->n_bb; ++i) { oidx[oc[h->h_bb_obj[i]]++] = (uint32_t)i; pidx[pc[h->h_bb_pose[i]]++] = (uint32_t)i; }
     h->d_bbo_ptr.upload(optr, s); h->d_bbo_idx.upload(oidx, s); h->d_bbp_ptr.upload(pptr, s); h->d_bbp_idx.upload(pidx, s);
     h->d_bb_blk.resize((size_t)62 * (size_t)h->n_bb + 1);
+    if (h->deterministic) {
+      // priors and relative-pose factors by target block (objects, then poses), in factor order: entry = 2 slot + side
+      const int64_t nsl = h->n_sp + h->n_lt + h->n_rl;
+      std::vector<uint32_t> tptr((size_t)O + (size_t)P + 1, 0), tidx;
+      for (int64_t i = 0; i < h->n_sp; ++i) tptr[h->h_sp_obj[i] + 1]++;
+      for (int64_t i = 0; i < h->n_lt; ++i) tptr[h->h_lt_obj[i] + 1]++;
+      for (int64_t i = 0; i < h->n_rl; ++i) { tptr[O + h->h_rl_a[i] + 1]++; tptr[O + h->h_rl_b[i] + 1]++; }
+      for (size_t t = 0; t + 1 < tptr.size(); ++t) tptr[t + 1] += tptr[t];
+      tidx.resize(tptr.back() + 1);
+      std::vector<uint32_t> cur(tptr.begin(), tptr.end() - 1);
+      for (int64_t i = 0; i < h->n_sp; ++i) tidx[cur[h->h_sp_obj[i]]++] = (uint32_t)(2 * i);
+      for (int64_t i = 0; i < h->n_lt; ++i) tidx[cur[h->h_lt_obj[i]]++] = (uint32_t)(2 * (h->n_sp + i));
+      for (int64_t i = 0; i < h->n_rl; ++i) {
+        tidx[cur[O + h->h_rl_a[i]]++] = (uint32_t)(2 * (h->n_sp + h->n_lt + i));
+        tidx[cur[O + h->h_rl_b[i]]++] = (uint32_t)(2 * (h->n_sp + h->n_lt + i) + 1);
+      }
+      h->d_smt_ptr.upload(tptr, s); h->d_smt_idx.upload(tidx, s);
+      h->d_sm_blk.resize((size_t)62 * (size_t)nsl + 1);
+    }
     // does any (object, pose) pair occur twice?  (inside a pose's list: the same object twice)
     h->bb_pairs_unique = 1;
     std::vector<uint32_t> objs;
@@ -1239,7 +1266,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   double* scal = h->d_scal.get();
   const double fixed = h->h_scal[SC_COST_FIXED];
   record(h, PH_POSE_CACHE);
-  if (!h->pc_valid) launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  if (!h->pc_valid) launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   h->pc_valid = true;
   if (!h->tiles_cleared) launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed));
   h->tiles_cleared = false;
@@ -1248,7 +1275,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // Schur complement (everything they share is accumulated with atomics), so they run beside them on the side stream.
   // Not with a multi-GPU exchange in the chain (its collective is ordered on the main stream) nor in an instrumented solve.
   static const bool side_ok = !std::getenv("OBVI_SIDE") || std::atoi(std::getenv("OBVI_SIDE")) != 0;   // tuning knob
-  const bool side = !exchange && h->profiling < 2 && side_ok;
+  const bool side = !exchange && h->profiling < 2 && side_ok && !h->deterministic;   // deterministic mode: one stream, so that the kernels that add to the same tiles do so in a fixed order
   hipStream_t s2 = side ? h->stream2 : s;
   // the point pass first, alone: it and the pose-side pass stream the same observation arrays and are both HBM-bound (side by side the
   // point pass took 0.35 ms instead of 0.24); the side stream starts behind it and runs beside the Schur complement, which is bound
@@ -1404,6 +1431,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (options && options->object_block_size != 0 && options->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  if (options && options->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && options->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return OBVI_ERR_NO_DEVICE;
   const int dev = options ? options->device_id : 0;
@@ -1411,6 +1439,8 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   obvi_ba_handle* h = new (std::nothrow) obvi_ba_handle();
   if (!h) return OBVI_ERR_HIP;
   h->device = dev;
+  if (options) { h->reproj_variant = options->reprojection_variant; h->deterministic = options->deterministic != 0; }
+  if (const char* env = std::getenv("OBVI_DETERMINISTIC")) { if (std::atoi(env) != 0) h->deterministic = true; }   // every handle of the process (a session driven through a host that does not set the option)
   try {
     OBVI_HIP(hipSetDevice(dev));
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1418,7 +1448,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
     h->staging.cap = kStagingBytes;
-    h->d_scal.resize(SC_COUNT);
+    h->d_scal.resize(SC_COUNT + (h->deterministic ? (size_t)kDetSlots * (size_t)kDetStride : 0));   // deterministic mode: per-workgroup partial sums behind the block (ba_device.h)
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
@@ -1454,7 +1484,10 @@ int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const dou
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   h->h_cams.resize(n);
-  for (int i = 0; i < n; ++i) make_cam(K + 4 * i, ext + 7 * i, &h->h_cams[i]);
+  for (int i = 0; i < n; ++i) {
+    make_cam(K + 4 * i, ext + 7 * i, &h->h_cams[i]);
+    if (h->reproj_variant == OBVI_REPROJECTION_ANALYTIC) h->h_cams[i].depth_min = OBVI_ANALYTIC_EPSILON;
+  }
   h->d_cams.upload(h->h_cams, h->stream);
   finish_upload(h);
   bake_bbox(h);   // the bounding-box factors already uploaded follow the new intrinsics
@@ -1728,7 +1761,7 @@ int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double
   const int64_t nres = obvi_ba_num_residuals(h), nfac = h->n_rp + h->n_bb + h->n_sp + h->n_lt + h->n_rl;
   h->d_eval_res.resize((size_t)nres + 1); h->d_eval_sq.resize((size_t)nfac + 1);
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
-  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   launch_evaluate(s, blocks_dev(h), reproj_dev(h), h->d_rp_perm.get(), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(),
                   h->d_point.get(), h->d_obj.get(), apply_loss, h->d_eval_res.get(), h->d_eval_sq.get(), h->d_scal.get());
   double c = 0.0;
@@ -1760,7 +1793,7 @@ int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t type, double* r, double* 
   DevBuf<double> dr, dJ0, dJ1;
   dr.resize((size_t)n * m + 1); dJ0.resize((size_t)n * m * d0 + 1); dJ1.resize((size_t)n * m * d1 + 1);
   if (type == OBVI_FACTOR_REPROJECTION) {
-    launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+    launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
     launch_debug_linearize_reproj(s, reproj_dev(h), h->d_rp_perm.get(), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), dr.get(), dJ0.get(), dJ1.get());
   } else {
     launch_debug_linearize_small(s, type, small_dev(h), h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), dr.get(), dJ0.get(), dJ1.get());
@@ -1784,7 +1817,7 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h); const ReprojDev rp = reproj_dev(h); const SmallFactorsDev sf = small_dev(h);
   const ReducedDev rd = reduced_dev(h); const PointDev pt = point_dev(h);
-  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, 0.0));
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, 1, h->d_scal.get(), h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   launch_pose_pass(s, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
@@ -1940,7 +1973,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   copy_current(h, h->d_pose_e, h->d_point_e, h->d_obj_e);
   // fixed cost: residual blocks with only constant parameter blocks
   OBVI_HIP(hipMemsetAsync(h->d_scal.get(), 0, sizeof(double) * SC_COUNT, s));
-  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get());
+  launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   launch_cost(s, blocks_dev(h), reproj_pose_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
               h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), 1, h->d_scal.get());
   if (h->allreduce != nullptr && !h->h_shared_ov.empty() &&

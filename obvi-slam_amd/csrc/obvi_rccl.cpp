@@ -12,6 +12,9 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <sys/stat.h>
+#include <ctime>
+#include <algorithm>
 #include <thread>
 
 static_assert(sizeof(ncclUniqueId) == OBVI_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
@@ -73,7 +76,12 @@ int obvi_rccl_comm_create(const char id_bytes[OBVI_RCCL_ID_BYTES], int32_t rank,
 int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, double timeout_s, obvi_rccl_comm** out) {
   if (!path || !out) return OBVI_ERR_INVALID_ARGUMENT;
   char id[OBVI_RCCL_ID_BYTES];
+  // The file lives only between rank 0's write and the end of the collective initialisation: rank 0 removes whatever an earlier
+  // (crashed) run left at `path` before it writes, and removes its own file once ncclCommInitRank has returned -- by then every rank
+  // has read it.  A rank that still meets a leftover (it started before rank 0 got to the unlink) rejects it by age: a file older than
+  // the rendezvous time-out cannot belong to this launch.
   if (rank == 0) {
+    std::remove(path);
     const int rc = obvi_rccl_unique_id(id);
     if (rc != OBVI_OK) return rc;
     const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
@@ -85,7 +93,9 @@ int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t worl
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-      FILE* f = std::fopen(path, "rb");
+      struct stat st;
+      const bool fresh = ::stat(path, &st) == 0 && std::difftime(std::time(nullptr), st.st_mtime) <= std::max(1.0, timeout_s);
+      FILE* f = fresh ? std::fopen(path, "rb") : nullptr;
       if (f) {
         const size_t n = std::fread(id, 1, sizeof(id), f);
         std::fclose(f);
@@ -95,7 +105,9 @@ int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t worl
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
   }
-  return obvi_rccl_comm_create(id, rank, world, device, out);
+  const int rc = obvi_rccl_comm_create(id, rank, world, device, out);
+  if (rank == 0) std::remove(path);   // initialised (or failed) everywhere: nobody needs the id any more, and the next run must not find it
+  return rc;
 }
 
 void obvi_rccl_comm_destroy(obvi_rccl_comm* c) {

@@ -75,6 +75,18 @@ struct FlatProblem {
   }
 };
 
+// Process-wide choices for every device handle the mirror creates (obvi_ba_options): which of the reference's two reprojection
+// functors runs (0: ReprojectionCostFunctor, what residual_creator.h:251-264 instantiates; 1: ReprojectionCostFunctorAnalyticJacobian)
+// and whether the device sums run in a fixed order (bit-identical reruns, as Ceres at a fixed num_threads).
+struct BackendOptions { int reprojection_variant = OBVI_REPROJECTION_AUTODIFF; bool deterministic = false; };
+inline BackendOptions& backendOptions() { static BackendOptions o; return o; }
+inline obvi_ba_options makeHandleOptions(int device_id) {
+  obvi_ba_options opt{};
+  opt.device_id = device_id; opt.object_block_size = 7;
+  opt.reprojection_variant = backendOptions().reprojection_variant; opt.deterministic = backendOptions().deterministic ? 1 : 0;
+  return opt;
+}
+
 class Problem {
  public:
   explicit Problem(int device_id = 0, bool dry_run = false) : device_id_(device_id), dry_run_(dry_run) {}
@@ -90,7 +102,7 @@ class Problem {
   bool dryRun() const { return dry_run_; }
   obvi_ba_handle* handle() {
     if (!h_ && !dry_run_) {
-      obvi_ba_options opt{}; opt.device_id = device_id_; opt.object_block_size = 7;
+      const obvi_ba_options opt = makeHandleOptions(device_id_);
       const int rc = obvi_ba_create(&opt, &h_);
       if (rc != OBVI_OK) { std::cerr << "obvi_ba_create failed: status " << rc << " (no HIP device? there is no CPU path)" << std::endl; h_ = nullptr; }
     }

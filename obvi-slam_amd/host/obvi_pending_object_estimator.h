@@ -82,7 +82,7 @@ inline bool refineInitialEstimateForPendingObjects(const std::unordered_map<Obje
   if (updated_estimates) *updated_estimates = rough_initial_estimates;
   if (objects.empty() || cam_K.empty()) return true;                       // nothing to refine
 
-  obvi_ba_options opt{}; opt.device_id = device_id; opt.object_block_size = 7;
+  const obvi_ba_options opt = obvi::makeHandleOptions(device_id);
   obvi_ba_handle* h = nullptr;
   if (obvi_ba_create(&opt, &h) != OBVI_OK || h == nullptr) { std::cerr << "obvi_ba_create failed (no HIP device? there is no CPU path)" << std::endl; return false; }
   const std::vector<uint8_t> pose_const(poses.size() / 6, 1), obj_const(objects.size() / 7, 0);       // problem.SetParameterBlockConstant(robot_pose_block), :99-103

@@ -6,6 +6,7 @@
 //   run_offline_ba --from-checkpoint <pose_graph_state.json> <out.json> [--ltm] [--device D]   the shape of run_opt_from_pg_state: final global BA (+ long-term map) from a checkpoint
 //   run_offline_ba --checkpoint-roundtrip <in.json> <out.json>                                  (no GPU) read a pose-graph state and write it back
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
+//   any mode: [--deterministic] fixed-order device sums (bit-identical reruns)   [--analytic-reprojection] the reference's analytic-Jacobian reprojection functor
 // Parameter values: config/base7a_2_fallback.json of the reference.
 #include <chrono>
 #include <cstdlib>
@@ -128,6 +129,8 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--iteration-log-dir") && i + 1 < argc) iteration_log_dir = argv[++i];
     else if (!std::strcmp(argv[i], "--merge-distance") && i + 1 < argc) config.post_session_object_merge_params_.max_merge_distance_ = std::atof(argv[++i]);
     else if (!std::strcmp(argv[i], "--pending-objects")) pending = true;
+    else if (!std::strcmp(argv[i], "--analytic-reprojection")) obvi::backendOptions().reprojection_variant = OBVI_REPROJECTION_ANALYTIC;   // ReprojectionCostFunctorAnalyticJacobian instead of ReprojectionCostFunctor
+    else if (!std::strcmp(argv[i], "--deterministic")) obvi::backendOptions().deterministic = true;   // fixed-order device sums: reruns are bit-identical
     else if (!std::strcmp(argv[i], "--visual-front-end")) visual_front_end = true;
     else if (!std::strcmp(argv[i], "--front-end-only")) { visual_front_end = true; front_end_only = true; }
     else if (!std::strcmp(argv[i], "--no-epipolar")) front_end_params.enforce_epipolar_error_requirement_ = false;
@@ -266,7 +269,7 @@ int main(int argc, char** argv) {
   std::unique_ptr<VisualFeatureFrontend> front_end;
   VisualFeatureAdder visual_adder;
   if (visual_front_end) {
-    obvi_ba_options opt{}; opt.device_id = device;
+    const obvi_ba_options opt = obvi::makeHandleOptions(device);
     if (obvi_ba_create(&opt, &front_end_handle) != 0) { std::cerr << "no device handle for the visual front end" << std::endl; return 1; }
     const SlidingWindowParams sw2 = config.sliding_window_params_;
     front_end = std::make_unique<VisualFeatureFrontend>(front_end_handle, [sw2, max_frame_id](const FrameId& f) { return f - provideOptimizationWindow(f, max_frame_id, sw2) > sw2.local_ba_window_size_; },

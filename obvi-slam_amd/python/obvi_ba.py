@@ -23,7 +23,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 
 
 class Options(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("object_block_size", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("device_id", C.c_int32), ("object_block_size", C.c_int32), ("reprojection_variant", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class SolverParams(C.Structure):
@@ -102,14 +102,14 @@ def _ptr(a, ctype):
 class BundleAdjuster:
     """One handle == one GPU == one HIP stream (include/obvi_ba.h)."""
 
-    def __init__(self, device_id=0, library=None, prefix="obvi_"):
+    def __init__(self, device_id=0, library=None, prefix="obvi_", reprojection_variant=0, deterministic=False):
         path = library or default_library_path()
         if not os.path.exists(path):
             raise ObviError("%s not found: build it with __graft_entry__.build() -- there is no CPU fallback" % path)
         self._lib = C.CDLL(path)
         self._pre = prefix
         self._h = C.c_void_p()
-        opt = Options(device_id, 7)
+        opt = Options(device_id, 7, int(reprojection_variant), 1 if deterministic else 0)
         self._check(self._fn("ba_create")(C.byref(opt), C.byref(self._h)), "create")
         self._keep = []
         self._n = {t: 0 for t in FACTOR_TYPES}

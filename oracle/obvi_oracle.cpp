@@ -68,6 +68,7 @@ void parallel_ranges(int64_t n, F&& fn) {   // fn(thread, begin, end), contiguou
 }
 
 struct OracleProblem {
+  int reproj_variant = 0;   // obvi_ba_options.reprojection_variant: 0 = a3 (production functor), 1 = a2 (analytic-Jacobian functor)
   std::vector<CameraConst> cams;
   int64_t P = 0, L = 0, O = 0;
   std::vector<double> poses, points, objects;
@@ -139,12 +140,18 @@ void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   const double* pose = &pb.poses[6 * f->i0];
   const double* pt = &pb.points[3 * f->i1];
   const CameraConst& cam = pb.cams[pb.rp_cam[i]];
-  if (!jac) { reprojection_residual<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r); return; }
+  const bool analytic = pb.reproj_variant == OBVI_REPROJECTION_ANALYTIC;
+  if (!jac) {
+    if (analytic) reprojection_residual_analytic<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
+    else reprojection_residual<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
+    return;
+  }
   typedef Dual<9> D;
   D dp[6], dx[3], dr[2];
   for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], k);
   for (int k = 0; k < 3; ++k) dx[k] = D::var(pt[k], 6 + k);
-  reprojection_residual<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
+  if (analytic) reprojection_residual_analytic<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
+  else reprojection_residual<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
   for (int a = 0; a < 2; ++a) {
     f->r[a] = dr[a].v;
     for (int k = 0; k < 6; ++k) f->J0[6 * a + k] = dr[a].d[k];
@@ -673,7 +680,9 @@ int32_t oracle_get_threads(void) { return g_threads; }
 int oracle_ba_create(const obvi_ba_options* opt, oracle_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
   if (opt && opt->object_block_size != 0 && opt->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  if (opt && opt->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && opt->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
   *out = new oracle_handle();
+  if (opt) (*out)->pb.reproj_variant = opt->reprojection_variant;   // opt->deterministic: the oracle is sequential in its sums, always deterministic
   return OBVI_OK;
 }
 void oracle_ba_destroy(oracle_handle* h) { delete h; }
@@ -1274,6 +1283,20 @@ void oracle_reproj(const double* pose6, const double* point3, const double* K4, 
   for (int k = 0; k < 6; ++k) dp[k] = D::var(pose6[k], k);
   for (int k = 0; k < 3; ++k) dx[k] = D::var(point3[k], 6 + k);
   reprojection_residual<D>(dp, dx, cam, pixel2, sigma, dr);
+  for (int a = 0; a < 2; ++a) {
+    r2[a] = dr[a].v;
+    if (Jpose) for (int k = 0; k < 6; ++k) Jpose[6 * a + k] = dr[a].d[k];
+    if (Jpoint) for (int k = 0; k < 3; ++k) Jpoint[3 * a + k] = dr[a].d[6 + k];
+  }
+}
+// the analytic-Jacobian functor (a2), same signature
+void oracle_reproj_analytic(const double* pose6, const double* point3, const double* K4, const double* ext7, const double* pixel2,
+                            double sigma, double* r2, double* Jpose, double* Jpoint) {
+  CameraConst cam; make_camera_const(K4, ext7, &cam);
+  typedef Dual<9> D; D dp[6], dx[3], dr[2];
+  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose6[k], k);
+  for (int k = 0; k < 3; ++k) dx[k] = D::var(point3[k], 6 + k);
+  reprojection_residual_analytic<D>(dp, dx, cam, pixel2, sigma, dr);
   for (int a = 0; a < 2; ++a) {
     r2[a] = dr[a].v;
     if (Jpose) for (int k = 0; k < 6; ++k) Jpose[6 * a + k] = dr[a].d[k];

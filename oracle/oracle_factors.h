@@ -170,6 +170,55 @@ inline void reprojection_residual(const T* pose, const T* point, const CameraCon
 }
 
 // ---------------------------------------------------------------------------------------
+// a2 / a1: ReprojectionCostFunctorAnalyticJacobian::Evaluate
+// (reprojection_cost_functor_analytic_jacobian.h:59-566; the same expression tree as
+// symforce/reprojectionResidual_with_jacobians012.h:37-521, spec reprojection_factor_code_generation.py:26-45).
+// Differences from a3, all restated here:
+//   * the robot rotation comes from the rotation vector through a quaternion with kEpsilon INSIDE the norm
+//     (:63-70: theta = sqrt(|aa|^2 + eps), q = (aa sin(theta/2)/theta, cos(theta/2))) -- smooth at aa = 0, no
+//     constant small-angle branch, so d r / d aa does not vanish there;
+//   * the camera depth is clamped, z <- max(z, kEpsilon) (:160), and the derivative of that clamp is the
+//     sign expression of :289-292: ((z - eps > 0) - (z - eps < 0) + 1) / 2 = 1 above, 1/2 at, 0 below eps;
+//   * kEpsilon = 1e-15 (:591).
+// The functor's Jacobian is the analytic derivative of this function; differentiating the same operation
+// sequence with duals gives it (checked against the reference's own outputs, tests/golden/a2_analytic_jacobian.json).
+// ---------------------------------------------------------------------------------------
+static const double kAnalyticEpsilon = 1e-15;  // reprojection_cost_functor_analytic_jacobian.h:591
+inline double clamp_depth(double z) { return std::max(z, kAnalyticEpsilon); }
+template <int N> inline Dual<N> clamp_depth(const Dual<N>& z) {
+  Dual<N> r;
+  r.v = std::max(z.v, kAnalyticEpsilon);
+  const double d = z.v - kAnalyticEpsilon;
+  const double gate = 0.5 * (double((d > 0) - (d < 0)) + 1.0);
+  for (int i = 0; i < N; ++i) r.d[i] = gate * z.d[i];
+  return r;
+}
+template <class T>
+inline void reprojection_residual_analytic(const T* pose, const T* point, const CameraConst& cam,
+                                           const double* pixel, double sigma, T* residual) {
+  // rotation vector -> quaternion (x y z w), epsilon inside the norm
+  const T theta = sqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5] + kAnalyticEpsilon);
+  const T half = theta * 0.5;
+  const T k = sin(half) / theta;
+  const T qx = pose[3] * k, qy = pose[4] * k, qz = pose[5] * k, qw = cos(half);
+  // world <- robot rotation of that quaternion (the unit-quaternion formula; no normalisation)
+  const T R[9] = {1.0 - 2.0 * (qy * qy + qz * qz), 2.0 * (qx * qy - qz * qw), 2.0 * (qx * qz + qy * qw),
+                  2.0 * (qx * qy + qz * qw), 1.0 - 2.0 * (qx * qx + qz * qz), 2.0 * (qy * qz - qx * qw),
+                  2.0 * (qx * qz - qy * qw), 2.0 * (qy * qz + qx * qw), 1.0 - 2.0 * (qx * qx + qy * qy)};
+  // point in the robot frame, then in the camera frame: T_ext^-1 T_robot^-1 l
+  const T d[3] = {point[0] - pose[0], point[1] - pose[1], point[2] - pose[2]};
+  T pr[3];
+  for (int i = 0; i < 3; ++i) pr[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];   // R^T d
+  T pc[3];
+  for (int i = 0; i < 3; ++i)
+    pc[i] = pr[0] * cam.Rinv[3 * i] + pr[1] * cam.Rinv[3 * i + 1] + pr[2] * cam.Rinv[3 * i + 2] + cam.tinv[i];
+  const T inv_z = T(1.0) / clamp_depth(pc[2]);
+  const double rect_x = (pixel[0] - cam.cx) / cam.fx, rect_y = (pixel[1] - cam.cy) / cam.fy;
+  residual[0] = (pc[0] * inv_z - rect_x) * (cam.fx / sigma);
+  residual[1] = (pc[1] * inv_z - rect_y) * (cam.fy / sigma);
+}
+
+// ---------------------------------------------------------------------------------------
 // a5: getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273), yaw-only ellipsoid.
 // Returns false in the invalid case (either radicand <= 0, :257-259).
 // ---------------------------------------------------------------------------------------

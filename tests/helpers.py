@@ -17,12 +17,12 @@ def ensure_oracle():
     return ORACLE_LIB
 
 
-def oracle_ba():
-    return obvi_ba.BundleAdjuster(library=ensure_oracle(), prefix="oracle_")
+def oracle_ba(**options):
+    return obvi_ba.BundleAdjuster(library=ensure_oracle(), prefix="oracle_", **options)
 
 
-def product_ba(device=0):
-    return obvi_ba.BundleAdjuster(device_id=device, library=PRODUCT_LIB, prefix="obvi_")
+def product_ba(device=0, **options):
+    return obvi_ba.BundleAdjuster(device_id=device, library=PRODUCT_LIB, prefix="obvi_", **options)
 
 
 def rel_err(a, b):

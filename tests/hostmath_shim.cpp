@@ -13,12 +13,21 @@ static void make_cam(const double* K4, const double* e, DevCam* c) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c->Rinv[3 * i + j] = R[3 * j + i];
   for (int i = 0; i < 3; ++i) c->tinv[i] = -(c->Rinv[3 * i] * e[4] + c->Rinv[3 * i + 1] * e[5] + c->Rinv[3 * i + 2] * e[6]);
   c->fx = K4[0]; c->fy = K4[1]; c->cx = K4[2]; c->cy = K4[3];
+  c->depth_min = -INFINITY;
 }
 extern "C" {
 void hostmath_reproj(const double* pose, const double* X, const double* K4, const double* ext7, const double* pix,
                      double sigma, double* r, double* Jp, double* Jl) {
   DevCam cam; make_cam(K4, ext7, &cam);
   PoseCache pc; make_pose_cache(pose, &pc);
+  reproj_eval<true>(pc, cam, X, pix[0], pix[1], sigma, r, Jp, Jl);
+}
+// the analytic-Jacobian variant (obvi_ba_options.reprojection_variant = OBVI_REPROJECTION_ANALYTIC)
+void hostmath_reproj_analytic(const double* pose, const double* X, const double* K4, const double* ext7, const double* pix,
+                              double sigma, double* r, double* Jp, double* Jl) {
+  DevCam cam; make_cam(K4, ext7, &cam);
+  cam.depth_min = OBVI_ANALYTIC_EPSILON;
+  PoseCache pc; make_pose_cache(pose, &pc, true);
   reproj_eval<true>(pc, cam, X, pix[0], pix[1], sigma, r, Jp, Jl);
 }
 int hostmath_bbox(const double* ell, const double* pose, const double* K4, const double* ext7, const double* rect,

@@ -46,6 +46,56 @@ def test_reference_tuple_reprojection(oracle, hostmath):
         assert helpers.rel_err(r, t["residual"]) < t["residual_rel_tol"]
 
 
+# kinds of tests/golden/a2_analytic_jacobian.json whose camera depth lies within a few thousand ulps of the clamp: there the depth itself
+# (a difference of O(1) numbers) carries a relative rounding error of 1e-16 / |z|, and so does everything divided by it
+A2_TOL = {"depth_1e-06": 1e-8, "depth_0.001": 1e-11, "depth_5e-16": 1e-11, "depth_-1e-12": 1e-11, "depth_0": 1e-11}
+A2_SKIP = ("depth_2e-15", "depth_1e-12")   # z = 2e-15 / 1e-12 known to 5 % / 1e-4 only: which side of 1e-15 it falls on is rounding
+
+
+def a2_cases():
+    return json.load(open(os.path.join(GOLD, "a2_analytic_jacobian.json")))["cases"]
+
+
+def test_analytic_jacobian_functor_against_the_reference_outputs(oracle, hostmath):
+    """SURVEY row a2 (== a1): ReprojectionCostFunctorAnalyticJacobian::Evaluate.  The vectors are outputs of the reference's own function
+    body (tests/golden/gen_a2_vectors.py): residual and both Jacobians to 1e-12 relative, for the oracle's restatement of
+    reprojection_cost_functor_analytic_jacobian.h:63-70, 160, 289-292 and for the product's arithmetic (host build of csrc/ba_math.h with
+    reprojection_variant = OBVI_REPROJECTION_ANALYTIC): generic cases, rotation vectors down to exactly zero (no constant branch), points behind
+    the camera / on the image plane (clamped depth, gated derivative)."""
+    seen = set()
+    for c in a2_cases():
+        if c["kind"] in A2_SKIP:
+            continue
+        seen.add(c["kind"].split("_")[0])
+        tol = A2_TOL.get(c["kind"], 1e-12)
+        cc = dict(pose=c["pose_t_aa"], point=c["point"], K=c["K"], ext=c["ext_qxyzw_t"], pixel=c["pixel"], sigma=c["sigma"])
+        for lib, fn in ((oracle, "oracle_reproj_analytic"), (hostmath, "hostmath_reproj_analytic")):
+            r, Jp, Jl = _reproj(lib, fn, cc)
+            assert helpers.rel_err(r, c["residual"]) < tol, (fn, c["kind"])
+            assert helpers.rel_err(Jp.ravel(), c["J_pose_2x6"]) < tol, (fn, c["kind"])
+            assert helpers.rel_err(Jl.ravel(), c["J_point_2x3"]) < tol, (fn, c["kind"])
+    assert seen >= {"survey", "generic", "small", "depth", "exact"}
+
+
+def test_analytic_and_production_functors_differ_where_the_reference_says(oracle, hostmath):
+    """a2 vs a3 on the same inputs: equal (1e-12) away from the two places the functors differ; below |aa| = 1e-8 the production functor's rotation is
+    a constant (zero d r / d aa, vslam_math_util.h:363-369) and the analytic one's is not; behind the camera the production functor
+    divides by the negative depth and the analytic one by 1e-15."""
+    for c in a2_cases():
+        cc = dict(pose=c["pose_t_aa"], point=c["point"], K=c["K"], ext=c["ext_qxyzw_t"], pixel=c["pixel"], sigma=c["sigma"])
+        for lib, pre in ((oracle, "oracle_reproj"), (hostmath, "hostmath_reproj")):
+            r3, Jp3, Jl3 = _reproj(lib, pre, cc)
+            r2, Jp2, Jl2 = _reproj(lib, pre + "_analytic", cc)
+            aa = np.linalg.norm(c["pose_t_aa"][3:])
+            if c["kind"] in ("generic", "survey_tuple") or (c["kind"].startswith("small_angle") and aa > 1e-8):
+                tol = 1e-12 if aa >= 1e-2 or pre == "hostmath_reproj" else 1e-9   # the dual-number path through aa/|aa| loses digits at tiny angles
+                assert helpers.rel_err(r2, r3) < 1e-12 and helpers.rel_err(Jp2, Jp3) < tol and helpers.rel_err(Jl2, Jl3) < 1e-12, (pre, c["kind"])
+            elif c["kind"].startswith("small_angle"):
+                assert helpers.rel_err(r2, r3) < 1e-6 and np.all(Jp3[:, 3:] == 0.0) and np.abs(Jp2[:, 3:]).max() > 1.0, (pre, c["kind"])
+            elif c["kind"] in ("depth_-5", "depth_-0.001", "exact_depth_-2"):
+                assert np.abs(r2).max() > 1e12 and np.abs(r3).max() < 1e9, (pre, c["kind"])
+
+
 def test_reference_tuple_bbox(oracle):
     t = json.load(open(os.path.join(GOLD, "reference_tuples.json")))["ellipsoid_bbox"]
     c = np.zeros(4)

@@ -1,0 +1,115 @@
+"""GPU (-m gpu): the deterministic mode of the HIP path (obvi_ba_options.deterministic / OBVI_DETERMINISTIC=1 / run_offline_ba --deterministic).
+
+Ceres at a fixed num_threads is deterministic from run to run (object_pose_graph_optimizer.h:664); the default HIP path is not -- fp64
+hardware atomics add in whatever order the workgroups arrive.  In deterministic mode every cross-workgroup sum has one writer or a fixed
+order (DESIGN.md 5 "Determinism"), so two runs agree bit for bit, and whole sessions can be compared with the oracle's exactly:
+  * two solves of the same problem: every iteration record and every parameter block bit-identical
+  * deterministic vs default mode: the same LM trajectory to round-off (1e-9 relative on the costs)
+  * an 80-frame sliding-window session (162 optimisations): the driver's output is byte-identical between two runs, and against the
+    oracle-driven session: the same LM iteration count in EVERY optimisation, final costs to 1e-6 relative, poses to 1e-6 m / rad
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+import synth
+from test_host_mirror import driver, oracle_driver, scene  # noqa: F401  (fixtures: the host mirror's driver on libobvi_ba.so / on the oracle, the 80-frame scene)
+
+pytestmark = pytest.mark.gpu
+
+
+def all_families(P, L, O, seed):
+    prob = synth.make_problem(P=P, L=L, O=O, seed=seed, object_classes=("bench", "chair"), bbox_noise=5.0, min_obj_obs=5)
+    n = len(prob["objects"])
+    A = np.random.default_rng(seed).normal(size=(n, 7, 7))
+    prob.update(lt_obj=np.arange(n, dtype=np.uint32), lt_mean=prob["gt_objects"] + 0.05,
+                lt_cov=(A @ A.transpose(0, 2, 1) + 7 * np.eye(7)).reshape(n, 49) * 0.01, lt_huber=1.0)
+    return prob
+
+
+def run(prob, prm, **options):
+    ba = helpers.product_ba(**options)
+    synth.upload(ba, prob)
+    c0 = ba.evaluate(True)
+    s = ba.solve(prm)
+    its = [(i.iteration, i.step_is_successful, i.cost, i.cost_change, i.gradient_max_norm, i.gradient_norm, i.step_norm, i.relative_decrease, i.trust_region_radius) for i in ba.iterations()]
+    cov = ba.object_covariances(np.arange(len(prob["objects"])), np.arange(len(prob["objects"]))) if len(prob["objects"]) else None
+    return dict(eval_cost=c0[0], eval_res=c0[1], summary=(s.num_iterations, s.termination_type, s.initial_cost, s.final_cost, s.fixed_cost), its=its,
+                poses=ba.get_poses(), points=ba.get_points(), objects=ba.get_objects(), cov=cov)
+
+
+@pytest.mark.parametrize("shape", [(40, 500, 4, 3), (320, 5000, 12, 4)])   # one dissection leaf; several levels, update jobs, level-by-level backward substitution
+def test_two_deterministic_solves_are_bit_identical(shape):
+    P, L, O, seed = shape
+    prob = all_families(P, L, O, seed)
+    prm = helpers.ba_params(max_it=8, ftol=1e-9)
+    a, b = run(prob, prm, deterministic=True), run(prob, prm, deterministic=True)
+    assert a["summary"] == b["summary"] and a["its"] == b["its"] and a["eval_cost"] == b["eval_cost"]
+    for k in ("eval_res", "poses", "points", "objects", "cov"):
+        assert np.array_equal(a[k], b[k]), k
+    # ... and the default (atomic) mode follows the same trajectory to round-off
+    d = run(prob, prm)
+    assert d["summary"][:2] == a["summary"][:2]
+    for x, y in zip(d["its"], a["its"]):
+        assert x[1] == y[1] and abs(x[2] - y[2]) <= 1e-9 * y[2]
+    assert np.abs(d["poses"] - a["poses"]).max() < 1e-7
+
+
+def test_deterministic_mode_against_the_oracle():
+    prob = all_families(30, 400, 3, 1)
+    o, g = helpers.oracle_ba(), helpers.product_ba(deterministic=True)
+    for ba in (o, g):
+        synth.upload(ba, prob)
+    co, ro, _ = o.evaluate(True); cg, rg, _ = g.evaluate(True)
+    assert abs(cg - co) <= 1e-12 * co and np.abs(rg - ro).max() <= 1e-12 * np.abs(ro).max()
+    So, bo = o.debug_reduced_system(100.0); Sg, bg = g.debug_reduced_system(100.0)
+    assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
+    prm = helpers.ba_params(max_it=30)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.num_iterations == so.num_iterations and sg.termination_type == so.termination_type
+    for a, b in zip(o.iterations(), g.iterations()):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-8
+    n = len(prob["objects"])
+    Co, Cg = o.object_covariances(np.arange(n), np.arange(n)), g.object_covariances(np.arange(n), np.arange(n))
+    assert np.abs(Cg - Co).max() <= 1e-8 * np.abs(Co).max()
+
+
+def strip_times(o):
+    if isinstance(o, dict):
+        return {k: strip_times(v) for k, v in o.items() if "time" not in k and "seconds" not in k}
+    if isinstance(o, list):
+        return [strip_times(v) for v in o]
+    return o
+
+
+def test_deterministic_sessions_are_byte_identical_and_equal_the_oracle_session(driver, oracle_driver, scene, tmp_path):  # noqa: F811
+    """The 80-frame session of tests/test_host_mirror.py (window 20, global BA every 25 frames, long-term map at the end) through the host mirror
+    with --deterministic: twice on the HIP path, once through the oracle."""
+    prob, path, _ = scene
+    outs = []
+    for k in range(2):
+        out, csv = str(tmp_path / ("hip%d.json" % k)), str(tmp_path / ("hip%d.csv" % k))
+        subprocess.check_call([driver, path, out, "--window", "20", "--gba-frequency", "25", "--ltm", "--deterministic", "--csv", csv], timeout=900)
+        rows = [ln.split(",") for ln in open(csv).read().strip().split("\n")]
+        keep = [i for i, name in enumerate(rows[0]) if "time" not in name]
+        outs.append((json.dumps(strip_times(json.load(open(out))), sort_keys=True), [[r[i] for i in keep] for r in rows]))
+    assert outs[0][0] == outs[1][0], "two deterministic sessions differ"
+    assert outs[0][1] == outs[1][1]
+    ora_out = str(tmp_path / "oracle.json")
+    subprocess.check_call([oracle_driver, path, ora_out, "--window", "20", "--gba-frequency", "25", "--ltm"], timeout=1500)
+    hip, ora = json.load(open(str(tmp_path / "hip0.json"))), json.load(open(ora_out))
+    rh, ro = hip["records"], ora["records"]
+    assert [(r["kind"], r["min_frame"], r["max_frame"], r["n_poses"], r["n_features"], r["n_excluded"]) for r in rh] == [(r["kind"], r["min_frame"], r["max_frame"], r["n_poses"], r["n_features"], r["n_excluded"]) for r in ro]
+    assert [r["iterations"] for r in rh] == [r["iterations"] for r in ro]                      # all 162 optimisations
+    rel = [abs(a["final_cost"] - b["final_cost"]) / max(b["final_cost"], 1e-12) for a, b in zip(rh, ro)]
+    assert max(rel) <= 1e-6, max(rel)
+    ph, po = np.array(hip["poses"]), np.array(ora["poses"])
+    assert np.abs(ph - po).max() <= 1e-6                                                       # m / rad
+    assert set(hip["objects"]) == set(ora["objects"]) and set(hip["long_term_map"]) == set(ora["long_term_map"])
+    for oid in ora["objects"]:
+        assert np.abs(np.array(hip["objects"][oid]) - np.array(ora["objects"][oid])).max() <= 1e-5

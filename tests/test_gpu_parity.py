@@ -147,6 +147,73 @@ def test_reference_tuples_through_the_abi():
     assert np.abs(corners - np.array(e["rectified_corners"])).max() < e["corners_abs_tol"]
 
 
+def test_analytic_jacobian_functor_through_the_abi():
+    """a handle created with reprojection_variant = OBVI_REPROJECTION_ANALYTIC evaluates the reference's analytic-Jacobian functor
+    (depth clamp max(z, 1e-15) with its gated derivative, rotation smooth through aa = 0).  The golden vectors are the outputs of the reference's
+    own Evaluate body (tests/golden/a2_analytic_jacobian.json): every case is an observation with its own pose, point and camera."""
+    from test_golden import A2_SKIP, A2_TOL, a2_cases
+    cases = [c for c in a2_cases() if c["kind"] not in A2_SKIP]
+    n = len(cases)
+    for ba in (helpers.product_ba(reprojection_variant=1), helpers.oracle_ba(reprojection_variant=1)):
+        ba.set_cameras([c["K"] for c in cases], [c["ext_qxyzw_t"] for c in cases])
+        ba.set_poses([c["pose_t_aa"] for c in cases]); ba.set_points([c["point"] for c in cases]); ba.set_objects(np.zeros((0, 7)))
+        ba.set_reproj(np.arange(n), np.arange(n), np.arange(n), [c["pixel"] for c in cases], np.array([c["sigma"] for c in cases]), 1.0)
+        r, Jp, Jl = ba.debug_linearize(0)
+        _, res, sq = ba.evaluate(False)
+        for i, c in enumerate(cases):
+            tol = A2_TOL.get(c["kind"], 1e-12)
+            assert rel_err(r[i], c["residual"]) < tol and rel_err(res[2 * i:2 * i + 2], c["residual"]) < tol, c["kind"]
+            assert rel_err(Jp[i].ravel(), c["J_pose_2x6"]) < tol and rel_err(Jl[i].ravel(), c["J_point_2x3"]) < tol, c["kind"]
+            assert abs(sq[i] - np.dot(c["residual"], c["residual"])) <= 2 * tol * sq[i], c["kind"]
+    # the default handle is the production functor: no clamp (a point behind the camera projects through the negative depth), constant rotation below 1e-8
+    ba = helpers.product_ba()
+    ba.set_cameras([c["K"] for c in cases], [c["ext_qxyzw_t"] for c in cases])
+    ba.set_poses([c["pose_t_aa"] for c in cases]); ba.set_points([c["point"] for c in cases]); ba.set_objects(np.zeros((0, 7)))
+    ba.set_reproj(np.arange(n), np.arange(n), np.arange(n), [c["pixel"] for c in cases], np.array([c["sigma"] for c in cases]), 1.0)
+    r3, Jp3, _ = ba.debug_linearize(0)
+    for i, c in enumerate(cases):
+        if c["kind"] in ("depth_-5", "exact_depth_-2"):
+            assert np.abs(r3[i]).max() < 1e9 < 1e12 < np.abs(c["residual"]).max()
+        if c["kind"] in ("small_angle_0", "small_angle_1e-10", "small_angle_5e-09"):
+            assert np.all(Jp3[i][:, 3:] == 0.0) and np.abs(np.array(c["J_pose_2x6"]).reshape(2, 6)[:, 3:]).max() > 1.0
+
+
+def test_analytic_variant_solve_follows_the_oracle(small):
+    """The whole path in the analytic variant, HIP vs oracle, where the two functors differ.  Evaluation / linearisation: a few features start
+    behind their cameras (clamped depth: residuals of 1e17; the production functor would see a finite mirror image).  LM trajectory: pose 1 starts
+    with a zero rotation vector, the constant-rotation branch of the production functor, which can then never rotate it."""
+    from scipy.spatial.transform import Rotation as Rot
+    prob = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in small.items()}
+    prob["poses"][1, 3:6] = 0.0
+    behind = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in prob.items()}
+    for a in np.unique(prob["rp_point"], return_index=True)[1][:3]:          # three features placed 2 m behind their first observing camera
+        p = prob["poses"][prob["rp_pose"][a]]
+        behind["points"][prob["rp_point"][a]] = p[:3] + Rot.from_rotvec(p[3:6]).apply([-2.0, 0.1, 0.2])    # robot x forward = optical z
+    o, g = helpers.oracle_ba(reprojection_variant=1), helpers.product_ba(reprojection_variant=1)
+    for ba in (o, g):
+        synth.upload(ba, behind)
+    for loss in (True, False):
+        co, ro, _ = o.evaluate(loss); cg, rg, _ = g.evaluate(loss)
+        assert abs(cg - co) <= 1e-12 * co and np.abs(rg - ro).max() <= 1e-12 * np.abs(ro).max()
+    assert np.abs(ro).max() > 1e12                                           # the clamp is active in this problem
+    ro, J0o, J1o = o.debug_linearize(0); rg, J0g, J1g = g.debug_linearize(0)
+    sc = np.maximum(1.0, np.abs(J0o).max(axis=(1, 2)))[:, None, None]
+    assert (np.abs(J0g - J0o) / sc).max() < 1e-9 and (np.abs(J1g - J1o) / sc).max() < 1e-9    # per observation (the oracle's duals lose digits at tiny angles)
+    for ba in (o, g):
+        ba.update_points(prob["points"])                                     # every feature in front of its cameras again
+    prm = helpers.ba_params(max_it=12)
+    so, sg = o.solve(prm), g.solve(prm)
+    assert sg.num_iterations == so.num_iterations and sg.termination_type == so.termination_type
+    for a, b in zip(o.iterations(), g.iterations()):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-8 * a.cost
+    assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-7
+    assert np.abs(g.get_poses()[1, 3:6]).max() > 1e-6                       # the pose that started at aa = 0 did rotate
+    p3 = helpers.product_ba()
+    synth.upload(p3, prob)
+    p3.solve(prm)
+    assert np.all(p3.get_poses()[1, 3:6] == 0.0)                             # ... and cannot under the production functor (zero d r / d aa)
+
+
 def test_two_phase_outlier_rejection(small):
     """offline_problem_runner.h:541-894: solve, drop the top 10 % per factor type, revert, rebuild, solve again."""
     o, g = pair(small)
