@@ -1124,15 +1124,27 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
     }
     __syncthreads();
   }
-  if (with_rhs) {
+  if (with_rhs) {   // uniform per workgroup
+    // the four streams' partial sums of (Z u) meet in LDS and are added by one wavefront, in a fixed order: one atomic per row and
+    // workgroup instead of four whose order would change from run to run
 #pragma unroll
     for (int r = 0; r < kSTR; ++r) {
       double tot = racc[r];
       tot += __shfl_xor(tot, 16, 64);
       tot += __shfl_xor(tot, 32, 64);
-      const int row = 16 * r + m;
-      const int64_t rp_ = rown[kSBack + row / 6];
-      if (kq == 0 && tot != 0.0 && rp_ >= 0) atomic_add_f64(rd.rhs + rp_ + row % 6, -tot);
+      if (kq == 0) red[(wv * kSTR + r) * 16 + m] = tot;
+    }
+    __syncthreads();
+    if (wv == 0 && kq == 0) {
+#pragma unroll
+      for (int r = 0; r < kSTR; ++r) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kSWv; ++w) tot += red[(w * kSTR + r) * 16 + m];
+        const int row = 16 * r + m;
+        const int64_t rp_ = rown[kSBack + row / 6];
+        if (tot != 0.0 && rp_ >= 0) atomic_add_f64(rd.rhs + rp_ + row % 6, -tot);
+      }
     }
   }
 }

@@ -718,7 +718,7 @@ void prepare(obvi_ba_handle* h) {
   }
   // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
   // (deterministic mode: a work list is never cut -- one workgroup, hence one writer, per strip)
-  const int64_t slice = h->deterministic ? std::numeric_limits<int64_t>::max() : std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
+  const int64_t slice = h->deterministic ? ((int64_t)1 << 40) : std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
   // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
   // slots: one per strip frame over the range of its row frames and of its column frames in the group (source: the Z
   // record, or the zero page for a frame the point skips), the point's (u_l, 0) tail, and -- stereo -- a second layer
@@ -819,7 +819,7 @@ void prepare(obvi_ba_handle* h) {
   for (size_t k = 0; k < pairs.size(); ++k) {
     // a block's pairs are cut into work items of at most kPairsPerItem (k_schur_blocks adds its sums atomically): a few long tracks in a
     // small window would otherwise leave one workgroup with thousands of pairs on the critical path
-    const size_t kPairsPerItem = h->deterministic ? std::numeric_limits<size_t>::max() : 256;   // deterministic mode: one work item, hence one writer, per block
+    const size_t kPairsPerItem = h->deterministic ? ((size_t)1 << 40) : 256;   // deterministic mode: one work item, hence one writer, per block
     if (k == 0 || pairs[k].key != pairs[k - 1].key || k - blk_ptr.back() >= kPairsPerItem) {
       blk_row.push_back((uint32_t)h->h_pose_row[pairs[k].key / (uint64_t)(h->nPv + 1)]);
       blk_col.push_back((uint32_t)h->h_pose_row[pairs[k].key % (uint64_t)(h->nPv + 1)]);
@@ -881,7 +881,7 @@ void prepare(obvi_ba_handle* h) {
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
   std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, job_signal, k_need_of(nt, 0);
   std::vector<uint8_t> upd_flag;
-  const int kUpdChunk = h->deterministic ? std::numeric_limits<int>::max() : std::max(1, env_int("OBVI_UPD_CHUNK", 4));   // products per update job (tuning knob; deterministic mode: a target's products are never split over jobs that would meet in atomics)
+  const int kUpdChunk = h->deterministic ? (1 << 30) : std::max(1, env_int("OBVI_UPD_CHUNK", 4));   // products per update job (tuning knob; deterministic mode: a target's products are never split over jobs that would meet in atomics)
   const int64_t env_slice_max = std::getenv("OBVI_SLICE_MAX") ? std::atoi(std::getenv("OBVI_SLICE_MAX")) : 512;   // tuning knob
   // a potrf workgroup applies up to this many products of the previous level to its own diagonal tile (tuning knob)
   const size_t pre_max = (size_t)std::max(0, env_int("OBVI_PRE_MAX", 2));

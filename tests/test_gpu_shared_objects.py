@@ -340,11 +340,16 @@ def test_compiled_rccl_hook_one_rank_communicator(scene):
 
 
 def test_rccl_rendezvous_file(tmp_path):
-    """obvi_rccl_comm_create_from_file: the launcher-less rendezvous of a C++ host (rank 0 writes the id, the others poll)."""
+    """obvi_rccl_comm_create_from_file: the launcher-less rendezvous of a C++ host (rank 0 writes the id, the others poll).  The file lives only
+    for the rendezvous: rank 0 replaces whatever an earlier run left at the path and removes its own file once the communicator exists, so a
+    second run on the same path can never pick up the first run's id."""
+    import os
     path = str(tmp_path / "rccl_id")
-    comm = dist_util.RcclComm(0, 1, 0, id_file=path)
-    try:
-        import os
-        assert os.path.getsize(path) == dist_util.RcclComm.ID_BYTES and comm.world() == 1
-    finally:
-        comm.close()
+    with open(path, "wb") as f:
+        f.write(b"\x5a" * dist_util.RcclComm.ID_BYTES)        # a leftover of a crashed run: a syntactically valid, wrong id
+    for _ in range(2):                                        # ... and the same path twice in a row
+        comm = dist_util.RcclComm(0, 1, 0, id_file=path)
+        try:
+            assert comm.world() == 1 and not os.path.exists(path)
+        finally:
+            comm.close()
