@@ -262,10 +262,11 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
  *   (1) op SUM  on the packed J^T J diagonal blocks and gradients of the shared objects   (n_shared * 56 doubles)
  *   (2) op SUM  on the trailing shared-object tiles of the reduced system + right-hand side, after the rank's own
  *               poses / points / private objects have been eliminated
- *   (3) op SUM / MAX on the scalar block (costs, model change, step and gradient norms) so that every rank takes the
- *               same accept / reject decision.
- * `fn` sums (op 0) or maximises (op 1) `count_f64` doubles in place across ranks -- ncclAllReduce on `stream`
- * (a hipStream_t) in a C++ host, torch.distributed.all_reduce from Python.  Non-zero return aborts the solve. */
+ *   (3) op SUM  on the scalar block (costs, model change, step and gradient norms) followed by one slot per rank that carries
+ *               that rank's gradient maximum (9 + world doubles), so that every rank takes the same accept / reject decision.
+ * (1) is issued on the handle's side stream -- it overlaps the Schur complement of the rank's own blocks --, (2) and (3) on its main
+ * stream, always in this order on every rank.  `fn` sums (op 0) or maximises (op 1) `count_f64` doubles in place across ranks --
+ * ncclAllReduce on `stream` (a hipStream_t) in a C++ host, torch.distributed.all_reduce from Python.  Non-zero return aborts the solve. */
 typedef int (*obvi_allreduce_fn)(void* user, void* device_buf, int64_t count_f64, int32_t op, void* stream);
 int obvi_ba_set_allreduce(obvi_ba_handle* h, obvi_allreduce_fn fn, void* user);
 /* is_shared[i] != 0: object i is shared across ranks.  rank / world: this handle's position in the job. */
@@ -298,6 +299,19 @@ int obvi_ba_set_profiling(obvi_ba_handle* h, int32_t level);
  * names is a NUL-separated list; returns number of entries. */
 int obvi_ba_get_kernel_times(const obvi_ba_handle* h, char* names, int32_t names_cap, double* total_ms,
                              int64_t* launches, int32_t cap);
+
+/* What this device delivers for the two resources the kernels are priced against (the public peaks "to be re-measured on
+ * the box with a triad and a DGEMM microbenchmark"): HBM bandwidth of a triad / copy / read over 1 GiB arrays, and the fp64 matrix rate of
+ * v_mfma_f64_16x16x4_f64 -- the bare issue rate (operands in registers) and the 64x64x64 tile product of the tile Cholesky fed from LDS.
+ * About 50 ms; allocates 3 GiB for the duration of the call. */
+typedef struct {
+  double hbm_triad_gbs, hbm_copy_gbs, hbm_read_gbs;
+  double mfma_f64_issue_tflops, mfma_f64_tile_tflops;
+  double clock_mhz;
+  int32_t compute_units;
+  int32_t reserved;
+} obvi_measured_peaks;
+int obvi_ba_measure_peaks(obvi_ba_handle* h, obvi_measured_peaks* out);
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,8 @@ void launch_fill(hipStream_t s, double* p, int64_t n, double v);
 // multi-GPU exchange buffers: shared objects' (Hdiag 49 | g 7) and the trailing tiles [t0, nt) + rhs rows
 void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack);
 void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* buf, int unpack);
+// scalar sums [SC_COST, SC_SUM_END) + one gradient-maximum slot per rank: (SC_SUM_END - SC_COST) + world doubles, one all-reduce (sum)
+void launch_pack_scalars(hipStream_t s, double* scal, double* buf, int32_t rank, int32_t world, int unpack);
 
 // ---- outlier selection (select_kernels.hip) ---------------------------------------------
 struct SelectScratch {

@@ -1667,6 +1667,25 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
 void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack) {
   if (n_shared > 0) hipLaunchKernelGGL(k_pack_shared_blocks, dim3(n_shared), dim3(64), 0, s, b, rd, shared_ov, n_shared, buf, unpack);
 }
+// multi-GPU: the scalar block's sums and the gradient maximum in ONE all-reduce (sum): buf = [SC_COST, SC_SUM_END) | one slot per rank
+// holding that rank's maximum (zero elsewhere), so that after the sum every rank sees every maximum and takes the largest itself
+__global__ void __launch_bounds__(64) k_pack_scalars(double* scal, double* buf, int32_t rank, int32_t world, int unpack) {
+  const int t = threadIdx.x;
+  constexpr int n = SC_SUM_END - SC_COST;
+  if (!unpack) {
+    for (int i = t; i < n + world; i += 64) buf[i] = i < n ? scal[SC_COST + i] : (i - n == rank ? scal[SC_GMAX_BITS] : 0.0);
+  } else {
+    for (int i = t; i < n; i += 64) scal[SC_COST + i] = buf[i];
+    if (t == 0) {
+      double m = 0.0;   // non-negative doubles: the value whose bits the slot holds
+      for (int r = 0; r < world; ++r) m = fmax(m, buf[n + r]);
+      scal[SC_GMAX_BITS] = m;
+    }
+  }
+}
+void launch_pack_scalars(hipStream_t s, double* scal, double* buf, int32_t rank, int32_t world, int unpack) {
+  hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(64), 0, s, scal, buf, rank, world, unpack);
+}
 void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* buf, int unpack) {
   const int ntail = rd.nt - t0;
   if (ntail > 0) hipLaunchKernelGGL(k_pack_tail, dim3(ntail * (ntail + 1) / 2 + 1), dim3(kBlock), 0, s, rd, t0, buf, unpack);

@@ -163,7 +163,7 @@ struct obvi_ba_handle {
   std::vector<int32_t> h_shared_ov;      // reduced object indices of the shared objects, in object-index order
   DevBuf<int32_t> d_shared_ov;
   DevBuf<uint8_t> d_obj_shared;
-  DevBuf<double> d_xbuf;                 // exchange buffer
+  DevBuf<double> d_xbuf, d_xbuf2;        // exchange buffers: main stream (tail, scalars) / side stream (shared blocks)
   int32_t tail_t0 = -1, tail_level0 = -1;   // first tile / first level of the shared tail (-1: none)
 
   // ---- phase timing ----
@@ -1125,7 +1125,8 @@ void prepare(obvi_ba_handle* h) {
     for (int32_t ov : h->h_shared_ov) sh[ov] = 1;
     h->d_obj_shared.upload(sh, s); h->d_shared_ov.upload(h->h_shared_ov, s);
     const int64_t ntail = h->tail_t0 >= 0 ? nt - h->tail_t0 : 0;
-    h->d_xbuf.resize((size_t)std::max<int64_t>(56 * (int64_t)h->h_shared_ov.size(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile) + 64);
+    h->d_xbuf.resize((size_t)std::max<int64_t>(56 * (int64_t)h->h_shared_ov.size(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile) + 64 + (size_t)h->world);
+    h->d_xbuf2.resize((size_t)(56 * (int64_t)h->h_shared_ov.size()) + 64);
   }
   h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
   h->d_g.resize((size_t)h->m_canon + 1); h->d_scale.resize((size_t)h->m_canon + 1); h->d_lam.resize((size_t)h->m_canon + 1);
@@ -1273,9 +1274,10 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   const bool exchange = h->allreduce != nullptr && !h->h_shared_ov.empty();
   // Fork: the pose-side pass, the small factor families and the diagonal blocks do not depend on the point pass or the
   // Schur complement (everything they share is accumulated with atomics), so they run beside them on the side stream.
-  // Not with a multi-GPU exchange in the chain (its collective is ordered on the main stream) nor in an instrumented solve.
+  // With a multi-GPU exchange the first collective (the shared objects' blocks) rides on the side stream too: it needs the pose pass and the
+  // small factors, and only the diagonal-block kernel behind it needs its result.  Not in an instrumented solve.
   static const bool side_ok = !std::getenv("OBVI_SIDE") || std::atoi(std::getenv("OBVI_SIDE")) != 0;   // tuning knob
-  const bool side = !exchange && h->profiling < 2 && side_ok && !h->deterministic;   // deterministic mode: one stream, so that the kernels that add to the same tiles do so in a fixed order
+  const bool side = h->profiling < 2 && side_ok && !h->deterministic;   // deterministic mode: one stream, so that the kernels that add to the same tiles do so in a fixed order
   hipStream_t s2 = side ? h->stream2 : s;
   // the point pass first, alone: it and the pose-side pass stream the same observation arrays and are both HBM-bound (side by side the
   // point pass took 0.35 ms instead of 0.24); the side stream starts behind it and runs beside the Schur complement, which is bound
@@ -1292,9 +1294,9 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   record(h, PH_DIAG, s2);
   if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
     const int32_t ns = (int32_t)h->h_shared_ov.size();
-    launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 0);
-    if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), 56 * (int64_t)ns, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
-    launch_pack_shared_blocks(s, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf.get(), 1);
+    launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 0);
+    if (h->allreduce(h->allreduce_user, h->d_xbuf2.get(), 56 * (int64_t)ns, 0, s2)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
+    launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 1);
   }
   launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
   if (side) record_end(h, PH_DIAG, s2);
@@ -1335,9 +1337,10 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   if (solve) launch_cost(s, b, reproj_pose_dev(h), sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
                          h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);
   record(h, PH_COUNT);
-  if (exchange) {   // (3) every rank must take the same decision
-    if (h->allreduce(h->allreduce_user, scal + SC_COST, SC_SUM_END - SC_COST, 0, s) || h->allreduce(h->allreduce_user, scal + SC_GMAX_BITS, 1, 1, s))
-      throw HipError{hipErrorUnknown, "allreduce hook (scalars)", __FILE__, __LINE__};
+  if (exchange) {   // (3) every rank must take the same decision: the sums and every rank's gradient maximum in one collective
+    launch_pack_scalars(s, scal, h->d_xbuf.get(), h->rank, h->world, 0);
+    if (h->allreduce(h->allreduce_user, h->d_xbuf.get(), (SC_SUM_END - SC_COST) + h->world, 0, s)) throw HipError{hipErrorUnknown, "allreduce hook (scalars)", __FILE__, __LINE__};
+    launch_pack_scalars(s, scal, h->d_xbuf.get(), h->rank, h->world, 1);
   }
   static const bool poll_ok = !std::getenv("OBVI_POLL_SCALARS") || std::atoi(std::getenv("OBVI_POLL_SCALARS")) != 0;   // tuning knob
   const bool poll = poll_ok && h->profiling < 1 && !keep_factor;

@@ -352,6 +352,15 @@ class BundleAdjuster:
         m = None if is_shared is None else np.ascontiguousarray(is_shared, dtype=np.uint8)
         self._check(self._fn("ba_set_shared_objects")(self._h, _ptr(m, C.c_uint8), C.c_int32(rank), C.c_int32(world)), "set_shared_objects")
 
+    def measure_peaks(self):
+        """HBM triad / copy / read bandwidth (GB/s) and the fp64 MFMA rates (TFLOP/s) of this device (obvi_ba_measure_peaks)."""
+        class Peaks(C.Structure):
+            _fields_ = [("hbm_triad_gbs", C.c_double), ("hbm_copy_gbs", C.c_double), ("hbm_read_gbs", C.c_double), ("mfma_f64_issue_tflops", C.c_double),
+                        ("mfma_f64_tile_tflops", C.c_double), ("clock_mhz", C.c_double), ("compute_units", C.c_int32), ("reserved", C.c_int32)]
+        p = Peaks()
+        self._check(self._fn("ba_measure_peaks")(self._h, C.byref(p)), "measure_peaks")
+        return {name: getattr(p, name) for name, _ in Peaks._fields_ if name != "reserved"}
+
     def debug_linearize(self, factor_type):
         n, m = self._n[factor_type], RESIDUAL_DIM[factor_type]
         d0, d1 = BLOCK_DIMS[factor_type]
