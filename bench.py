@@ -351,6 +351,7 @@ def main():
     summ = ba.solve(solver_params(obvi_ba, args.steps))
     barrier()
     dt = time.perf_counter() - t0
+    ba_timed_iterations = ba.iterations()
     steps_done = summ.num_iterations - 1
     dt, steps_done = dist_util.reduce_timing(dist, "cuda", dt, steps_done)
 
@@ -456,13 +457,17 @@ def main():
             # the same steps in deterministic mode (obvi_ba_options.deterministic: fixed-order sums, one stream; for parity runs)
             bd = obvi_ba.BundleAdjuster(device_id=local_rank, deterministic=True)
             synth.upload(bd, prob)
-            bd.solve(solver_params(obvi_ba, max(1, args.warmup)))
+            if args.warmup > 0:
+                bd.solve(solver_params(obvi_ba, args.warmup))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             sd = bd.solve(solver_params(obvi_ba, args.steps))
             torch.cuda.synchronize()
+            its_d, its_0 = bd.iterations(), ba_timed_iterations
             out["deterministic_mode"] = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / max(1, sd.num_iterations - 1), 4), "steps": sd.num_iterations - 1,
-                                         "final_cost_rel_diff_vs_default": abs(sd.final_cost - summ.final_cost) / summ.final_cost}
+                                         # the two modes differ by the order of their sums only: the first steps agree to round-off, later ones as far as this
+                                         # ill-conditioned problem amplifies it (zero tolerances, non-monotonic steps: a chaotic trajectory)
+                                         "cost_rel_diff_vs_default": {"after_step_%d" % k: abs(its_d[k].cost - its_0[k].cost) / its_0[k].cost for k in (1, 2, 4, 8, len(its_0) - 1) if k < min(len(its_d), len(its_0))}}
             bd.close()
         if world == 1 and args.config == 3 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_global_ba(obvi_ba, synth, prob, local_rank)

@@ -202,6 +202,7 @@ struct CholPlan {
   int32_t nt;
   int32_t nlevels;
   int32_t deterministic;      // column-oriented backward substitution without atomics (one launch per level)
+  int32_t fused_potrf;        // 1: k_update_potrf (a level's updates + the next level's potrf in one grid, potrf workgroups wait for their jobs); 0: two launches
   const int32_t* lvl_k_ptr;   // host [nlevels+1]   tile columns of each level
   const int32_t* lvl_k;       // device
   const int32_t* trsm_ptr;    // host [nlevels+1]   trsm jobs (i,k), k in the level

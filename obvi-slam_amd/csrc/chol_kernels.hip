@@ -846,7 +846,7 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& p, int l0, int l1, do
     const int npk = l + 1 < l1 ? p.lvl_k_ptr[l + 2] - p.lvl_k_ptr[l + 1] : 0;
     UpdateJobs u{nup, p.upd_ij + 2 * (int64_t)p.upd_ptr[l], p.upd_kptr + p.upd_ptr[l], p.upd_k, p.upd_flag + p.upd_ptr[l],
                  p.rh_i + p.rh_ptr[l], p.rh_kptr + p.rh_ptr[l], p.rh_k};
-    static const bool fused = !std::getenv("OBVI_FUSED_POTRF") || std::atoi(std::getenv("OBVI_FUSED_POTRF")) != 0;   // 0: two launches per level, nothing waits inside a launch (CI parity run)
+    const bool fused = p.fused_potrf != 0;   // 0: two launches per level, nothing waits inside a launch (handle state: OBVI_FUSED_POTRF=0, or after a wait time-out)
     if (npk > 0 && !fused) {
       if (nup + nrh > 0) { hipLaunchKernelGGL(k_update, dim3(sl * nup + nrh), dim3(kThreads), 0, s, S, nt, u, rhs, sl); tick(s, timers, CK_UPDATE); }
       hipLaunchKernelGGL(k_potrf_pre, dim3(npk), dim3(512), 0, s, S, nt, p.lvl_k + p.lvl_k_ptr[l + 1], p.pre_ptr + p.lvl_k_ptr[l + 1], p.pre_j, Linv, rhs, scal);

@@ -45,6 +45,9 @@ struct obvi_ba_handle {
   int device = 0;
   int reproj_variant = OBVI_REPROJECTION_AUTODIFF;   // obvi_ba_options.reprojection_variant
   bool deterministic = false;                        // obvi_ba_options.deterministic
+  bool fused_potrf = true;                           // k_update_potrf (updates of level l + potrf of level l + 1 in one grid); switched off for the rest of the handle's life
+                                                     // after a potrf workgroup timed out waiting for its jobs (HIP does not promise dispatch order): two launches per level then
+  int potrf_wait_timeouts = 0;
   hipStream_t stream = nullptr;
   obvi::StagingArena staging;   // pinned; the uploads of an API call are copied through it (host_util.h)
   std::string err;
@@ -236,7 +239,11 @@ void wait_scalars(obvi_ba_handle* h) {
   for (;;) {
     for (int spin = 0; spin < 4096; ++spin) {
       if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
     }
     const hipError_t q = hipStreamQuery(h->stream);
     if (q == hipSuccess) { if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; } sync(h); if (*seq != h->scal_seq) throw HipError{hipErrorUnknown, "the step's scalar block never arrived", __FILE__, __LINE__}; return; }
@@ -296,7 +303,7 @@ PointDev point_dev(const obvi_ba_handle* h) {
 }
 CholPlan chol_plan(const obvi_ba_handle* h) {
   CholPlan c;
-  c.nt = h->nt; c.nlevels = h->nlevels; c.deterministic = h->deterministic ? 1 : 0;
+  c.nt = h->nt; c.nlevels = h->nlevels; c.deterministic = h->deterministic ? 1 : 0; c.fused_potrf = h->fused_potrf ? 1 : 0;
   c.lvl_k_ptr = h->h_lvl_k_ptr.data(); c.lvl_k = h->d_lvl_k.get();
   c.trsm_ptr = h->h_trsm_ptr.data(); c.trsm_ik = h->d_trsm_ik.get();
   c.upd_ptr = h->h_upd_ptr.data(); c.upd_ij = h->d_upd_ij.get(); c.upd_kptr = h->d_upd_kptr.get(); c.upd_k = h->d_upd_k.get();
@@ -1350,7 +1357,14 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // (not when the caller goes on to use the factor that is in the tiles: covariance extraction)
   if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
   if (poll) wait_scalars(h); else sync(h);
-  if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) throw HipError{hipErrorLaunchTimeOut, "tile Cholesky: a potrf workgroup timed out waiting for the previous level's update jobs (set OBVI_FUSED_POTRF=0 for the two-launch schedule)", __FILE__, __LINE__};
+  if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) {
+    // a scheduling event, not a numerical one: nothing the step wrote is kept (the current point is untouched, the accumulators were
+    // cleared behind it), so the same step is submitted again on the schedule that cannot wait -- and the handle stays on it
+    if (!h->fused_potrf) throw HipError{hipErrorLaunchTimeOut, "tile Cholesky: wait time-out on the two-launch schedule", __FILE__, __LINE__};
+    h->fused_potrf = false; h->potrf_wait_timeouts++;
+    submit_step(h, radius, first_iter, solve, keep_factor);
+    return;
+  }
   for (int p = 0; p < PH_COUNT && h->profiling >= 1; ++p) {   // phase timings are opt-in: a dozen event queries per LM iteration are not free
     float ms = 0.f;
     if (h->phase_on_side[p]) { OBVI_HIP(hipEventElapsedTime(&ms, h->ev[p], h->ev_end[p])); }
@@ -1443,11 +1457,14 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   if (!h) return OBVI_ERR_HIP;
   h->device = dev;
   if (options) { h->reproj_variant = options->reprojection_variant; h->deterministic = options->deterministic != 0; }
+  if (const char* env = std::getenv("OBVI_FUSED_POTRF")) h->fused_potrf = std::atoi(env) != 0;   // 0: two launches per level from the start (CI parity run)
   if (const char* env = std::getenv("OBVI_DETERMINISTIC")) { if (std::atoi(env) != 0) h->deterministic = true; }   // every handle of the process (a session driven through a host that does not set the option)
   try {
     OBVI_HIP(hipSetDevice(dev));
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocDefault));
+    // coherent (fine-grained): the host polls this page while the step is still running (wait_scalars); with a non-coherent mapping it
+    // would see the device's write only at the end of the stream
+    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocCoherent));
     std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
     h->staging.cap = kStagingBytes;

@@ -37,16 +37,23 @@ __global__ void __launch_bounds__(256) k_peak_read(const double2* __restrict__ b
   if (s == 1.2345e300) out[0] = s;
 }
 
+// the accumulator tied in place in VGPRs (asm): the builtin form lets the compiler park the accumulators in AGPRs and copy all of them
+// back and forth around every trip of the loop, which measures the copies
+__device__ __forceinline__ void mfma_acc(f64x4& acc, double a, double b) {
+  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 constexpr int kIssueAcc = 8;
 __global__ void __launch_bounds__(256) k_peak_mfma_issue(double* out, int iters, double a0, double b0) {
   f64x4 acc[kIssueAcc];
 #pragma unroll
   for (int i = 0; i < kIssueAcc; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
   const double a = a0 + 1e-9 * (threadIdx.x & 63), b = b0 - 1e-9 * (threadIdx.x & 63);
+  asm volatile("s_nop 4" ::: "memory");
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < kIssueAcc; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < kIssueAcc; ++i) mfma_acc(acc[i], a, b);
   }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA result -> VALU read
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < kIssueAcc; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];

@@ -19,6 +19,7 @@
 #define OBVI_HOST_CHECKPOINT_IO_H_
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,8 +64,11 @@ class Parser {
   [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string(what) + " at byte " + std::to_string(p_)); }
   void skip() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\n' || s_[p_] == '\t' || s_[p_] == '\r')) ++p_; }
   bool lit(const char* w) { const size_t n = std::strlen(w); if (s_.compare(p_, n, w) == 0) { p_ += n; return true; } return false; }
+  struct Depth { int& d; explicit Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } };
   Value value() {
     if (p_ >= s_.size()) fail("unexpected end");
+    const Depth depth(depth_);
+    if (depth_ > kMaxDepth) fail("nesting deeper than 64 levels");   // a pose-graph state nests 8 deep; a hostile file must not exhaust the stack
     const char c = s_[p_];
     Value v;
     if (c == '{') {
@@ -105,11 +109,15 @@ class Parser {
     if (lit(".Inf") || lit("+.Inf") || lit(".inf")) { v.number = std::numeric_limits<double>::infinity(); return v; }
     if (lit("-.Inf") || lit("-.inf")) { v.number = -std::numeric_limits<double>::infinity(); return v; }
     if (lit(".Nan") || lit(".NaN") || lit(".nan")) { v.number = std::numeric_limits<double>::quiet_NaN(); return v; }
-    const char* b = s_.c_str() + p_;
-    char* e = nullptr;
-    v.number = std::strtod(b, &e);   // accepts "1.", ".5", exponents
-    if (e == b) fail("value expected");
-    p_ += (size_t)(e - b);
+    // std::from_chars: locale-independent (std::strtod follows the process locale: a comma-decimal locale would stop at the '.');
+    // accepts "1.", ".5", exponents
+    size_t e = p_;
+    while (e < s_.size() && (std::isdigit((unsigned char)s_[e]) || s_[e] == '+' || s_[e] == '-' || s_[e] == '.' || s_[e] == 'e' || s_[e] == 'E')) ++e;
+    if (e == p_) fail("value expected");
+    const char* first = s_.data() + p_ + (s_[p_] == '+' ? 1 : 0);
+    const std::from_chars_result r = std::from_chars(first, s_.data() + e, v.number);
+    if (r.ec != std::errc() || r.ptr != s_.data() + e) fail("malformed number");
+    p_ = e;
     return v;
   }
   std::string str() {
@@ -122,11 +130,28 @@ class Parser {
         const char e = s_[p_++];
         switch (e) {
           case 'n': c = '\n'; break; case 't': c = '\t'; break; case 'r': c = '\r'; break; case 'b': c = '\b'; break; case 'f': c = '\f'; break;
-          case 'u': {   // \uXXXX: labels and class names are ASCII; anything else is kept as '?'
-            if (p_ + 4 > s_.size()) fail("bad \\u escape");
-            const unsigned code = (unsigned)std::strtoul(s_.substr(p_, 4).c_str(), nullptr, 16);
-            p_ += 4; c = code < 128 ? (char)code : '?';
-            break;
+          case 'u': {   // \uXXXX -> UTF-8 (surrogate pairs joined)
+            auto hex4 = [&]() -> unsigned {
+              if (p_ + 4 > s_.size()) fail("bad \\u escape");
+              unsigned code = 0;
+              for (int k = 0; k < 4; ++k) {
+                const char h = s_[p_++];
+                code = code * 16 + (h >= '0' && h <= '9' ? (unsigned)(h - '0') : h >= 'a' && h <= 'f' ? (unsigned)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (unsigned)(h - 'A' + 10) : (fail("bad \\u escape"), 0u));
+              }
+              return code;
+            };
+            unsigned code = hex4();
+            if (code >= 0xD800 && code < 0xDC00 && p_ + 6 <= s_.size() && s_[p_] == '\\' && s_[p_ + 1] == 'u') {
+              p_ += 2;
+              const unsigned lo = hex4();
+              if (lo < 0xDC00 || lo > 0xDFFF) fail("bad surrogate pair");
+              code = 0x10000 + ((code - 0xD800) << 10) + (lo - 0xDC00);
+            }
+            if (code < 0x80) out.push_back((char)code);
+            else if (code < 0x800) { out.push_back((char)(0xC0 | (code >> 6))); out.push_back((char)(0x80 | (code & 0x3F))); }
+            else if (code < 0x10000) { out.push_back((char)(0xE0 | (code >> 12))); out.push_back((char)(0x80 | ((code >> 6) & 0x3F))); out.push_back((char)(0x80 | (code & 0x3F))); }
+            else { out.push_back((char)(0xF0 | (code >> 18))); out.push_back((char)(0x80 | ((code >> 12) & 0x3F))); out.push_back((char)(0x80 | ((code >> 6) & 0x3F))); out.push_back((char)(0x80 | (code & 0x3F))); }
+            continue;
           }
           default: c = e;
         }
@@ -137,8 +162,10 @@ class Parser {
     ++p_;
     return out;
   }
+  static constexpr int kMaxDepth = 64;
   const std::string& s_;
   size_t p_ = 0;
+  int depth_ = 0;
 };
 
 }  // namespace json
@@ -156,9 +183,23 @@ inline const Value& member(const Value& v, const char* key) {
   if (!m) throw ReadError(std::string("missing member ") + key);
   return *m;
 }
-inline uint64_t read_id(const Value& v) {   // SerializableUint64: a decimal string (a bare number is accepted too)
-  if (v.kind == Value::String) return std::strtoull(v.string.c_str(), nullptr, 10);
-  if (v.kind == Value::Number) return (uint64_t)v.number;
+inline uint64_t read_id(const Value& v) {   // SerializableUint64: a decimal string (a bare number is accepted too, while a double holds it exactly)
+  if (v.kind == Value::String) {
+    const std::string& t = v.string;
+    if (t.empty() || t.size() > 20) throw ReadError("id: a decimal string of 1 to 20 digits expected, got \"" + t + "\"");
+    uint64_t id = 0;
+    for (char c : t) {
+      if (c < '0' || c > '9') throw ReadError("id: not a decimal number: \"" + t + "\"");
+      const uint64_t d = (uint64_t)(c - '0');
+      if (id > (std::numeric_limits<uint64_t>::max() - d) / 10) throw ReadError("id: exceeds 64 bits: \"" + t + "\"");
+      id = id * 10 + d;
+    }
+    return id;
+  }
+  if (v.kind == Value::Number) {
+    if (!(v.number >= 0.0) || v.number > 9007199254740992.0 || v.number != std::floor(v.number)) throw ReadError("id: a bare number must be a non-negative integer below 2^53");
+    return (uint64_t)v.number;
+  }
   throw ReadError("id expected");
 }
 inline double read_num(const Value& v) { if (v.kind != Value::Number) throw ReadError("number expected"); return v.number; }
@@ -198,7 +239,7 @@ inline FactorInfoSet read_factor_info_set(const Value& v) {
 // ---- writer -----------------------------------------------------------------------------------------
 struct Writer {
   std::ostringstream os;
-  Writer() { os.precision(17); }
+  Writer() { os.imbue(std::locale::classic()); os.precision(17); }   // '.' as the decimal point whatever the process locale
   void num(double v) {
     if (std::isnan(v)) os << ".Nan"; else if (std::isinf(v)) os << (v > 0 ? ".Inf" : "-.Inf");
     else { os << v; }

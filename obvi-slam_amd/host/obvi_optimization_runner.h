@@ -63,7 +63,7 @@ struct FullOVSLAMConfig {
 
 // What runFullOptimization hands back (LongTermObjectMapAndResults, output_problem_data.h:11-40, reduced to the path's outputs)
 struct LongTermObjectMapAndResults {
-  std::vector<OfflineProblemRunner::LongTermMapEntry> long_term_map_;          // ellipsoid means + 7x7 marginal covariances
+  std::vector<LongTermMapEntry> long_term_map_;          // ellipsoid means + 7x7 marginal covariances
   std::unordered_map<FrameId, RawPose3d> robot_pose_results_;
   std::unordered_map<ObjectId, RawEllipsoid> ellipsoid_results_;
   std::unordered_map<FeatureId, Position3d> visual_feature_results_;
@@ -89,7 +89,19 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
     if (max_frame_to_opt % config.sliding_window_params_.global_ba_frequency_ == 0) return config.global_ba_iteration_params_;
     return config.local_ba_iteration_params_;
   };
-  OfflineProblemRunner runner(config.object_visual_pose_graph_residual_params_, config.pgo_solver_params_, window_provider_func, gba_checker, solver_params_provider_func, device_id);
+  // the output extractor (optimization_runner.h:217-260): estimates of the final pose graph; the long-term map the runner extracted from the
+  // final problem rides along (the reference's extractor calls its long-term-map extractor here)
+  using Runner = OfflineProblemRunner<LongTermObjectMapAndResults>;
+  Runner* runner_ptr = nullptr;
+  Runner::OutputDataExtractor output_data_extractor = [&runner_ptr](const OfflineProblemData&, const MainPgPtr& pose_graph, const pose_graph_optimizer::OptimizationFactorsEnabledParams&,
+                                                                     LongTermObjectMapAndResults& output_problem_data) {
+    pose_graph->getRobotPoseEstimates(output_problem_data.robot_pose_results_);
+    pose_graph->getObjectEstimates(output_problem_data.ellipsoid_results_);
+    pose_graph->getVisualFeatureEstimates(output_problem_data.visual_feature_results_);
+    if (runner_ptr) { output_problem_data.long_term_map_ = runner_ptr->longTermMap(); output_problem_data.covariance_rank_repairs_ = runner_ptr->covarianceRankRepairs(); }
+  };
+  Runner runner(config.object_visual_pose_graph_residual_params_, config.pgo_solver_params_, window_provider_func, output_data_extractor, gba_checker, solver_params_provider_func, device_id);
+  runner_ptr = &runner;
   if (pose_graph_creator) runner.setPoseGraphCreator(pose_graph_creator);
   // :545-640 the post-session merger: decide by centre proximity, merge in the pose graph (the front end's own bookkeeping of the
   // merged objects is association state and not part of this path)
@@ -102,17 +114,12 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
   if (visual_feature_adder) runner.setVisualFeatureAdder(visual_feature_adder);   // the visual front end decides what enters the graph (obvi_visual_feature_front_end.h)
   runner.setExtractLongTermMap(extract_long_term_map);
   runner.setLongTermMapTunableParams(config.ltm_tunable_params_);
-  MainPgPtr pose_graph;
-  const bool ok = runner.runOptimization(problem_data, config.optimization_factors_enabled_params_, opt_logger, pose_graph, start_at_frame, add_data_for_starting_frame);
+  const bool ok = runner.runOptimization(problem_data, config.optimization_factors_enabled_params_, opt_logger, output_results, start_at_frame, add_data_for_starting_frame);
   if (std::getenv("OBVI_HOST_TIMING")) runner.printTiming(std::cerr);
   output_results.records_ = runner.records();
   output_results.post_session_merge_rounds_ = runner.mergeRounds();
+  const MainPgPtr pose_graph = runner.poseGraph();
   if (!ok || !pose_graph) return false;
-  pose_graph->getRobotPoseEstimates(output_results.robot_pose_results_);
-  pose_graph->getObjectEstimates(output_results.ellipsoid_results_);
-  pose_graph->getVisualFeatureEstimates(output_results.visual_feature_results_);
-  output_results.long_term_map_ = runner.longTermMap();
-  output_results.covariance_rank_repairs_ = runner.covarianceRankRepairs();
   if (!output_checkpoints_dir.empty()) {   // :499-507 the final state as a checkpoint (kLtmCheckpointOutputFileBaseName + .json): what run_opt_from_pg_state / ltm_extraction_only replay
     const std::string dir = output_checkpoints_dir.back() == '/' ? output_checkpoints_dir : output_checkpoints_dir + "/";
     if (!outputPoseGraphToFile(pose_graph, dir + "long_term_map_checkpoint.json")) std::cerr << "could not write the final checkpoint to " << dir << std::endl;

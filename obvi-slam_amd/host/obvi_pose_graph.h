@@ -300,7 +300,9 @@ class ObjectAndReprojectionFeaturePoseGraph {
     L.camera_extrinsics_by_camera_ = camera_extrinsics_by_camera_; L.camera_intrinsics_by_camera_ = camera_intrinsics_by_camera_;
     L.visual_factor_type_ = kReprojectionErrorFactorTypeId;
     L.min_frame_id_ = min_frame_id_; L.max_frame_id_ = max_frame_id_;
-    L.max_feature_factor_id_ = next_visual_factor_id_; L.max_pose_factor_id_ = next_pose_factor_id_;
+    // The reference stores the LAST id it issued and hands out max + 1 next (low_level_feature_pose_graph.h:452-453, 485-486, 604-605);
+    // the counters here hold the NEXT id, so the state gets next - 1 (0 while nothing was issued, the reference's initial value :258-259)
+    L.max_feature_factor_id_ = next_visual_factor_id_ ? next_visual_factor_id_ - 1 : 0; L.max_pose_factor_id_ = next_pose_factor_id_ ? next_pose_factor_id_ - 1 : 0;
     for (const auto& p : robot_poses_) L.robot_poses_[p.first] = *p.second;
     for (const auto& f : pose_factors_by_frame_) for (FeatureFactorId id : f.second) L.pose_factors_by_frame_[f.first].insert({kPairwiseRobotPoseFactorTypeId, id});
     for (const auto& f : visual_factors_by_frame_) for (FeatureFactorId id : f.second) L.visual_feature_factors_by_frame_[f.first].push_back({kReprojectionErrorFactorTypeId, id});
@@ -314,12 +316,18 @@ class ObjectAndReprojectionFeaturePoseGraph {
       R.min_feature_id_ = first ? p.first : std::min(R.min_feature_id_, p.first); R.max_feature_id_ = first ? p.first : std::max(R.max_feature_id_, p.first); first = false;
     }
     O.mean_and_cov_by_semantic_class_ = mean_and_cov_by_semantic_class_;
-    O.min_object_id_ = 0; O.max_object_id_ = next_object_id_;
+    // object ids: smallest / largest id in the graph (object_pose_graph.h:831-838), never below the last id issued (:356-357)
+    O.min_object_id_ = 0; O.max_object_id_ = next_object_id_ ? next_object_id_ - 1 : 0;
+    { bool any = false; for (const auto& p : ellipsoid_estimates_) { O.min_object_id_ = any ? std::min(O.min_object_id_, p.first) : p.first; O.max_object_id_ = std::max(O.max_object_id_, p.first); any = true; } }
     for (const auto& p : ellipsoid_estimates_) O.ellipsoid_estimates_[p.first] = *p.second;
     O.semantic_class_for_object_ = semantic_class_for_object_;
     O.long_term_map_object_ids_ = long_term_map_object_ids_;
     O.object_observation_factors_ = object_observation_factors_; O.shape_dim_prior_factors_ = shape_dim_prior_factors_;
-    O.min_object_observation_factor_ = 0; O.max_object_observation_factor_ = next_obj_factor_id_; O.min_obj_specific_factor_ = 0; O.max_obj_specific_factor_ = next_obj_factor_id_;
+    // the reference numbers observation factors and object-specific (shape prior) factors in two sequences (object_pose_graph.h:391-392, 419-420);
+    // here they share one counter, so each kind reports the ids it actually holds: resuming either way cannot reuse an id
+    O.min_object_observation_factor_ = O.max_object_observation_factor_ = O.min_obj_specific_factor_ = O.max_obj_specific_factor_ = 0;
+    { bool any = false; for (const auto& f : object_observation_factors_) { O.min_object_observation_factor_ = any ? std::min(O.min_object_observation_factor_, f.first) : f.first; O.max_object_observation_factor_ = std::max(O.max_object_observation_factor_, f.first); any = true; } }
+    { bool any = false; for (const auto& f : shape_dim_prior_factors_) { O.min_obj_specific_factor_ = any ? std::min(O.min_obj_specific_factor_, f.first) : f.first; O.max_obj_specific_factor_ = std::max(O.max_obj_specific_factor_, f.first); any = true; } }
     for (const auto& f : object_observation_factors_) {
       auto lo = O.first_observed_frame_by_object_.find(f.second.object_id_);
       if (lo == O.first_observed_frame_by_object_.end() || f.second.frame_id_ < lo->second) O.first_observed_frame_by_object_[f.second.object_id_] = f.second.frame_id_;
@@ -347,7 +355,9 @@ class ObjectAndReprojectionFeaturePoseGraph {
     pg->first_observed_frame_by_feature_ = L.first_observed_frame_by_feature_;
     pg->pose_factors_ = L.pose_factors_;
     for (const auto& f : L.pose_factors_by_frame_) { auto& v = pg->pose_factors_by_frame_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
-    FeatureFactorId next_v = L.max_feature_factor_id_, next_p = L.max_pose_factor_id_;
+    // max_* is the last id issued (the reference continues with max + 1); an empty graph with max 0 has issued nothing yet
+    FeatureFactorId next_v = (L.factors_.empty() && L.max_feature_factor_id_ == 0) ? 0 : L.max_feature_factor_id_ + 1;
+    FeatureFactorId next_p = (L.pose_factors_.empty() && L.max_pose_factor_id_ == 0) ? 0 : L.max_pose_factor_id_ + 1;
     for (const auto& f : L.factors_) next_v = std::max(next_v, f.first + 1);
     for (const auto& f : L.pose_factors_) next_p = std::max(next_p, f.first + 1);
     pg->next_visual_factor_id_ = next_v; pg->next_pose_factor_id_ = next_p;
@@ -359,10 +369,11 @@ class ObjectAndReprojectionFeaturePoseGraph {
     for (const auto& f : O.shape_dim_prior_factors_) pg->shape_dim_factor_for_object_[f.second.object_id_] = f.first;
     for (const auto& f : O.observation_factors_by_frame_) { auto& v = pg->observation_factors_by_frame_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
     for (const auto& f : O.observation_factors_by_object_) { auto& v = pg->observation_factors_by_object_[f.first]; for (const FactorInfo& fi : f.second) v.push_back(fi.second); std::sort(v.begin(), v.end()); }
-    ObjectId next_o = O.max_object_id_;
+    ObjectId next_o = (O.ellipsoid_estimates_.empty() && O.max_object_id_ == 0) ? 0 : O.max_object_id_ + 1;
     for (const auto& p : O.ellipsoid_estimates_) next_o = std::max(next_o, p.first + 1);
     pg->next_object_id_ = next_o;
-    FeatureFactorId next_f = std::max(O.max_object_observation_factor_, O.max_obj_specific_factor_);
+    FeatureFactorId next_f = (O.object_observation_factors_.empty() && O.shape_dim_prior_factors_.empty() && O.max_object_observation_factor_ == 0 && O.max_obj_specific_factor_ == 0)
+                                 ? 0 : std::max(O.max_object_observation_factor_, O.max_obj_specific_factor_) + 1;
     for (const auto& f : O.object_observation_factors_) next_f = std::max(next_f, f.first + 1);
     for (const auto& f : O.shape_dim_prior_factors_) next_f = std::max(next_f, f.first + 1);
     pg->next_obj_factor_id_ = next_f;

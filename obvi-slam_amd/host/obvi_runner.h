@@ -117,21 +117,32 @@ struct OptimizationRecord {   // one row per solve, for tests / logging
   FrameId min_frame, max_frame; std::string kind; int iterations; double initial_cost, final_cost; size_t n_poses, n_features, n_objects, n_excluded;
 };
 
+// an object of the long-term map as the extraction hands it over: estimate + its 7x7 marginal covariance
+struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
+
+// OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType>
+// (offline_problem_runner.h:23-98) with the input, factor, cache and pose-graph types this path has fixed; the output type and its
+// extractor stay the caller's, as in the reference (:63-67, :100-107, :269-273).
+template <typename OutputProblemData>
 class OfflineProblemRunner {
  public:
+  using LongTermMapEntry = vslam_types_refactor::LongTermMapEntry;
+  using OutputDataExtractor = std::function<void(const OfflineProblemData&, const MainPgPtr&, const pose_graph_optimizer::OptimizationFactorsEnabledParams&, OutputProblemData&)>;
   OfflineProblemRunner(const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
                        const pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams& pgo_solver_params,
                        const std::function<FrameId(const FrameId&)>& window_provider_func,
+                       const OutputDataExtractor& output_data_extractor,
                        const std::function<bool(const FrameId&)>& gba_checker,
                        const std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)>& iteration_params_provider_func,
                        int device_id = 0)
-      : residual_params_(residual_params), pgo_solver_params_(pgo_solver_params), window_provider_func_(window_provider_func), gba_checker_(gba_checker),
-        iteration_params_provider_func_(iteration_params_provider_func), device_id_(device_id) {}
+      : residual_params_(residual_params), pgo_solver_params_(pgo_solver_params), window_provider_func_(window_provider_func), output_data_extractor_(output_data_extractor),
+        gba_checker_(gba_checker), iteration_params_provider_func_(iteration_params_provider_func), device_id_(device_id) {}
 
   // offline_problem_runner.h:100-274
   bool runOptimization(const OfflineProblemData& problem_data, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
-                       std::optional<OptimizationLogger>& opt_logger, MainPgPtr& pose_graph_out, const FrameId& start_at_frame = 0,
+                       std::optional<OptimizationLogger>& opt_logger, OutputProblemData& output_problem_data, const FrameId& start_at_frame = 0,
                        const bool& add_data_for_starting_frame = true) {
+    pose_graph_.reset();
     if (opt_logger.has_value()) opt_logger->writeOptInfoHeader();
     obvi::Problem problem(device_id_);
     pose_graph_optimizer::OptimizationScopeParams scope;                                                                     // :115-142
@@ -181,9 +192,12 @@ class OfflineProblemRunner {
         long_term_map_.push_back(e);
       }
     }
-    pose_graph_out = pose_graph;
+    pose_graph_ = pose_graph;
+    if (output_data_extractor_) output_data_extractor_(problem_data, pose_graph, enabled, output_problem_data);   // :269-272
     return true;
   }
+  // the session's pose graph after runOptimization (what the extractor was given): checkpoint writers
+  const MainPgPtr& poseGraph() const { return pose_graph_; }
   // :918-958 until there are no more objects to merge, merge and re-run the final optimisation (attempt numbers 2, 3, ...)
   bool mergeObjectsAtSessionEnd(const FrameId& max_frame_id, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
                                 const pose_graph_optimizer::OptimizationScopeParams& scope, std::optional<OptimizationLogger>& opt_logger, MainPgPtr& pose_graph,
@@ -215,7 +229,6 @@ class OfflineProblemRunner {
                            << check_.size_mismatches << " max_initial_cost_rel " << check_.max_initial_cost_rel << " max_final_cost_rel " << check_.max_final_cost_rel << " max_value_diff "
                            << check_.max_value_diff << " points " << check_.points << " points_apart " << check_.points_apart << " objects " << check_.objects << " objects_apart " << check_.objects_apart << std::endl;
   }
-  struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
   void setVisualFeatureAdder(const VisualFeatureAdder& adder) { visual_feature_adder_ = adder; }
   void setExtractLongTermMap(bool on) { extract_long_term_map_ = on; }
   void setLongTermMapTunableParams(const LongTermMapExtractionTunableParams& p) { ltm_tunable_params_ = p; }
@@ -449,6 +462,8 @@ class OfflineProblemRunner {
   pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
   pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams pgo_solver_params_;
   std::function<FrameId(const FrameId&)> window_provider_func_;
+  OutputDataExtractor output_data_extractor_;
+  MainPgPtr pose_graph_;
   std::function<bool(const FrameId&)> gba_checker_;
   std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)> iteration_params_provider_func_;
   int device_id_;

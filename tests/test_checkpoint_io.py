@@ -120,6 +120,39 @@ def test_malformed_checkpoints_are_refused(driver, tmp_path):
     assert p.returncode == 1 and "does not exist" in p.stderr
 
 
+def test_reader_is_strict_about_ids_depth_numbers_and_escapes(driver, tmp_path):
+    """Ids must be whole decimal strings that fit 64 bits (not "12abc", "", "-1": strtoull would have read 12, 0, 2^64-1), a bare number only
+    while a double holds it exactly; nesting is capped (a hostile file must not exhaust the stack); numbers parse the same in a comma-decimal
+    locale; \\u escapes become UTF-8 (semantic class names)."""
+    src = os.path.join(GOLDEN, "pose_graph_state_reference_roundtrip.json")
+    text = open(src).read()
+    bad, out = tmp_path / "bad.json", str(tmp_path / "o.json")
+    key = '"max_frame_id":"500"'
+    assert key in text
+    for repl in ('"500abc"', '""', '"-1"', '"18446744073709551616"', '1e300', '12.5', '-3'):
+        bad.write_text(text.replace(key, '"max_frame_id":' + repl, 1))
+        p = subprocess.run([driver, "--checkpoint-roundtrip", str(bad), out], capture_output=True, text=True)
+        assert p.returncode == 1 and "Could not read pose graph state" in p.stderr, repl
+    for repl in ('"18446744073709551615"', '4096'):                       # the largest id; a small bare number
+        bad.write_text(text.replace(key, '"max_frame_id":' + repl, 1))
+        assert subprocess.run([driver, "--checkpoint-roundtrip", str(bad), out]).returncode == 0, repl
+        assert ('"max_frame_id": "%s"' % repl.strip('"')) in open(out).read()
+    bad.write_text("[" * 100000 + "]" * 100000)                           # 100 000 levels deep: an error, not a crash
+    p = subprocess.run([driver, "--checkpoint-roundtrip", str(bad), out], capture_output=True, text=True)
+    assert p.returncode == 1 and "nesting" in p.stderr
+    # the same file under a comma-decimal locale (if the box has one) reads and writes the same numbers
+    env = dict(os.environ, LC_ALL="de_DE.UTF-8", LANG="de_DE.UTF-8")
+    a, b = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    subprocess.check_call([driver, "--checkpoint-roundtrip", src, a])
+    subprocess.check_call([driver, "--checkpoint-roundtrip", src, b], env=env)
+    assert open(a).read() == open(b).read()
+    # a class name with non-ASCII characters written as \\u escapes comes back as UTF-8
+    assert '"chair"' in text
+    bad.write_text(text.replace('"chair"', '"caf\\u00e9 \\ud83d\\ude00"'))
+    assert subprocess.run([driver, "--checkpoint-roundtrip", str(bad), out]).returncode == 0
+    assert "caf\u00e9 \U0001F600" in open(out, encoding="utf-8").read()
+
+
 @pytest.mark.gpu
 def test_checkpoint_replay_the_run_opt_from_pg_state_way(driver, tmp_path):
     """A session writes its final state as long_term_map_checkpoint.json (optimization_runner.h:499-507); the checkpoint is then
