@@ -1275,6 +1275,16 @@ int oracle_ba_update_points(oracle_handle* h, int64_t n, const double* xyz) {
   h->pb.points.assign(xyz, xyz + 3 * n); return OBVI_OK;
 }
 
+// values only, constness untouched (tests/lockstep_shim.cpp hands the oracle the other backend's result after a solve)
+int oracle_ba_update_poses(oracle_handle* h, int64_t n, const double* v) {
+  if (n != h->pb.P) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.poses.assign(v, v + 6 * n); return OBVI_OK;
+}
+int oracle_ba_update_objects(oracle_handle* h, int64_t n, const double* v) {
+  if (n != h->pb.O) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.objects.assign(v, v + 7 * n); return OBVI_OK;
+}
+
 // ---- factor-level entry points for golden-vector tests ---------------------------------
 void oracle_reproj(const double* pose6, const double* point3, const double* K4, const double* ext7, const double* pixel2,
                    double sigma, double* r2, double* Jpose, double* Jpoint) {
