@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="default: 3 on one GPU, 4 (windows sharing objects, RCCL all-reduce) on several")
     ap.add_argument("--hook", choices=("rccl", "torch"), default="rccl", help="all-reduce callback of config 4: libobvi_rccl.so (compiled) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the deterministic-mode timing of the same steps")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end two-phase global BA (config 3, one GPU; about 2 s)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -453,7 +454,7 @@ def main():
         if scaling_baseline is not None:
             out["scaling_baseline"] = scaling_baseline
             out["weak_scaling_efficiency"] = round(out["value"] / (world * scaling_baseline["value_one_gpu"]), 4)
-        if world == 1:
+        if world == 1 and not args.no_deterministic_leg:
             # the same steps in deterministic mode (obvi_ba_options.deterministic: fixed-order sums, one stream; for parity runs)
             bd = obvi_ba.BundleAdjuster(device_id=local_rank, deterministic=True)
             synth.upload(bd, prob)

@@ -974,12 +974,20 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
   const bool with_rhs = cbase + kSGC == kSTC;   // the group holding the chunk's own frames sees every visit of the chunk once
   if (tid < kSFr) { const int32_t f = fbase + tid; rown[tid] = (f >= 0 && f < b.nPv) ? row_of_nat[f] : -1; }
   if (tid < 2) zero2[tid] = 0.0;
-  // per-lane operand coordinates: frame offset in the strip and byte offset in the record, of row tile r / column tile cbase + c
-  uint32_t foA[kSTR], offA[kSTR], foB[kSGC], offB[kSGC];
+  // per-lane operand addresses: an operand of row tile r / column tile cbase + c sits at (byte offset of strip frame 0 in the batch image:
+  // visit-uniform, from the record) + 144 (frame offset of the lane's matrix row) + (offset in the record) -- the host lays a visit out so
+  // that every frame an active tile touches has a slot (zeros where the point has no observation), hence no range test.  Lanes kq = 3 pad
+  // K = 3 to the instruction's 4: multiplier 0 and the address of a zero.  One v_mad per operand; constants per batch buffer.
+  const uint32_t kmul = kq < 3 ? 1u : 0u;
+  uint32_t cA[2][kSTR], cB[2][kSGC];
 #pragma unroll
-  for (int r = 0; r < kSTR; ++r) { const int row = 16 * (kSDiag + r) + m; foA[r] = row / 6; offA[r] = 8 * ((row % 6) * 3 + kq); }
+  for (int bf = 0; bf < 2; ++bf) {
+    const uint32_t img = lds_address(bf ? &zbuf1[0] : &zbuf0[0]), zr = lds_address(&zero2[0]);
 #pragma unroll
-  for (int c = 0; c < kSGC; ++c) { const int col = 16 * (cbase + c) + m; foB[c] = col / 6; offB[c] = 8 * ((col % 6) * 3 + kq); }
+    for (int r = 0; r < kSTR; ++r) { const int row = 16 * (kSDiag + r) + m; cA[bf][r] = kq < 3 ? img + 144u * (uint32_t)(row / 6) + 8u * (uint32_t)((row % 6) * 3 + kq) : zr; }
+#pragma unroll
+    for (int c = 0; c < kSGC; ++c) { const int col = 16 * (cbase + c) + m; cB[bf][c] = kq < 3 ? img + 144u * (uint32_t)(col / 6) + 8u * (uint32_t)((col % 6) * 3 + kq) : zr; }
+  }
   sf64x4 acc[kSGC][kSTR];
 #pragma unroll
   for (int c = 0; c < kSGC; ++c)
@@ -1014,33 +1022,31 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
         if (c0 + lane < nv) gather16_to_lds(visits + vb + c0 + lane, lds_address(rb_) + 16u * c0);
   };
 
-  // ---- one visit.  Record: x = slot | first frame offset << 16 | frames << 22 | twin << 28 of the row frames, y = the same of the
-  //      group's column frames, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r
-  schur_lds8* zero_l = (schur_lds8*)(&zero2[0]);
+  // ---- one visit.  Record: x = byte offset of strip frame 0 in the batch image for the row operands (int32), y = the same for the
+  //      group's column operands, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r | stereo << 15 | row tiles << 16
   // A visit in two halves -- load_ops issues every LDS read of the visit (row operands, the operands of the active column tiles,
   // (u_l, 0)), multiply does the rest -- so that a wavefront can take its visits two at a time: both records, then both sets of
   // operands, are read together and the read latency (exposed at two wavefronts per SIMD) is paid once per pair.
   struct Ops { double a[kSTR]; double b[kSGC]; double ul; uint32_t bits; };
-  auto load_ops = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t bits, auto which) -> Ops {
-    schur_lds8* zimg = decltype(which)::value ? (schur_lds8*)(&zbuf1[0]) : (schur_lds8*)(&zbuf0[0]);
-    const bool twin = TWIN && ((vx >> 28) & 1u);
-    const uint32_t layer2 = 144u * (vz >> 16);
-    auto operand = [&](uint32_t rec, uint32_t fo, uint32_t off) -> double {
-      const uint32_t d = fo - ((rec >> 16) & 63u);
-      const bool ok = kq < 3 && d < ((rec >> 22) & 63u);
-      const uint32_t at = 144u * ((rec & 0xffffu) + d) + off;
-      schur_lds8* p_ = ok ? zimg + at : zero_l;
-      double val = *reinterpret_cast<schur_ldsd*>(p_);
-      if (TWIN && twin) { schur_lds8* p2 = ok ? zimg + (at + layer2) : zero_l; val += *reinterpret_cast<schur_ldsd*>(p2); }
+  auto load_ops = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t vw, auto which) -> Ops {
+    constexpr int bf = decltype(which)::value;
+    schur_lds8* zimg = bf ? (schur_lds8*)(&zbuf1[0]) : (schur_lds8*)(&zbuf0[0]);
+    const bool twin = TWIN && ((vw >> 15) & 1u);
+    const uint32_t layer2 = 144u * (vz >> 16) * kmul;
+    auto lds_f64 = [](uint32_t addr) -> double { return *reinterpret_cast<schur_ldsd*>((schur_lds8*)(uintptr_t)addr); };
+    auto operand = [&](uint32_t base, uint32_t lane_const) -> double {
+      const uint32_t at = base * kmul + lane_const;
+      double val = lds_f64(at);
+      if (TWIN && twin) val += lds_f64(at + layer2);
       return val;
     };
     Ops o;
-    o.bits = bits;
+    o.bits = vw & 0x7fffu;
 #pragma unroll
-    for (int r = 0; r < kSTR; ++r) o.a[r] = operand(vx, foA[r], offA[r]);
+    for (int r = 0; r < kSTR; ++r) o.a[r] = ((vw >> (16 + r)) & 1u) ? operand(vx, cA[bf][r]) : 0.0;
     o.ul = with_rhs ? *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq)) : 0.0;   // (u_l, 0)
 #pragma unroll
-    for (int c = 0; c < kSGC; ++c) o.b[c] = ((bits >> (3 * c)) & 7u) ? operand(vy, foB[c], offB[c]) : 0.0;
+    for (int c = 0; c < kSGC; ++c) o.b[c] = ((vw >> (3 * c)) & 7u) ? operand(vy, cB[bf][c]) : 0.0;
     return o;
   };
   auto multiply = [&](const Ops& o) {

@@ -736,46 +736,58 @@ void prepare(obvi_ba_handle* h) {
   visits.reserve(4 * gv.size());
   constexpr uint32_t kBatchSlots = kSchurBatchBytes / 144;
   auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) {
+    // The image of a visit covers every strip frame that an ACTIVE tile of the visit touches -- row tiles that hold one of the point's
+    // row frames, column tiles of the group that hold one of its column frames -- with the zero page for the frames the point does not
+    // observe.  A lane's operand is then at (visit-uniform base) + (lane constant), no range test: k_schur_window.
     const int32_t fbase = v.chunk * SR - SBACK;
-    const int32_t gA0 = SBACK, gA1 = kSchurWindowFrames - 1;                                                     // row frames (strip offsets)
-    const int32_t gB0 = (16 * kSchurGroupCols * v.group) / 6, gB1 = (16 * kSchurGroupCols * (v.group + 1) - 1) / 6;   // column frames of the group
-    int32_t loA = INT32_MAX, hiA = -1, loB = INT32_MAX, hiB = -1;
+    constexpr int kRowTile0 = SBACK * 6 / 16;
+    uint32_t rows = 0;
+    int32_t A0 = INT32_MAX, A1 = -1, B0 = INT32_MAX, B1 = -1;
+    for (int c = 0; c < kSchurGroupCols; ++c) {
+      const uint32_t t3 = (v.bits >> (3 * c)) & 7u;
+      if (!t3) continue;
+      rows |= t3;
+      const int t = kSchurGroupCols * v.group + c;
+      B0 = std::min<int32_t>(B0, (16 * t) / 6); B1 = std::max<int32_t>(B1, (16 * t + 15) / 6);
+    }
+    for (int r = 0; r < 3; ++r)
+      if ((rows >> r) & 1u) { const int t = kRowTile0 + r; A0 = std::min<int32_t>(A0, (16 * t) / 6); A1 = std::max<int32_t>(A1, (16 * t + 15) / 6); }
+    A1 = std::min<int32_t>(A1, kSchurWindowFrames - 1); B1 = std::min<int32_t>(B1, kSchurWindowFrames - 1);
     uint32_t prim[kSchurWindowFrames], sec[kSchurWindowFrames];
     for (int i = 0; i < kSchurWindowFrames; ++i) prim[i] = sec[i] = zero16;
     for (uint32_t a = v.beg; a < v.beg + v.k; ++a) {
       if (!h->h_rp_active[a] || pose_vid[h->h_rp_pose[a]] < 0) continue;
       const int32_t fo = nat[h->h_rp_pose[a]] - fbase;
       if (fo < 0 || fo >= kSchurWindowFrames) continue;
-      if (fo >= gA0 && fo <= gA1) { loA = std::min(loA, fo); hiA = std::max(hiA, fo); }
-      if (fo >= gB0 && fo <= gB1) { loB = std::min(loB, fo); hiB = std::max(hiB, fo); }
       const uint32_t src = (uint32_t)((18ull * a + 4ull * v.l) / 2);
       if (prim[fo] == zero16) prim[fo] = src; else sec[fo] = src;
     }
     out.clear();
-    uint32_t slotA, slotB, tail;
-    const bool merged = loB <= hiA + 1 && loA <= hiB + 1;
+    int32_t slotA0, slotB0;   // slot of strip frame 0 for the row operands / the column operands (may lie before the image: only covered frames are read)
+    uint32_t tail;
+    const bool merged = B0 <= A1 + 1 && A0 <= B1 + 1;
     if (merged) {
-      const int32_t lo = std::min(loA, loB), hi = std::max(hiA, hiB);
+      const int32_t lo = std::min(A0, B0), hi = std::max(A1, B1);
       for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(prim[fo]);
-      slotA = base + (uint32_t)(loA - lo); slotB = base + (uint32_t)(loB - lo); tail = base + (uint32_t)(hi - lo + 1);
+      slotA0 = slotB0 = (int32_t)base - lo; tail = base + (uint32_t)(hi - lo + 1);
       out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));   // z_tail()
       if (v.twin) for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(sec[fo]);
     } else {
-      for (int32_t fo = loA; fo <= hiA; ++fo) out.push_back(prim[fo]);
-      slotA = base; tail = base + (uint32_t)(hiA - loA + 1); slotB = tail + 1;
+      for (int32_t fo = A0; fo <= A1; ++fo) out.push_back(prim[fo]);
+      slotA0 = (int32_t)base - A0; tail = base + (uint32_t)(A1 - A0 + 1); slotB0 = (int32_t)tail + 1 - B0;
       out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));
-      for (int32_t fo = loB; fo <= hiB; ++fo) out.push_back(prim[fo]);
+      for (int32_t fo = B0; fo <= B1; ++fo) out.push_back(prim[fo]);
       if (v.twin) {
-        for (int32_t fo = loA; fo <= hiA; ++fo) out.push_back(sec[fo]);
+        for (int32_t fo = A0; fo <= A1; ++fo) out.push_back(sec[fo]);
         out.push_back(zero16);
-        for (int32_t fo = loB; fo <= hiB; ++fo) out.push_back(sec[fo]);
+        for (int32_t fo = B0; fo <= B1; ++fo) out.push_back(sec[fo]);
       }
     }
     const uint32_t layer = v.twin ? (uint32_t)out.size() / 2 + (merged ? 1u : 0u) : 0u;   // slots from a record to its second-layer twin
-    rec[0] = slotA | ((uint32_t)loA << 16) | ((uint32_t)(hiA - loA + 1) << 22) | (v.twin ? 1u << 28 : 0u);
-    rec[1] = slotB | ((uint32_t)loB << 16) | ((uint32_t)(hiB - loB + 1) << 22);
+    rec[0] = (uint32_t)(144 * slotA0);                                  // byte offset of strip frame 0 in the batch image, row operands (int32)
+    rec[1] = (uint32_t)(144 * slotB0);                                  // ... column operands
     rec[2] = tail | (layer << 16);
-    rec[3] = v.bits;
+    rec[3] = v.bits | (v.twin ? 1u << 15 : 0u) | (rows << 16);        // tile bits 3 c + r | stereo | row tiles in use
   };
   // the workgroups (slices of the work lists) are independent: ranges of them on host threads, joined in order
   struct WgRange { size_t w, we; int32_t chunk, group; };

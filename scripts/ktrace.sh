@@ -4,7 +4,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ktr_$TAG
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktr_$TAG -o run -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_rocprof.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktr_$TAG -o run -- python $R/bench.py --no-cpu-baseline --no-deterministic-leg --no-end-to-end "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_rocprof.err
 F=$(find /tmp/ktr_$TAG -name "*kernel_trace.csv" | head -1)
 python3 - "$F" $R/gpurun_out/${TAG}_timeline.txt <<'PY'
 import csv, re, sys
