@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
   };
 
   // ---- one visit.  Record: x = byte offset of strip frame 0 in the batch image for the row operands (int32), y = the same for the
-  //      group's column operands, z = tail slot | distance to the second layer << 16, w = tile bits 3 c + r | stereo << 15 | row tiles << 16
+  //      group's column operands, z = tail slot | distance to the second layer << 16, w = column tiles of the group in use (5 bits) | stereo << 15 | row tiles in use << 16
   // A visit in two halves -- load_ops issues every LDS read of the visit (row operands, the operands of the active column tiles,
   // (u_l, 0)), multiply does the rest -- so that a wavefront can take its visits two at a time: both records, then both sets of
   // operands, are read together and the read latency (exposed at two wavefronts per SIMD) is paid once per pair.
@@ -1041,26 +1041,36 @@ __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDe
       return val;
     };
     Ops o;
-    o.bits = vw & 0x7fffu;
+    o.bits = vw;
+    // every operand is read whether its tile is active or not (a read is an add and a ds_read_b64; testing the tile bits first cost five
+    // scalar instructions per operand): an inactive tile's address may lie anywhere -- beyond the allocation LDS returns zero -- and its
+    // value is never used (multiply() touches the row / column tiles of the visit's masks only)
 #pragma unroll
-    for (int r = 0; r < kSTR; ++r) o.a[r] = ((vw >> (16 + r)) & 1u) ? operand(vx, cA[bf][r]) : 0.0;
+    for (int r = 0; r < kSTR; ++r) o.a[r] = operand(vx, cA[bf][r]);
     o.ul = with_rhs ? *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq)) : 0.0;   // (u_l, 0)
 #pragma unroll
-    for (int c = 0; c < kSGC; ++c) o.b[c] = ((vw >> (3 * c)) & 7u) ? operand(vy, cB[bf][c]) : 0.0;
+    for (int c = 0; c < kSGC; ++c) o.b[c] = operand(vy, cB[bf][c]);
     return o;
   };
+  // The active tiles of a visit are (row tiles holding one of the point's row frames) x (column tiles of the group holding one of its
+  // column frames), minus -- in the group that holds the chunk's own frames -- the tiles above the diagonal: a rectangle given by two
+  // masks (a column bit, then the row bits of the columns in use).
+  constexpr int kCut = kSDiag - (kSTC - kSGC);   // diagonal group: column tile c of the group lies at or below row tile r iff c <= r + kCut
   auto multiply = [&](const Ops& o) {
+    const uint32_t R = (o.bits >> 16) & 7u;
     if (with_rhs) {
 #pragma unroll
-      for (int r = 0; r < kSTR; ++r) racc[r] += o.a[r] * o.ul;
+      for (int r = 0; r < kSTR; ++r) if (R & (1u << r)) racc[r] += o.a[r] * o.ul;
     }
 #pragma unroll
     for (int c = 0; c < kSGC; ++c) {
-      const uint32_t t3 = (o.bits >> (3 * c)) & 7u;
-      if (t3) {
+      if ((o.bits >> c) & 1u) {
+        // rows of this column tile: the visit's row mask, minus -- chunk's own group only -- the row tiles above the diagonal
+        uint32_t Rc = R;
+        if (c > kCut) Rc = with_rhs ? (R & ~((1u << (c - kCut)) - 1u)) : R;
 #pragma unroll
         for (int r = 0; r < kSTR; ++r)
-          if (t3 & (1u << r)) mfma_f64_acc(acc[c][r], o.a[r], o.b[c]);
+          if (Rc & (1u << r)) mfma_f64_acc(acc[c][r], o.a[r], o.b[c]);
       }
     }
   };

@@ -787,7 +787,11 @@ void prepare(obvi_ba_handle* h) {
     rec[0] = (uint32_t)(144 * slotA0);                                  // byte offset of strip frame 0 in the batch image, row operands (int32)
     rec[1] = (uint32_t)(144 * slotB0);                                  // ... column operands
     rec[2] = tail | (layer << 16);
-    rec[3] = v.bits | (v.twin ? 1u << 15 : 0u) | (rows << 16);        // tile bits 3 c + r | stereo | row tiles in use
+    uint32_t cols = 0;
+    for (int c = 0; c < kSchurGroupCols; ++c) if ((v.bits >> (3 * c)) & 7u) cols |= 1u << c;
+    // the visit's tiles are (row tiles in use) x (column tiles in use), minus the tiles above the diagonal in the chunk's own group (a cut
+    // the kernel knows at compile time): two masks instead of 15 tile bits
+    rec[3] = cols | (v.twin ? 1u << 15 : 0u) | (rows << 16);
   };
   // the workgroups (slices of the work lists) are independent: ranges of them on host threads, joined in order
   struct WgRange { size_t w, we; int32_t chunk, group; };

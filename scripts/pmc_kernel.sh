@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-include-regex "$K" --output-format csv -d $R/gpurun_out/$OUT -o pass$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$OUT.pass$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex "$K" --output-format csv -d $R/gpurun_out/$OUT -o pass$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-deterministic-leg --no-end-to-end > $R/gpurun_out/$OUT.pass$i.log 2>&1
 done
 python3 - "$R/gpurun_out/$OUT" <<'PY'
 import csv, glob, sys, collections
