@@ -14,17 +14,20 @@ mkdir -p $OUT
 SHA=$(python3 $R/scripts/source_sha.py)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py > $OUT/${TAG}_bench_cfg3.json 2> $OUT/bench.err
-rm -rf /tmp/pr_trace; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_trace -o cfg3 -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_cfg3_under_rocprof.json 2> $OUT/rocprof.err
+# (the legs of the default command that are not the timed workload -- CPU baseline, deterministic-mode comparison, end-to-end two-phase run -- are
+#  switched off under the profiler, so that a kernel's average is over the launches of the timed configuration only)
+LEGS="--no-cpu-baseline --no-deterministic-leg --no-end-to-end"
+rm -rf /tmp/pr_trace; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_trace -o cfg3 -- python $R/bench.py $LEGS > $OUT/${TAG}_bench_cfg3_under_rocprof.json 2> $OUT/rocprof.err
 cp $(find /tmp/pr_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_cfg3.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pr_$C
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pr_$C -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pr_$C -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 $LEGS > /dev/null 2> $OUT/pmc_$C.err
 done
 F=$(find /tmp/pr_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/pr_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 $R/scripts/pmc_summary.py "$F" "$W" $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic_cfg3.txt
 rm -rf /tmp/pr_sq
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-  --output-format csv -d /tmp/pr_sq -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
+  --output-format csv -d /tmp/pr_sq -o cfg3 -- python $R/bench.py --steps 4 --warmup 1 $LEGS > /dev/null 2> $OUT/pmc_sq.err
 python3 - "$(find /tmp/pr_sq -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_sq_counters.json <<'PY'
 import collections, csv, json, re, sys
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -56,7 +59,15 @@ PY
 python3 - $OUT $TAG $SHA <<'PY'
 import json, os, subprocess, sys
 out, tag, sha = sys.argv[1:4]
-json.dump({"tag": tag, "kernel_source_sha": sha, "files": {"bench": tag + "_bench_cfg3.json", "kernel_stats": tag + "_kernel_stats_cfg3.csv", "pmc_traffic": tag + "_pmc_traffic.json",
+peaks = None
+try:
+    peaks = json.load(open(os.path.join(out, tag + "_bench_cfg3.json")))["roofline"]["peaks_measured"]
+    json.dump({"_method": "obvi_ba_measure_peaks in the bench run of this set (csrc/peak_kernels.hip): HBM triad / copy / read over 1 GiB arrays, fp64 MFMA issue rate "
+                          "(v_mfma_f64_16x16x4_f64, register operands, 8 accumulators per wavefront, 2 wavefronts per SIMD) and the LDS-fed 64x64x64 tile product", "peaks": peaks},
+              open(os.path.join(out, tag + "_measured_peaks.json"), "w"), indent=1)
+except (OSError, ValueError, KeyError):
+    pass
+json.dump({"tag": tag, "kernel_source_sha": sha, "files": {"bench": tag + "_bench_cfg3.json", "measured_peaks": tag + "_measured_peaks.json", "kernel_stats": tag + "_kernel_stats_cfg3.csv", "pmc_traffic": tag + "_pmc_traffic.json",
                                                               "sq_counters": tag + "_sq_counters.json"},
            "note": "measured by scripts/profile_round.sh on one MI355X; kernel_source_sha = scripts/source_sha.py over obvi-slam_amd/csrc at measurement time"},
           open(os.path.join(out, "manifest.json"), "w"), indent=1)
