@@ -7,11 +7,16 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace obvi {
@@ -92,6 +97,78 @@ class DevBuf {
  private:
   T* p_ = nullptr;
   size_t n_ = 0, cap_ = 0;
+};
+
+// Worker threads of the host's symbolic phase and upload sorts, started once per process: a sliding-window session builds a plan per
+// window (a millisecond of work in ranges of points), and starting and joining std::threads for every range cost as much as the
+// ranges themselves.  run(parts, fn) calls fn(0) ... fn(parts - 1), each exactly once, on the workers and on the calling thread, and
+// returns when all are done; calls from different threads (one handle per thread) are serialised.  Workers spin briefly before they
+// sleep, so that back-to-back calls do not pay a wake-up each.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int i = 0; i < workers; ++i) {
+      try { threads_.emplace_back([this] { work(); }); }
+      catch (const std::system_error&) { break; }   // fewer workers: the caller takes the rest itself
+    }
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lock(m_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  int workers() const { return (int)threads_.size(); }
+  void run(int parts, const std::function<void(int)>& fn) {
+    if (parts <= 1 || threads_.empty()) { for (int i = 0; i < parts; ++i) fn(i); return; }
+    std::lock_guard<std::mutex> serial(callers_);
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      fn_.store(&fn, std::memory_order_relaxed); parts_.store(parts, std::memory_order_relaxed);
+      next_.store(0, std::memory_order_relaxed); left_.store(parts, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    take();
+    while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    std::lock_guard<std::mutex> lock(m_);
+    fn_.store(nullptr, std::memory_order_relaxed); parts_.store(0, std::memory_order_relaxed);
+  }
+
+ private:
+  void take() {
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_acq_rel);
+      if (i >= parts_.load(std::memory_order_acquire)) return;
+      (*fn_.load(std::memory_order_acquire))(i);
+      left_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void work() {
+    uint64_t seen = 0;
+    for (;;) {
+      for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      }
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        seen = gen_.load(std::memory_order_acquire);
+        if (stop_) return;
+        if (fn_.load(std::memory_order_relaxed) == nullptr) continue;
+      }
+      take();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_, callers_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> next_{0}, left_{0};
+  std::atomic<const std::function<void(int)>*> fn_{nullptr};
+  std::atomic<int> parts_{0};
+  bool stop_ = false;
 };
 
 // out = (sym(cov))^(-1/2) for an n x n (n <= 7) symmetric positive definite matrix, row-major.

@@ -321,25 +321,23 @@ int host_threads() {
   const int n = v ? std::atoi(v) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   return std::max(1, n);
 }
+HostPool& host_pool() {
+  static HostPool pool(std::max(0, host_threads() - 1));   // process-wide; the calling thread is the last worker
+  return pool;
+}
 template <class F>
 void parallel_ranges(int64_t n, int parts, F&& fn) {
   parts = (int)std::max<int64_t>(1, std::min<int64_t>(parts, n));
   if (parts == 1) { fn(0, (int64_t)0, n); return; }
   // nothing may escape a worker (std::terminate across the C ABI): the first exception is kept and rethrown on the caller's thread
-  // after every worker has been joined; a range whose thread cannot be started runs on the caller's thread
-  std::vector<std::thread> th;
+  // after every range has run
   std::exception_ptr first_error;
   std::mutex error_mutex;
-  auto guarded = [&](int t) {
+  const std::function<void(int)> guarded = [&](int t) {
     try { fn(t, n * t / parts, n * (t + 1) / parts); }
     catch (...) { std::lock_guard<std::mutex> lock(error_mutex); if (!first_error) first_error = std::current_exception(); }
   };
-  th.reserve(parts);
-  for (int t = 0; t < parts; ++t) {
-    try { th.emplace_back(guarded, t); }
-    catch (const std::system_error&) { guarded(t); }
-  }
-  for (auto& x : th) x.join();
+  host_pool().run(parts, guarded);
   if (first_error) std::rethrow_exception(first_error);
 }
 
@@ -609,9 +607,13 @@ void prepare(obvi_ba_handle* h) {
   {
     // points are independent: ranges of points on host threads (the bitmap is shared: every writer stores the same 1), lists joined in
     // point order.  Without the bitmap the tile marks go straight into the mask: one thread.
-    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 2048)) : 1;   // a thread is worth starting for a couple of thousand points
+    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 256)) : 1;   // the workers exist (host_pool): a range of a few hundred points is worth handing out
     std::vector<std::vector<Pair>> pairs_t(parts);
     std::vector<std::vector<Visit>> visits_t(parts);
+    // small windows: every range marks its pose pairs in a bitmap of its own (a few KB), merged afterwards -- sixteen threads storing
+    // into the same forty cache lines were slower than one
+    const bool private_bitmaps = pair_bitmap && parts > 1 && (size_t)h->nPv * (size_t)h->nPv <= ((size_t)1 << 18);
+    std::vector<std::vector<uint8_t>> pose_pair_t(private_bitmaps ? parts : 0);
     std::vector<int64_t> window_pairs_t(parts, 0);
     std::vector<uint8_t> twin_t(parts, 0);
     parallel_ranges(L, parts, [&](int part, int64_t l0, int64_t l1) {
@@ -620,6 +622,8 @@ void prepare(obvi_ba_handle* h) {
       std::vector<int32_t> chunks;
       std::vector<Pair>& pairs = pairs_t[part];
       std::vector<Visit>& visit_list = visits_t[part];
+      if (private_bitmaps) pose_pair_t[part].assign((size_t)h->nPv * (size_t)h->nPv, 0);
+      uint8_t* const pose_pair_w = private_bitmaps ? pose_pair_t[part].data() : pose_pair.data();
       int64_t n_window_pairs = 0;
       bool any_twin = false;
       for (int64_t l = l0; l < l1; ++l) {
@@ -670,14 +674,14 @@ void prepare(obvi_ba_handle* h) {
         if (all_in_window && pair_bitmap) {
           for (size_t i = 0; i < obs.size(); ++i)
             for (size_t j = 0; j <= i; ++j)
-              __atomic_store_n(&pose_pair[(size_t)std::max(obs[i].vid, obs[j].vid) * (size_t)h->nPv + (size_t)std::min(obs[i].vid, obs[j].vid)], (uint8_t)1, __ATOMIC_RELAXED);
+              __atomic_store_n(&pose_pair_w[(size_t)std::max(obs[i].vid, obs[j].vid) * (size_t)h->nPv + (size_t)std::min(obs[i].vid, obs[j].vid)], (uint8_t)1, __ATOMIC_RELAXED);
           continue;
         }
         if (all_in_window) n_window_pairs -= (int64_t)(obs.size() * (obs.size() + 1) / 2);   // counted pair by pair below
         for (size_t i = 0; i < obs.size(); ++i)
           for (size_t j = 0; j <= i; ++j) {
             const Ob& x = obs[i]; const Ob& y = obs[j];
-            if (pair_bitmap) __atomic_store_n(&pose_pair[(size_t)std::max(x.vid, y.vid) * (size_t)h->nPv + (size_t)std::min(x.vid, y.vid)], (uint8_t)1, __ATOMIC_RELAXED);
+            if (pair_bitmap) __atomic_store_n(&pose_pair_w[(size_t)std::max(x.vid, y.vid) * (size_t)h->nPv + (size_t)std::min(x.vid, y.vid)], (uint8_t)1, __ATOMIC_RELAXED);
             else mark(h->h_pose_row[std::max(x.vid, y.vid)], 6, h->h_pose_row[std::min(x.vid, y.vid)], 6);
             // inside the strip of the later frame's chunk?  (same test as the kernel's inverse map)
             const int32_t fp = std::max(x.f, y.f), fq = std::min(x.f, y.f);
@@ -689,6 +693,7 @@ void prepare(obvi_ba_handle* h) {
       }
       window_pairs_t[part] = n_window_pairs; twin_t[part] = any_twin ? 1 : 0;
     });
+    for (const auto& bm : pose_pair_t) for (size_t i = 0; i < bm.size(); ++i) pose_pair[i] |= bm[i];
     for (int t = 0; t < parts; ++t) {
       pairs.insert(pairs.end(), pairs_t[t].begin(), pairs_t[t].end());
       visit_list.insert(visit_list.end(), visits_t[t].begin(), visits_t[t].end());
@@ -804,7 +809,7 @@ void prepare(obvi_ba_handle* h) {
     q = e;
   }
   struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches; };
-  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 8192));
+  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 1024));
   std::vector<BatchLists> lists_t(parts2);
   parallel_ranges((int64_t)wgs.size(), parts2, [&](int part, int64_t g0, int64_t g1) {
     BatchLists& o = lists_t[part];
@@ -1588,7 +1593,7 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
   }
-  const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 65536));   // ranges of points / observations on host threads
+  const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 8192));   // ranges of points / observations on the host's worker threads
   parallel_ranges(h->L, threads, [&](int, int64_t l0, int64_t l1) {
     auto before = [&](uint32_t x, uint32_t y) { return pose_idx[x] < pose_idx[y] || (pose_idx[x] == pose_idx[y] && x < y); };
     for (int64_t l = l0; l < l1; ++l)
