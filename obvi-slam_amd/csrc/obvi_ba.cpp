@@ -1310,9 +1310,15 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // the point pass first, alone: it and the pose-side pass stream the same observation arrays and are both HBM-bound (side by side the
   // point pass took 0.35 ms instead of 0.24); the side stream starts behind it and runs beside the Schur complement, which is bound
   // by instruction issue and LDS, not by HBM
+  // ... on a big problem.  On a sliding window every kernel is a few microseconds of latency, nothing is bandwidth-bound, and the side stream
+  // (pose pass + small factors + diagonal blocks + far pairs: 63 us for 50 frames) is longer than point pass + Schur complement (47 us): there
+  // it forks in front of the point pass.
+  static const int64_t fork_early_below = std::getenv("OBVI_FORK_EARLY_BELOW") ? std::atoll(std::getenv("OBVI_FORK_EARLY_BELOW")) : 400000;   // tuning knob (observations)
+  const bool fork_early = side && h->n_rp < fork_early_below;
+  if (fork_early) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
-  if (side) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
+  if (side && !fork_early) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
   record(h, PH_POSE_PASS, s2);
   launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
   if (side) record_end(h, PH_POSE_PASS, s2);
@@ -1330,12 +1336,13 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   if (side) record_end(h, PH_DIAG, s2);
   // the pairs outside every strip (loop closures, very long tracks) only need the point pass: beside the strip kernel as well (both add
   // to the tile grid with atomics)
-  if (side && solve) launch_schur_blocks(s2, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  if (side && solve && !fork_early) launch_schur_blocks(s2, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   if (side) OBVI_HIP(hipEventRecord(h->ev_join, s2));
   record(h, PH_SCHUR);
   if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   record(h, PH_SCHUR_BLOCKS);
-  if (solve && !side) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  // (forked early, the side stream is not ordered behind the point pass whose Z records these pairs read: main stream then)
+  if (solve && (!side || fork_early)) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   if (side) OBVI_HIP(hipStreamWaitEvent(s, h->ev_join, 0));   // join
   record(h, PH_CHOL);
   if (solve && h->m > 0) {
