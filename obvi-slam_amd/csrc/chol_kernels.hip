@@ -126,49 +126,79 @@ __device__ __forceinline__ void stage_rows16(double* dst, const double* __restri
 // ---------------------------------------------------------------------------------------
 // potrf of one 64x64 tile with the panel solve and the trailing updates on the matrix cores.
 // A right-looking panel of 4 columns is exactly the K of v_mfma_f64_16x16x4_f64, so per panel step kb:
-//   (a) one thread factorises the 4x4 diagonal block and inverts it (D)                         [scalar, the serial part]
+//   (a) the 4x4 diagonal block is factorised and its factor inverted (D)                        [scalar, the serial part]
 //   (b) the solved panel X = P D^T (P = current panel columns) is never stored as a matrix: a wavefront that needs the rows of
 //       tile row J as an MFMA operand computes X_J^T = D P_J^T with one MFMA whose first result register IS that operand
 //       (lane (k, n) holds X[16 J + n][k], the A and B fragment layout alike), so nothing goes through LDS in between
 //   (c) trailing matrix  A -= X X^T  and  Acc -= X W  (W rows = D Acc rows, four fma per lane, again directly in B fragment
 //       layout):  one MFMA per 16x16 tile, finished rows / columns masked out of the operands
-// The trailing matrices stay in registers in the MFMA accumulator layout (wavefront I owns tile row I; wavefronts 0-3 A,
+// The trailing matrices stay in registers in the MFMA accumulator layout (a wavefront owns a tile row; wavefronts 0-3 A,
 // wavefronts 4-7 the accumulator of L^-1).  At the end of a step the 4 columns (rows) the next step needs are published to
-// LDS in operand layout (row-major [64][4]: a fragment is 64 consecutive doubles); the wavefront that owns the next diagonal
-// block has at most two tiles to update, publishes, and factorises the block right away (same wavefront: no barrier).
-// ONE workgroup barrier per panel step; P, D and the published accumulator rows alternate between two buffers.
+// LDS in operand layout (row-major [64][4]: a fragment is 64 consecutive doubles).
+// (a) is off the other wavefronts' path (look-ahead): the diagonal block of step kb + 1 after the update of step kb is
+// W - X X^T with W its 4x4 values BEFORE that update (published, with the panel, during step kb - 1) and X its four rows of
+// the panel times D_kb^T -- 24 fma on 16 lanes -- so one wavefront (accumulator row 0, idle after the first four steps) forms
+// and factorises it during step kb, while the others run the update, and D_kb+1 is in LDS when step kb + 1 starts.
+// The loop's critical path is that wavefront's chain D_kb -> D_kb+1 (about 130 dependent fp64 instructions) or the heaviest
+// tile row, whichever is longer (scripts/potrf_bench.hip: 17.0 -> 15.4 us for one tile with the look-ahead).
+// ONE workgroup barrier per panel step; P, W, D and the published accumulator rows alternate between two buffers.
 // Fragment layout: A: lane l -> A[l&15][l>>4]; B: lane l -> B[l>>4][l&15]; D: lane l, reg r -> D[(l>>4) + 4r][l&15].
 // ---------------------------------------------------------------------------------------
-constexpr int kPotrfMfmaLds = T * LD + 2 * (T * 4) + 2 * (T * 4) + 32 + T;   // doubles
-struct PotrfLds { double *Lsh, *Psh2, *AR2, *Dsh2; };
-// 4x4 Cholesky of the diagonal block kb and the inverse of its factor, one thread.  2x2 block pivots: for the pivot block
+constexpr int kPotrfMfmaLds = T * LD + 2 * (T * 4) + 2 * (T * 4) + 32 + T + 32;   // doubles
+struct PotrfLds { double *Lsh, *Psh2, *AR2, *Dsh2, *Wsh2; };
+// 4x4 Cholesky of a diagonal block and the inverse of its factor.  2x2 block pivots: for the pivot block
 // (p q; q r) the reciprocal square roots of p and of p r - q^2 are independent, so two columns cost one rsqrt latency:
 // l00 = p i0, l10 = q i0, 1/l11 = rsqrt(det) l00  (det has the same cancellation as r - l10^2).
 // A non-positive pivot is flagged and poisons the tile (NaN); the step is then rejected on the host.
-__device__ __forceinline__ void potrf_factor_diag(const PotrfLds& s, int kb, double& bad) {
-  const double* P = s.Psh2 + (kb & 1) * (T * 4) + (4 * kb) * 4;
-  const double p = P[0], q = P[4], r = P[5];
+// Only the inverse is handed on (its strict upper part stays zero from the start): the block's own factor falls out of the panel
+// solve, L_kk = A_kk D^T, with the rows below it.  d = (D00, D10, D11, D20, D21, D22, D30, D31, D32, D33).
+struct Diag4 { double b00, b10, b11, b20, b21, b22, b30, b31, b32, b33; };
+__device__ __forceinline__ void potrf_factor_block(const Diag4& B, double (&d)[10], double& bad) {
+  const double p = B.b00, q = B.b10, r = B.b11;
   const double det = fma(p, r, -(q * q));
   const double i0 = fast_rsqrt(p), id = fast_rsqrt(det);
   const double l00 = p * i0, l10 = q * i0, i1 = id * l00;
-  const double l20 = P[8] * i0, l30 = P[12] * i0;
-  const double l21 = fma(-l20, l10, P[9]) * i1, l31 = fma(-l30, l10, P[13]) * i1;
-  const double p2 = fma(-l21, l21, fma(-l20, l20, P[10])), q2 = fma(-l31, l21, fma(-l30, l20, P[14])), r2 = fma(-l31, l31, fma(-l30, l30, P[15]));
+  const double l20 = B.b20 * i0, l30 = B.b30 * i0;
+  const double l21 = fma(-l20, l10, B.b21) * i1, l31 = fma(-l30, l10, B.b31) * i1;
+  const double p2 = fma(-l21, l21, fma(-l20, l20, B.b22)), q2 = fma(-l31, l21, fma(-l30, l20, B.b32)), r2 = fma(-l31, l31, fma(-l30, l30, B.b33));
   const double det2 = fma(p2, r2, -(q2 * q2));
   const double i2 = fast_rsqrt(p2), id2 = fast_rsqrt(det2);
   const double l22 = p2 * i2, l32 = q2 * i2, i3 = id2 * l22;
-  if (!(p > 0.0) || !(det > 0.0) || !(p2 > 0.0) || !(det2 > 0.0)) bad = 1.0;
+  bad = fmin(bad, fmin(fmin(p, det), fmin(p2, det2)));   // smallest pivot quantity so far; fmin skips a NaN, the product below does not
   const double d10 = -l10 * i0 * i1, d21 = -l21 * i1 * i2, d32 = -l32 * i2 * i3;
   const double d20 = -(l20 * i0 + l21 * d10) * i2, d31 = -(l31 * i1 + l32 * d21) * i3;
   const double d30 = -(l30 * i0 + l31 * d10 + l32 * d20) * i3;
-  // only the inverse is handed on (its strict upper part stays zero from the start): the block's own factor falls out of the panel
-  // solve, L_kk = A_kk D^T, with the rows below it
-  double* D = s.Dsh2 + (kb & 1) * 16;
-  D[0] = i0; D[4] = d10; D[5] = i1; D[8] = d20; D[9] = d21; D[10] = i2; D[12] = d30; D[13] = d31; D[14] = d32; D[15] = i3;
+  bad = fma(0.0, i3, bad);   // i3 is NaN whenever a pivot quantity was
+  d[0] = i0; d[1] = d10; d[2] = i1; d[3] = d20; d[4] = d21; d[5] = i2; d[6] = d30; d[7] = d31; d[8] = d32; d[9] = i3;
+}
+__device__ __forceinline__ double lane_value(double v, int src) {   // v of lane src, wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// The look-ahead wavefront's duty of panel step kb: the inverse factor D of diagonal block kb + 1 while the other wavefronts run the
+// trailing update of panel kb.  The block after that update is  W - X X^T  with W the block's 4x4 values before the update (published
+// by its owner during step kb - 1), X = (rows of the block in panel kb) D_kb^T, D_kb in this wavefront's registers (d) from the step
+// before.  Lane 4 a + b forms entry (a, b); the ten entries of the lower triangle are then made wave-uniform and every lane runs the
+// 4x4 factorisation (no divergence); lane 0 publishes D.  Prow == nullptr: the block is W itself (block 0, before the loop).
+__device__ __forceinline__ void potrf_lookahead(const double* Prow, const double* W, double* Dout, double (&d)[10], double& bad) {
+  const int lane = threadIdx.x & 63, a = (lane >> 2) & 3, b = lane & 3;
+  double bp = W[a * 4 + b];
+  if (Prow) {
+    const double* pa = Prow + a * 4;
+    const double* pb = Prow + b * 4;
+    const double a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+    const double xa0 = a0 * d[0], xa1 = fma(a1, d[2], a0 * d[1]), xa2 = fma(a2, d[5], fma(a1, d[4], a0 * d[3])), xa3 = fma(a3, d[9], fma(a2, d[8], fma(a1, d[7], a0 * d[6])));
+    const double xb0 = b0 * d[0], xb1 = fma(b1, d[2], b0 * d[1]), xb2 = fma(b2, d[5], fma(b1, d[4], b0 * d[3])), xb3 = fma(b3, d[9], fma(b2, d[8], fma(b1, d[7], b0 * d[6])));
+    bp = fma(-xa3, xb3, fma(-xa2, xb2, fma(-xa1, xb1, fma(-xa0, xb0, bp))));
+  }
+  Diag4 B;
+  B.b00 = lane_value(bp, 0); B.b10 = lane_value(bp, 4); B.b11 = lane_value(bp, 5); B.b20 = lane_value(bp, 8); B.b21 = lane_value(bp, 9);
+  B.b22 = lane_value(bp, 10); B.b30 = lane_value(bp, 12); B.b31 = lane_value(bp, 13); B.b32 = lane_value(bp, 14); B.b33 = lane_value(bp, 15);
+  potrf_factor_block(B, d, bad);
+  if (lane == 0) { Dout[0] = d[0]; Dout[4] = d[1]; Dout[5] = d[2]; Dout[8] = d[3]; Dout[9] = d[4]; Dout[10] = d[5]; Dout[12] = d[6]; Dout[13] = d[7]; Dout[14] = d[8]; Dout[15] = d[9]; }
 }
 // the panel loop of one wavefront: tile row I of A (FAC) or of the accumulator of L^-1
 template <bool FAC>
-__device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, f64x4 (&acc)[4], double& bad) {
+__device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, f64x4 (&acc)[4], double (&dreg)[10], double& bad) {
   const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
   OBVI_TICK(0);
   OBVI_TICK(1);
@@ -181,6 +211,9 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
       const double* P = s.Psh2 + par * (T * 4);
       const double* D = s.Dsh2 + par * 16;
       double* Pn = s.Psh2 + (1 - par) * (T * 4);
+      // the look-ahead wavefront (accumulator row 0: one tile during the first four steps, nothing afterwards) first: its chain
+      // D_kb -> D_kb+1 is the critical path of the loop
+      if (!FAC && I == 0 && kb + 1 < 16) potrf_lookahead(P + 4 * (kb + 1) * 4, s.Wsh2 + par * 16, s.Dsh2 + (1 - par) * 16, dreg, bad);
       const bool live = I > Ik || (I == Ik && m < 3);   // the tile row still has rows below the diagonal block
       const int Jn = m == 3 ? Ik + 1 : Ik, mn = (m + 1) & 3;   // tile column / column block of the next panel
       const double dpad = c < 4 ? D[c * 4 + q] : 0.0;   // A operand of the panel solve: D padded to 16 x 4
@@ -192,7 +225,7 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
       };
       const bool live2 = I >= Ik;   // ... or the rows of the diagonal block itself (their part of X = P D^T is L_kk)
       double xI = 0.0, an = 0.0;
-      if (FAC ? live2 : live) {
+      if (FAC && live2) {
         xI = solved_rows(I);
         an = (16 * I + c > done) ? -xI : 0.0;
       }
@@ -214,23 +247,37 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
                 for (int r = 0; r < 4; ++r) Pn[(16 * I + q + 4 * r) * 4 + (c & 3)] = acc[J][r];
               }
           }
-          if (I == Jn) {   // this wavefront wrote the new diagonal block: no barrier needed before it is factorised
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane == 0) potrf_factor_diag(s, kb + 1, bad);
+        }
+        if (kb + 2 < 16) {   // the 4x4 diagonal block after next, as it stands after this panel's update: the look-ahead wavefront's W of the next step
+          const int m2 = (m + 2) & 3;
+          const int J2 = Ik + (m >= 2 ? 1 : 0);
+          if (I == J2 && (c >> 2) == m2) {
+            double* Wn = s.Wsh2 + (1 - par) * 16;
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+              if (J == J2) Wn[q * 4 + (c & 3)] = acc[J][m2];
           }
         }
         if (live2 && 16 * I + c >= 4 * kb) s.Lsh[(16 * I + c) * LD + 4 * kb + q] = xI;   // the panel's part of L incl. the diagonal block (read at the end)
       } else if (I >= Ik) {
         // rows kb of W = D Acc(rows kb): lane (q, c) forms W[4 kb + q][16 J + c], the B operand it needs; the wavefront that
         // owns these rows keeps them
-        const double d0 = D[q * 4], d1 = D[q * 4 + 1], d2 = D[q * 4 + 2], d3 = D[q * 4 + 3];
         const double* AR = s.AR2 + par * (T * 4);
+        const double pI = P[(16 * I + c) * 4 + q];
+        const double d0 = D[q * 4], d1 = D[q * 4 + 1], d2 = D[q * 4 + 2], d3 = D[q * 4 + 3];
+        double ar[4][4];
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ar[J][t] = AR[(16 * J + c) * 4 + t];
+        if (live) {
+          const f64x4 x = __builtin_amdgcn_mfma_f64_16x16x4f64(dpad, pI, f64x4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+          xI = x[0];
+          an = (16 * I + c > done) ? -xI : 0.0;
+        }
 #pragma unroll
         for (int J = 0; J < 4; ++J) if (J <= Ik) {
-          const double* a4 = AR + (16 * J + c) * 4;
-          const double w = fma(d3, a4[3], fma(d2, a4[2], fma(d1, a4[1], d0 * a4[0])));
+          const double w = fma(d3, ar[J][3], fma(d2, ar[J][2], fma(d1, ar[J][1], d0 * ar[J][0])));
           if (I == Ik) acc[J][m] = w;
           if (live) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, w, acc[J], 0, 0, 0);
         }
@@ -255,6 +302,7 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   s.AR2 = s.Psh2 + 2 * T * 4;   // 2 x [64][4] AR[c][t] = row 4kb+t of the accumulator of W, column c
   s.Dsh2 = s.AR2 + 2 * T * 4;   // 2 x 4x4 inverse of L_kk
   double* zsh = s.Dsh2 + 32;
+  s.Wsh2 = zsh + T;             // 2 x 4x4 diagonal block the look-ahead wavefront factorises next (values before the running panel's update)
   double* tile = tile_ptr(S, nt, k, k);
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr bool fac = FAC;
@@ -285,15 +333,18 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
 #pragma unroll
     for (int r = 0; r < 4; ++r) s.Psh2[(16 * I + q + 4 * r) * 4 + c] = acc[0][r];
   }
-  double bad = 0.0;
+  if (fac && I == 0 && c < 8) s.Wsh2[(c < 4 ? 16 : 0) + q * 4 + (c & 3)] = acc[0][c >> 2];   // diagonal blocks 0 (second buffer) and 1 (first: step 0 reads it)
+  double bad = 1.0, dreg[10] = {};
   __syncthreads();
-  if (tid == 0) potrf_factor_diag(s, 0, bad);
-  if (!fac && I == 0) s.AR2[c * 4 + q] = acc[0][0];
+  if (!fac && I == 0) {
+    potrf_lookahead(nullptr, s.Wsh2 + 16, s.Dsh2, dreg, bad);
+    s.AR2[c * 4 + q] = acc[0][0];
+  }
   __syncthreads();
   OBVI_MARK(1);
-  potrf_mfma_wave<FAC>(s, I, acc, bad);
+  potrf_mfma_wave<FAC>(s, I, acc, dreg, bad);
   OBVI_MARK(2);
-  if (bad != 0.0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  if (!(bad > 0.0)) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
   OBVI_MARK(3);
   if (fac) {   // L: coalesced from LDS; the strict upper part was never written (or holds round-off of the diagonal blocks): zeros
     double lv[16];
@@ -329,11 +380,12 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
 }
 
 __device__ __forceinline__ void potrf_mfma_tile(double* smem, double* S, int nt, int k, double* Linv_all, double* rhs, double* scal, const double* pre_tile = nullptr, const double* pre_z = nullptr) {
-  // wavefronts 0-3: tile rows 0-3 of A; wavefronts 4-7: tile rows 3-0 of the accumulator of L^-1 (the heavy rows of the two
-  // halves do not share a SIMD).  Two instruction streams (A / accumulator), tile row wave-uniform; both execute the same barriers.
+  // wavefronts 0-3: tile rows 0-3 of A; wavefronts 4-7: tile rows 0, 3, 2, 1 of the accumulator of L^-1.  Wavefronts w and w + 4 share a
+  // SIMD: the look-ahead wavefront (accumulator row 0) sits beside tile row 0 of A, which is finished after four steps, and the heavy
+  // rows of the two halves do not meet.  Two instruction streams (A / accumulator), tile row wave-uniform; both execute the same barriers.
   const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wvi < 4) potrf_mfma_rows<true>(wvi, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
-  else potrf_mfma_rows<false>(7 - wvi, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
+  else potrf_mfma_rows<false>((8 - wvi) & 3, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
 }
 
 __global__ void __launch_bounds__(512) k_potrf(double* S, int nt, const int32_t* __restrict__ klist, double* Linv_all, double* rhs, double* scal) {

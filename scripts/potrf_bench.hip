@@ -1,17 +1,19 @@
 // micro-benchmark + self-check of k_potrf (dev tool, not part of the product):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics scripts/potrf_bench.hip -o scripts/potrf_bench
 // phase clocks of one probe thread of workgroup 0, kept in registers: per-phase sums over the 16 panel steps
-__device__ long long g_ph[4], g_mark[8];
+__device__ long long g_ph[4], g_mark[8], g_step[32];
 __device__ int g_probe;
 enum { idx_ph1 = 0, idx_ph2 = 1, idx_ph3 = 2 };
+#ifndef NOPROBE
 #define OBVI_TICK(i) OBVI_TICK_##i
-#define OBVI_TICK_0 long long acc_[3] = {0, 0, 0}, last_ = 0
+#define OBVI_TICK_0 long long acc_[3] = {0, 0, 0}, last_ = 0; int si_ = 0
 #define OBVI_TICK_1 last_ = clock64()
 #define OBVI_TICK_2 do { if ((int)threadIdx.x == g_probe && blockIdx.x == 0) { g_ph[0] = acc_[0]; g_ph[1] = acc_[1]; g_ph[2] = acc_[2]; } } while (0)
 #define OBVI_TICK_3
 #define OBVI_TICK_4
 #define OBVI_MARK(i) do { if ((int)threadIdx.x == g_probe && blockIdx.x == 0) g_mark[i] = clock64(); } while (0)
-#define OBVI_PH(var) do { const long long now_ = clock64(); acc_[idx_##var] += now_ - last_; last_ = now_; } while (0)
+#define OBVI_PH(var) do { const long long now_ = clock64(); acc_[idx_##var] += now_ - last_; if ((int)threadIdx.x == g_probe && blockIdx.x == 0) g_step[si_] = now_ - last_; ++si_; last_ = now_; } while (0)
+#endif
 #include "../obvi-slam_amd/csrc/chol_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -64,6 +66,7 @@ int main() {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ph), sizeof(ph));
     { long long mk[8]; hipMemcpyFromSymbol(mk, HIP_SYMBOL(g_mark), sizeof(mk)); printf("            start->loop %lld   loop %lld   loop end->L stored %lld   ->W stored %lld   ->end %lld\n", mk[1] - mk[0], mk[2] - mk[1], mk[3] - mk[2], mk[4] - mk[3], mk[5] - mk[4]); }
+    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_step), sizeof(st)); printf("            per step work/wait:"); for (int i = 0; i < 32; i += 2) printf(" %lld/%lld", st[i], st[i + 1]); printf("\n"); }
     printf("thread %3d: phase 1 %lld   phase 2 %lld   phase 3 %lld   (cycles, sum over 16 steps: panel + barrier / trailing / publish + diagonal block + barrier)\n", probe, ph[0], ph[1], ph[2]);
   }
   std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost);
