@@ -366,8 +366,11 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
 // wavefront/LDS reduction per pose, no atomics.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
-                                                     const double* __restrict__ points, ReducedDev rd) {
-  const int64_t p = blockIdx.x;
+                                                     const double* __restrict__ points, ReducedDev rd, int slices) {
+  // slices > 1 (a sliding window: tens of poses with a thousand sightings each): `slices` workgroups share a pose, so that a thread has one
+  // or two sightings instead of a chain of dependent gathers, and add their sums atomically
+  const int64_t p = blockIdx.x / slices;
+  const int sl = blockIdx.x % slices;
   const int32_t vid = b.pose_vid[p];
   if (vid < 0) return;   // uniform per workgroup
   __shared__ double red[kBlock / 64][27];
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   const uint32_t beg = rq.pose_ptr[p], end = rq.pose_ptr[p + 1];
-  for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
+  for (uint32_t k = beg + sl * kBlock + threadIdx.x; k < end; k += kBlock * slices) {
     if (!rq.active[k]) continue;
     const uint32_t l = rq.point[k];
     const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
@@ -410,9 +413,9 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
       int x = 0, base = 0;
       while (base + x + 1 <= k) { base += x + 1; ++x; }
       const int y = k - base;
-      rd.Hdiag[36 * (int64_t)vid + 6 * x + y] += t;
+      if (slices > 1) atomic_add_f64(&rd.Hdiag[36 * (int64_t)vid + 6 * x + y], t); else rd.Hdiag[36 * (int64_t)vid + 6 * x + y] += t;
     } else {
-      rd.g[6 * (int64_t)vid + (k - 21)] += t;
+      if (slices > 1) atomic_add_f64(&rd.g[6 * (int64_t)vid + (k - 21)], t); else rd.g[6 * (int64_t)vid + (k - 21)] += t;
     }
   }
 }
@@ -1571,7 +1574,14 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
                       const ReducedDev& rd) {
-  if (b.P > 0 && rq.n > 0) hipLaunchKernelGGL(k_pose_pass, dim3((unsigned)b.P), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd);
+  if (b.P <= 0 || rq.n <= 0) return;
+  // a pose's workgroup walks its sightings 256 at a time; with few poses (a window) that loop is the latency of the launch: cut it
+  // (not in the deterministic mode: one writer per block)
+  static const int max_slices = std::getenv("OBVI_POSE_PASS_SLICES") ? std::atoi(std::getenv("OBVI_POSE_PASS_SLICES")) : 8;   // tuning knob
+  const int64_t per_pose = (rq.n + b.P - 1) / b.P;
+  int slices = 1;
+  if (!b.deterministic && b.P <= 256) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_pose_pass, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {

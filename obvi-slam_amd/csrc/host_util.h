@@ -86,6 +86,15 @@ class DevBuf {
     h2d_async(p_, h, n * sizeof(T), s);
   }
   void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+  // Upload without the host-side copy: stage_begin(n) sizes the buffer and hands out n elements of pinned memory from the running call's
+  // arena to be filled in place (nullptr when the arena has no room: fill a vector and upload() that), stage_commit starts the copy.
+  T* stage_begin(size_t n) {
+    resize(n);
+    StagingArena* a = tl_staging;
+    if (n == 0 || a == nullptr || n * sizeof(T) > kStagedCopyMaxBytes) return nullptr;
+    return static_cast<T*>(a->take(n * sizeof(T)));
+  }
+  void stage_commit(const T* staged, size_t n, hipStream_t s) { if (n) OBVI_HIP(hipMemcpyAsync(p_, staged, n * sizeof(T), hipMemcpyHostToDevice, s)); }
   void download(T* h, size_t n, hipStream_t s) const {
     if (n) OBVI_HIP(hipMemcpyAsync(h, p_, n * sizeof(T), hipMemcpyDeviceToHost, s));
   }

@@ -62,6 +62,7 @@ struct obvi_ba_handle {
   std::vector<uint8_t> h_rp_active;  // sorted order
   std::vector<int32_t> h_rp_yrow;
   std::vector<uint32_t> h_rq_src;    // CSR-by-pose copy: position -> index into the CSC-by-point arrays
+  std::vector<uint32_t> scr_cursor, scr_wave_obs, scr_long_points, scr_pose_ptr;   // scratch of set_reproj, kept between calls
   double rp_huber = 1.0;
   int64_t n_bb = 0, n_sp = 0, n_lt = 0, n_rl = 0;
   std::vector<uint32_t> h_bb_obj, h_bb_pose, h_sp_obj, h_lt_obj, h_rl_a, h_rl_b;
@@ -202,7 +203,32 @@ struct StagingScope {
   explicit StagingScope(const obvi_ba_handle* h) : prev(tl_staging) { tl_staging = h ? const_cast<StagingArena*>(&h->staging) : nullptr; }
   ~StagingScope() { tl_staging = prev; }
 };
-#define OBVI_API_BEGIN try { StagingScope staging_scope_(h);
+// OBVI_API_TIMING=1: wall time per entry point (and of the symbolic phase inside obvi_ba_solve), summed over the process, on stderr at exit
+struct ApiTimes {
+  struct Row { const char* name; double ms = 0.0; int64_t calls = 0; };
+  std::mutex mu;
+  std::vector<Row> rows;
+  void add(const char* name, double ms) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (Row& r : rows) if (r.name == name || std::strcmp(r.name, name) == 0) { r.ms += ms; ++r.calls; return; }
+    rows.push_back({name, ms, 1});
+  }
+  ~ApiTimes() {
+    for (const Row& r : rows) std::fprintf(stderr, "api timing: %-30s %9.2f ms in %7lld calls (%8.4f ms each)\n", r.name, r.ms, (long long)r.calls, r.ms / (double)r.calls);
+  }
+};
+inline ApiTimes* api_times() {
+  static ApiTimes* t = std::getenv("OBVI_API_TIMING") ? new ApiTimes : nullptr;
+  static const bool registered = t && (std::atexit([] { delete api_times(); }), true);
+  (void)registered;
+  return t;
+}
+struct ApiTimer {
+  const char* name; double t0;
+  explicit ApiTimer(const char* n) : name(n), t0(api_times() ? wall_s() : 0.0) {}
+  ~ApiTimer() { if (ApiTimes* t = api_times()) t->add(name, 1e3 * (wall_s() - t0)); }
+};
+#define OBVI_API_BEGIN try { StagingScope staging_scope_(h); ApiTimer api_timer_(__func__);
 #define OBVI_API_END(h)                                           \
   }                                                               \
   catch (const HipError& e) { return hip_fail(h, e); }            \
@@ -387,8 +413,9 @@ void bake_bbox(obvi_ba_handle* h) {
 // ---------------------------------------------------------------------------------------
 bool prepare_masks(obvi_ba_handle* h);
 void prepare(obvi_ba_handle* h) {
-  if (!h->dirty && h->mask_dirty && prepare_masks(h)) return;
   if (!h->dirty && !h->mask_dirty) return;
+  ApiTimer api_timer_(h->dirty ? "  prepare (symbolic phase)" : "  prepare (masks only)");
+  if (!h->dirty && h->mask_dirty && prepare_masks(h)) return;
   // OBVI_DEBUG_PREPARE: stage times of the symbolic phase on stderr
   const bool stage_times = std::getenv("OBVI_DEBUG_PREPARE") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
@@ -1030,7 +1057,9 @@ void prepare(obvi_ba_handle* h) {
   // y of its ancestors inside the launch itself (k_backward; chain record per row) and tiles between two rows of a launch get no
   // workgroup.  The launches are listed in the order of the forward levels and run last to first.
   std::vector<int32_t> bw_kj, bw_chains;
-  const int bw_levels = std::max(1, std::min(8, env_int("OBVI_BACKWARD_LEVELS", 4)));   // tuning knob: levels per launch (1: one level per launch; chains of at most 7)
+  // levels per launch (tuning knob; 1: one level per launch; chains of at most 7): four, or the whole tree when it has at most eight levels
+  // (a sliding window: one launch instead of two)
+  const int bw_levels = std::max(1, std::min(8, env_int("OBVI_BACKWARD_LEVELS", nlev <= 8 ? 8 : 4)));
   h->h_bw_ptr.assign(1, 0);
   {
     int top = nlev - 1;             // the levels are grouped from the top
@@ -1286,6 +1315,7 @@ void record_end(obvi_ba_handle* h, int idx, hipStream_t on) { if (h->profiling >
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
 void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, bool keep_factor = false) {
+  ApiTimer api_timer_("  LM step (submit + wait)");
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h);
   const ReprojDev rp = reproj_dev(h);
@@ -1315,34 +1345,60 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // it forks in front of the point pass.
   static const int64_t fork_early_below = std::getenv("OBVI_FORK_EARLY_BELOW") ? std::atoll(std::getenv("OBVI_FORK_EARLY_BELOW")) : 400000;   // tuning knob (observations)
   const bool fork_early = side && h->n_rp < fork_early_below;
+  auto side_pose_pass = [&] {
+    record(h, PH_POSE_PASS, s2);
+    launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
+    if (side) record_end(h, PH_POSE_PASS, s2);
+  };
+  auto side_small_factors = [&] {
+    record(h, PH_SMALL, s2);
+    launch_small_factors(s2, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
+    if (side) record_end(h, PH_SMALL, s2);
+  };
+  auto side_diagonal = [&] {
+    record(h, PH_DIAG, s2);
+    if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
+      const int32_t ns = (int32_t)h->h_shared_ov.size();
+      launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 0);
+      if (h->allreduce(h->allreduce_user, h->d_xbuf2.get(), 56 * (int64_t)ns, 0, s2)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
+      launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 1);
+    }
+    launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
+    if (side) record_end(h, PH_DIAG, s2);
+  };
+  auto main_schur_window = [&] {
+    record(h, PH_SCHUR);
+    if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
+  };
+  auto schur_blocks_on = [&](hipStream_t st) {
+    launch_schur_blocks(st, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
+  };
   if (fork_early) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
   record(h, PH_POINT_PASS);
   launch_point_pass(s, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd, pt, radius, first_iter ? 1 : 0, scal, h->d_wave_obs.get(), h->n_point_waves, h->d_long_points.get(), h->n_long_points);
   if (side && !fork_early) { OBVI_HIP(hipEventRecord(h->ev_fork, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
-  record(h, PH_POSE_PASS, s2);
-  launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
-  if (side) record_end(h, PH_POSE_PASS, s2);
-  record(h, PH_SMALL, s2);
-  launch_small_factors(s2, b, sf, h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, scal);
-  if (side) record_end(h, PH_SMALL, s2);
-  record(h, PH_DIAG, s2);
-  if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
-    const int32_t ns = (int32_t)h->h_shared_ov.size();
-    launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 0);
-    if (h->allreduce(h->allreduce_user, h->d_xbuf2.get(), 56 * (int64_t)ns, 0, s2)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
-    launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 1);
+  if (fork_early) {
+    // a sliding window: every kernel is 5-25 us and the host needs about 5 us per launch, so the two streams are fed alternately -- behind
+    // one another, the strip kernel reached its stream 19 us after the point pass had finished (of a 223 us iteration)
+    side_pose_pass();
+    main_schur_window();
+    side_small_factors();
+    record(h, PH_SCHUR_BLOCKS);
+    if (solve) schur_blocks_on(s);   // (forked early, the side stream is not ordered behind the point pass whose Z records these pairs read: main stream)
+    side_diagonal();
+    OBVI_HIP(hipEventRecord(h->ev_join, s2));
+  } else {
+    side_pose_pass();
+    side_small_factors();
+    side_diagonal();
+    // the pairs outside every strip (loop closures, very long tracks) only need the point pass: beside the strip kernel as well (both add
+    // to the tile grid with atomics)
+    if (side && solve) schur_blocks_on(s2);
+    if (side) OBVI_HIP(hipEventRecord(h->ev_join, s2));
+    main_schur_window();
+    record(h, PH_SCHUR_BLOCKS);
+    if (solve && !side) schur_blocks_on(s);
   }
-  launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);
-  if (side) record_end(h, PH_DIAG, s2);
-  // the pairs outside every strip (loop closures, very long tracks) only need the point pass: beside the strip kernel as well (both add
-  // to the tile grid with atomics)
-  if (side && solve && !fork_early) launch_schur_blocks(s2, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
-  if (side) OBVI_HIP(hipEventRecord(h->ev_join, s2));
-  record(h, PH_SCHUR);
-  if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
-  record(h, PH_SCHUR_BLOCKS);
-  // (forked early, the side stream is not ordered behind the point pass whose Z records these pairs read: main stream then)
-  if (solve && (!side || fork_early)) launch_schur_blocks(s, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
   if (side) OBVI_HIP(hipStreamWaitEvent(s, h->ev_join, 0));   // join
   record(h, PH_CHOL);
   if (solve && h->m > 0) {
@@ -1474,6 +1530,7 @@ const char* obvi_ba_last_error(const obvi_ba_handle* h) { return h ? h->err.c_st
 
 int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
+  ApiTimer api_timer_(__func__);
   *out = nullptr;
   if (options && options->object_block_size != 0 && options->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
   if (options && options->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && options->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
@@ -1511,6 +1568,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
 
 void obvi_ba_destroy(obvi_ba_handle* h) {
   if (!h) return;
+  ApiTimer api_timer_(__func__);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -1592,27 +1650,39 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     const int cam = cam_idx ? cam_idx[i] : 0;
     if (pose_idx[i] >= h->P || point_idx[i] >= h->L || cam >= (int)h->h_cams.size()) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_reproj: index out of range");
   }
-  // CSC by point: counting sort on the point index, then by pose inside each point
-  std::vector<uint32_t> perm(n), ptr(h->L + 1, 0);
+  double t_sub = wall_s();
+  auto sub = [&](const char* name) { if (ApiTimes* t = api_times()) { const double now = wall_s(); t->add(name, 1e3 * (now - t_sub)); t_sub = now; } };
+  sub("    set_reproj: validate");
+  // CSC by point: counting sort on the point index, then by pose inside each point.  (A sliding window calls this for every frame with
+  // about the same n: the index arrays live in the handle, the device-only arrays are filled in pinned memory -- no allocation, no
+  // second copy.)
+  std::vector<uint32_t>& perm = h->h_rp_perm;
+  std::vector<uint32_t>& ptr = h->h_point_ptr;
+  std::vector<uint32_t>& cur = h->scr_cursor;
+  perm.resize(n); ptr.assign(h->L + 1, 0);
   for (int64_t i = 0; i < n; ++i) ptr[point_idx[i] + 1]++;
   for (int64_t l = 0; l < h->L; ++l) ptr[l + 1] += ptr[l];
-  {
-    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
-  }
-  const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 8192));   // ranges of points / observations on the host's worker threads
+  cur.assign(ptr.begin(), ptr.end() - 1);
+  for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
+  // ranges of points / observations on the host's worker threads -- from a few hundred thousand observations on: a window's 50 k are
+  // 0.6 ms on one thread and 0.85-1.3 ms on 2-16 (waking the workers, 256 cores on two sockets passing cache lines around)
+  const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 131072));
   parallel_ranges(h->L, threads, [&](int, int64_t l0, int64_t l1) {
     auto before = [&](uint32_t x, uint32_t y) { return pose_idx[x] < pose_idx[y] || (pose_idx[x] == pose_idx[y] && x < y); };
     for (int64_t l = l0; l < l1; ++l)
       if (!std::is_sorted(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before)) std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before);
   });
+  sub("    set_reproj: sort by point");
   h->n_rp = n; h->rp_huber = huber;
   h->max_rp_pose = max_index(pose_idx, n); h->max_rp_point = max_index(point_idx, n); h->max_rp_cam = cam_idx ? max_index(cam_idx, n) : (n > 0 ? 0 : -1);
-  h->h_rp_perm = perm; h->h_point_ptr = ptr;
   h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
-  std::vector<uint16_t> cam(n);
-  std::vector<double2> pix(n);
-  std::vector<double> sg(n);
+  hipStream_t s = h->stream;
+  // the arrays only the device reads: filled in the staging arena when it has room, in scratch vectors otherwise
+  struct Spill { std::vector<uint16_t> cam, q_cam; std::vector<double2> pix, q_pix; std::vector<double> sg, q_sg; std::vector<uint32_t> q_point; std::vector<uint8_t> q_act; } spill;
+  auto staged = [&](auto& dev, auto& fallback, size_t count) { auto* q = dev.stage_begin(count); if (!q) { fallback.resize(count); q = fallback.data(); } return q; };
+  uint16_t* cam = staged(h->d_rp_cam, spill.cam, (size_t)n);
+  double2* pix = staged(h->d_rp_pixel, spill.pix, (size_t)n);
+  double* sg = staged(h->d_rp_sigma, spill.sg, (size_t)n);
   parallel_ranges(n, threads, [&](int, int64_t a0, int64_t a1) {
     for (int64_t a = a0; a < a1; ++a) {
       const uint32_t i = perm[a];
@@ -1622,9 +1692,11 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
       sg[a] = sigma ? sigma[i] : sigma_scalar;
     }
   });
-  hipStream_t s = h->stream;
+  sub("    set_reproj: gather");
   {   // k_point_pass: the observation list cut into wavefront-sized pieces (<= 64 observations, whole points); longer tracks go to the per-point kernel
-    std::vector<uint32_t> wave_obs, long_points;   // wave_obs: (first observation, count) per piece
+    std::vector<uint32_t>& wave_obs = h->scr_wave_obs;   // (first observation, count) per piece
+    std::vector<uint32_t>& long_points = h->scr_long_points;
+    wave_obs.clear(); long_points.clear();
     uint32_t start = 0, count = 0;
     int64_t lfirst = 0;
     for (int64_t l = 0; l < h->L; ++l) {
@@ -1640,27 +1712,36 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     h->n_long_points = (int64_t)long_points.size();
     h->d_wave_obs.upload(wave_obs, s); h->d_long_points.upload(long_points, s);
   }
+  sub("    set_reproj: wave pieces");
   h->d_rp_pose.upload(h->h_rp_pose, s); h->d_rp_point.upload(h->h_rp_point, s); h->d_rp_perm.upload(perm, s); h->d_point_ptr.upload(ptr, s);
-  h->d_rp_cam.upload(cam, s); h->d_rp_pixel.upload(pix, s); h->d_rp_sigma.upload(sg, s); h->d_rp_active.upload(h->h_rp_active, s);
+  h->d_rp_cam.stage_commit(cam, (size_t)n, s); h->d_rp_pixel.stage_commit(pix, (size_t)n, s); h->d_rp_sigma.stage_commit(sg, (size_t)n, s);
+  h->d_rp_active.upload(h->h_rp_active, s);
+  sub("    set_reproj: upload by point");
   // CSR-by-pose copy for the pose-side pass (counting sort on the pose index; stable, so points ascend inside a pose)
-  std::vector<uint32_t> pptr(h->P + 1, 0), q_point(n);
-  std::vector<uint16_t> q_cam(n);
-  std::vector<double2> q_pix(n);
-  std::vector<double> q_sg(n);
-  std::vector<uint8_t> q_act(n, 1);
+  std::vector<uint32_t>& pptr = h->scr_pose_ptr;
+  pptr.assign(h->P + 1, 0);
   h->h_rq_src.resize(n);
   for (int64_t a = 0; a < n; ++a) pptr[h->h_rp_pose[a] + 1]++;
   for (int64_t p = 0; p < h->P; ++p) pptr[p + 1] += pptr[p];
+  uint32_t* q_point = staged(h->d_rq_point, spill.q_point, (size_t)n);
+  uint16_t* q_cam = staged(h->d_rq_cam, spill.q_cam, (size_t)n);
+  double2* q_pix = staged(h->d_rq_pixel, spill.q_pix, (size_t)n);
+  double* q_sg = staged(h->d_rq_sigma, spill.q_sg, (size_t)n);
+  uint8_t* q_act = staged(h->d_rq_active, spill.q_act, (size_t)n);
   {
-    std::vector<uint32_t> cur(pptr.begin(), pptr.end() - 1);
+    cur.assign(pptr.begin(), pptr.end() - 1);
     for (int64_t a = 0; a < n; ++a) h->h_rq_src[cur[h->h_rp_pose[a]]++] = (uint32_t)a;
     parallel_ranges(n, threads, [&](int, int64_t k0, int64_t k1) {
-      for (int64_t k = k0; k < k1; ++k) { const uint32_t a = h->h_rq_src[k]; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a]; }
+      for (int64_t k = k0; k < k1; ++k) { const uint32_t a = h->h_rq_src[k]; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a]; q_act[k] = 1; }
     });
   }
-  h->d_rq_point.upload(q_point, s); h->d_rq_cam.upload(q_cam, s); h->d_rq_pixel.upload(q_pix, s); h->d_rq_sigma.upload(q_sg, s);
-  h->d_rq_active.upload(q_act, s); h->d_rq_pose_ptr.upload(pptr, s);
+  sub("    set_reproj: by pose");
+  h->d_rq_point.stage_commit(q_point, (size_t)n, s); h->d_rq_cam.stage_commit(q_cam, (size_t)n, s); h->d_rq_pixel.stage_commit(q_pix, (size_t)n, s);
+  h->d_rq_sigma.stage_commit(q_sg, (size_t)n, s); h->d_rq_active.stage_commit(q_act, (size_t)n, s); h->d_rq_pose_ptr.upload(pptr, s);
+  if (!spill.cam.empty() || !spill.pix.empty() || !spill.sg.empty() || !spill.q_point.empty() || !spill.q_cam.empty() || !spill.q_pix.empty() || !spill.q_sg.empty() || !spill.q_act.empty())
+    h->staging.spilled = true;   // a copy went out of pageable memory: finish_upload waits
   finish_upload(h);
+  sub("    set_reproj: upload by pose + finish");
   h->dirty = true;
   return OBVI_OK;
   OBVI_API_END(h)

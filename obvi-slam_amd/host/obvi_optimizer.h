@@ -18,6 +18,7 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <set>
 #include <sstream>
 
@@ -87,12 +88,58 @@ inline obvi_ba_options makeHandleOptions(int device_id) {
   return opt;
 }
 
+// Device handles outlive the Problem that used them: creating one allocates its streams, events, pinned pages and worker pool (about
+// 25 ms, 10 ms to destroy) and a session makes a new Problem at every global-BA frame (runPgoPlusEllipsoids).  A handle a Problem gives
+// back is handed to the next Problem with the same device and options; every set_* call replaces what the previous problem left, the
+// parameter priors are cleared here.  drain() destroys what is parked (the drivers call it before they exit).
+class HandlePool {
+ public:
+  static HandlePool& instance() { static HandlePool* p = new HandlePool; return *p; }   // never destroyed: no HIP calls from static destructors
+  obvi_ba_handle* acquire(const obvi_ba_options& opt) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (size_t i = 0; i < parked_.size(); ++i)
+        if (same(parked_[i].first, opt)) { obvi_ba_handle* h = parked_[i].second; parked_.erase(parked_.begin() + (long)i); return h; }
+    }
+    obvi_ba_handle* h = nullptr;
+    const int rc = obvi_ba_create(&opt, &h);
+    if (rc != OBVI_OK) { std::cerr << "obvi_ba_create failed: status " << rc << " (no HIP device? there is no CPU path)" << std::endl; return nullptr; }
+    return h;
+  }
+  void release(const obvi_ba_options& opt, obvi_ba_handle* h) {
+    if (h == nullptr) return;
+    // an empty problem: the next user may set fewer factor families than this one did
+    int rc = obvi_ba_set_parameter_priors(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!rc) rc = obvi_ba_set_reproj(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 1.0);
+    if (!rc) rc = obvi_ba_set_bbox(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.0);
+    if (!rc) rc = obvi_ba_set_shape_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
+    if (!rc) rc = obvi_ba_set_ltm_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
+    if (!rc) rc = obvi_ba_set_relpose(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0);
+    if (rc != OBVI_OK) { obvi_ba_destroy(h); return; }
+    std::lock_guard<std::mutex> lock(mu_);
+    if (parked_.size() >= kMaxParked) { obvi_ba_destroy(h); return; }
+    parked_.push_back({opt, h});
+  }
+  void drain() {
+    std::vector<std::pair<obvi_ba_options, obvi_ba_handle*>> all;
+    { std::lock_guard<std::mutex> lock(mu_); all.swap(parked_); }
+    for (auto& e : all) obvi_ba_destroy(e.second);
+  }
+ private:
+  static constexpr size_t kMaxParked = 8;
+  static bool same(const obvi_ba_options& a, const obvi_ba_options& b) {
+    return a.device_id == b.device_id && a.object_block_size == b.object_block_size && a.reprojection_variant == b.reprojection_variant && a.deterministic == b.deterministic;
+  }
+  std::mutex mu_;
+  std::vector<std::pair<obvi_ba_options, obvi_ba_handle*>> parked_;
+};
+
 class Problem {
  public:
   explicit Problem(int device_id = 0, bool dry_run = false) : device_id_(device_id), dry_run_(dry_run) {}
   Problem(const Problem&) = delete;
   Problem& operator=(const Problem&) = delete;
-  ~Problem() { if (h_) obvi_ba_destroy(h_); }
+  ~Problem() { if (h_) HandlePool::instance().release(opt_, h_); }
   // residual blocks added outside the factor store: runPgoPlusEllipsoids adds RelativePoseFactor blocks directly
   // to its ceres::Problem (pose_graph_plus_objects_optimizer.h:129-159); they stay for every later build on it.
   void AddRelativePoseResidualBlock(const vslam_types_refactor::RelPoseFactor& f, double huber) { extra_relpose_.push_back(f); extra_relpose_huber_ = huber; }
@@ -101,16 +148,13 @@ class Problem {
   FlatProblem flat;
   bool dryRun() const { return dry_run_; }
   obvi_ba_handle* handle() {
-    if (!h_ && !dry_run_) {
-      const obvi_ba_options opt = makeHandleOptions(device_id_);
-      const int rc = obvi_ba_create(&opt, &h_);
-      if (rc != OBVI_OK) { std::cerr << "obvi_ba_create failed: status " << rc << " (no HIP device? there is no CPU path)" << std::endl; h_ = nullptr; }
-    }
+    if (!h_ && !dry_run_) { opt_ = makeHandleOptions(device_id_); h_ = HandlePool::instance().acquire(opt_); }
     return h_;
   }
  private:
   int device_id_; bool dry_run_;
   obvi_ba_handle* h_ = nullptr;
+  obvi_ba_options opt_{};
   std::vector<vslam_types_refactor::RelPoseFactor> extra_relpose_;
   double extra_relpose_huber_ = 1.0;
 };

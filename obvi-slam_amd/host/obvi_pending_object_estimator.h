@@ -83,8 +83,8 @@ inline bool refineInitialEstimateForPendingObjects(const std::unordered_map<Obje
   if (objects.empty() || cam_K.empty()) return true;                       // nothing to refine
 
   const obvi_ba_options opt = obvi::makeHandleOptions(device_id);
-  obvi_ba_handle* h = nullptr;
-  if (obvi_ba_create(&opt, &h) != OBVI_OK || h == nullptr) { std::cerr << "obvi_ba_create failed (no HIP device? there is no CPU path)" << std::endl; return false; }
+  obvi_ba_handle* h = obvi::HandlePool::instance().acquire(opt);
+  if (h == nullptr) return false;
   const std::vector<uint8_t> pose_const(poses.size() / 6, 1), obj_const(objects.size() / 7, 0);       // problem.SetParameterBlockConstant(robot_pose_block), :99-103
   const auto& rp = estimator_params.object_residual_params_;
   int rc = obvi_ba_set_cameras(h, (int32_t)(cam_K.size() / 4), cam_K.data(), cam_ext.data());
@@ -112,7 +112,7 @@ inline bool refineInitialEstimateForPendingObjects(const std::unordered_map<Obje
       logger->logIterations(optimization_identifier, summary);
     }
   }
-  obvi_ba_destroy(h);
+  obvi::HandlePool::instance().release(opt, h);
   if (rc) return false;
   if (summary_out) *summary_out = s;
   if (s.termination_type == OBVI_FAILURE) { std::cerr << "Ceres optimization failed for pending  object estimation" << std::endl; return false; }

@@ -318,6 +318,7 @@ int main(int argc, char** argv) {
   if (std::getenv("OBVI_HOST_TIMING"))
     std::cerr << "driver: scene load + setup " << std::chrono::duration<double, std::milli>(t_run0 - t_main0).count() << " ms, runFullOptimization "
               << std::chrono::duration<double, std::milli>(t_run1 - t_run0).count() << " ms" << std::endl;
+  obvi::HandlePool::instance().drain();
   writeResults(out, ok, results, max_frame_id, ltm);
   return ok ? 0 : 1;
 }
