@@ -6,6 +6,10 @@
 #define OBVI_HOST_UTIL_H_
 
 #include <hip/hip_runtime.h>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -120,6 +124,7 @@ class HostPool {
       try { threads_.emplace_back([this] { work(); }); }
       catch (const std::system_error&) { break; }   // fewer workers: the caller takes the rest itself
     }
+    keep_near_caller();
   }
   ~HostPool() {
     { std::lock_guard<std::mutex> lock(m_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
@@ -144,6 +149,25 @@ class HostPool {
   }
 
  private:
+  // The workers read what the calling thread wrote a moment ago and the caller then overwrites what they read (one problem per frame in
+  // a sliding-window session).  Spread by the scheduler over a two-socket host, every such line crosses the sockets; kept on the caller's
+  // block of logical CPUs (same socket, neighbouring L3 slices) it does not.  OBVI_HOST_AFFINITY=0 leaves the placement to the scheduler.
+  void keep_near_caller() {
+#if defined(__linux__)
+    const char* v = std::getenv("OBVI_HOST_AFFINITY");
+    if (v != nullptr && std::atoi(v) == 0) return;
+    const int cpu = sched_getcpu();
+    cpu_set_t allowed;
+    if (cpu < 0 || threads_.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int block = 16, base = cpu - cpu % block;
+    cpu_set_t near;
+    CPU_ZERO(&near);
+    int n = 0;
+    for (int c = base; c < base + block; ++c) if (CPU_ISSET(c, &allowed)) { CPU_SET(c, &near); ++n; }
+    if (n < 2) return;
+    for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(near), &near);
+#endif
+  }
   void take() {
     for (;;) {
       const int i = next_.fetch_add(1, std::memory_order_acq_rel);
