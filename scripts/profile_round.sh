@@ -13,7 +13,6 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 SHA=$(python3 $R/scripts/source_sha.py)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $R/bench.py > $OUT/${TAG}_bench_cfg3.json 2> $OUT/bench.err
 # (the legs of the default command that are not the timed workload -- CPU baseline, deterministic-mode comparison, end-to-end two-phase run -- are
 #  switched off under the profiler, so that a kernel's average is over the launches of the timed configuration only)
 LEGS="--no-cpu-baseline --no-deterministic-leg --no-end-to-end"
@@ -56,6 +55,18 @@ json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1]["launches"])[:12]:
     print("%-22s launches %5d  mfma_busy %6.3f  active %5.2f  wait %5.2f  issue-stall %5.2f" % (k, e["launches"], e.get("mfma_busy_frac", float("nan")), e.get("active_frac", float("nan")), e.get("wait_frac", float("nan")), e.get("issue_stall_frac", float("nan"))))
 PY
+# the manifest and the counter summaries go into profiles/ of THIS copy of the repo first, so that the bench line measured next carries
+# traffic / rocprof_avg_us / sq from the set it belongs to (bench.py reads profiles/manifest.json and checks the kernel-source hash)
+python3 - $OUT $TAG $SHA <<'PY'
+import json, os, sys
+out, tag, sha = sys.argv[1:4]
+json.dump({"tag": tag, "kernel_source_sha": sha, "files": {"bench": tag + "_bench_cfg3.json", "measured_peaks": tag + "_measured_peaks.json", "kernel_stats": tag + "_kernel_stats_cfg3.csv", "pmc_traffic": tag + "_pmc_traffic.json",
+                                                              "sq_counters": tag + "_sq_counters.json"},
+           "note": "measured by scripts/profile_round.sh on one MI355X; kernel_source_sha = scripts/source_sha.py over obvi-slam_amd/csrc at measurement time"},
+          open(os.path.join(out, "manifest.json"), "w"), indent=1)
+PY
+cp $OUT/manifest.json $OUT/${TAG}_kernel_stats_cfg3.csv $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_sq_counters.json $R/profiles/ 2>/dev/null
+timeout 900 python $R/bench.py > $OUT/${TAG}_bench_cfg3.json 2> $OUT/bench.err
 python3 - $OUT $TAG $SHA <<'PY'
 import json, os, subprocess, sys
 out, tag, sha = sys.argv[1:4]
