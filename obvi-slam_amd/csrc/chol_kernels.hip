@@ -344,7 +344,7 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   OBVI_MARK(1);
   potrf_mfma_wave<FAC>(s, I, acc, dreg, bad);
   OBVI_MARK(2);
-  if (!(bad > 0.0)) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);
+  if (!(bad > 0.0) && lane == 0) unsafeAtomicAdd(scal + SC_CHOL_FAIL, 1.0);   // (every lane of the look-ahead wavefront holds the same verdict)
   OBVI_MARK(3);
   if (fac) {   // L: coalesced from LDS; the strict upper part was never written (or holds round-off of the diagonal blocks): zeros
     double lv[16];

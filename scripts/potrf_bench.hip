@@ -70,6 +70,16 @@ int main() {
     printf("thread %3d: phase 1 %lld   phase 2 %lld   phase 3 %lld   (cycles, sum over 16 steps: panel + barrier / trailing / publish + diagonal block + barrier)\n", probe, ph[0], ph[1], ph[2]);
   }
   std::vector<double> sc(32); hipMemcpy(sc.data(), dscal, 256, hipMemcpyDeviceToHost);
+  {   // a tile that is not positive definite (one pivot <= 0 at column 21, nothing non-finite on the way in) and one with a NaN: both must raise the flag
+    for (int which = 0; which < 2; ++which) {
+      std::vector<double> Sb(S.begin(), S.begin() + (size_t)T * T);
+      if (which == 0) Sb[21 * T + 21] = -1.0; else Sb[40 * T + 3] = Sb[3 * T + 40] = std::nan("");
+      hipMemcpy(dS, Sb.data(), Sb.size() * 8, hipMemcpyHostToDevice); hipMemset(dscal, 0, 256);
+      hipLaunchKernelGGL(k_potrf, dim3(1), dim3(512), 0, 0, dS, nt, dk, dL, dr, dscal);
+      std::vector<double> sb(32); hipMemcpy(sb.data(), dscal, 256, hipMemcpyDeviceToHost);
+      printf("%s tile: chol_fail %g (expected > 0)\n", which == 0 ? "indefinite" : "NaN", sb[SC_CHOL_FAIL]);
+    }
+  }
   printf("chol_fail %g   max |L L^T - A|/64 %.2e   max |L W - I| %.2e   max |L z - b| %.2e\n", sc[SC_CHOL_FAIL], e_llt, e_inv, e_z);
   return 0;
 }
