@@ -1580,7 +1580,8 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
   static const int max_slices = std::getenv("OBVI_POSE_PASS_SLICES") ? std::atoi(std::getenv("OBVI_POSE_PASS_SLICES")) : 8;   // tuning knob
   const int64_t per_pose = (rq.n + b.P - 1) / b.P;
   int slices = 1;
-  if (!b.deterministic && b.P <= 256) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
+  static const int64_t slice_below = std::getenv("OBVI_POSE_PASS_SLICE_BELOW") ? std::atoll(std::getenv("OBVI_POSE_PASS_SLICE_BELOW")) : 256;   // tuning knob (poses)
+  if (!b.deterministic && b.P <= slice_below) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(k_pose_pass, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
