@@ -233,7 +233,6 @@ struct CholPlan {
   const int32_t* row_ptr;     // device [nt+1]      row structure of L: columns j < k with L(k,j) != 0 (forward substitution with many right-hand sides)
   const int32_t* row_j;       // device
 };
-void launch_publish_scalars(hipStream_t s, const double* scal, double* host_pinned, int n, double seq);   // n <= 64
 void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, double* d1, const double* s1, int64_t n1, double* d2, const double* s2, int64_t n2);
 // small accumulators cleared at the start of an LM step, together with the tiles (one launch)
 struct StepClear {
@@ -244,6 +243,7 @@ struct StepClear {
   double* scal; int64_t n_scal;         // scalar block; scal[fixed_slot] = fixed_cost
   int64_t fixed_slot; double fixed_cost;
   int64_t n_max;
+  double* pub_host; double pub_seq;      // not null: the workgroup that clears the scalar block first writes it to this pinned page, then pub_seq behind it (the LM loop's read-back)
 };
 void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row, const StepClear& c);
 // optional per-kernel timing (profiling level 2): an event is recorded after every launch, tagged with the kernel class

@@ -1730,19 +1730,6 @@ void launch_copy3(hipStream_t s, double* d0, const double* s0, int64_t n0, doubl
   const int64_t n = n0 + n1 + n2;
   if (n > 0) hipLaunchKernelGGL(k_copy3, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, s, d0, s0, n0, d1, s1, n1, d2, s2, n2);
 }
-// The scalar block of one LM step, written straight into the host's pinned page by the device, then a sequence number behind a
-// system-scope fence: the host polls the number instead of sleeping in hipStreamSynchronize (whose wake-up costs tens of microseconds
-// per LM iteration).
-__global__ void k_publish_scalars(const double* __restrict__ scal, volatile double* host, int n, double seq) {
-  const int t = threadIdx.x;
-  if (t < n) host[t] = scal[t];
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) { __threadfence_system(); host[n] = seq; }
-}
-void launch_publish_scalars(hipStream_t s, const double* scal, double* host, int n, double seq) {
-  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, scal, host, n, seq);
-}
 void launch_fill(hipStream_t s, double* p, int64_t n, double v) {
   if (n > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, s, p, n, v);
 }

@@ -35,12 +35,21 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
 }
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
-// Start of an LM step, one launch: zero the structurally non-zero tiles (identity on padding rows); the workgroups behind them
-// clear the small accumulators of the step (diagonal blocks, gradient, right-hand side, potrf counters, scalar block).
-__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int ntiles, const uint8_t* __restrict__ is_pad_row, StepClear c) {
-  if ((int)blockIdx.x >= ntiles) {
-    const int64_t stride = (int64_t)(gridDim.x - ntiles) * kThreads;
-    for (int64_t i = (int64_t)(blockIdx.x - ntiles) * kThreads + threadIdx.x; i < c.n_max; i += stride) {
+// Start of an LM step, one launch: the first workgroups clear the small accumulators of the step (diagonal blocks, gradient, right-hand
+// side, potrf counters, scalar block), the others zero the structurally non-zero tiles (identity on padding rows).
+__global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, const int32_t* __restrict__ tiles, int ntiles, const uint8_t* __restrict__ is_pad_row, StepClear c, int extra) {
+  if ((int)blockIdx.x < extra) {
+    if (c.pub_host != nullptr && blockIdx.x == 0) {
+      // the scalar block of the step that just ended goes to the host before it is cleared (the threads below clear the entries they
+      // published): one launch less between the trial cost and the host's accept / reject decision.  Workgroup 0: the first to start.
+      volatile double* host = c.pub_host;
+      if ((int64_t)threadIdx.x < c.n_scal) host[threadIdx.x] = c.scal[threadIdx.x];
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) { __threadfence_system(); host[c.n_scal] = c.pub_seq; }
+    }
+    const int64_t stride = (int64_t)extra * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < c.n_max; i += stride) {
       if (i < c.n_hdiag) c.hdiag[i] = 0.0;
       if (i < c.n_g) c.g[i] = 0.0;
       if (i < c.n_rhs) c.rhs[i] = 0.0;
@@ -49,7 +58,8 @@ __global__ void __launch_bounds__(kThreads) k_zero_tiles(double* S, int nt, cons
     }
     return;
   }
-  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  const int tb = (int)blockIdx.x - extra;
+  const int ti = tiles[2 * tb], tj = tiles[2 * tb + 1];
   double* t = tile_ptr(S, nt, ti, tj);
   for (int e = threadIdx.x; e < T * T; e += kThreads) {
     double v = 0.0;
@@ -869,8 +879,8 @@ __global__ void __launch_bounds__(kCovThreads) k_cov_pairs(const double* __restr
 }  // namespace
 
 void launch_zero_tiles(hipStream_t s, double* S, int32_t nt, const int32_t* tile_list, int32_t ntiles, const uint8_t* is_pad_row, const StepClear& c) {
-  const int extra = (int)std::min<int64_t>(64, (c.n_max + kThreads - 1) / kThreads);
-  if (ntiles + extra > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles + extra), dim3(kThreads), 0, s, S, nt, tile_list, ntiles, is_pad_row, c);
+  const int extra = (int)std::max<int64_t>(c.pub_host ? 1 : 0, std::min<int64_t>(64, (c.n_max + kThreads - 1) / kThreads));
+  if (ntiles + extra > 0) hipLaunchKernelGGL(k_zero_tiles, dim3(ntiles + extra), dim3(kThreads), 0, s, S, nt, tile_list, ntiles, is_pad_row, c, extra);
 }
 
 static void tick(hipStream_t s, CholTimers* t, int tag) {

@@ -131,7 +131,8 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_sel_mask;
   DevBuf<uint32_t> d_rp_inv;
   SelectScratch sel_scratch;
-  double* h_scal = nullptr;  // pinned; [SC_COUNT] is the sequence number k_publish_scalars writes last
+  double* h_scal = nullptr;  // pinned; the device writes the scalar block of an LM step straight into it and, behind a system-scope fence, the sequence number [SC_COUNT]
+                             // (k_zero_tiles): the host polls the number instead of sleeping in hipStreamSynchronize (whose wake-up costs tens of microseconds)
   double scal_seq = 0.0;
 
   // ---- reduced-program bookkeeping (prepare()) ----
@@ -1303,6 +1304,7 @@ StepClear step_clear(obvi_ba_handle* h, double fixed_cost) {
   c.diag_done = h->d_diag_done.get(); c.n_done = (int64_t)h->d_diag_done.size();
   c.scal = h->d_scal.get(); c.n_scal = SC_COUNT; c.fixed_slot = SC_COST_FIXED; c.fixed_cost = fixed_cost;
   c.n_max = std::max({c.n_hdiag, c.n_g, c.n_rhs, c.n_done, c.n_scal});
+  c.pub_host = nullptr; c.pub_seq = 0.0;
   return c;
 }
 void record(obvi_ba_handle* h, int idx, hipStream_t on = nullptr) {
@@ -1435,11 +1437,18 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   }
   static const bool poll_ok = !std::getenv("OBVI_POLL_SCALARS") || std::atoi(std::getenv("OBVI_POLL_SCALARS")) != 0;   // tuning knob
   const bool poll = poll_ok && h->profiling < 1 && !keep_factor;
-  if (poll) { h->scal_seq += 1.0; launch_publish_scalars(s, scal, h->h_scal, SC_COUNT, h->scal_seq); }
-  else OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   // the clear of the next LM step does not depend on the accept / reject decision: it runs while the host takes it
-  // (not when the caller goes on to use the factor that is in the tiles: covariance extraction)
-  if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
+  // (not when the caller goes on to use the factor that is in the tiles: covariance extraction) -- and its first workgroup behind the
+  // tiles hands the scalar block to the host before it clears it
+  if (poll) {
+    h->scal_seq += 1.0;
+    StepClear c = step_clear(h, fixed);
+    c.pub_host = h->h_scal; c.pub_seq = h->scal_seq;
+    launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), c); h->tiles_cleared = true;
+  } else {
+    OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+    if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
+  }
   if (poll) wait_scalars(h); else sync(h);
   if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) {
     // a scheduling event, not a numerical one: nothing the step wrote is kept (the current point is untouched, the accumulators were
