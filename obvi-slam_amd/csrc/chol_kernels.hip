@@ -105,13 +105,33 @@ __device__ __forceinline__ void tile_abt_mfma(const double* A, const double* B, 
     }
   }
 }
-__device__ __forceinline__ void stage_tile(double* dst, const double* __restrict__ src) {
-  // 64x64 row-major global tile -> LDS with leading dimension LDM; 16-byte global loads
-  for (int e = threadIdx.x; e < T * T / 2; e += kThreads) {
-    const int r = e / (T / 2), c2 = e % (T / 2);
-    const double2 v = reinterpret_cast<const double2*>(src)[e];
-    dst[r * LDM + 2 * c2] = v.x; dst[r * LDM + 2 * c2 + 1] = v.y;
+// A tile (or 16 rows of one) travels global -> registers -> LDS in two separate phases: every 16-byte load of a thread first, then the LDS
+// writes.  (Written as one loop of load + store, the compiler clustered five of a tile's eight loads and waited for each of the other
+// three on its own: four memory latencies per tile, eight for the two operands of a product.)
+struct TileRegs { double2 v[T * T / 2 / kThreads]; };    // 8 x 16 bytes per thread of a 256-thread group
+__device__ __forceinline__ void tile_fetch(TileRegs& r, const double* __restrict__ src) {
+#pragma unroll
+  for (int x = 0; x < T * T / 2 / kThreads; ++x) r.v[x] = reinterpret_cast<const double2*>(src)[threadIdx.x + kThreads * x];
+}
+__device__ __forceinline__ void tile_put(double* dst, const TileRegs& r) {   // row-major tile -> LDS with leading dimension LDM
+#pragma unroll
+  for (int x = 0; x < T * T / 2 / kThreads; ++x) {
+    const int e = threadIdx.x + kThreads * x, row = e / (T / 2), c2 = e % (T / 2);
+    dst[row * LDM + 2 * c2] = r.v[x].x; dst[row * LDM + 2 * c2 + 1] = r.v[x].y;
   }
+}
+__device__ __forceinline__ void stage_tile(double* dst, const double* __restrict__ src) {
+  TileRegs r;
+  tile_fetch(r, src);
+  tile_put(dst, r);
+}
+// two tiles: all sixteen loads in flight together
+__device__ __forceinline__ void stage_tiles(double* dstA, const double* __restrict__ srcA, double* dstB, const double* __restrict__ srcB) {
+  TileRegs ra, rb;
+  tile_fetch(ra, srcA);
+  tile_fetch(rb, srcB);
+  tile_put(dstA, ra);
+  tile_put(dstB, rb);
 }
 
 // Row slice q (16 rows) of  C += A * B^T:  As holds rows [16 q, 16 q + 16) of A, B the whole tile; wavefront w computes the
@@ -411,8 +431,7 @@ __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int3
   double* tile = tile_ptr(S, nt, i, k);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (slices == 1) {
-    stage_tile(A, tile);
-    stage_tile(B, Linv_all + (int64_t)k * (T * T));
+    stage_tiles(A, tile, B, Linv_all + (int64_t)k * (T * T));
     __syncthreads();
     f64x4 acc[4] = {};
     tile_abt_mfma(A, B, acc);   // X = S_ik * Linv^T
@@ -421,8 +440,7 @@ __global__ void __launch_bounds__(kThreads) k_trsm(double* S, int nt, const int3
 #pragma unroll
       for (int r = 0; r < 4; ++r) tile[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = acc[rt][r];
   } else {   // rows [16 q, 16 q + 16) of X: this workgroup reads and writes only these rows of the tile
-    stage_rows16(A, tile + 16 * q * T);
-    stage_tile(B, Linv_all + (int64_t)k * (T * T));
+    { TileRegs rb; tile_fetch(rb, Linv_all + (int64_t)k * (T * T)); stage_rows16(A, tile + 16 * q * T); tile_put(B, rb); }
     __syncthreads();
     f64x4 acc = {};
     tile_abt_mfma_rows(A, B, acc);
@@ -450,8 +468,7 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
       const int k = u.upd_k[q];
       __syncthreads();
-      stage_rows16(A, tile_ptr(S, nt, i, k) + 16 * slice * T);
-      stage_tile(B, tile_ptr(S, nt, j, k));
+      { TileRegs rb; tile_fetch(rb, tile_ptr(S, nt, j, k)); stage_rows16(A, tile_ptr(S, nt, i, k) + 16 * slice * T); tile_put(B, rb); }
       __syncthreads();
       tile_abt_mfma_rows(A, B, acc);
     }
@@ -470,8 +487,8 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
       const int k = u.upd_k[q];
       __syncthreads();
-      stage_tile(A, tile_ptr(S, nt, i, k));
-      if (i != j) stage_tile(B, tile_ptr(S, nt, j, k));
+      if (i != j) stage_tiles(A, tile_ptr(S, nt, i, k), B, tile_ptr(S, nt, j, k));
+      else stage_tile(A, tile_ptr(S, nt, i, k));
       __syncthreads();
       tile_abt_mfma(A, i != j ? B : A, acc);
     }
