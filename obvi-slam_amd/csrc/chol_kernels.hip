@@ -463,9 +463,12 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
   double* B = smem + T * LDM;
   const int tid = threadIdx.x;
   if (g < u.n_upd && slice >= 0) {   // rows [16 slice, 16 slice + 16) of the target
-    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1];
+    // (the job's scalars once, in front: read inside the loop or behind it they are a load and a full wait each -- the compiler cannot
+    // know that the tile stores do not alias them)
+    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1], q0 = u.upd_kptr[g], q1 = u.upd_kptr[g + 1];
+    const bool atomic = u.upd_flag[g] != 0;
     f64x4 acc = {};
-    for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int k = u.upd_k[q];
       __syncthreads();
       { TileRegs rb; tile_fetch(rb, tile_ptr(S, nt, j, k)); stage_rows16(A, tile_ptr(S, nt, i, k) + 16 * slice * T); tile_put(B, rb); }
@@ -474,17 +477,26 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     }
     double* C = tile_ptr(S, nt, i, j);
     const int lane = tid & 63, wv = tid >> 6;
+    double* c[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double* c = &C[(16 * slice + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)];
-      if (u.upd_flag[g]) unsafeAtomicAdd(c, -acc[r]); else *c -= acc[r];
+    for (int r = 0; r < 4; ++r) c[r] = &C[(16 * slice + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)];
+    if (atomic) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c[r], -acc[r]);
+    } else {   // the four reads together, then the four writes
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = *c[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *c[r] = v[r] - acc[r];
     }
     return;
   }
   if (g < u.n_upd) {
-    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1];
+    const int i = u.upd_ij[2 * g], j = u.upd_ij[2 * g + 1], q0 = u.upd_kptr[g], q1 = u.upd_kptr[g + 1];
+    const bool atomic = u.upd_flag[g] != 0;
     f64x4 acc[4] = {};
-    for (int q = u.upd_kptr[g]; q < u.upd_kptr[g + 1]; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int k = u.upd_k[q];
       __syncthreads();
       if (i != j) stage_tiles(A, tile_ptr(S, nt, i, k), B, tile_ptr(S, nt, j, k));
@@ -494,16 +506,21 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     }
     double* C = tile_ptr(S, nt, i, j);
     const int lane = tid & 63, wv = tid >> 6;
-    if (u.upd_flag[g]) {
+    if (atomic) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(&C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)], -acc[rt][r]);
     } else {
+      double v[4][4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] -= acc[rt][r];
+        for (int r = 0; r < 4; ++r) v[rt][r] = C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(16 * rt + (lane >> 4) + 4 * r) * T + 16 * wv + (lane & 15)] = v[rt][r] - acc[rt][r];
     }
   } else {
     const int h = g - u.n_upd;
@@ -511,7 +528,8 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
     // thread (r = tid/4, part = tid%4): 16 columns each
     const int r = tid >> 2, part = tid & 3;
     double s = 0.0;
-    for (int q = u.rh_kptr[h]; q < u.rh_kptr[h + 1]; ++q) {
+    const int q0 = u.rh_kptr[h], q1 = u.rh_kptr[h + 1];
+    for (int q = q0; q < q1; ++q) {
       const int k = u.rh_k[q];
       const double* X = tile_ptr(S, nt, i, k) + r * T + part * 16;
       const double* z = rhs + (int64_t)k * T + part * 16;
