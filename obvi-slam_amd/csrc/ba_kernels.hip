@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
 // entries of rho' Jp^T Jp and the 6 of rho' Jp^T r over its observations; one deterministic
 // wavefront/LDS reduction per pose, no atomics.
 // ---------------------------------------------------------------------------------------
+template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
                                                      const double* __restrict__ points, ReducedDev rd, int slices) {
   // slices > 1 (a sliding window: tens of poses with a thousand sightings each): `slices` workgroups share a pose, so that a thread has one
@@ -379,23 +380,55 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   const uint32_t beg = rq.pose_ptr[p], end = rq.pose_ptr[p + 1];
-  for (uint32_t k = beg + sl * kBlock + threadIdx.x; k < end; k += kBlock * slices) {
-    if (!rq.active[k]) continue;
-    const uint32_t l = rq.point[k];
-    const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
-    const double2 px = rq.pixel[k];
-    double r[2], Jp[12], Jl[6];
-    reproj_eval<true>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, Jp, Jl);
-    double rho0, w;
-    huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
-    int e = 0;
-#pragma unroll
-    for (int x = 0; x < 6; ++x) {
-#pragma unroll
-      for (int y = 0; y <= x; ++y) acc[e++] += w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]);
+  if (PIPE) {
+    // (loads in two rounds, the next sighting's first round in flight during this one's arithmetic: a window's pose pass is one sighting per thread and three dependent loads deep otherwise)
+    struct ByK { uint32_t l; double2 px; double sg; uint16_t cam; uint8_t act; };
+    auto by_k = [&](uint32_t k) { ByK o; o.act = rq.active[k]; o.l = rq.point[k]; o.px = rq.pixel[k]; o.cam = rq.cam[k]; o.sg = rq.sigma[k]; return o; };
+    uint32_t k = beg + sl * kBlock + threadIdx.x;
+    const uint32_t kstep = kBlock * slices;
+    ByK cur = {};
+    if (k < end) cur = by_k(k);
+    for (; k < end; k += kstep) {
+      ByK nxt = {};
+      if (k + kstep < end) nxt = by_k(k + kstep);
+      const ByK o = cur;
+      cur = nxt;
+      const uint32_t l = o.l;
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      double r[2], Jp[12], Jl[6];
+      reproj_eval<true>(cache, cams[o.cam], X, o.px.x, o.px.y, o.sg, r, Jp, Jl);
+      double rho0, w;
+      huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+      if (o.act) {   // (a masked sighting is evaluated -- its loads were in flight anyway -- and not added: its Jacobian may be non-finite)
+        int e = 0;
+  #pragma unroll
+        for (int x = 0; x < 6; ++x) {
+  #pragma unroll
+          for (int y = 0; y <= x; ++y) acc[e++] += w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]);
+        }
+  #pragma unroll
+        for (int x = 0; x < 6; ++x) acc[21 + x] += w * (Jp[x] * r[0] + Jp[6 + x] * r[1]);
+      }
     }
-#pragma unroll
-    for (int x = 0; x < 6; ++x) acc[21 + x] += w * (Jp[x] * r[0] + Jp[6 + x] * r[1]);
+  } else {
+    for (uint32_t k = beg + sl * kBlock + threadIdx.x; k < end; k += kBlock * slices) {
+      if (!rq.active[k]) continue;
+      const uint32_t l = rq.point[k];
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      const double2 px = rq.pixel[k];
+      double r[2], Jp[12], Jl[6];
+      reproj_eval<true>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, Jp, Jl);
+      double rho0, w;
+      huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+      int e = 0;
+  #pragma unroll
+      for (int x = 0; x < 6; ++x) {
+  #pragma unroll
+        for (int y = 0; y <= x; ++y) acc[e++] += w * (Jp[x] * Jp[y] + Jp[6 + x] * Jp[6 + y]);
+      }
+  #pragma unroll
+      for (int x = 0; x < 6; ++x) acc[21 + x] += w * (Jp[x] * r[0] + Jp[6 + x] * r[1]);
+    }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -1280,23 +1313,49 @@ __global__ void __launch_bounds__(kBlock) k_backsub_apply(BlocksDev b, ReprojDev
 // ---------------------------------------------------------------------------------------
 // One workgroup per pose over the pose-ordered copy of the observations: the pose cache is uniform per workgroup (a gather
 // of it per observation, in point order, costs more L2 bandwidth than everything else the kernel reads).
+template <bool PIPE>
 __device__ __forceinline__ void cost_reproj_block(int64_t p, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* __restrict__ cams,
                                                   const PoseCache* __restrict__ pc, const double* __restrict__ points, int mode, double* scal) {
   const bool pose_var = b.pose_vid[p] >= 0;
   const PoseCache cache = pc[p];
   double cost = 0.0;
   const uint32_t beg = rq.pose_ptr[p], end = rq.pose_ptr[p + 1];
-  for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
-    if (!rq.active[k]) continue;
-    const uint32_t l = rq.point[k];
-    const bool var = pose_var || b.point_var[l] != 0;
-    if (var != (mode == 0)) continue;
-    const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
-    const double2 px = rq.pixel[k];
-    double r[2], rho0, w;
-    reproj_eval<false>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, nullptr, nullptr);
-    huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
-    cost += 0.5 * rho0;
+  if (PIPE) {
+    // A window (tens of poses, a thousand sightings each): a thread's 4-5 sightings are a chain of four dependent loads each (flag -> feature
+    // index -> its flag -> its position) and there are too few wavefronts to hide it.  Two rounds instead -- everything indexed by k, then
+    // everything indexed by the feature -- and the first round of the NEXT sighting in flight while this one is evaluated; an inactive or
+    // unwanted sighting is evaluated and not added (its data is valid, only masked).  (On the 2 000-pose problem this form is 5 us slower.)
+    struct ByK { uint32_t l; double2 px; double sg; uint16_t cam; uint8_t act; };
+    auto by_k = [&](uint32_t k) { ByK o; o.act = rq.active[k]; o.l = rq.point[k]; o.px = rq.pixel[k]; o.cam = rq.cam[k]; o.sg = rq.sigma[k]; return o; };
+    uint32_t k = beg + threadIdx.x;
+    ByK cur = {};
+    if (k < end) cur = by_k(k);
+    while (k < end) {
+      const uint32_t kn = k + kBlock;
+      ByK nxt = {};
+      if (kn < end) nxt = by_k(kn);
+      const uint32_t l = cur.l;
+      const bool var = pose_var || b.point_var[l] != 0;
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      double r[2], rho0, w;
+      reproj_eval<false>(cache, cams[cur.cam], X, cur.px.x, cur.px.y, cur.sg, r, nullptr, nullptr);
+      huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+      if (cur.act && var == (mode == 0)) cost += 0.5 * rho0;
+      cur = nxt; k = kn;
+    }
+  } else {
+    for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
+      if (!rq.active[k]) continue;
+      const uint32_t l = rq.point[k];
+      const bool var = pose_var || b.point_var[l] != 0;
+      if (var != (mode == 0)) continue;
+      const double X[3] = {points[3 * (int64_t)l], points[3 * (int64_t)l + 1], points[3 * (int64_t)l + 2]};
+      const double2 px = rq.pixel[k];
+      double r[2], rho0, w;
+      reproj_eval<false>(cache, cams[rq.cam[k]], X, px.x, px.y, rq.sigma[k], r, nullptr, nullptr);
+      huber_eval(r[0] * r[0] + r[1] * r[1], rq.huber, &rho0, &w);
+      cost += 0.5 * rho0;
+    }
   }
   block_accumulate(cost, scal, mode == 0 ? SC_COST_CAND : SC_COST_FIXED, b.deterministic);
 }
@@ -1349,10 +1408,11 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
   block_accumulate(cost, scal, mode == 0 ? SC_COST_CAND : SC_COST_FIXED, b.deterministic);
 }
 // one launch: workgroups [0, n_pose_blocks) take the reprojection factors of a pose, the rest the small factor families
+template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, SmallFactorsDev sf, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
                                                 const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ objects, int mode,
                                                 int n_pose_blocks, double* scal) {
-  if ((int)blockIdx.x < n_pose_blocks) cost_reproj_block(blockIdx.x, b, rq, cams, pc, points, mode, scal);
+  if ((int)blockIdx.x < n_pose_blocks) cost_reproj_block<PIPE>(blockIdx.x, b, rq, cams, pc, points, mode, scal);
   else cost_small_block((int64_t)blockIdx.x - n_pose_blocks, b, sf, cams, poses, objects, mode, scal);
 }
 
@@ -1582,7 +1642,10 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
   int slices = 1;
   static const int64_t slice_below = std::getenv("OBVI_POSE_PASS_SLICE_BELOW") ? std::atoll(std::getenv("OBVI_POSE_PASS_SLICE_BELOW")) : 256;   // tuning knob (poses)
   if (!b.deterministic && b.P <= slice_below) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(k_pose_pass, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
+  // few poses: the loads of a sighting in two rounds with the next sighting's first round in flight (150 registers); many poses: the plain loop
+  // (120 registers: beside the strip kernel the side stream is otherwise the longer one -- 2.02 vs 1.95 ms per LM iteration)
+  if (b.P <= slice_below) hipLaunchKernelGGL(k_pose_pass<true>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
+  else hipLaunchKernelGGL(k_pose_pass<false>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
@@ -1657,7 +1720,8 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   const unsigned grid = (unsigned)n_pose_blocks + grid_for(ns, kBlock);
   if (grid > 0) {
-    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
+    if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);   // (few poses: cost_reproj_block)
+    else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
     if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED));
   }
 }
