@@ -356,7 +356,6 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
   double zv = 0.0;
   if (tid < T) zv = pre_z ? pre_z[tid] : rhs[(int64_t)k * T + tid];
   if (pre_tile) __syncthreads();
-  if (tid < T) zsh[tid] = zv;
   for (int e = tid; e < 2 * T * 4; e += 512) s.AR2[e] = 0.0;
   if (tid < 32) s.Dsh2[tid] = 0.0;
   if (fac && c < 4) {
@@ -370,6 +369,7 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
     potrf_lookahead(nullptr, s.Wsh2 + 16, s.Dsh2, dreg, bad);
     s.AR2[c * 4 + q] = acc[0][0];
   }
+  if (tid < T) zsh[tid] = zv;   // (only read behind the panel loop; stored here so that the wait for its load does not sit in front of the tile's loads)
   __syncthreads();
   OBVI_MARK(1);
   potrf_mfma_wave<FAC>(s, I, acc, dreg, bad);
