@@ -551,38 +551,62 @@ __global__ void __launch_bounds__(kThreads) k_update(double* S, int nt, UpdateJo
 // potrf of tile column k preceded by the few products of the previous level that finish its diagonal tile and right-hand-side
 // block (pre list, may be empty): wavefronts 0-3 form A_kk - sum L_kj L_kj^T on the matrix cores, wavefronts 4-7 z_k - sum L_kj z_j;
 // the results stay in LDS and the factorisation starts from there.  512 threads, smem = 2 T LDM + T doubles.
+// one 16x16 tile (rows of tile row rt, columns of tile row w) of  A A^T, A a 64x64 tile in LDS (LDM): 16 MFMAs
+__device__ __forceinline__ void syrk_tile16(const double* A, int rt, int w, f64x4& acc) {
+  const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+  const double* Ap = A + (16 * rt + r16) * LDM + kq;
+  const double* Bp = A + (16 * w + r16) * LDM + kq;
+#pragma unroll 4
+  for (int k0 = 0; k0 < T; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k0], Bp[k0], acc, 0, 0, 0);
+}
 __device__ __forceinline__ void potrf_column(double* smem, double* S, int nt, int k, int pb, int pe, const int32_t* __restrict__ pre_j, double* Linv_all, double* rhs, double* scal) {
   if (pe == pb) { potrf_mfma_tile(smem, S, nt, k, Linv_all, rhs, scal); return; }
   double* A = smem;
   double* Ct = smem + T * LDM;
   double* zpre = smem + 2 * T * LDM;
-  const int tid = threadIdx.x;
-  f64x4 acc[4] = {};
+  const int tid = threadIdx.x, wvi = tid >> 6, lane = tid & 63;
+  // The factorisation reads the lower triangle of A_kk - sum L_kj L_kj^T only: its ten 16x16 tiles are spread over the eight wavefronts
+  // (tiles v and v + 8 of the list below: two tiles for wavefronts 0 and 1, one for the others; all four wavefronts of the first half used to
+  // form whole block columns, four tiles in the first), wavefronts 4-7 also take z_k - sum L_kj z_j.
+  //   tile list (row tile, column tile): (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3)
+  constexpr int kRt[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3}, kW[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
+  int rt0 = 0, w0 = 0, rt1 = 0, w1 = 0;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) { if (t == wvi) { rt0 = kRt[t]; w0 = kW[t]; } if (t == wvi + 8) { rt1 = kRt[t]; w1 = kW[t]; } }
+  const bool two = wvi < 2;
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double zs = 0.0;
   for (int q = pb; q < pe; ++q) {
     const int j = pre_j[q];
     __syncthreads();
     if (tid < kThreads) stage_tile(A, tile_ptr(S, nt, k, j));
     __syncthreads();
-    if (tid < kThreads) tile_abt_mfma(A, A, acc);
-    else {
+    syrk_tile16(A, rt0, w0, acc0);
+    if (two) syrk_tile16(A, rt1, w1, acc1);
+    if (tid >= kThreads) {
       const int r = (tid - kThreads) >> 2, part = tid & 3;
       const double* z = rhs + (int64_t)j * T + part * 16;
 #pragma unroll
       for (int c = 0; c < 16; ++c) zs += A[r * LDM + part * 16 + c] * z[c];
     }
   }
-  if (tid < kThreads) {
-    const int lane = tid & 63, wv = tid >> 6;
+  {
     const double* C = tile_ptr(S, nt, k, k);
+    const int q4 = lane >> 4, c16 = lane & 15;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rt0 + q4 + 4 * r, col = 16 * w0 + c16;
+      Ct[row * LDM + col] = C[row * T + col] - acc0[r];
+    }
+    if (two) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rt + (lane >> 4) + 4 * r, col = 16 * wv + (lane & 15);
-        Ct[row * LDM + col] = C[row * T + col] - acc[rt][r];
+        const int row = 16 * rt1 + q4 + 4 * r, col = 16 * w1 + c16;
+        Ct[row * LDM + col] = C[row * T + col] - acc1[r];
       }
-  } else {
+    }
+  }
+  if (tid >= kThreads) {
     const int r = (tid - kThreads) >> 2, part = tid & 3;
     zs += __shfl_xor(zs, 1, 64);
     zs += __shfl_xor(zs, 2, 64);
