@@ -937,7 +937,7 @@ void prepare(obvi_ba_handle* h) {
   for (int k = 0; k < nt; ++k) by_level[level[k]].push_back(k);
   std::vector<int32_t> lvl_k, trsm_ik, upd_ij, upd_kptr(1, 0), upd_k, rh_i, rh_kptr(1, 0), rh_k, job_signal, k_need_of(nt, 0);
   std::vector<uint8_t> upd_flag;
-  const int kUpdChunk = h->deterministic ? (1 << 30) : std::max(1, env_int("OBVI_UPD_CHUNK", 4));   // products per update job (tuning knob; deterministic mode: a target's products are never split over jobs that would meet in atomics)
+  const int kUpdChunk = h->deterministic ? (1 << 30) : std::max(1, env_int("OBVI_UPD_CHUNK", 2));   // products per update job (tuning knob; deterministic mode: a target's products are never split over jobs that would meet in atomics)
   const int64_t env_slice_max = std::getenv("OBVI_SLICE_MAX") ? std::atoi(std::getenv("OBVI_SLICE_MAX")) : 512;   // tuning knob
   // a potrf workgroup applies up to this many products of the previous level to its own diagonal tile (tuning knob)
   const size_t pre_max = (size_t)std::max(0, env_int("OBVI_PRE_MAX", 2));
