@@ -713,6 +713,53 @@ __global__ void __launch_bounds__(kBackThreads) k_backward(const double* __restr
 #pragma unroll
     for (int r = 0; r < R; ++r) x[r] = X[r * T];
   }
+  if (n <= 3) {
+    // Short chains (the default of four levels per launch): everything the chain will read -- the L^-1 rows of every step, the tiles between
+    // the ancestors, the t blocks -- is requested before the first step, so that a step is two reductions instead of a memory latency and two
+    // reductions.  Slot of the tile (ancestor u, step st): st (st - 1) / 2 + u.
+    double wv[4][R], xv[6][R], tv[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      if (st <= n) {
+        const int m = st < n ? ch[1 + st] : k;
+        const double* Li = Linv_all + (int64_t)m * (T * T) + (q * R) * T + c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[st][r] = Li[r * T];
+        tv[st] = tid < T ? t[(int64_t)m * T + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (u < st && ((bits >> (8 * st + u)) & 1ull)) {
+            const double* Xu = tile_ptr(const_cast<double*>(S), nt, ch[1 + u], m) + (q * R) * T + c;
+#pragma unroll
+            for (int r = 0; r < R; ++r) xv[st * (st - 1) / 2 + u][r] = Xu[r * T];
+          }
+      }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      if (st <= n) {
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (u < st && ((bits >> (8 * st + u)) & 1ull)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s += xv[st * (st - 1) / 2 + u][r] * ych[u][q * R + r];
+          }
+        if (st > 0) {
+          const double a = reduce(s);
+          if (tid < T) vsh[tid] = tv[st] - a;
+          __syncthreads();
+        } else {
+          if (tid < T) vsh[tid] = tv[0];
+          __syncthreads();
+        }
+        s = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s += wv[st][r] * vsh[q * R + r];   // L^-1 is lower triangular with an explicit zero upper part
+        const double a = reduce(s);
+        if (tid < T) { ych[st][tid] = a; if (st == n && j < 0) y[(int64_t)k * T + tid] = a; }
+        __syncthreads();
+      }
+  } else
   for (int st = 0; st <= n; ++st) {
     const int m = st < n ? ch[1 + st] : k;
     // all tiles of the step are loaded before the first is used
