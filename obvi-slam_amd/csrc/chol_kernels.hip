@@ -95,7 +95,7 @@ __device__ __forceinline__ void tile_abt_mfma(const double* A, const double* B, 
   const int r16 = lane & 15, kq = lane >> 4;
   const double* Bp = B + (16 * wv + r16) * LDM + kq;
   const double* Ap = A + r16 * LDM + kq;
-#pragma unroll 4
+#pragma unroll
   for (int k0 = 0; k0 < T; k0 += 4) {
     const double bv = Bp[k0];
 #pragma unroll
@@ -142,7 +142,7 @@ __device__ __forceinline__ void tile_abt_mfma_rows(const double* As, const doubl
   const int r16 = lane & 15, kq = lane >> 4;
   const double* Ap = As + r16 * LDM + kq;
   const double* Bp = B + (16 * wv + r16) * LDM + kq;
-#pragma unroll 4
+#pragma unroll
   for (int k0 = 0; k0 < T; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k0], Bp[k0], acc, 0, 0, 0);
 }
 __device__ __forceinline__ void stage_rows16(double* dst, const double* __restrict__ src) {   // 16 rows of a row-major tile -> LDS (LDM)
@@ -556,7 +556,7 @@ __device__ __forceinline__ void syrk_tile16(const double* A, int rt, int w, f64x
   const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   const double* Ap = A + (16 * rt + r16) * LDM + kq;
   const double* Bp = A + (16 * w + r16) * LDM + kq;
-#pragma unroll 4
+#pragma unroll
   for (int k0 = 0; k0 < T; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[k0], Bp[k0], acc, 0, 0, 0);
 }
 __device__ __forceinline__ void potrf_column(double* smem, double* S, int nt, int k, int pb, int pe, const int32_t* __restrict__ pre_j, double* Linv_all, double* rhs, double* scal) {
