@@ -20,15 +20,36 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// Wavefront reductions on the data-parallel-primitive path of the vector ALU (a lane reads a neighbour's register as part of a
+// v_mov: row_shr inside the rows of 16 lanes, then the two row broadcasts) instead of six rounds of ds_bpermute through the LDS crossbar:
+// 12 DPP moves of 4 cycles for a double instead of 12 LDS permutes.  The total ends up in lane 63 and is handed to every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v, double identity) {   // lanes without a source (or of a masked row) get `identity`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_last_lane(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_take<0x111, 0xf>(v, 0.0);   // row_shr:1
+  v += dpp_take<0x112, 0xf>(v, 0.0);   // row_shr:2
+  v += dpp_take<0x114, 0xf>(v, 0.0);   // row_shr:4
+  v += dpp_take<0x118, 0xf>(v, 0.0);   // row_shr:8   -> lane 15 of a row: the row's sum
+  v += dpp_take<0x142, 0xa>(v, 0.0);   // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v, 0.0);   // row_bcast:31 into rows 2 and 3  -> lane 63: the wavefront's sum
+  return wave_last_lane(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-  return v;
+  const double ninf = -__builtin_huge_val();
+  v = fmax(v, dpp_take<0x111, 0xf>(v, ninf));
+  v = fmax(v, dpp_take<0x112, 0xf>(v, ninf));
+  v = fmax(v, dpp_take<0x114, 0xf>(v, ninf));
+  v = fmax(v, dpp_take<0x118, 0xf>(v, ninf));
+  v = fmax(v, dpp_take<0x142, 0xa>(v, ninf));
+  v = fmax(v, dpp_take<0x143, 0xc>(v, ninf));
+  return wave_last_lane(v);
 }
 // a workgroup's total for scalar `sc`, one thread per workgroup: an fp64 atomic, or -- deterministic mode, ba_device.h -- the
 // workgroup's slot of the partial sums behind the scalar block (every workgroup of the grid must get here: the slots are not cleared)
