@@ -246,12 +246,13 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
       if (!FAC && I == 0 && kb + 1 < 16) potrf_lookahead(P + 4 * (kb + 1) * 4, s.Wsh2 + par * 16, s.Dsh2 + (1 - par) * 16, dreg, bad);
       const bool live = I > Ik || (I == Ik && m < 3);   // the tile row still has rows below the diagonal block
       const int Jn = m == 3 ? Ik + 1 : Ik, mn = (m + 1) & 3;   // tile column / column block of the next panel
-      const double dpad = c < 4 ? D[c * 4 + q] : 0.0;   // A operand of the panel solve: D padded to 16 x 4
-      // operand of tile row J for the trailing updates: lane (q, c) <- X[16 J + c][q], X = P D^T
+      // operand of tile row J for the trailing updates: lane (q, c) <- X[16 J + c][q], X = P D^T: row q of D (lower triangular, zeros stored)
+      // times the four panel values of row 16 J + c -- four fma per lane.  (As an MFMA with D padded to 16 x 4 the solve cost a 64-cycle
+      // slot of the matrix pipe and 17 wait states before its result could be masked, per tile and step.)
+      const double dq0 = D[q * 4], dq1 = D[q * 4 + 1], dq2 = D[q * 4 + 2], dq3 = D[q * 4 + 3];
       auto solved_rows = [&](int J) -> double {
-        f64x4 x = {};
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(dpad, P[(16 * J + c) * 4 + q], x, 0, 0, 0);
-        return x[0];
+        const double* p4 = P + (16 * J + c) * 4;
+        return fma(dq3, p4[3], fma(dq2, p4[2], fma(dq1, p4[1], dq0 * p4[0])));
       };
       const bool live2 = I >= Ik;   // ... or the rows of the diagonal block itself (their part of X = P D^T is L_kk)
       double xI = 0.0, an = 0.0;
@@ -293,16 +294,14 @@ __device__ __forceinline__ void potrf_mfma_wave(const PotrfLds& s, const int I, 
         // rows kb of W = D Acc(rows kb): lane (q, c) forms W[4 kb + q][16 J + c], the B operand it needs; the wavefront that
         // owns these rows keeps them
         const double* AR = s.AR2 + par * (T * 4);
-        const double pI = P[(16 * I + c) * 4 + q];
-        const double d0 = D[q * 4], d1 = D[q * 4 + 1], d2 = D[q * 4 + 2], d3 = D[q * 4 + 3];
+        const double d0 = dq0, d1 = dq1, d2 = dq2, d3 = dq3;
         double ar[4][4];
 #pragma unroll
         for (int J = 0; J < 4; ++J)
 #pragma unroll
           for (int t = 0; t < 4; ++t) ar[J][t] = AR[(16 * J + c) * 4 + t];
         if (live) {
-          const f64x4 x = __builtin_amdgcn_mfma_f64_16x16x4f64(dpad, pI, f64x4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-          xI = x[0];
+          xI = solved_rows(I);
           an = (16 * I + c > done) ? -xI : 0.0;
         }
 #pragma unroll
