@@ -33,6 +33,21 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
   const double c = fma(e, 0.375, 0.5);   // 1/2 + 3 e / 8
   return fma(y * e, c, y);
 }
+// sum over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15), in the row's last lane: four row shifts on the vector ALU instead of four
+// ds_bpermute round trips
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum_to_last(double v) {
+  v += dpp_row_shr<0x111>(v);
+  v += dpp_row_shr<0x112>(v);
+  v += dpp_row_shr<0x114>(v);
+  v += dpp_row_shr<0x118>(v);
+  return v;
+}
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
 // Start of an LM step, one launch: the first workgroups clear the small accumulators of the step (diagonal blocks, gradient, right-hand
@@ -400,8 +415,8 @@ __device__ __forceinline__ void potrf_mfma_rows(const int I, double* smem, doubl
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double v = zp[r];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      if (c == 0) rhs[(int64_t)k * T + 16 * I + q + 4 * r] = v;
+      v = row16_sum_to_last(v);   // the 16 lanes that share the row (a DPP row): the sum lands in lane c == 15
+      if (c == 15) rhs[(int64_t)k * T + 16 * I + q + 4 * r] = v;
     }
   }
   OBVI_MARK(4);
