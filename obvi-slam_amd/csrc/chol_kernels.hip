@@ -48,6 +48,12 @@ __device__ __forceinline__ double row16_sum_to_last(double v) {
   v += dpp_row_shr<0x118>(v);
   return v;
 }
+// sum over the four lanes of a quad, in all four (DPP quad permutes)
+__device__ __forceinline__ double quad_sum(double v) {
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+  return v;
+}
 __device__ __forceinline__ double* tile_ptr(double* S, int nt, int i, int j) { return S + ((int64_t)i * nt + j) * (T * T); }
 
 // Start of an LM step, one launch: the first workgroups clear the small accumulators of the step (diagonal blocks, gradient, right-hand
@@ -550,8 +556,7 @@ __device__ __forceinline__ void update_job(double* smem, double* S, int nt, cons
 #pragma unroll
       for (int c = 0; c < 16; ++c) s += X[c] * z[c];
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    s = quad_sum(s);
     if (part == 0) rhs[(int64_t)i * T + r] -= s;
   }
 }
@@ -622,8 +627,7 @@ __device__ __forceinline__ void potrf_column(double* smem, double* S, int nt, in
   }
   if (tid >= kThreads) {
     const int r = (tid - kThreads) >> 2, part = tid & 3;
-    zs += __shfl_xor(zs, 1, 64);
-    zs += __shfl_xor(zs, 2, 64);
+    zs = quad_sum(zs);
     if (part == 0) zpre[r] = rhs[(int64_t)k * T + r] - zs;
   }
   __syncthreads();
