@@ -29,6 +29,10 @@ __device__ __forceinline__ double dpp_take(double v, double identity) {   // lan
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {   // a quad permute of a double (all four lanes of a quad are sources: no identity needed)
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ double wave_last_lane(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
@@ -1255,7 +1259,11 @@ __device__ __forceinline__ void point_backsub_block(int64_t block, int64_t strid
         for (int x = 0; x < 6; ++x) { const double yx = on * y[x]; t0 -= Z[3 * x] * yx; t1 -= Z[3 * x + 1] * yx; t2 -= Z[3 * x + 2] * yx; }
       }
 #pragma unroll
-      for (int m = 1; m < G; m <<= 1) { t0 += __shfl_xor(t0, m); t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
+      for (int m = 1; m < G; m <<= 1) {   // butterfly over the G lanes of the feature: inside a quad by DPP quad permutes, beyond it through ds_bpermute
+        if (m == 1) { t0 += dpp_quad<0xB1>(t0); t1 += dpp_quad<0xB1>(t1); t2 += dpp_quad<0xB1>(t2); }        // quad_perm:[1,0,3,2]
+        else if (m == 2) { t0 += dpp_quad<0x4E>(t0); t1 += dpp_quad<0x4E>(t1); t2 += dpp_quad<0x4E>(t2); }   // quad_perm:[2,3,0,1]
+        else { t0 += __shfl_xor(t0, m); t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
+      }
       if (g == 0) {
         t0 += pt.u[3 * l]; t1 += pt.u[3 * l + 1]; t2 += pt.u[3 * l + 2];
         const double* Ci = pt.Ci + 6 * l;
