@@ -175,12 +175,12 @@ __device__ __forceinline__ void stage_rows16(double* dst, const double* __restri
 }
 
 // ---------------------------------------------------------------------------------------
-// potrf of one 64x64 tile with the panel solve and the trailing updates on the matrix cores.
+// potrf of one 64x64 tile with the trailing updates on the matrix cores.
 // A right-looking panel of 4 columns is exactly the K of v_mfma_f64_16x16x4_f64, so per panel step kb:
 //   (a) the 4x4 diagonal block is factorised and its factor inverted (D)                        [scalar, the serial part]
 //   (b) the solved panel X = P D^T (P = current panel columns) is never stored as a matrix: a wavefront that needs the rows of
-//       tile row J as an MFMA operand computes X_J^T = D P_J^T with one MFMA whose first result register IS that operand
-//       (lane (k, n) holds X[16 J + n][k], the A and B fragment layout alike), so nothing goes through LDS in between
+//       tile row J as an MFMA operand forms them itself, lane (k, n) <- X[16 J + n][k] = row k of D times the four panel values of
+//       row 16 J + n (four fma; the A and B fragment layout alike), so nothing goes through LDS in between
 //   (c) trailing matrix  A -= X X^T  and  Acc -= X W  (W rows = D Acc rows, four fma per lane, again directly in B fragment
 //       layout):  one MFMA per 16x16 tile, finished rows / columns masked out of the operands
 // The trailing matrices stay in registers in the MFMA accumulator layout (a wavefront owns a tile row; wavefronts 0-3 A,
@@ -191,7 +191,8 @@ __device__ __forceinline__ void stage_rows16(double* dst, const double* __restri
 // the panel times D_kb^T -- 24 fma on 16 lanes -- so one wavefront (accumulator row 0, idle after the first four steps) forms
 // and factorises it during step kb, while the others run the update, and D_kb+1 is in LDS when step kb + 1 starts.
 // The loop's critical path is that wavefront's chain D_kb -> D_kb+1 (about 130 dependent fp64 instructions) or the heaviest
-// tile row, whichever is longer (scripts/potrf_bench.hip: 17.0 -> 15.4 us for one tile with the look-ahead).
+// tile row, whichever is longer (scripts/potrf_bench.hip: 17.0 -> 15.4 us for one tile with the look-ahead, 14.2 us with (b) as fma instead of
+// an MFMA per tile row and the epilogue's row sums on DPP moves).
 // ONE workgroup barrier per panel step; P, W, D and the published accumulator rows alternate between two buffers.
 // Fragment layout: A: lane l -> A[l&15][l>>4]; B: lane l -> B[l>>4][l&15]; D: lane l, reg r -> D[(l>>4) + 4r][l&15].
 // ---------------------------------------------------------------------------------------
