@@ -435,6 +435,7 @@ __device__ __forceinline__ void potrf_mfma_tile(double* smem, double* S, int nt,
   // SIMD: the look-ahead wavefront (accumulator row 0) sits beside tile row 0 of A, which is finished after four steps, and the heavy
   // rows of the two halves do not meet.  Two instruction streams (A / accumulator), tile row wave-uniform; both execute the same barriers.
   const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wvi == 4) __builtin_amdgcn_s_setprio(3);   // the look-ahead wavefront's chain is the critical path of the panel loop
   if (wvi < 4) potrf_mfma_rows<true>(wvi, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
   else potrf_mfma_rows<false>((8 - wvi) & 3, smem, S, nt, k, Linv_all, rhs, scal, pre_tile, pre_z);
 }
