@@ -140,6 +140,11 @@ struct PointDev {           // per eliminated point
 };
 
 // ---- launchers (ba_kernels.hip) --------------------------------------------------------
+// obvi_ba_set_reproj: the arrays only the device reads (camera, pixel, sigma), in both observation orders (by point: a -> perm[a]; by pose:
+// k -> perm[rq_src[k]]), gathered from the caller's order on the device; raw_cam / raw_sigma may be null (camera 0 / one sigma for all)
+void launch_reproj_gather(hipStream_t s, int64_t n, const uint32_t* perm, const uint32_t* rq_src, const uint32_t* rp_point, const uint16_t* raw_cam,
+                          const double2* raw_pixel, const double* raw_sigma, double sigma_scalar, uint16_t* cam, double2* pixel, double* sigma,
+                          uint32_t* q_point, uint16_t* q_cam, double2* q_pixel, double* q_sigma, uint8_t* q_active);
 void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out, int analytic /* obvi_ba_options.reprojection_variant == OBVI_REPROJECTION_ANALYTIC */);
 void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,

@@ -132,6 +132,20 @@ __device__ __forceinline__ double lm_lambda(double colsq, double scale, double r
 }
 
 // ---------------------------------------------------------------------------------------
+
+// obvi_ba_set_reproj: camera / pixel / sigma of every observation in the two orders the kernels stream them in (launch_reproj_gather)
+__global__ void __launch_bounds__(kBlock) k_reproj_gather(int64_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rq_src, const uint32_t* __restrict__ rp_point,
+                                                         const uint16_t* __restrict__ raw_cam, const double2* __restrict__ raw_pixel, const double* __restrict__ raw_sigma,
+                                                         double sigma_scalar, uint16_t* __restrict__ cam, double2* __restrict__ pixel, double* __restrict__ sigma,
+                                                         uint32_t* __restrict__ q_point, uint16_t* __restrict__ q_cam, double2* __restrict__ q_pixel, double* __restrict__ q_sigma,
+                                                         uint8_t* __restrict__ q_active) {
+  const int64_t a = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  if (a >= n) return;
+  const uint32_t b = rq_src[a];
+  const uint32_t i = perm[a], j = perm[b];
+  cam[a] = raw_cam ? raw_cam[i] : (uint16_t)0; pixel[a] = raw_pixel[i]; sigma[a] = raw_sigma ? raw_sigma[i] : sigma_scalar;
+  q_point[a] = rp_point[b]; q_cam[a] = raw_cam ? raw_cam[j] : (uint16_t)0; q_pixel[a] = raw_pixel[j]; q_sigma[a] = raw_sigma ? raw_sigma[j] : sigma_scalar; q_active[a] = 1;
+}
 __global__ void __launch_bounds__(kBlock) k_pose_cache(int64_t P, const double* __restrict__ poses, PoseCache* __restrict__ out, int analytic) {
   const int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   if (p >= P) return;
@@ -1646,6 +1660,12 @@ void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t sc
   if (nblocks > 0) hipLaunchKernelGGL(k_det_reduce, dim3(kDetSlots), dim3(kBlock), 0, s, scal, nblocks, scalar_mask);
 }
 #define OBVI_SC(x) (1u << (x))
+void launch_reproj_gather(hipStream_t s, int64_t n, const uint32_t* perm, const uint32_t* rq_src, const uint32_t* rp_point, const uint16_t* raw_cam,
+                          const double2* raw_pixel, const double* raw_sigma, double sigma_scalar, uint16_t* cam, double2* pixel, double* sigma,
+                          uint32_t* q_point, uint16_t* q_cam, double2* q_pixel, double* q_sigma, uint8_t* q_active) {
+  if (n > 0) hipLaunchKernelGGL(k_reproj_gather, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, perm, rq_src, rp_point, raw_cam, raw_pixel, raw_sigma, sigma_scalar, cam, pixel, sigma,
+                                q_point, q_cam, q_pixel, q_sigma, q_active);
+}
 void launch_pose_cache(hipStream_t s, int64_t P, const double* poses, PoseCache* out, int analytic) {
   if (P > 0) hipLaunchKernelGGL(k_pose_cache, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, P, poses, out, analytic);
 }

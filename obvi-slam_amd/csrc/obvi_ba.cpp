@@ -98,6 +98,7 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_rp_active;
   DevBuf<int32_t> d_rp_yrow;             // per observation: row of its pose in the reduced system (prepare())
   DevBuf<uint32_t> d_rq_point, d_rq_pose_ptr;
+  DevBuf<uint16_t> d_raw_cam; DevBuf<double2> d_raw_pixel; DevBuf<double> d_raw_sigma; DevBuf<uint32_t> d_rq_src;   // obvi_ba_set_reproj: the caller's arrays as they came + the by-pose order, sources of the gather on the device
   DevBuf<uint16_t> d_rq_cam;
   DevBuf<double2> d_rq_pixel;
   DevBuf<double> d_rq_sigma;
@@ -1686,19 +1687,16 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   h->max_rp_pose = max_index(pose_idx, n); h->max_rp_point = max_index(point_idx, n); h->max_rp_cam = cam_idx ? max_index(cam_idx, n) : (n > 0 ? 0 : -1);
   h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
   hipStream_t s = h->stream;
-  // the arrays only the device reads: filled in the staging arena when it has room, in scratch vectors otherwise
-  struct Spill { std::vector<uint16_t> cam, q_cam; std::vector<double2> pix, q_pix; std::vector<double> sg, q_sg; std::vector<uint32_t> q_point; std::vector<uint8_t> q_act; } spill;
-  auto staged = [&](auto& dev, auto& fallback, size_t count) { auto* q = dev.stage_begin(count); if (!q) { fallback.resize(count); q = fallback.data(); } return q; };
-  uint16_t* cam = staged(h->d_rp_cam, spill.cam, (size_t)n);
-  double2* pix = staged(h->d_rp_pixel, spill.pix, (size_t)n);
-  double* sg = staged(h->d_rp_sigma, spill.sg, (size_t)n);
+  // the arrays only the device reads (camera, pixel, sigma) go up the way they came and are put in both observation orders by a kernel
+  // (launch_reproj_gather); the host keeps and permutes the index arrays its symbolic phase reads
+  if (cam_idx) h->d_raw_cam.upload(cam_idx, (size_t)n, s);
+  h->d_raw_pixel.upload(reinterpret_cast<const double2*>(pixel), (size_t)n, s);
+  if (sigma) h->d_raw_sigma.upload(sigma, (size_t)n, s);
   parallel_ranges(n, threads, [&](int, int64_t a0, int64_t a1) {
     for (int64_t a = a0; a < a1; ++a) {
       const uint32_t i = perm[a];
       h->h_rp_inv[i] = (uint32_t)a;
-      h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i]; cam[a] = cam_idx ? cam_idx[i] : 0;
-      pix[a] = make_double2(pixel[2 * (int64_t)i], pixel[2 * (int64_t)i + 1]);
-      sg[a] = sigma ? sigma[i] : sigma_scalar;
+      h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i];
     }
   });
   sub("    set_reproj: gather");
@@ -1723,32 +1721,23 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   }
   sub("    set_reproj: wave pieces");
   h->d_rp_pose.upload(h->h_rp_pose, s); h->d_rp_point.upload(h->h_rp_point, s); h->d_rp_perm.upload(perm, s); h->d_point_ptr.upload(ptr, s);
-  h->d_rp_cam.stage_commit(cam, (size_t)n, s); h->d_rp_pixel.stage_commit(pix, (size_t)n, s); h->d_rp_sigma.stage_commit(sg, (size_t)n, s);
   h->d_rp_active.upload(h->h_rp_active, s);
   sub("    set_reproj: upload by point");
-  // CSR-by-pose copy for the pose-side pass (counting sort on the pose index; stable, so points ascend inside a pose)
+  // CSR-by-pose order for the pose-side pass (counting sort on the pose index; stable, so points ascend inside a pose)
   std::vector<uint32_t>& pptr = h->scr_pose_ptr;
   pptr.assign(h->P + 1, 0);
   h->h_rq_src.resize(n);
   for (int64_t a = 0; a < n; ++a) pptr[h->h_rp_pose[a] + 1]++;
   for (int64_t p = 0; p < h->P; ++p) pptr[p + 1] += pptr[p];
-  uint32_t* q_point = staged(h->d_rq_point, spill.q_point, (size_t)n);
-  uint16_t* q_cam = staged(h->d_rq_cam, spill.q_cam, (size_t)n);
-  double2* q_pix = staged(h->d_rq_pixel, spill.q_pix, (size_t)n);
-  double* q_sg = staged(h->d_rq_sigma, spill.q_sg, (size_t)n);
-  uint8_t* q_act = staged(h->d_rq_active, spill.q_act, (size_t)n);
-  {
-    cur.assign(pptr.begin(), pptr.end() - 1);
-    for (int64_t a = 0; a < n; ++a) h->h_rq_src[cur[h->h_rp_pose[a]]++] = (uint32_t)a;
-    parallel_ranges(n, threads, [&](int, int64_t k0, int64_t k1) {
-      for (int64_t k = k0; k < k1; ++k) { const uint32_t a = h->h_rq_src[k]; q_point[k] = h->h_rp_point[a]; q_cam[k] = cam[a]; q_pix[k] = pix[a]; q_sg[k] = sg[a]; q_act[k] = 1; }
-    });
-  }
+  cur.assign(pptr.begin(), pptr.end() - 1);
+  for (int64_t a = 0; a < n; ++a) h->h_rq_src[cur[h->h_rp_pose[a]]++] = (uint32_t)a;
   sub("    set_reproj: by pose");
-  h->d_rq_point.stage_commit(q_point, (size_t)n, s); h->d_rq_cam.stage_commit(q_cam, (size_t)n, s); h->d_rq_pixel.stage_commit(q_pix, (size_t)n, s);
-  h->d_rq_sigma.stage_commit(q_sg, (size_t)n, s); h->d_rq_active.stage_commit(q_act, (size_t)n, s); h->d_rq_pose_ptr.upload(pptr, s);
-  if (!spill.cam.empty() || !spill.pix.empty() || !spill.sg.empty() || !spill.q_point.empty() || !spill.q_cam.empty() || !spill.q_pix.empty() || !spill.q_sg.empty() || !spill.q_act.empty())
-    h->staging.spilled = true;   // a copy went out of pageable memory: finish_upload waits
+  h->d_rq_src.upload(h->h_rq_src, s); h->d_rq_pose_ptr.upload(pptr, s);
+  h->d_rp_cam.resize((size_t)n); h->d_rp_pixel.resize((size_t)n); h->d_rp_sigma.resize((size_t)n);
+  h->d_rq_point.resize((size_t)n); h->d_rq_cam.resize((size_t)n); h->d_rq_pixel.resize((size_t)n); h->d_rq_sigma.resize((size_t)n); h->d_rq_active.resize((size_t)n);
+  launch_reproj_gather(s, n, h->d_rp_perm.get(), h->d_rq_src.get(), h->d_rp_point.get(), cam_idx ? h->d_raw_cam.get() : nullptr, h->d_raw_pixel.get(), sigma ? h->d_raw_sigma.get() : nullptr,
+                       sigma_scalar, h->d_rp_cam.get(), h->d_rp_pixel.get(), h->d_rp_sigma.get(), h->d_rq_point.get(), h->d_rq_cam.get(), h->d_rq_pixel.get(), h->d_rq_sigma.get(),
+                       h->d_rq_active.get());
   finish_upload(h);
   sub("    set_reproj: upload by pose + finish");
   h->dirty = true;
