@@ -1,5 +1,6 @@
-run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-deterministic-leg 2>/dev/null | python -c "
+#!/bin/bash
 # usage (GPU box, repo root): bash scripts/sweep_final.sh  -- one bench line per value of the plan / schedule knobs (ms per LM step, reduced solve, strip kernel)
+run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-deterministic-leg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); p=d['phases_ms_avg']
 print(sys.argv[1], 'ms/step %.4f' % d['ms_per_step'], 'chol', p['cholesky_solve'], 'schur', p['schur_window'])" "$1"; }
