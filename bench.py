@@ -322,11 +322,36 @@ def main():
         synth.upload(ba, prob)      # back to the initial values for the group solve
     if shared:
         is_shared = np.ones(len(prob["objects"]), np.uint8)
+        def all_ranks_ok(flag):     # one rank without the compiled hook must not leave the others waiting in a collective
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
         if args.hook == "rccl":
             # the job's ncclUniqueId travels over the launcher's process group; the data path then never touches Python
-            ids = [dist_util.RcclComm.unique_id() if rank == 0 else None]
+            my_id, err = None, None
+            try:
+                my_id = dist_util.RcclComm.unique_id()      # (every rank: shows that the library loads; rank 0's id is the job's)
+            except Exception as e:                          # noqa: BLE001 -- reported below, the run goes on with the other hook
+                err = e
+            if not all_ranks_ok(err is None):
+                if rank == 0:
+                    print("bench.py: libobvi_rccl.so unusable on some rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
+                args.hook = "torch"
+        if args.hook == "rccl":
+            ids = [my_id if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
+            try:
+                comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
+            except Exception as e:                          # noqa: BLE001
+                comm, err = None, e
+            if not all_ranks_ok(comm is not None):
+                if comm is not None:
+                    comm.close()
+                comm = None
+                if rank == 0:
+                    print("bench.py: the RCCL communicator of libobvi_rccl.so could not be formed on every rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
+                args.hook = "torch"
+        if args.hook == "rccl":
             comm.attach(ba, is_shared)
             rccl_ranks = comm.world()
         else:
