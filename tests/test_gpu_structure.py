@@ -250,6 +250,41 @@ def test_uploads_outlive_their_source_buffers_and_the_staging_arena_wraps():
     assert np.array_equal(g.get_points(), big_copy)
 
 
+def test_reprojection_upload_forms_scalar_sigma_default_camera_empty_and_reused_buffers():
+    """obvi_ba_set_reproj takes sigma as an array or as one number, camera indices as an array or not at all (camera 0), and n = 0; the
+    arrays only the device reads go up in the caller's order and a kernel permutes them (k_reproj_gather), so the caller's buffers are
+    free the moment the call returns.  All forms of the same problem evaluate to the same residuals, bit for bit; the oracle agrees."""
+    prob = synth.make_problem(P=30, L=900, O=3, seed=23, bbox_noise=2.0)
+    prob["rp_cam"] = np.zeros_like(prob["rp_cam"]); prob["rp_sigma"] = np.full(len(prob["rp_pose"]), 1.75)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    c0, r0, q0 = g.evaluate(True)
+    o = helpers.oracle_ba(); synth.upload(o, prob)
+    assert abs(o.evaluate(True, False)[0] - c0) <= 1e-12 * c0
+    # one sigma for all, no camera indices
+    g.set_reproj(prob["rp_pose"], prob["rp_point"], None, prob["rp_pixel"], 1.75, prob["rp_huber"])
+    c1, r1, q1 = g.evaluate(True)
+    assert abs(c1 - c0) <= 1e-13 * c0 and np.array_equal(r1, r0) and np.array_equal(q1, q0)   # (the cost is a sum of atomics: last bits)
+    # the caller scribbles over its buffers right behind the call
+    pose, point, cam = prob["rp_pose"].copy(), prob["rp_point"].copy(), prob["rp_cam"].copy()
+    pix, sig = prob["rp_pixel"].copy(), prob["rp_sigma"].copy()
+    g.set_reproj(pose, point, cam, pix, sig, prob["rp_huber"])
+    pix[:] = -1e9; sig[:] = 1e-9; cam[:] = 0
+    c2, r2, _ = g.evaluate(True)
+    assert abs(c2 - c0) <= 1e-13 * c0 and np.array_equal(r2, r0)
+    # a shuffled factor order is the same problem: residuals come back in the caller's order
+    perm = np.random.default_rng(5).permutation(len(pose))
+    g.set_reproj(prob["rp_pose"][perm], prob["rp_point"][perm], prob["rp_cam"][perm], prob["rp_pixel"][perm], prob["rp_sigma"][perm], prob["rp_huber"])
+    c3, r3, _ = g.evaluate(True)
+    n2 = 2 * len(pose)
+    assert abs(c3 - c0) <= 1e-13 * c0 and np.array_equal(r3[:n2].reshape(-1, 2), r0[:n2].reshape(-1, 2)[perm])
+    # no reprojection factors at all
+    g.set_reproj(pose[:0], point[:0], None, pix[:0], 1.0, prob["rp_huber"])
+    c4, r4, _ = g.evaluate(True)
+    assert len(r4) == len(r0) - n2 and 0.0 < c4 < c0
+    s = g.solve(helpers.ba_params(max_it=3))
+    assert s.final_cost <= s.initial_cost
+
+
 def test_two_launch_schedule_of_the_tile_cholesky(monkeypatch):
     """OBVI_FUSED_POTRF=0: update jobs of a level and the potrf of the next level as two launches (nothing waits inside a launch);
     same steps as the fused schedule and as the oracle.  The knob is read once per process, so this runs in a child process."""
