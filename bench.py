@@ -91,6 +91,25 @@ def rocprof_avg_us(kernel, man):
     return None
 
 
+def pmc_step_bytes(man, table):
+    """HBM bytes of one LM step by the committed PMC passes: bytes per launch x launches per step, over every kernel that has both."""
+    if man is None:
+        return None
+    try:
+        per = json.load(open(os.path.join(ROOT, "profiles", man["files"]["pmc_traffic"]))).get("kernels", {})
+    except (ValueError, OSError, KeyError, TypeError):
+        return None
+    alias = {"point_pass": "k_point_pass", "pose_pass": "k_pose_pass", "schur_window": "k_schur_window", "schur_blocks": "k_schur_blocks", "point_backsub": "k_backsub_apply",
+             "cost": "k_cost", "small_factors": "k_small_lin_lanes", "k_trsm": "k_trsm", "k_update_potrf": "k_update_potrf", "k_backward": "k_backward", "k_potrf": "k_potrf"}
+    tot, seen = 0.0, 0
+    for name, row in table.items():
+        e = per.get(alias.get(name, name))
+        if e and e.get("hbm_bytes_per_launch") is not None:
+            tot += e["hbm_bytes_per_launch"] * row["launches_per_step"]
+            seen += 1
+    return tot if seen else None
+
+
 def sq_counters(kernel, man):
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", man["files"]["sq_counters"])))["kernels"].get(kernel if kernel.startswith("k_") else "k_" + kernel)
@@ -99,7 +118,33 @@ def sq_counters(kernel, man):
         return None
 
 
-def cpu_baseline(prob, budget_iters=3):
+def parity_vs_oracle(oracle_its, legs):
+    """HIP against the oracle on THIS workload, for the LM steps the oracle's bounded run made (cpu_baseline leg: the oracle is the
+    checker here, as in tests/test_gpu_parity.py::test_config3_follows_the_oracle_for_two_steps).  Per leg (default / deterministic
+    handle) and step: relative difference of cost, step norm, relative decrease, and whether the accept flags agree."""
+    def rel(a, b):
+        return abs(a - b) / max(abs(b), 1e-300)
+    out = {}
+    for name, its in legs.items():
+        if not its:
+            continue
+        rows = []
+        for k in range(min(len(its), len(oracle_its))):
+            g, o = its[k], oracle_its[k]
+            row = {"step": k, "cost_rel": rel(g.cost, o.cost)}
+            if k > 0:
+                row.update(step_norm_rel=rel(g.step_norm, o.step_norm), relative_decrease_abs=abs(g.relative_decrease - o.relative_decrease),
+                           same_decision=bool(g.step_is_successful == o.step_is_successful and g.step_is_valid == o.step_is_valid),
+                           radius_rel=rel(g.trust_region_radius, o.trust_region_radius))
+            rows.append(row)
+        out[name] = rows
+    out["note"] = ("step 0 = initial cost (same arithmetic: 1e-12); step 1 = one reduced solve from identical values (measured 1e-9 .. 1e-8: the "
+                   "conditioning of S times round-off); from step 2 on the difference of step 1 is amplified by this ill-conditioned problem "
+                   "(free gauge, zero tolerances, non-monotonic steps) -- DESIGN.md section 6 has the extended-precision arbiter")
+    return out
+
+
+def cpu_baseline(prob, budget_iters=3, legs=None):
     """The CPU oracle on the same problem, on the host cores of this box: min(20, hardware threads) threads -- 20 is the reference's
     own Solver::Options::num_threads (object_pose_graph_optimizer.h:662) -- bounded to a few LM iterations.  The rate is taken
     from the per-iteration records of iterations 1..K (the initial evaluation, which also first-touches the oracle's
@@ -121,7 +166,7 @@ def cpu_baseline(prob, budget_iters=3):
     steady = sum(i.iteration_time_in_seconds for i in its[1:])
     n = max(1, len(its) - 1)
     ceres = ceres_harness(prob, budget_iters, threads)
-    return {"value": n / steady, "unit": "LM iterations/s", "cores": threads, "kind": "port",
+    return {"parity_vs_oracle": parity_vs_oracle(its, legs or {}), "value": n / steady, "unit": "LM iterations/s", "cores": threads, "kind": "port",
             "sample": "%d LM iterations of the same problem (oracle/libobvi_oracle.so, fp64, %d host threads of %d; %.1f s wall incl. %.1f s "
                       "initial evaluation)" % (n, threads, os.cpu_count() or 1, dt, dt - steady),
             "ms_per_step": 1e3 * steady / n, "reference_ceres": ceres}
@@ -245,6 +290,46 @@ def end_to_end_global_ba(obvi_ba, synth, prob, device):
                     "of this process (Python binding included), inputs start on the host"}
 
 
+def collective_latency(torch, ba, comm, dist, args, prob, world, reps=50):
+    """Microseconds per all-reduce of the three per-step sizes of the config-4 exchange (shared objects' blocks 56 doubles each; the shared
+    tail tiles + right-hand side; the scalar sums + one slot per rank), on the live communicator / process group, back to back on one stream.
+    A window step is ~0.4 ms: this is the latency budget the three collectives take out of it."""
+    import ctypes
+    n_sh = len(prob["objects"])
+    ntail = -(-7 * n_sh // 64)
+    sizes = {"shared_blocks": 56 * n_sh, "shared_tail": ntail * (ntail + 1) // 2 * 64 * 64 + ntail * 64, "scalars": 9 + world}
+    out = {}
+    st = torch.cuda.Stream()
+    for name, n in sizes.items():
+        buf = torch.zeros(max(1, n), dtype=torch.float64, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if comm is not None:
+            fn = lambda: comm._lib.obvi_rccl_allreduce(comm._c, ctypes.c_void_p(buf.data_ptr()), ctypes.c_int64(n), ctypes.c_int32(0), ctypes.c_void_p(st.cuda_stream))   # noqa: E731
+        elif args.oversubscribe:
+            hook = dist_util_staged(dist)
+            fn = lambda: hook(buf.data_ptr(), n, 0, st.cuda_stream)   # noqa: E731
+        else:
+            def fn():
+                with torch.cuda.stream(st):
+                    dist.all_reduce(buf)
+        for _ in range(5):
+            fn()
+        st.synchronize()
+        t0 = time.perf_counter()
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        st.synchronize()
+        out[name] = {"doubles": n, "us_stream": round(1e3 * e0.elapsed_time(e1) / reps, 2), "us_host": round(1e6 * (time.perf_counter() - t0) / reps, 2)}
+    return out
+
+
+def dist_util_staged(dist):
+    import dist_util
+    return dist_util.staged_allreduce(dist)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,6 +337,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="default: 3 on one GPU, 4 (windows sharing objects, RCCL all-reduce) on several")
     ap.add_argument("--hook", choices=("rccl", "torch"), default="rccl", help="all-reduce callback of config 4: libobvi_rccl.so (compiled) or torch.distributed")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="N > 1 on ONE GPU: every rank uses device 0, the process group is gloo and the exchange goes through dist_util.staged_allreduce "
+                         "(device -> host -> gloo -> device).  Not a measurement of scaling: it exercises the whole N > 1 code path of this script where "
+                         "only one GPU exists (tests/test_gpu_shared_objects.py runs it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the deterministic-mode timing of the same steps")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end two-phase global BA (config 3, one GPU; about 2 s)")
@@ -277,13 +366,20 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    if args.oversubscribe:
+        local_rank = 0
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit("bench.py: rank %d needs device %d but only %d visible (one process per GPU)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.oversubscribe:
+            dist.init_process_group(backend="gloo")
+            args.hook = "staged-gloo"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ddev = "cpu" if args.oversubscribe else "cuda"      # where the launcher group's own small tensors live
     if args.config is None:
         args.config = 3 if world == 1 else 4
 
@@ -302,6 +398,8 @@ def main():
     rccl_ranks = None
     comm = None
     scaling_baseline = None
+    rccl_versions = None
+    issue_log = dist_util.IssueLog()
     if shared:
         # the N = 1 point of THIS workload (the driver's N = 1 run is the config-3 headline, another problem): every rank solves its own
         # window alone -- no exchange attached yet, shared objects are ordinary objects -- for the same steps, before the group solve
@@ -313,7 +411,7 @@ def main():
         s1 = ba.solve(solver_params(obvi_ba, args.steps))
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t0
-        tt = torch.tensor([dt1, float(s1.num_iterations - 1)], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt1, float(s1.num_iterations - 1)], dtype=torch.float64, device=ddev)
         lst = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(lst, tt)
         per_rank = [(float(x[1]) / float(x[0])) for x in lst]
@@ -323,13 +421,18 @@ def main():
     if shared:
         is_shared = np.ones(len(prob["objects"]), np.uint8)
         def all_ranks_ok(flag):     # one rank without the compiled hook must not leave the others waiting in a collective
-            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda")
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=ddev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item() > 0.5)
         if args.hook == "rccl":
             # the job's ncclUniqueId travels over the launcher's process group; the data path then never touches Python
             my_id, err = None, None
             try:
+                # libobvi_rccl.so resolves /opt/rocm/lib/librccl while torch has mapped its own librccl.so: only the same build on both sides
+                ok, ours, theirs = dist_util.RcclComm.check_against_torch()
+                rccl_versions = {"libobvi_rccl": ours, "torch": theirs}
+                if not ok:
+                    raise RuntimeError("libobvi_rccl.so resolves RCCL %s, torch.distributed uses %s" % (ours, theirs))
                 my_id = dist_util.RcclComm.unique_id()      # (every rank: shows that the library loads; rank 0's id is the job's)
             except Exception as e:                          # noqa: BLE001 -- reported below, the run goes on with the other hook
                 err = e
@@ -356,7 +459,7 @@ def main():
             rccl_ranks = comm.world()
         else:
             ba.set_shared_objects(is_shared, rank, world)
-            ba.set_allreduce(dist_util.torch_allreduce(dist))
+            ba.set_allreduce(dist_util.staged_allreduce(dist, issue_log) if args.oversubscribe else dist_util.torch_allreduce(dist, issue_log))
             rccl_ranks = dist.get_world_size()
     t_sym = time.perf_counter()
     ba.evaluate(True, False)        # builds the reduced-program bookkeeping / symbolic plan (not timed: the reference times "build" separately)
@@ -379,7 +482,17 @@ def main():
     dt = time.perf_counter() - t0
     ba_timed_iterations = ba.iterations()
     steps_done = summ.num_iterations - 1
-    dt, steps_done = dist_util.reduce_timing(dist, "cuda", dt, steps_done)
+    dt, steps_done = dist_util.reduce_timing(dist, ddev, dt, steps_done)
+    # one communicator, two streams (first collective of a step on the side stream, the other two on the main stream): legal only if every rank
+    # issues the same collectives in the same host order -- compared here, after the timed solve
+    issue_order = None
+    if shared:
+        calls = comm.sequence()[0] if comm is not None else issue_log.calls
+        same = comm.same_issue_order() if comm is not None else dist_util.same_issue_order(dist, issue_log.calls, issue_log.digest())
+        issue_order = {"collectives_issued": calls, "same_on_every_rank": bool(same)}
+        if not same:
+            raise SystemExit("bench.py: the ranks issued different sequences of collectives")
+    collectives_us = collective_latency(torch, ba, comm, dist, args, prob, world) if shared else None
 
     # Device timings come from two more solves of the same K steps, outside the timed region (the timed solve records no
     # events at all): level 1 = one HIP event pair per phase of an LM step, same schedule as the timed solve (side stream on);
@@ -394,6 +507,7 @@ def main():
     p1 = ba.kernel_times()
     ba.set_profiling(0)
 
+    det_first = None
     if rank == 0:
         pst = ba.problem_stats()
         n_r, n_b = pst["reproj_active"], pst["bbox_active"]
@@ -408,11 +522,13 @@ def main():
             "cost": n_r * 32.0,
             "small_factors": n_b * (168.0 + 672.0),
         }
-        nlev = max(pst["chol_levels"], 1.0)
-        flops = {   # per launch = per level of the tile elimination tree
-            "k_trsm": pst["trsm_jobs"] * t3 / nlev,
+        # flops of ONE launch = the factorisation's total / the launches of that kernel per factorisation (chol_levels levels: a k_trsm and a
+        # k_update_potrf launch for every level but the last; the first level's potrf is its own launch)
+        nlaunch = max(pst["chol_levels"] - 1.0, 1.0)
+        flops = {
+            "k_trsm": pst["trsm_jobs"] * t3 / nlaunch,
             # updates of a level + factor and inverse of the next level's diagonal tiles, one launch
-            "k_update_potrf": (pst["update_jobs"] * 2.0 * t3 + pst["tiles_per_dim"] * (2.0 * t3 / 3.0)) / nlev,
+            "k_update_potrf": (pst["update_jobs"] * 2.0 * t3 + pst["tiles_per_dim"] * (2.0 * t3 / 3.0)) / nlaunch,
         }
         def delta(k1_, k0_):
             out = {}
@@ -426,7 +542,8 @@ def main():
         phases = delta(k1, k0)
         kern = delta(p1, p0)
         kern.pop("cholesky_solve", None)           # replaced by its kernels
-        steps_prof = max(1, kern["point_pass"]["launches"])
+        # steps of the instrumented solve that factorise (the submission at the iteration cap linearises only: it has a point pass and nothing else)
+        steps_prof = max(1, kern["point_backsub"]["launches"] if "point_backsub" in kern else kern["point_pass"]["launches"])
         table = {}
         for name, v in kern.items():
             row = {"avg_us": round(1e3 * v["ms_avg"], 2), "launches_per_step": round(v["launches"] / steps_prof, 1), "ms_per_step": round(v["ms_total"] / steps_prof, 4)}
@@ -461,6 +578,15 @@ def main():
                         "boundary, about 3 us) in an instrumented solve of the same steps in THIS run; traffic, rocprof_avg_us and sq come from the "
                         "rocprofv3 passes committed under profiles/ and are null when profiles/manifest.json was not measured on the kernel sources "
                         "this run uses (profiles.stale says why)"}
+        ms_step = 1e3 * dt / max(steps_done, 1)
+        alg_step = n_r * 496.0 + n_b * 1008.0             # B_step without B_S
+        pmc_step = pmc_step_bytes(fresh, table)
+        roof["step"] = {"alg_bytes": alg_step, "pmc_bytes": pmc_step, "ms": round(ms_step, 4),
+                        "achieved_gbs": round(alg_step / (ms_step * 1e-3) / 1e9, 1),
+                        "frac_of_peak": round(alg_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "frac_of_measured": round(alg_step / (ms_step * 1e-3) / 1e9 / peaks["hbm_triad_gbs"], 4),
+                        "note": "whole LM step: algorithmic bytes N_r 496 + N_b 1008 (SURVEY 8d) over the TIMED ms per step, against the 8 TB/s public figure and the "
+                                "triad measured in this run; pmc_bytes = sum over the step's launches of the committed FETCH/WRITE passes (null when stale)"}
         out = {
             "metric": "global-BA LM iterations/s" if not cfg.get("shared") else "local-BA LM iterations/s (windows sharing objects)", "value": dist_util.aggregate_throughput(world, steps_done, dt), "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(steps_done, 1),
@@ -468,7 +594,8 @@ def main():
             "config": {"workload": cfg["name"], "keyframes": stats["P"], "features": stats["L"], "objects": stats["O"],
                        "reprojection_obs": stats["N_r"], "bbox_obs": stats["N_b"], "reduced_rows": int(pst["reduced_rows"]),
                        "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single",
-                       "rccl_ranks": rccl_ranks, "allreduce_hook": (args.hook if shared else None), "steps_done": steps_done,
+                       "rccl_ranks": rccl_ranks, "allreduce_hook": (args.hook if shared else None), "oversubscribed": bool(args.oversubscribe),
+                       "rccl_versions": rccl_versions, "collective_issue_order": issue_order, "collectives_us": collectives_us, "steps_done": steps_done,
                        "final_cost": summ.final_cost, "termination": summ.message.decode()},
             "roofline": roof,
             "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
@@ -483,6 +610,9 @@ def main():
             # the same steps in deterministic mode (obvi_ba_options.deterministic: fixed-order sums, one stream; for parity runs)
             bd = obvi_ba.BundleAdjuster(device_id=local_rank, deterministic=True)
             synth.upload(bd, prob)
+            bd.solve(solver_params(obvi_ba, 3))      # from the uploaded values, like the oracle's bounded run: the records parity_vs_oracle compares
+            bd_first = bd.iterations()
+            synth.upload(bd, prob)
             if args.warmup > 0:
                 bd.solve(solver_params(obvi_ba, args.warmup))
             torch.cuda.synchronize()
@@ -490,6 +620,7 @@ def main():
             sd = bd.solve(solver_params(obvi_ba, args.steps))
             torch.cuda.synchronize()
             its_d, its_0 = bd.iterations(), ba_timed_iterations
+            det_first = bd_first
             out["deterministic_mode"] = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / max(1, sd.num_iterations - 1), 4), "steps": sd.num_iterations - 1,
                                          # the two modes differ by the order of their sums only: the first steps agree to round-off, later ones as far as this
                                          # ill-conditioned problem amplifies it (zero tolerances, non-monotonic steps: a chaotic trajectory)
@@ -498,7 +629,14 @@ def main():
         if world == 1 and args.config == 3 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_global_ba(obvi_ba, synth, prob, local_rank)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob)
+            legs = {}
+            if world == 1:
+                synth.upload(ba, prob)
+                ba.solve(solver_params(obvi_ba, 3))
+                legs["default"] = ba.iterations()
+                if det_first is not None:
+                    legs["deterministic"] = det_first
+            out["cpu_baseline"] = cpu_baseline(prob, legs=legs)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

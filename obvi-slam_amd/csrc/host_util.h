@@ -117,6 +117,10 @@ class DevBuf {
 // ranges themselves.  run(parts, fn) calls fn(0) ... fn(parts - 1), each exactly once, on the workers and on the calling thread, and
 // returns when all are done; calls from different threads (one handle per thread) are serialised.  Workers spin briefly before they
 // sleep, so that back-to-back calls do not pay a wake-up each.
+// A call is ONE immutable job record (function, part count, its own hand-out and completion counters) on the caller's stack, published
+// through job_ under the mutex.  A worker enters a job only under that mutex (and is counted in job->inside while it holds the pointer);
+// run() unpublishes the job under the same mutex and leaves only when every part is done AND no worker is inside any more, so a part
+// index never travels from one job to the next and nothing of a finished job is touched after run() has returned.
 class HostPool {
  public:
   explicit HostPool(int workers) {
@@ -135,27 +139,34 @@ class HostPool {
   void run(int parts, const std::function<void(int)>& fn) {
     if (parts <= 1 || threads_.empty()) { for (int i = 0; i < parts; ++i) fn(i); return; }
     std::lock_guard<std::mutex> serial(callers_);
+    Job job(&fn, parts);
     {
       std::lock_guard<std::mutex> lock(m_);
-      fn_.store(&fn, std::memory_order_relaxed); parts_.store(parts, std::memory_order_relaxed);
-      next_.store(0, std::memory_order_relaxed); left_.store(parts, std::memory_order_relaxed);
+      job_ = &job;
       gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
-    take();
-    while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
-    std::lock_guard<std::mutex> lock(m_);
-    fn_.store(nullptr, std::memory_order_relaxed); parts_.store(0, std::memory_order_relaxed);
+    take(job);
+    while (job.left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    { std::lock_guard<std::mutex> lock(m_); job_ = nullptr; }                               // nobody enters from here on
+    while (job.inside.load(std::memory_order_acquire) != 0) std::this_thread::yield();     // ... and those who did have left
   }
 
  private:
+  struct Job {
+    Job(const std::function<void(int)>* f, int n) : fn(f), parts(n), left(n) {}
+    const std::function<void(int)>* const fn;
+    const int parts;
+    std::atomic<int> next{0}, left, inside{0};
+  };
   // The workers read what the calling thread wrote a moment ago and the caller then overwrites what they read (one problem per frame in
   // a sliding-window session).  Spread by the scheduler over a two-socket host, every such line crosses the sockets; kept on the caller's
-  // block of logical CPUs (same socket, neighbouring L3 slices) it does not.  OBVI_HOST_AFFINITY=0 leaves the placement to the scheduler.
+  // block of logical CPUs (same socket, neighbouring L3 slices) it does not -- worth 2-3 % of a session on a 2 x 64-core host.  A library
+  // must not change thread placement behind its host's back, so this is opt-in: OBVI_HOST_AFFINITY=1 (run_offline_ba sets it for itself).
   void keep_near_caller() {
 #if defined(__linux__)
     const char* v = std::getenv("OBVI_HOST_AFFINITY");
-    if (v != nullptr && std::atoi(v) == 0) return;
+    if (v == nullptr || std::atoi(v) != 1) return;
     const int cpu = sched_getcpu();
     cpu_set_t allowed;
     if (cpu < 0 || threads_.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
@@ -168,12 +179,12 @@ class HostPool {
     for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(near), &near);
 #endif
   }
-  void take() {
+  static void take(Job& job) {
     for (;;) {
-      const int i = next_.fetch_add(1, std::memory_order_acq_rel);
-      if (i >= parts_.load(std::memory_order_acquire)) return;
-      (*fn_.load(std::memory_order_acquire))(i);
-      left_.fetch_sub(1, std::memory_order_release);
+      const int i = job.next.fetch_add(1, std::memory_order_acq_rel);
+      if (i >= job.parts) return;
+      (*job.fn)(i);
+      job.left.fetch_sub(1, std::memory_order_release);
     }
   }
   void work() {
@@ -184,23 +195,25 @@ class HostPool {
         __builtin_ia32_pause();
 #endif
       }
+      Job* job;
       {
         std::unique_lock<std::mutex> lock(m_);
         cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
         seen = gen_.load(std::memory_order_acquire);
         if (stop_) return;
-        if (fn_.load(std::memory_order_relaxed) == nullptr) continue;
+        job = job_;
+        if (job == nullptr) continue;                          // the job of this generation is already over
+        job->inside.fetch_add(1, std::memory_order_acq_rel);   // counted while the pointer is held: run() waits for zero
       }
-      take();
+      take(*job);
+      job->inside.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> threads_;
   std::mutex m_, callers_;
   std::condition_variable cv_;
   std::atomic<uint64_t> gen_{0};
-  std::atomic<int> next_{0}, left_{0};
-  std::atomic<const std::function<void(int)>*> fn_{nullptr};
-  std::atomic<int> parts_{0};
+  Job* job_ = nullptr;   // guarded by m_
   bool stop_ = false;
 };
 

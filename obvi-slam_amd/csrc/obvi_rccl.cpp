@@ -7,7 +7,9 @@
 #include <rccl/rccl.h>
 #include <unistd.h>
 
+#include <cctype>
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -25,6 +27,12 @@ struct obvi_rccl_comm {
   double* bounce = nullptr;     // device buffer for the small host all-reduces
   hipStream_t stream = nullptr; // their stream
   std::string err;
+  // Issue order of the data-path collectives (obvi_rccl_allreduce): one communicator is driven from two streams of a handle, which is
+  // legal only if every rank enqueues the same collectives in the same host order.  Every call folds (count, op, ordinal of the stream
+  // among the streams seen so far) into a running hash; ranks compare (calls, hash) with obvi_rccl_sequence.
+  uint64_t seq_calls = 0, seq_hash = 1469598103934665603ull;
+  void* seq_streams[8] = {};
+  int seq_nstreams = 0;
 };
 
 namespace {
@@ -36,6 +44,11 @@ int fail(obvi_rccl_comm* c, int code, const char* what, const char* detail) {
 }  // namespace
 
 extern "C" {
+
+int32_t obvi_rccl_nccl_version(void) {
+  int v = 0;
+  return ncclGetVersion(&v) == ncclSuccess ? (int32_t)v : -1;
+}
 
 int obvi_rccl_unique_id(char out[OBVI_RCCL_ID_BYTES]) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
@@ -73,13 +86,28 @@ int obvi_rccl_comm_create(const char id_bytes[OBVI_RCCL_ID_BYTES], int32_t rank,
   return OBVI_OK;
 }
 
-int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, double timeout_s, obvi_rccl_comm** out) {
-  if (!path || !out) return OBVI_ERR_INVALID_ARGUMENT;
+int obvi_rccl_comm_create_from_file(const char* path_in, int32_t rank, int32_t world, int32_t device, double timeout_s, obvi_rccl_comm** out) {
+  if (!path_in || !out) return OBVI_ERR_INVALID_ARGUMENT;
   char id[OBVI_RCCL_ID_BYTES];
   // The file lives only between rank 0's write and the end of the collective initialisation: rank 0 removes whatever an earlier
   // (crashed) run left at `path` before it writes, and removes its own file once ncclCommInitRank has returned -- by then every rank
-  // has read it.  A rank that still meets a leftover (it started before rank 0 got to the unlink) rejects it by age: a file older than
-  // the rendezvous time-out cannot belong to this launch.
+  // has read it.  What tells this launch's file from a leftover is a per-launch tag that the launcher gives every rank: OBVI_RCCL_JOB
+  // (any string: a job id, rank 0's pid + start time), else the launcher's own TORCHELASTIC_RUN_ID / MASTER_PORT.  It becomes part of
+  // the file NAME, so a rank never opens another launch's file and no clocks are compared.  Only without any tag does a rank fall back
+  // to rejecting a file by age (older than the rendezvous time-out) -- same-host clocks, and a leftover younger than the time-out is
+  // then still accepted: give launches a tag.
+  std::string tagged(path_in);
+  bool have_tag = false;
+  for (const char* name : {"OBVI_RCCL_JOB", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
+    const char* v = std::getenv(name);
+    if (v != nullptr && *v != 0) {
+      tagged += ".";
+      for (const char* ch = v; *ch; ++ch) tagged += (std::isalnum((unsigned char)*ch) || *ch == '-' || *ch == '_') ? *ch : '_';
+      have_tag = true;
+      break;
+    }
+  }
+  const char* path = tagged.c_str();
   if (rank == 0) {
     std::remove(path);
     const int rc = obvi_rccl_unique_id(id);
@@ -94,7 +122,7 @@ int obvi_rccl_comm_create_from_file(const char* path, int32_t rank, int32_t worl
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       struct stat st;
-      const bool fresh = ::stat(path, &st) == 0 && std::difftime(std::time(nullptr), st.st_mtime) <= std::max(1.0, timeout_s);
+      const bool fresh = ::stat(path, &st) == 0 && (have_tag || std::difftime(std::time(nullptr), st.st_mtime) <= std::max(1.0, timeout_s));
       FILE* f = fresh ? std::fopen(path, "rb") : nullptr;
       if (f) {
         const size_t n = std::fread(id, 1, sizeof(id), f);
@@ -133,9 +161,22 @@ int obvi_rccl_allreduce(void* user, void* device_buf, int64_t count_f64, int32_t
   if (!c || !c->comm || !device_buf || count_f64 < 0) return OBVI_ERR_INVALID_ARGUMENT;
   if (count_f64 == 0) return 0;
   const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+  {
+    int ord = 0;
+    while (ord < c->seq_nstreams && c->seq_streams[ord] != stream) ++ord;
+    if (ord == c->seq_nstreams && c->seq_nstreams < 8) c->seq_streams[c->seq_nstreams++] = stream;
+    for (uint64_t w : {(uint64_t)count_f64, (uint64_t)(uint32_t)op, (uint64_t)ord}) { c->seq_hash ^= w; c->seq_hash *= 1099511628211ull; }
+    ++c->seq_calls;
+  }
   const ncclResult_t r = ncclAllReduce(device_buf, device_buf, (size_t)count_f64, ncclDouble, rop, c->comm, static_cast<hipStream_t>(stream));
   if (r != ncclSuccess) return fail(c, (int)r, "ncclAllReduce", ncclGetErrorString(r));
   return 0;
+}
+
+int obvi_rccl_sequence(const obvi_rccl_comm* c, uint64_t* calls, uint64_t* hash) {
+  if (!c || !calls || !hash) return OBVI_ERR_INVALID_ARGUMENT;
+  *calls = c->seq_calls; *hash = c->seq_hash;
+  return OBVI_OK;
 }
 
 int obvi_rccl_attach(obvi_ba_handle* h, obvi_rccl_comm* c, const uint8_t* is_shared) {

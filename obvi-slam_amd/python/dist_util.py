@@ -43,24 +43,61 @@ def device_tensor(ptr, n):
     return torch.as_tensor(_DeviceArray(ptr, n), device="cuda")
 
 
-def torch_allreduce(dist):
+class IssueLog:
+    """Issue order of a rank's data-path collectives: (count, op, ordinal of the stream among the streams seen so far) per call, the same
+    record libobvi_rccl.so folds into obvi_rccl_sequence.  One communicator is driven from two streams of a handle, which is legal only if
+    every rank enqueues the same collectives in the same host order: ranks compare `calls` and `digest()` at a quiescent point."""
+
+    def __init__(self):
+        self.calls, self._hash, self._streams, self.records = 0, 1469598103934665603, [], []
+
+    def note(self, count, op, stream):
+        if stream not in self._streams:
+            self._streams.append(stream)
+        rec = (int(count), int(op), self._streams.index(stream))
+        for w in rec:
+            self._hash = ((self._hash ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        self.calls += 1
+        self.records.append(rec)
+
+    def digest(self):
+        return self._hash
+
+
+def same_issue_order(dist, calls, digest):
+    """True iff every rank of the torch.distributed group reports the same (calls, digest) -- any backend (values travel as float64 halves)."""
+    import torch
+    mine = torch.tensor([float(calls), float(digest >> 32), float(digest & 0xFFFFFFFF)], dtype=torch.float64)
+    lo, hi = mine.clone(), mine.clone()
+    if dist.get_backend() == "nccl":
+        lo, hi = lo.cuda(), hi.cuda()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool((lo == hi).all().item())
+
+
+def torch_allreduce(dist, log=None):
     """obvi_ba all-reduce hook on top of torch.distributed (backend nccl == RCCL over xGMI): the collective is enqueued
     behind the library's own HIP stream, no host synchronisation."""
     import torch
 
     def fn(ptr, count, op, stream):
+        if log is not None:
+            log.note(count, op, stream)
         with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
             dist.all_reduce(device_tensor(ptr, count), op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
         return 0
     return fn
 
 
-def staged_allreduce(dist):
-    """The same hook over any torch.distributed backend (gloo in the tests: two ranks on ONE GPU, where RCCL refuses to form a
-    communicator): device -> host on the library's stream, all_reduce on the host, host -> device on the same stream."""
+def staged_allreduce(dist, log=None):
+    """The same hook over any torch.distributed backend (gloo in the tests and in `bench.py --oversubscribe`: several ranks on ONE GPU, where
+    RCCL refuses to form a communicator): device -> host on the library's stream, all_reduce on the host, host -> device on the same stream."""
     import torch
 
     def fn(ptr, count, op, stream):
+        if log is not None:
+            log.note(count, op, stream)
         with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
             d = device_tensor(ptr, count)
             h = d.cpu()                                     # synchronises the stream: everything before the exchange is done
@@ -68,6 +105,19 @@ def staged_allreduce(dist):
             d.copy_(h)
         return 0
     return fn
+
+
+def torch_rccl_version():
+    """NCCL_VERSION_CODE-style integer of the librccl torch.distributed uses (torch.cuda.nccl.version()), or None."""
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        if isinstance(v, tuple):
+            major, minor, patch = (list(v) + [0, 0])[:3]
+            return int(major) * 10000 + int(minor) * 100 + int(patch) if major >= 2 and (major > 2 or minor >= 9) else int(major) * 1000 + int(minor) * 100 + int(patch)
+        return int(v)
+    except Exception:      # noqa: BLE001 -- a torch without the nccl bindings: nothing to compare with
+        return None
 
 
 class RcclComm:
@@ -90,6 +140,39 @@ class RcclComm:
         if rc != 0:
             raise RuntimeError("obvi_rccl_comm_create failed: status %d" % rc)
         self.rank, self.world_requested = rank, world
+
+    @staticmethod
+    def library_path(library=None):
+        here = os.path.dirname(os.path.abspath(__file__))
+        return library or os.path.join(os.path.dirname(here), "csrc", "libobvi_rccl.so")
+
+    @staticmethod
+    def nccl_version(library=None):
+        """ncclGetVersion as libobvi_rccl.so resolves it in THIS process (obvi_rccl_nccl_version)."""
+        lib = C.CDLL(RcclComm.library_path(library))
+        lib.obvi_rccl_nccl_version.restype = C.c_int32
+        return int(lib.obvi_rccl_nccl_version())
+
+    @staticmethod
+    def check_against_torch(library=None):
+        """libobvi_rccl.so links /opt/rocm/lib/librccl, torch maps its own librccl.so into the same process.  Two different RCCL builds
+        behind one set of symbols is not a configuration anybody has run with eight ranks: refuse (the caller falls back to the
+        torch.distributed hook) unless both report the same version.  Returns (ok, ours, torchs)."""
+        ours, theirs = RcclComm.nccl_version(library), torch_rccl_version()
+        return (theirs is None or ours == theirs), ours, theirs
+
+    def sequence(self):
+        """(calls, hash) of the data-path collectives issued on this communicator so far (obvi_rccl_sequence)."""
+        calls, h = C.c_uint64(), C.c_uint64()
+        if self._lib.obvi_rccl_sequence(self._c, C.byref(calls), C.byref(h)) != 0:
+            raise RuntimeError("obvi_rccl_sequence failed")
+        return int(calls.value), int(h.value)
+
+    def same_issue_order(self):
+        """True iff every rank of the communicator has issued the same sequence of collectives (min == max of calls / hash halves)."""
+        calls, h = self.sequence()
+        v = [float(calls), float(h >> 32), float(h & 0xFFFFFFFF)]
+        return self.host_allreduce(v, op=2) == self.host_allreduce(v, op=1)
 
     @staticmethod
     def unique_id(library=None):

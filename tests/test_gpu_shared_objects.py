@@ -70,9 +70,11 @@ class EmulatedAllReduce:
     """Stands in for RCCL: sums / maximises the exchange buffers of `world` handles living on one GPU."""
     def __init__(self, world):
         self.world, self.bar, self.slots, self.res, self.calls, self.log = world, threading.Barrier(world), [None] * world, None, 0, []
+        self.issue = [dist_util.IssueLog() for _ in range(world)]      # per rank: (count, op, stream ordinal) in host issue order
 
     def hook(self, rank):
         def fn(ptr, count, op, stream):
+            self.issue[rank].note(count, op, stream)
             torch.cuda.synchronize()
             t = dist_util.device_tensor(ptr, count)
             self.slots[rank] = t
@@ -255,6 +257,14 @@ def test_config4_eight_windows_on_one_device():
     [t.start() for t in th]; [t.join(timeout=900) for t in th]
     assert all(o is not None and o.num_iterations == 7 for o in out2)
     assert check_collectives(emu2.log, 25, world) == 7                                     # three collectives per LM submission, seven submissions
+    # ONE communicator is driven from two streams of a handle (shared blocks on the side stream, tail and scalars on the main stream): legal for
+    # RCCL only if every rank enqueues the same collectives in the same host order -- the per-rank issue logs must be identical, and the
+    # stream pattern is the documented one
+    for rank in range(1, world):
+        assert emu2.issue[rank].records == emu2.issue[0].records and emu2.issue[rank].digest() == emu2.issue[0].digest()
+    recs0 = emu2.issue[0].records
+    assert len({st for n, _, st in recs0 if n == 56 * 25}) == 1                          # shared blocks: always the same stream (the side stream) ...
+    assert all(st == recs0[0][2] for n, _, st in recs0 if n != 56 * 25)                  # ... everything else on the stream the solve started on
     for rank in range(1, world):
         assert out2[rank].final_cost == out2[0].final_cost and np.array_equal(handles[rank].get_objects(), handles[0].get_objects())
         assert [i.step_is_successful for i in handles[rank].iterations()] == [i.step_is_successful for i in handles[0].iterations()]
@@ -399,6 +409,34 @@ def test_compiled_rccl_hook_one_rank_communicator(scene):
         comm.close()
 
 
+def test_bench_two_ranks_oversubscribed():
+    """`bench.py --gpus 2` end to end where only one GPU exists: the script spawns its two ranks itself, both on device 0, process group gloo,
+    the three per-step collectives through dist_util.staged_allreduce.  Everything of the N > 1 path that does not need a second device runs:
+    self-spawn, per-rank seeds, the scaling baseline, the shared-object exchange, the issue-order check, the timing reduction, the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["unit"] == "LM iterations/s"
+    assert cfg["rccl_ranks"] == 2 and cfg["parallelism"] == "windows+allreduce" and cfg["oversubscribed"] and cfg["allreduce_hook"] == "staged-gloo"
+    assert cfg["steps_done"] == 3 and cfg["collective_issue_order"]["same_on_every_rank"] and cfg["collective_issue_order"]["collectives_issued"] >= 3 * 3
+    assert set(cfg["collectives_us"]) == {"shared_blocks", "shared_tail", "scalars"}
+    sb = line["scaling_baseline"]
+    assert sb["steps"] == 3 and len(sb["per_rank_value"]) == 2 and sb["value_one_gpu"] > 0
+    assert 0 < line["weak_scaling_efficiency"] <= 1.5 and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["roofline"]["kernel"] and "cpu_baseline" not in line
+
+
 def test_rccl_rendezvous_file(tmp_path):
     """obvi_rccl_comm_create_from_file: the launcher-less rendezvous of a C++ host (rank 0 writes the id, the others poll).  The file lives only
     for the rendezvous: rank 0 replaces whatever an earlier run left at the path and removes its own file once the communicator exists, so a
@@ -413,3 +451,34 @@ def test_rccl_rendezvous_file(tmp_path):
             assert comm.world() == 1 and not os.path.exists(path)
         finally:
             comm.close()
+    # a per-launch tag from the environment becomes part of the file name: a leftover at the untagged path is not even looked at
+    with open(path, "wb") as f:
+        f.write(b"\x5a" * dist_util.RcclComm.ID_BYTES)
+    os.environ["OBVI_RCCL_JOB"] = "job 42/a"
+    try:
+        comm = dist_util.RcclComm(0, 1, 0, id_file=path)
+        try:
+            assert comm.world() == 1 and os.path.exists(path) and not os.path.exists(path + ".job_42_a")
+        finally:
+            comm.close()
+    finally:
+        del os.environ["OBVI_RCCL_JOB"]
+
+
+def test_rccl_library_reports_its_version_and_issue_sequence(scene):
+    """obvi_rccl_nccl_version (compared with torch's before a communicator is formed: dist_util.RcclComm.check_against_torch) and
+    obvi_rccl_sequence (calls + hash of the data-path collectives, what ranks compare to prove the same host issue order)."""
+    ok, ours, theirs = dist_util.RcclComm.check_against_torch()
+    assert ours > 20000 and (theirs is None or ok == (ours == theirs))
+    comm = dist_util.RcclComm(0, 1, 0, unique_id=dist_util.RcclComm.unique_id())
+    try:
+        assert comm.sequence()[0] == 0
+        b = helpers.product_ba()
+        synth.upload(b, scene)
+        comm.attach(b, np.ones(len(scene["objects"]), np.uint8))
+        s = b.solve(helpers.ba_params(max_it=4))
+        calls, digest = comm.sequence()
+        assert calls >= 3 * (s.num_iterations - 1) and digest != 1469598103934665603 and comm.same_issue_order()
+        b.close()
+    finally:
+        comm.close()
