@@ -102,6 +102,9 @@ static void writeResults(std::ostream& out, bool ok, const LongTermObjectMapAndR
 }
 
 int main(int argc, char** argv) {
+  // this process is the library's only host: its worker threads may stay on the calling thread's block of logical CPUs (a library does not
+  // decide that for an application: host_util.h, OBVI_HOST_AFFINITY)
+  setenv("OBVI_HOST_AFFINITY", "1", 0);
   if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options] | --from-checkpoint state.json out.json | --checkpoint-roundtrip in.json out.json" << std::endl; return 2; }
   if (!std::strcmp(argv[1], "--checkpoint-roundtrip")) {   // no GPU: the reader and the writer of obvi_checkpoint_io.h
     if (argc < 4) return 2;

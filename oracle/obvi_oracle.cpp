@@ -48,6 +48,17 @@
 namespace {
 using namespace oracle;  // NOLINT
 
+// Scalar of the solver-level sums: every accumulation of the normal equations (J^T J blocks, gradient, column norms), the Schur
+// complement, the skyline factorisation, both substitutions, the model cost change and the cost sums.  `double` in libobvi_oracle.so --
+// the checker.  Compiled a second time with -DOBVI_ORACLE_REAL="long double" (libobvi_oracle_ld.so, `make arbiter`) the same code is the
+// ARBITER of DESIGN.md section 6: factor records (r, J) and the parameter blocks stay fp64 -- identical inputs -- while everything
+// that is summed from them carries 64 mantissa bits, so its round-off sits three decimal digits below both the checker's and the HIP
+// path's; |HIP - arbiter| against |oracle - arbiter| then says which of the two fp64 runs is closer to the exact-arithmetic step.
+#ifndef OBVI_ORACLE_REAL
+#define OBVI_ORACLE_REAL double
+#endif
+typedef OBVI_ORACLE_REAL real;
+
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -255,12 +266,12 @@ struct Workspace {
   std::vector<FactorLin> lin;
   // skyline storage of the reduced system: row i holds columns first[i]..i
   std::vector<int64_t> first, rowptr;
-  std::vector<double> S, rhs;
+  std::vector<real> S, rhs;
   // point blocks
-  std::vector<double> Hll, gl;            // 9 / 3 per point
+  std::vector<real> Hll, gl;              // 9 / 3 per point
   std::vector<double> Hpp_diag;           // diag(J^T J) per reduced row (poses, objects)
-  std::vector<double> colsq_c, colsq_l;   // squared column norms: reduced rows / points (3 per point)
-  std::vector<double> g_c;                // gradient, reduced rows
+  std::vector<real> colsq_c, colsq_l;     // squared column norms: reduced rows / points (3 per point)
+  std::vector<real> g_c;                  // gradient, reduced rows
   std::vector<std::vector<int64_t>> point_obs;  // per point: indices into lin of its reprojection records
   int64_t object_row0 = 0;                // first object row of the reduced system (= 6 nPv): rows from here on form the arrow's border
 };
@@ -313,11 +324,11 @@ int64_t reduced_row(const Reduced& rd, BlockKind k, int64_t i) {
 
 // Cost only (trial point evaluation) over the reduced program.
 double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
-  double cost = 0.0;
+  real cost = 0.0;
   for (const Family& fam : families(pb)) {
-    std::vector<double> part((size_t)std::max(1, g_threads), 0.0);
+    std::vector<real> part((size_t)std::max(1, g_threads), 0.0);
     parallel_ranges(fam.n, [&](int t, int64_t i0, int64_t i1) {
-      double c = 0.0;
+      real c = 0.0;
       for (int64_t i = i0; i < i1; ++i) {
         if (!(*fam.active)[i]) continue;
         FactorLin f; fam.lin(pb, i, false, &f);
@@ -327,9 +338,9 @@ double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
       }
       part[t] = c;
     });
-    for (double c : part) cost += c;   // one thread: the plain running sum
+    for (real c : part) cost += c;   // one thread: the plain running sum
   }
-  return cost;
+  return (double)cost;
 }
 
 // Full linearisation at the current estimate: robustified r, J per residual block;
@@ -339,7 +350,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   const double t_begin = now_s();
   ws->lin.clear();
   ws->point_obs.assign(pb.L, {});
-  double cost = 0.0;
+  real cost = 0.0;
   for (const Family& fam : families(pb)) {
     if (g_threads > 1 && fam.n >= 1024) {
       // same records in the same order as the loop below: which factors stay is decided first (values only, cheap), then the
@@ -397,23 +408,23 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
       if (!is_var(pb, rd, ks[b], is[b])) continue;
       const int d = kBlockDim[ks[b]];
       if (ks[b] == KIND_POINT) {
-        double* c = &ws->colsq_l[3 * is[b]]; double* g = &ws->gl[3 * is[b]]; double* H = &ws->Hll[9 * is[b]];
+        real* c = &ws->colsq_l[3 * is[b]]; real* g = &ws->gl[3 * is[b]]; real* H = &ws->Hll[9 * is[b]];
         for (int a = 0; a < f.m; ++a) for (int k = 0; k < 3; ++k) {
-          const double j = Js[b][3 * a + k];
+          const real j = Js[b][3 * a + k];
           c[k] += j * j; g[k] += j * f.r[a];
           for (int k2 = 0; k2 < 3; ++k2) H[3 * k + k2] += j * Js[b][3 * a + k2];
         }
       } else {
         const int64_t row = reduced_row(rd, ks[b], is[b]);
         for (int a = 0; a < f.m; ++a) for (int k = 0; k < d; ++k) {
-          const double j = Js[b][d * a + k];
+          const real j = Js[b][d * a + k];
           ws->colsq_c[row + k] += j * j; ws->g_c[row + k] += j * f.r[a];
         }
       }
     }
   }
   if (timing) std::fprintf(stderr, "oracle linearize: total %.3f s\n", now_s() - t_begin);
-  return cost;
+  return (double)cost;
 }
 
 // Envelope of the reduced system: block row r couples to the lowest reduced row it shares a
@@ -450,15 +461,15 @@ void build_envelope(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   ws->S.assign(ws->rowptr[rd.m], 0.0);
   ws->rhs.assign(rd.m, 0.0);
 }
-inline double& Sat(Workspace* ws, int64_t i, int64_t j) {  // i >= j >= first[i]
+inline real& Sat(Workspace* ws, int64_t i, int64_t j) {  // i >= j >= first[i]
   return ws->S[ws->rowptr[i] + (j - ws->first[i])];
 }
 
 // Assemble the Schur complement for the per-parameter damping lambda (unscaled normal
 // equations, see solve()):  (H + Lambda) y = g  with the points eliminated.
 // [Ceres-doc: SchurEliminator::Eliminate]
-bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vector<double>& lam_c,
-                    const std::vector<double>& lam_l, Workspace* ws, std::vector<double>* Hll_inv) {
+bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vector<real>& lam_c,
+                    const std::vector<real>& lam_l, Workspace* ws, std::vector<real>* Hll_inv) {
   std::fill(ws->S.begin(), ws->S.end(), 0.0);
   for (int64_t i = 0; i < rd.m; ++i) { ws->rhs[i] = ws->g_c[i]; Sat(ws, i, i) = lam_c[i]; }
   // camera/object blocks: J_c^T J_c (lower triangle).  A factor's two blocks are distinct
@@ -474,8 +485,8 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
         if (rb > ra || (a != b && ra == rb)) continue;
         for (int x = 0; x < da; ++x) for (int y = 0; y < db; ++y) {
           if (ra == rb && y > x) continue;
-          double acc = 0.0;
-          for (int q = 0; q < f.m; ++q) acc += Js[a][da * q + x] * Js[b][db * q + y];
+          real acc = 0.0;
+          for (int q = 0; q < f.m; ++q) acc += (real)Js[a][da * q + x] * Js[b][db * q + y];
           Sat(ws, ra + x, rb + y) += acc;
         }
       }
@@ -490,26 +501,26 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
   parallel_ranges(pb.L, [&](int tid, int64_t l_begin, int64_t l_end) {
   for (int64_t l = l_begin; l < l_end; ++l) {
     if (!rd.point_var[l]) continue;
-    double H[9];
+    real H[9];
     for (int k = 0; k < 9; ++k) H[k] = ws->Hll[9 * l + k];
     for (int k = 0; k < 3; ++k) H[4 * k] += lam_l[3 * l + k];
     // 3x3 symmetric inverse via cofactors
-    const double c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
-    const double det = H[0] * c00 + H[1] * c01 + H[2] * c02;
+    const real c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
+    const real det = H[0] * c00 + H[1] * c01 + H[2] * c02;
     if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) { bad_part[tid] = 1; return; }
-    double* Hi = &(*Hll_inv)[9 * l];
+    real* Hi = &(*Hll_inv)[9 * l];
     Hi[0] = c00 / det; Hi[1] = (H[2] * H[7] - H[1] * H[8]) / det; Hi[2] = (H[1] * H[5] - H[2] * H[4]) / det;
     Hi[3] = Hi[1];     Hi[4] = (H[0] * H[8] - H[2] * H[6]) / det; Hi[5] = (H[2] * H[3] - H[0] * H[5]) / det;
     Hi[6] = Hi[2];     Hi[7] = Hi[5];                             Hi[8] = (H[0] * H[4] - H[1] * H[3]) / det;
     const std::vector<int64_t>& obs = ws->point_obs[l];
     // W_i = J_p,i^T J_l,i (6x3) for observations with a variable pose
-    std::vector<double> W(18 * obs.size()), Y(18 * obs.size());
+    std::vector<real> W(18 * obs.size()), Y(18 * obs.size());
     for (size_t a = 0; a < obs.size(); ++a) {
       const FactorLin& f = ws->lin[obs[a]];
       if (rd.pose_vid[f.i0] < 0) continue;
-      double* Wa = &W[18 * a]; double* Ya = &Y[18 * a];
+      real* Wa = &W[18 * a]; real* Ya = &Y[18 * a];
       for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
-        Wa[3 * x + k] = f.J0[x] * f.J1[k] + f.J0[6 + x] * f.J1[3 + k];
+        Wa[3 * x + k] = (real)f.J0[x] * f.J1[k] + (real)f.J0[6 + x] * f.J1[3 + k];
       for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
         Ya[3 * x + k] = Wa[3 * x] * Hi[k] + Wa[3 * x + 1] * Hi[3 + k] + Wa[3 * x + 2] * Hi[6 + k];
       const int64_t ra = pose_row(rd, f.i0);
@@ -529,7 +540,7 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
         if (rd.pose_vid[fb.i0] < 0) continue;
         const int64_t rb = pose_row(rd, fb.i0);
         if (rb > ra) continue;
-        const double* Ya = &Y[18 * a]; const double* Wb = &W[18 * b];
+        const real* Ya = &Y[18 * a]; const real* Wb = &W[18 * b];
         for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
           if (ra == rb && y > x) continue;
           Sat(ws, ra + x, rb + y) -= Ya[3 * x] * Wb[3 * y] + Ya[3 * x + 1] * Wb[3 * y + 1] + Ya[3 * x + 2] * Wb[3 * y + 2];
@@ -557,15 +568,15 @@ bool skyline_factor_arrow(Workspace* ws, int64_t m) {
   bool ok = true;
   for (int64_t i = 0; i < r0 && ok; ++i) {
     const int64_t fi = ws->first[i];
-    double* Li = row(i);
+    real* Li = row(i);
     for (int64_t j = fi; j < i; ++j) {
       const int64_t fj = ws->first[j];
-      const double* Lj = row(j);
-      double s = Li[j];
+      const real* Lj = row(j);
+      real s = Li[j];
       for (int64_t k = std::max(fi, fj); k < j; ++k) s -= Li[k] * Lj[k];
       Li[j] = s / Lj[j];
     }
-    double s = Li[i];
+    real s = Li[i];
     for (int64_t k = fi; k < i; ++k) s -= Li[k] * Li[k];
     if (!(s > 0.0) || !std::isfinite(s)) ok = false;
     Li[i] = std::sqrt(s);
@@ -580,37 +591,37 @@ bool skyline_factor_arrow(Workspace* ws, int64_t m) {
   };
   border_rows([&](int64_t i) {   // (1)
     const int64_t fi = ws->first[i];
-    double* Li = row(i);
+    real* Li = row(i);
     for (int64_t j = fi; j < std::min(i, r0); ++j) {
       const int64_t fj = ws->first[j];
-      const double* Lj = row(j);
-      double s = Li[j];
+      const real* Lj = row(j);
+      real s = Li[j];
       for (int64_t k = std::max(fi, fj); k < j; ++k) s -= Li[k] * Lj[k];
       Li[j] = s / Lj[j];
     }
   });
   border_rows([&](int64_t i) {   // (2a)
     const int64_t fi = ws->first[i];
-    double* Li = row(i);
+    real* Li = row(i);
     for (int64_t j = std::max(fi, r0); j <= i; ++j) {
       const int64_t fj = ws->first[j];
-      const double* Lj = row(j);
-      double s = Li[j];
+      const real* Lj = row(j);
+      real s = Li[j];
       for (int64_t k = std::max(fi, fj); k < std::min(j, r0); ++k) s -= Li[k] * Lj[k];
       Li[j] = s;
     }
   });
   for (int64_t i = r0; i < m; ++i) {   // (2b)
     const int64_t fi = ws->first[i];
-    double* Li = row(i);
+    real* Li = row(i);
     for (int64_t j = std::max(fi, r0); j < i; ++j) {
       const int64_t fj = ws->first[j];
-      const double* Lj = row(j);
-      double s = Li[j];
+      const real* Lj = row(j);
+      real s = Li[j];
       for (int64_t k = std::max({fi, fj, r0}); k < j; ++k) s -= Li[k] * Lj[k];
       Li[j] = s / Lj[j];
     }
-    double s = Li[i];
+    real s = Li[i];
     for (int64_t k = std::max(fi, r0); k < i; ++k) s -= Li[k] * Li[k];
     if (!(s > 0.0) || !std::isfinite(s)) return false;
     Li[i] = std::sqrt(s);
@@ -621,39 +632,39 @@ bool skyline_factor(Workspace* ws, int64_t m) {
   if (g_threads > 1 && ws->object_row0 < m) return skyline_factor_arrow(ws, m);
   for (int64_t i = 0; i < m; ++i) {
     const int64_t fi = ws->first[i];
-    double* Li = &ws->S[ws->rowptr[i]] - fi;
+    real* Li = &ws->S[ws->rowptr[i]] - fi;
     for (int64_t j = fi; j < i; ++j) {
       const int64_t fj = ws->first[j];
-      const double* Lj = &ws->S[ws->rowptr[j]] - fj;
+      const real* Lj = &ws->S[ws->rowptr[j]] - fj;
       const int64_t k0 = std::max(fi, fj);
-      double s = Li[j];
+      real s = Li[j];
       for (int64_t k = k0; k < j; ++k) s -= Li[k] * Lj[k];
       Li[j] = s / Lj[j];
     }
-    double s = Li[i];
+    real s = Li[i];
     for (int64_t k = fi; k < i; ++k) s -= Li[k] * Li[k];
     if (!(s > 0.0) || !std::isfinite(s)) return false;
     Li[i] = std::sqrt(s);
   }
   return true;
 }
-void skyline_solve_inplace(const Workspace* ws, int64_t m, std::vector<double>* x) {
+void skyline_solve_inplace(const Workspace* ws, int64_t m, std::vector<real>* x) {
   for (int64_t i = 0; i < m; ++i) {  // L z = b
     const int64_t fi = ws->first[i];
-    const double* Li = &ws->S[ws->rowptr[i]] - fi;
-    double s = (*x)[i];
+    const real* Li = &ws->S[ws->rowptr[i]] - fi;
+    real s = (*x)[i];
     for (int64_t k = fi; k < i; ++k) s -= Li[k] * (*x)[k];
     (*x)[i] = s / Li[i];
   }
   for (int64_t i = m - 1; i >= 0; --i) {  // L^T y = z
     const int64_t fi = ws->first[i];
-    const double* Li = &ws->S[ws->rowptr[i]] - fi;
-    const double xi = (*x)[i] / Li[i];
+    const real* Li = &ws->S[ws->rowptr[i]] - fi;
+    const real xi = (*x)[i] / Li[i];
     (*x)[i] = xi;
     for (int64_t k = fi; k < i; ++k) (*x)[k] -= Li[k] * xi;
   }
 }
-bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<double>* x) {
+bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<real>* x) {
   if (!skyline_factor(ws, m)) return false;
   x->assign(ws->rhs.begin(), ws->rhs.end());
   skyline_solve_inplace(ws, m, x);
@@ -879,21 +890,21 @@ int oracle_ba_debug_reduced_system(oracle_handle* h, double radius, double* lhs,
   if (m_out) *m_out = (int32_t)rd.m;
   if (rd.m > m_cap) return OBVI_ERR_INVALID_ARGUMENT;
   Workspace ws; linearize(pb, rd, &ws); build_envelope(pb, rd, &ws);
-  std::vector<double> lam_c(rd.m), lam_l(3 * pb.L, 0.0);
+  std::vector<real> lam_c(rd.m), lam_l(3 * pb.L, 0.0);
   auto lam = [&](double c) {
     const double s = 1.0 / (1.0 + std::sqrt(c));
     const double d = std::min(std::max(c * s * s, 1e-6), 1e32);
     return d / radius / (s * s);
   };
-  for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = lam(ws.colsq_c[i]);
-  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) lam_l[3 * l + k] = lam(ws.colsq_l[3 * l + k]);
-  std::vector<double> Hinv;
+  for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = lam((double)ws.colsq_c[i]);
+  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) lam_l[3 * l + k] = lam((double)ws.colsq_l[3 * l + k]);
+  std::vector<real> Hinv;
   if (!assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hinv)) return OBVI_ERR_NUMERICAL;
   for (int64_t i = 0; i < rd.m; ++i) {
     for (int64_t j = 0; j < rd.m; ++j) lhs[i * rd.m + j] = 0.0;
-    rhs[i] = ws.rhs[i];
+    rhs[i] = (double)ws.rhs[i];
   }
-  for (int64_t i = 0; i < rd.m; ++i) for (int64_t j = ws.first[i]; j <= i; ++j) { lhs[i * rd.m + j] = Sat(&ws, i, j); lhs[j * rd.m + i] = Sat(&ws, i, j); }
+  for (int64_t i = 0; i < rd.m; ++i) for (int64_t j = ws.first[i]; j <= i; ++j) { lhs[i * rd.m + j] = (double)Sat(&ws, i, j); lhs[j * rd.m + i] = (double)Sat(&ws, i, j); }
   return OBVI_OK;
 }
 
@@ -909,7 +920,7 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
   for (int64_t i = 0; i < n_pairs; ++i) if (obj_a[i] >= (uint64_t)pb.O || obj_b[i] >= (uint64_t)pb.O) return OBVI_ERR_INVALID_ARGUMENT;
   Reduced rd; build_reduced(pb, &rd);
   Workspace ws; linearize(pb, rd, &ws); build_envelope(pb, rd, &ws);
-  std::vector<double> lam_c(rd.m, 0.0), lam_l(3 * pb.L, 0.0), Hinv;
+  std::vector<real> lam_c(rd.m, 0.0), lam_l(3 * pb.L, 0.0), Hinv;
   // a ParameterPrior's Jacobian is 1 / std_dev in its parameter's column (its residual is zero at mean = estimate): 1 / std_dev^2 on the diagonal
   for (size_t i = 0; i < pb.pp_kind.size(); ++i) {
     const double w = 1.0 / (pb.pp_std[i] * pb.pp_std[i]);
@@ -921,7 +932,7 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
   if (!assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hinv)) return OBVI_ERR_NUMERICAL;
   if (!skyline_factor(&ws, rd.m)) return OBVI_ERR_NUMERICAL;
   std::vector<int32_t> solved_for(pb.O, -1);           // object -> slot in `cols`
-  std::vector<std::vector<double>> cols;              // 7 solution vectors per object that occurs as the second of a pair
+  std::vector<std::vector<real>> cols;                // 7 solution vectors per object that occurs as the second of a pair
   for (int64_t i = 0; i < n_pairs; ++i) {
     double* out = cov49 + 49 * i;
     std::fill(out, out + 49, 0.0);
@@ -930,14 +941,14 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
     if (solved_for[b] < 0) {
       solved_for[b] = (int32_t)cols.size();
       for (int k = 0; k < 7; ++k) {
-        std::vector<double> x(rd.m, 0.0);
+        std::vector<real> x(rd.m, 0.0);
         x[obj_row(rd, b) + k] = 1.0;
         skyline_solve_inplace(&ws, rd.m, &x);
-        if (!std::isfinite(x[obj_row(rd, b) + k])) return OBVI_ERR_NUMERICAL;
+        if (!std::isfinite((double)x[obj_row(rd, b) + k])) return OBVI_ERR_NUMERICAL;
         cols.push_back(std::move(x));
       }
     }
-    for (int r = 0; r < 7; ++r) for (int k = 0; k < 7; ++k) out[7 * r + k] = cols[solved_for[b] + k][obj_row(rd, a) + r];
+    for (int r = 0; r < 7; ++r) for (int k = 0; k < 7; ++k) out[7 * r + k] = (double)cols[solved_for[b] + k][obj_row(rd, a) + r];
   }
   return OBVI_OK;
 }
@@ -962,9 +973,9 @@ int oracle_ba_column_sqnorms(oracle_handle* h, double* pose6, double* point3, do
   OracleProblem& pb = h->pb;
   Reduced rd; build_reduced(pb, &rd);
   Workspace ws; linearize(pb, rd, &ws);
-  if (pose6) for (int64_t p = 0; p < pb.P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = rd.pose_vid[p] >= 0 ? ws.colsq_c[pose_row(rd, p) + k] : -1.0;
-  if (point3) for (int64_t l = 0; l < pb.L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = rd.point_var[l] ? ws.colsq_l[3 * l + k] : -1.0;
-  if (object7) for (int64_t o = 0; o < pb.O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = rd.obj_vid[o] >= 0 ? ws.colsq_c[obj_row(rd, o) + k] : -1.0;
+  if (pose6) for (int64_t p = 0; p < pb.P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = rd.pose_vid[p] >= 0 ? (double)ws.colsq_c[pose_row(rd, p) + k] : -1.0;
+  if (point3) for (int64_t l = 0; l < pb.L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = rd.point_var[l] ? (double)ws.colsq_l[3 * l + k] : -1.0;
+  if (object7) for (int64_t o = 0; o < pb.O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = rd.obj_vid[o] >= 0 ? (double)ws.colsq_c[obj_row(rd, o) + k] : -1.0;
   for (size_t i = 0; i < pb.pp_kind.size(); ++i) {
     const double w = 1.0 / (pb.pp_std[i] * pb.pp_std[i]);
     const int64_t b = pb.pp_block[i];
@@ -1020,22 +1031,22 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   t_lin += now_s() - tt;
 
   // Jacobi scaling, computed once at iteration 0: s_j = 1 / (1 + sqrt(colsq_j))
-  std::vector<double> scale_c(rd.m), scale_l(3 * pb.L, 1.0);
-  for (int64_t i = 0; i < rd.m; ++i) scale_c[i] = 1.0 / (1.0 + std::sqrt(ws.colsq_c[i]));
-  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) scale_l[3 * l + k] = 1.0 / (1.0 + std::sqrt(ws.colsq_l[3 * l + k]));
+  std::vector<real> scale_c(rd.m), scale_l(3 * pb.L, 1.0);
+  for (int64_t i = 0; i < rd.m; ++i) scale_c[i] = (real)1.0 / ((real)1.0 + std::sqrt(ws.colsq_c[i]));
+  for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) scale_l[3 * l + k] = (real)1.0 / ((real)1.0 + std::sqrt(ws.colsq_l[3 * l + k]));
 
   auto grad_norms = [&](double* gmax, double* gnorm) {
-    double mx = 0.0, sq = 0.0;
+    real mx = 0.0, sq = 0.0;
     for (int64_t i = 0; i < rd.m; ++i) { mx = std::max(mx, std::fabs(ws.g_c[i])); sq += ws.g_c[i] * ws.g_c[i]; }
-    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const double g = ws.gl[3 * l + k]; mx = std::max(mx, std::fabs(g)); sq += g * g; }
-    *gmax = mx; *gnorm = std::sqrt(sq);
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const real g = ws.gl[3 * l + k]; mx = std::max(mx, std::fabs(g)); sq += g * g; }
+    *gmax = (double)mx; *gnorm = (double)std::sqrt(sq);
   };
   auto x_norm_fn = [&]() {
-    double sq = 0.0;
+    real sq = 0.0;
     for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) sq += pb.poses[6 * p + k] * pb.poses[6 * p + k];
     for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) sq += pb.objects[7 * o + k] * pb.objects[7 * o + k];
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) sq += pb.points[3 * l + k] * pb.points[3 * l + k];
-    return std::sqrt(sq);
+    return (double)std::sqrt(sq);
   };
 
   // LevenbergMarquardtStrategy state
@@ -1043,8 +1054,9 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   const double max_radius = prm->max_trust_region_radius;
   double decrease_factor = 2.0;
   bool reuse_diagonal = false;
-  std::vector<double> diag_c(rd.m), diag_l(3 * pb.L, 0.0);
-  const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDecrease = 1e-3, kMinRadius = 1e-32;
+  std::vector<real> diag_c(rd.m), diag_l(3 * pb.L, 0.0);
+  const real kMinDiag = 1e-6, kMaxDiag = 1e32;
+  const double kMinRelDecrease = 1e-3, kMinRadius = 1e-32;
   const int kMaxInvalid = 5;
   // TrustRegionStepEvaluator state
   const int max_nonmono = prm->allow_non_monotonic_steps ? 5 : 0;
@@ -1066,7 +1078,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   double x_norm = x_norm_fn();
   int num_invalid = 0;
   double iter_t0 = now_s();
-  std::vector<double> y_c, Hll_inv, lam_c(rd.m), lam_l(3 * pb.L, 0.0), delta_l(3 * pb.L, 0.0);
+  std::vector<real> y_c, Hll_inv, lam_c(rd.m), lam_l(3 * pb.L, 0.0), delta_l(3 * pb.L, 0.0);
 
   for (;;) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -1105,18 +1117,18 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     if (ok) {
       for (int64_t l = 0; l < pb.L; ++l) {
         if (!rd.point_var[l]) continue;
-        double b[3] = {ws.gl[3 * l], ws.gl[3 * l + 1], ws.gl[3 * l + 2]};
+        real b[3] = {ws.gl[3 * l], ws.gl[3 * l + 1], ws.gl[3 * l + 2]};
         for (int64_t idx : ws.point_obs[l]) {
           const FactorLin& f = ws.lin[idx];
           if (rd.pose_vid[f.i0] < 0) continue;
           const int64_t ra = pose_row(rd, f.i0);
           for (int k = 0; k < 3; ++k) {
-            double acc = 0.0;  // (W^T y)_k = sum_x W[x][k] y[x], W = Jp^T Jl
-            for (int x = 0; x < 6; ++x) acc += (f.J0[x] * f.J1[k] + f.J0[6 + x] * f.J1[3 + k]) * y_c[ra + x];
+            real acc = 0.0;  // (W^T y)_k = sum_x W[x][k] y[x], W = Jp^T Jl
+            for (int x = 0; x < 6; ++x) acc += ((real)f.J0[x] * f.J1[k] + (real)f.J0[6 + x] * f.J1[3 + k]) * y_c[ra + x];
             b[k] -= acc;
           }
         }
-        const double* Hi = &Hll_inv[9 * l];
+        const real* Hi = &Hll_inv[9 * l];
         for (int k = 0; k < 3; ++k) delta_l[3 * l + k] = -(Hi[3 * k] * b[0] + Hi[3 * k + 1] * b[1] + Hi[3 * k + 2] * b[2]);
       }
     }
@@ -1124,26 +1136,27 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     t_solve += now_s() - tt;
     bool finite = ok;
     if (ok) {
-      for (int64_t i = 0; i < rd.m && finite; ++i) finite = std::isfinite(y_c[i]);
-      for (int64_t l = 0; l < pb.L && finite; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(delta_l[3 * l + k]);
+      for (int64_t i = 0; i < rd.m && finite; ++i) finite = std::isfinite((double)y_c[i]);
+      for (int64_t l = 0; l < pb.L && finite; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) finite = finite && std::isfinite((double)delta_l[3 * l + k]);
     }
     // model_cost_change = -(J delta)^T (r + J delta / 2)
-    double model_cost_change = 0.0;
+    real model_acc = 0.0;
     if (finite) {
       for (const FactorLin& f : ws.lin) {
-        double Jd[7] = {0, 0, 0, 0, 0, 0, 0};
+        real Jd[7] = {0, 0, 0, 0, 0, 0, 0};
         const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
         for (int b = 0; b < 2; ++b) {
           if (!is_var(pb, rd, ks[b], is[b])) continue;
           const int d = kBlockDim[ks[b]];
           for (int k = 0; k < d; ++k) {
-            const double dk = (ks[b] == KIND_POINT) ? delta_l[3 * is[b] + k] : -y_c[reduced_row(rd, ks[b], is[b]) + k];
+            const real dk = (ks[b] == KIND_POINT) ? delta_l[3 * is[b] + k] : -y_c[reduced_row(rd, ks[b], is[b]) + k];
             for (int a = 0; a < f.m; ++a) Jd[a] += Js[b][d * a + k] * dk;
           }
         }
-        for (int a = 0; a < f.m; ++a) model_cost_change -= Jd[a] * (f.r[a] + 0.5 * Jd[a]);
+        for (int a = 0; a < f.m; ++a) model_acc -= Jd[a] * (f.r[a] + (real)0.5 * Jd[a]);
       }
     }
+    const double model_cost_change = (double)model_acc;
     it.step_is_valid = (finite && model_cost_change > 0.0) ? 1 : 0;
     if (!it.step_is_valid) {
       // HandleInvalidStep
@@ -1162,10 +1175,10 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
 
     // ---- candidate point ----
     std::vector<double> old_poses = pb.poses, old_points = pb.points, old_objects = pb.objects;
-    double step_sq = 0.0;
-    for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) { const double d = -y_c[pose_row(rd, p) + k]; pb.poses[6 * p + k] += d; step_sq += d * d; }
-    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const double d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] += d; step_sq += d * d; }
-    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const double d = delta_l[3 * l + k]; pb.points[3 * l + k] += d; step_sq += d * d; }
+    real step_sq = 0.0;   // (the parameter blocks are fp64 in every build: the step is rounded once, where it is added)
+    for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) { const real d = -y_c[pose_row(rd, p) + k]; pb.poses[6 * p + k] = (double)(pb.poses[6 * p + k] + d); step_sq += d * d; }
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const real d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] = (double)(pb.objects[7 * o + k] + d); step_sq += d * d; }
+    for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const real d = delta_l[3 * l + k]; pb.points[3 * l + k] = (double)(pb.points[3 * l + k] + d); step_sq += d * d; }
     tt = now_s();
     double cand_cost = reduced_cost(pb, rd);
     t_res += now_s() - tt;
@@ -1173,7 +1186,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
 
     auto revert = [&]() { pb.poses = old_poses; pb.points = old_points; pb.objects = old_objects; };
     // ParameterToleranceReached
-    it.step_norm = std::sqrt(step_sq);
+    it.step_norm = (double)std::sqrt(step_sq);
     if (it.step_norm <= prm->parameter_tolerance * (x_norm + prm->parameter_tolerance)) {
       revert();
       finish(OBVI_CONVERGENCE, "Parameter tolerance reached.");

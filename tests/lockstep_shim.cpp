@@ -1,6 +1,8 @@
 // Test infrastructure (see lockstep_shim.h): the C ABI forwarded to the HIP library and to the CPU oracle in lock step.
 // Compiled WITHOUT the renaming header, so obvi_ba_* below are the real entry points of libobvi_ba.so.
 // One JSON line per compared call goes to $OBVI_LOCKSTEP_LOG.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -46,9 +48,41 @@ int64_t oracle_ba_num_factors(const oracle_handle*, int32_t);
 }
 
 namespace {
+// Optional third backend, the ARBITER: $OBVI_LOCKSTEP_ARBITER = path of oracle/libobvi_oracle_ld.so (the oracle's source with every
+// solver-level sum in extended precision).  Same `oracle_` symbols as the checker this file links, hence dlopen(RTLD_LOCAL) + dlsym.
+// It receives every upload, starts every solve from the same values, and its solve is logged beside the other two: when HIP and the
+// oracle part ways, |HIP - arbiter| against |oracle - arbiter| says whether one of them is the outlier.
+struct Arbiter {
+  void* lib = nullptr;
+  template <class F> void sym(F& f, const char* name) { f = lib ? reinterpret_cast<F>(dlsym(lib, name)) : nullptr; if (lib && !f) { std::fprintf(stderr, "lockstep: arbiter lacks %s\n", name); std::abort(); } }
+  decltype(&oracle_ba_create) create; decltype(&oracle_ba_destroy) destroy; decltype(&oracle_ba_set_cameras) set_cameras; decltype(&oracle_ba_set_poses) set_poses;
+  decltype(&oracle_ba_set_points) set_points; decltype(&oracle_ba_set_objects) set_objects; decltype(&oracle_ba_set_const_flags) set_const_flags;
+  decltype(&oracle_ba_set_reproj) set_reproj; decltype(&oracle_ba_set_bbox) set_bbox; decltype(&oracle_ba_set_shape_priors) set_shape_priors;
+  decltype(&oracle_ba_set_ltm_priors) set_ltm_priors; decltype(&oracle_ba_set_relpose) set_relpose; decltype(&oracle_ba_set_active_mask) set_active_mask;
+  decltype(&oracle_ba_set_parameter_priors) set_parameter_priors; decltype(&oracle_ba_solve) solve; decltype(&oracle_ba_get_iterations) get_iterations;
+  decltype(&oracle_ba_snapshot) snapshot; decltype(&oracle_ba_restore) restore; decltype(&oracle_ba_get_poses) get_poses; decltype(&oracle_ba_get_points) get_points;
+  decltype(&oracle_ba_get_objects) get_objects; decltype(&oracle_ba_update_points) update_points; decltype(&oracle_ba_update_poses) update_poses; decltype(&oracle_ba_update_objects) update_objects;
+  void (*set_threads)(int32_t);
+  Arbiter() {
+    const char* path = std::getenv("OBVI_LOCKSTEP_ARBITER");
+    if (!path || !*path) return;
+    lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { std::fprintf(stderr, "lockstep: cannot load the arbiter %s: %s\n", path, dlerror()); std::abort(); }
+    sym(create, "oracle_ba_create"); sym(destroy, "oracle_ba_destroy"); sym(set_cameras, "oracle_ba_set_cameras"); sym(set_poses, "oracle_ba_set_poses"); sym(set_points, "oracle_ba_set_points");
+    sym(set_objects, "oracle_ba_set_objects"); sym(set_const_flags, "oracle_ba_set_const_flags"); sym(set_reproj, "oracle_ba_set_reproj"); sym(set_bbox, "oracle_ba_set_bbox");
+    sym(set_shape_priors, "oracle_ba_set_shape_priors"); sym(set_ltm_priors, "oracle_ba_set_ltm_priors"); sym(set_relpose, "oracle_ba_set_relpose"); sym(set_active_mask, "oracle_ba_set_active_mask");
+    sym(set_parameter_priors, "oracle_ba_set_parameter_priors"); sym(solve, "oracle_ba_solve"); sym(get_iterations, "oracle_ba_get_iterations"); sym(snapshot, "oracle_ba_snapshot");
+    sym(restore, "oracle_ba_restore"); sym(get_poses, "oracle_ba_get_poses"); sym(get_points, "oracle_ba_get_points"); sym(get_objects, "oracle_ba_get_objects");
+    sym(update_points, "oracle_ba_update_points"); sym(update_poses, "oracle_ba_update_poses"); sym(update_objects, "oracle_ba_update_objects"); sym(set_threads, "oracle_set_threads");
+    if (const char* t = std::getenv("OBVI_LOCKSTEP_ARBITER_THREADS")) set_threads(std::atoi(t));
+  }
+};
+Arbiter& arb() { static Arbiter a; return a; }
+#define ARB(call) do { if (arb().lib && L_(h)->arb) (void)arb().call; } while (0)
 struct Lock {
   obvi_ba_handle* hip = nullptr;
   oracle_handle* ora = nullptr;
+  oracle_handle* arb = nullptr;
   int64_t P = 0, L = 0, O = 0;
 };
 Lock* L_(obvi_ba_handle* h) { return reinterpret_cast<Lock*>(h); }
@@ -80,39 +114,40 @@ int lock_ba_create(const obvi_ba_options* opt, obvi_ba_handle** out) {
   Lock* l = new Lock();
   const int rh = obvi_ba_create(opt, &l->hip), ro = oracle_ba_create(opt, &l->ora);
   if (rh != 0 || ro != 0) { if (l->hip) obvi_ba_destroy(l->hip); if (l->ora) oracle_ba_destroy(l->ora); delete l; *out = nullptr; return rh ? rh : ro; }
+  if (arb().lib && arb().create(opt, &l->arb) != 0) l->arb = nullptr;
   *out = reinterpret_cast<obvi_ba_handle*>(l);
   return 0;
 }
-void lock_ba_destroy(obvi_ba_handle* h) { if (!h) return; Lock* l = L_(h); obvi_ba_destroy(l->hip); oracle_ba_destroy(l->ora); delete l; }
+void lock_ba_destroy(obvi_ba_handle* h) { if (!h) return; Lock* l = L_(h); obvi_ba_destroy(l->hip); oracle_ba_destroy(l->ora); if (l->arb) arb().destroy(l->arb); delete l; }
 const char* lock_ba_last_error(const obvi_ba_handle* h) { return h ? obvi_ba_last_error(L_(h)->hip) : "null handle"; }
-int lock_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const double* e) { return both(obvi_ba_set_cameras(L_(h)->hip, n, K, e), oracle_ba_set_cameras(L_(h)->ora, n, K, e), "set_cameras"); }
-int lock_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->P = n; return both(obvi_ba_set_poses(L_(h)->hip, n, v, c), oracle_ba_set_poses(L_(h)->ora, n, v, c), "set_poses"); }
-int lock_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->L = n; return both(obvi_ba_set_points(L_(h)->hip, n, v, c), oracle_ba_set_points(L_(h)->ora, n, v, c), "set_points"); }
-int lock_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->O = n; return both(obvi_ba_set_objects(L_(h)->hip, n, v, c), oracle_ba_set_objects(L_(h)->ora, n, v, c), "set_objects"); }
-int lock_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* a, const uint8_t* b, const uint8_t* c) { return both(obvi_ba_set_const_flags(L_(h)->hip, a, b, c), oracle_ba_set_const_flags(L_(h)->ora, a, b, c), "set_const_flags"); }
+int lock_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const double* e) { ARB(set_cameras(L_(h)->arb, n, K, e)); return both(obvi_ba_set_cameras(L_(h)->hip, n, K, e), oracle_ba_set_cameras(L_(h)->ora, n, K, e), "set_cameras"); }
+int lock_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->P = n; ARB(set_poses(L_(h)->arb, n, v, c)); return both(obvi_ba_set_poses(L_(h)->hip, n, v, c), oracle_ba_set_poses(L_(h)->ora, n, v, c), "set_poses"); }
+int lock_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->L = n; ARB(set_points(L_(h)->arb, n, v, c)); return both(obvi_ba_set_points(L_(h)->hip, n, v, c), oracle_ba_set_points(L_(h)->ora, n, v, c), "set_points"); }
+int lock_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { L_(h)->O = n; ARB(set_objects(L_(h)->arb, n, v, c)); return both(obvi_ba_set_objects(L_(h)->hip, n, v, c), oracle_ba_set_objects(L_(h)->ora, n, v, c), "set_objects"); }
+int lock_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* a, const uint8_t* b, const uint8_t* c) { ARB(set_const_flags(L_(h)->arb, a, b, c)); return both(obvi_ba_set_const_flags(L_(h)->hip, a, b, c), oracle_ba_set_const_flags(L_(h)->ora, a, b, c), "set_const_flags"); }
 int lock_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* a, const uint32_t* b, const uint16_t* c, const double* px, const double* sg, double ss, double hu) {
-  return both(obvi_ba_set_reproj(L_(h)->hip, n, a, b, c, px, sg, ss, hu), oracle_ba_set_reproj(L_(h)->ora, n, a, b, c, px, sg, ss, hu), "set_reproj");
+  ARB(set_reproj(L_(h)->arb, n, a, b, c, px, sg, ss, hu)); return both(obvi_ba_set_reproj(L_(h)->hip, n, a, b, c, px, sg, ss, hu), oracle_ba_set_reproj(L_(h)->ora, n, a, b, c, px, sg, ss, hu), "set_reproj");
 }
 int lock_ba_set_bbox(obvi_ba_handle* h, int64_t n, const uint32_t* a, const uint32_t* b, const uint16_t* c, const double* co, const double* cv, double hu, double inv) {
-  return both(obvi_ba_set_bbox(L_(h)->hip, n, a, b, c, co, cv, hu, inv), oracle_ba_set_bbox(L_(h)->ora, n, a, b, c, co, cv, hu, inv), "set_bbox");
+  ARB(set_bbox(L_(h)->arb, n, a, b, c, co, cv, hu, inv)); return both(obvi_ba_set_bbox(L_(h)->hip, n, a, b, c, co, cv, hu, inv), oracle_ba_set_bbox(L_(h)->ora, n, a, b, c, co, cv, hu, inv), "set_bbox");
 }
-int lock_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* a, const double* m, const double* c, double hu) { return both(obvi_ba_set_shape_priors(L_(h)->hip, n, a, m, c, hu), oracle_ba_set_shape_priors(L_(h)->ora, n, a, m, c, hu), "set_shape_priors"); }
-int lock_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* a, const double* m, const double* c, double hu) { return both(obvi_ba_set_ltm_priors(L_(h)->hip, n, a, m, c, hu), oracle_ba_set_ltm_priors(L_(h)->ora, n, a, m, c, hu), "set_ltm_priors"); }
+int lock_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* a, const double* m, const double* c, double hu) { ARB(set_shape_priors(L_(h)->arb, n, a, m, c, hu)); return both(obvi_ba_set_shape_priors(L_(h)->hip, n, a, m, c, hu), oracle_ba_set_shape_priors(L_(h)->ora, n, a, m, c, hu), "set_shape_priors"); }
+int lock_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* a, const double* m, const double* c, double hu) { ARB(set_ltm_priors(L_(h)->arb, n, a, m, c, hu)); return both(obvi_ba_set_ltm_priors(L_(h)->hip, n, a, m, c, hu), oracle_ba_set_ltm_priors(L_(h)->ora, n, a, m, c, hu), "set_ltm_priors"); }
 int lock_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* a, const uint32_t* b, const double* t, const double* aa, const double* c, double hu) {
-  return both(obvi_ba_set_relpose(L_(h)->hip, n, a, b, t, aa, c, hu), oracle_ba_set_relpose(L_(h)->ora, n, a, b, t, aa, c, hu), "set_relpose");
+  ARB(set_relpose(L_(h)->arb, n, a, b, t, aa, c, hu)); return both(obvi_ba_set_relpose(L_(h)->hip, n, a, b, t, aa, c, hu), oracle_ba_set_relpose(L_(h)->ora, n, a, b, t, aa, c, hu), "set_relpose");
 }
-int lock_ba_set_active_mask(obvi_ba_handle* h, int32_t t, const uint8_t* m) { return both(obvi_ba_set_active_mask(L_(h)->hip, t, m), oracle_ba_set_active_mask(L_(h)->ora, t, m), "set_active_mask"); }
+int lock_ba_set_active_mask(obvi_ba_handle* h, int32_t t, const uint8_t* m) { ARB(set_active_mask(L_(h)->arb, t, m)); return both(obvi_ba_set_active_mask(L_(h)->hip, t, m), oracle_ba_set_active_mask(L_(h)->ora, t, m), "set_active_mask"); }
 int lock_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* k, const uint32_t* b, const uint8_t* p, const double* m, const double* s) {
-  return both(obvi_ba_set_parameter_priors(L_(h)->hip, n, k, b, p, m, s), oracle_ba_set_parameter_priors(L_(h)->ora, n, k, b, p, m, s), "set_parameter_priors");
+  ARB(set_parameter_priors(L_(h)->arb, n, k, b, p, m, s)); return both(obvi_ba_set_parameter_priors(L_(h)->hip, n, k, b, p, m, s), oracle_ba_set_parameter_priors(L_(h)->ora, n, k, b, p, m, s), "set_parameter_priors");
 }
 int64_t lock_ba_num_residuals(const obvi_ba_handle* h) { return obvi_ba_num_residuals(L_(h)->hip); }
 int64_t lock_ba_num_factors(const obvi_ba_handle* h, int32_t t) { return obvi_ba_num_factors(L_(h)->hip, t); }
-int lock_ba_snapshot(obvi_ba_handle* h) { return both(obvi_ba_snapshot(L_(h)->hip), oracle_ba_snapshot(L_(h)->ora), "snapshot"); }
-int lock_ba_restore(obvi_ba_handle* h) { return both(obvi_ba_restore(L_(h)->hip), oracle_ba_restore(L_(h)->ora), "restore"); }
+int lock_ba_snapshot(obvi_ba_handle* h) { ARB(snapshot(L_(h)->arb)); return both(obvi_ba_snapshot(L_(h)->hip), oracle_ba_snapshot(L_(h)->ora), "snapshot"); }
+int lock_ba_restore(obvi_ba_handle* h) { ARB(restore(L_(h)->arb)); return both(obvi_ba_restore(L_(h)->hip), oracle_ba_restore(L_(h)->ora), "restore"); }
 int lock_ba_get_poses(obvi_ba_handle* h, double* out) { return obvi_ba_get_poses(L_(h)->hip, out); }
 int lock_ba_get_points(obvi_ba_handle* h, double* out) { return obvi_ba_get_points(L_(h)->hip, out); }
 int lock_ba_get_objects(obvi_ba_handle* h, double* out) { return obvi_ba_get_objects(L_(h)->hip, out); }
-int lock_ba_update_points(obvi_ba_handle* h, int64_t n, const double* x) { return both(obvi_ba_update_points(L_(h)->hip, n, x), oracle_ba_update_points(L_(h)->ora, n, x), "update_points"); }
+int lock_ba_update_points(obvi_ba_handle* h, int64_t n, const double* x) { ARB(update_points(L_(h)->arb, n, x)); return both(obvi_ba_update_points(L_(h)->hip, n, x), oracle_ba_update_points(L_(h)->ora, n, x), "update_points"); }
 int lock_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap) { return obvi_ba_get_iterations(L_(h)->hip, out, cap); }
 
 int lock_ba_evaluate(obvi_ba_handle* h, int32_t loss, double* cost, double* res, double* sq) {
@@ -155,6 +190,30 @@ int lock_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
                  rel(sum->initial_cost, so.initial_cost), rel(sum->final_cost, so.final_cost), it_cost_rel, max_abs_diff(ph, po), max_abs_diff(xh, xo), object_diff(oh, oo),
                  (sum->num_parameters_reduced == so.num_parameters_reduced && sum->num_residuals_reduced == so.num_residuals_reduced) ? 1 : 0);
     std::fflush(f);
+  }
+  if (arb().lib && l->arb) {
+    // the same solve once more, with every solver-level sum in extended precision; then the arbiter, too, continues from the HIP result
+    obvi_summary sa; std::memset(&sa, 0, sizeof(sa));
+    arb().solve(l->arb, prm, &sa);
+    std::vector<double> pa(ph.size()), xa(xh.size()), oa(oh.size());
+    arb().get_poses(l->arb, pa.data()); arb().get_points(l->arb, xa.data()); arb().get_objects(l->arb, oa.data());
+    if (FILE* f = log_file()) {
+      std::vector<obvi_iteration_summary> ia((size_t)std::max(1, sa.num_iterations)), ih((size_t)std::max(1, sum->num_iterations)), io((size_t)std::max(1, so.num_iterations));
+      const int na = arb().get_iterations(l->arb, ia.data(), (int32_t)ia.size());
+      const int nh = obvi_ba_get_iterations(l->hip, ih.data(), (int32_t)ih.size()), no = oracle_ba_get_iterations(l->ora, io.data(), (int32_t)io.size());
+      // how long each fp64 run follows the arbiter: first iteration whose accept flag differs, or whose cost is further than 1e-6 away
+      auto follows = [&](const std::vector<obvi_iteration_summary>& x, int nx) {
+        int k = 0;
+        while (k < std::min(nx, na) && x[k].step_is_successful == ia[k].step_is_successful && rel(x[k].cost, ia[k].cost) <= 1e-6) ++k;
+        return k;
+      };
+      std::fprintf(f, "{\"call\": \"arbiter\", \"iterations_arbiter\": %d, \"iterations_hip\": %d, \"iterations_oracle\": %d, \"termination_arbiter\": %d, \"hip_follows\": %d, \"oracle_follows\": %d, "
+                      "\"final_cost_arbiter\": %.17g, \"hip_final_cost_rel\": %.3e, \"oracle_final_cost_rel\": %.3e, \"hip_pose_diff\": %.3e, \"oracle_pose_diff\": %.3e, \"hip_object_diff\": %.3e, \"oracle_object_diff\": %.3e}\n",
+                   na, nh, no, sa.termination_type, follows(ih, nh), follows(io, no), sa.final_cost, rel(sum->final_cost, sa.final_cost), rel(so.final_cost, sa.final_cost),
+                   max_abs_diff(ph, pa), max_abs_diff(po, pa), object_diff(oh, oa), object_diff(oo, oa));
+      std::fflush(f);
+    }
+    arb().update_poses(l->arb, l->P, ph.data()); arb().update_points(l->arb, l->L, xh.data()); arb().update_objects(l->arb, l->O, oh.data());
   }
   // lock step: the oracle continues from the HIP path's result
   oracle_ba_update_poses(l->ora, l->P, ph.data()); oracle_ba_update_points(l->ora, l->L, xh.data()); oracle_ba_update_objects(l->ora, l->O, oh.data());

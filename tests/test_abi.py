@@ -97,3 +97,13 @@ def test_generator_shapes():
     px, z = synth.project_points(prob["gt_poses"][prob["rp_pose"]], prob["gt_points"][prob["rp_point"]])
     inl = ~prob["rp_is_outlier"]
     assert np.abs(px - prob["rp_pixel"])[inl].std() < 1.2 and z.min() > 0.5
+
+
+def test_host_pool_hands_every_part_out_exactly_once(tmp_path):
+    """csrc/host_util.h HostPool (the worker threads of the symbolic phase): 40 000 back-to-back runs of changing part counts from two
+    caller threads -- every part exactly once, nothing after run() has returned (a part index could cross from one run to the next)."""
+    import subprocess
+    exe = str(tmp_path / "hostpool_stress")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, os.path.join(helpers.ROOT, "tests", "hostpool_stress.cpp")])
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr

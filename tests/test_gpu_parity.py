@@ -375,6 +375,48 @@ def test_bench_workload_invariants():
     assert st["reduced_rows"] == 6 * 1999 + 7 * 200 and st["chol_levels"] < 40
 
 
+def test_config3_follows_the_oracle_for_two_steps():
+    """The HEADLINE workload itself (bench.py config 3: seed 20241008 + 3, 2000 KF / 200 objects / 300k features, zero tolerances) against the
+    oracle -- 20 host threads, about 2 s per LM step -- for two LM steps, deterministic handle and default handle.
+    Tolerances, measured (scripts/arbiter.py, profiles/r04_arbiter_cfg3.txt) and why:
+      step 0  initial cost: the same arithmetic summed in another order                                   -> 1e-12
+      step 1  ONE reduced solve from identical values: the conditioning of S (~1e9) times fp64 round-off; the extended-precision arbiter
+              puts HIP and the oracle at the same distance (1e-9 .. 1e-8 in cost) from the exact step              -> cost 1e-6, |step| 1e-5, rho 1e-5
+      step 2  starts from two states 1e-8 apart on a problem with a free gauge, zero tolerances and non-monotonic steps: the difference
+              of step 1 is amplified ~1e4 x per step (the same factor separates the product's OWN two modes)       -> cost 1e-2, same decision
+    """
+    import ctypes
+    prob = synth.make_problem(P=2000, L=300000, O=200, seed=20241008 + 3, const_poses=1, min_obj_obs=10)
+    prm = obvi_ba.SolverParams(max_num_iterations=2, allow_non_monotonic_steps=True, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+                               initial_trust_region_radius=100.0, max_trust_region_radius=1e4)
+    lib = ctypes.CDLL(helpers.ensure_oracle())
+    before = lib.oracle_get_threads()
+    lib.oracle_set_threads(ctypes.c_int32(max(1, min(20, os.cpu_count() or 1))))
+    try:
+        o = helpers.oracle_ba(); synth.upload(o, prob)
+        o.solve(prm)
+        io = o.iterations()
+    finally:
+        lib.oracle_set_threads(ctypes.c_int32(before))
+    assert len(io) == 3
+    for det in (True, False):
+        g = helpers.product_ba(deterministic=det); synth.upload(g, prob)
+        g.solve(prm)
+        ig = g.iterations()
+        g.close()
+        assert len(ig) == 3
+        rel = lambda a, b: abs(a - b) / abs(b)      # noqa: E731
+        print("config 3 vs oracle (%s): cost %.2e / %.2e / %.2e, step norm %.2e / %.2e, rho %.2e / %.2e" % (
+            "deterministic" if det else "default", rel(ig[0].cost, io[0].cost), rel(ig[1].cost, io[1].cost), rel(ig[2].cost, io[2].cost),
+            rel(ig[1].step_norm, io[1].step_norm), rel(ig[2].step_norm, io[2].step_norm), abs(ig[1].relative_decrease - io[1].relative_decrease), abs(ig[2].relative_decrease - io[2].relative_decrease)))
+        assert rel(ig[0].cost, io[0].cost) <= 1e-12 and rel(ig[0].gradient_max_norm, io[0].gradient_max_norm) <= 1e-10
+        assert (ig[1].step_is_valid, ig[1].step_is_successful) == (io[1].step_is_valid, io[1].step_is_successful)
+        assert rel(ig[1].cost, io[1].cost) <= 1e-6 and rel(ig[1].step_norm, io[1].step_norm) <= 1e-5 and abs(ig[1].relative_decrease - io[1].relative_decrease) <= 1e-5
+        assert rel(ig[1].trust_region_radius, io[1].trust_region_radius) <= 1e-4
+        assert (ig[2].step_is_valid, ig[2].step_is_successful) == (io[2].step_is_valid, io[2].step_is_successful)
+        assert rel(ig[2].cost, io[2].cost) <= 1e-2
+
+
 def test_stereo_rig_matches_oracle():
     """Two cameras: a point is observed twice from the same pose, which exercises the same-pose observation pairs
     of the Schur complement (diagonal blocks receive both orders of the pair)."""
