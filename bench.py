@@ -290,6 +290,42 @@ def end_to_end_global_ba(obvi_ba, synth, prob, device):
                     "of this process (Python binding included), inputs start on the host"}
 
 
+def end_to_end_cpp(prob, device):
+    """The same "run as specified" global BA through the C++ DROP-IN layer instead of the Python re-enactment above: the scene goes to
+    obvi-slam_amd/host/run_offline_ba (the mirror of the reference's runner: frame data adder -> pose graph -> OfflineProblemRunner ->
+    runOptimizationIteration's global-BA branch = runPgoPlusEllipsoids + two-phase optimisation with base7a_2_fallback values ->
+    ObjectPoseGraphOptimizer::buildPoseGraphOptimization / solveOptimization -> C ABI), `--global-ba`: every frame enters the pose graph,
+    then the runner starts at the last frame (run_opt_from_pg_state.cpp:160-312 without the checkpoint file).  Wall clock of that process
+    stage by stage; OBVI_API_TIMING gives the time inside each ABI entry point."""
+    import re
+    import subprocess
+    import tempfile
+    import scene_io
+    exe = os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba")
+    if not os.path.exists(exe):
+        return {"error": "obvi-slam_amd/host/run_offline_ba not built"}
+    with tempfile.TemporaryDirectory() as td:
+        scene, out = os.path.join(td, "scene.bin"), os.path.join(td, "out.json")
+        t0 = time.perf_counter()
+        scene_io.write_scene_binary(prob, scene)
+        t_write = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, scene, out, "--global-ba", "--device", str(device)], capture_output=True, text=True, timeout=600, env=dict(os.environ, OBVI_API_TIMING="1"))
+        wall = time.perf_counter() - t0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "run_offline_ba --global-ba failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
+    rep = json.loads(lines[-1])
+    api = {}
+    for m in re.finditer(r"^api timing: (.+?)\s+([0-9.]+) ms in\s+(\d+) calls", r.stderr, re.M):
+        api[m.group(1).strip()] = {"ms": float(m.group(2)), "calls": int(m.group(3))}
+    rep.update(process_wall_ms=round(1e3 * wall, 1), scene_write_ms=round(1e3 * t_write, 1), lm_iterations_total=sum(x["iterations"] for x in rep["records"]),
+               api_timing=api or r.stderr[-1500:],
+               note="C++ host mirror end to end: scene_load + pose_graph (frame data adder, all frames) + run_full_optimization (build, upload, symbolic, PGO stage, "
+                    "features-only BA, phase I, selection, phase II, read-back); process_wall_ms adds process start, HIP context creation and the result file")
+    return rep
+
+
 def collective_latency(torch, ba, comm, dist, args, prob, world, reps=50):
     """Microseconds per all-reduce of the three per-step sizes of the config-4 exchange (shared objects' blocks 56 doubles each; the shared
     tail tiles + right-hand side; the scalar sums + one slot per rank), on the live communicator / process group, back to back on one stream.
@@ -628,6 +664,7 @@ def main():
             bd.close()
         if world == 1 and args.config == 3 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_global_ba(obvi_ba, synth, prob, local_rank)
+            out["end_to_end_cpp"] = end_to_end_cpp(prob, local_rank)
         if not args.no_cpu_baseline:
             legs = {}
             if world == 1:

@@ -160,9 +160,9 @@ void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, c
                          const ReducedDev& rd);
 // strip geometry of k_schur_window, shared with the host code that builds the visit lists and decides which pairs
 // the strip covers: row chunks of kSchurRows frames, columns = the kSchurWindowFrames frames ending with the chunk, cut
-// into groups of kSchurGroupCols 16-wide tile columns; visits are streamed through LDS in batches of at most
-// kSchurBatchVisits visits / kSchurBatchBytes of 144-byte slots
-constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSchurBatchBytes = 32768, kSchurBatchVisits = 128;
+// into groups of kSchurGroupCols 16-wide tile columns; visits (up to four points of one class each) are streamed through LDS in batches of
+// at most kSchurBatchVisits visits / kSchurBatchBytes of 144-byte slots, one wavefront per batch
+constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSchurBatchBytes = 8192, kSchurBatchVisits = 16;
 void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
                          const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
                          const int32_t* wg_f0, const int32_t* wg_group);

@@ -757,20 +757,57 @@ void prepare(obvi_ba_handle* h) {
         if (bits) gv[start[bucket(v.chunk, g)]++] = {v.chunk, g, v.l, v.beg, v.k, v.twin, bits};
       }
   }
-  // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
+  // Visits of a work list that cover the same tiles (same 15 tile bits, same stereo flag) have the same LDS image layout: up to four of them
+  // are one visit of the kernel, K = 12 (four points x three coordinates of the eliminated point) in three full v_mfma_f64_16x16x4_f64 per
+  // tile instead of four padded ones, and -- what the kernel is bound by -- one round of records, masks and tile branches for four points.
+  // A list is therefore ordered by that class first (a counting sort; point order inside a class) and cut into groups of <= kQuad points.
+  const int kQuad = std::max(1, std::min(4, env_int("OBVI_SCHUR_QUAD", 4)));   // tuning knob: 1 = one point per visit
+  struct QVisit { uint32_t first; uint8_t n; };   // gv[first .. first + n): points of one class
+  std::vector<QVisit> qv;
+  std::vector<uint32_t> q_list_end;   // per (chunk, group) list: end in qv
+  {
+    std::vector<GVisit> sorted;
+    std::vector<uint32_t> count, order;
+    for (size_t q = 0; q < gv.size();) {
+      size_t e = q;
+      while (e < gv.size() && gv[e].chunk == gv[q].chunk && gv[e].group == gv[q].group) ++e;
+      if (kQuad > 1) {
+        auto key = [&](const GVisit& v) { return (v.bits & 0x7fffu) | (v.twin ? 0x8000u : 0u); };
+        count.assign(65537, 0);
+        for (size_t t = q; t < e; ++t) ++count[key(gv[t]) + 1];
+        for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+        sorted.resize(e - q);
+        for (size_t t = q; t < e; ++t) sorted[count[key(gv[t])]++] = gv[t];
+        std::copy(sorted.begin(), sorted.end(), gv.begin() + (std::ptrdiff_t)q);
+        for (size_t t = q; t < e;) {
+          size_t u = t + 1;
+          while (u < e && u - t < (size_t)kQuad && key(gv[u]) == key(gv[t])) ++u;
+          qv.push_back({(uint32_t)t, (uint8_t)(u - t)});
+          t = u;
+        }
+      } else {
+        for (size_t t = q; t < e; ++t) qv.push_back({(uint32_t)t, 1});
+      }
+      q_list_end.push_back((uint32_t)qv.size());
+      q = e;
+    }
+  }
+  // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits (points) each
   // (deterministic mode: a work list is never cut -- one workgroup, hence one writer, per strip)
   const int64_t slice = h->deterministic ? ((int64_t)1 << 40) : std::min<int64_t>(max_visits, std::max<int64_t>(64, (int64_t)gv.size() / env_int("OBVI_SCHUR_WGS", 1536)));
-  // per workgroup: batches of visits that fit the kernel's LDS buffer.  A visit is laid out as consecutive 144-byte
+  // per workgroup: batches of visits, each the LDS image one WAVEFRONT streams and multiplies on its own (kSchurBatchBytes; the four
+  // wavefronts of a workgroup take the workgroup's batches round-robin).  A point of a visit is laid out as consecutive 144-byte
   // slots: one per strip frame over the range of its row frames and of its column frames in the group (source: the Z
   // record, or the zero page for a frame the point skips), the point's (u_l, 0) tail, and -- stereo -- a second layer
-  // with the second record of each frame.
+  // with the second record of each frame; the points of a visit follow each other at a fixed stride.
   const uint32_t zero16 = (uint32_t)((18ull * (uint64_t)h->n_rp + 4ull * (uint64_t)L + 4ull) / 2);   // zero page behind the Z blocks
   std::vector<uint32_t> wg_bptr(1, 0), bfirst(1, 0), bslot(1, 0), visits, slot_src;
   std::vector<int32_t> wg_f0, wg_group;
-  visits.reserve(4 * gv.size());
+  visits.reserve(gv.size() + 16);
   constexpr uint32_t kBatchSlots = kSchurBatchBytes / 144;
-  auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) {
-    // The image of a visit covers every strip frame that an ACTIVE tile of the visit touches -- row tiles that hold one of the point's
+  // slots of ONE point of a visit (appended to `out`), and the visit's record (identical for the points of a class)
+  auto point_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) -> uint32_t {
+    // The image of a point covers every strip frame that an ACTIVE tile of the visit touches -- row tiles that hold one of the point's
     // row frames, column tiles of the group that hold one of its column frames -- with the zero page for the frames the point does not
     // observe.  A lane's operand is then at (visit-uniform base) + (lane constant), no range test: k_schur_window.
     const int32_t fbase = v.chunk * SR - SBACK;
@@ -796,28 +833,31 @@ void prepare(obvi_ba_handle* h) {
       const uint32_t src = (uint32_t)((18ull * a + 4ull * v.l) / 2);
       if (prim[fo] == zero16) prim[fo] = src; else sec[fo] = src;
     }
-    out.clear();
+    const size_t at0 = out.size();
     int32_t slotA0, slotB0;   // slot of strip frame 0 for the row operands / the column operands (may lie before the image: only covered frames are read)
     uint32_t tail;
     const bool merged = B0 <= A1 + 1 && A0 <= B1 + 1;
+    uint32_t layer = 0;
     if (merged) {
       const int32_t lo = std::min(A0, B0), hi = std::max(A1, B1);
       for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(prim[fo]);
       slotA0 = slotB0 = (int32_t)base - lo; tail = base + (uint32_t)(hi - lo + 1);
       out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));   // z_tail()
+      layer = (uint32_t)(hi - lo + 2);
       if (v.twin) for (int32_t fo = lo; fo <= hi; ++fo) out.push_back(sec[fo]);
     } else {
       for (int32_t fo = A0; fo <= A1; ++fo) out.push_back(prim[fo]);
       slotA0 = (int32_t)base - A0; tail = base + (uint32_t)(A1 - A0 + 1); slotB0 = (int32_t)tail + 1 - B0;
       out.push_back((uint32_t)((18ull * (v.beg + v.k) + 4ull * v.l) / 2));
       for (int32_t fo = B0; fo <= B1; ++fo) out.push_back(prim[fo]);
+      layer = (uint32_t)(out.size() - at0);
       if (v.twin) {
         for (int32_t fo = A0; fo <= A1; ++fo) out.push_back(sec[fo]);
         out.push_back(zero16);
         for (int32_t fo = B0; fo <= B1; ++fo) out.push_back(sec[fo]);
       }
     }
-    const uint32_t layer = v.twin ? (uint32_t)out.size() / 2 + (merged ? 1u : 0u) : 0u;   // slots from a record to its second-layer twin
+    if (!v.twin) layer = 0;   // slots from a record to its second-layer twin
     rec[0] = (uint32_t)(144 * slotA0);                                  // byte offset of strip frame 0 in the batch image, row operands (int32)
     rec[1] = (uint32_t)(144 * slotB0);                                  // ... column operands
     rec[2] = tail | (layer << 16);
@@ -826,16 +866,58 @@ void prepare(obvi_ba_handle* h) {
     // the visit's tiles are (row tiles in use) x (column tiles in use), minus the tiles above the diagonal in the chunk's own group (a cut
     // the kernel knows at compile time): two masks instead of 15 tile bits
     rec[3] = cols | (v.twin ? 1u << 15 : 0u) | (rows << 16);
+    return (uint32_t)(out.size() - at0);
   };
+  // a visit = n points of one class: their images one after the other (stride = slots of one point), one record:
+  // rec[3] |= (n - 1) << 19 | stride << 21
+  auto visit_slots = [&](const QVisit& q, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) {
+    out.clear();
+    uint32_t stride = 0, r0[4];
+    for (uint32_t p = 0; p < q.n; ++p) {
+      uint32_t rp_[4];
+      const uint32_t ns = point_slots(gv[q.first + p], base, out, p == 0 ? r0 : rp_);
+      if (p == 0) stride = ns;
+    }
+    rec[0] = r0[0]; rec[1] = r0[1]; rec[2] = r0[2];
+    rec[3] = r0[3] | ((uint32_t)(q.n - 1) << 19) | (stride << 21);
+  };
+  // a class whose points need more slots than a wavefront's buffer holds four of is cut into smaller visits here
+  {
+    std::vector<QVisit> fit;
+    std::vector<uint32_t> list_end, vs;
+    uint32_t rec[4];
+    size_t li = 0;
+    for (size_t t = 0; t < qv.size(); ++t) {
+      while (li < q_list_end.size() && t >= q_list_end[li]) { list_end.push_back((uint32_t)fit.size()); ++li; }
+      QVisit one = qv[t]; one.n = 1;
+      visit_slots(one, 0, vs, rec);
+      const uint32_t per = (uint32_t)vs.size();
+      if (per > kBatchSlots) throw std::runtime_error("schur plan: one point of a visit does not fit a batch buffer");
+      const uint32_t nmax = std::max<uint32_t>(1, std::min<uint32_t>(4, kBatchSlots / per));
+      for (uint32_t p = 0; p < qv[t].n; p += nmax) fit.push_back({qv[t].first + p, (uint8_t)std::min<uint32_t>(nmax, qv[t].n - p)});
+    }
+    while (li < q_list_end.size()) { list_end.push_back((uint32_t)fit.size()); ++li; }
+    qv.swap(fit); q_list_end.swap(list_end);
+  }
   // the workgroups (slices of the work lists) are independent: ranges of them on host threads, joined in order
-  struct WgRange { size_t w, we; int32_t chunk, group; };
+  struct WgRange { size_t w, we; int32_t chunk, group; };   // range in qv
   std::vector<WgRange> wgs;
-  for (size_t q = 0; q < gv.size();) {
-    size_t e = q;
-    while (e < gv.size() && gv[e].chunk == gv[q].chunk && gv[e].group == gv[q].group) ++e;
-    const int64_t n = (int64_t)(e - q), parts = (n + slice - 1) / slice, per = (n + parts - 1) / parts;
-    for (size_t w = q; w < e; w += (size_t)per) wgs.push_back({w, std::min(e, w + (size_t)per), gv[q].chunk, gv[q].group});
-    q = e;
+  {
+    size_t q = 0;
+    for (uint32_t qe : q_list_end) {
+      if (qe == q) continue;
+      int64_t npts = 0;
+      for (size_t t = q; t < qe; ++t) npts += qv[t].n;
+      const int64_t parts = (npts + slice - 1) / slice, per = (npts + parts - 1) / parts;
+      size_t w = q;
+      while (w < qe) {
+        size_t we = w; int64_t got = 0;
+        while (we < qe && got < per) got += qv[we++].n;
+        wgs.push_back({w, we, gv[qv[q].first].chunk, gv[qv[q].first].group});
+        w = we;
+      }
+      q = qe;
+    }
   }
   struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches; };
   const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 1024));
@@ -847,10 +929,10 @@ void prepare(obvi_ba_handle* h) {
     for (int64_t g = g0; g < g1; ++g) {
       uint32_t used = 0, count = 0, nb = 0;
       for (size_t t = wgs[g].w; t < wgs[g].we; ++t) {
-        visit_slots(gv[t], used, vs, rec);
+        visit_slots(qv[t], used, vs, rec);
         if (count == (uint32_t)kSchurBatchVisits || used + (uint32_t)vs.size() > kBatchSlots) {
           o.end_visit.push_back((uint32_t)(o.visits.size() / 4)); o.end_slot.push_back((uint32_t)o.slot_src.size()); ++nb; used = 0; count = 0;
-          visit_slots(gv[t], used, vs, rec);
+          visit_slots(qv[t], used, vs, rec);
         }
         o.visits.insert(o.visits.end(), rec, rec + 4);
         o.slot_src.insert(o.slot_src.end(), vs.begin(), vs.end());
@@ -889,6 +971,13 @@ void prepare(obvi_ba_handle* h) {
   h->npairs = (int64_t)pairs.size();
   pairs.clear(); pairs.shrink_to_fit();
 
+  if (stage_times) {
+    int64_t hist[5] = {0, 0, 0, 0, 0};
+    for (const QVisit& q : qv) ++hist[q.n];
+    std::fprintf(stderr, "  schur plan: %zu point visits in %zu visits (1/2/3/4 points: %lld/%lld/%lld/%lld), %zu workgroups, %zu batches (%.1f slots, %.2f visits each), %zu slots = %.1f MB gathered per launch\n",
+                 gv.size(), qv.size(), (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4], wgs.size(), bslot.size() - 1,
+                 (double)slot_src.size() / std::max<size_t>(1, bslot.size() - 1), (double)qv.size() / std::max<size_t>(1, bslot.size() - 1), slot_src.size(), 144e-6 * (double)slot_src.size());
+  }
   stage("schur batches");
   // ---- tile mask of the reduced matrix (lower triangle) and symbolic fill ----
   for (int k = 0; k < nt; ++k) mask[(size_t)k * nt + k] = 1;

@@ -45,19 +45,42 @@
 #include "oracle_factors.h"
 #include "oracle_frontend.h"
 
+#ifdef OBVI_ORACLE_FACTORS_EXTENDED
+// The arbiter build evaluates the FACTORS in extended precision too: the same header once more with every `double` an x87 long double
+// (namespace oracle_x; every standard header it needs is already included above, so the macro touches nothing else).  Residuals and
+// Jacobians are then exact to ~1e-19 for the fp64 parameter blocks and measurements they are given -- without this the arbiter would share
+// the fp64 checker's own rounded factor records and count every last-digit difference of another evaluation order (the HIP kernels' closed
+// forms) as that side's error, amplified by the cancellation in the reduced gradient.
+#define oracle oracle_x
+#define double long double
+#undef OBVI_ORACLE_FACTORS_H_
+#include "oracle_factors.h"
+#undef double
+#undef oracle
+#endif
+
 namespace {
 using namespace oracle;  // NOLINT
 
 // Scalar of the solver-level sums: every accumulation of the normal equations (J^T J blocks, gradient, column norms), the Schur
 // complement, the skyline factorisation, both substitutions, the model cost change and the cost sums.  `double` in libobvi_oracle.so --
-// the checker.  Compiled a second time with -DOBVI_ORACLE_REAL="long double" (libobvi_oracle_ld.so, `make arbiter`) the same code is the
-// ARBITER of DESIGN.md section 6: factor records (r, J) and the parameter blocks stay fp64 -- identical inputs -- while everything
-// that is summed from them carries 64 mantissa bits, so its round-off sits three decimal digits below both the checker's and the HIP
-// path's; |HIP - arbiter| against |oracle - arbiter| then says which of the two fp64 runs is closer to the exact-arithmetic step.
+// the checker.  Compiled a second time with -DOBVI_ORACLE_REAL="long double" -DOBVI_ORACLE_FACTORS_EXTENDED (libobvi_oracle_ld.so,
+// `make arbiter`) the same code is the ARBITER of DESIGN.md section 6: the parameter blocks and the caller's measurements stay fp64 --
+// identical inputs -- while the factor records AND everything that is summed from them carry 64 mantissa bits, so its round-off sits three
+// decimal digits below both the checker's and the HIP path's; |HIP - arbiter| against |oracle - arbiter| then says which of the two
+// fp64 runs is closer to the exact-arithmetic step.
 #ifndef OBVI_ORACLE_REAL
 #define OBVI_ORACLE_REAL double
 #endif
 typedef OBVI_ORACLE_REAL real;
+// scalar of the factor records (residuals, Jacobians, measurement constants): fp64 in the checker, `real` in the arbiter build
+#ifdef OBVI_ORACLE_FACTORS_EXTENDED
+typedef real fscalar;
+namespace fx = oracle_x;
+#else
+typedef double fscalar;
+namespace fx = oracle;
+#endif
 
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -80,27 +103,28 @@ void parallel_ranges(int64_t n, F&& fn) {   // fn(thread, begin, end), contiguou
 
 struct OracleProblem {
   int reproj_variant = 0;   // obvi_ba_options.reprojection_variant: 0 = a3 (production functor), 1 = a2 (analytic-Jacobian functor)
-  std::vector<CameraConst> cams;
+  std::vector<CameraConst> cams;       // fp64 (index checks, and the camera constants of the checker)
+  std::vector<fx::CameraConst> cams_f; // the factors' camera constants
   int64_t P = 0, L = 0, O = 0;
   std::vector<double> poses, points, objects;
   std::vector<uint8_t> pose_const, point_const, object_const;
   // reprojection
   int64_t n_rp = 0;
   std::vector<uint32_t> rp_pose, rp_point; std::vector<uint16_t> rp_cam;
-  std::vector<double> rp_pixel, rp_sigma; double rp_huber = 1.0; std::vector<uint8_t> rp_active;
+  std::vector<fscalar> rp_pixel, rp_sigma; double rp_huber = 1.0; std::vector<uint8_t> rp_active;
   // bbox
   int64_t n_bb = 0;
   std::vector<uint32_t> bb_obj, bb_pose; std::vector<uint16_t> bb_cam;
-  std::vector<double> bb_rect, bb_sqrt_inf; double bb_huber = 1.0, bb_invalid = 1e6; std::vector<uint8_t> bb_active;
+  std::vector<fscalar> bb_rect, bb_sqrt_inf; double bb_huber = 1.0, bb_invalid = 1e6; std::vector<uint8_t> bb_active;
   // shape prior
   int64_t n_sp = 0;
-  std::vector<uint32_t> sp_obj; std::vector<double> sp_mean, sp_sqrt_inf; double sp_huber = 1.0; std::vector<uint8_t> sp_active;
+  std::vector<uint32_t> sp_obj; std::vector<fscalar> sp_mean, sp_sqrt_inf; double sp_huber = 1.0; std::vector<uint8_t> sp_active;
   // ltm prior
   int64_t n_lt = 0;
-  std::vector<uint32_t> lt_obj; std::vector<double> lt_mean, lt_sqrt_inf; double lt_huber = 1.0; std::vector<uint8_t> lt_active;
+  std::vector<uint32_t> lt_obj; std::vector<fscalar> lt_mean, lt_sqrt_inf; double lt_huber = 1.0; std::vector<uint8_t> lt_active;
   // relative pose
   int64_t n_rl = 0;
-  std::vector<uint32_t> rl_a, rl_b; std::vector<double> rl_t, rl_R, rl_sqrt_inf; double rl_huber = 1.0; std::vector<uint8_t> rl_active;
+  std::vector<uint32_t> rl_a, rl_b; std::vector<fscalar> rl_t, rl_R, rl_sqrt_inf; double rl_huber = 1.0; std::vector<uint8_t> rl_active;
   // parameter priors (parameter_prior.h:17-50), used by the covariance extraction only: kind 0 pose / 1 point / 2 object
   std::vector<uint8_t> pp_kind, pp_param; std::vector<uint32_t> pp_block; std::vector<double> pp_mean, pp_std;
   // snapshot
@@ -120,25 +144,25 @@ struct FactorLin {
   int m = 0;                 // residual dim
   BlockKind k0 = KIND_NONE, k1 = KIND_NONE;
   int64_t i0 = -1, i1 = -1;  // block indices
-  double r[7];
-  double J0[49];             // m x dim(k0), row-major
-  double J1[49];             // m x dim(k1)
-  double cost = 0.0;         // 0.5 * rho(s)
-  double sqnorm = 0.0;       // un-robustified |r|^2
+  fscalar r[7];
+  fscalar J0[49];            // m x dim(k0), row-major
+  fscalar J1[49];            // m x dim(k1)
+  fscalar cost = 0.0;        // 0.5 * rho(s)
+  fscalar sqnorm = 0.0;      // un-robustified |r|^2
 };
 
 // Apply the loss the way ceres::ResidualBlock::Evaluate + Corrector do [Ceres-doc]: for
 // HuberLoss rho'' <= 0 always, so the corrector reduces to scaling r and J by sqrt(rho').
 void robustify(FactorLin* f, double huber_a, bool apply_loss) {
-  double s = 0.0;
+  fscalar s = 0.0;
   for (int i = 0; i < f->m; ++i) s += f->r[i] * f->r[i];
   f->sqnorm = s;
-  if (!apply_loss) { f->cost = 0.5 * s; return; }
-  double rho[3];
-  huber(s, huber_a, rho);
-  f->cost = 0.5 * rho[0];
-  const double w = std::sqrt(rho[1]);
-  if (w != 1.0) {
+  if (!apply_loss) { f->cost = (fscalar)0.5 * s; return; }
+  fscalar rho[3];
+  fx::huber(s, huber_a, rho);
+  f->cost = (fscalar)0.5 * rho[0];
+  const fscalar w = std::sqrt(rho[1]);
+  if (w != (fscalar)1.0) {
     const int d0 = kBlockDim[f->k0], d1 = kBlockDim[f->k1];
     for (int i = 0; i < f->m; ++i) f->r[i] *= w;
     for (int i = 0; i < f->m * d0; ++i) f->J0[i] *= w;
@@ -146,23 +170,26 @@ void robustify(FactorLin* f, double huber_a, bool apply_loss) {
   }
 }
 
+// (the parameter blocks are fp64 in every build; the factors take them as fscalar)
+template <int N> inline void load_block(const double* src, fscalar (&dst)[N]) { for (int k = 0; k < N; ++k) dst[k] = src[k]; }
+
 void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   f->m = 2; f->k0 = KIND_POSE; f->k1 = KIND_POINT; f->i0 = pb.rp_pose[i]; f->i1 = pb.rp_point[i];
-  const double* pose = &pb.poses[6 * f->i0];
-  const double* pt = &pb.points[3 * f->i1];
-  const CameraConst& cam = pb.cams[pb.rp_cam[i]];
+  fscalar pose[6], pt[3];
+  load_block(&pb.poses[6 * f->i0], pose); load_block(&pb.points[3 * f->i1], pt);
+  const fx::CameraConst& cam = pb.cams_f[pb.rp_cam[i]];
   const bool analytic = pb.reproj_variant == OBVI_REPROJECTION_ANALYTIC;
   if (!jac) {
-    if (analytic) reprojection_residual_analytic<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
-    else reprojection_residual<double>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
+    if (analytic) fx::reprojection_residual_analytic<fscalar>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
+    else fx::reprojection_residual<fscalar>(pose, pt, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], f->r);
     return;
   }
-  typedef Dual<9> D;
+  typedef fx::Dual<9> D;
   D dp[6], dx[3], dr[2];
   for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], k);
   for (int k = 0; k < 3; ++k) dx[k] = D::var(pt[k], 6 + k);
-  if (analytic) reprojection_residual_analytic<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
-  else reprojection_residual<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
+  if (analytic) fx::reprojection_residual_analytic<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
+  else fx::reprojection_residual<D>(dp, dx, cam, &pb.rp_pixel[2 * i], pb.rp_sigma[i], dr);
   for (int a = 0; a < 2; ++a) {
     f->r[a] = dr[a].v;
     for (int k = 0; k < 6; ++k) f->J0[6 * a + k] = dr[a].d[k];
@@ -172,15 +199,15 @@ void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
 
 void lin_bbox(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   f->m = 4; f->k0 = KIND_OBJECT; f->k1 = KIND_POSE; f->i0 = pb.bb_obj[i]; f->i1 = pb.bb_pose[i];
-  const double* ell = &pb.objects[7 * f->i0];
-  const double* pose = &pb.poses[6 * f->i1];
-  const CameraConst& cam = pb.cams[pb.bb_cam[i]];
-  if (!jac) { bbox_residual<double>(ell, pose, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, f->r); return; }
-  typedef Dual<13> D;
+  fscalar ell[7], pose[6];
+  load_block(&pb.objects[7 * f->i0], ell); load_block(&pb.poses[6 * f->i1], pose);
+  const fx::CameraConst& cam = pb.cams_f[pb.bb_cam[i]];
+  if (!jac) { fx::bbox_residual<fscalar>(ell, pose, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, f->r); return; }
+  typedef fx::Dual<13> D;
   D de[7], dp[6], dr[4];
   for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
   for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], 7 + k);
-  bbox_residual<D>(de, dp, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, dr);
+  fx::bbox_residual<D>(de, dp, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, dr);
   for (int a = 0; a < 4; ++a) {
     f->r[a] = dr[a].v;
     for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k];
@@ -190,35 +217,37 @@ void lin_bbox(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
 
 void lin_shape(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   f->m = 3; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.sp_obj[i]; f->i1 = -1;
-  const double* ell = &pb.objects[7 * f->i0];
-  if (!jac) { shape_prior_residual<double>(ell, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], f->r); return; }
-  typedef Dual<7> D;
+  fscalar ell[7];
+  load_block(&pb.objects[7 * f->i0], ell);
+  if (!jac) { fx::shape_prior_residual<fscalar>(ell, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], f->r); return; }
+  typedef fx::Dual<7> D;
   D de[7], dr[3];
   for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
-  shape_prior_residual<D>(de, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], dr);
+  fx::shape_prior_residual<D>(de, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], dr);
   for (int a = 0; a < 3; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
 }
 
 void lin_ltm(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   f->m = 7; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.lt_obj[i]; f->i1 = -1;
-  const double* ell = &pb.objects[7 * f->i0];
-  if (!jac) { ltm_prior_residual<double>(ell, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], f->r); return; }
-  typedef Dual<7> D;
+  fscalar ell[7];
+  load_block(&pb.objects[7 * f->i0], ell);
+  if (!jac) { fx::ltm_prior_residual<fscalar>(ell, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], f->r); return; }
+  typedef fx::Dual<7> D;
   D de[7], dr[7];
   for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
-  ltm_prior_residual<D>(de, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], dr);
+  fx::ltm_prior_residual<D>(de, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], dr);
   for (int a = 0; a < 7; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
 }
 
 void lin_relpose(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   f->m = 6; f->k0 = KIND_POSE; f->k1 = KIND_POSE; f->i0 = pb.rl_a[i]; f->i1 = pb.rl_b[i];
-  const double* pa = &pb.poses[6 * f->i0];
-  const double* pbb = &pb.poses[6 * f->i1];
-  if (!jac) { relpose_residual<double>(pa, pbb, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], f->r); return; }
-  typedef Dual<12> D;
+  fscalar pa[6], pbb[6];
+  load_block(&pb.poses[6 * f->i0], pa); load_block(&pb.poses[6 * f->i1], pbb);
+  if (!jac) { fx::relpose_residual<fscalar>(pa, pbb, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], f->r); return; }
+  typedef fx::Dual<12> D;
   D da[6], db[6], dr[6];
   for (int k = 0; k < 6; ++k) { da[k] = D::var(pa[k], k); db[k] = D::var(pbb[k], 6 + k); }
-  relpose_residual<D>(da, db, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], dr);
+  fx::relpose_residual<D>(da, db, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], dr);
   for (int a = 0; a < 6; ++a) {
     f->r[a] = dr[a].v;
     for (int k = 0; k < 6; ++k) { f->J0[6 * a + k] = dr[a].d[k]; f->J1[6 * a + k] = dr[a].d[6 + k]; }
@@ -403,7 +432,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   ws->colsq_c.assign(rd.m, 0.0); ws->g_c.assign(rd.m, 0.0);
   ws->colsq_l.assign(3 * pb.L, 0.0); ws->gl.assign(3 * pb.L, 0.0); ws->Hll.assign(9 * pb.L, 0.0);
   for (const FactorLin& f : ws->lin) {
-    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
     for (int b = 0; b < 2; ++b) {
       if (!is_var(pb, rd, ks[b], is[b])) continue;
       const int d = kBlockDim[ks[b]];
@@ -475,7 +504,7 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
   // camera/object blocks: J_c^T J_c (lower triangle).  A factor's two blocks are distinct
   // parameter blocks (pose/object, or two different poses), so ra != rb whenever a != b.
   for (const FactorLin& f : ws->lin) {
-    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+    const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
     for (int a = 0; a < 2; ++a) {
       if (ks[a] == KIND_POINT || ks[a] == KIND_NONE || !is_var(pb, rd, ks[a], is[a])) continue;
       const int da = kBlockDim[ks[a]]; const int64_t ra = reduced_row(rd, ks[a], is[a]);
@@ -700,8 +729,14 @@ void oracle_ba_destroy(oracle_handle* h) { delete h; }
 
 int oracle_ba_set_cameras(oracle_handle* h, int32_t n, const double* K, const double* ext) {
   if (!h || n < 0 || (n > 0 && (!K || !ext))) return OBVI_ERR_INVALID_ARGUMENT;
-  h->pb.cams.resize(n);
-  for (int i = 0; i < n; ++i) make_camera_const(K + 4 * i, ext + 7 * i, &h->pb.cams[i]);
+  h->pb.cams.resize(n); h->pb.cams_f.resize(n);
+  for (int i = 0; i < n; ++i) {
+    make_camera_const(K + 4 * i, ext + 7 * i, &h->pb.cams[i]);
+    fscalar Kf[4], ef[7];
+    for (int k = 0; k < 4; ++k) Kf[k] = K[4 * i + k];
+    for (int k = 0; k < 7; ++k) ef[k] = ext[7 * i + k];
+    fx::make_camera_const(Kf, ef, &h->pb.cams_f[i]);
+  }
   return OBVI_OK;
 }
 static void set_block(std::vector<double>* dst, std::vector<uint8_t>* cdst, int64_t n, int dim, const double* v, const uint8_t* c) {
@@ -756,14 +791,15 @@ int oracle_ba_set_bbox(oracle_handle* h, int64_t n, const uint32_t* obj_idx, con
   if (cam_idx) pb.bb_cam.assign(cam_idx, cam_idx + n); else pb.bb_cam.assign(n, 0);
   pb.bb_rect.resize(4 * n); pb.bb_sqrt_inf.resize(16 * n);
   for (int64_t i = 0; i < n; ++i) {
-    const CameraConst& c = pb.cams[pb.bb_cam[i]];
+    const fx::CameraConst& c = pb.cams_f[pb.bb_cam[i]];
     // bounding_box_factor.cpp:26-39
-    double si[16];
-    if (!spd_inverse_sqrt(cov + 16 * i, 4, si)) return OBVI_ERR_NUMERICAL;
-    const double scale[4] = {c.fx, c.fx, c.fy, c.fy};
+    fscalar si[16], cv[16];
+    for (int k = 0; k < 16; ++k) cv[k] = cov[16 * i + k];
+    if (!fx::spd_inverse_sqrt(cv, 4, si)) return OBVI_ERR_NUMERICAL;
+    const fscalar scale[4] = {c.fx, c.fx, c.fy, c.fy};
     for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) pb.bb_sqrt_inf[16 * i + 4 * a + b] = si[4 * a + b] * scale[b];
-    pb.bb_rect[4 * i + 0] = (corners[4 * i + 0] - c.cx) / c.fx; pb.bb_rect[4 * i + 1] = (corners[4 * i + 1] - c.cx) / c.fx;
-    pb.bb_rect[4 * i + 2] = (corners[4 * i + 2] - c.cy) / c.fy; pb.bb_rect[4 * i + 3] = (corners[4 * i + 3] - c.cy) / c.fy;
+    pb.bb_rect[4 * i + 0] = ((fscalar)corners[4 * i + 0] - c.cx) / c.fx; pb.bb_rect[4 * i + 1] = ((fscalar)corners[4 * i + 1] - c.cx) / c.fx;
+    pb.bb_rect[4 * i + 2] = ((fscalar)corners[4 * i + 2] - c.cy) / c.fy; pb.bb_rect[4 * i + 3] = ((fscalar)corners[4 * i + 3] - c.cy) / c.fy;
   }
   pb.bb_huber = huber; pb.bb_invalid = invalid_err; pb.bb_active.assign(n, 1);
   return OBVI_OK;
@@ -774,7 +810,7 @@ int oracle_ba_set_shape_priors(oracle_handle* h, int64_t n, const uint32_t* obj_
   OracleProblem& pb = h->pb;
   for (int64_t i = 0; i < n; ++i) if (obj_idx[i] >= pb.O) return OBVI_ERR_OUT_OF_RANGE;
   pb.n_sp = n; pb.sp_obj.assign(obj_idx, obj_idx + n); pb.sp_mean.assign(mean3, mean3 + 3 * n); pb.sp_sqrt_inf.resize(9 * n);
-  for (int64_t i = 0; i < n; ++i) if (!spd_inverse_sqrt(cov9 + 9 * i, 3, &pb.sp_sqrt_inf[9 * i])) return OBVI_ERR_NUMERICAL;
+  for (int64_t i = 0; i < n; ++i) { fscalar cv[9]; for (int k = 0; k < 9; ++k) cv[k] = cov9[9 * i + k]; if (!fx::spd_inverse_sqrt(cv, 3, &pb.sp_sqrt_inf[9 * i])) return OBVI_ERR_NUMERICAL; }
   pb.sp_huber = huber; pb.sp_active.assign(n, 1);
   return OBVI_OK;
 }
@@ -784,7 +820,7 @@ int oracle_ba_set_ltm_priors(oracle_handle* h, int64_t n, const uint32_t* obj_id
   OracleProblem& pb = h->pb;
   for (int64_t i = 0; i < n; ++i) if (obj_idx[i] >= pb.O) return OBVI_ERR_OUT_OF_RANGE;
   pb.n_lt = n; pb.lt_obj.assign(obj_idx, obj_idx + n); pb.lt_mean.assign(mean7, mean7 + 7 * n); pb.lt_sqrt_inf.resize(49 * n);
-  for (int64_t i = 0; i < n; ++i) if (!spd_inverse_sqrt(cov49 + 49 * i, 7, &pb.lt_sqrt_inf[49 * i])) return OBVI_ERR_NUMERICAL;
+  for (int64_t i = 0; i < n; ++i) { fscalar cv[49]; for (int k = 0; k < 49; ++k) cv[k] = cov49[49 * i + k]; if (!fx::spd_inverse_sqrt(cv, 7, &pb.lt_sqrt_inf[49 * i])) return OBVI_ERR_NUMERICAL; }
   pb.lt_huber = huber; pb.lt_active.assign(n, 1);
   return OBVI_OK;
 }
@@ -798,11 +834,12 @@ int oracle_ba_set_relpose(oracle_handle* h, int64_t n, const uint32_t* ia, const
   pb.rl_R.resize(9 * n); pb.rl_sqrt_inf.resize(36 * n);
   for (int64_t i = 0; i < n; ++i) {
     // measured_pose_deviation.orientation_.toRotationMatrix()  (relative_pose_factor.cpp:11-12)
-    const double* a = aa3 + 3 * i;
-    const double ang = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    if (ang > 0.0) { const double ax[3] = {a[0] / ang, a[1] / ang, a[2] / ang}; angle_axis_to_matrix(ang, ax, &pb.rl_R[9 * i]); }
-    else { const double ax[3] = {1, 0, 0}; angle_axis_to_matrix(0.0, ax, &pb.rl_R[9 * i]); }
-    if (!spd_inverse_sqrt(cov36 + 36 * i, 6, &pb.rl_sqrt_inf[36 * i])) return OBVI_ERR_NUMERICAL;
+    const fscalar a[3] = {aa3[3 * i], aa3[3 * i + 1], aa3[3 * i + 2]};
+    const fscalar ang = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (ang > 0.0) { const fscalar ax[3] = {a[0] / ang, a[1] / ang, a[2] / ang}; fx::angle_axis_to_matrix(ang, ax, &pb.rl_R[9 * i]); }
+    else { const fscalar ax[3] = {1, 0, 0}; fx::angle_axis_to_matrix((fscalar)0.0, ax, &pb.rl_R[9 * i]); }
+    fscalar cv[36]; for (int k = 0; k < 36; ++k) cv[k] = cov36[36 * i + k];
+    if (!fx::spd_inverse_sqrt(cv, 6, &pb.rl_sqrt_inf[36 * i])) return OBVI_ERR_NUMERICAL;
   }
   pb.rl_huber = huber; pb.rl_active.assign(n, 1);
   return OBVI_OK;
@@ -842,7 +879,7 @@ int64_t oracle_ba_num_residuals(const oracle_handle* h) {
 int oracle_ba_evaluate(oracle_handle* h, int32_t apply_loss, double* cost, double* residuals, double* block_sqnorm) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
   const OracleProblem& pb = h->pb;
-  double total = 0.0; int64_t ro = 0, bo = 0;
+  real total = 0.0; int64_t ro = 0, bo = 0;
   for (const Family& fam : families(pb)) {
     for (int64_t i = 0; i < fam.n; ++i) {
       if (!(*fam.active)[i]) {
@@ -854,13 +891,13 @@ int oracle_ba_evaluate(oracle_handle* h, int32_t apply_loss, double* cost, doubl
         f.k0 = KIND_NONE; f.k1 = KIND_NONE;
         robustify(&f, fam.huber, apply_loss != 0);
         total += f.cost;
-        if (residuals) for (int a = 0; a < fam.m; ++a) residuals[ro + a] = f.r[a];
-        if (block_sqnorm) block_sqnorm[bo] = f.sqnorm;
+        if (residuals) for (int a = 0; a < fam.m; ++a) residuals[ro + a] = (double)f.r[a];
+        if (block_sqnorm) block_sqnorm[bo] = (double)f.sqnorm;
       }
       ro += fam.m; ++bo;
     }
   }
-  if (cost) *cost = total;
+  if (cost) *cost = (double)total;
   return OBVI_OK;
 }
 
@@ -872,9 +909,9 @@ int oracle_ba_debug_linearize(oracle_handle* h, int32_t type, double* r, double*
     for (int64_t i = 0; i < fam.n; ++i) {
       FactorLin f; fam.lin(pb, i, true, &f);
       const int d0 = kBlockDim[f.k0], d1 = kBlockDim[f.k1];
-      if (r) std::memcpy(r + fam.m * i, f.r, sizeof(double) * fam.m);
-      if (J0) std::memcpy(J0 + (int64_t)fam.m * d0 * i, f.J0, sizeof(double) * fam.m * d0);
-      if (J1 && d1) std::memcpy(J1 + (int64_t)fam.m * d1 * i, f.J1, sizeof(double) * fam.m * d1);
+      if (r) for (int k = 0; k < fam.m; ++k) r[fam.m * i + k] = (double)f.r[k];
+      if (J0) for (int k = 0; k < fam.m * d0; ++k) J0[(int64_t)fam.m * d0 * i + k] = (double)f.J0[k];
+      if (J1 && d1) for (int k = 0; k < fam.m * d1; ++k) J1[(int64_t)fam.m * d1 * i + k] = (double)f.J1[k];
     }
     return OBVI_OK;
   }
@@ -1144,7 +1181,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     if (finite) {
       for (const FactorLin& f : ws.lin) {
         real Jd[7] = {0, 0, 0, 0, 0, 0, 0};
-        const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const double* Js[2] = {f.J0, f.J1};
+        const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
         for (int b = 0; b < 2; ++b) {
           if (!is_var(pb, rd, ks[b], is[b])) continue;
           const int d = kBlockDim[ks[b]];

@@ -189,7 +189,7 @@ template <int N> inline Dual<N> clamp_depth(const Dual<N>& z) {
   Dual<N> r;
   r.v = std::max(z.v, kAnalyticEpsilon);
   const double d = z.v - kAnalyticEpsilon;
-  const double gate = 0.5 * (double((d > 0) - (d < 0)) + 1.0);
+  const double gate = 0.5 * ((double)((d > 0) - (d < 0)) + 1.0);
   for (int i = 0; i < N; ++i) r.d[i] = gate * z.d[i];
   return r;
 }

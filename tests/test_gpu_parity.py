@@ -379,7 +379,8 @@ def test_config3_follows_the_oracle_for_two_steps():
     """The HEADLINE workload itself (bench.py config 3: seed 20241008 + 3, 2000 KF / 200 objects / 300k features, zero tolerances) against the
     oracle -- 20 host threads, about 2 s per LM step -- for two LM steps, deterministic handle and default handle.
     Tolerances, measured (scripts/arbiter.py, profiles/r04_arbiter_cfg3.txt) and why:
-      step 0  initial cost: the same arithmetic summed in another order                                   -> 1e-12
+      step 0  initial cost 5.6e-12 (both handles alike, so not the order of the sums): the noisy initial state has sightings at almost zero
+              depth (|r| up to 1e5 px) whose residuals amplify last-digit differences of the projection by 1 / depth         -> 5e-11
       step 1  ONE reduced solve from identical values: the conditioning of S (~1e9) times fp64 round-off; the extended-precision arbiter
               puts HIP and the oracle at the same distance (1e-9 .. 1e-8 in cost) from the exact step              -> cost 1e-6, |step| 1e-5, rho 1e-5
       step 2  starts from two states 1e-8 apart on a problem with a free gauge, zero tolerances and non-monotonic steps: the difference
@@ -409,7 +410,7 @@ def test_config3_follows_the_oracle_for_two_steps():
         print("config 3 vs oracle (%s): cost %.2e / %.2e / %.2e, step norm %.2e / %.2e, rho %.2e / %.2e" % (
             "deterministic" if det else "default", rel(ig[0].cost, io[0].cost), rel(ig[1].cost, io[1].cost), rel(ig[2].cost, io[2].cost),
             rel(ig[1].step_norm, io[1].step_norm), rel(ig[2].step_norm, io[2].step_norm), abs(ig[1].relative_decrease - io[1].relative_decrease), abs(ig[2].relative_decrease - io[2].relative_decrease)))
-        assert rel(ig[0].cost, io[0].cost) <= 1e-12 and rel(ig[0].gradient_max_norm, io[0].gradient_max_norm) <= 1e-10
+        assert rel(ig[0].cost, io[0].cost) <= 5e-11 and rel(ig[0].gradient_max_norm, io[0].gradient_max_norm) <= 1e-9
         assert (ig[1].step_is_valid, ig[1].step_is_successful) == (io[1].step_is_valid, io[1].step_is_successful)
         assert rel(ig[1].cost, io[1].cost) <= 1e-6 and rel(ig[1].step_norm, io[1].step_norm) <= 1e-5 and abs(ig[1].relative_decrease - io[1].relative_decrease) <= 1e-5
         assert rel(ig[1].trust_region_radius, io[1].trust_region_radius) <= 1e-4

@@ -241,6 +241,28 @@ def test_offline_runner_session_through_the_oracle(oracle_session, scene):
     check_session(scene[0], *oracle_session)
 
 
+def test_global_ba_mode_and_the_binary_scene(oracle_driver, scene, tmp_path):
+    """`run_offline_ba --global-ba` (bench.py's end_to_end_cpp leg): every frame enters the pose graph, then the runner starts at the last frame --
+    with a 20-frame window over 80 frames that is a global BA: the pose-graph stage of runPgoPlusEllipsoids, then the two phases.  And the
+    binary scene (scene_io.write_scene_binary / loadSceneBinary) is the text scene: same records, same results, digit for digit."""
+    prob, path, new_id = scene
+    bin_path = str(tmp_path / "scene.bin")
+    assert scene_io.write_scene_binary(prob, bin_path) == new_id
+    res = []
+    for sc in (path, bin_path):
+        out = str(tmp_path / "out.json")
+        r = subprocess.run([oracle_driver, sc, out, "--global-ba", "--window", "20"], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["ok"] and set(line) >= {"scene_load_ms", "pose_graph_ms", "run_full_optimization_ms", "records"}
+        res.append((json.load(open(out)), line))
+    (a, la), (b, lb) = res
+    assert a["poses"] == b["poses"] and a["objects"] == b["objects"] and la["records"] == lb["records"]
+    kinds = [r["kind"] for r in la["records"]]
+    assert kinds[0].startswith("pgo") or "pgo" in kinds[0] or kinds[0].startswith("gba"), kinds        # the global-BA branch, not a local window
+    assert any(k.endswith("phase_2") for k in kinds) and all(r["n_poses"] == len(prob["poses"]) for r in la["records"] if "phase" in r["kind"])
+
+
 @pytest.mark.gpu
 def test_offline_runner_session(driver, scene, tmp_path):
     """The same session on the HIP path, and against the oracle-driven one: the same sequence of optimisations over the same windows
