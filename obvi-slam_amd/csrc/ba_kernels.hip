@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
 // ---------------------------------------------------------------------------------------
 template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
-                                                     const double* __restrict__ points, ReducedDev rd, int slices) {
+                                                     const double* __restrict__ points, ReducedDev rd, int slices, double* __restrict__ stage, double* __restrict__ stage_scal) {
+  if (stage_scal != nullptr && blockIdx.x == 0 && threadIdx.x < SC_COUNT) stage_scal[threadIdx.x] = 0.0;   // (speculative pass: the staging scalars of the kernel behind this one)
   // slices > 1 (a sliding window: tens of poses with a thousand sightings each): `slices` workgroups share a pose, so that a thread has one
   // or two sightings instead of a chain of dependent gathers, and add their sums atomically
   const int64_t p = blockIdx.x / slices;
@@ -480,7 +481,11 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
     double t = 0.0;
     for (int i = 0; i < kBlock / 64; ++i) t += red[i][threadIdx.x];
     const int k = threadIdx.x;
-    if (k < 21) {
+    if (stage != nullptr) {
+      // speculative pass at a candidate point (obvi_ba.cpp, submit_step): the sums wait in a staging array -- 27 per pose, lower-packed block |
+      // gradient -- until the step is accepted; k_spec_apply adds them to the diagonal blocks of the step that linearises there
+      stage[27 * (int64_t)vid + k] = t;
+    } else if (k < 21) {
       // packed lower-triangular index -> (x, y)
       int x = 0, base = 0;
       while (base + x + 1 <= k) { base += x + 1; ++x; }
@@ -626,6 +631,7 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
         for (int y = 0; y < 6; ++y) {
           double acc2 = 0.0;
           for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
+          if (sf.bb_off != nullptr) { sf.bb_off[(int64_t)42 * i + 6 * x + y] = w * acc2; continue; }   // speculative pass: the tiles are not cleared yet (k_spec_apply)
           double* dst = obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
           if (sf.bb_pairs_unique) *dst = w * acc2; else atomic_add_f64(dst, w * acc2);
         }
@@ -860,6 +866,40 @@ __global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFacto
   }
 }
 
+// What a speculative side pass (pose pass + bounding-box factors at a candidate point, run while the trial cost was evaluated and the
+// next point pass ran) left in its staging set goes into the step that linearises at that point: the poses' J_p^T J_p | J_p^T r sums (27 per
+// pose) onto the diagonal blocks and the gradient, the bounding-box factors' 7x6 object-pose blocks into their tiles, their cost onto the
+// step's cost.  One launch: workgroups [0, nbp) poses (a lane per entry), the rest a thread per entry of an off-diagonal block.
+__global__ void __launch_bounds__(kBlock) k_spec_apply(BlocksDev b, SmallFactorsDev sf, ReducedDev rd, const double* __restrict__ stage_pose, const double* __restrict__ stage_scal,
+                                                      double* scal, int nbp) {
+  if ((int)blockIdx.x < nbp) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t == 0) scal_add(scal, b.deterministic, SC_COST, stage_scal[SC_COST]);
+    const int64_t v = t / 27;
+    const int k = (int)(t % 27);
+    if (v >= b.nPv) return;
+    const double val = stage_pose[t];
+    if (k < 21) {
+      int x = 0, base = 0;
+      while (base + x + 1 <= k) { base += x + 1; ++x; }
+      rd.Hdiag[36 * v + 6 * x + (k - base)] += val;
+    } else {
+      rd.g[6 * v + (k - 21)] += val;
+    }
+    return;
+  }
+  const int64_t t = ((int64_t)blockIdx.x - nbp) * kBlock + threadIdx.x;
+  const int64_t i = t / 42;
+  if (i >= sf.n_bb || !sf.bb_active[i]) return;
+  const int32_t ov = b.obj_vid[sf.bb_obj[i]], pv = b.pose_vid[sf.bb_pose[i]];
+  if (ov < 0 || pv < 0) return;
+  const int e = (int)(t % 42), x = e / 6, y = e % 6;
+  const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
+  double* dst = orow > prow ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
+  const double val = sf.bb_off[t];
+  if (sf.bb_pairs_unique) *dst = val; else atomic_add_f64(dst, val);
+}
+
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
 __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
                                                         ReducedDev rd, double radius, int first_iter, double* scal) {
@@ -1004,7 +1044,7 @@ __global__ void __launch_bounds__(kBlock) k_schur_blocks(int64_t nblk, const uin
 constexpr int kSR = kSchurRows, kSFr = kSchurWindowFrames, kSBack = kSFr - kSR;
 constexpr int kSTR = kSR * 6 / 16, kSTC = kSFr * 6 / 16, kSDiag = kSBack * 6 / 16, kSWv = 4, kSGC = kSchurGroupCols;
 static_assert(kSR * 6 % 16 == 0 && kSFr * 6 % 16 == 0 && kSBack * 6 % 16 == 0 && kSFr <= 64 && kSTC % kSGC == 0, "strip must be whole MFMA tiles");
-static_assert(kSchurBatchBytes % (16 * 64) == 0, "a batch is whole gather instructions of one wavefront");
+static_assert(kSchurBatchBytes % (16 * 64 * kSWv) == 0, "a batch is whole gather instructions");
 typedef double sf64x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void schur_gptr;
 typedef __attribute__((address_space(3))) void schur_lptr;
@@ -1012,7 +1052,7 @@ typedef __attribute__((address_space(3))) const unsigned char schur_lds8;
 typedef __attribute__((address_space(3))) const double schur_ldsd;
 // global -> LDS gather of 16 bytes per lane: lane l's bytes land at lds_base + 16 l (lds_base wave-uniform).  Issued as asm so
 // that the compiler does not order every later LDS read of the *other* batch buffer behind it (it would wait vmcnt(0));
-// the batch loop waits for it explicitly.  M0 recipe: cdna_hip_programming.md 5.7.
+// the batch loop waits for it explicitly before its barrier.  M0 recipe: cdna_hip_programming.md 5.7.
 __device__ __forceinline__ void gather16_to_lds(const void* gsrc, uint32_t lds_base) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -1027,176 +1067,163 @@ __device__ __forceinline__ void mfma_f64_acc(sf64x4& acc, double a, double bv) {
   asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bv));
 }
 
-// Round 4.  (1) A visit is up to FOUR points of one class (same tiles, same image layout; the host groups them): K = 12 = (point, coordinate)
-// in three full MFMAs per tile -- lane (m, kq) of MFMA s holds k' = 4 s + kq, i.e. coordinate k' % 3 of point k' / 3 -- instead of four MFMAs
-// padded from K = 3, and one round of record decoding / masks / tile branches for four points (the kernel was bound by the ~150 instructions
-// around 5.6 MFMAs of a one-point visit).  The points' images follow each other at a visit-uniform stride, so an operand is still one add and
-// one ds_read_b64; lanes whose point does not exist (a visit of fewer than four) read a zero region instead.
-// (2) Batches are per WAVEFRONT: each of the four wavefronts streams its own 8 KB images (double-buffered LDS-DMA) and multiplies them into its
-// private strip, taking the workgroup's batches round-robin; no workgroup barrier inside the loop (a batch of four-point visits holds only a
-// handful of them -- shared by four wavefronts it would leave them waiting for each other).  They meet once, for the flush.
+#ifndef OBVI_SCHUR_VISIT_GROUP
+#define OBVI_SCHUR_VISIT_GROUP 2
+#endif
 template <bool TWIN>
 __global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDev pt, ReducedDev rd, const int32_t* __restrict__ row_of_nat,
                                                           const uint32_t* __restrict__ wg_bptr, const uint32_t* __restrict__ bfirst,
                                                           const uint32_t* __restrict__ bslot, const uint4* __restrict__ visits,
                                                           const uint32_t* __restrict__ slot_src, const int32_t* __restrict__ wg_f0,
                                                           const int32_t* __restrict__ wg_group) {
-  constexpr int kZeroBytes = 144 * (kSFr + 1) + 16;   // every lane constant (frame offset + place in the record) stays inside it
-  __shared__ __attribute__((aligned(16))) unsigned char zbuf[kSWv][2][kSchurBatchBytes];
-  __shared__ __attribute__((aligned(16))) uint4 recbuf[kSWv][2][kSchurBatchVisits];
-  __shared__ __attribute__((aligned(16))) unsigned char zeros[kZeroBytes];
+  // two batch buffers as separate objects, each addressed statically (the loop below is unrolled by two): the compiler then
+  // knows that the reads of one do not alias the gather in flight into the other and does not wait for it
+  __shared__ __attribute__((aligned(16))) unsigned char zbuf0[kSchurBatchBytes], zbuf1[kSchurBatchBytes];
+  __shared__ __attribute__((aligned(16))) uint4 recbuf0[kSchurBatchVisits], recbuf1[kSchurBatchVisits];
+  __shared__ __attribute__((aligned(16))) double zero2[2];
   __shared__ int32_t rown[kSFr];
-  constexpr int kIters = kSchurBatchBytes / 16 / 64;   // gather instructions per batch (one wavefront)
+  constexpr int kIters = kSchurBatchBytes / 16 / (64 * kSWv);   // gather instructions per lane per batch
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
   const int32_t f0 = wg_f0[blockIdx.x], fbase = f0 - kSBack, cbase = kSGC * wg_group[blockIdx.x];
   const bool with_rhs = cbase + kSGC == kSTC;   // the group holding the chunk's own frames sees every visit of the chunk once
   if (tid < kSFr) { const int32_t f = fbase + tid; rown[tid] = (f >= 0 && f < b.nPv) ? row_of_nat[f] : -1; }
-  for (int i = tid; i < kZeroBytes / 8; i += 64 * kSWv) reinterpret_cast<double*>(zeros)[i] = 0.0;
-  __syncthreads();
-  // per-lane operand constants: an operand of row tile r / column tile cbase + c of MFMA s sits at (byte address of strip frame 0 of the
-  // lane's point: per visit) + 144 (frame offset of the lane's matrix row) + 8 (3 x + coordinate of the lane in MFMA s)
-  int pS[3], kkS[3];   // point / coordinate of lane group kq in MFMA s
+  if (tid < 2) zero2[tid] = 0.0;
+  // per-lane operand addresses: an operand of row tile r / column tile cbase + c sits at (byte offset of strip frame 0 in the batch image:
+  // visit-uniform, from the record) + 144 (frame offset of the lane's matrix row) + (offset in the record) -- the host lays a visit out so
+  // that every frame an active tile touches has a slot (zeros where the point has no observation), hence no range test.  Lanes kq = 3 pad
+  // K = 3 to the instruction's 4: multiplier 0 and the address of a zero.  One v_mad per operand; constants per batch buffer.
+  const uint32_t kmul = kq < 3 ? 1u : 0u;
+  uint32_t cA[2][kSTR], cB[2][kSGC];
 #pragma unroll
-  for (int s3 = 0; s3 < 3; ++s3) { const int kp = 4 * s3 + kq; pS[s3] = kp / 3; kkS[s3] = kp % 3; }
-  uint32_t cA[3][kSTR], cB[3][kSGC];
+  for (int bf = 0; bf < 2; ++bf) {
+    const uint32_t img = lds_address(bf ? &zbuf1[0] : &zbuf0[0]), zr = lds_address(&zero2[0]);
 #pragma unroll
-  for (int s3 = 0; s3 < 3; ++s3) {
+    for (int r = 0; r < kSTR; ++r) { const int row = 16 * (kSDiag + r) + m; cA[bf][r] = kq < 3 ? img + 144u * (uint32_t)(row / 6) + 8u * (uint32_t)((row % 6) * 3 + kq) : zr; }
 #pragma unroll
-    for (int r = 0; r < kSTR; ++r) { const int row = 16 * (kSDiag + r) + m; cA[s3][r] = 144u * (uint32_t)(row / 6) + 8u * (uint32_t)((row % 6) * 3 + kkS[s3]); }
-#pragma unroll
-    for (int c = 0; c < kSGC; ++c) { const int col = 16 * (cbase + c) + m; cB[s3][c] = 144u * (uint32_t)(col / 6) + 8u * (uint32_t)((col % 6) * 3 + kkS[s3]); }
+    for (int c = 0; c < kSGC; ++c) { const int col = 16 * (cbase + c) + m; cB[bf][c] = kq < 3 ? img + 144u * (uint32_t)(col / 6) + 8u * (uint32_t)((col % 6) * 3 + kq) : zr; }
   }
-  const uint32_t zero_at = lds_address(&zeros[0]);
   sf64x4 acc[kSGC][kSTR];
 #pragma unroll
   for (int c = 0; c < kSGC; ++c)
 #pragma unroll
     for (int r = 0; r < kSTR; ++r) acc[c][r] = sf64x4{0.0, 0.0, 0.0, 0.0};
-  double racc[kSTR] = {};   // partial of (Z u) for row 16 r + m, summed over the lane's k'
+  double racc[kSTR] = {};   // partial of (Z u) for row 16 r + m, component kq
 
-  // ---- batch gather (one wavefront): chunk q (16 bytes) of the batch image comes from slot_src[slot0 + q / 9] + q % 9.
-  // Three stages per batch, each issued a full loop trip ahead of the next so that a trip waits for ONE memory latency:
-  //   scalars (first slot / slot count / first visit / visit count: wave-uniform loads)  ->  table entries (one per lane and gather
-  //   instruction)  ->  the gather itself (LDS-DMA) and the visit records
-  struct BatchScalars { uint32_t s0, ns, v0, nv; };
-  auto load_scalars = [&](uint32_t bi, uint32_t bend) -> BatchScalars {
-    BatchScalars q{0u, 0u, 0u, 0u};
-    if (bi < bend) { q.s0 = bslot[bi]; q.ns = bslot[bi + 1] - q.s0; q.v0 = bfirst[bi]; q.nv = bfirst[bi + 1] - q.v0; }
-    return q;
-  };
-  uint32_t src_next[kIters];   // table entries of the batch to stream next
-  auto load_table = [&](const BatchScalars& q) {
+  // ---- batch gather: chunk q (16 bytes) of the batch image comes from slot_src[slot0 + q / 9] + q % 9
+  uint32_t src_next[kIters];   // table entries of the batch to stream next, loaded one batch ahead
+  auto load_table = [&](uint32_t bi) {
+    const uint32_t s0 = bslot[bi], ns = bslot[bi + 1] - s0;
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
-      const uint32_t slot = ((uint32_t)(64 * i) + (uint32_t)lane) / 9u;
-      src_next[i] = slot < q.ns ? slot_src[q.s0 + slot] : 0xffffffffu;
+      const uint32_t slot = ((uint32_t)(64 * kSWv * i) + (uint32_t)tid) / 9u;
+      src_next[i] = slot < ns ? slot_src[s0 + slot] : 0xffffffffu;
     }
   };
-  auto stream_batch = [&](const BatchScalars& q, int bf) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
-    const uint32_t zb = lds_address(&zbuf[wv][bf][0]), rb = lds_address(&recbuf[wv][bf][0]);
+  using Buf0 = std::integral_constant<int, 0>;
+  using Buf1 = std::integral_constant<int, 1>;
+  auto stream_batch = [&](uint32_t bi, auto which) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
+    unsigned char* zb_ = decltype(which)::value ? zbuf1 : zbuf0;
+    uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
 #pragma unroll
     for (int i = 0; i < kIters; ++i)
       if (src_next[i] != 0xffffffffu) {
-        const uint32_t c16 = (uint32_t)(64 * i) + (uint32_t)lane;
-        gather16_to_lds(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * (src_next[i] + c16 % 9u), zb + 16u * (uint32_t)(64 * i));
+        const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid;
+        gather16_to_lds(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * (src_next[i] + q % 9u), lds_address(zb_) + 16u * (uint32_t)(64 * kSWv * i + 64 * wv));
       }
-    if ((uint32_t)lane < q.nv) gather16_to_lds(visits + q.v0 + lane, rb);
+    const uint32_t vb = bfirst[bi], nv = bfirst[bi + 1] - vb;
+    if (wv == 0)
+      for (uint32_t c0 = 0; c0 < nv; c0 += 64)
+        if (c0 + lane < nv) gather16_to_lds(visits + vb + c0 + lane, lds_address(rb_) + 16u * c0);
   };
 
-  // ---- one visit.  Record: x = byte offset of strip frame 0 of point 0 in the batch image for the row operands (int32), y = the same for
-  //      the group's column operands, z = tail slot of point 0 | distance to the second layer << 16, w = column tiles of the group in use (5 bits)
-  //      | stereo << 15 | row tiles in use << 16 | (points - 1) << 19 | slots per point << 21
-  struct Ops { double a[3][kSTR]; double b[3][kSGC]; double ul[3]; };
-  auto lds_f64 = [](uint32_t addr) -> double { return *reinterpret_cast<schur_ldsd*>((schur_lds8*)(uintptr_t)addr); };
-  constexpr int kCut = kSDiag - (kSTC - kSGC);   // diagonal group: column tile c of the group lies at or below row tile r iff c <= r + kCut
-  auto visit = [&](const uint32_t img, const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t vw) {
-    const uint32_t np = ((vw >> 19) & 3u) + 1u, stride = 144u * ((vw >> 21) & 63u);
+  // ---- one visit.  Record: x = byte offset of strip frame 0 in the batch image for the row operands (int32), y = the same for the
+  //      group's column operands, z = tail slot | distance to the second layer << 16, w = column tiles of the group in use (5 bits) | stereo << 15 | row tiles in use << 16
+  // A visit in two halves -- load_ops issues every LDS read of the visit (row operands, the operands of the active column tiles,
+  // (u_l, 0)), multiply does the rest -- so that a wavefront can take its visits two at a time: both records, then both sets of
+  // operands, are read together and the read latency (exposed at two wavefronts per SIMD) is paid once per pair.
+  struct Ops { double a[kSTR]; double b[kSGC]; double ul; uint32_t bits; };
+  auto load_ops = [&](const uint32_t vx, const uint32_t vy, const uint32_t vz, const uint32_t vw, auto which) -> Ops {
+    constexpr int bf = decltype(which)::value;
+    schur_lds8* zimg = bf ? (schur_lds8*)(&zbuf1[0]) : (schur_lds8*)(&zbuf0[0]);
     const bool twin = TWIN && ((vw >> 15) & 1u);
-    const uint32_t layer2 = 144u * (vz >> 16);
-    const uint32_t ns = np == 1u ? 1u : (np == 2u ? 2u : 3u);   // MFMAs per tile: ceil(3 np / 4)
+    const uint32_t layer2 = 144u * (vz >> 16) * kmul;
+    auto lds_f64 = [](uint32_t addr) -> double { return *reinterpret_cast<schur_ldsd*>((schur_lds8*)(uintptr_t)addr); };
+    auto operand = [&](uint32_t base, uint32_t lane_const) -> double {
+      const uint32_t at = base * kmul + lane_const;
+      double val = lds_f64(at);
+      if (TWIN && twin) val += lds_f64(at + layer2);
+      return val;
+    };
     Ops o;
+    o.bits = vw;
     // every operand is read whether its tile is active or not (a read is an add and a ds_read_b64; testing the tile bits first cost five
     // scalar instructions per operand): an inactive tile's address may lie anywhere -- beyond the allocation LDS returns zero -- and its
-    // value is never used (the multiplication touches the row / column tiles of the visit's masks only)
+    // value is never used (multiply() touches the row / column tiles of the visit's masks only)
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-      if ((uint32_t)s3 < ns) {   // wave-uniform
-        const bool have = (uint32_t)pS[s3] < np;
-        const uint32_t off = (uint32_t)pS[s3] * stride;
-        const uint32_t baseA = have ? img + vx + off : zero_at, baseB = have ? img + vy + off : zero_at;
-        const uint32_t l2 = have ? layer2 : 0u;
+    for (int r = 0; r < kSTR; ++r) o.a[r] = operand(vx, cA[bf][r]);
+    o.ul = with_rhs ? *reinterpret_cast<schur_ldsd*>(zimg + (144u * (vz & 0xffffu) + 8u * kq)) : 0.0;   // (u_l, 0)
 #pragma unroll
-        for (int r = 0; r < kSTR; ++r) {
-          double v = lds_f64(baseA + cA[s3][r]);
-          if (TWIN && twin) v += lds_f64(baseA + cA[s3][r] + l2);
-          o.a[s3][r] = v;
-        }
-        o.ul[s3] = with_rhs ? lds_f64(have ? img + 144u * (vz & 0xffffu) + off + 8u * (uint32_t)kkS[s3] : zero_at) : 0.0;   // (u_l, 0) of the lane's point
-#pragma unroll
-        for (int c = 0; c < kSGC; ++c) {
-          double v = lds_f64(baseB + cB[s3][c]);
-          if (TWIN && twin) v += lds_f64(baseB + cB[s3][c] + l2);
-          o.b[s3][c] = v;
-        }
-      }
-    }
-    // The active tiles of a visit are (row tiles holding one of the points' row frames) x (column tiles of the group holding one of their
-    // column frames), minus -- in the group that holds the chunk's own frames -- the tiles above the diagonal: a rectangle given by two masks.
-    const uint32_t R = (vw >> 16) & 7u;
+    for (int c = 0; c < kSGC; ++c) o.b[c] = operand(vy, cB[bf][c]);
+    return o;
+  };
+  // The active tiles of a visit are (row tiles holding one of the point's row frames) x (column tiles of the group holding one of its
+  // column frames), minus -- in the group that holds the chunk's own frames -- the tiles above the diagonal: a rectangle given by two
+  // masks (a column bit, then the row bits of the columns in use).
+  constexpr int kCut = kSDiag - (kSTC - kSGC);   // diagonal group: column tile c of the group lies at or below row tile r iff c <= r + kCut
+  auto multiply = [&](const Ops& o) {
+    const uint32_t R = (o.bits >> 16) & 7u;
     if (with_rhs) {
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3)
-        if ((uint32_t)s3 < ns) {
-#pragma unroll
-          for (int r = 0; r < kSTR; ++r) if (R & (1u << r)) racc[r] += o.a[s3][r] * o.ul[s3];
-        }
+      for (int r = 0; r < kSTR; ++r) if (R & (1u << r)) racc[r] += o.a[r] * o.ul;
     }
 #pragma unroll
     for (int c = 0; c < kSGC; ++c) {
-      if ((vw >> c) & 1u) {
+      if ((o.bits >> c) & 1u) {
         // rows of this column tile: the visit's row mask, minus -- chunk's own group only -- the row tiles above the diagonal
         uint32_t Rc = R;
         if (c > kCut) Rc = with_rhs ? (R & ~((1u << (c - kCut)) - 1u)) : R;
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-          if ((uint32_t)s3 < ns) {
-#pragma unroll
-            for (int r = 0; r < kSTR; ++r)
-              if (Rc & (1u << r)) mfma_f64_acc(acc[c][r], o.a[s3][r], o.b[s3][c]);
-          }
+        for (int r = 0; r < kSTR; ++r)
+          if (Rc & (1u << r)) mfma_f64_acc(acc[c][r], o.a[r], o.b[c]);
       }
     }
   };
 
-  const uint32_t b0 = wg_bptr[blockIdx.x] + (uint32_t)wv, b1 = wg_bptr[blockIdx.x + 1];
-  BatchScalars q0 = load_scalars(b0, b1), q1 = load_scalars(b0 + kSWv, b1), q2 = load_scalars(b0 + 2 * kSWv, b1);
-  if (b0 < b1) {
-    load_table(q0);
-    stream_batch(q0, 0);          // (waits for the table entries: the only exposed dependent pair of the kernel)
-    load_table(q1);
-  }
-  int bf = 0;
-  for (uint32_t bi = b0; bi < b1; bi += kSWv, bf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's batch bi has landed, its successor's table entries too
-    stream_batch(q1, bf ^ 1);                          // batch bi + 4 (nothing if there is none: its counts are zero)
-    load_table(q2);                                    // table of batch bi + 8
-    const BatchScalars q3 = load_scalars(bi + 3 * kSWv, b1);   // scalars of batch bi + 12: here by the next trip
-    const uint32_t nv = q0.nv;
-    const uint32_t img = lds_address(&zbuf[wv][bf][0]);
-    const uint4* rb_ = &recbuf[wv][bf][0];
-    for (uint32_t i = 0; i < nv; ++i) {
-      const uint4 rv = rb_[i];
-      visit(img, __builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z), __builtin_amdgcn_readfirstlane(rv.w));
+  const uint32_t b0 = wg_bptr[blockIdx.x], b1 = wg_bptr[blockIdx.x + 1];
+  if (b0 < b1) { load_table(b0); stream_batch(b0, Buf0{}); }
+  if (b0 + 1 < b1) load_table(b0 + 1);
+  auto batch = [&](uint32_t bi, auto which, auto other) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's part of batch bi has landed, its successor's table entries too
+    __syncthreads();                                    // ... everybody's; and the other buffer is free
+    if (bi + 1 < b1) { stream_batch(bi + 1, other); if (bi + 2 < b1) load_table(bi + 2); }
+    const uint32_t nv = bfirst[bi + 1] - bfirst[bi];
+    const uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
+    auto ops_of = [&](uint32_t x) {
+      const uint4 rv = rb_[x];
+      return load_ops(__builtin_amdgcn_readfirstlane(rv.x), __builtin_amdgcn_readfirstlane(rv.y), __builtin_amdgcn_readfirstlane(rv.z), __builtin_amdgcn_readfirstlane(rv.w), which);
+    };
+    constexpr int kVisitGroup = OBVI_SCHUR_VISIT_GROUP;   // visits a wavefront takes together
+    uint32_t i = (uint32_t)wv;
+    for (; i + (kVisitGroup - 1) * kSWv < nv; i += kVisitGroup * kSWv) {
+      Ops o[kVisitGroup];
+#pragma unroll
+      for (int v = 0; v < kVisitGroup; ++v) o[v] = ops_of(i + v * kSWv);
+#pragma unroll
+      for (int v = 0; v < kVisitGroup; ++v) multiply(o[v]);
     }
-    q0 = q1; q1 = q2; q2 = q3;
+    for (; i < nv; i += kSWv) multiply(ops_of(i));
+  };
+  for (uint32_t bi = b0; bi < b1; bi += 2) {
+    batch(bi, Buf0{}, Buf1{});
+    if (bi + 1 < b1) batch(bi + 1, Buf1{}, Buf0{});
   }
 
   // ---- add the workgroup's tiles to the tile grid: tile (r, cbase + c), lane, register q -> row 16 r + kq + 4 q, column 16 (cbase + c) + m.
   //      The four wavefronts hold private accumulators of the same strip: they are summed through LDS first (the batch buffers are free),
   //      tile column by tile column, so that the strip costs one set of atomics instead of four.
-  static_assert(kSWv * kSTR * 4 * 64 * sizeof(double) <= sizeof(zbuf) && (kSTR * 4) % kSWv == 0, "one tile column of every wavefront fits the batch buffers");
-  double* red = reinterpret_cast<double*>(&zbuf[0][0][0]);   // [wavefront][r][q][lane]
+  static_assert(kSWv * kSTR * 4 * 64 * sizeof(double) <= kSchurBatchBytes && (kSTR * 4) % kSWv == 0, "one tile column of every wavefront fits a batch buffer");
+  double* red = reinterpret_cast<double*>(&zbuf0[0]);   // [wavefront][r][q][lane]
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < kSGC; ++c) {
@@ -1467,7 +1494,10 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
 template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, SmallFactorsDev sf, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
                                                 const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ objects, int mode,
-                                                int n_pose_blocks, double* scal) {
+                                                int n_pose_blocks, double* scal, double* started_host, double started_seq) {
+  // "the kernels in front of this one on the stream are done" for the host (a pinned page; obvi_ba.cpp starts the candidate's side pass on
+  // the other stream when it sees it -- an event the other queue waits for would sit there through the whole factorisation, see submit_step)
+  if (started_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { *reinterpret_cast<volatile double*>(started_host) = started_seq; __threadfence_system(); }
   if ((int)blockIdx.x < n_pose_blocks) cost_reproj_block<PIPE>(blockIdx.x, b, rq, cams, pc, points, mode, scal);
   else cost_small_block((int64_t)blockIdx.x - n_pose_blocks, b, sf, cams, poses, objects, mode, scal);
 }
@@ -1695,7 +1725,7 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
   }
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
-                      const ReducedDev& rd) {
+                      const ReducedDev& rd, double* stage, double* stage_scal) {
   if (b.P <= 0 || rq.n <= 0) return;
   // a pose's workgroup walks its sightings 256 at a time; with few poses (a window) that loop is the latency of the launch: cut it
   // (not in the deterministic mode: one writer per block)
@@ -1706,8 +1736,25 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
   if (!b.deterministic && b.P <= slice_below) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
   // few poses: the loads of a sighting in two rounds with the next sighting's first round in flight (150 registers); many poses: the plain loop
   // (120 registers: beside the strip kernel the side stream is otherwise the longer one -- 2.02 vs 1.95 ms per LM iteration)
-  if (b.P <= slice_below) hipLaunchKernelGGL(k_pose_pass<true>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
-  else hipLaunchKernelGGL(k_pose_pass<false>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
+  if (stage != nullptr) slices = 1;   // (a staging array takes stores, not sums)
+  if (b.P <= slice_below) hipLaunchKernelGGL(k_pose_pass<true>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices, stage, stage_scal);
+  else hipLaunchKernelGGL(k_pose_pass<false>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices, stage, stage_scal);
+}
+// The speculative side pass of the bounding-box factors: per-factor blocks (diagonal blocks into sf.bb_blk, the object-pose block into
+// sf.bb_off) and the cost into a staging scalar block; nothing of the step's accumulators is touched.
+void launch_bbox_spec(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd, double* stage_scal) {
+  const int nb_bbox = (int)grid_for(sf.n_bb, 4);   // (stage_scal was cleared by the pose pass in front: launch_pose_pass(..., stage, stage_scal))
+  if (nb_bbox > 0) hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox), dim3(64), 0, s, b, sf, cams, poses, objects, rd, stage_scal, nb_bbox, 0);
+}
+// ... and what follows it in the step that uses the staged results: k_spec_apply, the priors and relative-pose factors (evaluated here: a
+// handful of blocks), the per-object / per-pose sums of the bounding-box blocks
+void launch_spec_apply_and_rest(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd,
+                                const double* stage_pose, const double* stage_scal, double* scal) {
+  const int nbp = (int)grid_for(27 * b.nPv, kBlock), nbo = (int)grid_for(42 * sf.n_bb, kBlock);
+  if (nbp + nbo > 0) hipLaunchKernelGGL(k_spec_apply, dim3(std::max(1, nbp) + nbo), dim3(kBlock), 0, s, b, sf, rd, stage_pose, stage_scal, scal, std::max(1, nbp));
+  const int nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
+  if (nb_priors + nb_rel > 0) hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, 0, nb_priors);
+  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
@@ -1772,7 +1819,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
-                 const double* points_cand, const double* objects_cand, int mode, double* scal) {
+                 const double* points_cand, const double* objects_cand, int mode, double* scal, double* started_host, double started_seq) {
   // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
   const PoseCache* pc = mode == 0 ? pc_cand : pc_cur;
   const double* poses = mode == 0 ? poses_cand : poses_cur;
@@ -1782,8 +1829,8 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   const unsigned grid = (unsigned)n_pose_blocks + grid_for(ns, kBlock);
   if (grid > 0) {
-    if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);   // (few poses: cost_reproj_block)
-    else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
+    if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal, started_host, started_seq);   // (few poses: cost_reproj_block)
+    else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal, started_host, started_seq);
     if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED));
   }
 }

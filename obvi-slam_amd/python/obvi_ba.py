@@ -84,8 +84,9 @@ class ObviError(RuntimeError):
 
 
 def default_library_path():
+    """csrc/libobvi_ba.so; OBVI_BA_LIBRARY names another build of the same product (A/B runs of compile-time variants: scripts/ab_env.sh)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    return os.path.join(os.path.dirname(here), "csrc", "libobvi_ba.so")
+    return os.environ.get("OBVI_BA_LIBRARY") or os.path.join(os.path.dirname(here), "csrc", "libobvi_ba.so")
 
 
 def _f64(a, shape=None):
