@@ -101,7 +101,6 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
   int64_t n_bb; const uint32_t* bb_obj; const uint32_t* bb_pose; const uint16_t* bb_cam;
   const double* bb_rect; const double* bb_sqrt_inf; const uint8_t* bb_active; double bb_huber, bb_invalid;
   double* bb_blk;                                       // [n_bb][62] per-factor diagonal blocks (big problems: k_small_lin_lanes<true> / k_bbox_gather)
-  double* bb_off;                                       // NULL, or [n_bb][42]: the speculative side pass leaves the 7x6 object-pose blocks here instead of in their tiles (k_spec_apply)
   int32_t bb_pairs_unique;                              // no (object, pose) pair occurs twice: the off-diagonal block of a factor is its own
   const uint32_t* bbo_ptr; const uint32_t* bbo_idx;     // factors by object: [O+1], [n_bb]
   const uint32_t* bbp_ptr; const uint32_t* bbp_idx;     // factors by pose:   [P+1], [n_bb]
@@ -151,14 +150,7 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
                        const uint32_t* long_points, int64_t n_long);
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc,
-                      const double* points, const ReducedDev& rd, double* stage = nullptr /* not null: the sums are STORED there, 27 per variable pose (speculative pass) */,
-                      double* stage_scal = nullptr /* not null: cleared (SC_COUNT doubles) for launch_bbox_spec behind it */);
-// speculative side pass at a candidate point (submit_step): the bounding-box factors' blocks into sf.bb_blk / sf.bb_off, their cost into
-// stage_scal[SC_COST]; and, in the step that linearises at that point, the staged sums applied + the remaining small factors + the
-// per-object / per-pose sums
-void launch_bbox_spec(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd, double* stage_scal);
-void launch_spec_apply_and_rest(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd,
-                                const double* stage_pose, const double* stage_scal, double* scal);
+                      const double* points, const ReducedDev& rd);
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams,
                           const double* poses, const double* objects, const ReducedDev& rd, double* scal);
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects,
@@ -182,7 +174,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams,
                  const PoseCache* pc_cur, const double* poses_cur, const double* points_cur, const double* objects_cur,
                  const PoseCache* pc_cand, const double* poses_cand, const double* points_cand, const double* objects_cand,
-                 int mode, double* scal, double* started_host = nullptr /* pinned: receives started_seq when the kernel starts */, double started_seq = 0.0);
+                 int mode, double* scal);
 // problem->Evaluate: raw / robustified residuals of every factor in caller order
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf,
                      const DevCam* cams, const PoseCache* pc, const double* poses, const double* points, const double* objects,

@@ -406,8 +406,7 @@ __global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp
 // ---------------------------------------------------------------------------------------
 template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev rq, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
-                                                     const double* __restrict__ points, ReducedDev rd, int slices, double* __restrict__ stage, double* __restrict__ stage_scal) {
-  if (stage_scal != nullptr && blockIdx.x == 0 && threadIdx.x < SC_COUNT) stage_scal[threadIdx.x] = 0.0;   // (speculative pass: the staging scalars of the kernel behind this one)
+                                                     const double* __restrict__ points, ReducedDev rd, int slices) {
   // slices > 1 (a sliding window: tens of poses with a thousand sightings each): `slices` workgroups share a pose, so that a thread has one
   // or two sightings instead of a chain of dependent gathers, and add their sums atomically
   const int64_t p = blockIdx.x / slices;
@@ -481,11 +480,7 @@ __global__ void __launch_bounds__(kBlock) k_pose_pass(BlocksDev b, ReprojPoseDev
     double t = 0.0;
     for (int i = 0; i < kBlock / 64; ++i) t += red[i][threadIdx.x];
     const int k = threadIdx.x;
-    if (stage != nullptr) {
-      // speculative pass at a candidate point (obvi_ba.cpp, submit_step): the sums wait in a staging array -- 27 per pose, lower-packed block |
-      // gradient -- until the step is accepted; k_spec_apply adds them to the diagonal blocks of the step that linearises there
-      stage[27 * (int64_t)vid + k] = t;
-    } else if (k < 21) {
+    if (k < 21) {
       // packed lower-triangular index -> (x, y)
       int x = 0, base = 0;
       while (base + x + 1 <= k) { base += x + 1; ++x; }
@@ -631,7 +626,6 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
         for (int y = 0; y < 6; ++y) {
           double acc2 = 0.0;
           for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
-          if (sf.bb_off != nullptr) { sf.bb_off[(int64_t)42 * i + 6 * x + y] = w * acc2; continue; }   // speculative pass: the tiles are not cleared yet (k_spec_apply)
           double* dst = obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
           if (sf.bb_pairs_unique) *dst = w * acc2; else atomic_add_f64(dst, w * acc2);
         }
@@ -864,40 +858,6 @@ __global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFacto
   } else {
     gd[lane - nh] += acc;
   }
-}
-
-// What a speculative side pass (pose pass + bounding-box factors at a candidate point, run while the trial cost was evaluated and the
-// next point pass ran) left in its staging set goes into the step that linearises at that point: the poses' J_p^T J_p | J_p^T r sums (27 per
-// pose) onto the diagonal blocks and the gradient, the bounding-box factors' 7x6 object-pose blocks into their tiles, their cost onto the
-// step's cost.  One launch: workgroups [0, nbp) poses (a lane per entry), the rest a thread per entry of an off-diagonal block.
-__global__ void __launch_bounds__(kBlock) k_spec_apply(BlocksDev b, SmallFactorsDev sf, ReducedDev rd, const double* __restrict__ stage_pose, const double* __restrict__ stage_scal,
-                                                      double* scal, int nbp) {
-  if ((int)blockIdx.x < nbp) {
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t == 0) scal_add(scal, b.deterministic, SC_COST, stage_scal[SC_COST]);
-    const int64_t v = t / 27;
-    const int k = (int)(t % 27);
-    if (v >= b.nPv) return;
-    const double val = stage_pose[t];
-    if (k < 21) {
-      int x = 0, base = 0;
-      while (base + x + 1 <= k) { base += x + 1; ++x; }
-      rd.Hdiag[36 * v + 6 * x + (k - base)] += val;
-    } else {
-      rd.g[6 * v + (k - 21)] += val;
-    }
-    return;
-  }
-  const int64_t t = ((int64_t)blockIdx.x - nbp) * kBlock + threadIdx.x;
-  const int64_t i = t / 42;
-  if (i >= sf.n_bb || !sf.bb_active[i]) return;
-  const int32_t ov = b.obj_vid[sf.bb_obj[i]], pv = b.pose_vid[sf.bb_pose[i]];
-  if (ov < 0 || pv < 0) return;
-  const int e = (int)(t % 42), x = e / 6, y = e % 6;
-  const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
-  double* dst = orow > prow ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
-  const double val = sf.bb_off[t];
-  if (sf.bb_pairs_unique) *dst = val; else atomic_add_f64(dst, val);
 }
 
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
@@ -1494,10 +1454,7 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
 template <bool PIPE>
 __global__ void __launch_bounds__(kBlock) k_cost(BlocksDev b, ReprojPoseDev rq, SmallFactorsDev sf, const DevCam* __restrict__ cams, const PoseCache* __restrict__ pc,
                                                 const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ objects, int mode,
-                                                int n_pose_blocks, double* scal, double* started_host, double started_seq) {
-  // "the kernels in front of this one on the stream are done" for the host (a pinned page; obvi_ba.cpp starts the candidate's side pass on
-  // the other stream when it sees it -- an event the other queue waits for would sit there through the whole factorisation, see submit_step)
-  if (started_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { *reinterpret_cast<volatile double*>(started_host) = started_seq; __threadfence_system(); }
+                                                int n_pose_blocks, double* scal) {
   if ((int)blockIdx.x < n_pose_blocks) cost_reproj_block<PIPE>(blockIdx.x, b, rq, cams, pc, points, mode, scal);
   else cost_small_block((int64_t)blockIdx.x - n_pose_blocks, b, sf, cams, poses, objects, mode, scal);
 }
@@ -1725,7 +1682,7 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
   }
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
-                      const ReducedDev& rd, double* stage, double* stage_scal) {
+                      const ReducedDev& rd) {
   if (b.P <= 0 || rq.n <= 0) return;
   // a pose's workgroup walks its sightings 256 at a time; with few poses (a window) that loop is the latency of the launch: cut it
   // (not in the deterministic mode: one writer per block)
@@ -1736,25 +1693,8 @@ void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq
   if (!b.deterministic && b.P <= slice_below) slices = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (per_pose + kBlock - 1) / kBlock));
   // few poses: the loads of a sighting in two rounds with the next sighting's first round in flight (150 registers); many poses: the plain loop
   // (120 registers: beside the strip kernel the side stream is otherwise the longer one -- 2.02 vs 1.95 ms per LM iteration)
-  if (stage != nullptr) slices = 1;   // (a staging array takes stores, not sums)
-  if (b.P <= slice_below) hipLaunchKernelGGL(k_pose_pass<true>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices, stage, stage_scal);
-  else hipLaunchKernelGGL(k_pose_pass<false>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices, stage, stage_scal);
-}
-// The speculative side pass of the bounding-box factors: per-factor blocks (diagonal blocks into sf.bb_blk, the object-pose block into
-// sf.bb_off) and the cost into a staging scalar block; nothing of the step's accumulators is touched.
-void launch_bbox_spec(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd, double* stage_scal) {
-  const int nb_bbox = (int)grid_for(sf.n_bb, 4);   // (stage_scal was cleared by the pose pass in front: launch_pose_pass(..., stage, stage_scal))
-  if (nb_bbox > 0) hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox), dim3(64), 0, s, b, sf, cams, poses, objects, rd, stage_scal, nb_bbox, 0);
-}
-// ... and what follows it in the step that uses the staged results: k_spec_apply, the priors and relative-pose factors (evaluated here: a
-// handful of blocks), the per-object / per-pose sums of the bounding-box blocks
-void launch_spec_apply_and_rest(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses, const double* objects, const ReducedDev& rd,
-                                const double* stage_pose, const double* stage_scal, double* scal) {
-  const int nbp = (int)grid_for(27 * b.nPv, kBlock), nbo = (int)grid_for(42 * sf.n_bb, kBlock);
-  if (nbp + nbo > 0) hipLaunchKernelGGL(k_spec_apply, dim3(std::max(1, nbp) + nbo), dim3(kBlock), 0, s, b, sf, rd, stage_pose, stage_scal, scal, std::max(1, nbp));
-  const int nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
-  if (nb_priors + nb_rel > 0) hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, 0, nb_priors);
-  if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
+  if (b.P <= slice_below) hipLaunchKernelGGL(k_pose_pass<true>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
+  else hipLaunchKernelGGL(k_pose_pass<false>, dim3((unsigned)(b.P * slices)), dim3(kBlock), 0, s, b, rq, cams, pc, points, rd, slices);
 }
 void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* cams, const double* poses,
                           const double* objects, const ReducedDev& rd, double* scal) {
@@ -1819,7 +1759,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
-                 const double* points_cand, const double* objects_cand, int mode, double* scal, double* started_host, double started_seq) {
+                 const double* points_cand, const double* objects_cand, int mode, double* scal) {
   // mode 0: cost of the variable residual blocks at the candidate; mode 1: cost of the all-constant blocks at the current point
   const PoseCache* pc = mode == 0 ? pc_cand : pc_cur;
   const double* poses = mode == 0 ? poses_cand : poses_cur;
@@ -1829,8 +1769,8 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   const unsigned grid = (unsigned)n_pose_blocks + grid_for(ns, kBlock);
   if (grid > 0) {
-    if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal, started_host, started_seq);   // (few poses: cost_reproj_block)
-    else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal, started_host, started_seq);
+    if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);   // (few poses: cost_reproj_block)
+    else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
     if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED));
   }
 }

@@ -108,13 +108,6 @@ struct obvi_ba_handle {
   DevBuf<double> d_bb_rect, d_bb_sqrt_inf, d_sp_mean, d_sp_sqrt_inf, d_lt_mean, d_lt_sqrt_inf, d_rl_t, d_rl_R, d_rl_sqrt_inf;
   DevBuf<uint8_t> d_bb_active, d_sp_active, d_lt_active, d_rl_active;
   DevBuf<double> d_bb_blk;                                    // per-factor blocks of the bounding-box factors (k_bbox_gather)
-  // Speculative side pass (submit_step): the pose pass and the bounding-box factors of the NEXT linearisation point are evaluated at the
-  // candidate, on the side stream, while the trial cost / the host's decision / the clear / the next point pass run; their results wait in
-  // one of two staging sets.  spec_cur: the set that belongs to the current point (valid: spec_cur_valid), the other one takes the candidate's.
-  DevBuf<double> d_spec_pose[2], d_spec_blk[2], d_spec_off[2], d_spec_scal[2];
-  int spec_cur = 0;
-  bool spec_cur_valid = false, spec_cand_valid = false;
-  hipEvent_t ev_spec = nullptr;
   DevBuf<double> d_sm_blk; DevBuf<uint32_t> d_smt_ptr, d_smt_idx;   // deterministic mode: the same for the priors and relative-pose factors (k_small_gather)
   int32_t bb_pairs_unique = 1;
   DevBuf<uint32_t> d_bbo_ptr, d_bbo_idx, d_bbp_ptr, d_bbp_idx;   // ... and the factor lists by object / by pose (prepare())
@@ -139,7 +132,6 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_sel_mask;
   DevBuf<uint32_t> d_rp_inv;
   SelectScratch sel_scratch;
-  double started_seq = 0.0;  // sequence number the trial-cost kernel writes to h_scal[SC_COUNT + 1] when it starts (host-triggered side pass)
   double* h_scal = nullptr;  // pinned; the device writes the scalar block of an LM step straight into it and, behind a system-scope fence, the sequence number [SC_COUNT]
                              // (k_zero_tiles): the host polls the number instead of sleeping in hipStreamSynchronize (whose wake-up costs tens of microseconds)
   double scal_seq = 0.0;
@@ -270,12 +262,11 @@ void finish_upload(obvi_ba_handle* h) { if (h->staging.spilled || tl_staging != 
 
 // Waits for the scalar block of the step just submitted: polls the sequence number the device writes behind the block, and asks the
 // stream now and then so that a failed launch surfaces as an error instead of a hang.
-void wait_scalars(obvi_ba_handle* h, int slot = SC_COUNT, double want = -1.0) {
-  volatile const double* seq = h->h_scal + slot;
-  const double expect = slot == SC_COUNT ? h->scal_seq : want;
+void wait_scalars(obvi_ba_handle* h) {
+  volatile const double* seq = h->h_scal + SC_COUNT;
   for (;;) {
     for (int spin = 0; spin < 4096; ++spin) {
-      if (*seq == expect) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+      if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #else
@@ -283,7 +274,7 @@ void wait_scalars(obvi_ba_handle* h, int slot = SC_COUNT, double want = -1.0) {
 #endif
     }
     const hipError_t q = hipStreamQuery(h->stream);
-    if (q == hipSuccess) { if (*seq == expect) { std::atomic_thread_fence(std::memory_order_acquire); return; } sync(h); if (*seq != expect) throw HipError{hipErrorUnknown, "the step's scalar block never arrived", __FILE__, __LINE__}; return; }
+    if (q == hipSuccess) { if (*seq == h->scal_seq) { std::atomic_thread_fence(std::memory_order_acquire); return; } sync(h); if (*seq != h->scal_seq) throw HipError{hipErrorUnknown, "the step's scalar block never arrived", __FILE__, __LINE__}; return; }
     if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery", __FILE__, __LINE__};
   }
 }
@@ -310,13 +301,13 @@ ReprojPoseDev reproj_pose_dev(const obvi_ba_handle* h) {
   r.active = h->d_rq_active.get(); r.pose_ptr = h->d_rq_pose_ptr.get(); r.huber = h->rp_huber;
   return r;
 }
-SmallFactorsDev small_dev(const obvi_ba_handle* h, int spec_set = -1) {
+SmallFactorsDev small_dev(const obvi_ba_handle* h) {
   SmallFactorsDev s;
   s.n_bb = h->n_bb; s.bb_obj = h->d_bb_obj.get(); s.bb_pose = h->d_bb_pose.get(); s.bb_cam = h->d_bb_cam.get();
   s.bb_rect = h->d_bb_rect.get(); s.bb_sqrt_inf = h->d_bb_sqrt_inf.get(); s.bb_active = h->d_bb_active.get();
   s.bb_huber = h->bb_huber; s.bb_invalid = h->bb_invalid;
   s.sm_blk = h->d_sm_blk.get(); s.smt_ptr = h->d_smt_ptr.get(); s.smt_idx = h->d_smt_idx.get();
-  s.bb_pairs_unique = h->bb_pairs_unique; s.bb_blk = spec_set >= 0 ? h->d_spec_blk[spec_set].get() : h->d_bb_blk.get(); s.bb_off = spec_set >= 0 ? h->d_spec_off[spec_set].get() : nullptr; s.bbo_ptr = h->d_bbo_ptr.get(); s.bbo_idx = h->d_bbo_idx.get(); s.bbp_ptr = h->d_bbp_ptr.get(); s.bbp_idx = h->d_bbp_idx.get();
+  s.bb_pairs_unique = h->bb_pairs_unique; s.bb_blk = h->d_bb_blk.get(); s.bbo_ptr = h->d_bbo_ptr.get(); s.bbo_idx = h->d_bbo_idx.get(); s.bbp_ptr = h->d_bbp_ptr.get(); s.bbp_idx = h->d_bbp_idx.get();
   s.n_sp = h->n_sp; s.sp_obj = h->d_sp_obj.get(); s.sp_mean = h->d_sp_mean.get(); s.sp_sqrt_inf = h->d_sp_sqrt_inf.get();
   s.sp_active = h->d_sp_active.get(); s.sp_huber = h->sp_huber;
   s.n_lt = h->n_lt; s.lt_obj = h->d_lt_obj.get(); s.lt_mean = h->d_lt_mean.get(); s.lt_sqrt_inf = h->d_lt_sqrt_inf.get();
@@ -1360,25 +1351,6 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // it forks in front of the point pass.
   const int64_t fork_early_below = std::getenv("OBVI_FORK_EARLY_BELOW") ? std::atoll(std::getenv("OBVI_FORK_EARLY_BELOW")) : 400000;   // tuning knob (observations); read per step: the tests flip it
   const bool fork_early = side && h->n_rp < fork_early_below;
-  // Speculative side pass (big problems, two streams, no multi-GPU exchange): the pose pass and the bounding-box factors do not depend on the
-  // trust-region radius, only on the linearisation point -- and the next linearisation point is, unless the step is rejected, the candidate
-  // that exists as soon as the back-substitution has run.  They are therefore evaluated THERE, at the end of this submission, on the side
-  // stream, beside the trial cost, the host's decision, the clear and the next point pass, into a staging set; the submission that linearises
-  // at that point only applies the set (k_spec_apply) -- and a rejected step, which linearises at the same point again, applies the set it
-  // already has.  What is left of the side stream beside the strip kernel is then a few tens of microseconds (it was as long as the kernel).
-  const bool spec_ok = !std::getenv("OBVI_SPECULATE") || std::atoi(std::getenv("OBVI_SPECULATE")) != 0;   // tuning knob; read per step: the tests flip it
-  const bool spec = spec_ok && side && !fork_early && !exchange && h->n_rp > 0 && h->profiling < 2;
-  if (first_iter || !spec) { h->spec_cur_valid = false; h->spec_cand_valid = false; }
-  if (spec) {
-    for (int q = 0; q < 2; ++q) {
-      h->d_spec_pose[q].resize((size_t)27 * (size_t)h->nPv + 1); h->d_spec_blk[q].resize((size_t)62 * (size_t)h->n_bb + 1);
-      h->d_spec_off[q].resize((size_t)42 * (size_t)h->n_bb + 1); h->d_spec_scal[q].resize(SC_COUNT);
-    }
-  }
-  auto spec_pass = [&](int set, const PoseCache* pc, const double* poses, const double* points, const double* objects) {
-    launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), pc, points, rd, h->d_spec_pose[set].get(), h->d_spec_scal[set].get());
-    launch_bbox_spec(s2, b, small_dev(h, set), h->d_cams.get(), poses, objects, rd, h->d_spec_scal[set].get());
-  };
   auto side_pose_pass = [&] {
     record(h, PH_POSE_PASS, s2);
     launch_pose_pass(s2, b, reproj_pose_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_point.get(), rd);
@@ -1421,21 +1393,6 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     if (solve) schur_blocks_on(s);   // (forked early, the side stream is not ordered behind the point pass whose Z records these pairs read: main stream)
     side_diagonal();
     OBVI_HIP(hipEventRecord(h->ev_join, s2));
-  } else if (spec) {
-    record(h, PH_POSE_PASS, s2);
-    if (!h->spec_cur_valid) {   // no staged sums for this point yet (first step of a solve): formed here, the way the tail forms a candidate's
-      spec_pass(h->spec_cur, h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get());
-      h->spec_cur_valid = true;
-    }
-    record_end(h, PH_POSE_PASS, s2);
-    record(h, PH_SMALL, s2);
-    launch_spec_apply_and_rest(s2, b, small_dev(h, h->spec_cur), h->d_cams.get(), h->d_pose.get(), h->d_obj.get(), rd, h->d_spec_pose[h->spec_cur].get(), h->d_spec_scal[h->spec_cur].get(), scal);
-    record_end(h, PH_SMALL, s2);
-    side_diagonal();
-    if (solve) schur_blocks_on(s2);
-    OBVI_HIP(hipEventRecord(h->ev_join, s2));
-    main_schur_window();
-    record(h, PH_SCHUR_BLOCKS);
   } else {
     side_pose_pass();
     side_small_factors();
@@ -1473,26 +1430,9 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   record(h, PH_BACKSUB);
   if (solve) launch_backsub_apply(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), h->d_pc_c.get(), scal);
   record(h, PH_APPLY);   // (the candidate poses / objects are formed in the same launch)
-  // The candidate exists when the back-substitution has run: its side pass starts then, on the side stream.  Not behind an event: a
-  // hipStreamWaitEvent would sit at the head of the side queue from now (the host is a whole step ahead) until the end of the step, and a
-  // queue with a pending wait costs every launch of the OTHER queue -- the ~70 back-to-back kernels of the factorisation -- 0.7 us
-  // (measured: 877 vs 827 us).  Instead the trial-cost kernel, which starts when the back-substitution is done, says so in a pinned page and
-  // the host, which only waits for the step's scalars anyway, launches the side pass when it sees that.  (Event version: OBVI_SPEC_TAIL=2,
-  // and whenever the host does not poll.)
-  static const int spec_tail = std::getenv("OBVI_SPEC_TAIL") ? std::atoi(std::getenv("OBVI_SPEC_TAIL")) : 1;   // tuning knob: 0 = the staged sums are formed at the start of every step instead
-  const bool poll_ok_ = !std::getenv("OBVI_POLL_SCALARS") || std::atoi(std::getenv("OBVI_POLL_SCALARS")) != 0;
-  const bool will_poll = poll_ok_ && h->profiling < 1 && !keep_factor;
-  const bool tail = spec && solve && spec_tail != 0;
-  const bool tail_by_host = tail && will_poll && spec_tail != 2;
-  if (tail && !tail_by_host) {
-    OBVI_HIP(hipEventRecord(h->ev_spec, s)); OBVI_HIP(hipStreamWaitEvent(s2, h->ev_spec, 0));
-    spec_pass(1 - h->spec_cur, h->d_pc_c.get(), h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get());
-    h->spec_cand_valid = true;
-  }
   record(h, PH_COST);
-  if (tail_by_host) h->started_seq += 1.0;
   if (solve) launch_cost(s, b, reproj_pose_dev(h), sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),
-                         h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal, tail_by_host ? h->h_scal + SC_COUNT + 1 : nullptr, h->started_seq);
+                         h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get(), 0, scal);
   record(h, PH_COUNT);
   if (exchange) {   // (3) every rank must take the same decision: the sums and every rank's gradient maximum in one collective
     launch_pack_scalars(s, scal, h->d_xbuf.get(), h->rank, h->world, 0);
@@ -1512,11 +1452,6 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   } else {
     OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
     if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
-  }
-  if (tail_by_host) {
-    wait_scalars(h, /*slot=*/SC_COUNT + 1, h->started_seq);   // the back-substitution is done (the trial cost has started)
-    spec_pass(1 - h->spec_cur, h->d_pc_c.get(), h->d_pose_c.get(), h->d_point_c.get(), h->d_obj_c.get());
-    h->spec_cand_valid = true;
   }
   if (poll) wait_scalars(h); else sync(h);
   if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) {
@@ -1627,8 +1562,8 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     // coherent (fine-grained): the host polls this page while the step is still running (wait_scalars); with a non-coherent mapping it
     // would see the device's write only at the end of the stream
-    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 2), hipHostMallocCoherent));
-    std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 2));
+    OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocCoherent));
+    std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
     h->staging.cap = kStagingBytes;
     h->d_scal.resize(SC_COUNT + (h->deterministic ? (size_t)kDetSlots * (size_t)kDetStride : 0));   // deterministic mode: per-workgroup partial sums behind the block (ba_device.h)
@@ -1636,7 +1571,6 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
     OBVI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); OBVI_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));   // ordering only: no timestamps
-    OBVI_HIP(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
   } catch (const HipError&) {
     delete h;
     return OBVI_ERR_HIP;
@@ -1653,7 +1587,7 @@ void obvi_ba_destroy(obvi_ba_handle* h) {
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev_end) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_spec}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_fork, h->ev_join}) if (e) (void)hipEventDestroy(e);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->staging.base) (void)hipHostFree(h->staging.base);
@@ -2275,7 +2209,6 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
         break;
       }
       radius /= decrease_factor; decrease_factor *= 2.0;  // StepIsInvalid
-      h->spec_cand_valid = false;
       it.cost = x_cost + fixed_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
       if (!push_and_check(it)) break;
       submit_step(h, radius, false, true);
@@ -2299,8 +2232,6 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     if (it.relative_decrease > kMinRelDecrease) {
       // HandleSuccessfulStep: the candidate becomes the current point
       h->d_pose.swap(h->d_pose_c); h->d_point.swap(h->d_point_c); h->d_obj.swap(h->d_obj_c); h->d_pc.swap(h->d_pc_c);   // the candidate's pose cache comes along
-      if (h->spec_cand_valid) { h->spec_cur ^= 1; h->spec_cur_valid = true; } else h->spec_cur_valid = false;   // ... and so does its side pass, if one ran
-      h->spec_cand_valid = false;
       if (best_is_current) {   // the point just left is the best so far: it stays where it is, the old best buffers take the next candidate
         h->d_pose_c.swap(h->d_pose_b); h->d_point_c.swap(h->d_point_b); h->d_obj_c.swap(h->d_obj_b);
         best_is_current = false;
@@ -2318,7 +2249,6 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
       submit_step(h, radius, false, it.iteration < prm->max_num_iterations);
     } else {
       it.step_is_successful = 0;
-      h->spec_cand_valid = false;         // the candidate's side pass is dropped; the current point's staging set is still the right one
       it.cost = cand_cost + fixed_cost;   // HandleUnsuccessfulStep records the CANDIDATE's cost [Ceres-doc trust_region_minimizer.cc]
       it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
       radius /= decrease_factor; decrease_factor *= 2.0;  // StepRejected
