@@ -13,6 +13,7 @@
 #include <obvi_ba.h>
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <fstream>
 #include <functional>
@@ -417,6 +418,14 @@ class ObjectPoseGraphOptimizer {
       std::shared_ptr<PoseGraphType>& pose_graph, obvi::Problem* problem, std::optional<OptimizationLogger>& opt_logger,
       const FactorInfoSet& excluded_feature_factor_types_and_ids = {}) {
     residual_params_ = residual_params;
+    const bool timing_ = std::getenv("OBVI_HOST_TIMING") != nullptr && std::getenv("OBVI_HOST_TIMING")[0] == '2';
+    auto t_last_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* what) {
+      if (!timing_) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::cerr << "    build: " << what << " " << std::chrono::duration<double, std::milli>(now - t_last_).count() << " ms" << std::endl;
+      t_last_ = now;
+    };
     std::set<FrameId> optimized_frames;
     std::unordered_set<ObjectId> ltm_object_ids;
     std::map<ObjectId, FactorInfoSet> objects_to_include;
@@ -470,6 +479,7 @@ class ObjectPoseGraphOptimizer {
       if (!std::is_sorted(keyed.begin(), keyed.end())) std::sort(keyed.begin(), keyed.end());
       for (size_t i = 0; i < keyed.size(); ++i) included_slots[i] = keyed[i].second;
     }
+    lap_("sightings per feature, included features");
     if (use_object_param_blocks) pose_graph->getLongTermMapObjects(ltm_object_ids);                                         // :301-306
     if (use_object_pose_factors) {                                                                                           // :308-340
       FactorInfoSet matching;
@@ -493,6 +503,7 @@ class ObjectPoseGraphOptimizer {
       }
     }
 
+    lap_("object factors");
     // ---- flatten (the part that replaces addOrRefreshResidualBlocksForRequiredFactors, :415, :991-1055) ----
     obvi::FlatProblem& fp = problem->flat;
     fp.reset();
@@ -549,6 +560,7 @@ class ObjectPoseGraphOptimizer {
         fp.object_const.push_back((fix_object_param_blocks || (fix_ltm_param_blocks && is_ltm)) ? 1 : 0);
       }
     }
+    lap_("parameter blocks");
     const auto& rp = residual_params;
     // residual blocks, type by type in the evaluate order of the ABI; inside a type by factor id
     std::unordered_map<FrameId, size_t> obs_per_frame;
@@ -572,6 +584,76 @@ class ObjectPoseGraphOptimizer {
       for (const auto& sp : spans) total += sp.second;
       fp.rp_pose.resize(total); fp.rp_point.resize(total); fp.rp_cam.resize(total); fp.rp_pixel.resize(2 * total); fp.rp_sigma.resize(total); fp.blocks.resize(total);
       bool ascending = true, first = true; FeatureFactorId last_id = 0;
+      // A global-BA frame flattens millions of records: the frames' spans are then written by ranges of spans on host threads (each span's
+      // share of the arrays is known after a counting pass: same arrays, same order); a window's few ten thousand go the plain way.
+      const unsigned hw = std::getenv("OBVI_HOST_BUILD_THREADS") ? (unsigned)std::atoi(std::getenv("OBVI_HOST_BUILD_THREADS")) : std::thread::hardware_concurrency();   // (knob: 1 = the plain loop)
+      const size_t n_threads = total >= ((size_t)1 << 18) && hw > 1 ? std::min<size_t>({(size_t)8, (size_t)hw, spans.size()}) : 1;
+      if (n_threads > 1) {
+        std::vector<size_t> kept_of(spans.size(), 0), at(spans.size() + 1, 0);
+        struct RangeIds { bool any = false, ascending = true; FeatureFactorId first_id = 0, last_id = 0; };
+        std::vector<RangeIds> ids(n_threads);
+        auto ranges = [&](auto&& body) {
+          std::vector<std::thread> th;
+          for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { body(t, spans.size() * t / n_threads, spans.size() * (t + 1) / n_threads); });
+          for (auto& x : th) x.join();
+        };
+        ranges([&](size_t t, size_t s0, size_t s1) {
+          RangeIds& r = ids[t];
+          for (size_t si = s0; si < s1; ++si) {
+            size_t kept = 0;
+            for (const VisualRecord* v = spans[si].first, *e = v + spans[si].second; v != e; ++v) {
+              if (sightings_[v->feature_slot] < min_obs || visual_excluded(*v)) continue;
+              ++kept;
+              if (r.any && v->id < r.last_id) r.ascending = false;
+              if (!r.any) { r.first_id = v->id; r.any = true; }
+              r.last_id = v->id;
+            }
+            kept_of[si] = kept;
+          }
+        });
+        for (const RangeIds& r : ids) {
+          if (!r.any) continue;
+          if (!r.ascending || (!first && r.first_id < last_id)) ascending = false;
+          last_id = r.last_id; first = false;
+        }
+        for (size_t si = 0; si < spans.size(); ++si) at[si + 1] = at[si] + kept_of[si];
+        if (ascending) {
+          // (a record whose pose / point / camera is not in the problem is dropped by put(): then the arrays are compacted below)
+          std::vector<size_t> written(spans.size(), 0);
+          ranges([&](size_t, size_t s0, size_t s1) {
+            for (size_t si = s0; si < s1; ++si) {
+              if (spans[si].second == 0) continue;
+              const int64_t pose = pose_of(spans[si].first->frame_id);
+              CameraId last_cam = spans[si].first->camera_id; int32_t cam = cam_of(last_cam);
+              size_t w = at[si];
+              for (const VisualRecord* v = spans[si].first, *e = v + spans[si].second; v != e; ++v) {
+                if (sightings_[v->feature_slot] < min_obs || visual_excluded(*v)) continue;
+                if (v->camera_id != last_cam) { last_cam = v->camera_id; cam = cam_of(last_cam); }
+                const int32_t point = point_of_slot[v->feature_slot];
+                if (pose < 0 || point < 0 || cam < 0) continue;
+                fp.rp_pose[w] = (uint32_t)pose; fp.rp_point[w] = (uint32_t)point; fp.rp_cam[w] = (uint16_t)cam;
+                fp.rp_pixel[2 * w] = v->px; fp.rp_pixel[2 * w + 1] = v->py; fp.rp_sigma[w] = v->sigma;
+                fp.blocks[w] = {kReprojectionErrorFactorTypeId, v->id};
+                ++w;
+              }
+              written[si] = w - at[si];
+            }
+          });
+          bool holes = false;
+          for (size_t si = 0; si < spans.size(); ++si) holes = holes || written[si] != kept_of[si];
+          n = at[spans.size()];
+          if (holes) {   // rare: compact in order
+            n = 0;
+            for (size_t si = 0; si < spans.size(); ++si)
+              for (size_t k = 0; k < written[si]; ++k, ++n) {
+                const size_t from = at[si] + k;
+                fp.rp_pose[n] = fp.rp_pose[from]; fp.rp_point[n] = fp.rp_point[from]; fp.rp_cam[n] = fp.rp_cam[from];
+                fp.rp_pixel[2 * n] = fp.rp_pixel[2 * from]; fp.rp_pixel[2 * n + 1] = fp.rp_pixel[2 * from + 1]; fp.rp_sigma[n] = fp.rp_sigma[from]; fp.blocks[n] = fp.blocks[from];
+              }
+          }
+        }
+        for (size_t si = 0; si < spans.size(); ++si) if (kept_of[si]) obs_per_frame[spans[si].first->frame_id] += kept_of[si];
+      } else
       for (const auto& sp : spans) {
         if (sp.second == 0) continue;
         const int64_t pose = pose_of(sp.first->frame_id);
@@ -597,6 +679,7 @@ class ObjectPoseGraphOptimizer {
       }
       fp.rp_pose.resize(n); fp.rp_point.resize(n); fp.rp_cam.resize(n); fp.rp_pixel.resize(2 * n); fp.rp_sigma.resize(n); fp.blocks.resize(n);
     }
+    lap_("reprojection factors");
     if (use_relative_pose_factors) {                                                                                         // :240-299
       for (const FrameId& f : optimized_frames) {
         auto it = obs_per_frame.find(f);
@@ -651,6 +734,7 @@ class ObjectPoseGraphOptimizer {
     }
     last_optimized_nodes_ = optimized_frames.size(); last_optimized_features_ = fp.features.size(); last_optimized_objects_ = fp.objects.size();
     if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);   // :625-629
+    lap_("small factor families");
     return ResidualBlockInfoMap(fp.blocks);
   }
 
@@ -832,10 +916,19 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
                                  const pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams& pgo_solver_params, const bool& final_run,
                                  std::optional<OptimizationLogger>& opt_logger, std::shared_ptr<PoseGraphType>& pose_graph, int device_id = 0,
                                  const int& attempt_num = 0) {
+  const bool timing = std::getenv("OBVI_HOST_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::cerr << "  runPgoPlusEllipsoids: " << what << " " << std::chrono::duration<double, std::milli>(now - t_last).count() << " ms" << std::endl;
+    t_last = now;
+  };
   std::unordered_map<FrameId, RawPose3d> raw;
   pose_graph->getRobotPoseEstimates(raw);
   ObjectPoseGraphOptimizer optimizer;
   obvi::Problem problem(device_id);
+  lap("estimates + problem (device handle)");
   for (FrameId f = 1; f <= max_frame_id; ++f) {                                                                              // :94-127
     if (!raw.count(f) || !raw.count(f - 1)) { std::cerr << "Could not find current estimate for frame num " << f << std::endl; return false; }
     RelPoseFactor rel;
@@ -849,39 +942,61 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
   OptimizationScopeParams scope_pgo = optimization_scope_params;                                                              // :161-165
   scope_pgo.include_visual_factors_ = false;
   scope_pgo.poses_prior_to_window_to_keep_constant_ = 1;
-  // (the reference keys this by feature id in a map filled from a copy of all feature estimates; a flat list over the graph's own
-  // feature table holds the same entries -- tens of thousands at a global-BA frame)
-  struct RelativeToFirst { FeatureId feature; FrameId first; Position3d relative; };
+  // (the reference keys this by feature id in a map filled from a copy of all feature estimates and looks every feature's first frame and that
+  // frame's pose up in two more maps; the graph's dense feature slots hold the same entries -- 300 000 at a global-BA frame -- and the poses
+  // are an array by frame here: same values, no hashing)
+  struct RelativeToFirst { uint32_t slot; FrameId first; Position3d relative; };
   std::vector<RelativeToFirst> relative_positions_from_first;
+  // the rotation of a frame's pose once per frame (getPositionRelativeToPose / combinePoseAndPosition form it per call: the same matrix
+  // for every feature first seen from that frame)
+  struct FramePose { bool have = false; Mat3 R; Position3d t; };
+  std::vector<FramePose> pose_of_frame((size_t)max_frame_id + 1);
+  auto cache_poses = [&]() {
+    for (FramePose& fp : pose_of_frame) fp.have = false;
+    for (const auto& r : raw) if (r.first <= max_frame_id) { FramePose& fp = pose_of_frame[r.first]; fp.have = true; fp.R = rotationFromAxisAngle({{r.second[3], r.second[4], r.second[5]}}); fp.t = {{r.second[0], r.second[1], r.second[2]}}; }
+  };
+  cache_poses();
   if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :167-199
-    relative_positions_from_first.reserve(pose_graph->featurePositions().size());
-    for (const auto& f : pose_graph->featurePositions()) {
-      FrameId first;
-      if (!pose_graph->getFirstObservedFrameForFeature(f.first, first)) continue;
-      const auto pose_of_first = raw.find(first);
-      if (pose_of_first != raw.end()) relative_positions_from_first.push_back({f.first, first, getPositionRelativeToPose(convertToPose3D(pose_of_first->second), *f.second)});
+    const size_t n_slots = pose_graph->numFeatureSlots();
+    relative_positions_from_first.reserve(n_slots);
+    for (uint32_t slot = 0; slot < n_slots; ++slot) {
+      const double* p = pose_graph->featurePointerOfSlot(slot);
+      const FrameId first = pose_graph->firstObservedFrameOfSlot(slot);
+      if (p == nullptr || first == PoseGraphType::kNoFrame || first > max_frame_id || !pose_of_frame[first].have) continue;
+      const Mat3& R = pose_of_frame[first].R; const Position3d& t = pose_of_frame[first].t;
+      Position3d o;   // getPositionRelativeToPose
+      for (int i = 0; i < 3; ++i) o[i] = R[i] * (p[0] - t[0]) + R[3 + i] * (p[1] - t[1]) + R[6 + i] * (p[2] - t[2]);
+      relative_positions_from_first.push_back({slot, first, o});
     }
   }
+  lap("relative-pose factors + feature positions relative to their first frame");
   if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(max_frame_id, false, true, true, attempt_num);          // :201-204
   optimizer.buildPoseGraphOptimization(scope_pgo, residual_params, pose_graph, &problem, opt_logger);
+  lap("build (objects + relative poses)");
   if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_pgo_optimization_solver_params_ : pgo_solver_params.pgo_optimization_solver_params_,
                                    opt_logger)) {                                                                            // :221-232
     std::cerr << "Pose-graph + object optimization failed at max frame id " << max_frame_id << std::endl;
     return false;
   }
   if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
+  lap("solve (pose graph + objects)");
   if (pgo_solver_params.enable_visual_non_opt_feature_adjustment_post_pgo_) {                                                // :238-283
     pose_graph->getRobotPoseEstimates(raw);
+    cache_poses();
     for (const RelativeToFirst& f : relative_positions_from_first) {
-      const auto pose_of_first = raw.find(f.first);
-      if (pose_of_first != raw.end()) pose_graph->updateVisualPositionParams(f.feature, combinePoseAndPosition(convertToPose3D(pose_of_first->second), f.relative));
+      if (!pose_of_frame[f.first].have) continue;
+      const Mat3& R = pose_of_frame[f.first].R; const Position3d& t = pose_of_frame[f.first].t; const Position3d& p = f.relative;
+      double* pos = pose_graph->featurePointerOfSlot(f.slot);   // combinePoseAndPosition
+      for (int i = 0; i < 3; ++i) pos[i] = t[i] + R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
     }
   }
+  lap("features follow their first frame");
   if (pgo_solver_params.enable_visual_feats_only_opt_post_pgo_) {                                                            // :284-350
     std::optional<OptimizationLogger> null_logger;
     OptimizationScopeParams scope_vf = optimization_scope_params;
     scope_vf.fix_poses_ = true; scope_vf.fix_objects_ = true; scope_vf.include_object_factors_ = false;
     optimizer.buildPoseGraphOptimization(scope_vf, residual_params, pose_graph, &problem, null_logger);
+    lap("build (features only)");
     if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_post_pgo_vf_adjustment_solver_params_ : pgo_solver_params.post_pgo_vf_adjustment_solver_params_,
                                      null_logger)) {
       std::cerr << "Visual feature adjustment after pose-graph optimization failed at max frame id " << max_frame_id << std::endl;
@@ -890,6 +1005,7 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
     // :338-345
     const std::shared_ptr<IterationLogger> vf_adjust_logger = IterationLoggerFactory::getInstance().getOrCreateLoggerOfType(IterationLoggerFactory::kVfAdjustOptimizationType);
     if (vf_adjust_logger != nullptr) vf_adjust_logger->logIterations(std::to_string(max_frame_id) + "_" + std::to_string(attempt_num), optimizer.lastSummary());
+    lap("solve (features only)");
   }
   return true;
 }

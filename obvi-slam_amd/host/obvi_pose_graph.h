@@ -7,6 +7,7 @@
 #ifndef OBVI_HOST_POSE_GRAPH_H_
 #define OBVI_HOST_POSE_GRAPH_H_
 
+#include <limits>
 #include <algorithm>
 #include <iostream>
 #include <map>
@@ -107,7 +108,9 @@ class ObjectAndReprojectionFeaturePoseGraph {
   FeatureFactorId addVisualFactor(const ReprojectionErrorFactor& factor) {               // low_level...h:341-369
     const FeatureFactorId id = next_visual_factor_id_++;
     factors_[id] = factor;
-    visual_records_by_frame_[factor.frame_id_].push_back({id, factor.feature_id_, factor.frame_id_, factor.camera_id_, featureSlot_(factor.feature_id_),
+    const uint32_t slot = featureSlot_(factor.feature_id_);
+    if (factor.frame_id_ < slot_first_frame_[slot]) slot_first_frame_[slot] = factor.frame_id_;
+    visual_records_by_frame_[factor.frame_id_].push_back({id, factor.feature_id_, factor.frame_id_, factor.camera_id_, slot,
                                                           factor.feature_pos_[0], factor.feature_pos_[1], factor.reprojection_error_std_dev_});
     visual_factors_by_frame_[factor.frame_id_].push_back(id);
     visual_factors_by_feature_[factor.feature_id_].push_back(id);
@@ -171,6 +174,9 @@ class ObjectAndReprojectionFeaturePoseGraph {
   size_t numFeatureSlots() const { return slot_feature_.size(); }
   FeatureId featureIdOfSlot(uint32_t slot) const { return slot_feature_[slot]; }
   double* featurePointerOfSlot(uint32_t slot) const { return slot_position_[slot]; }   // nullptr: factors seen, feature not added (yet)
+  // getFirstObservedFrameForFeature by slot, without the hash lookup (kNoFrame: no factor seen)
+  static constexpr FrameId kNoFrame = std::numeric_limits<FrameId>::max();
+  FrameId firstObservedFrameOfSlot(uint32_t slot) const { return slot_first_frame_[slot]; }
   bool getFeatureIdForObservationFactor(const FactorInfo& info, FeatureId& feature_id) const {
     if (info.first != kReprojectionErrorFactorTypeId) return false;
     auto it = factors_.find(info.second); if (it == factors_.end()) return false; feature_id = it->second.feature_id_; return true;
@@ -401,11 +407,11 @@ class ObjectAndReprojectionFeaturePoseGraph {
     const auto it = feature_slot_.find(id);
     if (it != feature_slot_.end()) return it->second;
     const uint32_t slot = (uint32_t)slot_feature_.size();
-    feature_slot_.emplace(id, slot); slot_feature_.push_back(id); slot_position_.push_back(nullptr);
+    feature_slot_.emplace(id, slot); slot_feature_.push_back(id); slot_position_.push_back(nullptr); slot_first_frame_.push_back(kNoFrame);
     return slot;
   }
   void rebuildVisualIndex_() {   // from factors_ / visual_factors_by_frame_ / feature_positions_ (a graph made from a state)
-    feature_slot_.clear(); slot_feature_.clear(); slot_position_.clear(); visual_records_by_frame_.clear();
+    feature_slot_.clear(); slot_feature_.clear(); slot_position_.clear(); slot_first_frame_.clear(); visual_records_by_frame_.clear();
     std::vector<FeatureId> ids;
     for (const auto& p : feature_positions_) ids.push_back(p.first);
     for (const auto& f : factors_) ids.push_back(f.second.feature_id_);
@@ -413,6 +419,7 @@ class ObjectAndReprojectionFeaturePoseGraph {
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     for (const FeatureId& id : ids) featureSlot_(id);
     for (const auto& p : feature_positions_) slot_position_[feature_slot_.at(p.first)] = p.second->data();
+    for (const auto& p : first_observed_frame_by_feature_) { const auto it = feature_slot_.find(p.first); if (it != feature_slot_.end()) slot_first_frame_[it->second] = p.second; }
     for (const auto& fr : visual_factors_by_frame_) {
       auto& v = visual_records_by_frame_[fr.first];
       for (FeatureFactorId id : fr.second) {
@@ -427,6 +434,7 @@ class ObjectAndReprojectionFeaturePoseGraph {
   std::unordered_map<FeatureId, uint32_t> feature_slot_;
   std::vector<FeatureId> slot_feature_;
   std::vector<double*> slot_position_;
+  std::vector<FrameId> slot_first_frame_;
   std::unordered_map<CameraId, CameraExtrinsics> camera_extrinsics_by_camera_;
   std::unordered_map<CameraId, CameraIntrinsicsMat> camera_intrinsics_by_camera_;
   std::unordered_map<FrameId, RawPose3dPtr> robot_poses_;

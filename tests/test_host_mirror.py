@@ -38,7 +38,7 @@ def oracle_driver():
         subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "oracle")])
     deps = srcs + [os.path.join(helpers.ROOT, "tests", "oracle_abi_shim.h"), helpers.ORACLE_LIB] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
     if not os.path.exists(ORACLE_DRIVER) or os.path.getmtime(ORACLE_DRIVER) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(helpers.ROOT, "include"), "-I" + HOST, "-include", os.path.join(helpers.ROOT, "tests", "oracle_abi_shim.h"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(helpers.ROOT, "include"), "-I" + HOST, "-include", os.path.join(helpers.ROOT, "tests", "oracle_abi_shim.h"),
                                "-o", ORACLE_DRIVER] + srcs + ["-L" + os.path.join(helpers.ROOT, "oracle"), "-lobvi_oracle", "-Wl,-rpath,$ORIGIN/../oracle"])
     return ORACLE_DRIVER
 
@@ -239,6 +239,23 @@ def oracle_session(oracle_driver, scene, tmp_path_factory):
 def test_offline_runner_session_through_the_oracle(oracle_session, scene):
     """The host mirror's session logic end to end on the CPU: the driver bound to the oracle instead of libobvi_ba.so."""
     check_session(scene[0], *oracle_session)
+
+
+def test_big_builds_flatten_on_host_threads_into_the_same_arrays(driver, tmp_path):
+    """A global-BA frame flattens millions of sightings: above 2^18 records buildPoseGraphOptimization writes the frames' spans on host
+    threads.  Same flat problem, array for array, as the plain loop (OBVI_HOST_BUILD_THREADS=1) -- also when frames were filled last
+    frame first (factor ids descend: the sorted route) and with every third factor excluded."""
+    prob = synth.make_problem(P=260, L=36000, O=3, seed=8, min_obj_obs=6, bbox_noise=5.0, object_classes=("bench",))
+    assert len(prob["rp_pose"]) > (1 << 18)
+    path = str(tmp_path / "scene.bin")
+    scene_io.write_scene_binary(prob, path)
+    for extra in ([], ["--frames-reversed"], ["--excluded-every", "3"]):
+        outs = []
+        for threads in ("1", "6"):
+            out = str(tmp_path / ("build_%s.json" % threads))
+            subprocess.check_call([driver, path, out, "--dump-build", "0", "259"] + extra, timeout=900, env=dict(os.environ, OBVI_HOST_BUILD_THREADS=threads))
+            outs.append(open(out).read())
+        assert outs[0] == outs[1] and len(outs[0]) > 1000000, extra
 
 
 def test_global_ba_mode_and_the_binary_scene(oracle_driver, scene, tmp_path):

@@ -30,7 +30,7 @@ def lockstep_driver():
     if not os.path.exists(LOCKSTEP_DRIVER) or os.path.getmtime(LOCKSTEP_DRIVER) < max(os.path.getmtime(d) for d in deps):
         obj = os.path.join(tests, "lockstep_shim.o")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-c", "-o", obj, srcs[1]])          # the shim itself sees the real names
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(helpers.ROOT, "include"), "-I" + HOST, "-include", srcs[2], "-o", LOCKSTEP_DRIVER, srcs[0], obj,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(helpers.ROOT, "include"), "-I" + HOST, "-include", srcs[2], "-o", LOCKSTEP_DRIVER, srcs[0], obj,
                                "-L" + os.path.dirname(helpers.PRODUCT_LIB), "-lobvi_ba", "-L" + os.path.join(helpers.ROOT, "oracle"), "-lobvi_oracle",
                                "-Wl,-rpath,$ORIGIN/../obvi-slam_amd/csrc", "-Wl,-rpath,$ORIGIN/../oracle", "-ldl"])
     return LOCKSTEP_DRIVER
