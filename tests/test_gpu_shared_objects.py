@@ -437,11 +437,13 @@ def test_bench_two_ranks_oversubscribed():
     assert line["roofline"]["kernel"] and "cpu_baseline" not in line
 
 
-def test_rccl_rendezvous_file(tmp_path):
+def test_rccl_rendezvous_file(tmp_path, monkeypatch):
     """obvi_rccl_comm_create_from_file: the launcher-less rendezvous of a C++ host (rank 0 writes the id, the others poll).  The file lives only
     for the rendezvous: rank 0 replaces whatever an earlier run left at the path and removes its own file once the communicator exists, so a
     second run on the same path can never pick up the first run's id."""
     import os
+    for name in ("OBVI_RCCL_JOB", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):      # (no per-launch tag: the file is `path` itself; another test of this process may have left MASTER_PORT behind)
+        monkeypatch.delenv(name, raising=False)
     path = str(tmp_path / "rccl_id")
     with open(path, "wb") as f:
         f.write(b"\x5a" * dist_util.RcclComm.ID_BYTES)        # a leftover of a crashed run: a syntactically valid, wrong id
@@ -454,15 +456,12 @@ def test_rccl_rendezvous_file(tmp_path):
     # a per-launch tag from the environment becomes part of the file name: a leftover at the untagged path is not even looked at
     with open(path, "wb") as f:
         f.write(b"\x5a" * dist_util.RcclComm.ID_BYTES)
-    os.environ["OBVI_RCCL_JOB"] = "job 42/a"
+    monkeypatch.setenv("OBVI_RCCL_JOB", "job 42/a")
+    comm = dist_util.RcclComm(0, 1, 0, id_file=path)
     try:
-        comm = dist_util.RcclComm(0, 1, 0, id_file=path)
-        try:
-            assert comm.world() == 1 and os.path.exists(path) and not os.path.exists(path + ".job_42_a")
-        finally:
-            comm.close()
+        assert comm.world() == 1 and os.path.exists(path) and not os.path.exists(path + ".job_42_a")
     finally:
-        del os.environ["OBVI_RCCL_JOB"]
+        comm.close()
 
 
 def test_rccl_library_reports_its_version_and_issue_sequence(scene):
