@@ -154,6 +154,11 @@ typedef struct {
 /* ---- lifetime ---------------------------------------------------------------------- */
 int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out);
 void obvi_ba_destroy(obvi_ba_handle* h);
+/* Back to the state obvi_ba_create left -- no cameras, blocks, factors or parameter priors, nothing shared (rank 0 of 1) and no exchange
+ * hook, no snapshot, no iteration records, profiling off -- with the device memory, streams and pinned pages kept: what a pool of handles
+ * calls before it hands one to its next user (the reference builds a fresh ceres::Problem per optimisation, offline_problem_runner.h:164-166;
+ * creating a handle costs ~25 ms). */
+int obvi_ba_reset(obvi_ba_handle* h);
 const char* obvi_ba_last_error(const obvi_ba_handle* h);
 const char* obvi_ba_version(void);
 

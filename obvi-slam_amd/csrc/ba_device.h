@@ -44,18 +44,25 @@ enum Scalar {
 
 // Deterministic mode (obvi_ba_options.deterministic).  The sums a solve's decisions are taken from -- costs, |g|^2, |x|^2, |delta|^2, the
 // model cost change -- are then not added to the scalar block with fp64 atomics (whose order changes from run to run): workgroup b of
-// a kernel stores its partial sum at scal[SC_COUNT + slot * kDetStride + b], and a one-workgroup-per-slot kernel behind it adds them up
-// in a fixed order (launch_det_reduce).  The scalar block of a deterministic handle is allocated with that tail.  Counters (failed
-// pivots, non-finite entries: small integers, exact in any order) and the gradient maximum stay atomic.
+// a kernel stores its partial sum at scal[SC_COUNT + slot * stride + b], and a one-workgroup-per-slot kernel behind it adds them up
+// in a fixed order (launch_det_reduce, which refuses a grid larger than the stride).  stride = BlocksDev.deterministic, the room the
+// handle gave the slots for the problem it holds (ensure_det_slots in obvi_ba.cpp: the largest grid, a power of two >= 4096).
+// What stays atomic in this mode, and why the result is still the same from run to run:
+//   - counters (failed pivots, non-finite entries: small integers) and the gradient maximum (integer max): exact in any order;
+//   - the fp64 adds into the reduced system's tiles, right-hand side and diagonal (k_schur_window, k_schur_blocks, k_reduced_diag, the
+//     small-factor gathers, the tile Cholesky's updates): every address has ONE writer per kernel -- the plan never cuts a strip, a block's
+//     pair list, a target tile's products or a tile row over workgroups in this mode (prepare_plan), the small factors go through per-factor
+//     scratch and a gather -- and all kernels run on one stream, so the adds reach an address in launch order.  The atomic is then only
+//     the instruction the non-deterministic build shares; tests/test_gpu_deterministic.py holds reruns to bit-identity.
 constexpr int kDetSlots = 7;
-constexpr int64_t kDetStride = 1 << 20;   // workgroups per kernel (a launcher refuses a larger grid in deterministic mode)
+constexpr int64_t kDetMaxStride = 1 << 24;   // 2^24 workgroups per kernel: beyond any problem that fits the device
 inline __host__ __device__ int det_slot_of(int sc) {
   return sc == SC_COST ? 0 : sc == SC_COST_CAND ? 1 : sc == SC_GSQ ? 2 : sc == SC_XSQ ? 3 : sc == SC_STEPSQ ? 4 : sc == SC_MODEL_CHANGE ? 5 : sc == SC_COST_FIXED ? 6 : -1;
 }
 inline __host__ __device__ int det_scalar_of(int slot) {
   return slot == 0 ? SC_COST : slot == 1 ? SC_COST_CAND : slot == 2 ? SC_GSQ : slot == 3 ? SC_XSQ : slot == 4 ? SC_STEPSQ : slot == 5 ? SC_MODEL_CHANGE : SC_COST_FIXED;
 }
-void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask /* bit sc: scalar sc was written by the kernel */);
+void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask /* bit sc: scalar sc was written by the kernel */, int stride);
 
 struct ReprojDev {          // observations sorted by (point, pose): CSC by point
   int64_t n;
@@ -93,7 +100,7 @@ struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   const int32_t* obj_vid;   // [O]
   const uint8_t* point_var; // [L]
   int32_t analytic_rotation; // the pose caches follow the analytic-Jacobian functor (make_pose_cache, ba_math.h)
-  int32_t deterministic;     // obvi_ba_options.deterministic: per-workgroup partial sums behind the scalar block instead of fp64 atomics (kDetStride)
+  int32_t deterministic;     // obvi_ba_options.deterministic: 0, or the stride of the per-workgroup partial sums behind the scalar block that replace the fp64 atomics
 };
 
 struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include <cstdlib>
+#include <stdexcept>
 #include "ba_device.h"
 
 namespace obvi {
@@ -56,9 +57,10 @@ __device__ __forceinline__ double wave_max(double v) {
   return wave_last_lane(v);
 }
 // a workgroup's total for scalar `sc`, one thread per workgroup: an fp64 atomic, or -- deterministic mode, ba_device.h -- the
-// workgroup's slot of the partial sums behind the scalar block (every workgroup of the grid must get here: the slots are not cleared)
+// workgroup's slot of the partial sums behind the scalar block (every workgroup of the grid must get here: the slots are not cleared).
+// `det` is BlocksDev.deterministic: 0, or the number of workgroups each slot has room for
 __device__ __forceinline__ void scal_add(double* scal, int det, int sc, double t) {
-  if (det) scal[SC_COUNT + (int64_t)det_slot_of(sc) * kDetStride + blockIdx.x] = t;
+  if (det) scal[SC_COUNT + (int64_t)det_slot_of(sc) * det + blockIdx.x] = t;
   else if (t != 0.0) atomic_add_f64(scal + sc, t);
 }
 // block-wide sum -> one atomic (or one partial-sum slot) per block
@@ -1558,11 +1560,11 @@ __global__ void __launch_bounds__(64) k_eval_small(SmallFactorsDev sf, const Dev
 
 // deterministic mode: the partial sums the workgroups of the previous kernel left behind the scalar block, added up in a fixed order (one
 // workgroup per scalar: strided per-thread sums, then a fixed tree) and added to the scalar -- plain read-modify-write, stream order
-__global__ void __launch_bounds__(kBlock) k_det_reduce(double* scal, int64_t nblocks, uint32_t scalar_mask) {
+__global__ void __launch_bounds__(kBlock) k_det_reduce(double* scal, int64_t nblocks, uint32_t scalar_mask, int stride) {
   const int slot = blockIdx.x, sc = det_scalar_of(slot);
   if (!((scalar_mask >> sc) & 1u)) return;
   __shared__ double sm[kBlock];
-  const double* part = scal + SC_COUNT + (int64_t)slot * kDetStride;
+  const double* part = scal + SC_COUNT + (int64_t)slot * stride;
   double acc = 0.0;
   for (int64_t i = threadIdx.x; i < nblocks; i += kBlock) acc += part[i];
   sm[threadIdx.x] = acc;
@@ -1656,8 +1658,9 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 }  // namespace
 
 // =========================================================================================
-void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask) {
-  if (nblocks > 0) hipLaunchKernelGGL(k_det_reduce, dim3(kDetSlots), dim3(kBlock), 0, s, scal, nblocks, scalar_mask);
+void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask, int stride) {
+  if (nblocks > stride) throw std::logic_error("deterministic mode: a grid larger than the partial-sum slots (ensure_det_slots() in obvi_ba.cpp undercounts)");
+  if (nblocks > 0) hipLaunchKernelGGL(k_det_reduce, dim3(kDetSlots), dim3(kBlock), 0, s, scal, nblocks, scalar_mask, stride);
 }
 #define OBVI_SC(x) (1u << (x))
 void launch_reproj_gather(hipStream_t s, int64_t n, const uint32_t* perm, const uint32_t* rq_src, const uint32_t* rp_point, const uint16_t* raw_cam,
@@ -1674,11 +1677,11 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
                        const uint32_t* long_points, int64_t n_long) {
   if (n_waves > 0) {
     hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, wave_obs, n_waves);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_waves, kBlock / 64), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_waves, kBlock / 64), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
   }
   if (n_long > 0) {
     hipLaunchKernelGGL(k_point_pass_long, dim3(grid_for(n_long, kBlock)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, long_points, n_long);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_long, kBlock), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_long, kBlock), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
   }
 }
 void launch_pose_pass(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const DevCam* cams, const PoseCache* pc, const double* points,
@@ -1705,7 +1708,7 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
   if (b.deterministic) {
     // no fp64 atomics on the diagonal blocks: every factor leaves its blocks in a scratch slot, the gathers add them per target in list order
     hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
-    launch_det_reduce(s, scal, nb_bbox + nb_priors + nb_rel, OBVI_SC(SC_COST));
+    launch_det_reduce(s, scal, nb_bbox + nb_priors + nb_rel, OBVI_SC(SC_COST), b.deterministic);
     if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
     if (sf.n_sp + sf.n_lt + sf.n_rl > 0) hipLaunchKernelGGL(k_small_gather, dim3(grid_for(b.O + b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
     return;
@@ -1724,7 +1727,7 @@ void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses,
                          int first_iter, double* scal) {
   if (b.P + b.O > 0) {
     hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(8 * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(8 * (b.P + b.O), kBlock), OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ));
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(8 * (b.P + b.O), kBlock), OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
   }
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
@@ -1755,7 +1758,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
 #define OBVI_BACKSUB(GG) hipLaunchKernelGGL(k_backsub_apply<GG>, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal)
   switch (G) { case 32: OBVI_BACKSUB(32); break; case 16: OBVI_BACKSUB(16); break; case 8: OBVI_BACKSUB(8); break; case 4: OBVI_BACKSUB(4); break; case 2: OBVI_BACKSUB(2); break; default: OBVI_BACKSUB(1); }
 #undef OBVI_BACKSUB
-  if (b.deterministic) launch_det_reduce(s, scal, grid, OBVI_SC(SC_STEPSQ) | OBVI_SC(SC_MODEL_CHANGE));
+  if (b.deterministic) launch_det_reduce(s, scal, grid, OBVI_SC(SC_STEPSQ) | OBVI_SC(SC_MODEL_CHANGE), b.deterministic);
 }
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams, const PoseCache* pc_cur,
                  const double* poses_cur, const double* points_cur, const double* objects_cur, const PoseCache* pc_cand, const double* poses_cand,
@@ -1771,7 +1774,7 @@ void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, con
   if (grid > 0) {
     if (b.P <= 256) hipLaunchKernelGGL(k_cost<true>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);   // (few poses: cost_reproj_block)
     else hipLaunchKernelGGL(k_cost<false>, dim3(grid), dim3(kBlock), 0, s, b, rq, sf, cams, pc, poses, points, objects, mode, n_pose_blocks, scal);
-    if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED));
+    if (b.deterministic) launch_det_reduce(s, scal, grid, mode == 0 ? OBVI_SC(SC_COST_CAND) : OBVI_SC(SC_COST_FIXED), b.deterministic);
   }
 }
 void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const uint32_t* rp_perm, const SmallFactorsDev& sf, const DevCam* cams,
@@ -1779,7 +1782,7 @@ void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, con
                      double* sqnorm, double* scal) {
   if (rp.n > 0) {
     hipLaunchKernelGGL(k_eval_reproj, dim3(grid_for(rp.n, kBlock)), dim3(kBlock), 0, s, rp, rp_perm, cams, pc, points, apply_loss, residuals, sqnorm, scal, b.deterministic);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(rp.n, kBlock), OBVI_SC(SC_COST));
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(rp.n, kBlock), OBVI_SC(SC_COST), b.deterministic);
   }
   const int64_t ns = sf.n_bb + sf.n_sp + sf.n_lt + sf.n_rl;
   if (ns > 0) {
@@ -1792,7 +1795,7 @@ void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, con
     double* q_lt = sqnorm ? q_sp + sf.n_sp : nullptr;
     double* q_rl = sqnorm ? q_lt + sf.n_lt : nullptr;
     hipLaunchKernelGGL(k_eval_small, dim3(grid_for(ns, 64)), dim3(64), 0, s, sf, cams, poses, objects, apply_loss, r_bb, q_bb, r_sp, q_sp, r_lt, q_lt, r_rl, q_rl, scal, b.deterministic);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(ns, 64), OBVI_SC(SC_COST));
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(ns, 64), OBVI_SC(SC_COST), b.deterministic);
   }
 }
 void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uint32_t* rp_perm, const DevCam* cams, const PoseCache* pc,

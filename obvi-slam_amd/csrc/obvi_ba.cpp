@@ -45,6 +45,7 @@ struct obvi_ba_handle {
   int device = 0;
   int reproj_variant = OBVI_REPROJECTION_AUTODIFF;   // obvi_ba_options.reprojection_variant
   bool deterministic = false;                        // obvi_ba_options.deterministic
+  int32_t det_stride = 0;                            // ... workgroups each partial-sum slot behind d_scal has room for (ensure_det_slots)
   bool fused_potrf = true;                           // k_update_potrf (updates of level l + potrf of level l + 1 in one grid); switched off for the rest of the handle's life
                                                      // after a potrf workgroup timed out waiting for its jobs (HIP does not promise dispatch order): two launches per level then
   int potrf_wait_timeouts = 0;
@@ -285,7 +286,7 @@ BlocksDev blocks_dev(const obvi_ba_handle* h) {
   b.obj_shared = (h->allreduce && !h->h_shared_ov.empty()) ? h->d_obj_shared.get() : nullptr; b.shared_owner = h->rank == 0 ? 1 : 0;
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
   b.analytic_rotation = h->reproj_variant == OBVI_REPROJECTION_ANALYTIC ? 1 : 0;
-  b.deterministic = h->deterministic ? 1 : 0;
+  b.deterministic = h->deterministic ? h->det_stride : 0;
   return b;
 }
 ReprojDev reproj_dev(const obvi_ba_handle* h) {
@@ -414,7 +415,29 @@ void bake_bbox(obvi_ba_handle* h) {
 // Reduced program [Ceres-doc Program::RemoveFixedBlocks], Schur pair lists, tile plan.
 // ---------------------------------------------------------------------------------------
 bool prepare_masks(obvi_ba_handle* h);
+void prepare_plan(obvi_ba_handle* h);
+// Deterministic mode: room behind the scalar block for one partial sum per workgroup of the largest grid that leaves any (ba_device.h;
+// the grids are those of the launchers at the end of ba_kernels.hip, launch_det_reduce refuses a larger one).  The block is reallocated
+// when the problem outgrows it -- only between API calls: every call clears the scalars before its first launch.
+void ensure_det_slots(obvi_ba_handle* h) {
+  if (!h->deterministic) return;
+  const int64_t small = (h->n_bb + 3) / 4 + (h->n_sp + h->n_lt + 63) / 64 + (h->n_rl + 3) / 4, ns = h->n_bb + h->n_sp + h->n_lt + h->n_rl;
+  int64_t need = std::max<int64_t>({(h->n_point_waves + 3) / 4, (h->n_long_points + 255) / 256, small, (8 * (h->P + h->O) + 255) / 256, 2048 + (h->P + h->O + 255) / 256,
+                                    h->P + (ns + 255) / 256, (h->n_rp + 255) / 256, (ns + 63) / 64});
+  if (need > kDetMaxStride) throw HipError{hipErrorInvalidValue, "deterministic mode: the problem needs more partial-sum slots than kDetMaxStride", __FILE__, __LINE__};
+  if (need <= h->det_stride) return;
+  const char* min_env = std::getenv("OBVI_DET_MIN_STRIDE");
+  int64_t stride = std::max(1, min_env ? std::atoi(min_env) : 4096);   // (the tests start small to see the block grow)
+  while (stride < need) stride *= 2;
+  sync(h);
+  h->d_scal.resize(SC_COUNT + (size_t)kDetSlots * (size_t)stride);
+  h->det_stride = (int32_t)stride;
+}
 void prepare(obvi_ba_handle* h) {
+  prepare_plan(h);
+  ensure_det_slots(h);
+}
+void prepare_plan(obvi_ba_handle* h) {
   if (!h->dirty && !h->mask_dirty) return;
   ApiTimer api_timer_(h->dirty ? "  prepare (symbolic phase)" : "  prepare (masks only)");
   if (!h->dirty && h->mask_dirty && prepare_masks(h)) return;
@@ -1566,7 +1589,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
     std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
     h->staging.cap = kStagingBytes;
-    h->d_scal.resize(SC_COUNT + (h->deterministic ? (size_t)kDetSlots * (size_t)kDetStride : 0));   // deterministic mode: per-workgroup partial sums behind the block (ba_device.h)
+    h->d_scal.resize(SC_COUNT);   // deterministic mode: grown by ensure_det_slots() to hold per-workgroup partial sums behind the block (ba_device.h)
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
@@ -1596,6 +1619,39 @@ void obvi_ba_destroy(obvi_ba_handle* h) {
   hipStream_t s = h->stream;
   delete h;
   if (s) (void)hipStreamDestroy(s);
+}
+
+int obvi_ba_reset(obvi_ba_handle* h) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  // the state obvi_ba_create leaves, with the device allocations, streams, events and pinned pages kept: no cameras, blocks or factors, no
+  // parameter priors, nothing shared and no exchange hook, no snapshot, no iteration records, profiling off and its sums at zero
+  int rc = obvi_ba_set_parameter_priors(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (!rc) rc = obvi_ba_set_reproj(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 1.0);
+  if (!rc) rc = obvi_ba_set_bbox(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 1e6);
+  if (!rc) rc = obvi_ba_set_shape_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
+  if (!rc) rc = obvi_ba_set_ltm_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
+  if (!rc) rc = obvi_ba_set_relpose(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0);
+  if (!rc) rc = obvi_ba_set_poses(h, 0, nullptr, nullptr);
+  if (!rc) rc = obvi_ba_set_points(h, 0, nullptr, nullptr);
+  if (!rc) rc = obvi_ba_set_objects(h, 0, nullptr, nullptr);
+  if (!rc) rc = obvi_ba_set_cameras(h, 0, nullptr, nullptr);
+  if (rc) return rc;
+  OBVI_API_BEGIN
+  h->h_is_shared.clear(); h->h_shared_ov.clear(); h->rank = 0; h->world = 1; h->tail_t0 = -1; h->tail_level0 = -1;
+  h->allreduce = nullptr; h->allreduce_user = nullptr;
+  h->have_snapshot = false; h->use_extra = false; h->pc_valid = false; h->tiles_cleared = false;
+  h->iterations.clear();
+  h->profiling = 0; h->ck_used = 0;
+  for (auto& v : h->phase_ms) v = 0.0;
+  for (auto& v : h->phase_launches) v = 0;
+  for (auto& v : h->ck_ms) v = 0.0;
+  for (auto& v : h->ck_launches) v = 0;
+  h->fused_potrf = true; h->potrf_wait_timeouts = 0;
+  if (const char* env = std::getenv("OBVI_FUSED_POTRF")) h->fused_potrf = std::atoi(env) != 0;
+  h->dirty = true; h->mask_dirty = false;
+  h->err.clear();
+  return OBVI_OK;
+  OBVI_API_END(h)
 }
 
 int obvi_ba_set_cameras(obvi_ba_handle* h, int32_t n, const double* K, const double* ext) {

@@ -91,8 +91,7 @@ inline obvi_ba_options makeHandleOptions(int device_id) {
 
 // Device handles outlive the Problem that used them: creating one allocates its streams, events, pinned pages and worker pool (about
 // 25 ms, 10 ms to destroy) and a session makes a new Problem at every global-BA frame (runPgoPlusEllipsoids).  A handle a Problem gives
-// back is handed to the next Problem with the same device and options; every set_* call replaces what the previous problem left, the
-// parameter priors are cleared here.  drain() destroys what is parked (the drivers call it before they exit).
+// back is reset (obvi_ba_reset) and handed to the next Problem with the same device and options.  drain() destroys what is parked (the drivers call it before they exit).
 class HandlePool {
  public:
   static HandlePool& instance() { static HandlePool* p = new HandlePool; return *p; }   // never destroyed: no HIP calls from static destructors
@@ -109,13 +108,8 @@ class HandlePool {
   }
   void release(const obvi_ba_options& opt, obvi_ba_handle* h) {
     if (h == nullptr) return;
-    // an empty problem: the next user may set fewer factor families than this one did
-    int rc = obvi_ba_set_parameter_priors(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (!rc) rc = obvi_ba_set_reproj(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 1.0);
-    if (!rc) rc = obvi_ba_set_bbox(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0, 0.0);
-    if (!rc) rc = obvi_ba_set_shape_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
-    if (!rc) rc = obvi_ba_set_ltm_priors(h, 0, nullptr, nullptr, nullptr, 1.0);
-    if (!rc) rc = obvi_ba_set_relpose(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0);
+    // as obvi_ba_create left it: the next user may set fewer factor families than this one did, share nothing, install no hook
+    const int rc = obvi_ba_reset(h);
     if (rc != OBVI_OK) { obvi_ba_destroy(h); return; }
     std::lock_guard<std::mutex> lock(mu_);
     if (parked_.size() >= kMaxParked) { obvi_ba_destroy(h); return; }

@@ -315,6 +315,12 @@ class BundleAdjuster:
         return out
 
     # ---- state ---------------------------------------------------------------------------
+    def reset(self):
+        """obvi_ba_reset: the handle as create left it (no problem, no hook, nothing shared), allocations kept."""
+        self._check(self._fn("ba_reset")(self._h), "reset")
+        self._n = {t: 0 for t in FACTOR_TYPES}
+        self._keep.clear()
+
     def snapshot(self):
         self._check(self._fn("ba_snapshot")(self._h), "snapshot")
 

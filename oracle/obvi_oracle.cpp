@@ -726,6 +726,14 @@ int oracle_ba_create(const obvi_ba_options* opt, oracle_handle** out) {
   return OBVI_OK;
 }
 void oracle_ba_destroy(oracle_handle* h) { delete h; }
+// the counterpart of obvi_ba_reset (include/obvi_ba.h): the problem a fresh handle holds, same reprojection functor
+int oracle_ba_reset(oracle_handle* h) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  const int variant = h->pb.reproj_variant;
+  h->pb = OracleProblem();
+  h->pb.reproj_variant = variant;
+  return OBVI_OK;
+}
 
 int oracle_ba_set_cameras(oracle_handle* h, int32_t n, const double* K, const double* ext) {
   if (!h || n < 0 || (n > 0 && (!K || !ext))) return OBVI_ERR_INVALID_ARGUMENT;

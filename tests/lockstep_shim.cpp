@@ -17,6 +17,7 @@ struct oracle_handle;
 extern "C" {
 int oracle_ba_create(const obvi_ba_options*, oracle_handle**);
 void oracle_ba_destroy(oracle_handle*);
+int oracle_ba_reset(oracle_handle*);
 int oracle_ba_set_cameras(oracle_handle*, int32_t, const double*, const double*);
 int oracle_ba_set_poses(oracle_handle*, int64_t, const double*, const uint8_t*);
 int oracle_ba_set_points(oracle_handle*, int64_t, const double*, const uint8_t*);
@@ -55,7 +56,7 @@ namespace {
 struct Arbiter {
   void* lib = nullptr;
   template <class F> void sym(F& f, const char* name) { f = lib ? reinterpret_cast<F>(dlsym(lib, name)) : nullptr; if (lib && !f) { std::fprintf(stderr, "lockstep: arbiter lacks %s\n", name); std::abort(); } }
-  decltype(&oracle_ba_create) create; decltype(&oracle_ba_destroy) destroy; decltype(&oracle_ba_set_cameras) set_cameras; decltype(&oracle_ba_set_poses) set_poses;
+  decltype(&oracle_ba_create) create; decltype(&oracle_ba_destroy) destroy; decltype(&oracle_ba_reset) reset; decltype(&oracle_ba_set_cameras) set_cameras; decltype(&oracle_ba_set_poses) set_poses;
   decltype(&oracle_ba_set_points) set_points; decltype(&oracle_ba_set_objects) set_objects; decltype(&oracle_ba_set_const_flags) set_const_flags;
   decltype(&oracle_ba_set_reproj) set_reproj; decltype(&oracle_ba_set_bbox) set_bbox; decltype(&oracle_ba_set_shape_priors) set_shape_priors;
   decltype(&oracle_ba_set_ltm_priors) set_ltm_priors; decltype(&oracle_ba_set_relpose) set_relpose; decltype(&oracle_ba_set_active_mask) set_active_mask;
@@ -68,7 +69,7 @@ struct Arbiter {
     if (!path || !*path) return;
     lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { std::fprintf(stderr, "lockstep: cannot load the arbiter %s: %s\n", path, dlerror()); std::abort(); }
-    sym(create, "oracle_ba_create"); sym(destroy, "oracle_ba_destroy"); sym(set_cameras, "oracle_ba_set_cameras"); sym(set_poses, "oracle_ba_set_poses"); sym(set_points, "oracle_ba_set_points");
+    sym(create, "oracle_ba_create"); sym(destroy, "oracle_ba_destroy"); sym(reset, "oracle_ba_reset"); sym(set_cameras, "oracle_ba_set_cameras"); sym(set_poses, "oracle_ba_set_poses"); sym(set_points, "oracle_ba_set_points");
     sym(set_objects, "oracle_ba_set_objects"); sym(set_const_flags, "oracle_ba_set_const_flags"); sym(set_reproj, "oracle_ba_set_reproj"); sym(set_bbox, "oracle_ba_set_bbox");
     sym(set_shape_priors, "oracle_ba_set_shape_priors"); sym(set_ltm_priors, "oracle_ba_set_ltm_priors"); sym(set_relpose, "oracle_ba_set_relpose"); sym(set_active_mask, "oracle_ba_set_active_mask");
     sym(set_parameter_priors, "oracle_ba_set_parameter_priors"); sym(solve, "oracle_ba_solve"); sym(get_iterations, "oracle_ba_get_iterations"); sym(snapshot, "oracle_ba_snapshot");
@@ -142,6 +143,7 @@ int lock_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* k,
 }
 int64_t lock_ba_num_residuals(const obvi_ba_handle* h) { return obvi_ba_num_residuals(L_(h)->hip); }
 int64_t lock_ba_num_factors(const obvi_ba_handle* h, int32_t t) { return obvi_ba_num_factors(L_(h)->hip, t); }
+int lock_ba_reset(obvi_ba_handle* h) { ARB(reset(L_(h)->arb)); return both(obvi_ba_reset(L_(h)->hip), oracle_ba_reset(L_(h)->ora), "reset"); }
 int lock_ba_snapshot(obvi_ba_handle* h) { ARB(snapshot(L_(h)->arb)); return both(obvi_ba_snapshot(L_(h)->hip), oracle_ba_snapshot(L_(h)->ora), "snapshot"); }
 int lock_ba_restore(obvi_ba_handle* h) { ARB(restore(L_(h)->arb)); return both(obvi_ba_restore(L_(h)->hip), oracle_ba_restore(L_(h)->ora), "restore"); }
 int lock_ba_get_poses(obvi_ba_handle* h, double* out) { return obvi_ba_get_poses(L_(h)->hip, out); }

@@ -7,6 +7,7 @@
 #define OBVI_TESTS_LOCKSTEP_SHIM_H_
 #define obvi_ba_create lock_ba_create
 #define obvi_ba_destroy lock_ba_destroy
+#define obvi_ba_reset lock_ba_reset
 #define obvi_ba_last_error lock_ba_last_error
 #define obvi_ba_set_cameras lock_ba_set_cameras
 #define obvi_ba_set_poses lock_ba_set_poses

@@ -6,6 +6,7 @@
 #define OBVI_TESTS_ORACLE_ABI_SHIM_H_
 #define obvi_ba_create oracle_ba_create
 #define obvi_ba_destroy oracle_ba_destroy
+#define obvi_ba_reset oracle_ba_reset
 #define obvi_ba_last_error oracle_ba_last_error
 #define obvi_ba_set_cameras oracle_ba_set_cameras
 #define obvi_ba_set_poses oracle_ba_set_poses

@@ -122,3 +122,41 @@ def test_deterministic_sessions_are_byte_identical_and_equal_the_oracle_session(
     assert np.median(rel) <= 1e-4 and max(rel) <= 5e-2
     assert np.abs(ph[:, :3] - po[:, :3]).max() <= 2e-2 and np.abs(ph[:, 3:] - po[:, 3:]).max() <= 2e-3
     assert set(hip["objects"]) == set(ora["objects"]) and set(hip["long_term_map"]) == set(ora["long_term_map"])
+
+
+def test_a_reset_handle_is_a_fresh_handle(monkeypatch):
+    """obvi_ba_reset (what the host mirror's HandlePool calls before it hands a handle to the next Problem): after a problem with every
+    factor family, shared objects, an exchange hook, a snapshot and profiling, the handle solves the NEXT problem -- a smaller one with fewer
+    families, then a larger one that outgrows the partial-sum slots of deterministic mode (OBVI_DET_MIN_STRIDE=16 makes them start
+    small) -- bit for bit as a handle that never saw anything else."""
+    monkeypatch.setenv("OBVI_DET_MIN_STRIDE", "16")
+    first, small, large = all_families(60, 900, 5, 7), synth.make_problem(P=24, L=300, O=0, seed=8), all_families(200, 6000, 9, 9)
+    prm = helpers.ba_params(max_it=5, ftol=1e-9)
+    used = helpers.product_ba(deterministic=True)
+    synth.upload(used, first)
+    calls = []
+    used.set_shared_objects(np.ones(len(first["objects"]), np.uint8), 0, 1)
+    used.set_allreduce(lambda buf, count, op, stream: calls.append(count) or 0)
+    used.set_profiling(2)
+    used.snapshot()
+    used.solve(prm)
+    assert calls                                   # the hook ran: there was something to forget
+    for prob in (small, large):
+        used.reset()
+        n_calls = len(calls)
+        empty = used.evaluate(True)
+        assert empty[0] == 0.0 and len(empty[1]) == 0   # an empty problem, as after create
+        with pytest.raises(Exception):
+            used.restore()                         # ... without a snapshot
+        synth.upload(used, prob)
+        c0 = used.evaluate(True)
+        s = used.solve(prm)
+        got = dict(eval_cost=c0[0], summary=(s.num_iterations, s.termination_type, s.initial_cost, s.final_cost, s.fixed_cost),
+                   its=[(i.iteration, i.step_is_successful, i.cost, i.gradient_max_norm, i.step_norm, i.trust_region_radius) for i in used.iterations()],
+                   poses=used.get_poses(), points=used.get_points(), objects=used.get_objects())
+        fresh = run(prob, prm, deterministic=True)
+        assert len(calls) == n_calls               # the old hook is gone
+        assert got["eval_cost"] == fresh["eval_cost"] and got["summary"] == fresh["summary"]
+        assert got["its"] == [(i[0], i[1], i[2], i[4], i[6], i[8]) for i in fresh["its"]]
+        for k in ("poses", "points", "objects"):
+            assert np.array_equal(got[k], fresh[k]), k
