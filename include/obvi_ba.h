@@ -255,6 +255,9 @@ int obvi_ba_restore(obvi_ba_handle* h);
 int obvi_ba_get_poses(obvi_ba_handle* h, double* out /*[n][6]*/);
 int obvi_ba_get_points(obvi_ba_handle* h, double* out /*[n][3]*/);
 int obvi_ba_get_objects(obvi_ba_handle* h, double* out /*[n][7]*/);
+/* all three at once (a null pointer skips one): what the reference reads in place after Solve() -- Ceres has updated the pose graph's
+ * parameter blocks (object_pose_graph_optimizer.h:664-667) -- with one wait for the device instead of three */
+int obvi_ba_get_state(obvi_ba_handle* h, double* poses /*[n][6]*/, double* points /*[n][3]*/, double* objects /*[n][7]*/);
 /* overwrite values only (feature re-attachment after PGO,
  * pose_graph_plus_objects_optimizer.h:238-283) */
 int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);

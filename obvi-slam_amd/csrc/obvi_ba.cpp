@@ -2388,6 +2388,24 @@ int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return h ? get_blocks(h,
 int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_point, h->L, 3, out) : OBVI_ERR_INVALID_ARGUMENT; }
 int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_obj, h->O, 7, out) : OBVI_ERR_INVALID_ARGUMENT; }
 
+int obvi_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* objects) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  // the three copies land in the handle's pinned arena (a copy into pageable memory blocks, one after the other), ONE wait, then out
+  struct Part { double* out; const DevBuf<double>* d; size_t n; void* pinned; } parts[3] = {
+      {poses, &h->d_pose, (size_t)h->P * 6, nullptr}, {points, &h->d_point, (size_t)h->L * 3, nullptr}, {objects, &h->d_obj, (size_t)h->O * 7, nullptr}};
+  for (Part& p : parts) {
+    if (!p.out || !p.n) continue;
+    p.pinned = h->staging.take(p.n * sizeof(double));
+    p.d->download(p.pinned ? static_cast<double*>(p.pinned) : p.out, p.n, h->stream);
+  }
+  sync(h);
+  for (Part& p : parts) if (p.pinned) std::memcpy(p.out, p.pinned, p.n * sizeof(double));
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
 int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared, int32_t rank, int32_t world) {
   if (!h || world < 1 || rank < 0 || rank >= world) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN

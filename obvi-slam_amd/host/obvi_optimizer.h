@@ -146,6 +146,10 @@ class Problem {
     if (!h_ && !dry_run_) { opt_ = makeHandleOptions(device_id_); h_ = HandlePool::instance().acquire(opt_); }
     return h_;
   }
+  // Hands the device handle to the pool until the next handle() call: a stage that runs on a Problem of its own in between
+  // (runPgoPlusEllipsoids at a global-BA frame) then works on this handle -- its streams, pinned pages and grown allocations -- instead
+  // of creating a second one.  Whatever was on the device is gone; the next build uploads everything anyway.
+  void parkHandle() { if (h_) { HandlePool::instance().release(opt_, h_); h_ = nullptr; } }
  private:
   int device_id_; bool dry_run_;
   obvi_ba_handle* h_ = nullptr;
@@ -864,7 +868,7 @@ class ObjectPoseGraphOptimizer {
     // Ceres mutates the parameter blocks in place; copy the device state back into the pose graph's blocks -- unless the solve
     // failed: Ceres leaves the user's blocks as they were when the solution is not usable (the library hands the entry state back)
     if (summary.IsSolutionUsable()) {
-      if (obvi_ba_get_poses(h, poses.data()) || obvi_ba_get_points(h, points.data()) || obvi_ba_get_objects(h, objects.data())) return false;
+      if (obvi_ba_get_state(h, poses.data(), points.data(), objects.data())) return false;
       for (size_t i = 0; i < fp.pose_ptrs.size(); ++i) std::copy_n(&poses[6 * i], 6, fp.pose_ptrs[i]);
       for (size_t i = 0; i < fp.point_ptrs.size(); ++i) std::copy_n(&points[3 * i], 3, fp.point_ptrs[i]);
       for (size_t i = 0; i < fp.object_ptrs.size(); ++i) std::copy_n(&objects[7 * i], 7, fp.object_ptrs[i]);

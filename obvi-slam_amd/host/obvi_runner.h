@@ -296,6 +296,7 @@ class OfflineProblemRunner {
         }
         record("pre_pgo_track", tracking.min_frame_id_, next_frame_id, problem, 0);
         const auto t_pgo0 = std::chrono::steady_clock::now();
+        problem.parkHandle();   // the stage builds a Problem of its own (:pose_graph_plus_objects_optimizer.h:86): let it have this one's device handle
         if (!pose_graph_optimizer::runPgoPlusEllipsoids(next_frame_id, scope, residual_params_, pgo_solver_params_, next_frame_id == max_frame_id, opt_logger, pose_graph,
                                                         device_id_, attempt_num))
           std::cerr << "PGO+objs failed at frame " << next_frame_id << std::endl;

@@ -319,6 +319,7 @@ class BundleAdjuster:
         """obvi_ba_reset: the handle as create left it (no problem, no hook, nothing shared), allocations kept."""
         self._check(self._fn("ba_reset")(self._h), "reset")
         self._n = {t: 0 for t in FACTOR_TYPES}
+        self.P = self.L = self.O = 0
         self._keep.clear()
 
     def snapshot(self):
@@ -340,6 +341,12 @@ class BundleAdjuster:
 
     def get_objects(self):
         return self._get("ba_get_objects", self.O, 7)
+
+    def get_state(self):
+        """(poses, points, objects) with one wait for the device (obvi_ba_get_state)."""
+        po, pt, ob = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, 7))
+        self._check(self._fn("ba_get_state")(self._h, _ptr(po, C.c_double), _ptr(pt, C.c_double), _ptr(ob, C.c_double)), "get_state")
+        return po, pt, ob
 
     def update_points(self, xyz):
         x = _f64(xyz, (-1, 3))

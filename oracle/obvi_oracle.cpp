@@ -1328,6 +1328,12 @@ int oracle_ba_restore(oracle_handle* h) {
 int oracle_ba_get_poses(oracle_handle* h, double* out) { std::memcpy(out, h->pb.poses.data(), sizeof(double) * h->pb.poses.size()); return OBVI_OK; }
 int oracle_ba_get_points(oracle_handle* h, double* out) { std::memcpy(out, h->pb.points.data(), sizeof(double) * h->pb.points.size()); return OBVI_OK; }
 int oracle_ba_get_objects(oracle_handle* h, double* out) { std::memcpy(out, h->pb.objects.data(), sizeof(double) * h->pb.objects.size()); return OBVI_OK; }
+int oracle_ba_get_state(oracle_handle* h, double* poses, double* points, double* objects) {
+  if (poses) oracle_ba_get_poses(h, poses);
+  if (points) oracle_ba_get_points(h, points);
+  if (objects) oracle_ba_get_objects(h, objects);
+  return OBVI_OK;
+}
 int oracle_ba_update_points(oracle_handle* h, int64_t n, const double* xyz) {
   if (n != h->pb.L) return OBVI_ERR_INVALID_ARGUMENT;
   h->pb.points.assign(xyz, xyz + 3 * n); return OBVI_OK;

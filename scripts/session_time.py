@@ -9,8 +9,8 @@ import synth, scene_io
 P, L, O = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (300, 30000, 20)
 prob = synth.make_problem(P=P, L=L, O=O, seed=4, min_obj_obs=10, bbox_noise=5.0, object_classes=("bench",))
 d = tempfile.mkdtemp()
-scene, out, csv = os.path.join(d, "scene.txt"), os.path.join(d, "out.json"), os.path.join(d, "opt.csv")
-scene_io.write_scene(prob, scene)
+scene, out, csv = os.path.join(d, "scene.bin"), os.path.join(d, "out.json"), os.path.join(d, "opt.csv")
+(scene_io.write_scene if os.environ.get("OBVI_SCENE_TEXT") else scene_io.write_scene_binary)(prob, scene)   # the binary form loads in ~5 ms, the text form in ~95
 t = time.time()
 subprocess.check_call([os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba"), scene, out, "--window", "50", "--gba-frequency", "100", "--csv", csv])
 wall = time.time() - t

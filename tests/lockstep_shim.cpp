@@ -149,6 +149,7 @@ int lock_ba_restore(obvi_ba_handle* h) { ARB(restore(L_(h)->arb)); return both(o
 int lock_ba_get_poses(obvi_ba_handle* h, double* out) { return obvi_ba_get_poses(L_(h)->hip, out); }
 int lock_ba_get_points(obvi_ba_handle* h, double* out) { return obvi_ba_get_points(L_(h)->hip, out); }
 int lock_ba_get_objects(obvi_ba_handle* h, double* out) { return obvi_ba_get_objects(L_(h)->hip, out); }
+int lock_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* objects) { return obvi_ba_get_state(L_(h)->hip, poses, points, objects); }
 int lock_ba_update_points(obvi_ba_handle* h, int64_t n, const double* x) { ARB(update_points(L_(h)->arb, n, x)); return both(obvi_ba_update_points(L_(h)->hip, n, x), oracle_ba_update_points(L_(h)->ora, n, x), "update_points"); }
 int lock_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap) { return obvi_ba_get_iterations(L_(h)->hip, out, cap); }
 

@@ -31,6 +31,7 @@
 #define obvi_ba_get_poses oracle_ba_get_poses
 #define obvi_ba_get_points oracle_ba_get_points
 #define obvi_ba_get_objects oracle_ba_get_objects
+#define obvi_ba_get_state oracle_ba_get_state
 #define obvi_ba_update_points oracle_ba_update_points
 #define obvi_ba_num_residuals oracle_ba_num_residuals
 #define obvi_ba_num_factors oracle_ba_num_factors

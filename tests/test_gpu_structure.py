@@ -371,3 +371,21 @@ def test_non_finite_input_is_a_failed_solve_and_the_handle_survives():
     assert sg.num_iterations == so.num_iterations and np.isfinite(sg.final_cost)
     assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost
     assert np.abs(g.get_poses() - o.get_poses()).max() < 1e-8
+
+
+def test_get_state_reads_what_the_three_getters_read():
+    """obvi_ba_get_state (one wait, copies through the handle's pinned arena) against obvi_ba_get_poses / _points / _objects, after an
+    upload and after a solve; on a problem whose points do not fit the arena any more (16 MB) the copies go straight out."""
+    for P, L in ((40, 600), (60, 800000)):
+        prob = synth.make_problem(P=P, L=L, O=4 if L < 10000 else 0, seed=3, bbox_noise=5.0, object_classes=("bench",), min_obj_obs=5)
+        g = helpers.product_ba()
+        synth.upload(g, prob)
+        for solved in (False, True):
+            if solved:
+                if L > 10000:
+                    break
+                g.solve(helpers.ba_params(max_it=3))
+            po, pt, ob = g.get_state()
+            assert np.array_equal(po, g.get_poses()) and np.array_equal(pt, g.get_points()) and np.array_equal(ob, g.get_objects())
+            if not solved:
+                assert np.array_equal(po, prob["poses"]) and np.array_equal(pt, prob["points"])
