@@ -133,6 +133,9 @@ struct obvi_ba_handle {
   DevBuf<uint8_t> d_sel_mask;
   DevBuf<uint32_t> d_rp_inv;
   SelectScratch sel_scratch;
+  uint64_t api_calls = 0;     // entry points run on this handle so far (OBVI_API_BEGIN)
+  uint64_t eval_sq_call = 0;  // ... when d_eval_sq was last filled with the un-robustified block norms of the CURRENT state: a selection that is the very next call reuses them
+  bool rp_inv_on_device = false;   // d_rp_inv holds h_rp_inv of the current reprojection factors
   double* h_scal = nullptr;  // pinned; the device writes the scalar block of an LM step straight into it and, behind a system-scope fence, the sequence number [SC_COUNT]
                              // (k_zero_tiles): the host polls the number instead of sleeping in hipStreamSynchronize (whose wake-up costs tens of microseconds)
   double scal_seq = 0.0;
@@ -203,7 +206,7 @@ constexpr size_t kStagingBytes = (size_t)16 << 20;   // a sliding window's uploa
 // every API call runs with its handle's staging arena as the destination of DevBuf::upload / h2d_async (host_util.h)
 struct StagingScope {
   StagingArena* prev;
-  explicit StagingScope(const obvi_ba_handle* h) : prev(tl_staging) { tl_staging = h ? const_cast<StagingArena*>(&h->staging) : nullptr; }
+  explicit StagingScope(const obvi_ba_handle* h) : prev(tl_staging) { tl_staging = h ? const_cast<StagingArena*>(&h->staging) : nullptr; if (h) ++const_cast<obvi_ba_handle*>(h)->api_calls; }
   ~StagingScope() { tl_staging = prev; }
 };
 // OBVI_API_TIMING=1: wall time per entry point (and of the symbolic phase inside obvi_ba_solve), summed over the process, on stderr at exit
@@ -1570,8 +1573,18 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   *out = nullptr;
   if (options && options->object_block_size != 0 && options->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
   if (options && options->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && options->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
+  // OBVI_DEBUG_CREATE: where the time of a create goes, on stderr (the first one of a process also starts the HIP runtime)
+  const bool create_times = std::getenv("OBVI_DEBUG_CREATE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!create_times) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "create: %-44s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return OBVI_ERR_NO_DEVICE;
+  lap("hipGetDeviceCount (runtime start)");
   const int dev = options ? options->device_id : 0;
   if (dev < 0 || dev >= count) return OBVI_ERR_NO_DEVICE;
   obvi_ba_handle* h = new (std::nothrow) obvi_ba_handle();
@@ -1582,18 +1595,23 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   if (const char* env = std::getenv("OBVI_DETERMINISTIC")) { if (std::atoi(env) != 0) h->deterministic = true; }   // every handle of the process (a session driven through a host that does not set the option)
   try {
     OBVI_HIP(hipSetDevice(dev));
+    lap("hipSetDevice");
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    lap("first stream");
     // coherent (fine-grained): the host polls this page while the step is still running (wait_scalars); with a non-coherent mapping it
     // would see the device's write only at the end of the stream
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * (SC_COUNT + 1), hipHostMallocCoherent));
     std::memset(h->h_scal, 0, sizeof(double) * (SC_COUNT + 1));
+    lap("pinned scalar page");
     OBVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->staging.base), kStagingBytes, hipHostMallocDefault));
     h->staging.cap = kStagingBytes;
+    lap("pinned staging arena");
     h->d_scal.resize(SC_COUNT);   // deterministic mode: grown by ensure_det_slots() to hold per-workgroup partial sums behind the block (ba_device.h)
     OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) OBVI_HIP(hipEventCreate(&e));
     for (auto& e : h->ev_end) OBVI_HIP(hipEventCreate(&e));
     OBVI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); OBVI_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));   // ordering only: no timestamps
+    lap("scalar block, second stream, events");
   } catch (const HipError&) {
     delete h;
     return OBVI_ERR_HIP;
@@ -1742,7 +1760,7 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
       if (!std::is_sorted(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before)) std::sort(perm.begin() + ptr[l], perm.begin() + ptr[l + 1], before);
   });
   sub("    set_reproj: sort by point");
-  h->n_rp = n; h->rp_huber = huber;
+  h->n_rp = n; h->rp_huber = huber; h->rp_inv_on_device = false;
   h->max_rp_pose = max_index(pose_idx, n); h->max_rp_point = max_index(point_idx, n); h->max_rp_cam = cam_idx ? max_index(cam_idx, n) : (n > 0 ? 0 : -1);
   h->h_rp_pose.resize(n); h->h_rp_point.resize(n); h->h_rp_active.assign(n, 1); h->h_rp_inv.resize(n);
   hipStream_t s = h->stream;
@@ -1950,6 +1968,7 @@ int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   launch_evaluate(s, blocks_dev(h), reproj_dev(h), h->d_rp_perm.get(), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(),
                   h->d_point.get(), h->d_obj.get(), apply_loss, h->d_eval_res.get(), h->d_eval_sq.get(), h->d_scal.get());
+  if (!cost && !residuals && !block_sqnorm) return OBVI_OK;   // nothing to hand back (obvi_ba_select_outliers: its kernels follow on the same stream)
   double c = 0.0;
   OBVI_HIP(hipMemcpyAsync(&c, h->d_scal.get() + SC_COST, sizeof(double), hipMemcpyDeviceToHost, s));
   if (residuals) h->d_eval_res.download(residuals, (size_t)nres, s);
@@ -2327,29 +2346,80 @@ int obvi_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out,
   return n;
 }
 
+namespace {
+// the selection over `n` block norms on the device (select_kernels.hip), the mask into the caller's memory: ONE wait for the device
+// unless the threshold route has to hand over to the sort (more than 4096 distinct values sharing their top 24 bits)
+void run_selection(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t* act, const uint32_t* inv, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
+  h->d_sel_mask.resize((size_t)n + 1);
+  static const bool sort_route = std::getenv("OBVI_SELECT_SORT") && std::atoi(std::getenv("OBVI_SELECT_SORT")) != 0;   // route (b) always (its check)
+  int n_out = 0;
+  bool done = false;
+  if (!sort_route) {
+    const int* result_dev = nullptr;
+    OBVI_HIP(select_by_threshold(h->stream, n, sq, act, inv, fraction, h->d_sel_mask.get(), &h->sel_scratch, &result_dev));
+    void* pinned_mask = n ? h->staging.take((size_t)n) : nullptr;
+    int* pinned_result = static_cast<int*>(h->staging.take(2 * sizeof(int)));
+    int pageable_result[2] = {0, 0};
+    if (n) OBVI_HIP(hipMemcpyAsync(pinned_mask ? pinned_mask : mask_out, h->d_sel_mask.get(), (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    OBVI_HIP(hipMemcpyAsync(pinned_result ? pinned_result : pageable_result, result_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    const int* result = pinned_result ? pinned_result : pageable_result;
+    if (result[1] == 0) {
+      if (pinned_mask) std::memcpy(mask_out, pinned_mask, (size_t)n);
+      n_out = result[0];
+      done = true;
+    }
+  }
+  if (!done) {
+    OBVI_HIP(select_outliers_sorted(h->stream, n, sq, act, inv, fraction, h->d_sel_mask.get(), &n_out, &h->sel_scratch));
+    h->d_sel_mask.download(mask_out, (size_t)n, h->stream);
+    sync(h);
+  }
+  if (num_excluded) *num_excluded = n_out;
+}
+}  // namespace
+
 int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
-  // un-robustified per-block squared norms at the current estimate (object_pose_graph_optimizer.h:682-693), kept on the device
-  const int rc = obvi_ba_evaluate(h, 0, nullptr, nullptr, nullptr);
-  if (rc != OBVI_OK) return rc;
+  // un-robustified per-block squared norms at the current estimate (object_pose_graph_optimizer.h:682-693), kept on the device; the
+  // runner selects for one factor type after the other (offline_problem_runner.h:769-800): the second call finds them in place
+  const uint64_t this_call = h->api_calls;
+  if (h->eval_sq_call == 0 || h->eval_sq_call + 1 != this_call) {
+    const int rc = obvi_ba_evaluate(h, 0, nullptr, nullptr, nullptr);
+    if (rc != OBVI_OK) return rc;
+  }
   int64_t off = 0, n = 0;
   const uint8_t* act = nullptr;
   const uint32_t* inv = nullptr;
   switch (type) {
-    case OBVI_FACTOR_REPROJECTION: off = 0; n = h->n_rp; act = h->d_rp_active.get(); h->d_rp_inv.upload(h->h_rp_inv, h->stream); inv = h->d_rp_inv.get(); break;
+    case OBVI_FACTOR_REPROJECTION:
+      off = 0; n = h->n_rp; act = h->d_rp_active.get();
+      if (!h->rp_inv_on_device) { h->d_rp_inv.upload(h->h_rp_inv, h->stream); h->rp_inv_on_device = true; }
+      inv = h->d_rp_inv.get();
+      break;
     case OBVI_FACTOR_BBOX: off = h->n_rp; n = h->n_bb; act = h->d_bb_active.get(); break;
     case OBVI_FACTOR_SHAPE_PRIOR: off = h->n_rp + h->n_bb; n = h->n_sp; act = h->d_sp_active.get(); break;
     case OBVI_FACTOR_LTM_PRIOR: off = h->n_rp + h->n_bb + h->n_sp; n = h->n_lt; act = h->d_lt_active.get(); break;
     case OBVI_FACTOR_REL_POSE: off = h->n_rp + h->n_bb + h->n_sp + h->n_lt; n = h->n_rl; act = h->d_rl_active.get(); break;
     default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "select_outliers: unknown factor type");
   }
-  h->d_sel_mask.resize((size_t)n + 1);
-  int n_out = 0;
-  OBVI_HIP(select_outliers_device(h->stream, n, h->d_eval_sq.get() + off, act, inv, fraction, h->d_sel_mask.get(), &n_out, &h->sel_scratch));
-  h->d_sel_mask.download(mask_out, (size_t)n, h->stream);
+  run_selection(h, n, h->d_eval_sq.get() + off, act, inv, fraction, mask_out, num_excluded);
+  h->eval_sq_call = h->api_calls;   // (the evaluate above counted as a call of its own)
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
+int obvi_ba_debug_select(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t* active, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
+  if (!h || n < 0 || (n > 0 && (!sq || !mask_out))) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  DevBuf<double> d_sq; DevBuf<uint8_t> d_act;
+  std::vector<uint8_t> ones;
+  if (!active) { ones.assign((size_t)n, 1); active = ones.data(); }
+  d_sq.upload(sq, (size_t)n, h->stream); d_act.upload(active, (size_t)n, h->stream);
   sync(h);
-  if (num_excluded) *num_excluded = n_out;
+  run_selection(h, n, d_sq.get(), d_act.get(), nullptr, fraction, mask_out, num_excluded);
   return OBVI_OK;
   OBVI_API_END(h)
 }

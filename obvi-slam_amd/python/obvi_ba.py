@@ -252,6 +252,16 @@ class BundleAdjuster:
                                                    _ptr(mask, C.c_uint8), C.byref(nex)), "select_outliers")
         return mask, nex.value
 
+    def debug_select(self, sq, active, fraction):
+        """obvi_ba_debug_select: the two-phase selection rule on block norms given here (active None: all)."""
+        v = np.ascontiguousarray(sq, dtype=np.float64)
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        mask = np.zeros(len(v), dtype=np.uint8)
+        nex = C.c_int64(0)
+        self._check(self._fn("ba_debug_select")(self._h, C.c_int64(len(v)), _ptr(v, C.c_double), _ptr(a, C.c_uint8), C.c_double(fraction),
+                                                _ptr(mask, C.c_uint8), C.byref(nex)), "debug_select")
+        return mask, nex.value
+
     def object_covariances(self, obj_a, obj_b=None):
         """7x7 covariance blocks of object pairs (obj_b None: the objects' own blocks)."""
         a = np.ascontiguousarray(obj_a, dtype=np.uint32)

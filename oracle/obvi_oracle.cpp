@@ -1292,6 +1292,27 @@ int oracle_ba_get_iterations(const oracle_handle* h, obvi_iteration_summary* out
 // offline_problem_runner.h:769-800: per factor type, order blocks by un-robustified |r|^2
 // descending in a std::map keyed by the value (equal values collapse into one entry), take the
 // first floor(size * fraction) entries.
+// offline_problem_runner.h:769-800 on (value, index) pairs: std::map<double, id, greater> -- later insertions with an equal key overwrite; the
+// map is filled by iterating an unordered_map, so which duplicate survives is unspecified.  We keep the highest index, and count
+// distinct values like the map's size() does.  Clears mask[index] of the first floor(size * fraction) entries; returns how many.
+static size_t map_rule(std::vector<std::pair<double, int64_t>>* values, double fraction, uint8_t* mask) {
+  std::vector<std::pair<double, int64_t>>& v = *values;
+  std::sort(v.begin(), v.end(), [](const std::pair<double, int64_t>& a, const std::pair<double, int64_t>& b) {
+    return a.first > b.first || (a.first == b.first && a.second > b.second); });
+  std::vector<std::pair<double, int64_t>> uniq;
+  for (const auto& e : v) if (uniq.empty() || uniq.back().first != e.first) uniq.push_back(e);
+  const size_t n_out = (size_t)(uniq.size() * fraction);
+  for (size_t k = 0; k < n_out; ++k) mask[uniq[k].second] = 0;
+  return n_out;
+}
+int oracle_ba_debug_select(oracle_handle* h, int64_t n, const double* sq, const uint8_t* active, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
+  if (!h || n < 0 || (n > 0 && (!sq || !mask_out))) return OBVI_ERR_INVALID_ARGUMENT;
+  std::vector<std::pair<double, int64_t>> v;
+  for (int64_t i = 0; i < n; ++i) { mask_out[i] = active ? (active[i] != 0) : 1; if (mask_out[i]) v.push_back({sq[i], i}); }
+  const size_t n_out = map_rule(&v, fraction, mask_out);
+  if (num_excluded) *num_excluded = (int64_t)n_out;
+  return OBVI_OK;
+}
 int oracle_ba_select_outliers(oracle_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
   const OracleProblem& pb = h->pb;
@@ -1305,15 +1326,7 @@ int oracle_ba_select_outliers(oracle_handle* h, int32_t type, double fraction, u
       double s = 0.0; for (int a = 0; a < fam.m; ++a) s += f.r[a] * f.r[a];
       v.push_back({s, i});
     }
-    // std::map<double, id, greater>: later insertions with an equal key overwrite; the map is
-    // filled by iterating an unordered_map, so which duplicate survives is unspecified.  We keep
-    // the highest index, and count distinct values like the map's size() does.
-    std::sort(v.begin(), v.end(), [](const std::pair<double, int64_t>& a, const std::pair<double, int64_t>& b) {
-      return a.first > b.first || (a.first == b.first && a.second > b.second); });
-    std::vector<std::pair<double, int64_t>> uniq;
-    for (const auto& e : v) if (uniq.empty() || uniq.back().first != e.first) uniq.push_back(e);
-    const size_t n_out = (size_t)(uniq.size() * fraction);
-    for (size_t k = 0; k < n_out; ++k) mask_out[uniq[k].second] = 0;
+    const size_t n_out = map_rule(&v, fraction, mask_out);
     if (num_excluded) *num_excluded = (int64_t)n_out;
     return OBVI_OK;
   }

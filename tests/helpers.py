@@ -75,3 +75,18 @@ def numpy_robust_residuals(prob):
             out.append(robustified(np.stack([W @ d for W, d in zip(W_rl, np.concatenate([t_rel - prob["rl_t"], rot], axis=1))]), prob["rl_huber"]))
         return np.concatenate(out)
     return f
+
+
+def map_rule(sq, active, fraction):
+    """offline_problem_runner.h:769-800 stated in numpy: the active values as keys of a map in descending order (equal values are one
+    entry; its member here: the highest index), the first floor(entries * fraction) entries go."""
+    sq, active = np.asarray(sq, np.float64), np.asarray(active, bool)
+    mask = active.astype(np.uint8)
+    entries = {}
+    for i in np.flatnonzero(active):
+        entries[sq[i]] = i                      # ascending i: the highest index stays
+    keys = sorted(entries, reverse=True)
+    n_out = int(len(keys) * fraction)
+    for k in keys[:n_out]:
+        mask[entries[k]] = 0
+    return mask, n_out

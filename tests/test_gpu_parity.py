@@ -599,3 +599,33 @@ def test_column_norms_and_parameter_priors_of_the_covariance_extraction():
         ba.set_parameter_priors([], [], [], [], [])
     with pytest.raises(obvi_ba.ObviError, match="status -6"):
         g.object_covariances(np.arange(3))
+
+
+@pytest.mark.parametrize("route", ["threshold", "sort"])
+def test_outlier_selection_rule_on_given_values(route, monkeypatch):
+    """K8 alone (obvi_ba_debug_select) against the map rule: values spread over many exponents and values packed into one (the radix
+    select's three levels), heavy ties (a handful of distinct values: the entries are the distinct ones), inactive factors, zeros,
+    fractions 0 / tiny / 0.1 / 1, one value, none, and more than 4096 distinct values sharing their top 24 bits (the threshold route hands
+    over to the sort).  Both routes -- the histogram / hash-table one and the radix sort (OBVI_SELECT_SORT=1) -- give the same masks."""
+    if route == "sort":
+        monkeypatch.setenv("OBVI_SELECT_SORT", "1")
+    g = helpers.product_ba()
+    rng = np.random.default_rng(12)
+    cases = []
+    for n in (1, 2, 63, 1000, 50000, 300000):
+        cases.append((np.exp(rng.normal(size=n) * 3.0), rng.random(n) < 0.9))                         # many exponents
+        cases.append((1.0 + rng.random(n) * 1e-3, rng.random(n) < 0.5))                               # one exponent, top mantissa bits shared
+        cases.append((rng.integers(0, 7, size=n).astype(np.float64), rng.random(n) < 0.8))            # seven distinct values, one of them zero
+        cases.append((np.round(np.exp(rng.normal(size=n)), 2), None))                                 # some ties, everything active
+    cases.append((1.0 + np.arange(20000) * 2.0 ** -52, None))                                         # 20000 neighbours in the last mantissa bits
+    cases.append((np.zeros(0), None))
+    cases.append((np.full(100, 3.5), np.zeros(100, bool)))                                            # nothing active
+    for sq, active in cases:
+        act = np.ones(len(sq), bool) if active is None else active
+        for fraction in (0.0, 1e-4, 0.1, 0.37, 1.0):
+            want, n_want = helpers.map_rule(sq, act, fraction)
+            got, n_got = g.debug_select(sq, active, fraction)
+            assert n_got == n_want and np.array_equal(got, want), (len(sq), fraction)
+    # the calls leave their scratch ready for the next one whatever came before: the first case again
+    sq, active = cases[0]
+    assert np.array_equal(g.debug_select(sq, active, 0.1)[0], helpers.map_rule(sq, active, 0.1)[0])

@@ -334,3 +334,18 @@ def test_object_covariances_are_blocks_of_the_dense_inverse():
     ba2 = helpers.oracle_ba(); synth.upload(ba2, prob2)
     c2 = ba2.object_covariances(np.arange(O))
     assert np.all(c2[0] == 0.0) and np.all(np.diag(c2[1]) <= np.diag(own[1]) * (1 + 1e-9))
+
+
+def test_oracle_selection_rule_against_the_map_rule_in_numpy():
+    """oracle_ba_debug_select (the rule of offline_problem_runner.h:769-800 as the oracle applies it in oracle_ba_select_outliers) against
+    helpers.map_rule: ties, inactive factors, zeros, the fractions' edge cases."""
+    o = helpers.oracle_ba()
+    rng = np.random.default_rng(12)
+    for n in (0, 1, 2, 63, 5000):
+        for sq, active in ((np.exp(rng.normal(size=n) * 3.0), rng.random(n) < 0.9), (rng.integers(0, 7, size=n).astype(np.float64), rng.random(n) < 0.8),
+                           (np.round(np.exp(rng.normal(size=n)), 2), None)):
+            act = np.ones(n, bool) if active is None else active
+            for fraction in (0.0, 1e-4, 0.1, 0.37, 1.0):
+                want, n_want = helpers.map_rule(sq, act, fraction)
+                got, n_got = o.debug_select(sq, active, fraction)
+                assert n_got == n_want and np.array_equal(got, want), (n, fraction)
