@@ -64,6 +64,7 @@ struct obvi_ba_handle {
   std::vector<int32_t> h_rp_yrow;
   std::vector<uint32_t> h_rq_src;    // CSR-by-pose copy: position -> index into the CSC-by-point arrays
   std::vector<uint32_t> scr_cursor, scr_wave_obs, scr_long_points, scr_pose_ptr;   // scratch of set_reproj, kept between calls
+  std::vector<uint8_t> scr_pose_used, scr_obj_used, scr_point_used, scr_point_var, scr_is_pad; std::vector<int32_t> scr_pose_vid, scr_obj_vid;   // ... of prepare_masks
   double rp_huber = 1.0;
   int64_t n_bb = 0, n_sp = 0, n_lt = 0, n_rl = 0;
   std::vector<uint32_t> h_bb_obj, h_bb_pose, h_sp_obj, h_lt_obj, h_rl_a, h_rl_b;
@@ -1254,18 +1255,26 @@ bool prepare_masks(obvi_ba_handle* h) {
     for (size_t i = 0; i < now.size(); ++i) if (now[i] && !plan[i]) return false;
     return true;
   };
-  if (!subset(h->h_rp_active, h->plan_rp_active) || !subset(h->h_bb_active, h->plan_bb_active) || !subset(h->h_sp_active, h->plan_sp_active) ||
+  if (h->h_rp_active.size() != h->plan_rp_active.size() || !subset(h->h_bb_active, h->plan_bb_active) || !subset(h->h_sp_active, h->plan_sp_active) ||
       !subset(h->h_lt_active, h->plan_lt_active) || !subset(h->h_rl_active, h->plan_rl_active)) return false;
-  std::vector<uint8_t> pose_used(P, 0), obj_used(O, 0), point_used(L, 0);
+  // (scratch kept between calls: a session runs this once per frame)
+  std::vector<uint8_t>& pose_used = h->scr_pose_used; std::vector<uint8_t>& obj_used = h->scr_obj_used; std::vector<uint8_t>& point_used = h->scr_point_used;
+  pose_used.assign(P, 0); obj_used.assign(O, 0); point_used.assign(L, 0);
   int64_t nres = 0;
-  for (int64_t a = 0; a < h->n_rp; ++a) {
-    if (!h->h_rp_active[a]) continue;
-    const uint32_t p = h->h_rp_pose[a], l = h->h_rp_point[a];
-    const bool cp = h->h_pose_const[p], cl = h->h_point_const[l];
-    if (cp && cl) continue;
-    nres += 2;
-    if (!cp) pose_used[p] = 1;
-    if (!cl) point_used[l] = 1;
+  {   // the observations once: subset test of their mask, residual count, blocks in use
+    const uint8_t* act = h->h_rp_active.data(); const uint8_t* plan = h->plan_rp_active.data();
+    const uint32_t* op = h->h_rp_pose.data(); const uint32_t* ol = h->h_rp_point.data();
+    const uint8_t* pc = h->h_pose_const.data(); const uint8_t* lc = h->h_point_const.data();
+    for (int64_t a = 0; a < h->n_rp; ++a) {
+      if (!act[a]) continue;
+      if (!plan[a]) return false;
+      const uint32_t p = op[a], l = ol[a];
+      const bool cp = pc[p], cl = lc[l];
+      if (cp && cl) continue;
+      nres += 2;
+      if (!cp) pose_used[p] = 1;
+      if (!cl) point_used[l] = 1;
+    }
   }
   for (int64_t i = 0; i < h->n_bb; ++i) {
     if (!h->h_bb_active[i]) continue;
@@ -1288,8 +1297,9 @@ bool prepare_masks(obvi_ba_handle* h) {
     if (!cb) pose_used[b] = 1;
   }
   if (!h->h_is_shared.empty()) for (int64_t o = 0; o < O; ++o) if (h->h_is_shared[o]) obj_used[o] = 1;
-  std::vector<int32_t> pose_vid(P, -1), obj_vid(O, -1);
-  std::vector<uint8_t> point_var(L, 0), is_pad = h->plan_is_pad;
+  std::vector<int32_t>& pose_vid = h->scr_pose_vid; std::vector<int32_t>& obj_vid = h->scr_obj_vid;
+  std::vector<uint8_t>& point_var = h->scr_point_var; std::vector<uint8_t>& is_pad = h->scr_is_pad;
+  pose_vid.assign(P, -1); obj_vid.assign(O, -1); point_var.assign(L, 0); is_pad = h->plan_is_pad;
   int64_t nP = 0, nO = 0, nL = 0;
   for (int64_t p = 0; p < P; ++p) {
     const bool var = !h->h_pose_const[p] && pose_used[p];
@@ -1321,7 +1331,7 @@ bool prepare_masks(obvi_ba_handle* h) {
   h->nLv = nL; h->live_rows = 6 * nP + 7 * nO;
   h->num_params = h->live_rows + 3 * nL;
   h->num_residuals = nres;
-  sync(h);
+  finish_upload(h);   // (the copies went through the pinned arena: nothing to wait for; the solve's first launches follow on the same stream)
   h->mask_dirty = false; h->pc_valid = false; h->tiles_cleared = false;
   return true;
 }
