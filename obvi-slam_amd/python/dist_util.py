@@ -107,6 +107,21 @@ def staged_allreduce(dist, log=None):
     return fn
 
 
+def host_allreduce(dist, log=None):
+    """The hook for a library whose exchange buffers live in HOST memory -- the CPU oracle, which runs the same exchange protocol on the host
+    (oracle_ba_set_allreduce; stream is NULL): torch.distributed.all_reduce in place on the buffer, any backend that takes CPU tensors (gloo)."""
+    import numpy as np
+    import torch
+
+    def fn(ptr, count, op, stream):
+        if log is not None:
+            log.note(count, op, stream)
+        t = torch.from_numpy(np.ctypeslib.as_array((C.c_double * int(count)).from_address(int(ptr))))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+        return 0
+    return fn
+
+
 def torch_rccl_version():
     """NCCL_VERSION_CODE-style integer of the librccl torch.distributed uses (torch.cuda.nccl.version()), or None."""
     try:

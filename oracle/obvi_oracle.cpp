@@ -19,6 +19,9 @@
 //                       trust_region_step_evaluator.cc / schur_complement_solver.cc of Ceres
 //                       1.14-2.x) and is marked [Ceres-doc] where it does.
 //   select_outliers  -> include/refactoring/offline/offline_problem_runner.h:769-800
+//   shared objects   -> no reference counterpart (the reference is one process): the exchange protocol of include/obvi_ba.h
+//                       ("multi-GPU") on host buffers, so that the N > 1 path has a CPU stand-in that is held against this
+//                       oracle's own solve of the joint problem (tests/test_distributed_gloo.py, world size 2 over gloo)
 //
 // PARITY STATUS: factor arithmetic is pinned by the two golden tuples the survey derived from
 // the reference's own code (tests/golden/reference_tuples.json), the reference's simulated data
@@ -129,6 +132,10 @@ struct OracleProblem {
   std::vector<uint8_t> pp_kind, pp_param; std::vector<uint32_t> pp_block; std::vector<double> pp_mean, pp_std;
   // snapshot
   std::vector<double> snap_poses, snap_points, snap_objects;
+  // objects shared with other ranks (obvi_ba_set_shared_objects / obvi_ba_set_allreduce): the solve then runs the exchange protocol of
+  // include/obvi_ba.h on host buffers
+  std::vector<uint8_t> is_shared; int32_t rank = 0, world = 1;
+  obvi_allreduce_fn allreduce = nullptr; void* allreduce_user = nullptr;
   // last solve
   std::vector<obvi_iteration_summary> iterations;
   std::string err;
@@ -288,6 +295,8 @@ struct Reduced {
   int64_t m = 0;                           // reduced (Schur) system rows = 6 nPv + 7 nOv
   int64_t num_params = 0, num_residuals = 0;
   double fixed_cost = 0.0;
+  int64_t nOs = 0;                         // shared variable objects: the LAST nOs object blocks of the reduced system
+  int64_t shared_row0 = 0;                 // first row of the shared objects (= m without any)
 };
 
 struct Workspace {
@@ -331,10 +340,16 @@ void build_reduced(const OracleProblem& pb, Reduced* rd) {
     }
   }
   rd->nPv = rd->nOv = rd->nLv = 0;
+  const bool sharing = (int64_t)pb.is_shared.size() == pb.O;
+  auto shared = [&](int64_t o) { return sharing && pb.is_shared[o] != 0; };
+  for (int64_t o = 0; o < pb.O; ++o) if (shared(o)) obj_used[o] = 1;   // a shared object exists on every rank, observed there or not
   for (int64_t p = 0; p < pb.P; ++p) if (!pb.pose_const[p] && pose_used[p]) rd->pose_vid[p] = (int32_t)rd->nPv++;
-  for (int64_t o = 0; o < pb.O; ++o) if (!pb.object_const[o] && obj_used[o]) rd->obj_vid[o] = (int32_t)rd->nOv++;
+  for (int64_t o = 0; o < pb.O; ++o) if (!pb.object_const[o] && obj_used[o] && !shared(o)) rd->obj_vid[o] = (int32_t)rd->nOv++;
+  rd->nOs = 0;
+  for (int64_t o = 0; o < pb.O; ++o) if (!pb.object_const[o] && obj_used[o] && shared(o)) { rd->obj_vid[o] = (int32_t)rd->nOv++; rd->nOs++; }   // eliminated last, in index order
   for (int64_t l = 0; l < pb.L; ++l) if (!pb.point_const[l] && point_used[l]) { rd->point_var[l] = 1; rd->nLv++; }
   rd->m = 6 * rd->nPv + 7 * rd->nOv;
+  rd->shared_row0 = rd->m - 7 * rd->nOs;
   rd->num_params = rd->m + 3 * rd->nLv;
 }
 
@@ -700,6 +715,73 @@ bool skyline_cholesky_solve(Workspace* ws, int64_t m, std::vector<real>* x) {
   return true;
 }
 
+// The reduced solve of a rank whose last rows belong to objects shared with other ranks (include/obvi_ba.h, exchange (2)): the rank's own
+// rows A = [0, r0) are eliminated, the Schur complement onto the shared rows B and its right-hand side are summed over the ranks through the
+// hook, every rank factorises the sum and back-substitutes into its own rows.  Dense (row-oriented Cholesky on the expanded envelope): this
+// path exists for problems the tests hold against the joint solve.  A rank whose own block is not positive definite still takes part in the
+// exchange (the ranks must stay in step) and reports the failure; the caller sums the failure flags.
+bool shared_tail_solve(const OracleProblem& pb, Workspace* ws, int64_t m, int64_t r0, std::vector<real>* y) {
+  const int64_t nB = m - r0;
+  std::vector<real> D((size_t)m * (size_t)m, 0.0);
+  for (int64_t i = 0; i < m; ++i) for (int64_t j = ws->first[i]; j <= i; ++j) D[(size_t)i * m + j] = ws->S[ws->rowptr[i] + (j - ws->first[i])];
+  std::vector<real> z(ws->rhs.begin(), ws->rhs.end());
+  bool ok = true;
+  for (int64_t i = 0; i < m && ok; ++i) {
+    real* Li = &D[(size_t)i * m];
+    const int64_t jend = std::min(i, r0 - 1);
+    for (int64_t j = 0; j <= jend; ++j) {            // columns of A
+      const real* Lj = &D[(size_t)j * m];
+      real v = Li[j];
+      for (int64_t k = 0; k < j; ++k) v -= Li[k] * Lj[k];
+      if (j == i) { if (!(v > 0.0)) { ok = false; break; } Li[i] = std::sqrt(v); }
+      else Li[j] = v / Lj[j];
+    }
+    if (!ok) break;
+    for (int64_t j = r0; j <= i; ++j) {              // columns of B (rows of B only): the Schur complement, not divided yet
+      const real* Lj = &D[(size_t)j * m];
+      real v = Li[j];
+      for (int64_t k = 0; k < r0; ++k) v -= Li[k] * Lj[k];
+      Li[j] = v;
+    }
+    real t = z[i];                                    // forward substitution through the columns of A
+    for (int64_t k = 0; k < std::min(i, r0); ++k) t -= Li[k] * z[k];
+    z[i] = i < r0 ? t / Li[i] : t;
+  }
+  std::vector<double> buf((size_t)(nB * (nB + 1) / 2 + nB), 0.0);
+  if (ok) {
+    size_t q = 0;
+    for (int64_t i = r0; i < m; ++i) for (int64_t j = r0; j <= i; ++j) buf[q++] = (double)D[(size_t)i * m + j];
+    for (int64_t i = r0; i < m; ++i) buf[q++] = (double)z[i];
+  }
+  if (pb.allreduce(pb.allreduce_user, buf.data(), (int64_t)buf.size(), 0, nullptr)) return false;
+  if (!ok) return false;
+  {
+    size_t q = 0;
+    for (int64_t i = r0; i < m; ++i) for (int64_t j = r0; j <= i; ++j) D[(size_t)i * m + j] = buf[q++];
+    for (int64_t i = r0; i < m; ++i) z[i] = buf[q++];
+  }
+  for (int64_t i = r0; i < m; ++i) {                  // the summed block: the same factorisation on every rank
+    real* Li = &D[(size_t)i * m];
+    for (int64_t j = r0; j <= i; ++j) {
+      const real* Lj = &D[(size_t)j * m];
+      real v = Li[j];
+      for (int64_t k = r0; k < j; ++k) v -= Li[k] * Lj[k];
+      if (j == i) { if (!(v > 0.0)) return false; Li[i] = std::sqrt(v); }
+      else Li[j] = v / Lj[j];
+    }
+    real t = z[i];
+    for (int64_t k = r0; k < i; ++k) t -= Li[k] * z[k];
+    z[i] = t / Li[i];
+  }
+  for (int64_t i = m - 1; i >= 0; --i) {              // L^T y = z
+    const real yi = z[i] / D[(size_t)i * m + i];
+    z[i] = yi;
+    for (int64_t k = 0; k < i; ++k) z[k] -= D[(size_t)i * m + k] * yi;
+  }
+  y->assign(z.begin(), z.end());
+  return true;
+}
+
 void copy_params(const OracleProblem& pb, std::vector<double>* a, std::vector<double>* b, std::vector<double>* c) {
   *a = pb.poses; *b = pb.points; *c = pb.objects;
 }
@@ -853,6 +935,17 @@ int oracle_ba_set_relpose(oracle_handle* h, int64_t n, const uint32_t* ia, const
   return OBVI_OK;
 }
 
+int oracle_ba_set_shared_objects(oracle_handle* h, const uint8_t* is_shared, int32_t rank, int32_t world) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return OBVI_ERR_INVALID_ARGUMENT;
+  if (is_shared) h->pb.is_shared.assign(is_shared, is_shared + h->pb.O); else h->pb.is_shared.clear();
+  h->pb.rank = rank; h->pb.world = world;
+  return OBVI_OK;
+}
+int oracle_ba_set_allreduce(oracle_handle* h, obvi_allreduce_fn fn, void* user) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  h->pb.allreduce = fn; h->pb.allreduce_user = user;
+  return OBVI_OK;
+}
 int oracle_ba_set_active_mask(oracle_handle* h, int32_t type, const uint8_t* mask) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
   OracleProblem& pb = h->pb;
@@ -1041,6 +1134,18 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   double t_lin = 0, t_res = 0, t_solve = 0;
 
   Reduced rd; build_reduced(pb, &rd);
+  // Objects shared across ranks (include/obvi_ba.h "multi-GPU"): every sum the decisions are taken from runs over all ranks through the
+  // hook -- here on host buffers, stream = NULL --, the shared objects' own terms (their rows of the gradient, of x and of the step) are
+  // counted by rank 0 only, and the reduced solve exchanges the Schur complement onto the shared rows (shared_tail_solve).  The collectives,
+  // in this order on every rank: the fixed cost once; per linearisation the shared rows' column norms and gradient (14 per object), then
+  // cost / |g|^2 / |x|^2 and one gradient-maximum slot per rank; per step the shared tail, then failure flag + model cost change, then
+  // |step|^2 + trial cost + its failure flag.  (The device library packs the same exchanges into three collectives per step.)
+  const bool dist = pb.allreduce != nullptr && rd.nOs > 0;
+  bool hook_failed = false;
+  auto xsum = [&](std::vector<double>* v) { if (dist && pb.allreduce(pb.allreduce_user, v->data(), (int64_t)v->size(), 0, nullptr)) hook_failed = true; };
+  const bool owner = pb.rank == 0;
+  auto counted_row = [&](int64_t row) { return !dist || row < rd.shared_row0 || owner; };
+  if (dist) { std::vector<double> v(1, rd.fixed_cost); xsum(&v); rd.fixed_cost = v[0]; }
   sum->fixed_cost = rd.fixed_cost;
   sum->num_parameters_reduced = (int32_t)rd.num_params;
   sum->num_residuals_reduced = (int32_t)rd.num_residuals;
@@ -1074,25 +1179,52 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   double x_cost = linearize(pb, rd, &ws);
   build_envelope(pb, rd, &ws);
   t_lin += now_s() - tt;
+  // the shared rows' squared column norms and gradient, summed over the ranks (exchange (1) of the protocol)
+  auto share_linearisation = [&]() {
+    if (!dist) return;
+    std::vector<double> v((size_t)(2 * (rd.m - rd.shared_row0)));
+    for (int64_t i = rd.shared_row0; i < rd.m; ++i) { v[(size_t)(2 * (i - rd.shared_row0))] = (double)ws.colsq_c[i]; v[(size_t)(2 * (i - rd.shared_row0) + 1)] = (double)ws.g_c[i]; }
+    xsum(&v);
+    for (int64_t i = rd.shared_row0; i < rd.m; ++i) { ws.colsq_c[i] = v[(size_t)(2 * (i - rd.shared_row0))]; ws.g_c[i] = v[(size_t)(2 * (i - rd.shared_row0) + 1)]; }
+  };
+  share_linearisation();
 
   // Jacobi scaling, computed once at iteration 0: s_j = 1 / (1 + sqrt(colsq_j))
   std::vector<real> scale_c(rd.m), scale_l(3 * pb.L, 1.0);
   for (int64_t i = 0; i < rd.m; ++i) scale_c[i] = (real)1.0 / ((real)1.0 + std::sqrt(ws.colsq_c[i]));
   for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) scale_l[3 * l + k] = (real)1.0 / ((real)1.0 + std::sqrt(ws.colsq_l[3 * l + k]));
 
-  auto grad_norms = [&](double* gmax, double* gnorm) {
+  // (with shared objects: this rank's part -- squares, to be summed over the ranks; the shared rows by rank 0 only)
+  auto grad_norms_sq = [&](double* gmax, double* gsq) {
     real mx = 0.0, sq = 0.0;
-    for (int64_t i = 0; i < rd.m; ++i) { mx = std::max(mx, std::fabs(ws.g_c[i])); sq += ws.g_c[i] * ws.g_c[i]; }
+    for (int64_t i = 0; i < rd.m; ++i) if (counted_row(i)) { mx = std::max(mx, std::fabs(ws.g_c[i])); sq += ws.g_c[i] * ws.g_c[i]; }
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const real g = ws.gl[3 * l + k]; mx = std::max(mx, std::fabs(g)); sq += g * g; }
-    *gmax = (double)mx; *gnorm = (double)std::sqrt(sq);
+    *gmax = (double)mx; *gsq = (double)sq;
   };
-  auto x_norm_fn = [&]() {
+  auto x_norm_sq = [&]() {
     real sq = 0.0;
     for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) sq += pb.poses[6 * p + k] * pb.poses[6 * p + k];
-    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) sq += pb.objects[7 * o + k] * pb.objects[7 * o + k];
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0 && counted_row(obj_row(rd, o))) for (int k = 0; k < 7; ++k) sq += pb.objects[7 * o + k] * pb.objects[7 * o + k];
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) sq += pb.points[3 * l + k] * pb.points[3 * l + k];
-    return (double)std::sqrt(sq);
+    return (double)sq;
   };
+  // cost, gradient norms and |x| of the point just linearised, over all ranks (part of exchange (3) of the protocol)
+  double lin_x_norm = 0.0;
+  auto point_scalars = [&](double* cost, double* gmax, double* gnorm) {
+    double mx, gsq;
+    grad_norms_sq(&mx, &gsq);
+    double xsq = x_norm_sq();
+    if (dist) {
+      std::vector<double> v((size_t)(3 + pb.world), 0.0);
+      v[0] = *cost; v[1] = gsq; v[2] = xsq; v[(size_t)(3 + pb.rank)] = mx;
+      xsum(&v);
+      *cost = v[0]; gsq = v[1]; xsq = v[2];
+      for (int r = 0; r < pb.world; ++r) mx = std::max(mx, v[(size_t)(3 + r)]);
+    }
+    *gmax = mx; *gnorm = std::sqrt(gsq); lin_x_norm = std::sqrt(xsq);
+  };
+  double gmax0 = 0.0, gnorm0 = 0.0;
+  point_scalars(&x_cost, &gmax0, &gnorm0);
 
   // LevenbergMarquardtStrategy state
   double radius = prm->initial_trust_region_radius;
@@ -1118,9 +1250,9 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   sum->initial_cost = x_cost + rd.fixed_cost;
   obvi_iteration_summary it; std::memset(&it, 0, sizeof(it));
   it.iteration = 0; it.cost = x_cost + rd.fixed_cost; it.step_is_valid = 1; it.step_is_successful = 1;
-  grad_norms(&it.gradient_max_norm, &it.gradient_norm);
+  it.gradient_max_norm = gmax0; it.gradient_norm = gnorm0;
   it.trust_region_radius = radius;
-  double x_norm = x_norm_fn();
+  double x_norm = lin_x_norm;
   int num_invalid = 0;
   double iter_t0 = now_s();
   std::vector<real> y_c, Hll_inv, lam_c(rd.m), lam_l(3 * pb.L, 0.0), delta_l(3 * pb.L, 0.0);
@@ -1150,13 +1282,19 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     }
     // scaled system (J_s^T J_s + D^2) y_s = J_s^T r, D^2 = diag/radius; in unscaled variables
     // delta = s .* y_s this is (J^T J + D^2/s^2) delta = J^T r.
-    for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = diag_c[i] / radius / (scale_c[i] * scale_c[i]);
+    for (int64_t i = 0; i < rd.m; ++i) lam_c[i] = counted_row(i) ? diag_c[i] / radius / (scale_c[i] * scale_c[i]) : (real)0.0;   // (a shared row's damping enters the summed tail once)
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k)
       lam_l[3 * l + k] = diag_l[3 * l + k] / radius / (scale_l[3 * l + k] * scale_l[3 * l + k]);
     const double t_asm = now_s();
+    // (the shared rows' gradient is the sum over the ranks on every rank: it enters the summed tail once, through rank 0)
+    std::vector<real> g_shared;
+    if (dist && !owner) { g_shared.assign(ws.g_c.begin() + rd.shared_row0, ws.g_c.end()); std::fill(ws.g_c.begin() + rd.shared_row0, ws.g_c.end(), (real)0.0); }
     bool ok = assemble_schur(pb, rd, lam_c, lam_l, &ws, &Hll_inv);
+    if (dist && !owner) std::copy(g_shared.begin(), g_shared.end(), ws.g_c.begin() + rd.shared_row0);
     const double t_fac = now_s();
-    if (ok) ok = skyline_cholesky_solve(&ws, rd.m, &y_c);
+    if (dist) { if (!shared_tail_solve(pb, &ws, rd.m, rd.shared_row0, &y_c)) ok = false; }   // (every rank takes part in the exchange, whatever its own assembly said)
+    else if (ok) ok = skyline_cholesky_solve(&ws, rd.m, &y_c);
+    if (!ok) y_c.assign((size_t)rd.m, 0.0);
     if (std::getenv("OBVI_ORACLE_TIMING")) std::fprintf(stderr, "oracle step: assemble_schur %.3f s, skyline factor + solve %.3f s (envelope %.1f M entries)\n", t_fac - t_asm, now_s() - t_fac, 1e-6 * (double)ws.S.size());
     // back-substitution  y_l = Hll^-1 (g_l - W^T y_c)
     if (ok) {
@@ -1201,7 +1339,12 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
         for (int a = 0; a < f.m; ++a) model_acc -= Jd[a] * (f.r[a] + (real)0.5 * Jd[a]);
       }
     }
-    const double model_cost_change = (double)model_acc;
+    double model_cost_change = (double)model_acc;
+    if (dist) {   // one decision for all ranks
+      std::vector<double> v = {finite ? 0.0 : 1.0, finite ? model_cost_change : 0.0};
+      xsum(&v);
+      finite = v[0] == 0.0 && !hook_failed; model_cost_change = v[1];
+    }
     it.step_is_valid = (finite && model_cost_change > 0.0) ? 1 : 0;
     if (!it.step_is_valid) {
       // HandleInvalidStep
@@ -1222,11 +1365,17 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     std::vector<double> old_poses = pb.poses, old_points = pb.points, old_objects = pb.objects;
     real step_sq = 0.0;   // (the parameter blocks are fp64 in every build: the step is rounded once, where it is added)
     for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) { const real d = -y_c[pose_row(rd, p) + k]; pb.poses[6 * p + k] = (double)(pb.poses[6 * p + k] + d); step_sq += d * d; }
-    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const real d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] = (double)(pb.objects[7 * o + k] + d); step_sq += d * d; }
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const real d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] = (double)(pb.objects[7 * o + k] + d); if (counted_row(obj_row(rd, o))) step_sq += d * d; }
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const real d = delta_l[3 * l + k]; pb.points[3 * l + k] = (double)(pb.points[3 * l + k] + d); step_sq += d * d; }
     tt = now_s();
     double cand_cost = reduced_cost(pb, rd);
     t_res += now_s() - tt;
+    if (dist) {
+      const bool bad = !std::isfinite(cand_cost);
+      std::vector<double> v = {(double)step_sq, bad ? 0.0 : cand_cost, bad ? 1.0 : 0.0};
+      xsum(&v);
+      step_sq = v[0]; cand_cost = v[2] == 0.0 ? v[1] : std::numeric_limits<double>::infinity();
+    }
     if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
 
     auto revert = [&]() { pb.poses = old_poses; pb.points = old_points; pb.objects = old_objects; };
@@ -1252,12 +1401,13 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     }
     if (it.relative_decrease > kMinRelDecrease) {
       // HandleSuccessfulStep
-      x_norm = x_norm_fn();
       tt = now_s();
       x_cost = linearize(pb, rd, &ws);
       t_lin += now_s() - tt;
+      share_linearisation();
+      point_scalars(&x_cost, &it.gradient_max_norm, &it.gradient_norm);
+      x_norm = lin_x_norm;
       it.cost = x_cost + rd.fixed_cost;
-      grad_norms(&it.gradient_max_norm, &it.gradient_norm);
       it.step_is_successful = 1;
       // strategy->StepAccepted
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
@@ -1277,6 +1427,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;  // StepRejected
     }
   }
+  if (hook_failed) { pb.poses = entry_poses; pb.points = entry_points; pb.objects = entry_objects; pb.err = "all-reduce hook failed"; return OBVI_ERR_HIP; }
   // write back the minimum-cost iterate (the entry state after a FAILURE)
   if (failed) { pb.poses = entry_poses; pb.points = entry_points; pb.objects = entry_objects; }
   else { pb.poses = best_poses; pb.points = best_points; pb.objects = best_objects; }

@@ -90,3 +90,41 @@ def map_rule(sq, active, fraction):
     for k in keys[:n_out]:
         mask[entries[k]] = 0
     return mask, n_out
+
+
+def split_problem(prob, cut):
+    """Two windows [0,cut) and [cut,P) sharing every object; points seen from both sides are dropped."""
+    P = len(prob["poses"])
+    side = (prob["rp_pose"] >= cut).astype(int)
+    lo = np.full(len(prob["points"]), 2); hi = np.full(len(prob["points"]), -1)
+    np.minimum.at(lo, prob["rp_point"], side); np.maximum.at(hi, prob["rp_point"], side)
+    pt_side = np.where(lo == hi, lo, -1)
+    wins = []
+    for w, (a, b) in enumerate(((0, cut), (cut, P))):
+        pts = np.nonzero(pt_side == w)[0]
+        pmap = -np.ones(len(prob["points"]), int); pmap[pts] = np.arange(len(pts))
+        r = (side == w) & (pt_side[prob["rp_point"]] == w)
+        bb = (prob["bb_pose"] >= a) & (prob["bb_pose"] < b)
+        rl = (prob["rl_a"] >= a) & (prob["rl_b"] < b)
+        q = dict(K=prob["K"], ext=prob["ext"], poses=prob["poses"][a:b].copy(), pose_const=np.zeros(b - a, np.uint8), points=prob["points"][pts].copy(),
+                 point_const=np.zeros(len(pts), np.uint8), objects=prob["objects"].copy(), object_const=np.zeros(len(prob["objects"]), np.uint8),
+                 rp_pose=prob["rp_pose"][r] - a, rp_point=pmap[prob["rp_point"][r]], rp_cam=prob["rp_cam"][r], rp_pixel=prob["rp_pixel"][r],
+                 rp_sigma=prob["rp_sigma"], rp_huber=prob["rp_huber"], bb_obj=prob["bb_obj"][bb], bb_pose=prob["bb_pose"][bb] - a, bb_cam=prob["bb_cam"][bb],
+                 bb_corners=prob["bb_corners"][bb], bb_cov=prob["bb_cov"][bb], bb_huber=prob["bb_huber"], bb_invalid=prob["bb_invalid"],
+                 sp_obj=prob["sp_obj"] if w == 0 else prob["sp_obj"][:0], sp_mean=prob["sp_mean"] if w == 0 else prob["sp_mean"][:0],
+                 sp_cov=prob["sp_cov"] if w == 0 else prob["sp_cov"][:0], sp_huber=prob["sp_huber"],
+                 rl_a=prob["rl_a"][rl] - a, rl_b=prob["rl_b"][rl] - a, rl_t=prob["rl_t"][rl], rl_aa=prob["rl_aa"][rl], rl_cov=prob["rl_cov"][rl], rl_huber=prob["rl_huber"])
+        q["pose_const"][0] = 1
+        wins.append((q, pts, (a, b)))
+    # joint problem: both windows in one handle
+    keep_pts = np.nonzero(pt_side >= 0)[0]
+    jm = -np.ones(len(prob["points"]), int); jm[keep_pts] = np.arange(len(keep_pts))
+    r = pt_side[prob["rp_point"]] >= 0
+    r &= (side == pt_side[prob["rp_point"]])
+    rl = ~((prob["rl_a"] < cut) & (prob["rl_b"] >= cut))
+    joint = dict(prob)
+    joint.update(points=prob["points"][keep_pts].copy(), point_const=np.zeros(len(keep_pts), np.uint8), rp_pose=prob["rp_pose"][r], rp_point=jm[prob["rp_point"][r]],
+                 rp_cam=prob["rp_cam"][r], rp_pixel=prob["rp_pixel"][r], rl_a=prob["rl_a"][rl], rl_b=prob["rl_b"][rl], rl_t=prob["rl_t"][rl], rl_aa=prob["rl_aa"][rl],
+                 rl_cov=prob["rl_cov"][rl], pose_const=np.zeros(P, np.uint8))
+    joint["pose_const"][[0, cut]] = 1
+    return wins, joint, keep_pts

@@ -48,8 +48,7 @@ def test_frontend_and_rccl_libraries_export_their_headers(lib):
 
 def test_oracle_mirrors_the_abi():
     o = C.CDLL(helpers.ensure_oracle())
-    skip = {"obvi_ba_last_error", "obvi_ba_version", "obvi_ba_set_allreduce", "obvi_ba_get_kernel_times", "obvi_ba_get_problem_stats", "obvi_ba_set_shared_objects", "obvi_ba_set_profiling",
-            "obvi_ba_measure_peaks"}   # device-only hooks
+    skip = {"obvi_ba_last_error", "obvi_ba_version", "obvi_ba_get_kernel_times", "obvi_ba_get_problem_stats", "obvi_ba_set_profiling", "obvi_ba_measure_peaks"}   # device-only hooks
     for s in _abi_symbols():
         if s not in skip:
             assert hasattr(o, s.replace("obvi_", "oracle_", 1)), s
