@@ -62,7 +62,11 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
         shutil.copy(log, os.path.join(helpers.ROOT, "gpurun_out", "lockstep_%s.jsonl" % ("det" if deterministic else "default")))
     assert all(r["params_reduced_equal"] == 1 for r in solves) and max(r["initial_cost_rel"] for r in busy) <= 1e-11     # the same problem, the same objective at the same point: everywhere
     # Where the two LM runs are the same run (all but a handful of windows): the stated end-state tolerances
-    assert len(good) >= 0.9 * len(busy)                                                           # measured: 156 of 165
+    # measured: 147 ... 158 of 165 over some sixty runs of the default mode (it differs from run to run: fp64 atomics), 155 in deterministic mode.  Most of the
+    # others are local BAs that stop ONE iteration apart: |cost change| <= function_tolerance * cost is decided in the last bits, a coin a dozen windows toss
+    # per session -- 18 heads came up twice in those sixty runs, so the bar is 85 %, not 90 (against the extended-precision arbiter the
+    # HIP run follows the exact LM sequence as long as the oracle does or longer)
+    assert len(good) >= 0.85 * len(busy)
     assert med["final_cost_rel"] <= 1e-10 and med["pose_diff"] <= 1e-10 and med["point_diff"] <= 1e-9      # measured: 5e-13, 1.4e-13, 3.5e-12
     assert worst["max_iteration_cost_rel"] <= 2e-4 and worst["final_cost_rel"] <= 2e-4 and worst["pose_diff"] <= 1e-4   # measured: 1.5e-4, 2.5e-5, 1.7e-5 (the long global-BA runs)
     assert med["object_diff"] <= 1e-6 and worst["object_diff"] <= 1.0       # measured: 5e-8; 0.26 -- an object a window sees from a few frames only is weakly constrained along its viewing ray (yaw excluded altogether)
