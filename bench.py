@@ -21,6 +21,13 @@ own stream; `--hook torch` routes the same callback through torch.distributed in
 (`--config 4`); weak scaling: value = total LM iterations of all ranks / max-over-ranks time.  A monolithic global BA does not
 shard without exchanging the reduced system: `--config 3` with N > 1 runs N independent replicas, no data-path collective.
 
+`--config 5` (BASELINE.json configs[4], SURVEY.md 8e "config #5: 2 sessions per GPU"): `--sessions S` (default 16) sessions of 500 keyframes /
+50 000 features over ONE 200-object map, S / N per GPU, solved JOINTLY: every session is a handle (one host thread each), a rank's
+handles meet in obvi_rccl_group_* (libobvi_rccl.so: device sum over the rank's handles, ONE ncclAllReduce per collective, fan back), and
+all S sessions take the same LM decisions.  Strong scaling: the job is the same S sessions for every N; value = S x LM iterations of the
+joint solve / max-over-ranks time.  `--chain` instead runs the reference's own semantics of that config on one GPU: the sessions one
+after the other, each starting from the long-term map of its predecessor (ltm_trajectory_sequence_executor.py:45-92).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,6 +46,8 @@ CONFIGS = {
     3: dict(name="global-BA 2000 KF / 200 objects / 300k features", P=2000, L=300000, O=200, const_poses=1),
     31: dict(name="(diagnostic) config 3 without objects", P=2000, L=300000, O=0, const_poses=1),
     4: dict(name="500-KF local-BA windows, one per GPU, sharing 25 objects (RCCL all-reduce of the shared object blocks)", P=500, L=50000, O=25, const_poses=5, shared=True),
+    5: dict(name="config 5: %d concurrent sessions x (500 KF / 50k features) over one 200-object map, %d per GPU, joint solve (RCCL all-reduce of the shared map's blocks)",
+            P=500, L=50000, O=200, const_poses=1, shared=True, sessions=16),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MATRIX_PEAK_TF = 78.6   # MI355X datasheet FP64 matrix (== FP64 vector) rate; not in the guide's table
@@ -366,6 +375,335 @@ def dist_util_staged(dist):
     return dist_util.staged_allreduce(dist)
 
 
+def kernel_table(pst, level1, level2, peaks):
+    """Per-kernel rows of the JSON line from the two instrumented solves (obvi_ba_set_profiling 1: one HIP event pair per phase, the timed
+    schedule; 2: an event after every launch of the tile Cholesky, one stream): average launch, launches per factorising step, algorithmic
+    GB/s (SURVEY 8d split of B_step) or TFLOP/s with the fraction of the public and of the measured peak.  level1 / level2 = (before,
+    after) snapshots of obvi_ba_get_kernel_times.  Returns (table, phases)."""
+    n_r, n_b = pst["reproj_active"], pst["bbox_active"]
+    t3 = 64.0 ** 3
+    # algorithmic HBM bytes (SURVEY 8d split of B_step) or flops of ONE launch of each kernel
+    hbm = {
+        "point_pass": n_r * (32.0 + 144.0),            # read observations, write Z (6x3 fp64)
+        "pose_pass": n_r * 32.0,
+        "schur_window": n_r * 144.0,                   # every Z record once
+        "schur_blocks": None,                          # far pairs only: no per-observation figure
+        "point_backsub": n_r * 144.0,
+        "cost": n_r * 32.0,
+        "small_factors": n_b * (168.0 + 672.0),
+    }
+    # flops of ONE launch = the factorisation's total / the launches of that kernel per factorisation (chol_levels levels: a k_trsm and a
+    # k_update_potrf launch for every level but the last; the first level's potrf is its own launch)
+    nlaunch = max(pst["chol_levels"] - 1.0, 1.0)
+    flops = {
+        "k_trsm": pst["trsm_jobs"] * t3 / nlaunch,
+        # updates of a level + factor and inverse of the next level's diagonal tiles, one launch
+        "k_update_potrf": (pst["update_jobs"] * 2.0 * t3 + pst["tiles_per_dim"] * (2.0 * t3 / 3.0)) / nlaunch,
+    }
+
+    def delta(k1_, k0_):
+        out = {}
+        for name in k1_:
+            ms = k1_[name][0] - k0_.get(name, (0.0, 0))[0]
+            n = k1_[name][1] - k0_.get(name, (0.0, 0))[1]
+            if n > 0:
+                out[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
+        return out
+    phases = delta(level1[1], level1[0])
+    kern = delta(level2[1], level2[0])
+    kern.pop("cholesky_solve", None)           # replaced by its kernels
+    # steps of the instrumented solve that FACTORISE: the submission at the iteration cap linearises only (point pass, pose pass, small factors,
+    # diagonal blocks and nothing else), but the library counts a phase record for every submission -- so the factorising steps are counted
+    # from the launches of the tile Cholesky itself (levels - 1 launches of k_update_potrf per factorisation), and the phases that exist
+    # only in a factorising step are averaged over those (round 4 divided them by the submissions: 5 % low at 20 steps)
+    solve_only = ("schur_window", "schur_blocks", "point_backsub", "apply_step", "cost")
+    if "k_update_potrf" in kern and pst["chol_levels"] > 1:
+        steps_prof = max(1, int(round(kern["k_update_potrf"]["launches"] / (pst["chol_levels"] - 1.0))))
+    else:
+        steps_prof = max(1, (kern["point_backsub"]["launches"] if "point_backsub" in kern else kern["point_pass"]["launches"]) - 1)
+    for tab in (phases, kern):
+        for name in solve_only:
+            if name in tab and tab[name]["launches"] > steps_prof:
+                tab[name]["launches"] = steps_prof
+                tab[name]["ms_avg"] = tab[name]["ms_total"] / steps_prof
+    table = {}
+    for name, v in kern.items():
+        row = {"avg_us": round(1e3 * v["ms_avg"], 2), "launches_per_step": round(v["launches"] / steps_prof, 1), "ms_per_step": round(v["ms_total"] / steps_prof, 4)}
+        if name in phases and name in ("schur_window", "point_pass", "point_backsub", "cost"):
+            # the same kernel in the configuration that is TIMED (main stream of the uninstrumented schedule: the Schur kernel then runs
+            # beside the side stream's pose pass / small factors): start-to-next-phase on the main stream, level-1 events
+            row["in_situ_us"] = round(1e3 * phases[name]["ms_avg"], 2)
+        t_us = row.get("in_situ_us", row["avg_us"])
+        if hbm.get(name):
+            row.update(bound="hbm", achieved=round(hbm[name] / (t_us * 1e-6) / 1e9, 1), unit="GB/s")
+            row["frac"] = round(row["achieved"] / HBM_PEAK_GBS, 4)
+            row["frac_measured"] = round(row["achieved"] / peaks["hbm_triad_gbs"], 4)
+        elif name in flops:
+            row.update(bound="mfma", achieved=round(flops[name] / (v["ms_avg"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
+            row["frac"] = round(row["achieved"] / FP64_MATRIX_PEAK_TF, 4)
+            row["frac_measured"] = round(row["achieved"] / peaks["mfma_f64_issue_tflops"], 4)
+        table[name] = row
+    return table, phases
+
+
+def form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev):
+    """The job's communicator of libobvi_rccl.so (`--hook rccl`): rank 0's ncclUniqueId travels over the launcher's process group, the data
+    path then never touches Python.  Every rank must succeed, or every rank falls back to `--hook torch` (args.hook is rewritten): one rank
+    without the compiled hook must not leave the others waiting in a collective.  Returns (comm or None, {"libobvi_rccl": v, "torch": v})."""
+    def all_ranks_ok(flag):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=ddev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+    comm, rccl_versions = None, None
+    if args.hook == "rccl":
+        my_id, err = None, None
+        try:
+            # libobvi_rccl.so resolves /opt/rocm/lib/librccl while torch has mapped its own librccl.so: only the same build on both sides
+            ok, ours, theirs = dist_util.RcclComm.check_against_torch()
+            rccl_versions = {"libobvi_rccl": ours, "torch": theirs}
+            if not ok:
+                raise RuntimeError("libobvi_rccl.so resolves RCCL %s, torch.distributed uses %s" % (ours, theirs))
+            my_id = dist_util.RcclComm.unique_id()      # (every rank: shows that the library loads; rank 0's id is the job's)
+        except Exception as e:                          # noqa: BLE001 -- reported below, the run goes on with the other hook
+            err = e
+        if not all_ranks_ok(err is None):
+            if rank == 0:
+                print("bench.py: libobvi_rccl.so unusable on some rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
+            args.hook = "torch"
+    if args.hook == "rccl":
+        ids = [my_id if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
+        except Exception as e:                          # noqa: BLE001
+            comm, err = None, e
+        if not all_ranks_ok(comm is not None):
+            if comm is not None:
+                comm.close()
+            comm = None
+            if rank == 0:
+                print("bench.py: the RCCL communicator of libobvi_rccl.so could not be formed on every rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
+            args.hook = "torch"
+    return comm, rccl_versions
+
+
+def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world, dist, ddev):
+    """`--config 5`: S concurrent sessions over one object map, S / world per rank, one joint solve (module docstring)."""
+    import threading
+    cfg = CONFIGS[5]
+    S = args.sessions or cfg["sessions"]
+    if args.chain:
+        if world != 1:
+            raise SystemExit("bench.py --config 5 --chain: the chain is sequential by construction (session s starts from the map of s - 1): one GPU")
+        return run_session_chain(args, torch, obvi_ba, synth, S)
+    if S % world != 0 or S < world:
+        raise SystemExit("bench.py --config 5: --sessions %d is not a multiple of --gpus %d" % (S, world))
+    k = S // world
+    base = 20241008
+    mine = []
+    for m in range(k):
+        g = rank * k + m                                                # global session index = contributor index of the job
+        q = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(base, 5, g), const_poses=cfg["const_poses"], object_seed=base + 5, min_obj_obs=10)
+        if g != 0:                                                      # object-only factors of the shared map: contributor 0 alone
+            for key in ("sp_obj", "sp_mean", "sp_cov"):
+                q[key] = q[key][:0]
+        mine.append(q)
+    for q in mine[1:]:
+        assert np.array_equal(q["objects"], mine[0]["objects"])
+    n_obj = len(mine[0]["objects"])
+    issue_log = dist_util.IssueLog()
+    comm, rccl_versions, hook = None, None, "group"
+    if world > 1:
+        comm, rccl_versions = form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev)
+        hook = "group+" + args.hook
+    if comm is not None:
+        group = dist_util.RcclGroup(k, comm=comm)
+    elif world > 1:
+        inner = dist_util.staged_allreduce(dist, issue_log) if args.oversubscribe else dist_util.torch_allreduce(dist, issue_log)
+        group = dist_util.RcclGroup(k, inner=inner, rank=rank, world=world, device=local_rank)
+    else:
+        group = dist_util.RcclGroup(k, device=local_rank)
+    handles, upload_ms = [], 0.0
+    for m, q in enumerate(mine):
+        ba = obvi_ba.BundleAdjuster(device_id=local_rank)
+        t0 = time.perf_counter()
+        synth.upload(ba, q)
+        upload_ms += 1e3 * (time.perf_counter() - t0)
+        handles.append(ba)
+
+    def in_threads(fn):
+        out, err = [None] * k, [None] * k
+
+        def run(m):
+            try:
+                out[m] = fn(m)
+            except Exception as e:                                      # noqa: BLE001 -- re-raised on the main thread
+                err[m] = e
+        th = [threading.Thread(target=run, args=(m,)) for m in range(k)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # what one session costs alone on this GPU (no exchange attached: the shared objects are ordinary objects): the serial yardstick of the rank
+    alone = None
+    if rank == 0:
+        handles[0].evaluate(True, False)
+        if args.warmup > 0:
+            handles[0].solve(solver_params(obvi_ba, args.warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sa = handles[0].solve(solver_params(obvi_ba, args.steps))
+        torch.cuda.synchronize()
+        alone = 1e3 * (time.perf_counter() - t0) / max(1, sa.num_iterations - 1)
+        synth.upload(handles[0], mine[0])
+    is_shared = np.ones(n_obj, np.uint8)
+    for m, ba in enumerate(handles):
+        group.attach(m, ba, is_shared)
+    # symbolic phase of the rank's k sessions, all at once (HostPool runs the k plans concurrently)
+    t0 = time.perf_counter()
+    in_threads(lambda m: handles[m].evaluate(True, False))
+    symbolic_ms = 1e3 * (time.perf_counter() - t0)
+    if args.warmup > 0:
+        in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.warmup)))
+    barrier()
+    c0 = group.stats()
+    t0 = time.perf_counter()
+    summ = in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.steps)))
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = group.stats()
+    steps_done = min(sm.num_iterations for sm in summ) - 1
+    dt, steps_done = dist_util.reduce_timing(dist, ddev, dt, steps_done)
+    issue_order = None
+    if world > 1:
+        if comm is not None:
+            calls, same = comm.sequence()[0], comm.same_issue_order()
+        else:
+            calls, same = issue_log.calls, dist_util.same_issue_order(dist, issue_log.calls, issue_log.digest())
+        issue_order = {"collectives_issued": calls, "same_on_every_rank": bool(same)}
+        if not same:
+            raise SystemExit("bench.py: the ranks issued different sequences of collectives")
+    # device timings: the same steps twice more with events on (every handle runs them: the collectives need all contributors); rank 0 reads session 0
+    for ba in handles:
+        ba.set_profiling(1)
+    k0 = handles[0].kernel_times()
+    in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.steps)))
+    k1 = handles[0].kernel_times()
+    for ba in handles:
+        ba.set_profiling(2)
+    p0 = handles[0].kernel_times()
+    in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.steps)))
+    p1 = handles[0].kernel_times()
+    for ba in handles:
+        ba.set_profiling(0)
+    if rank == 0:
+        pst = handles[0].problem_stats()
+        peaks = handles[0].measure_peaks()
+        table, phases = kernel_table(pst, (k0, k1), (p0, p1), peaks)
+        dom = max(table, key=lambda kk: table[kk]["ms_per_step"])
+        d = table[dom]
+        ntail = -(-7 * n_obj // 64)
+        submissions = steps_done + 1                                    # every LM step + the linearisation-only submission behind the last one
+        sizes = {"shared_blocks": 8 * 56 * n_obj, "shared_tail": 8 * (ntail * (ntail + 1) // 2 * 64 * 64 + ntail * 64), "scalars": 8 * (9 + S)}
+        stats = [synth.problem_stats(q) for q in mine]
+        ms_step = 1e3 * dt / max(steps_done, 1)
+        out = {
+            "metric": "local-BA LM iterations/s (concurrent sessions sharing one object map, joint solve)", "value": S * steps_done / dt, "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"] % (S, k), "sessions": S, "sessions_per_rank": k, "keyframes": stats[0]["P"], "features": stats[0]["L"], "objects": n_obj,
+                       "reprojection_obs_per_session": stats[0]["N_r"], "bbox_obs_per_session": stats[0]["N_b"], "reduced_rows_per_session": int(pst["reduced_rows"]),
+                       "parallelism": "sessions x %d per GPU + group sum + all-reduce" % k if world > 1 else "sessions x %d on one GPU + group sum" % k,
+                       "rccl_ranks": (comm.world() if comm is not None else (dist.get_world_size() if dist is not None else 1)), "allreduce_hook": hook,
+                       "oversubscribed": bool(args.oversubscribe), "rccl_versions": rccl_versions, "collective_issue_order": issue_order, "steps_done": steps_done,
+                       "collectives_per_lm_step": round((c1[0] - c0[0] - 1) / max(1, submissions), 2),
+                       "collective_bytes": {"per_lm_step": int(8 * (c1[1] - c0[1]) / max(1, submissions)), "by_collective": sizes,
+                                            "note": "bytes a rank hands to the inter-rank all-reduce per LM step (the group's sum over its own sessions travels ONCE, whatever "
+                                                    "k is); the tail is the dense lower triangle of the shared map's reduced block: every session observes the map, so after "
+                                                    "eliminating a session's own poses every pair of map objects is coupled on every rank -- no tile of it is structurally "
+                                                    "zero on all ranks (DESIGN.md section 8)"},
+                       "final_cost_per_session": [sm.final_cost for sm in summ], "termination": summ[0].message.decode()},
+            "value_note": "value = sessions x LM iterations of the joint solve / max-over-ranks seconds (every session advances one iteration per joint step; config 4 counts "
+                          "its windows the same way); ms_per_step = one JOINT LM step of all %d sessions" % S,
+            "concurrency": {"one_session_alone_ms_per_step": round(alone, 4), "sessions_on_this_gpu": k, "joint_ms_per_step": round(ms_step, 4),
+                            "speedup_vs_serial": round(k * alone / ms_step, 3),
+                            "note": "k sessions of this GPU in k host threads, one stream pair each, against k x one session solved alone (no exchange): what running the "
+                                    "window-sized solves side by side buys on a device that one of them leaves mostly idle"},
+            "roofline": {"kernel": dom, "bound": d.get("bound", "hbm"), "achieved": d.get("achieved"), "peak": HBM_PEAK_GBS if d.get("bound", "hbm") == "hbm" else FP64_MATRIX_PEAK_TF,
+                         "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "frac_measured": d.get("frac_measured"), "traffic": None, "avg_launch_us": d["avg_us"],
+                         "peaks_measured": {kk: round(v, 2) for kk, v in peaks.items()},
+                         "note": "dominant kernel of session 0 on rank 0 by device time per LM step, HIP events in an instrumented solve of the same steps while the rank's other "
+                                 "sessions run beside it (their kernels share the device: launch durations include that); traffic: no PMC pass for this workload"},
+            "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
+            "host": {"upload_ms_all_sessions": round(upload_ms, 1), "symbolic_phase_ms_all_sessions_concurrently": round(symbolic_ms, 1)},
+        }
+        if not args.no_cpu_baseline:
+            q0 = dict(mine[0])
+            base_line = cpu_baseline(q0, legs={})
+            if base_line is not None:
+                base_line["sample"] = "ONE of the %d sessions alone (the joint step is %d of these plus the shared tail): " % (S, S) + base_line["sample"]
+                base_line.pop("parity_vs_oracle", None)
+            out["cpu_baseline"] = base_line
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+    for ba in handles:
+        ba.close()
+    group.close()
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_session_chain(args, torch, obvi_ba, synth, S):
+    """`--config 5 --chain`: the reference's semantics of the multi-session config (ltm_trajectory_sequence_executor.py:45-92): the sessions
+    one after the other on one GPU, session s starting from the long-term map (ellipsoid estimates + marginal covariances as
+    IndependentObjectMapFactor priors) that session s - 1 extracted.  A step here = one session (upload, two-phase BA, map extraction)."""
+    cfg = CONFIGS[5]
+    prm = obvi_ba.SolverParams(max_num_iterations=50, allow_non_monotonic_steps=True, function_tolerance=1e-4, gradient_tolerance=1e-10,
+                               parameter_tolerance=1e-8, initial_trust_region_radius=100.0, max_trust_region_radius=1e4)
+    g = obvi_ba.BundleAdjuster(device_id=0)
+    ltm, rows, iters, t_all = None, [], 0, 0.0
+    for sidx in range(S):
+        prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=1000 + sidx, object_seed=77, const_poses=1, min_obj_obs=10, object_classes=("bench",))
+        if ltm is not None:
+            prob["objects"][ltm[0]] = ltm[1]
+            prob.update(lt_obj=ltm[0].astype(np.uint32), lt_mean=ltm[1], lt_cov=ltm[2].reshape(-1, 49), lt_huber=1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        synth.upload(g, prob)
+        s1 = g.solve(prm)
+        mask, _ = g.select_outliers(0, 0.1)
+        g.set_active_mask(0, mask)
+        s2 = g.solve(prm)
+        g.set_active_mask(0, np.ones_like(mask))
+        ids = np.arange(len(prob["objects"]), dtype=np.uint32)
+        cov = g.object_covariances(ids)
+        est = g.get_objects()
+        dt = time.perf_counter() - t0
+        seen = np.abs(cov).max(axis=(1, 2)) > 0
+        err = np.linalg.norm(est[seen, :3] - prob["gt_objects"][seen, :3], axis=1)
+        rows.append({"session": sidx, "ms": round(1e3 * dt, 2), "lm_iterations": int(s1.num_iterations + s2.num_iterations - 2), "objects_mapped": int(seen.sum()),
+                     "centre_error_median_m": round(float(np.median(err)), 4)})
+        iters += s1.num_iterations + s2.num_iterations - 2
+        t_all += dt
+        ltm = (ids[seen], est[seen], cov[seen])
+    print(json.dumps({"metric": "local-BA LM iterations/s (sessions chained through the long-term map)", "value": iters / t_all, "unit": "LM iterations/s", "n_gpus": 1,
+                      "steps": S, "warmup": 0, "ms_per_step": 1e3 * t_all / S, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "config 5 (chain): %d sessions x (500 KF / 50k features) over one 200-object map, one after the other through the long-term map" % S,
+                                 "sessions": S, "step": "one session: upload + two-phase BA + map extraction"}, "sessions": rows}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +715,8 @@ def main():
                     help="N > 1 on ONE GPU: every rank uses device 0, the process group is gloo and the exchange goes through dist_util.staged_allreduce "
                          "(device -> host -> gloo -> device).  Not a measurement of scaling: it exercises the whole N > 1 code path of this script where "
                          "only one GPU exists (tests/test_gpu_shared_objects.py runs it)")
+    ap.add_argument("--sessions", type=int, default=None, help="config 5: total number of sessions of the job (default 16; must be a multiple of --gpus)")
+    ap.add_argument("--chain", action="store_true", help="config 5 the reference's way: sessions one after the other through the long-term map, one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the deterministic-mode timing of the same steps")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end two-phase global BA (config 3, one GPU; about 2 s)")
@@ -419,6 +759,9 @@ def main():
     if args.config is None:
         args.config = 3 if world == 1 else 4
 
+    if args.config == 5:
+        run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world, dist, ddev)
+        return
     cfg = CONFIGS[args.config]
     shared = bool(cfg.get("shared")) and world > 1
     prob = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(20241008, args.config, rank), const_poses=cfg["const_poses"],
@@ -456,40 +799,7 @@ def main():
         synth.upload(ba, prob)      # back to the initial values for the group solve
     if shared:
         is_shared = np.ones(len(prob["objects"]), np.uint8)
-        def all_ranks_ok(flag):     # one rank without the compiled hook must not leave the others waiting in a collective
-            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=ddev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item() > 0.5)
-        if args.hook == "rccl":
-            # the job's ncclUniqueId travels over the launcher's process group; the data path then never touches Python
-            my_id, err = None, None
-            try:
-                # libobvi_rccl.so resolves /opt/rocm/lib/librccl while torch has mapped its own librccl.so: only the same build on both sides
-                ok, ours, theirs = dist_util.RcclComm.check_against_torch()
-                rccl_versions = {"libobvi_rccl": ours, "torch": theirs}
-                if not ok:
-                    raise RuntimeError("libobvi_rccl.so resolves RCCL %s, torch.distributed uses %s" % (ours, theirs))
-                my_id = dist_util.RcclComm.unique_id()      # (every rank: shows that the library loads; rank 0's id is the job's)
-            except Exception as e:                          # noqa: BLE001 -- reported below, the run goes on with the other hook
-                err = e
-            if not all_ranks_ok(err is None):
-                if rank == 0:
-                    print("bench.py: libobvi_rccl.so unusable on some rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
-                args.hook = "torch"
-        if args.hook == "rccl":
-            ids = [my_id if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            try:
-                comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
-            except Exception as e:                          # noqa: BLE001
-                comm, err = None, e
-            if not all_ranks_ok(comm is not None):
-                if comm is not None:
-                    comm.close()
-                comm = None
-                if rank == 0:
-                    print("bench.py: the RCCL communicator of libobvi_rccl.so could not be formed on every rank (%r): falling back to --hook torch" % (err,), file=sys.stderr)
-                args.hook = "torch"
+        comm, rccl_versions = form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev)
         if args.hook == "rccl":
             comm.attach(ba, is_shared)
             rccl_ranks = comm.world()
@@ -547,56 +857,8 @@ def main():
     if rank == 0:
         pst = ba.problem_stats()
         n_r, n_b = pst["reproj_active"], pst["bbox_active"]
-        t3 = 64.0 ** 3
-        # algorithmic HBM bytes (SURVEY 8d split of B_step) or flops of ONE launch of each kernel
-        hbm = {
-            "point_pass": n_r * (32.0 + 144.0),            # read observations, write Z (6x3 fp64)
-            "pose_pass": n_r * 32.0,
-            "schur_window": n_r * 144.0,                   # every Z record once
-            "schur_blocks": None,                          # far pairs only: no per-observation figure
-            "point_backsub": n_r * 144.0,
-            "cost": n_r * 32.0,
-            "small_factors": n_b * (168.0 + 672.0),
-        }
-        # flops of ONE launch = the factorisation's total / the launches of that kernel per factorisation (chol_levels levels: a k_trsm and a
-        # k_update_potrf launch for every level but the last; the first level's potrf is its own launch)
-        nlaunch = max(pst["chol_levels"] - 1.0, 1.0)
-        flops = {
-            "k_trsm": pst["trsm_jobs"] * t3 / nlaunch,
-            # updates of a level + factor and inverse of the next level's diagonal tiles, one launch
-            "k_update_potrf": (pst["update_jobs"] * 2.0 * t3 + pst["tiles_per_dim"] * (2.0 * t3 / 3.0)) / nlaunch,
-        }
-        def delta(k1_, k0_):
-            out = {}
-            for name in k1_:
-                ms = k1_[name][0] - k0_.get(name, (0.0, 0))[0]
-                n = k1_[name][1] - k0_.get(name, (0.0, 0))[1]
-                if n > 0:
-                    out[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
-            return out
         peaks = ba.measure_peaks()   # triad / copy / read GB/s and the fp64 MFMA rates of THIS device (obvi_ba_measure_peaks)
-        phases = delta(k1, k0)
-        kern = delta(p1, p0)
-        kern.pop("cholesky_solve", None)           # replaced by its kernels
-        # steps of the instrumented solve that factorise (the submission at the iteration cap linearises only: it has a point pass and nothing else)
-        steps_prof = max(1, kern["point_backsub"]["launches"] if "point_backsub" in kern else kern["point_pass"]["launches"])
-        table = {}
-        for name, v in kern.items():
-            row = {"avg_us": round(1e3 * v["ms_avg"], 2), "launches_per_step": round(v["launches"] / steps_prof, 1), "ms_per_step": round(v["ms_total"] / steps_prof, 4)}
-            if name in phases and name in ("schur_window", "point_pass", "point_backsub", "cost"):
-                # the same kernel in the configuration that is TIMED (main stream of the uninstrumented schedule: the Schur kernel then runs
-                # beside the side stream's pose pass / small factors): start-to-next-phase on the main stream, level-1 events
-                row["in_situ_us"] = round(1e3 * phases[name]["ms_avg"], 2)
-            t_us = row.get("in_situ_us", row["avg_us"])
-            if hbm.get(name):
-                row.update(bound="hbm", achieved=round(hbm[name] / (t_us * 1e-6) / 1e9, 1), unit="GB/s")
-                row["frac"] = round(row["achieved"] / HBM_PEAK_GBS, 4)
-                row["frac_measured"] = round(row["achieved"] / peaks["hbm_triad_gbs"], 4)
-            elif name in flops:
-                row.update(bound="mfma", achieved=round(flops[name] / (v["ms_avg"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
-                row["frac"] = round(row["achieved"] / FP64_MATRIX_PEAK_TF, 4)
-                row["frac_measured"] = round(row["achieved"] / peaks["mfma_f64_issue_tflops"], 4)
-            table[name] = row
+        table, phases = kernel_table(pst, (k0, k1), (p0, p1), peaks)
         dom = max(table, key=lambda k: table[k]["ms_per_step"])
         d = table[dom]
         man, stale = profile_manifest()

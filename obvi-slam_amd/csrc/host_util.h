@@ -115,10 +115,12 @@ class DevBuf {
 // Worker threads of the host's symbolic phase and upload sorts, started once per process: a sliding-window session builds a plan per
 // window (a millisecond of work in ranges of points), and starting and joining std::threads for every range cost as much as the
 // ranges themselves.  run(parts, fn) calls fn(0) ... fn(parts - 1), each exactly once, on the workers and on the calling thread, and
-// returns when all are done; calls from different threads (one handle per thread) are serialised.  Workers spin briefly before they
-// sleep, so that back-to-back calls do not pay a wake-up each.
+// returns when all are done.  Calls from different threads (one handle per thread: several sessions of one process, config #5) run
+// CONCURRENTLY: every call publishes its own job, a free worker enters any published job that still has parts to hand out, and a
+// caller always works on its own job, so no call waits for another one (round 4 serialised them behind one mutex: k handles planning at
+// once queued).  Workers spin briefly before they sleep, so that back-to-back calls do not pay a wake-up each.
 // A call is ONE immutable job record (function, part count, its own hand-out and completion counters) on the caller's stack, published
-// through job_ under the mutex.  A worker enters a job only under that mutex (and is counted in job->inside while it holds the pointer);
+// in jobs_ under the mutex.  A worker enters a job only under that mutex (and is counted in job->inside while it holds the pointer);
 // run() unpublishes the job under the same mutex and leaves only when every part is done AND no worker is inside any more, so a part
 // index never travels from one job to the next and nothing of a finished job is touched after run() has returned.
 class HostPool {
@@ -138,17 +140,19 @@ class HostPool {
   int workers() const { return (int)threads_.size(); }
   void run(int parts, const std::function<void(int)>& fn) {
     if (parts <= 1 || threads_.empty()) { for (int i = 0; i < parts; ++i) fn(i); return; }
-    std::lock_guard<std::mutex> serial(callers_);
     Job job(&fn, parts);
     {
       std::lock_guard<std::mutex> lock(m_);
-      job_ = &job;
+      jobs_.push_back(&job);
       gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     take(job);
     while (job.left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
-    { std::lock_guard<std::mutex> lock(m_); job_ = nullptr; }                               // nobody enters from here on
+    {                                                                                       // nobody enters from here on
+      std::lock_guard<std::mutex> lock(m_);
+      for (size_t i = 0; i < jobs_.size(); ++i) if (jobs_[i] == &job) { jobs_.erase(jobs_.begin() + (std::ptrdiff_t)i); break; }
+    }
     while (job.inside.load(std::memory_order_acquire) != 0) std::this_thread::yield();     // ... and those who did have left
   }
 
@@ -195,25 +199,25 @@ class HostPool {
         __builtin_ia32_pause();
 #endif
       }
-      Job* job;
+      Job* job = nullptr;
       {
         std::unique_lock<std::mutex> lock(m_);
         cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-        seen = gen_.load(std::memory_order_acquire);
         if (stop_) return;
-        job = job_;
-        if (job == nullptr) continue;                          // the job of this generation is already over
+        for (Job* j : jobs_) if (j->next.load(std::memory_order_acquire) < j->parts) { job = j; break; }   // any caller's job with parts left
+        if (job == nullptr) { seen = gen_.load(std::memory_order_acquire); continue; }                    // nothing to do for this generation
         job->inside.fetch_add(1, std::memory_order_acq_rel);   // counted while the pointer is held: run() waits for zero
       }
       take(*job);
       job->inside.fetch_sub(1, std::memory_order_release);
+      // `seen` stays: the next round looks for another caller's job before it sleeps
     }
   }
   std::vector<std::thread> threads_;
-  std::mutex m_, callers_;
+  std::mutex m_;
   std::condition_variable cv_;
   std::atomic<uint64_t> gen_{0};
-  Job* job_ = nullptr;   // guarded by m_
+  std::vector<Job*> jobs_;   // published jobs, guarded by m_
   bool stop_ = false;
 };
 

@@ -1674,8 +1674,8 @@ int obvi_ba_reset(obvi_ba_handle* h) {
   for (auto& v : h->phase_launches) v = 0;
   for (auto& v : h->ck_ms) v = 0.0;
   for (auto& v : h->ck_launches) v = 0;
-  h->fused_potrf = true; h->potrf_wait_timeouts = 0;
-  if (const char* env = std::getenv("OBVI_FUSED_POTRF")) h->fused_potrf = std::atoi(env) != 0;
+  // fused_potrf / potrf_wait_timeouts stay: a wait time-out of the fused kernel is a property of the device and runtime (dispatch order), not of
+  // the problem -- a pooled handle that learned it does not pay the on-device wait again at every reuse
   h->dirty = true; h->mask_dirty = false;
   h->err.clear();
   return OBVI_OK;
@@ -2361,7 +2361,8 @@ namespace {
 // unless the threshold route has to hand over to the sort (more than 4096 distinct values sharing their top 24 bits)
 void run_selection(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t* act, const uint32_t* inv, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   h->d_sel_mask.resize((size_t)n + 1);
-  static const bool sort_route = std::getenv("OBVI_SELECT_SORT") && std::atoi(std::getenv("OBVI_SELECT_SORT")) != 0;   // route (b) always (its check)
+  const char* sort_env = std::getenv("OBVI_SELECT_SORT");   // read per call: a host (or a test) may set it after the first selection of the process
+  const bool sort_route = sort_env != nullptr && std::atoi(sort_env) != 0;   // route (b) always (its check)
   int n_out = 0;
   bool done = false;
   if (!sort_route) {
@@ -2392,6 +2393,7 @@ void run_selection(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t
 int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t type, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   if (!h || !mask_out) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));   // (the evaluate below is skipped when the previous call already left the norms: this path allocates and launches as well)
   // un-robustified per-block squared norms at the current estimate (object_pose_graph_optimizer.h:682-693), kept on the device; the
   // runner selects for one factor type after the other (offline_problem_runner.h:769-800): the second call finds them in place
   const uint64_t this_call = h->api_calls;

@@ -230,3 +230,86 @@ class RcclComm:
             self._lib.obvi_rccl_comm_destroy.restype = None
             self._lib.obvi_rccl_comm_destroy(self._c)
             self._c = C.c_void_p()
+
+
+class RcclGroup:
+    """ctypes binding of the obvi_rccl_group_* part of include/obvi_rccl.h: k handles of THIS process (one host thread each) behind one
+    inter-rank all-reduce per collective (config #5: sessions over one object map, 16 / N of them per GPU).  The inter-rank step is a
+    communicator of libobvi_rccl.so (`comm`), any Python hook of the obvi_ba_set_allreduce shape (`inner`: torch_allreduce /
+    staged_allreduce above), or nothing (a job of one rank)."""
+
+    def __init__(self, n_members, comm=None, inner=None, rank=0, world=1, device=0, library=None):
+        import obvi_ba
+        self._lib = C.CDLL(RcclComm.library_path(library))
+        self._g = C.c_void_p()
+        self._keep = []
+        self.n_members = n_members
+        if comm is not None:
+            rc = self._lib.obvi_rccl_group_create_on_comm(comm._c, C.c_int32(n_members), C.byref(self._g))
+            self.rank, self.world = comm.rank, comm.world_requested
+        else:
+            cb = C.cast(None, obvi_ba.ALLREDUCE_FN) if inner is None else obvi_ba.ALLREDUCE_FN(lambda user, buf, count, op, stream: int(inner(buf or 0, count, op, stream or 0)))
+            self._keep.append(cb)
+            rc = self._lib.obvi_rccl_group_create(cb, None, C.c_int32(rank), C.c_int32(world), C.c_int32(n_members), C.c_int32(device), C.byref(self._g))
+            self.rank, self.world = rank, world
+        if rc != 0:
+            raise RuntimeError("obvi_rccl_group_create failed: status %d" % rc)
+
+    def attach(self, member, ba, is_shared):
+        """The handle becomes contributor rank * k + member of world * k (obvi_ba_set_shared_objects) and exchanges through the group."""
+        import numpy as np
+        m = None if is_shared is None else np.ascontiguousarray(is_shared, dtype=np.uint8)
+        rc = self._lib.obvi_rccl_group_attach(self._g, C.c_int32(member), ba._h, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            raise RuntimeError("obvi_rccl_group_attach failed: status %d" % rc)
+        self._keep.append(m)
+
+    def set_timeout(self, seconds):
+        self._lib.obvi_rccl_group_set_timeout.restype = None
+        self._lib.obvi_rccl_group_set_timeout(self._g, C.c_double(seconds))
+
+    def stats(self):
+        """(collectives completed, doubles carried between ranks)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        if self._lib.obvi_rccl_group_stats(self._g, C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError("obvi_rccl_group_stats failed")
+        return int(a.value), int(b.value)
+
+    def close(self):
+        if self._g:
+            self._lib.obvi_rccl_group_destroy.restype = None
+            self._lib.obvi_rccl_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+
+class HostGroup:
+    """The group for libraries whose exchange buffers live in HOST memory (the CPU oracle; tests/test_distributed_gloo.py): k handles of this
+    process, one thread each; per collective the last one to arrive sums / maximises the k buffers, runs ONE inter-rank all-reduce
+    (`inner`, e.g. host_allreduce(dist); None = one rank) and copies the result back into every buffer.  Test plumbing."""
+
+    def __init__(self, n_members, inner=None, timeout_s=300.0):
+        import threading
+        self.n, self.inner, self.timeout_s = n_members, inner, timeout_s
+        self._bar = threading.Barrier(n_members)
+        self._slots = [None] * n_members
+        self.collectives, self.doubles = 0, 0
+
+    def hook(self, member):
+        import numpy as np
+
+        def fn(ptr, count, op, stream):
+            self._slots[member] = np.ctypeslib.as_array((C.c_double * int(count)).from_address(int(ptr)))
+            self._bar.wait(self.timeout_s)
+            if member == 0:
+                st = np.stack(self._slots)
+                acc = st.max(0) if op else st.sum(0)
+                if self.inner is not None:
+                    acc = np.ascontiguousarray(acc)
+                    self.inner(acc.ctypes.data, count, op, stream)
+                for s in self._slots:
+                    s[:] = acc
+                self.collectives += 1
+                self.doubles += int(count)
+            self._bar.wait(self.timeout_s)
+            return 0
+        return fn

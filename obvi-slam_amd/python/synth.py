@@ -347,3 +347,52 @@ def dump_flat(prob, path, max_it=3, nonmono=True, ftol=0.0, gtol=0.0, ptol=0.0, 
         scal(f, prob.get("rl_huber", 1.0))
         for v in (max_it, int(nonmono), ftol, gtol, ptol, radius, max_radius):
             scal(f, v)
+
+
+def make_sessions(n_sessions, P, L, O, seed0, object_seed, **kw):
+    """BASELINE configs[4] (config #5), concurrent form: `n_sessions` sessions over one place -- own trajectory noise, features and
+    sightings each (seed0 + s), ONE object map (object_seed: same objects, same initial estimates in every session).  The object-only
+    factors (shape priors) of the shared map are carried by session 0 alone, as obvi_ba_set_shared_objects asks."""
+    out = []
+    for s in range(n_sessions):
+        q = make_problem(P=P, L=L, O=O, seed=seed0 + s, object_seed=object_seed, **kw)
+        if s != 0:
+            for k in ("sp_obj", "sp_mean", "sp_cov"):
+                q[k] = q[k][:0]
+        out.append(q)
+    for q in out[1:]:
+        assert np.array_equal(q["objects"], out[0]["objects"]), "sessions of one map must start from the same object estimates"
+    return out
+
+
+def join_problems(probs):
+    """The joint problem of sessions that share one object map: poses, features and every factor of every session in ONE problem (pose and
+    feature indices shifted session by session, objects unchanged) -- what the sharded solve of the sessions must equal."""
+    j = dict(probs[0])
+    p_off = np.cumsum([0] + [len(q["poses"]) for q in probs])
+    l_off = np.cumsum([0] + [len(q["points"]) for q in probs])
+
+    def cat(key, offs=None, dtype=None):
+        parts = []
+        for s, q in enumerate(probs):
+            a = np.asarray(q[key])
+            parts.append(a if offs is None else (a.astype(np.int64) + offs[s]))
+        a = np.concatenate(parts, axis=0)
+        return a.astype(dtype) if dtype is not None else a
+    j.update(poses=cat("poses"), pose_const=cat("pose_const"), points=cat("points"), point_const=cat("point_const"),
+             rp_pose=cat("rp_pose", p_off, np.uint32), rp_point=cat("rp_point", l_off, np.uint32), rp_cam=cat("rp_cam"), rp_pixel=cat("rp_pixel"),
+             bb_obj=cat("bb_obj"), bb_pose=cat("bb_pose", p_off, np.uint32), bb_cam=cat("bb_cam"), bb_corners=cat("bb_corners"), bb_cov=cat("bb_cov"),
+             sp_obj=cat("sp_obj"), sp_mean=cat("sp_mean"), sp_cov=cat("sp_cov"))
+    if np.ndim(probs[0]["rp_sigma"]) > 0:
+        j["rp_sigma"] = cat("rp_sigma")
+    for k in ("gt_poses", "gt_points", "rp_is_outlier"):
+        if k in probs[0]:
+            j[k] = cat(k)
+    if "rl_a" in probs[0]:
+        j.update(rl_a=cat("rl_a", p_off, np.uint32), rl_b=cat("rl_b", p_off, np.uint32), rl_t=cat("rl_t"), rl_aa=cat("rl_aa"), rl_cov=cat("rl_cov"))
+    if any("lt_obj" in q for q in probs):
+        have = [q for q in probs if "lt_obj" in q]
+        j.update(lt_obj=np.concatenate([q["lt_obj"] for q in have]), lt_mean=np.concatenate([q["lt_mean"] for q in have]),
+                 lt_cov=np.concatenate([q["lt_cov"] for q in have]), lt_huber=have[0]["lt_huber"])
+    j["session_pose_offsets"], j["session_point_offsets"] = p_off, l_off
+    return j

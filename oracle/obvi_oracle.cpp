@@ -60,6 +60,10 @@
 #include "oracle_factors.h"
 #undef double
 #undef oracle
+// the substitution really took effect: a factor-level type of the second inclusion carries long double members (a silent miss would give a
+// "arbiter" that shares the checker's fp64 factor records)
+static_assert(sizeof(oracle_x::CameraConst{}.fx) == sizeof(long double) && sizeof(oracle::CameraConst{}.fx) == sizeof(double) && sizeof(long double) > sizeof(double),
+              "arbiter build: oracle_factors.h was not re-instantiated in extended precision");
 #endif
 
 namespace {

@@ -122,3 +122,77 @@ def test_shared_objects_on_one_rank_are_the_plain_solve():
     assert calls and all(op == 0 for _, op in calls)
     assert ss.num_iterations == sp.num_iterations and abs(ss.final_cost - sp.final_cost) <= 1e-9 * sp.final_cost
     assert np.abs(shared.get_poses() - plain.get_poses()).max() < 1e-8 and np.abs(shared.get_objects() - plain.get_objects()).max() < 1e-7
+
+
+# ---- config #5 in small: sessions over ONE object map, several handles per rank ("config #5: 2 sessions per GPU") -------------
+
+SESSIONS = dict(n_sessions=4, P=60, L=900, O=3, seed0=500, object_seed=33, min_obj_obs=6, object_classes=("bench",), bbox_noise=5.0)
+
+
+def _sessions():
+    import synth
+    return synth.make_sessions(**SESSIONS)
+
+
+def _session_group_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, os.path.join(helpers.ROOT, "obvi-slam_amd", "python")); sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
+    import threading
+    import numpy as np
+    import dist_util, synth
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    sessions = _sessions()
+    k = len(sessions) // world                                     # sessions per rank
+    log = dist_util.IssueLog()
+    group = dist_util.HostGroup(k, inner=dist_util.host_allreduce(dist, log))
+    handles, res = [], [None] * k
+    for m in range(k):
+        q = sessions[rank * k + m]
+        o = helpers.oracle_ba(); synth.upload(o, q)
+        o.set_shared_objects(np.ones(len(q["objects"]), np.uint8), rank * k + m, world * k)   # contributor rank * k + m of world * k
+        o.set_allreduce(group.hook(m))
+        handles.append(o)
+
+    def run(m):
+        res[m] = handles[m].solve(helpers.ba_params(max_it=15))
+    th = [threading.Thread(target=run, args=(m,)) for m in range(k)]
+    [t.start() for t in th]; [t.join(timeout=600) for t in th]
+    same = dist_util.same_issue_order(dist, log.calls, log.digest())
+    out[rank] = dict(ok=all(r is not None for r in res), same=same, inter_rank_calls=log.calls, group_collectives=group.collectives,
+                     members=[dict(iterations=r.num_iterations, termination=r.termination_type, initial=r.initial_cost, final=r.final_cost,
+                                   its=[(i.step_is_successful, i.cost, i.step_norm, i.gradient_max_norm) for i in h.iterations()],
+                                   poses=h.get_poses(), points=h.get_points(), objects=h.get_objects()) for r, h in zip(res, handles)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_sessions_two_per_rank_over_gloo_land_on_the_joint_solve():
+    """Config #5 as SURVEY 8e states it, on the CPU: four sessions over one object map, TWO per rank (two gloo ranks, two oracle handles each,
+    one thread per handle), every object shared.  Per collective a rank first sums its own handles' buffers (dist_util.HostGroup, the host
+    twin of obvi_rccl_group_*), then ONE inter-rank all-reduce carries the sum.  Every handle must follow the oracle's solve of the JOINT
+    problem (all four sessions in one problem) step for step and land on its poses, features and objects."""
+    import numpy as np
+    import synth
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_session_group_worker, args=(world, port, out), nprocs=world, join=True)
+    sessions = _sessions()
+    joint = synth.join_problems(sessions)
+    ref = helpers.oracle_ba(); synth.upload(ref, joint)
+    sref = ref.solve(helpers.ba_params(max_it=15))
+    jits = ref.iterations()
+    jp, jo, jpts = ref.get_poses(), ref.get_objects(), ref.get_points()
+    po, lo = joint["session_pose_offsets"], joint["session_point_offsets"]
+    assert set(out.keys()) == {0, 1} and all(out[r]["ok"] and out[r]["same"] for r in (0, 1))
+    # one inter-rank collective per group collective: two handles per rank do not double the traffic between ranks
+    assert out[0]["inter_rank_calls"] == out[0]["group_collectives"] == out[1]["inter_rank_calls"] >= 1 + 3 * (sref.num_iterations - 1)
+    for rank in (0, 1):
+        for m, o in enumerate(out[rank]["members"]):
+            s = rank * 2 + m
+            assert o["iterations"] == sref.num_iterations and o["termination"] == sref.termination_type
+            assert abs(o["initial"] - sref.initial_cost) <= 1e-12 * sref.initial_cost and abs(o["final"] - sref.final_cost) <= 1e-8 * sref.final_cost
+            for (ok, cost, step, gmax), j in zip(o["its"], jits):
+                assert ok == j.step_is_successful and abs(cost - j.cost) <= 1e-8 * j.cost
+                assert abs(step - j.step_norm) <= 1e-6 * max(j.step_norm, 1e-12) and abs(gmax - j.gradient_max_norm) <= 1e-6 * j.gradient_max_norm
+            assert np.abs(o["poses"] - jp[po[s]:po[s + 1]]).max() < 1e-8 and np.abs(o["points"] - jpts[lo[s]:lo[s + 1]]).max() < 1e-7
+            assert np.abs(o["objects"] - jo).max() < 1e-7 and np.array_equal(o["objects"], out[0]["members"][0]["objects"])

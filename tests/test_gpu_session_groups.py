@@ -1,0 +1,197 @@
+"""GPU (-m gpu): BASELINE configs[4] (config #5) as north_star and SURVEY 8e state it -- CONCURRENT sessions over one object map, several
+per GPU, one joint solve.  A rank owns k handles (one host thread each); `obvi_rccl_group_*` (include/obvi_rccl.h) sums their exchange
+buffers on the device, runs ONE inter-rank all-reduce per collective and hands the result back to every handle.
+
+Parity is against the CPU ORACLE solving the same joint problem (all sessions in one problem), as SURVEY 8e asks.  The reference itself has
+no counterpart: it chains its sessions one after the other (ltm_trajectory_sequence_executor.py:45-92; that chain is
+tests/test_gpu_multi_session.py and `bench.py --config 5 --chain`)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import dist_util
+import helpers
+import obvi_ba
+import synth
+
+pytestmark = pytest.mark.gpu
+
+SESSIONS = dict(n_sessions=4, P=60, L=900, O=3, seed0=500, object_seed=33, min_obj_obs=6, object_classes=("bench",), bbox_noise=5.0)
+
+
+@pytest.fixture(scope="module")
+def sessions():
+    return synth.make_sessions(**SESSIONS)
+
+
+@pytest.fixture(scope="module")
+def joint_reference(sessions):
+    joint = synth.join_problems(sessions)
+    orc = helpers.oracle_ba()
+    synth.upload(orc, joint)
+    s = orc.solve(helpers.ba_params(max_it=15))
+    return dict(joint=joint, summary=s, its=orc.iterations(), poses=orc.get_poses(), objects=orc.get_objects(), points=orc.get_points())
+
+
+def check_member_against_joint(ref, s, summary, its, poses, points, objects):
+    """Session s of the sharded solve against the oracle's joint solve: tolerances of tests/test_gpu_shared_objects.py."""
+    sref, jits, joint = ref["summary"], ref["its"], ref["joint"]
+    po, lo = joint["session_pose_offsets"], joint["session_point_offsets"]
+    assert summary["num_iterations"] == sref.num_iterations and summary["termination_type"] == sref.termination_type
+    assert abs(summary["initial_cost"] - sref.initial_cost) <= 1e-10 * sref.initial_cost and abs(summary["final_cost"] - sref.final_cost) <= 1e-8 * sref.final_cost
+    assert [i[0] for i in its] == [i.step_is_successful for i in jits]
+    assert max(abs(a[1] - b.cost) / b.cost for a, b in zip(its, jits)) < 1e-8
+    assert np.abs(poses - ref["poses"][po[s]:po[s + 1]]).max() < 1e-8
+    assert np.abs(points - ref["points"][lo[s]:lo[s + 1]]).max() < 1e-7
+    assert np.abs(objects - ref["objects"]).max() < 1e-7
+
+
+def solve_in_threads(handles, prm):
+    out = [None] * len(handles)
+
+    def run(m):
+        out[m] = handles[m].solve(prm)
+    th = [threading.Thread(target=run, args=(m,)) for m in range(len(handles))]
+    [t.start() for t in th]; [t.join(timeout=600) for t in th]
+    return out
+
+
+def test_four_sessions_on_one_rank_through_the_compiled_group(sessions, joint_reference):
+    """One process, one GPU, FOUR handles behind one group with no inter-rank step: the group's device sum is the whole exchange (what
+    `bench.py --config 5` runs at N = 1 with sixteen).  No Python in the exchange: the callback is obvi_rccl_group_allreduce."""
+    group = dist_util.RcclGroup(len(sessions))
+    try:
+        handles = []
+        for m, q in enumerate(sessions):
+            ba = helpers.product_ba()
+            synth.upload(ba, q)
+            group.attach(m, ba, np.ones(len(q["objects"]), np.uint8))
+            handles.append(ba)
+        out = solve_in_threads(handles, helpers.ba_params(max_it=15))
+        assert all(o is not None for o in out)
+        n_coll, n_doubles = group.stats()
+        sref = joint_reference["summary"]
+        assert n_coll >= 1 + 3 * (sref.num_iterations - 1) and n_doubles > 56 * 3 * (sref.num_iterations - 1)
+        for m, (o, ba) in enumerate(zip(out, handles)):
+            check_member_against_joint(joint_reference, m, dict(num_iterations=o.num_iterations, termination_type=o.termination_type, initial_cost=o.initial_cost, final_cost=o.final_cost),
+                                       [(i.step_is_successful, i.cost) for i in ba.iterations()], ba.get_poses(), ba.get_points(), ba.get_objects())
+            assert np.array_equal(ba.get_objects(), handles[0].get_objects())       # every session holds the same map
+        # the same group again: a second solve from the solution takes the same decisions on every member (the group's rounds stay aligned)
+        out2 = solve_in_threads(handles, helpers.ba_params(max_it=3))
+        assert len({o.num_iterations for o in out2}) == 1 and len({o.final_cost for o in out2}) == 1
+        for ba in handles:
+            ba.close()
+    finally:
+        group.close()
+
+
+def _group_worker(rank, world, port, sessions, prm_kw, out):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(helpers.ROOT, "obvi-slam_amd", "python")); sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    k = len(sessions) // world
+    log = dist_util.IssueLog()
+    group = dist_util.RcclGroup(k, inner=dist_util.staged_allreduce(dist, log), rank=rank, world=world, device=0)
+    handles = []
+    for m in range(k):
+        q = sessions[rank * k + m]
+        ba = helpers.product_ba()
+        synth.upload(ba, q)
+        group.attach(m, ba, np.ones(len(q["objects"]), np.uint8))
+        handles.append(ba)
+    res = solve_in_threads(handles, helpers.ba_params(**prm_kw))
+    same = dist_util.same_issue_order(dist, log.calls, log.digest())
+    out[rank] = dict(same=same, inter_rank_calls=log.calls, group=group.stats(),
+                     members=[dict(summary=dict(num_iterations=r.num_iterations, termination_type=r.termination_type, initial_cost=r.initial_cost, final_cost=r.final_cost),
+                                   its=[(i.step_is_successful, i.cost) for i in h.iterations()], poses=h.get_poses(), points=h.get_points(), objects=h.get_objects())
+                              for r, h in zip(res, handles)])
+    for h in handles:
+        h.close()
+    group.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_sessions_as_two_ranks_of_two_handles_land_on_the_oracles_joint_solve(sessions, joint_reference):
+    """VERDICT r4 item 1, done-criterion: 4 sessions x 60 keyframes over one map as 2 ranks x 2 handles.  Two processes (both on this GPU: RCCL
+    will not form a communicator of two ranks on one device, so the inter-rank step of each rank's group is the staged gloo all-reduce),
+    two handles per process behind obvi_rccl_group_*: ONE inter-rank collective per group collective, and every one of the four handles
+    lands on the oracle's solve of the joint problem."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_group_worker, args=(2, port, sessions, dict(max_it=15), out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    sref = joint_reference["summary"]
+    for rank in (0, 1):
+        o = out[rank]
+        assert o["same"] and o["inter_rank_calls"] == o["group"][0] >= 1 + 3 * (sref.num_iterations - 1)      # two handles per rank, one collective between ranks
+        for m, mem in enumerate(o["members"]):
+            check_member_against_joint(joint_reference, rank * 2 + m, mem["summary"], mem["its"], mem["poses"], mem["points"], mem["objects"])
+            assert np.array_equal(mem["objects"], out[0]["members"][0]["objects"])
+
+
+def test_group_refuses_members_in_different_collectives_and_does_not_hang():
+    """The group's error behaviour: members that arrive with different counts are refused (every member gets the error), and a member that never
+    arrives makes the waiting one fail after the time-out instead of hanging the solve."""
+    lib = C.CDLL(dist_util.RcclComm.library_path())
+    lib.obvi_rccl_group_member.restype = C.c_void_p
+    group = dist_util.RcclGroup(2)
+    try:
+        group.set_timeout(1.0)
+        bufs = [torch.ones(64, dtype=torch.float64, device="cuda") * (m + 1) for m in range(2)]
+        st = [torch.cuda.Stream() for _ in range(2)]
+        rcs = [None, None]
+
+        def call(m, count):
+            rcs[m] = lib.obvi_rccl_group_allreduce(C.c_void_p(lib.obvi_rccl_group_member(group._g, C.c_int32(m))), C.c_void_p(bufs[m].data_ptr()), C.c_int64(count), C.c_int32(0), C.c_void_p(st[m].cuda_stream))
+        # a proper round first: both buffers hold the sum afterwards
+        th = [threading.Thread(target=call, args=(m, 64)) for m in range(2)]
+        [t.start() for t in th]; [t.join(timeout=60) for t in th]
+        torch.cuda.synchronize()
+        assert rcs == [0, 0] and float(bufs[0][0]) == 3.0 and float(bufs[1][63]) == 3.0
+        # different counts: refused for both
+        th = [threading.Thread(target=call, args=(m, 64 - 8 * m)) for m in range(2)]
+        [t.start() for t in th]; [t.join(timeout=60) for t in th]
+        assert rcs == [-1, -1]                                  # OBVI_ERR_INVALID_ARGUMENT
+        # one member alone: fails after the time-out, and the group stays failed
+        call(0, 64)
+        assert rcs[0] == -5                                     # OBVI_ERR_NOT_READY
+        call(1, 64)
+        assert rcs[1] == -5
+    finally:
+        group.close()
+
+
+def test_bench_config5_two_ranks_oversubscribed():
+    """`bench.py --gpus 2 --config 5 --oversubscribe` end to end on one GPU: two ranks (gloo), two sessions each behind the compiled group, the
+    joint solve of the four sessions timed; the JSON line names the workload and the sharding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--sessions", "4", "--oversubscribe", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert "config 5" in cfg["workload"] and "sessions" in cfg["workload"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong" and line["unit"] == "LM iterations/s"
+    assert cfg["rccl_ranks"] == 2 and cfg["sessions"] == 4 and cfg["sessions_per_rank"] == 2 and cfg["oversubscribed"] and cfg["allreduce_hook"] == "group+staged-gloo"
+    assert cfg["steps_done"] == 3 and cfg["collective_issue_order"]["same_on_every_rank"]
+    assert cfg["collective_bytes"]["per_lm_step"] > 0 and cfg["collectives_per_lm_step"] == pytest.approx(3.0, abs=0.5)
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["roofline"]["kernel"]
+    assert len(set(cfg["final_cost_per_session"])) == 1                                  # every session reports the job-wide cost

@@ -349,3 +349,31 @@ def test_oracle_selection_rule_against_the_map_rule_in_numpy():
                 want, n_want = helpers.map_rule(sq, act, fraction)
                 got, n_got = o.debug_select(sq, active, fraction)
                 assert n_got == n_want and np.array_equal(got, want), (n, fraction)
+
+
+def test_arbiter_build_really_runs_in_extended_precision():
+    """oracle/libobvi_oracle_ld.so (`make arbiter`: the oracle's source with `double` = long double in the factors and OBVI_ORACLE_REAL = long
+    double in every solver-level sum) is quoted as ground truth in DESIGN.md section 6.  The substitution is a macro: a static_assert in the
+    source pins the factor types, and here its numbers are checked to be what extended precision gives -- NOT bit-identical to the fp64
+    checker (that would mean the substitution silently did nothing), and not further from it than fp64 round-off."""
+    import os
+    import synth
+    ld = os.path.join(helpers.ROOT, "oracle", "libobvi_oracle_ld.so")
+    if not os.path.exists(ld):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "oracle"), "arbiter"])
+    prob = synth.make_problem(P=40, L=600, O=3, seed=7, min_obj_obs=6, object_classes=("bench",), bbox_noise=5.0)
+    o, a = helpers.oracle_ba(), obvi_ba.BundleAdjuster(library=ld, prefix="oracle_")
+    out = []
+    for ba in (o, a):
+        synth.upload(ba, prob)
+        cost, res = ba.evaluate(True, True)[:2]
+        s = ba.solve(helpers.ba_params(max_it=2))
+        out.append((cost, np.asarray(res), s.final_cost, [i.step_norm for i in ba.iterations()]))
+    (c0, r0, f0, n0), (c1, r1, f1, n1) = out
+    assert abs(c0 - c1) <= 1e-12 * c1 and abs(f0 - f1) <= 1e-9 * f1
+    # residuals leave the arbiter rounded to fp64: a good share of them sits one ulp away from the checker's (different intermediate rounding)
+    differ = np.count_nonzero(r0 != r1)
+    assert differ > 0.01 * len(r0), differ
+    assert np.abs(r0 - r1).max() <= 1e-11 * max(1.0, np.abs(r1).max())
+    assert n0[1] != n1[1] and abs(n0[1] - n1[1]) <= 1e-8 * n1[1]
