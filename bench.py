@@ -181,6 +181,37 @@ def cpu_baseline(prob, budget_iters=3, legs=None):
             "ms_per_step": 1e3 * steady / n, "reference_ceres": ceres}
 
 
+def end_state_vs_oracle(obvi_ba, synth, device, threads):
+    """LM END STATE on the HIP path against the CPU oracle, from a case the oracle finishes in seconds: BASELINE config #2
+    (500 keyframes / 50 000 features, reprojection only, first five poses constant) through the reference's two-phase local-BA block (50 it /
+    1e-3, the 10 % cut, 100 it / 1e-4).  The oracle is the checker here (as in tests/test_gpu_end_state.py); what the line carries: whether both
+    excluded the same factors and took the same LM sequence, and how far apart the two end states are.  A broken solve shows here as a
+    difference of many digits; the chaotic trajectory of the ill-conditioned bench workload (zero tolerances) does not."""
+    import ctypes
+    import end_state
+    lib = os.path.join(ROOT, "oracle", "libobvi_oracle.so")
+    if not os.path.exists(lib):
+        return None
+    prob = synth.make_problem(P=500, L=50000, O=0, seed=20241008 + 2, const_poses=5)
+    ctypes.CDLL(lib).oracle_set_threads(ctypes.c_int32(threads))
+    legs = {}
+    for name, make in (("hip", lambda: obvi_ba.BundleAdjuster(device_id=device)), ("oracle", lambda: obvi_ba.BundleAdjuster(library=lib, prefix="oracle_"))):
+        ba = make()
+        t0 = time.time()
+        legs[name] = end_state.run_two_phase(ba, prob, obvi_ba, synth, block=end_state.LOCAL_BA, polish_iterations=0)
+        legs[name]["seconds"] = time.time() - t0
+        ba.close()
+    c = end_state.compare(legs["hip"], legs["oracle"])
+    st = c["state_after_phase_2"]
+    return {"workload": "BASELINE config #2 (500 KF / 50k features, reprojection only, 5 constant poses), local_ba_iteration_params: 50 it / 1e-3, 10 % cut, 100 it / 1e-4",
+            "same_excluded_sets": c["same_excluded_sets"], "same_lm_sequence": bool(c["phase_1"]["same_lm_sequence"] and c["phase_2"]["same_lm_sequence"]),
+            "lm_iterations": {"hip": [legs["hip"]["phase_1"]["iterations"], legs["hip"]["phase_2"]["iterations"]], "oracle": [legs["oracle"]["phase_1"]["iterations"], legs["oracle"]["phase_2"]["iterations"]]},
+            "final_cost": {"hip": legs["hip"]["phase_2"]["final_cost"], "oracle": legs["oracle"]["phase_2"]["final_cost"]}, "final_cost_rel": c["phase_2"]["final_cost_rel"],
+            "pose_translation_max_m": st["pose_translation_max_m"], "pose_rotation_max_rad": st["pose_rotation_max_rad"], "feature_median_m": st["point_median_m"], "feature_max_m": st["point_max_m"],
+            "seconds": {"hip": round(legs["hip"]["seconds"], 2), "oracle": round(legs["oracle"]["seconds"], 2)},
+            "bar": "BASELINE.md 2.4 (iii): cost 1e-6 relative, poses 1e-6 m / 1e-6 rad (tests/test_gpu_end_state.py asserts 1e-10 / 1e-9)"}
+
+
 def ceres_harness(prob=None, budget_iters=3, threads=20):
     """if Ceres is discoverable on this box, __graft_entry__.build() has built oracle/_ref/ceres_harness
     (oracle/ceres_harness: find_package(Ceres QUIET)); it times ceres::Solve with the reference's option block on the same problem.
@@ -446,6 +477,77 @@ def kernel_table(pst, level1, level2, peaks):
     return table, phases
 
 
+def guarded(fn, seconds, what):
+    """Runs fn() on a thread and waits at most `seconds` for it.  A solve whose collective never meets its partner on another rank (ranks that
+    issued different sequences, a rank that died) would wait inside the device queue for ever: the bench then says so and exits non-zero
+    instead of hanging the launcher (the issue-order comparison used to run only AFTER the timed solve)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except BaseException as e:             # noqa: BLE001 -- re-raised on the caller's thread
+            box["err"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        print("bench.py: %s did not finish within %.0f s -- a collective without its partner (ranks out of step or a rank gone)?  Giving up." % (what, seconds), file=sys.stderr, flush=True)
+        os._exit(3)
+    if "err" in box:
+        raise box["err"]
+    return box.get("out")
+
+
+def check_issue_order(comm, dist, dist_util, issue_log, when):
+    """Every rank must have issued the same collectives in the same host order (one communicator, two streams).  Compared over the launcher's own
+    process group / the communicator's host path, at a quiescent point; a difference is an error, reported with where it was seen."""
+    if comm is not None:
+        calls, same = comm.sequence()[0], comm.same_issue_order()
+    else:
+        calls, same = issue_log.calls, dist_util.same_issue_order(dist, issue_log.calls, issue_log.digest())
+    if not same:
+        raise SystemExit("bench.py: the ranks issued different sequences of collectives (%s)" % when)
+    return {"collectives_issued": calls, "same_on_every_rank": bool(same), "checked": when}
+
+
+class c_stdout_to_stderr:
+    """RCCL prints a version banner on the C library's stdout when a communicator is formed; this script's stdout carries ONE JSON line and nothing else.
+    Inside the block file descriptor 1 is the process's stderr (C stdio flushed on both sides)."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+def numa_node_of_caller():
+    """NUMA node of the CPU this thread runs on (the library's pool threads are the caller's neighbours with OBVI_HOST_AFFINITY=1), or None."""
+    try:
+        cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
+        if cpu is None:
+            import ctypes
+            cpu = ctypes.CDLL(None).sched_getcpu()
+        for node in sorted(os.listdir("/sys/devices/system/node")):
+            if node.startswith("node") and os.path.exists("/sys/devices/system/node/%s/cpu%d" % (node, cpu)):
+                return int(node[4:])
+    except Exception:      # noqa: BLE001 -- a diagnostic
+        pass
+    return None
+
+
 def form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev):
     """The job's communicator of libobvi_rccl.so (`--hook rccl`): rank 0's ncclUniqueId travels over the launcher's process group, the data
     path then never touches Python.  Every rank must succeed, or every rank falls back to `--hook torch` (args.hook is rewritten): one rank
@@ -474,7 +576,8 @@ def form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev):
         ids = [my_id if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         try:
-            comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
+            with c_stdout_to_stderr():
+                comm = dist_util.RcclComm(rank, world, local_rank, unique_id=ids[0])
         except Exception as e:                          # noqa: BLE001
             comm, err = None, e
         if not all_ranks_ok(comm is not None):
@@ -488,9 +591,13 @@ def form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev):
 
 
 def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world, dist, ddev):
-    """`--config 5`: S concurrent sessions over one object map, S / world per rank, one joint solve (module docstring)."""
+    """`--config 5`: S concurrent sessions over one object map, S / world per rank, one joint solve (module docstring).
+    `--config 4 --windows-per-gpu K` takes the same route with config 4's windows (500 keyframes / 50 000 features, 25 shared objects): K windows
+    per GPU behind the group hook -- what k concurrent window-sized solves buy on one device."""
     import threading
-    cfg = CONFIGS[5]
+    cfg = dict(CONFIGS[args.config])
+    if args.config == 4:
+        cfg.update(name="config 4 with %d windows (500 KF / 50k features, 25 shared objects), %d per GPU behind the group hook", sessions=world * args.windows_per_gpu)
     S = args.sessions or cfg["sessions"]
     if args.chain:
         if world != 1:
@@ -503,7 +610,7 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
     mine = []
     for m in range(k):
         g = rank * k + m                                                # global session index = contributor index of the job
-        q = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(base, 5, g), const_poses=cfg["const_poses"], object_seed=base + 5, min_obj_obs=10)
+        q = synth.make_problem(P=cfg["P"], L=cfg["L"], O=cfg["O"], seed=dist_util.rank_seed(base, args.config, g), const_poses=cfg["const_poses"], object_seed=base + args.config, min_obj_obs=10)
         if g != 0:                                                      # object-only factors of the shared map: contributor 0 alone
             for key in ("sp_obj", "sp_mean", "sp_cov"):
                 q[key] = q[key][:0]
@@ -511,6 +618,17 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
     for q in mine[1:]:
         assert np.array_equal(q["objects"], mine[0]["objects"])
     n_obj = len(mine[0]["objects"])
+    first_session = mine[0]
+    # How a rank runs its k sessions.  FUSED (default): the k sessions are ONE problem on ONE handle (poses and features of all of them, the map's
+    # objects once): every kernel of an LM step covers all k sessions -- the level-scheduled tile Cholesky eliminates the k session subtrees in
+    # the same launches, so the dependent chain of a step is as long as ONE session's -- and the rank is one contributor of the exchange.
+    # --group: k handles (one host thread, one stream pair each) behind obvi_rccl_group_*: the general mechanism (sessions that arrive as
+    # separate handles), k chains side by side and two cross-stream hops per collective (measured: profiles/r05_config5_*.txt).
+    fused = not args.group
+    k_sessions = k
+    if fused:
+        mine = [synth.join_problems(mine)] if k > 1 else mine
+        k = 1
     issue_log = dist_util.IssueLog()
     comm, rccl_versions, hook = None, None, "group"
     if world > 1:
@@ -523,6 +641,8 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
         group = dist_util.RcclGroup(k, inner=inner, rank=rank, world=world, device=local_rank)
     else:
         group = dist_util.RcclGroup(k, device=local_rank)
+    if fused:
+        hook = hook.replace("group", "fused")
     handles, upload_ms = [], 0.0
     for m, q in enumerate(mine):
         ba = obvi_ba.BundleAdjuster(device_id=local_rank)
@@ -555,7 +675,7 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
 
     # what one session costs alone on this GPU (no exchange attached: the shared objects are ordinary objects): the serial yardstick of the rank
     alone = None
-    if rank == 0:
+    if rank == 0 and not (fused and k_sessions > 1):
         handles[0].evaluate(True, False)
         if args.warmup > 0:
             handles[0].solve(solver_params(obvi_ba, args.warmup))
@@ -565,6 +685,19 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
         torch.cuda.synchronize()
         alone = 1e3 * (time.perf_counter() - t0) / max(1, sa.num_iterations - 1)
         synth.upload(handles[0], mine[0])
+    if rank == 0 and fused and k_sessions > 1:
+        # the yardstick is ONE session: a handle of its own for it
+        one = obvi_ba.BundleAdjuster(device_id=local_rank)
+        synth.upload(one, first_session)
+        one.evaluate(True, False)
+        if args.warmup > 0:
+            one.solve(solver_params(obvi_ba, args.warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sa = one.solve(solver_params(obvi_ba, args.steps))
+        torch.cuda.synchronize()
+        alone = 1e3 * (time.perf_counter() - t0) / max(1, sa.num_iterations - 1)
+        one.close()
     is_shared = np.ones(n_obj, np.uint8)
     for m, ba in enumerate(handles):
         group.attach(m, ba, is_shared)
@@ -572,26 +705,21 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
     t0 = time.perf_counter()
     in_threads(lambda m: handles[m].evaluate(True, False))
     symbolic_ms = 1e3 * (time.perf_counter() - t0)
+    limit = 180.0 + 0.5 * S * (args.steps + args.warmup)
     if args.warmup > 0:
-        in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.warmup)))
+        guarded(lambda: in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.warmup))), limit, "the warm-up solve")
+    if world > 1:
+        check_issue_order(comm, dist, dist_util, issue_log, "after the warm-up solve")
     barrier()
     c0 = group.stats()
     t0 = time.perf_counter()
-    summ = in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.steps)))
+    summ = guarded(lambda: in_threads(lambda m: handles[m].solve(solver_params(obvi_ba, args.steps))), limit, "the timed solve")
     barrier()
     dt = time.perf_counter() - t0
     c1 = group.stats()
     steps_done = min(sm.num_iterations for sm in summ) - 1
     dt, steps_done = dist_util.reduce_timing(dist, ddev, dt, steps_done)
-    issue_order = None
-    if world > 1:
-        if comm is not None:
-            calls, same = comm.sequence()[0], comm.same_issue_order()
-        else:
-            calls, same = issue_log.calls, dist_util.same_issue_order(dist, issue_log.calls, issue_log.digest())
-        issue_order = {"collectives_issued": calls, "same_on_every_rank": bool(same)}
-        if not same:
-            raise SystemExit("bench.py: the ranks issued different sequences of collectives")
+    issue_order = check_issue_order(comm, dist, dist_util, issue_log, "after the warm-up solve and after the timed solve") if world > 1 else None
     # device timings: the same steps twice more with events on (every handle runs them: the collectives need all contributors); rank 0 reads session 0
     for ba in handles:
         ba.set_profiling(1)
@@ -620,9 +748,11 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
             "metric": "local-BA LM iterations/s (concurrent sessions sharing one object map, joint solve)", "value": S * steps_done / dt, "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"] % (S, k), "sessions": S, "sessions_per_rank": k, "keyframes": stats[0]["P"], "features": stats[0]["L"], "objects": n_obj,
-                       "reprojection_obs_per_session": stats[0]["N_r"], "bbox_obs_per_session": stats[0]["N_b"], "reduced_rows_per_session": int(pst["reduced_rows"]),
-                       "parallelism": "sessions x %d per GPU + group sum + all-reduce" % k if world > 1 else "sessions x %d on one GPU + group sum" % k,
+            "config": {"workload": cfg["name"] % (S, k_sessions), "sessions": S, "sessions_per_rank": k_sessions, "handles_per_rank": k,
+                       "mode": "fused: a rank's sessions are one problem on one handle" if fused else "group: one handle per session behind obvi_rccl_group_*",
+                       "keyframes": cfg["P"], "features": cfg["L"], "objects": n_obj,
+                       "reprojection_obs_per_handle": stats[0]["N_r"], "bbox_obs_per_handle": stats[0]["N_b"], "reduced_rows_per_handle": int(pst["reduced_rows"]),
+                       "parallelism": ("%d sessions per GPU (%s) + all-reduce across GPUs" if world > 1 else "%d sessions on one GPU (%s)") % (k_sessions, "one fused problem" if fused else "group sum over k handles"),
                        "rccl_ranks": (comm.world() if comm is not None else (dist.get_world_size() if dist is not None else 1)), "allreduce_hook": hook,
                        "oversubscribed": bool(args.oversubscribe), "rccl_versions": rccl_versions, "collective_issue_order": issue_order, "steps_done": steps_done,
                        "collectives_per_lm_step": round((c1[0] - c0[0] - 1) / max(1, submissions), 2),
@@ -631,13 +761,13 @@ def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world
                                                     "k is); the tail is the dense lower triangle of the shared map's reduced block: every session observes the map, so after "
                                                     "eliminating a session's own poses every pair of map objects is coupled on every rank -- no tile of it is structurally "
                                                     "zero on all ranks (DESIGN.md section 8)"},
-                       "final_cost_per_session": [sm.final_cost for sm in summ], "termination": summ[0].message.decode()},
+                       "final_cost_per_session": [sm.final_cost for sm in summ] * (k_sessions if fused else 1), "termination": summ[0].message.decode()},
             "value_note": "value = sessions x LM iterations of the joint solve / max-over-ranks seconds (every session advances one iteration per joint step; config 4 counts "
                           "its windows the same way); ms_per_step = one JOINT LM step of all %d sessions" % S,
-            "concurrency": {"one_session_alone_ms_per_step": round(alone, 4), "sessions_on_this_gpu": k, "joint_ms_per_step": round(ms_step, 4),
-                            "speedup_vs_serial": round(k * alone / ms_step, 3),
-                            "note": "k sessions of this GPU in k host threads, one stream pair each, against k x one session solved alone (no exchange): what running the "
-                                    "window-sized solves side by side buys on a device that one of them leaves mostly idle"},
+            "concurrency": {"one_session_alone_ms_per_step": round(alone, 4), "sessions_on_this_gpu": k_sessions, "joint_ms_per_step": round(ms_step, 4),
+                            "speedup_vs_serial": round(k_sessions * alone / ms_step, 3),
+                            "note": "the k sessions of this GPU solved jointly (fused into one problem, or k handles in k host threads with --group) against k x ONE session solved "
+                                    "alone, no exchange: what putting window-sized solves together buys on a device that one of them leaves mostly idle"},
             "roofline": {"kernel": dom, "bound": d.get("bound", "hbm"), "achieved": d.get("achieved"), "peak": HBM_PEAK_GBS if d.get("bound", "hbm") == "hbm" else FP64_MATRIX_PEAK_TF,
                          "unit": d.get("unit", "GB/s"), "frac": d.get("frac"), "frac_measured": d.get("frac_measured"), "traffic": None, "avg_launch_us": d["avg_us"],
                          "peaks_measured": {kk: round(v, 2) for kk, v in peaks.items()},
@@ -716,6 +846,8 @@ def main():
                          "(device -> host -> gloo -> device).  Not a measurement of scaling: it exercises the whole N > 1 code path of this script where "
                          "only one GPU exists (tests/test_gpu_shared_objects.py runs it)")
     ap.add_argument("--sessions", type=int, default=None, help="config 5: total number of sessions of the job (default 16; must be a multiple of --gpus)")
+    ap.add_argument("--windows-per-gpu", type=int, default=0, help="config 4: K windows per GPU, all sharing the object set, behind the group hook (0: the one-window-per-GPU path)")
+    ap.add_argument("--group", action="store_true", help="config 5 / config 4 --windows-per-gpu: one handle per session behind obvi_rccl_group_* instead of fusing a rank's sessions into one problem")
     ap.add_argument("--chain", action="store_true", help="config 5 the reference's way: sessions one after the other through the long-term map, one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deterministic-leg", action="store_true", help="skip the deterministic-mode timing of the same steps")
@@ -754,12 +886,16 @@ def main():
             dist.init_process_group(backend="gloo")
             args.hook = "staged-gloo"
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            with c_stdout_to_stderr():
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)             # the communicator is formed lazily: here, where its banner goes to stderr
+                torch.cuda.synchronize()
     ddev = "cpu" if args.oversubscribe else "cuda"      # where the launcher group's own small tensors live
     if args.config is None:
         args.config = 3 if world == 1 else 4
 
-    if args.config == 5:
+    if args.config == 5 or (args.config == 4 and args.windows_per_gpu > 0):
         run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world, dist, ddev)
         return
     cfg = CONFIGS[args.config]
@@ -819,11 +955,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    limit = 120.0 + 0.25 * (args.steps + args.warmup)      # generous: a config-3 step is 2 ms; what it must catch is a wait that never ends
     if args.warmup > 0:
-        ba.solve(solver_params(obvi_ba, args.warmup))
+        guarded(lambda: ba.solve(solver_params(obvi_ba, args.warmup)), limit, "the warm-up solve")
+    if shared:
+        # BEFORE the timed region: the warm-up went through every collective of the protocol once per step -- ranks that are out of step are
+        # found here (and a rank that waits for ever in the warm-up or in the timed solve is found by the time limit), not after the fact
+        check_issue_order(comm, dist, dist_util, issue_log, "after the warm-up solve")
     barrier()
     t0 = time.perf_counter()
-    summ = ba.solve(solver_params(obvi_ba, args.steps))
+    summ = guarded(lambda: ba.solve(solver_params(obvi_ba, args.steps)), limit, "the timed solve")
     barrier()
     dt = time.perf_counter() - t0
     ba_timed_iterations = ba.iterations()
@@ -831,14 +972,20 @@ def main():
     dt, steps_done = dist_util.reduce_timing(dist, ddev, dt, steps_done)
     # one communicator, two streams (first collective of a step on the side stream, the other two on the main stream): legal only if every rank
     # issues the same collectives in the same host order -- compared here, after the timed solve
-    issue_order = None
-    if shared:
-        calls = comm.sequence()[0] if comm is not None else issue_log.calls
-        same = comm.same_issue_order() if comm is not None else dist_util.same_issue_order(dist, issue_log.calls, issue_log.digest())
-        issue_order = {"collectives_issued": calls, "same_on_every_rank": bool(same)}
-        if not same:
-            raise SystemExit("bench.py: the ranks issued different sequences of collectives")
+    issue_order = check_issue_order(comm, dist, dist_util, issue_log, "after the warm-up solve and after the timed solve") if shared else None
     collectives_us = collective_latency(torch, ba, comm, dist, args, prob, world) if shared else None
+    if world == 1 and rank == 0:
+        # the latency budget of the exchange is needed BEFORE eight ranks exist: the three per-step sizes of config 4 and of
+        # config 5 on a ONE-rank communicator of libobvi_rccl.so -- what RCCL's launch path costs per collective before any byte crosses xGMI
+        try:
+            with c_stdout_to_stderr():
+                comm1 = dist_util.RcclComm(0, 1, local_rank, unique_id=dist_util.RcclComm.unique_id())
+                collectives_us = {"communicator": "one rank: what RCCL's enqueue costs before any byte crosses xGMI (an in-place all-reduce of one rank moves nothing)"}
+                for label, nobj in (("config_4_25_shared_objects", 25), ("config_5_200_shared_objects", 200)):
+                    collectives_us[label] = collective_latency(torch, ba, comm1, None, args, {"objects": np.zeros((nobj, 7))}, 1)
+                comm1.close()
+        except Exception as e:                  # noqa: BLE001 -- a diagnostic: never fails the bench
+            collectives_us = "unavailable: %r" % (e,)
 
     # Device timings come from two more solves of the same K steps, outside the timed region (the timed solve records no
     # events at all): level 1 = one HIP event pair per phase of an LM step, same schedule as the timed solve (side stream on);
@@ -899,7 +1046,8 @@ def main():
             "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
             "phases_ms_avg": {k: round(v["ms_avg"], 4) for k, v in phases.items()},
             # once per problem, outside the timed region: host -> device upload through the binding, and the host's symbolic phase
-            "host": {"upload_ms": round(upload_ms, 1), "symbolic_phase_ms": round(symbolic_ms, 1)},
+            "host": {"upload_ms": round(upload_ms, 1), "symbolic_phase_ms": round(symbolic_ms, 1), "host_threads_used": int(pst.get("host_threads", 0)),
+                     "usable_cpus": int(pst.get("usable_cpus", 0)), "cpu_count": os.cpu_count(), "numa_node_of_caller": numa_node_of_caller()},
         }
         if scaling_baseline is not None:
             out["scaling_baseline"] = scaling_baseline
@@ -936,6 +1084,8 @@ def main():
                 if det_first is not None:
                     legs["deterministic"] = det_first
             out["cpu_baseline"] = cpu_baseline(prob, legs=legs)
+            if world == 1 and out["cpu_baseline"] is not None:
+                out["cpu_baseline"]["end_state_vs_oracle"] = end_state_vs_oracle(obvi_ba, synth, local_rank, out["cpu_baseline"]["cores"])
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -22,6 +22,14 @@ void make_dev_cam(const double* K4, const double* ext7, DevCam* out);
 // kTile x kTile fp64 tiles (row-major inside a tile, tiles row-major in the grid); only tiles
 // in the lower triangle that are structurally non-zero after symbolic fill are ever touched.
 constexpr int kTile = 64;
+// k_point_pass: a wavefront assembles the part of the Z storage that belongs to its piece of the observation list (records of 18 doubles + a
+// 4-double tail per point) in LDS and writes it out with coalesced 16-byte stores.  The host cuts the pieces (upload.cpp) so that an image never
+// exceeds this many doubles: 64 observations + 28 points.  1264 doubles x 4 wavefronts = 40 KB per workgroup, FOUR workgroups per compute unit
+// (160 KB of LDS) = 4 wavefronts per SIMD at <= 128 VGPRs; the round-1..4 layout (22 * 64 doubles, any 64 points) stopped at three (round 5).
+#ifndef OBVI_POINT_IMAGE_DOUBLES
+#define OBVI_POINT_IMAGE_DOUBLES 1264
+#endif
+constexpr int kPointImageDoubles = OBVI_POINT_IMAGE_DOUBLES;
 
 // Slots of the device scalar block (fp64 unless noted).  One 256-byte D2H copy per LM step.
 enum Scalar {
@@ -46,7 +54,7 @@ enum Scalar {
 // model cost change -- are then not added to the scalar block with fp64 atomics (whose order changes from run to run): workgroup b of
 // a kernel stores its partial sum at scal[SC_COUNT + slot * stride + b], and a one-workgroup-per-slot kernel behind it adds them up
 // in a fixed order (launch_det_reduce, which refuses a grid larger than the stride).  stride = BlocksDev.deterministic, the room the
-// handle gave the slots for the problem it holds (ensure_det_slots in obvi_ba.cpp: the largest grid, a power of two >= 4096).
+// handle gave the slots for the problem it holds (ensure_det_slots in ba_handle.h: the largest grid, a power of two >= 4096).
 // What stays atomic in this mode, and why the result is still the same from run to run:
 //   - counters (failed pivots, non-finite entries: small integers) and the gradient maximum (integer max): exact in any order;
 //   - the fp64 adds into the reduced system's tiles, right-hand side and diagonal (k_schur_window, k_schur_blocks, k_reduced_diag, the

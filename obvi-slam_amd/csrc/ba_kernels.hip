@@ -272,13 +272,13 @@ __global__ void __launch_bounds__(kBlock) k_point_pass_long(BlocksDev b, ReprojD
 // by a segmented scan over the run's lanes (shuffles); every lane forms the
 // 3x3 Cholesky of H_ll + lambda and its own Z = rho' Jp^T Jl C^-T.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
+__global__ void __launch_bounds__(kBlock, kPointImageDoubles <= 1264 ? 4 : 3) k_point_pass(BlocksDev b, ReprojDev rp, const DevCam* __restrict__ cams,
                                                       const PoseCache* __restrict__ pc, const double* __restrict__ points,
                                                       ReducedDev rd, PointDev pt, double radius, int first_iter, double* scal,
                                                       const uint32_t* __restrict__ wave_obs, int64_t n_waves) {
-  // per wavefront: the image of the wavefront's part of the Z storage (records + tails, 18 n + 4 points <= 18 * 64 + 4 * 64
-  // doubles), written out with coalesced 16-byte stores
-  __shared__ __attribute__((aligned(16))) double ex[kBlock / 64][22 * 64];
+  // per wavefront: the image of the wavefront's part of the Z storage (records + tails, 18 n + 4 points <= kPointImageDoubles: the host cuts
+  // the pieces accordingly), written out with coalesced 16-byte stores
+  __shared__ __attribute__((aligned(16))) double ex[kBlock / 64][kPointImageDoubles];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t gw = blockIdx.x * (int64_t)(kBlock / 64) + wv;
   double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
@@ -1659,7 +1659,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 // =========================================================================================
 void launch_det_reduce(hipStream_t s, double* scal, int64_t nblocks, uint32_t scalar_mask, int stride) {
-  if (nblocks > stride) throw std::logic_error("deterministic mode: a grid larger than the partial-sum slots (ensure_det_slots() in obvi_ba.cpp undercounts)");
+  if (nblocks > stride) throw std::logic_error("deterministic mode: a grid larger than the partial-sum slots (ensure_det_slots() in ba_handle.h undercounts)");
   if (nblocks > 0) hipLaunchKernelGGL(k_det_reduce, dim3(kDetSlots), dim3(kBlock), 0, s, scal, nblocks, scalar_mask, stride);
 }
 #define OBVI_SC(x) (1u << (x))

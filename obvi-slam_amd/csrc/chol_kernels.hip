@@ -4,7 +4,7 @@
 // (same level of the tile elimination tree) are processed by the same launch.  This is the role
 // Ceres' sparse Cholesky of the Schur complement plays behind SPARSE_SCHUR
 // (object_pose_graph_optimizer.h:665) [Ceres-doc]; because the factorisation is exact the
-// elimination order (obvi_ba.cpp: nested dissection of the pose chain, objects inside the tree) changes the
+// elimination order (plan.cpp: nested dissection of the pose chain, objects inside the tree) changes the
 // result only by round-off.
 //
 // Per level, two launches:

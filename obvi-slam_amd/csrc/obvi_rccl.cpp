@@ -311,6 +311,14 @@ int obvi_rccl_group_allreduce(void* user, void* device_buf, int64_t count_f64, i
   GroupMember* me = static_cast<GroupMember*>(user);
   if (!me || !me->g || !device_buf || count_f64 < 0 || op < 0 || op > 2) return OBVI_ERR_INVALID_ARGUMENT;
   obvi_rccl_group* g = me->g;
+  if (g->n == 1) {
+    // one handle on this rank (a rank whose sessions are fused into one problem): nothing to sum, no second stream, no event -- the
+    // inter-rank all-reduce goes straight onto the handle's own stream (a cross-stream hop costs tens of microseconds on this runtime,
+    // two of them per collective, three collectives per LM step)
+    const int rc1 = g->inner != nullptr && count_f64 > 0 ? g->inner(g->inner_user, device_buf, count_f64, op, stream) : 0;
+    g->collectives += 1; g->doubles += (uint64_t)count_f64;
+    return rc1 != 0 ? OBVI_ERR_HIP : 0;
+  }
   if (hipSetDevice(g->device) != hipSuccess) return OBVI_ERR_HIP;
   // this member's buffer is complete once its stream has reached this point
   if (hipEventRecord(me->ready, static_cast<hipStream_t>(stream)) != hipSuccess) return OBVI_ERR_HIP;

@@ -13,6 +13,7 @@
 #include <obvi_ba.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <thread>
 #include <cstdio>
 #include <fstream>
@@ -97,7 +98,8 @@ class HandlePool {
   static HandlePool& instance() { static HandlePool* p = new HandlePool; return *p; }   // never destroyed: no HIP calls from static destructors
   obvi_ba_handle* acquire(const obvi_ba_options& opt) {
     {
-      std::lock_guard<std::mutex> lock(mu_);
+      std::unique_lock<std::mutex> lock(mu_);
+      warm_cv_.wait(lock, [&] { return warming_ == 0; });   // a handle that is being created in the background (warm) is worth waiting for
       for (size_t i = 0; i < parked_.size(); ++i)
         if (same(parked_[i].first, opt)) { obvi_ba_handle* h = parked_[i].second; parked_.erase(parked_.begin() + (long)i); return h; }
     }
@@ -115,7 +117,22 @@ class HandlePool {
     if (parked_.size() >= kMaxParked) { obvi_ba_destroy(h); return; }
     parked_.push_back({opt, h});
   }
+  // Creates a handle on a thread of its own and parks it: a host that knows it will optimise calls this first thing, so that the start of
+  // the HIP runtime and the handle's allocations (90-130 ms in a fresh process) run beside its own start-up work -- reading the scene,
+  // filling the pose graph -- instead of in front of the first optimisation.  acquire() waits for a warm-up in flight.
+  void warm(const obvi_ba_options& opt) {
+    { std::lock_guard<std::mutex> lock(mu_); ++warming_; }
+    std::thread([this, opt] {
+      obvi_ba_handle* h = nullptr;
+      const int rc = obvi_ba_create(&opt, &h);
+      std::lock_guard<std::mutex> lock(mu_);
+      if (rc == OBVI_OK && h != nullptr) parked_.push_back({opt, h});
+      --warming_;
+      warm_cv_.notify_all();
+    }).detach();
+  }
   void drain() {
+    { std::unique_lock<std::mutex> lock(mu_); warm_cv_.wait(lock, [&] { return warming_ == 0; }); }
     std::vector<std::pair<obvi_ba_options, obvi_ba_handle*>> all;
     { std::lock_guard<std::mutex> lock(mu_); all.swap(parked_); }
     for (auto& e : all) obvi_ba_destroy(e.second);
@@ -126,6 +143,8 @@ class HandlePool {
     return a.device_id == b.device_id && a.object_block_size == b.object_block_size && a.reprojection_variant == b.reprojection_variant && a.deterministic == b.deterministic;
   }
   std::mutex mu_;
+  std::condition_variable warm_cv_;
+  int warming_ = 0;   // handles being created by warm(), guarded by mu_
   std::vector<std::pair<obvi_ba_options, obvi_ba_handle*>> parked_;
 };
 

@@ -80,11 +80,12 @@ def torch_allreduce(dist, log=None):
     """obvi_ba all-reduce hook on top of torch.distributed (backend nccl == RCCL over xGMI): the collective is enqueued
     behind the library's own HIP stream, no host synchronisation."""
     import torch
+    dev = torch.cuda.current_device()          # the hook may be called from another host thread (a solve on a worker thread): its device is the creator's
 
     def fn(ptr, count, op, stream):
         if log is not None:
             log.note(count, op, stream)
-        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+        with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
             dist.all_reduce(device_tensor(ptr, count), op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
         return 0
     return fn
@@ -94,11 +95,12 @@ def staged_allreduce(dist, log=None):
     """The same hook over any torch.distributed backend (gloo in the tests and in `bench.py --oversubscribe`: several ranks on ONE GPU, where
     RCCL refuses to form a communicator): device -> host on the library's stream, all_reduce on the host, host -> device on the same stream."""
     import torch
+    dev = torch.cuda.current_device()
 
     def fn(ptr, count, op, stream):
         if log is not None:
             log.note(count, op, stream)
-        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+        with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
             d = device_tensor(ptr, count)
             h = d.cpu()                                     # synchronises the stream: everything before the exchange is done
             dist.all_reduce(h, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)

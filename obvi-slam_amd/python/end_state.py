@@ -89,7 +89,9 @@ def compare_states(a, b):
                point_median_m=float(np.median(np.abs(a["points"] - b["points"]).max(axis=1))) if len(a["points"]) else 0.0)
     if len(a["objects"]):
         d = np.abs(a["objects"] - b["objects"])
-        out.update(object_centre_max_m=float(d[:, :3].max()), object_dims_max_m=float(d[:, 4:7].max()), object_yaw_max_rad=float(d[:, 3].max()))
+        out.update(object_centre_max_m=float(d[:, :3].max()), object_centre_median_m=float(np.median(d[:, :3].max(axis=1))), object_dims_max_m=float(d[:, 4:7].max()),
+                   object_dims_median_m=float(np.median(d[:, 4:7].max(axis=1))), object_yaw_max_rad=float(d[:, 3].max()), object_yaw_median_rad=float(np.median(d[:, 3])))
+    out["pose_translation_median_m"] = float(np.median(np.abs(a["poses"][:, :3] - b["poses"][:, :3]).max(axis=1))) if len(a["poses"]) else 0.0
     return out
 
 

@@ -188,10 +188,11 @@ int lock_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     for (int i = 0; i < std::min(nh, no); ++i) { if (ih[i].step_is_successful != io[i].step_is_successful) same_flags = 0; it_cost_rel = std::max(it_cost_rel, rel(ih[i].cost, io[i].cost)); }
     std::fprintf(f, "{\"call\": \"solve\", \"poses\": %lld, \"points\": %lld, \"objects\": %lld, \"iterations_hip\": %d, \"iterations_oracle\": %d, \"termination_hip\": %d, \"termination_oracle\": %d, "
                     "\"same_accept_sequence\": %d, \"initial_cost\": %.17g, \"initial_cost_rel\": %.3e, \"final_cost_rel\": %.3e, \"max_iteration_cost_rel\": %.3e, \"pose_diff\": %.3e, \"point_diff\": %.3e, \"object_diff\": %.3e, "
-                    "\"params_reduced_equal\": %d}\n",
+                    "\"params_reduced_equal\": %d, \"function_tolerance\": %.3e, \"max_num_iterations\": %d, \"message_hip\": \"%.40s\", \"message_oracle\": \"%.40s\"}\n",
                  (long long)l->P, (long long)l->L, (long long)l->O, sum->num_iterations, so.num_iterations, sum->termination_type, so.termination_type, same_flags, so.initial_cost,
                  rel(sum->initial_cost, so.initial_cost), rel(sum->final_cost, so.final_cost), it_cost_rel, max_abs_diff(ph, po), max_abs_diff(xh, xo), object_diff(oh, oo),
-                 (sum->num_parameters_reduced == so.num_parameters_reduced && sum->num_residuals_reduced == so.num_residuals_reduced) ? 1 : 0);
+                 (sum->num_parameters_reduced == so.num_parameters_reduced && sum->num_residuals_reduced == so.num_residuals_reduced) ? 1 : 0,
+                 prm->function_tolerance, (int)prm->max_num_iterations, sum->message, so.message);
     std::fflush(f);
   }
   if (arb().lib && l->arb) {

@@ -171,9 +171,11 @@ def test_group_refuses_members_in_different_collectives_and_does_not_hang():
         group.close()
 
 
-def test_bench_config5_two_ranks_oversubscribed():
-    """`bench.py --gpus 2 --config 5 --oversubscribe` end to end on one GPU: two ranks (gloo), two sessions each behind the compiled group, the
-    joint solve of the four sessions timed; the JSON line names the workload and the sharding."""
+@pytest.mark.parametrize("mode", ["fused", "group"])
+def test_bench_config5_two_ranks_oversubscribed(mode):
+    """`bench.py --gpus 2 --config 5 --oversubscribe` end to end on one GPU: two ranks (gloo), two sessions each -- fused into one problem per rank
+    (the default) or as two handles behind the compiled group (`--group`) --, the joint solve of the four sessions timed; the JSON line names the
+    workload and the sharding.  Both modes solve the same joint problem: same costs."""
     import json
     import os
     import subprocess
@@ -182,7 +184,7 @@ def test_bench_config5_two_ranks_oversubscribed():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--sessions", "4", "--oversubscribe", "--steps", "3", "--warmup", "1",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+                          "--no-cpu-baseline"] + (["--group"] if mode == "group" else []), capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -190,8 +192,15 @@ def test_bench_config5_two_ranks_oversubscribed():
     cfg = line["config"]
     assert "config 5" in cfg["workload"] and "sessions" in cfg["workload"]
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong" and line["unit"] == "LM iterations/s"
-    assert cfg["rccl_ranks"] == 2 and cfg["sessions"] == 4 and cfg["sessions_per_rank"] == 2 and cfg["oversubscribed"] and cfg["allreduce_hook"] == "group+staged-gloo"
+    assert cfg["rccl_ranks"] == 2 and cfg["sessions"] == 4 and cfg["sessions_per_rank"] == 2 and cfg["oversubscribed"]
+    assert cfg["allreduce_hook"] == mode + "+staged-gloo" and cfg["handles_per_rank"] == (1 if mode == "fused" else 2) and cfg["mode"].startswith(mode)
     assert cfg["steps_done"] == 3 and cfg["collective_issue_order"]["same_on_every_rank"]
     assert cfg["collective_bytes"]["per_lm_step"] > 0 and cfg["collectives_per_lm_step"] == pytest.approx(3.0, abs=0.5)
     assert line["value"] > 0 and line["ms_per_step"] > 0 and line["roofline"]["kernel"]
-    assert len(set(cfg["final_cost_per_session"])) == 1                                  # every session reports the job-wide cost
+    assert len(cfg["final_cost_per_session"]) == 2 and len(set(cfg["final_cost_per_session"])) == 1    # every session of the rank reports the job-wide cost
+    # the job-wide cost does not depend on how a rank holds its sessions (same seeds, same joint problem)
+    test_bench_config5_two_ranks_oversubscribed.costs = getattr(test_bench_config5_two_ranks_oversubscribed, "costs", {})
+    test_bench_config5_two_ranks_oversubscribed.costs[mode] = cfg["final_cost_per_session"][0]
+    c = test_bench_config5_two_ranks_oversubscribed.costs
+    if len(c) == 2:
+        assert abs(c["fused"] - c["group"]) <= 1e-6 * c["group"], c

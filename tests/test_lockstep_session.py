@@ -61,20 +61,30 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
         import shutil
         shutil.copy(log, os.path.join(helpers.ROOT, "gpurun_out", "lockstep_%s.jsonl" % ("det" if deterministic else "default")))
     assert all(r["params_reduced_equal"] == 1 for r in solves) and max(r["initial_cost_rel"] for r in busy) <= 1e-11     # the same problem, the same objective at the same point: everywhere
-    # Where the two LM runs are the same run (all but a handful of windows): the stated end-state tolerances
-    # measured: 147 ... 158 of 165 over some sixty runs of the default mode (it differs from run to run: fp64 atomics), 155 in deterministic mode.  Most of the
-    # others are local BAs that stop ONE iteration apart: |cost change| <= function_tolerance * cost is decided in the last bits, a coin a dozen windows toss
-    # per session -- 18 heads came up twice in those sixty runs, so the bar is 85 %, not 90 (against the extended-precision arbiter the
-    # HIP run follows the exact LM sequence as long as the oracle does or longer)
-    assert len(good) >= 0.85 * len(busy)
+    # (1) Where the two LM runs are the same run: the stated end-state tolerances.
     assert med["final_cost_rel"] <= 1e-10 and med["pose_diff"] <= 1e-10 and med["point_diff"] <= 1e-9      # measured: 5e-13, 1.4e-13, 3.5e-12
     assert worst["max_iteration_cost_rel"] <= 2e-4 and worst["final_cost_rel"] <= 2e-4 and worst["pose_diff"] <= 1e-4   # measured: 1.5e-4, 2.5e-5, 1.7e-5 (the long global-BA runs)
     assert med["object_diff"] <= 1e-6 and worst["object_diff"] <= 1.0       # measured: 5e-8; 0.26 -- an object a window sees from a few frames only is weakly constrained along its viewing ray (yaw excluded altogether)
-    # The others: a window with a direction the data barely constrains (a symmetric ellipsoid's yaw, a feature at the horizon) lets the
-    # trust region grow until round-off decides an accept / reject test; both runs then end at equally good points
-    # (measured over several runs of the default mode, which differs from run to run: the global BAs of 80 to 250 iterations, and a few
-    # local ones that stop one iteration apart; costs within 1e-4 ... 5.4e-3, poses within 1e-4 ... 1.0e-2)
-    assert all(r["final_cost_rel"] <= 2e-2 and r["pose_diff"] <= 5e-2 for r in bad)
+    # (2) Where they are not, the END STATE says why, run by run (round 5; before: a bar on the share of such runs, taken from its distribution over sixty sessions):
+    #   (a) the stopping rule.  A run of the reference's blocks ends when |cost change| <= function_tolerance * cost; decided in the last bits, two runs that agree to
+    #       1e-12 up to there stop k = 1 ... 4 iterations apart, and their final costs then differ by about k x that tolerance -- measured 0.8 ... 1.7 x k x the tolerance
+    #       of the solve (1e-4 for phase II of a local BA, 1e-6 for the final BA), poses within 3e-3 m.  tests/test_gpu_end_state.py shows the same against the extended-precision arbiter: the fp64
+    #       oracle itself stops one iteration from the arbiter there, 1e-4 apart.
+    #   (b) long runs on a problem with a direction the data barely constrains (pose-graph stages and global BAs of 25 ... 250 iterations, non-monotonic steps): the
+    #       trajectories of ANY two fp64 runs separate (profiles/r05_end_state_config3.txt: HIP default, HIP deterministic, the oracle and the oracle on one thread
+    #       fewer end pairwise as far apart as HIP and the oracle do here); both end at equally good points: costs within 1e-2, poses within 5e-2.
+    #   Anything else -- a short run that differs by more than its own tolerance explains -- fails.
+    def stopping_rule(r):
+        # k iterations apart: each of the iterations the longer run went on for lowered the cost by more than the tolerance (or it would have stopped) and, this
+        # close to the end, by not much more -- measured 0.8 ... 1.7 x k x tolerance over the sessions of rounds 4-5; allowed 2 (k + 1) x
+        k = abs(r["iterations_hip"] - r["iterations_oracle"])
+        return k <= 5 and max(r["iterations_hip"], r["iterations_oracle"]) <= 40 and \
+            r["final_cost_rel"] <= 2.0 * (k + 1) * max(r["function_tolerance"], 1e-8) and r["pose_diff"] <= 5e-3
+    def long_run(r):
+        return max(r["iterations_hip"], r["iterations_oracle"]) >= 25 and r["final_cost_rel"] <= 2e-2 and r["pose_diff"] <= 5e-2
+    unexplained = [r for r in bad if not (stopping_rule(r) or long_run(r))]
+    assert not unexplained, unexplained
+    assert len(good) >= 0.75 * len(busy)          # sanity only (measured 147 ... 158 of 165): what matters is (1) and (2), every run is in one of them
     # identical outlier selections (two-phase cut), evaluations and covariance blocks
     sel = [r for r in recs if r["call"] == "select_outliers"]
     assert len(sel) >= 100 and all(r["masks_differ"] == 0 and r["excluded_hip"] == r["excluded_oracle"] for r in sel)
