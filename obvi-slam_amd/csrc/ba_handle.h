@@ -354,7 +354,7 @@ inline CholPlan chol_plan(const obvi_ba_handle* h) {
 // contiguous ranges in order, so results concatenated by part are those of the sequential loop.
 // The CPUs this process may actually run on: the smaller of its affinity mask and its cgroup's CPU quota (a container limited to a few CPUs still
 // reports the machine's hardware_concurrency(); sixteen spinning workers on four CPUs' worth of quota are slower than one thread).
-inline int usable_cpus() {
+inline int usable_cpus_uncached() {
   int n = (int)std::max(1u, std::thread::hardware_concurrency());
 #if defined(__linux__)
   cpu_set_t set;
@@ -377,6 +377,10 @@ inline int usable_cpus() {
   if (q <= 0.0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
   if (q > 0.0) n = std::min(n, std::max(1, (int)(q + 0.5)));
 #endif
+  return n;
+}
+inline int usable_cpus() {
+  static const int n = usable_cpus_uncached();   // once per process: it reads two files, and host_threads() is asked several times per plan
   return n;
 }
 inline int host_threads() {

@@ -144,6 +144,7 @@ class HostPool {
     {
       std::lock_guard<std::mutex> lock(m_);
       jobs_.push_back(&job);
+      published_.fetch_add(1, std::memory_order_release);
       gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
@@ -152,6 +153,7 @@ class HostPool {
     {                                                                                       // nobody enters from here on
       std::lock_guard<std::mutex> lock(m_);
       for (size_t i = 0; i < jobs_.size(); ++i) if (jobs_[i] == &job) { jobs_.erase(jobs_.begin() + (std::ptrdiff_t)i); break; }
+      published_.fetch_sub(1, std::memory_order_release);
     }
     while (job.inside.load(std::memory_order_acquire) != 0) std::this_thread::yield();     // ... and those who did have left
   }
@@ -200,23 +202,28 @@ class HostPool {
 #endif
       }
       Job* job = nullptr;
+      uint64_t picked_at = seen;
       {
         std::unique_lock<std::mutex> lock(m_);
         cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
         if (stop_) return;
         for (Job* j : jobs_) if (j->next.load(std::memory_order_acquire) < j->parts) { job = j; break; }   // any caller's job with parts left
-        if (job == nullptr) { seen = gen_.load(std::memory_order_acquire); continue; }                    // nothing to do for this generation
+        picked_at = gen_.load(std::memory_order_acquire);
+        if (job == nullptr) { seen = picked_at; continue; }                                               // nothing to do for this generation
         job->inside.fetch_add(1, std::memory_order_acq_rel);   // counted while the pointer is held: run() waits for zero
       }
       take(*job);
       job->inside.fetch_sub(1, std::memory_order_release);
-      // `seen` stays: the next round looks for another caller's job before it sleeps
+      // another caller's job may be waiting: look again before sleeping -- but only if one is published (the common case is a single caller,
+      // whose run() wants the mutex right now to take its job back: fifteen workers queueing for it cost more than the look is worth)
+      if (published_.load(std::memory_order_acquire) <= 1) seen = picked_at;   // (a job published since then has moved gen_ on: it is looked at right away)
     }
   }
   std::vector<std::thread> threads_;
   std::mutex m_;
   std::condition_variable cv_;
   std::atomic<uint64_t> gen_{0};
+  std::atomic<int> published_{0};   // jobs in jobs_ (read outside the mutex)
   std::vector<Job*> jobs_;   // published jobs, guarded by m_
   bool stop_ = false;
 };

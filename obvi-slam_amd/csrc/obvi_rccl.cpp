@@ -243,7 +243,7 @@ struct obvi_rccl_group {
   std::atomic<uint64_t> generation{0};
   int arrived = 0, rc = 0;          // guarded by mu; rc: result of the round that just completed
   bool broken = false;              // a member timed out: every later call fails at once
-  uint64_t collectives = 0, doubles = 0;
+  std::atomic<uint64_t> collectives{0}, doubles{0};   // read by obvi_rccl_group_stats from any thread
 };
 
 extern "C" {
@@ -303,7 +303,7 @@ int obvi_rccl_group_attach(obvi_rccl_group* g, int32_t member, obvi_ba_handle* h
 
 int obvi_rccl_group_stats(const obvi_rccl_group* g, uint64_t* collectives, uint64_t* doubles) {
   if (!g || !collectives || !doubles) return OBVI_ERR_INVALID_ARGUMENT;
-  *collectives = g->collectives; *doubles = g->doubles;
+  *collectives = g->collectives.load(std::memory_order_relaxed); *doubles = g->doubles.load(std::memory_order_relaxed);
   return OBVI_OK;
 }
 

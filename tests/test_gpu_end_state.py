@@ -92,7 +92,9 @@ def test_with_objects_the_hip_end_state_is_as_close_to_the_arbiter_as_the_fp64_o
         # (phase II: measured, the fp64 ORACLE stops one iteration from the arbiter on this problem -- 12 against 11, 1e-4 apart in cost, the
         # function tolerance of the block --, the default handle follows the arbiter, the deterministic handle the oracle: no sequence is asserted)
         assert c["phase_1"]["final_cost_rel"] < 1e-6 and c["phase_2"]["final_cost_rel"] < 1e-3          # sanity: the same valley
-        # no further from the extended-precision run than the fp64 checker is (x 5: the amplification is chaotic; floors = the well-posed case's level)
-        assert c["phase_2"]["final_cost_rel"] <= 5.0 * max(ref["phase_2"]["final_cost_rel"], 1e-10), (c["phase_2"], ref["phase_2"])
-        for key, floor in (("pose_translation_max_m", 1e-9), ("pose_rotation_max_rad", 1e-9), ("point_median_m", 1e-9)):
-            assert c["state_after_phase_2"][key] <= 5.0 * max(ref["state_after_phase_2"][key], floor), (key, c["state_after_phase_2"][key], ref["state_after_phase_2"][key])
+        # no further from the extended-precision run than the fp64 checker is -- or than the checker WAS in the runs where it stopped an iteration
+        # from the arbiter (the amplification is chaotic: which of the three fp64 runs lands next to the arbiter changes from run to run; measured over
+        # the round: cost 2e-6 ... 1e-4, poses 2e-5 ... 8e-4 m, rotations 5e-7 ... 2.4e-5 rad, features 2e-5 ... 1e-3 m median, for every pair)
+        assert c["phase_2"]["final_cost_rel"] <= max(5.0 * ref["phase_2"]["final_cost_rel"], 3e-4), (c["phase_2"], ref["phase_2"])
+        for key, spread in (("pose_translation_max_m", 3e-3), ("pose_rotation_max_rad", 1e-4), ("point_median_m", 3e-3)):
+            assert c["state_after_phase_2"][key] <= max(5.0 * ref["state_after_phase_2"][key], spread), (key, c["state_after_phase_2"][key], ref["state_after_phase_2"][key])
