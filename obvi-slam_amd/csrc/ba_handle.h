@@ -59,6 +59,7 @@ struct obvi_ba_handle {
   std::vector<DevCam> h_cams;
   int64_t P = 0, L = 0, O = 0;
   std::vector<uint8_t> h_pose_const, h_point_const, h_object_const;
+  std::vector<double> h_obj_xy;   // (x, y) of every object AS UPLOADED (obvi_ba_set_objects): the spatial key that orders the shared tail (plan.cpp) -- the same on every rank
   // reprojection: sorted by (point, pose); perm[sorted] = caller index
   int64_t n_rp = 0;
   std::vector<uint32_t> h_rp_pose, h_rp_point, h_rp_perm, h_rp_inv, h_point_ptr;
@@ -173,7 +174,7 @@ struct obvi_ba_handle {
   void* allreduce_user = nullptr;
   std::vector<uint8_t> h_is_shared;      // per object index (caller order)
   int32_t rank = 0, world = 1;
-  std::vector<int32_t> h_shared_ov;      // reduced object indices of the shared objects, in object-index order
+  std::vector<int32_t> h_shared_ov;      // reduced object indices of the shared objects in the order of the tail (the same on every rank: plan.cpp)
   DevBuf<int32_t> d_shared_ov;
   DevBuf<uint8_t> d_obj_shared;
   DevBuf<double> d_xbuf, d_xbuf2;        // exchange buffers: main stream (tail, scalars) / side stream (shared blocks)

@@ -130,7 +130,7 @@ void prepare_plan(obvi_ba_handle* h) {
       if (f >= 0) { fa[o] = std::min(fa[o], f); fb[o] = std::max(fb[o], f); }
     }
     std::vector<std::vector<int64_t>> node_objs(nodes.size() + 1);   // last slot: no tree (no variable pose)
-    std::vector<int64_t> tail_objs;                                   // shared across ranks: eliminated last, in object-index order
+    std::vector<int64_t> tail_objs;                                   // shared across ranks: eliminated last, in an order every rank derives alike (below)
     for (int64_t o = 0; o < O; ++o) {
       if (obj_vid[o] < 0) continue;
       if (!h->h_is_shared.empty() && h->h_is_shared[o]) { tail_objs.push_back(o); continue; }
@@ -167,6 +167,36 @@ void prepare_plan(obvi_ba_handle* h) {
     place_node(0, 0, node_objs[nodes.size()]);
     h->tail_t0 = -1;
     h->h_shared_ov.clear();
+    if (tail_objs.size() > 1 && (int64_t)h->h_obj_xy.size() == 2 * O && (!std::getenv("OBVI_TAIL_SPATIAL") || std::atoi(std::getenv("OBVI_TAIL_SPATIAL")) != 0)) {
+      // Order of the shared tail (round 5).  Every rank must lay the shared objects out in the SAME order (the tail's tiles are summed across ranks), so the
+      // order can only depend on what all ranks share: the objects' index and their uploaded values.  Object-index order (rounds 2-4) is arbitrary with
+      // respect to the trajectory, so every pose tile column coupled with every object tile row of the tail (9 objects to a row: each row holds one that
+      // some frame of the column sees): config #5, 16 sessions fused: 322 k tile products per factorisation.  A Hilbert curve over the objects' (x, y) as
+      // uploaded puts objects that are seen together next to each other: a pose column then meets the few tail rows of its surroundings (116 k products
+      // with the objects in first-observing-frame order of a single-rank problem).  Ties: object index.
+      double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+      for (int64_t o : tail_objs) { x0 = std::min(x0, h->h_obj_xy[2 * o]); x1 = std::max(x1, h->h_obj_xy[2 * o]); y0 = std::min(y0, h->h_obj_xy[2 * o + 1]); y1 = std::max(y1, h->h_obj_xy[2 * o + 1]); }
+      const double span = std::max(std::max(x1 - x0, y1 - y0), 1e-12);
+      auto hilbert = [](uint32_t x, uint32_t y) {   // index of (x, y) on the 2^16 x 2^16 Hilbert curve
+        uint64_t d = 0;
+        for (uint32_t s = 1u << 15; s > 0; s >>= 1) {
+          const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+          d += (uint64_t)s * (uint64_t)s * ((3u * rx) ^ ry);
+          if (ry == 0) { if (rx == 1) { x = 65535u - x; y = 65535u - y; } std::swap(x, y); }
+        }
+        return d;
+      };
+      std::vector<std::pair<uint64_t, int64_t>> keyed;
+      keyed.reserve(tail_objs.size());
+      for (int64_t o : tail_objs) {
+        const double fx = (h->h_obj_xy[2 * o] - x0) / span, fy = (h->h_obj_xy[2 * o + 1] - y0) / span;
+        const bool finite = std::isfinite(fx) && std::isfinite(fy);
+        const uint32_t qx = finite ? (uint32_t)std::min(65535.0, std::max(0.0, fx * 65535.0)) : 0u, qy = finite ? (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0)) : 0u;
+        keyed.emplace_back(hilbert(qx, qy), o);
+      }
+      std::sort(keyed.begin(), keyed.end());
+      for (size_t i = 0; i < keyed.size(); ++i) tail_objs[i] = keyed[i].second;
+    }
     if (!tail_objs.empty()) {
       row = ((row + kTile - 1) / kTile) * kTile;
       h->tail_t0 = (int32_t)(row / kTile);

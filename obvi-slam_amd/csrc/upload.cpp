@@ -35,7 +35,14 @@ static int set_blocks(obvi_ba_handle* h, int64_t n, int dim, const double* v, co
 }
 int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 6, v, c, h ? &h->P : nullptr, h ? &h->h_pose_const : nullptr, h ? &h->d_pose : nullptr); }
 int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 3, v, c, h ? &h->L : nullptr, h ? &h->h_point_const : nullptr, h ? &h->d_point : nullptr); }
-int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr); }
+int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) {
+  const int rc = set_blocks(h, n, 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr);
+  if (rc == OBVI_OK) {   // where the objects are, for the order of the shared tail (every rank uploads the shared objects with the same values: include/obvi_ba.h)
+    h->h_obj_xy.resize((size_t)2 * (size_t)n);
+    for (int64_t o = 0; o < n; ++o) { h->h_obj_xy[2 * o] = v[7 * o]; h->h_obj_xy[2 * o + 1] = v[7 * o + 1]; }
+  }
+  return rc;
+}
 
 int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pc, const uint8_t* lc, const uint8_t* oc) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
