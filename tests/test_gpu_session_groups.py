@@ -139,6 +139,28 @@ def test_four_sessions_as_two_ranks_of_two_handles_land_on_the_oracles_joint_sol
             assert np.array_equal(mem["objects"], out[0]["members"][0]["objects"])
 
 
+def test_spatial_order_of_the_shared_tail_changes_round_off_only(monkeypatch):
+    """plan.cpp orders the shared tail along a Hilbert curve over the objects' uploaded (x, y) -- the same on every rank -- instead of by object index
+    (OBVI_TAIL_SPATIAL=0).  An elimination order: the solve may differ by round-off only; what it buys is fewer tile products per factorisation
+    (a pose tile column then couples with the tail rows of its surroundings, not with all of them)."""
+    sessions = synth.make_sessions(n_sessions=4, P=150, L=6000, O=60, seed0=900, object_seed=41, min_obj_obs=8, const_poses=1)
+    joint = synth.join_problems(sessions)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OBVI_TAIL_SPATIAL", mode)
+        ba = helpers.product_ba()
+        synth.upload(ba, joint)
+        ba.set_shared_objects(np.ones(len(joint["objects"]), np.uint8), 0, 1)
+        ba.set_allreduce(lambda ptr, n, op, stream: 0)            # one rank: the exchanges are identities
+        s = ba.solve(helpers.ba_params(max_it=6))
+        out[mode] = (s, [(i.step_is_successful, i.cost) for i in ba.iterations()], ba.get_poses(), ba.get_objects(), ba.problem_stats())
+        ba.close()
+    (s0, it0, p0, o0, st0), (s1, it1, p1, o1, st1) = out["0"], out["1"]
+    assert s0.num_iterations == s1.num_iterations and [a for a, _ in it0] == [a for a, _ in it1]
+    assert max(abs(a - b) / b for (_, a), (_, b) in zip(it0, it1)) < 1e-8 and np.abs(p0 - p1).max() < 1e-7 and np.abs(o0[:, [0, 1, 2, 4, 5, 6]] - o1[:, [0, 1, 2, 4, 5, 6]]).max() < 1e-5
+    assert st1["reduced_rows"] == st0["reduced_rows"] and st1["update_jobs"] < 0.9 * st0["update_jobs"], (st0["update_jobs"], st1["update_jobs"])
+
+
 def test_group_refuses_members_in_different_collectives_and_does_not_hang():
     """The group's error behaviour: members that arrive with different counts are refused (every member gets the error), and a member that never
     arrives makes the waiting one fail after the time-out instead of hanging the solve."""
