@@ -228,3 +228,30 @@ def test_bench_config5_two_ranks_oversubscribed(mode):
     c = test_bench_config5_two_ranks_oversubscribed.costs
     if len(c) == 2:
         assert abs(c["fused"] - c["group"]) <= 1e-6 * c["group"], c
+
+
+def _bench_line(args, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]          # ONE JSON line on stdout and nothing else (RCCL's banner goes to stderr)
+    return json.loads(lines[0])
+
+
+def test_bench_config5_chain_and_config4_windows_per_gpu():
+    """The two other forms of the multi-session bench on one GPU: `--config 5 --chain` (the reference's semantics: sessions one after the other through
+    the long-term map) and `--config 4 --windows-per-gpu K` (K windows sharing 25 objects, fused on one handle)."""
+    chain = _bench_line(["--config", "5", "--chain", "--sessions", "2"])
+    assert "chain" in chain["config"]["workload"] and chain["steps"] == 2 and len(chain["sessions"]) == 2 and chain["value"] > 0
+    assert all(r["objects_mapped"] > 100 and r["lm_iterations"] > 0 for r in chain["sessions"])
+    win = _bench_line(["--config", "4", "--windows-per-gpu", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    cfg = win["config"]
+    assert "config 4" in cfg["workload"] and cfg["sessions"] == 2 and cfg["sessions_per_rank"] == 2 and cfg["handles_per_rank"] == 1 and cfg["objects"] == 25
+    assert win["scaling"] == "strong" and cfg["steps_done"] == 3 and win["concurrency"]["sessions_on_this_gpu"] == 2 and win["concurrency"]["speedup_vs_serial"] > 0.8
