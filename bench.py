@@ -593,11 +593,11 @@ def form_rccl_comm(args, torch, dist, dist_util, rank, world, local_rank, ddev):
 def run_sessions(args, torch, obvi_ba, synth, dist_util, rank, local_rank, world, dist, ddev):
     """`--config 5`: S concurrent sessions over one object map, S / world per rank, one joint solve (module docstring).
     `--config 4 --windows-per-gpu K` takes the same route with config 4's windows (500 keyframes / 50 000 features, 25 shared objects): K windows
-    per GPU behind the group hook -- what k concurrent window-sized solves buy on one device."""
+    per GPU (fused into one problem, or behind the group hook with --group) -- what k window-sized solves together buy on one device."""
     import threading
     cfg = dict(CONFIGS[args.config])
     if args.config == 4:
-        cfg.update(name="config 4 with %d windows (500 KF / 50k features, 25 shared objects), %d per GPU behind the group hook", sessions=world * args.windows_per_gpu)
+        cfg.update(name="config 4 with %d windows (500 KF / 50k features, 25 shared objects), %d per GPU, joint solve", sessions=world * args.windows_per_gpu)
     S = args.sessions or cfg["sessions"]
     if args.chain:
         if world != 1:
