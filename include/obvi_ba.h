@@ -266,7 +266,9 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
  * Independent windows / sessions, one per rank, that share object blocks.  Every rank uploads ALL shared objects
  * (same indices, same initial values) plus its own poses, points and observations; object-only factors (shape / LTM
  * priors) of a shared object are uploaded by exactly one rank.  Shared objects are eliminated last on every rank; per
- * LM step the library calls `fn` three times on the handle's stream:
+ * LM step the library calls `fn` three times on the handle's stream (and once at the start of a solve, op SUM on 2 doubles: the job's fixed cost and a hash of this
+ * rank's order of the shared objects -- the shared tail follows the objects' UPLOADED positions, so a rank whose shared objects carry other values is refused with
+ * OBVI_ERR_INVALID_ARGUMENT instead of having its tiles summed against the wrong objects):
  *   (1) op SUM  on the packed J^T J diagonal blocks and gradients of the shared objects   (n_shared * 56 doubles)
  *   (2) op SUM  on the trailing shared-object tiles of the reduced system + right-hand side, after the rank's own
  *               poses / points / private objects have been eliminated

@@ -47,6 +47,8 @@ enum Scalar {
   SC_SUM_END,
   SC_GMAX_BITS = SC_SUM_END,  // max |g_i| (IEEE bits, via integer atomicMax; non-negative doubles order like u64)
   SC_COST_FIXED,      // residual blocks whose every parameter block is constant
+  SC_TAIL_ORDER,      // multi-GPU: a 40-bit hash of this rank's order of the shared tail (as double); summed with SC_COST_FIXED at the start of a solve:
+                      // every rank must find world x its own value (the tail's tiles are summed across ranks position by position)
   SC_COUNT = 32
 };
 

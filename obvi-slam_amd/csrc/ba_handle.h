@@ -174,6 +174,7 @@ struct obvi_ba_handle {
   void* allreduce_user = nullptr;
   std::vector<uint8_t> h_is_shared;      // per object index (caller order)
   int32_t rank = 0, world = 1;
+  double tail_order_hash = 0.0;          // 40-bit hash (as double) of the shared objects' indices in tail order (plan.cpp)
   std::vector<int32_t> h_shared_ov;      // reduced object indices of the shared objects in the order of the tail (the same on every rank: plan.cpp)
   DevBuf<int32_t> d_shared_ov;
   DevBuf<uint8_t> d_obj_shared;

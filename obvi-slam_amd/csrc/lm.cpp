@@ -198,10 +198,18 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   launch_pose_cache(s, h->P, h->d_pose.get(), h->d_pc.get(), h->reproj_variant == OBVI_REPROJECTION_ANALYTIC);
   launch_cost(s, blocks_dev(h), reproj_pose_dev(h), small_dev(h), h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(),
               h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), 1, h->d_scal.get());
-  if (h->allreduce != nullptr && !h->h_shared_ov.empty() &&
-      h->allreduce(h->allreduce_user, h->d_scal.get() + SC_COST_FIXED, 1, 0, s)) return fail(h, OBVI_ERR_HIP, "allreduce hook (fixed cost)");
+  const bool exchanging = h->allreduce != nullptr && !h->h_shared_ov.empty();
+  if (exchanging) {
+    // the fixed cost of the job, and -- in the same collective -- proof that every rank lays the shared tail out alike: the order follows the shared objects'
+    // uploaded positions (plan.cpp), which the contract says are the same on every rank; a host that breaks it must not get tiles summed across positions
+    static_assert(SC_TAIL_ORDER == SC_COST_FIXED + 1, "summed together");
+    h2d_async(h->d_scal.get() + SC_TAIL_ORDER, &h->tail_order_hash, sizeof(double), s);
+    if (h->allreduce(h->allreduce_user, h->d_scal.get() + SC_COST_FIXED, 2, 0, s)) return fail(h, OBVI_ERR_HIP, "allreduce hook (fixed cost)");
+  }
   OBVI_HIP(hipMemcpyAsync(h->h_scal, h->d_scal.get(), sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
   sync(h);
+  if (exchanging && h->h_scal[SC_TAIL_ORDER] != (double)h->world * h->tail_order_hash)
+    return fail(h, OBVI_ERR_INVALID_ARGUMENT, "solve: the ranks order the shared objects differently -- every rank must upload the shared objects with the same indices and the same values (include/obvi_ba.h, multi-GPU)");
   const double fixed_cost = h->h_scal[SC_COST_FIXED];
   sum->fixed_cost = fixed_cost;
   sum->num_parameters_reduced = (int32_t)h->num_params;

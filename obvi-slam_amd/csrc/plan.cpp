@@ -202,6 +202,9 @@ void prepare_plan(obvi_ba_handle* h) {
       h->tail_t0 = (int32_t)(row / kTile);
       place_node(0, 0, tail_objs);
       for (int64_t o : tail_objs) h->h_shared_ov.push_back(obj_vid[o]);
+      uint64_t hsh = 1469598103934665603ull;   // the order as this rank derived it: compared across ranks at the start of every solve (lm.cpp)
+      for (int64_t o : tail_objs) { hsh ^= (uint64_t)o; hsh *= 1099511628211ull; }
+      h->tail_order_hash = (double)(hsh >> 24);
     }
     for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) pose_vid[p] = pos[nat[p]];
     h->h_row_of_nat.resize(nPv);

@@ -19,13 +19,13 @@ split_problem = helpers.split_problem
 
 
 def check_collectives(log, n_shared, world):
-    """The protocol of include/obvi_ba.h: once per solve the fixed cost (1 double); per LM submission three sums -- the shared objects' blocks
+    """The protocol of include/obvi_ba.h: once per solve the fixed cost + the hash of the shared tail's order (2 doubles); per LM submission three sums -- the shared objects' blocks
     (56 per object), the shared tail of the reduced system (skipped by a linearisation-only submission), the scalar block + one
     gradient-maximum slot per rank -- and nothing else (no max-reduction, no fourth collective)."""
     assert all(op == 0 for _, op in log)
     blocks = sum(1 for n, _ in log if n == 56 * n_shared)
     scalars = sum(1 for n, _ in log if n == 9 + world)
-    fixed = sum(1 for n, _ in log if n == 1)
+    fixed = sum(1 for n, _ in log if n == 2)
     tails = len(log) - blocks - scalars - fixed
     assert blocks == scalars >= 1 and fixed == 1 and tails in (blocks, blocks - 1), (blocks, scalars, fixed, tails)
     return blocks
@@ -127,6 +127,33 @@ def test_two_windows_sharing_objects_equal_the_oracles_joint_solve(scene):
     for rank, (q, pts, rng) in enumerate(wins):
         idx = np.array([pos[int(p)] for p in pts])
         assert np.abs(handles[rank].get_points() - jpts[idx]).max() < 1e-7
+
+
+def test_ranks_that_upload_the_shared_objects_differently_are_refused(scene):
+    """The shared tail is laid out along the shared objects' UPLOADED positions (plan.cpp), the same on every rank because the contract says every rank
+    uploads the shared objects with the same values.  A host that breaks the contract -- here: rank 1 starts two objects from each other's place -- would have
+    its tail tiles summed against the wrong objects; the hash of the order travels with the fixed cost at the start of the solve and every rank refuses."""
+    wins, joint, keep_pts = split_problem(scene, 30)
+    q1 = dict(wins[1][0]); q1["objects"] = q1["objects"].copy()
+    q1["objects"][[0, 2], :2] = q1["objects"][[2, 0], :2] + 40.0        # far enough apart to change the curve's order
+    emu = EmulatedAllReduce(2)
+    handles, errs = [], [None, None]
+    for rank, q in enumerate((wins[0][0], q1)):
+        ba = helpers.product_ba()
+        synth.upload(ba, q)
+        ba.set_shared_objects(np.ones(len(q["objects"]), np.uint8), rank, 2)
+        ba.set_allreduce(emu.hook(rank))
+        handles.append(ba)
+
+    def run(rank):
+        try:
+            handles[rank].solve(helpers.ba_params(max_it=3))
+        except obvi_ba.ObviError as e:
+            errs[rank] = str(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join(timeout=120) for t in th]
+    assert all(e is not None and "status -1" in e and "order the shared objects differently" in e for e in errs), errs
+    assert emu.calls == 1                                               # the solve stopped at its first collective, on both ranks
 
 
 def config4_windows(world, P=500, L=50000, O=25):
