@@ -66,6 +66,11 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
       std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
       for (int c = 0; c < side_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
       OBVI_HIP(hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
+    } else if (const char* pr = std::getenv("OBVI_SIDE_PRIORITY")) {
+      // (tuning knob, round 5 A/B) the side stream at another dispatch priority than the main stream: 1 = lowest, -1 = highest the device offers
+      int lo = 0, hi = 0;
+      OBVI_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      OBVI_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, std::atoi(pr) > 0 ? lo : hi));
     } else {
       OBVI_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     }
