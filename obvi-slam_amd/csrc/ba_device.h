@@ -180,6 +180,11 @@ void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, c
 // into groups of kSchurGroupCols 16-wide tile columns; visits are streamed through LDS in batches of at most
 // kSchurBatchVisits visits / kSchurBatchBytes of 144-byte slots
 constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSchurBatchBytes = 32768, kSchurBatchVisits = 128;
+// the slot tables of the strip kernel, filled on the device (plan_kernels.hip): per visit the point, its tile bits of the (chunk, group) work list
+// (bit 15: two records per frame), the slot its image starts at inside its batch and the offset of its slots from the first slot of its workgroup
+struct PlanVisit { uint32_t l; uint16_t twin_bits; uint16_t base; uint32_t rel; };
+void launch_plan_visit_slots(hipStream_t s, int64_t nvis, const PlanVisit* pv, const uint32_t* wg_ptr, const uint32_t* wg_slot0, int32_t nwg, const int32_t* wg_f0, const int32_t* wg_group,
+                             const uint32_t* point_ptr, const uint8_t* rp_active, const uint32_t* rp_pose, const int32_t* frame_of_pose, uint32_t zero16, uint32_t* visits, uint32_t* slot_src);
 void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
                          const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
                          const int32_t* wg_f0, const int32_t* wg_group);

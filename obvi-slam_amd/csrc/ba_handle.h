@@ -122,6 +122,7 @@ struct obvi_ba_handle {
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b, d_chunk_ptr, d_chunk_points;
   DevBuf<int32_t> d_row_of_nat, d_chunk_f0, d_chunk_group;
   DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
+  DevBuf<PlanVisit> d_plan_visits; DevBuf<uint32_t> d_plan_wg_ptr, d_plan_wg_slot0; DevBuf<int32_t> d_plan_frame;   // inputs of the device-side slot fill (plan.cpp, plan_kernels.hip)
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;
   DevBuf<int32_t> d_tiles, d_lvl_k, d_trsm_ik, d_upd_ij, d_upd_kptr, d_upd_k, d_rh_i, d_rh_kptr, d_rh_k, d_col_ptr, d_col_i, d_bw_kj, d_bw_chains;

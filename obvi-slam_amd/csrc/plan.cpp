@@ -393,7 +393,7 @@ void prepare_plan(obvi_ba_handle* h) {
   const uint32_t zero16 = (uint32_t)((18ull * (uint64_t)h->n_rp + 4ull * (uint64_t)L + 4ull) / 2);   // zero page behind the Z blocks
   std::vector<uint32_t> wg_bptr(1, 0), bfirst(1, 0), bslot(1, 0), visits, slot_src;
   std::vector<int32_t> wg_f0, wg_group;
-  visits.reserve(4 * gv.size());
+
   constexpr uint32_t kBatchSlots = kSchurBatchBytes / 144;
   auto visit_slots = [&](const GVisit& v, uint32_t base, std::vector<uint32_t>& out, uint32_t* rec) {
     // The image of a visit covers every strip frame that an ACTIVE tile of the visit touches -- row tiles that hold one of the point's
@@ -463,36 +463,68 @@ void prepare_plan(obvi_ba_handle* h) {
     for (size_t w = q; w < e; w += (size_t)per) wgs.push_back({w, std::min(e, w + (size_t)per), gv[q].chunk, gv[q].group});
     q = e;
   }
-  struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches; };
+  // Who fills the slot tables.  Default (round 5): the DEVICE (plan_kernels.hip: one lane per visit walks the point's observations).  What is left for the
+  // host is to deal the visits to batches, which needs a visit's slot COUNT only -- a function of its tile bits, its group and the twin flag.
+  // OBVI_PLAN_SLOTS_ON_HOST=1: the host fills them as rounds 1-4 did (the check: both give the same tables).
+  const bool slots_on_host = std::getenv("OBVI_PLAN_SLOTS_ON_HOST") && std::atoi(std::getenv("OBVI_PLAN_SLOTS_ON_HOST")) != 0;
+  auto visit_slot_count = [&](const GVisit& v) -> uint32_t {
+    constexpr int kRowTile0 = SBACK * 6 / 16;
+    uint32_t rows = 0;
+    int32_t A0 = INT32_MAX, A1 = -1, B0 = INT32_MAX, B1 = -1;
+    for (int c = 0; c < kSchurGroupCols; ++c) {
+      const uint32_t t3 = (v.bits >> (3 * c)) & 7u;
+      if (!t3) continue;
+      rows |= t3;
+      const int t = kSchurGroupCols * v.group + c;
+      B0 = std::min<int32_t>(B0, (16 * t) / 6); B1 = std::max<int32_t>(B1, (16 * t + 15) / 6);
+    }
+    for (int r = 0; r < 3; ++r)
+      if ((rows >> r) & 1u) { const int t = kRowTile0 + r; A0 = std::min<int32_t>(A0, (16 * t) / 6); A1 = std::max<int32_t>(A1, (16 * t + 15) / 6); }
+    A1 = std::min<int32_t>(A1, kSchurWindowFrames - 1); B1 = std::min<int32_t>(B1, kSchurWindowFrames - 1);
+    const bool merged = B0 <= A1 + 1 && A0 <= B1 + 1;
+    if (merged) { const uint32_t span = (uint32_t)(std::max(A1, B1) - std::min(A0, B0) + 1); return span + 1 + (v.twin ? span : 0u); }
+    const uint32_t one = (uint32_t)(A1 - A0 + 1) + 1 + (uint32_t)(B1 - B0 + 1);
+    return v.twin ? 2 * one : one;
+  };
+  struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches, wg_slots; };
   const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 1024));
   std::vector<BatchLists> lists_t(parts2);
+  std::vector<PlanVisit> plan_visits(slots_on_host ? 0 : gv.size());
   parallel_ranges((int64_t)wgs.size(), parts2, [&](int part, int64_t g0, int64_t g1) {
     BatchLists& o = lists_t[part];
     std::vector<uint32_t> vs;
     uint32_t rec[4];
+    uint32_t nvis_part = 0, nslots_part = 0;   // visits / slots of this part so far (device route: the lists themselves are not kept)
     for (int64_t g = g0; g < g1; ++g) {
-      uint32_t used = 0, count = 0, nb = 0;
+      uint32_t used = 0, count = 0, nb = 0, wg_slots = 0;
       for (size_t t = wgs[g].w; t < wgs[g].we; ++t) {
-        visit_slots(gv[t], used, vs, rec);
-        if (count == (uint32_t)kSchurBatchVisits || used + (uint32_t)vs.size() > kBatchSlots) {
-          o.end_visit.push_back((uint32_t)(o.visits.size() / 4)); o.end_slot.push_back((uint32_t)o.slot_src.size()); ++nb; used = 0; count = 0;
-          visit_slots(gv[t], used, vs, rec);
+        const uint32_t n = slots_on_host ? (visit_slots(gv[t], used, vs, rec), (uint32_t)vs.size()) : visit_slot_count(gv[t]);
+        if (count == (uint32_t)kSchurBatchVisits || used + n > kBatchSlots) {
+          o.end_visit.push_back(nvis_part); o.end_slot.push_back(nslots_part); ++nb; used = 0; count = 0;
+          if (slots_on_host) visit_slots(gv[t], used, vs, rec);
         }
-        o.visits.insert(o.visits.end(), rec, rec + 4);
-        o.slot_src.insert(o.slot_src.end(), vs.begin(), vs.end());
-        used += (uint32_t)vs.size(); ++count;
+        if (slots_on_host) { o.visits.insert(o.visits.end(), rec, rec + 4); o.slot_src.insert(o.slot_src.end(), vs.begin(), vs.end()); }
+        else plan_visits[t] = PlanVisit{gv[t].l, (uint16_t)(gv[t].bits | (gv[t].twin ? 0x8000u : 0u)), (uint16_t)used, wg_slots};
+        used += n; ++count; ++nvis_part; nslots_part += n; wg_slots += n;
       }
-      o.end_visit.push_back((uint32_t)(o.visits.size() / 4)); o.end_slot.push_back((uint32_t)o.slot_src.size()); ++nb;
-      o.wg_batches.push_back(nb);
+      o.end_visit.push_back(nvis_part); o.end_slot.push_back(nslots_part); ++nb;
+      o.wg_batches.push_back(nb); o.wg_slots.push_back(wg_slots);
     }
   });
-  for (const BatchLists& o : lists_t) {
-    const uint32_t voff = (uint32_t)(visits.size() / 4), soff = (uint32_t)slot_src.size();
-    visits.insert(visits.end(), o.visits.begin(), o.visits.end());
-    slot_src.insert(slot_src.end(), o.slot_src.begin(), o.slot_src.end());
-    for (size_t b = 0; b < o.end_visit.size(); ++b) { bfirst.push_back(voff + o.end_visit[b]); bslot.push_back(soff + o.end_slot[b]); }
-    for (uint32_t nb : o.wg_batches) wg_bptr.push_back(wg_bptr.back() + nb);
+  std::vector<uint32_t> plan_wg_ptr, plan_wg_slot0;   // device route: first visit / first slot of every workgroup
+  size_t total_slots = 0;
+  {
+    uint32_t voff = 0, soff = 0;
+    for (const BatchLists& o : lists_t) {
+      if (slots_on_host) { visits.insert(visits.end(), o.visits.begin(), o.visits.end()); slot_src.insert(slot_src.end(), o.slot_src.begin(), o.slot_src.end()); }
+      for (size_t b = 0; b < o.end_visit.size(); ++b) { bfirst.push_back(voff + o.end_visit[b]); bslot.push_back(soff + o.end_slot[b]); }
+      uint32_t s0 = soff;
+      for (size_t w = 0; w < o.wg_batches.size(); ++w) { wg_bptr.push_back(wg_bptr.back() + o.wg_batches[w]); plan_wg_slot0.push_back(s0); s0 += o.wg_slots[w]; }
+      if (!o.end_visit.empty()) { voff += o.end_visit.back(); soff += o.end_slot.back(); }
+    }
+    total_slots = soff;
   }
+  for (const WgRange& g : wgs) plan_wg_ptr.push_back((uint32_t)g.w);
   for (const WgRange& g : wgs) { wg_f0.push_back(g.chunk * SR); wg_group.push_back(g.group); }
   h->schur_twins = any_twin ? 1 : 0;
   h->nchunks = (int64_t)wg_f0.size();
@@ -517,7 +549,7 @@ void prepare_plan(obvi_ba_handle* h) {
 
   if (stage_times)
     std::fprintf(stderr, "  schur plan: %zu visits, %zu workgroups, %zu batches (%.1f slots each), %zu slots = %.1f MB gathered per launch\n", gv.size(), wgs.size(), bslot.size() - 1,
-                 (double)slot_src.size() / std::max<size_t>(1, bslot.size() - 1), slot_src.size(), 144e-6 * (double)slot_src.size());
+                 (double)total_slots / std::max<size_t>(1, bslot.size() - 1), total_slots, 144e-6 * (double)total_slots);
   stage("schur batches");
   // ---- tile mask of the reduced matrix (lower triangle) and symbolic fill ----
   for (int k = 0; k < nt; ++k) mask[(size_t)k * nt + k] = 1;
@@ -754,8 +786,20 @@ void prepare_plan(obvi_ba_handle* h) {
   h->h_obj_vid = obj_vid;
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
   h->d_pair_a.upload(pair_a, s); h->d_pair_b.upload(pair_b, s);
-  h->d_chunk_ptr.upload(wg_bptr, s); h->d_batch_first.upload(bfirst, s); h->d_batch_slot.upload(bslot, s); h->d_chunk_points.upload(visits, s); h->d_chunk_f0.upload(wg_f0, s); h->d_chunk_group.upload(wg_group, s);
-  h->d_slot_src.upload(slot_src, s); h->d_row_of_nat.upload(h->h_row_of_nat, s);
+  h->d_chunk_ptr.upload(wg_bptr, s); h->d_batch_first.upload(bfirst, s); h->d_batch_slot.upload(bslot, s); h->d_chunk_f0.upload(wg_f0, s); h->d_chunk_group.upload(wg_group, s);
+  if (slots_on_host) {
+    h->d_chunk_points.upload(visits, s); h->d_slot_src.upload(slot_src, s);
+  } else {
+    // the two big tables are written where they are read: a lane per visit (plan_kernels.hip) from 12 bytes per visit instead of 60
+    std::vector<int32_t> frame_of_pose((size_t)P + 1, -1);
+    for (int64_t pz = 0; pz < P; ++pz) if (pose_vid[pz] >= 0) frame_of_pose[pz] = nat[pz];
+    h->d_plan_frame.upload(frame_of_pose, s); h->d_plan_visits.upload(plan_visits, s); h->d_plan_wg_ptr.upload(plan_wg_ptr, s); h->d_plan_wg_slot0.upload(plan_wg_slot0, s);
+    h->d_chunk_points.resize(4 * plan_visits.size() + 4); h->d_slot_src.resize(total_slots + 4);
+    launch_plan_visit_slots(s, (int64_t)plan_visits.size(), h->d_plan_visits.get(), h->d_plan_wg_ptr.get(), h->d_plan_wg_slot0.get(), (int32_t)plan_wg_ptr.size(), h->d_chunk_f0.get(), h->d_chunk_group.get(),
+                            h->d_point_ptr.get(), h->d_rp_active.get(), h->d_rp_pose.get(), h->d_plan_frame.get(), zero16, h->d_chunk_points.get(), h->d_slot_src.get());
+    OBVI_HIP(hipStreamSynchronize(s));   // the kernel reads vectors of this function (staged or straight from pageable memory): they must outlive it
+  }
+  h->d_row_of_nat.upload(h->h_row_of_nat, s);
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
   h->d_upd_ij.upload(upd_ij, s); h->d_upd_kptr.upload(upd_kptr, s); h->d_upd_k.upload(upd_k, s);
   h->d_rh_i.upload(rh_i, s); h->d_rh_kptr.upload(rh_kptr, s); h->d_rh_k.upload(rh_k, s);

@@ -89,6 +89,40 @@ def test_ragged_structures_with_a_stereo_rig():
     assert helpers.rel_err(Sg, So) < 1e-11 and helpers.rel_err(bg, bo) < 1e-10
 
 
+@pytest.mark.parametrize("which", ["ragged", "stereo", "window"])
+def test_slot_tables_filled_on_the_device_equal_the_hosts(which, monkeypatch):
+    """Round 5: the slot tables of the Schur strip kernel (per visit four words, per 144-byte slot its source) are filled on the device, one lane per visit
+    (plan_kernels.hip); the host only deals the visits to batches.  OBVI_PLAN_SLOTS_ON_HOST=1 is the host's own fill of rounds 1-4.  Same tables, hence --
+    on deterministic handles -- bit-identical reduced systems and LM runs: gaps, loop closures, tracks over 64 sightings, three sightings from one frame,
+    unobserved blocks (ragged), two records per frame (stereo: the second layer), and an ordinary window with objects."""
+    if which == "ragged":
+        prob = _ragged_problem()
+    elif which == "stereo":
+        prob = synth.make_problem(P=60, L=300, O=0, seed=9, stereo=True, outlier_frac=0.0)
+        keep = ~((prob["rp_point"] % 7 == 0) & (prob["rp_pose"] % 5 == 2))
+        for k in ("rp_pose", "rp_point", "rp_cam", "rp_pixel", "rp_sigma", "rp_is_outlier"):
+            if k in prob and np.ndim(prob[k]) > 0:
+                prob[k] = prob[k][keep]
+    else:
+        prob = synth.make_problem(P=130, L=9000, O=6, seed=21, const_poses=5, min_obj_obs=8)
+    out = []
+    for on_host in ("1", "0"):
+        monkeypatch.setenv("OBVI_PLAN_SLOTS_ON_HOST", on_host)
+        g = helpers.product_ba(deterministic=True)
+        synth.upload(g, prob)
+        S, b = g.debug_reduced_system(100.0)
+        s = g.solve(helpers.ba_params(max_it=3, ftol=0, ptol=0, gtol=0))
+        # a mask change keeps the plan (prepare_masks): the tables must serve the masked problem as well
+        mask = np.ones(len(prob["rp_pose"]), np.uint8); mask[::9] = 0
+        g.set_active_mask(0, mask)
+        s2 = g.solve(helpers.ba_params(max_it=2, ftol=0, ptol=0, gtol=0))
+        out.append((S, b, [(i.cost, i.step_norm, i.step_is_successful) for i in g.iterations()], s.final_cost, s2.final_cost, g.get_poses(), g.problem_stats()))
+        g.close()
+    (S0, b0, it0, f0, m0, p0, st0), (S1, b1, it1, f1, m1, p1, st1) = out
+    assert st0 == st1 and np.array_equal(S0, S1) and np.array_equal(b0, b1)
+    assert it0 == it1 and f0 == f1 and m0 == m1 and np.array_equal(p0, p1)
+
+
 @pytest.mark.parametrize("knobs", [
     {"OBVI_PRE_MAX": "0"},                                   # every diagonal product is an update job: the signal / wait path of k_update_potrf
     {"OBVI_PRE_MAX": "8"},                                   # ... all of them applied by the potrf workgroups
@@ -109,6 +143,7 @@ def test_ragged_structures_with_a_stereo_rig():
     {"OBVI_CHOL_XCD": "1", "OBVI_SLICE_MAX": "0"},           # ... with it
     {"OBVI_BACKSUB_LANES": "1"},                             # back-substitution: a lane per feature
     {"OBVI_BACKSUB_LANES": "32"},                            # ... 32 lanes per feature (most of them beyond the feature's last sighting)
+    {"OBVI_PLAN_SLOTS_ON_HOST": "1"},                        # the strip kernel's slot tables filled by the host (rounds 1-4) instead of by plan_kernels.hip
 ])
 def test_schedule_knobs_change_round_off_only(knobs, monkeypatch):
     """The elimination order and the launch schedule are free choices (exact factorisation): whatever the tuning knobs say, a step
