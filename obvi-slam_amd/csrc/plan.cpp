@@ -23,14 +23,27 @@ void prepare_plan(obvi_ba_handle* h) {
   const int64_t P = h->P, L = h->L, O = h->O;
   std::vector<uint8_t> pose_used(P, 0), obj_used(O, 0), point_used(L, 0);
   int64_t nres = 0;
-  for (int64_t a = 0; a < h->n_rp; ++a) {
-    if (!h->h_rp_active[a]) continue;
-    const uint32_t p = h->h_rp_pose[a], l = h->h_rp_point[a];
-    const bool cp = h->h_pose_const[p], cl = h->h_point_const[l];
-    if (cp && cl) continue;
-    nres += 2;
-    if (!cp) pose_used[p] = 1;
-    if (!cl) point_used[l] = 1;
+  {   // ranges of observations on the host threads: the flags are idempotent byte stores of 1 (relaxed atomics: ranges share poses, and a point at a range's edge)
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), h->n_rp / 65536));
+    std::vector<int64_t> nres_t(parts, 0);
+    std::vector<std::vector<uint8_t>> pose_used_t(parts);   // per range: every range sees every pose (sixteen threads storing into the same P bytes were slower than one)
+    parallel_ranges(h->n_rp, parts, [&](int part, int64_t a0, int64_t a1) {
+      int64_t n = 0;
+      std::vector<uint8_t>& pu = pose_used_t[part];
+      pu.assign((size_t)P, 0);
+      for (int64_t a = a0; a < a1; ++a) {
+        if (!h->h_rp_active[a]) continue;
+        const uint32_t p = h->h_rp_pose[a], l = h->h_rp_point[a];
+        const bool cp = h->h_pose_const[p], cl = h->h_point_const[l];
+        if (cp && cl) continue;
+        n += 2;
+        if (!cp) pu[p] = 1;
+        if (!cl) __atomic_store_n(&point_used[l], (uint8_t)1, __ATOMIC_RELAXED);   // the observations are in point order: ranges meet in one point at most
+      }
+      nres_t[part] = n;
+    });
+    for (int64_t n : nres_t) nres += n;
+    for (const auto& pu : pose_used_t) for (int64_t p = 0; p < P && !pu.empty(); ++p) pose_used[p] |= pu[p];
   }
   for (int64_t i = 0; i < h->n_bb; ++i) {
     if (!h->h_bb_active[i]) continue;
@@ -70,21 +83,29 @@ void prepare_plan(obvi_ba_handle* h) {
   {
     std::vector<int32_t> reach(nPv);
     for (int64_t f = 0; f < nPv; ++f) reach[f] = (int32_t)f;
-    for (int64_t l = 0; l < L; ++l) {
-      if (!point_var[l]) continue;
-      int32_t lo = INT32_MAX, hi = -1;
-      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
-        if (!h->h_rp_active[a]) continue;
-        const int32_t f = nat[h->h_rp_pose[a]];
-        if (f >= 0) { lo = std::min(lo, f); hi = std::max(hi, f); }
-      }
-      if (hi < 0) continue;
-      for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {   // every frame of the track couples to its last one
-        if (!h->h_rp_active[a]) continue;
-        const int32_t f = nat[h->h_rp_pose[a]];
-        if (f >= 0) reach[f] = std::max(reach[f], hi);
-      }
-      (void)lo;
+    {   // ranges of points on the host threads, every range with a reach array of its own (nPv integers), joined by maximum
+      const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 4096));
+      std::vector<std::vector<int32_t>> reach_t(parts);
+      parallel_ranges(L, parts, [&](int part, int64_t l0, int64_t l1) {
+        std::vector<int32_t>& r = reach_t[part];
+        r.assign((size_t)nPv, -1);
+        for (int64_t l = l0; l < l1; ++l) {
+          if (!point_var[l]) continue;
+          int32_t hi = -1;
+          for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {
+            if (!h->h_rp_active[a]) continue;
+            const int32_t f = nat[h->h_rp_pose[a]];
+            if (f >= 0) hi = std::max(hi, f);
+          }
+          if (hi < 0) continue;
+          for (uint32_t a = h->h_point_ptr[l]; a < h->h_point_ptr[l + 1]; ++a) {   // every frame of the track couples to its last one
+            if (!h->h_rp_active[a]) continue;
+            const int32_t f = nat[h->h_rp_pose[a]];
+            if (f >= 0) r[f] = std::max(r[f], hi);
+          }
+        }
+      });
+      for (const auto& r : reach_t) for (int64_t f = 0; f < nPv && !r.empty(); ++f) reach[f] = std::max(reach[f], r[f]);
     }
     for (int64_t i = 0; i < h->n_rl; ++i) {
       if (!h->h_rl_active[i]) continue;
@@ -252,7 +273,7 @@ void prepare_plan(obvi_ba_handle* h) {
   struct Pair { uint64_t key; uint32_t a, b; };
   std::vector<Pair> pairs;
   struct Visit { int32_t chunk; uint32_t l, beg, k; bool twin; uint64_t tiles; };
-  std::vector<Visit> visit_list;
+  std::vector<std::vector<Visit>> visits_t;   // the visits, in point order: one list per range of points (they are never merged: the counting sort below reads the ranges)
   int64_t n_window_pairs = 0;
   bool any_twin = false;
   // pose pairs that share a point: collected in a bitmap (one store per pair of sightings) and turned into tile marks once per
@@ -264,7 +285,7 @@ void prepare_plan(obvi_ba_handle* h) {
     // point order.  Without the bitmap the tile marks go straight into the mask: one thread.
     const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 256)) : 1;   // the workers exist (host_pool): a range of a few hundred points is worth handing out
     std::vector<std::vector<Pair>> pairs_t(parts);
-    std::vector<std::vector<Visit>> visits_t(parts);
+    visits_t.assign(parts, {});
     // small windows: every range marks its pose pairs in a bitmap of its own (a few KB), merged afterwards -- sixteen threads storing
     // into the same forty cache lines were slower than one
     const bool private_bitmaps = pair_bitmap && parts > 1 && (size_t)h->nPv * (size_t)h->nPv <= ((size_t)1 << 18);
@@ -351,37 +372,59 @@ void prepare_plan(obvi_ba_handle* h) {
     for (const auto& bm : pose_pair_t) for (size_t i = 0; i < bm.size(); ++i) pose_pair[i] |= bm[i];
     for (int t = 0; t < parts; ++t) {
       pairs.insert(pairs.end(), pairs_t[t].begin(), pairs_t[t].end());
-      visit_list.insert(visit_list.end(), visits_t[t].begin(), visits_t[t].end());
       n_window_pairs += window_pairs_t[t]; any_twin = any_twin || twin_t[t];
-      std::vector<Pair>().swap(pairs_t[t]); std::vector<Visit>().swap(visits_t[t]);
+      std::vector<Pair>().swap(pairs_t[t]);
     }
   }
-  if (pair_bitmap)
-    for (int64_t hi = 0; hi < h->nPv; ++hi) {
-      const uint8_t* row = &pose_pair[(size_t)hi * (size_t)h->nPv];
-      for (int64_t lo = 0; lo <= hi; ++lo) if (row[lo]) mark(h->h_pose_row[hi], 6, h->h_pose_row[lo], 6);
-    }
+  if (pair_bitmap)   // rows of the bitmap on the host threads: the marks are idempotent byte stores of 1 (relaxed atomics: two pose pairs may share a tile)
+    parallel_ranges(h->nPv, (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), h->nPv / 64)), [&](int, int64_t r0, int64_t r1) {
+      for (int64_t hi = r0; hi < r1; ++hi) {
+        const uint8_t* row = &pose_pair[(size_t)hi * (size_t)h->nPv];
+        const int64_t row_hi = h->h_pose_row[hi];
+        for (int64_t lo = 0; lo <= hi; ++lo) {
+          if (!row[lo]) continue;
+          const int64_t row_lo = h->h_pose_row[lo];
+          const int t0 = (int)(row_hi / kTile), t1 = (int)((row_hi + 5) / kTile), c0 = (int)(row_lo / kTile), c1 = (int)((row_lo + 5) / kTile);
+          for (int ti = t0; ti <= t1; ++ti) for (int tj = c0; tj <= c1; ++tj) if (ti >= tj) __atomic_store_n(&mask[(size_t)ti * nt_ + tj], (uint8_t)1, __ATOMIC_RELAXED);
+        }
+      }
+    });
   stage("schur pairs / visits");
   // one work list per (chunk, column group): the visits with a tile in that group
   constexpr int kGroups = (kSchurWindowFrames * 6 / 16) / kSchurGroupCols, kGroupBits = 3 * kSchurGroupCols;
   struct GVisit { int32_t chunk, group; uint32_t l, beg, k; bool twin; uint32_t bits; };
   std::vector<GVisit> gv;
   {
-    // ordered by chunk, then by group descending, visits of a list in point order: a counting sort over the (chunk, group) buckets
-    int32_t max_chunk = -1;
-    for (const Visit& v : visit_list) max_chunk = std::max(max_chunk, v.chunk);
-    std::vector<size_t> start((size_t)(max_chunk + 1) * kGroups + 1, 0);
+    // ordered by chunk, then by group descending, visits of a list in point order: a counting sort over the (chunk, group) buckets -- counted and
+    // scattered range by range on the host threads (the ranges are in point order: bucket by bucket, range after range, it is the serial sort)
+    const int nparts = (int)visits_t.size();
+    const size_t nbuckets = ((size_t)(h->nPv / SR) + 2) * kGroups;
     auto bucket = [&](int32_t chunk, int g) { return (size_t)chunk * kGroups + (size_t)(kGroups - 1 - g); };
     auto group_bits = [&](const Visit& v, int g) { return (uint32_t)(v.tiles >> (kGroupBits * g)) & ((1u << kGroupBits) - 1u); };
-    for (const Visit& v : visit_list)
-      for (int g = 0; g < kGroups; ++g) if (group_bits(v, g)) ++start[bucket(v.chunk, g) + 1];
-    for (size_t b2 = 1; b2 < start.size(); ++b2) start[b2] += start[b2 - 1];
-    gv.resize(start.back());
-    for (const Visit& v : visit_list)
-      for (int g = 0; g < kGroups; ++g) {
-        const uint32_t bits = group_bits(v, g);
-        if (bits) gv[start[bucket(v.chunk, g)]++] = {v.chunk, g, v.l, v.beg, v.k, v.twin, bits};
+    std::vector<std::vector<uint32_t>> cursor_t(nparts);
+    parallel_ranges(nparts, nparts, [&](int, int64_t p0, int64_t p1) {
+      for (int64_t p = p0; p < p1; ++p) {
+        std::vector<uint32_t>& c = cursor_t[p];
+        c.assign(nbuckets, 0);
+        for (const Visit& v : visits_t[p])
+          for (int g = 0; g < kGroups; ++g) if (group_bits(v, g)) ++c[bucket(v.chunk, g)];
       }
+    });
+    size_t total = 0;
+    for (size_t b2 = 0; b2 < nbuckets; ++b2)
+      for (int p = 0; p < nparts; ++p) { const uint32_t n = cursor_t[p][b2]; cursor_t[p][b2] = (uint32_t)total; total += n; }
+    gv.resize(total);
+    parallel_ranges(nparts, nparts, [&](int, int64_t p0, int64_t p1) {
+      for (int64_t p = p0; p < p1; ++p) {
+        std::vector<uint32_t>& c = cursor_t[p];
+        for (const Visit& v : visits_t[p])
+          for (int g = 0; g < kGroups; ++g) {
+            const uint32_t bits = group_bits(v, g);
+            if (bits) gv[c[bucket(v.chunk, g)]++] = {v.chunk, g, v.l, v.beg, v.k, v.twin, bits};
+          }
+        std::vector<Visit>().swap(visits_t[p]);
+      }
+    });
   }
   // slices of a work list: enough workgroups to fill the device on small problems, at most max_visits visits each
   // (deterministic mode: a work list is never cut -- one workgroup, hence one writer, per strip)
@@ -782,6 +825,7 @@ void prepare_plan(obvi_ba_handle* h) {
   stage("lists");
   // ---- upload ----
   hipStream_t s = h->stream;
+  std::vector<int32_t> frame_of_pose;   // (device-side slot fill: alive until finish_upload())
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s);
   h->h_obj_vid = obj_vid;
   h->d_blk_row.upload(blk_row, s); h->d_blk_col.upload(blk_col, s); h->d_blk_ptr.upload(blk_ptr, s);
@@ -791,13 +835,13 @@ void prepare_plan(obvi_ba_handle* h) {
     h->d_chunk_points.upload(visits, s); h->d_slot_src.upload(slot_src, s);
   } else {
     // the two big tables are written where they are read: a lane per visit (plan_kernels.hip) from 12 bytes per visit instead of 60
-    std::vector<int32_t> frame_of_pose((size_t)P + 1, -1);
+    frame_of_pose.assign((size_t)P + 1, -1);
     for (int64_t pz = 0; pz < P; ++pz) if (pose_vid[pz] >= 0) frame_of_pose[pz] = nat[pz];
     h->d_plan_frame.upload(frame_of_pose, s); h->d_plan_visits.upload(plan_visits, s); h->d_plan_wg_ptr.upload(plan_wg_ptr, s); h->d_plan_wg_slot0.upload(plan_wg_slot0, s);
     h->d_chunk_points.resize(4 * plan_visits.size() + 4); h->d_slot_src.resize(total_slots + 4);
     launch_plan_visit_slots(s, (int64_t)plan_visits.size(), h->d_plan_visits.get(), h->d_plan_wg_ptr.get(), h->d_plan_wg_slot0.get(), (int32_t)plan_wg_ptr.size(), h->d_chunk_f0.get(), h->d_chunk_group.get(),
                             h->d_point_ptr.get(), h->d_rp_active.get(), h->d_rp_pose.get(), h->d_plan_frame.get(), zero16, h->d_chunk_points.get(), h->d_slot_src.get());
-    OBVI_HIP(hipStreamSynchronize(s));   // the kernel reads vectors of this function (staged or straight from pageable memory): they must outlive it
+    // (the kernel's inputs went through the pinned arena, or -- too big for it -- straight from vectors of this function: finish_upload() at its end waits then)
   }
   h->d_row_of_nat.upload(h->h_row_of_nat, s);
   h->d_tiles.upload(tiles, s); h->d_lvl_k.upload(lvl_k, s); h->d_trsm_ik.upload(trsm_ik, s);
