@@ -283,7 +283,8 @@ void prepare_plan(obvi_ba_handle* h) {
   {
     // points are independent: ranges of points on host threads (the bitmap is shared: every writer stores the same 1), lists joined in
     // point order.  Without the bitmap the tile marks go straight into the mask: one thread.
-    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / 256)) : 1;   // the workers exist (host_pool): a range of a few hundred points is worth handing out
+    const int64_t grain = std::max(1, env_int("OBVI_PLAN_GRAIN", 256));   // points per range (tuning knob)
+    const int parts = pair_bitmap ? (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), L / grain)) : 1;   // the workers exist (host_pool): a range of a few hundred points is worth handing out
     std::vector<std::vector<Pair>> pairs_t(parts);
     visits_t.assign(parts, {});
     // small windows: every range marks its pose pairs in a bitmap of its own (a few KB), merged afterwards -- sixteen threads storing
@@ -530,7 +531,7 @@ void prepare_plan(obvi_ba_handle* h) {
     return v.twin ? 2 * one : one;
   };
   struct BatchLists { std::vector<uint32_t> visits, slot_src, end_visit, end_slot, wg_batches, wg_slots; };
-  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / 1024));
+  const int parts2 = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)gv.size() / (4 * (int64_t)std::max(1, env_int("OBVI_PLAN_GRAIN", 256)))));
   std::vector<BatchLists> lists_t(parts2);
   std::vector<PlanVisit> plan_visits(slots_on_host ? 0 : gv.size());
   parallel_ranges((int64_t)wgs.size(), parts2, [&](int part, int64_t g0, int64_t g1) {
