@@ -72,13 +72,24 @@ struct LongTermObjectMapAndResults {
   std::vector<obvi::CovarianceRankRepair> covariance_rank_repairs_;                  // parameters that needed a prior for the covariance to exist
 };
 
+// The reference's remaining runner hooks as runFullOptimization hands them on (optimization_runner.h:262-272 continue_opt_checker = ros::ok, :433-497 the
+// visualization callback, offline_object_visual_slam_main.cpp:1046-1049 the limit on the evaluated trajectory), and the switch that routes the session through the
+// runner's reference-shaped specialisation (five template parameters, fifteen constructor arguments; obvi_runner.h) instead of the short constructor + setters.
+struct RunnerHooks {
+  bool reference_shaped_runner_ = false;
+  LimitTrajectoryEvaluationParams limit_trajectory_eval_params_;
+  std::function<bool()> continue_opt_checker_ = []() { return true; };
+  std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&, const VisualizationTypeEnum&, const int&)> visualization_callback_;
+  std::vector<std::string> ignored_hooks_;   // out: the constructor hooks the reference-shaped runner accepted and does not use
+};
+
 // optimization_runner.h:22-651.  `problem_data` carries what the reference passes as bounding_boxes / visual_features / robot_poses /
 // long_term_map after its front ends; `pose_graph_creator` may be empty (a fresh graph) or hand out a checkpoint's graph.
 inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, const FullOVSLAMConfig& config, const OfflineProblemData& problem_data,
                                 const std::function<void(const OfflineProblemData&, MainPgPtr&)>& pose_graph_creator, const std::string& output_checkpoints_dir,
                                 LongTermObjectMapAndResults& output_results, const FrameId& start_at_frame = 0, const bool& add_data_for_starting_frame = true,
                                 int device_id = 0, bool extract_long_term_map = true, MainPgPtr* pose_graph_out = nullptr,
-                                const VisualFeatureAdder& visual_feature_adder = nullptr) {
+                                const VisualFeatureAdder& visual_feature_adder = nullptr, RunnerHooks* hooks = nullptr) {
   const FrameId max_frame_id = problem_data.getMaxFrameId();                                                                 // :186-189
   std::function<FrameId(const FrameId&)> window_provider_func = [&](const FrameId& f) { return provideOptimizationWindow(f, max_frame_id, config.sliding_window_params_); };
   std::function<bool(const FrameId&)> gba_checker = [&](const FrameId& max_frame_to_opt) {                                  // :195-203
@@ -100,18 +111,47 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
     pose_graph->getVisualFeatureEstimates(output_problem_data.visual_feature_results_);
     if (runner_ptr) { output_problem_data.long_term_map_ = runner_ptr->longTermMap(); output_problem_data.covariance_rank_repairs_ = runner_ptr->covarianceRankRepairs(); }
   };
-  Runner runner(config.object_visual_pose_graph_residual_params_, config.pgo_solver_params_, window_provider_func, output_data_extractor, gba_checker, solver_params_provider_func, device_id);
-  runner_ptr = &runner;
-  if (pose_graph_creator) runner.setPoseGraphCreator(pose_graph_creator);
   // :545-640 the post-session merger: decide by centre proximity, merge in the pose graph (the front end's own bookkeeping of the
   // merged objects is association state and not part of this path)
-  runner.setObjectMerger([&](const MainPgPtr& pose_graph) {
+  const std::function<bool(const MainPgPtr&)> object_merger = [&](const MainPgPtr& pose_graph) {
     std::unordered_map<ObjectId, std::unordered_set<ObjectId>> merge_results;
     identifyMergeObjectsBasedOnCenterProximity(pose_graph, config.post_session_object_merge_params_.max_merge_distance_, config.post_session_object_merge_params_.x_y_only_merge_, merge_results);
     if (merge_results.empty()) return false;
     return pose_graph->mergeObjects(merge_results);
-  });
-  if (visual_feature_adder) runner.setVisualFeatureAdder(visual_feature_adder);   // the visual front end decides what enters the graph (obvi_visual_feature_front_end.h)
+  };
+  std::unique_ptr<Runner> runner_holder;
+  if (hooks != nullptr && hooks->reference_shaped_runner_) {
+    // the construction site as the reference writes it (optimization_runner.h:509-543): every hook through the constructor, in the reference's order
+    struct CachedInfo {};   // the reference: util::EmptyStruct
+    using ReferenceShaped = OfflineProblemRunner<OfflineProblemData, ReprojectionErrorFactor, LongTermObjectMapAndResults, CachedInfo, MainPg>;
+    const ReferenceShaped::RefreshResidualChecker refresh_residual_checker = [](const std::pair<FactorType, FeatureFactorId>&, const MainPgPtr&, const CachedInfo&) { return true; };   // :273-279
+    const ReferenceShaped::ResidualCreator residual_creator = [](const std::pair<FactorType, FeatureFactorId>&, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams&, const MainPgPtr&,
+                                                                  obvi::Problem*, obvi::ResidualBlockId&, CachedInfo&) { return false; };                                               // :280-298
+    const std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&)> frame_data_adder =                                                         // :364-418
+        [&](const OfflineProblemData& data, const MainPgPtr& pose_graph, const FrameId& min_frame_id, const FrameId& frame_to_add) {
+          addFrameDataToPoseGraph(data, pose_graph, frame_to_add, config.object_visual_pose_graph_residual_params_.relative_pose_cov_params_, visual_feature_adder, min_frame_id);
+        };
+    const ReferenceShaped::CallbackCreator ceres_callback_creator = [](const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&) {                                  // :420-431
+      return std::vector<std::shared_ptr<obvi_placeholder::IterationCallback>>{};
+    };
+    auto shaped = std::make_unique<ReferenceShaped>(config.object_visual_pose_graph_residual_params_, hooks->limit_trajectory_eval_params_, config.pgo_solver_params_, hooks->continue_opt_checker_,
+                                                    window_provider_func, refresh_residual_checker, residual_creator, pose_graph_creator, frame_data_adder, output_data_extractor,
+                                                    ceres_callback_creator, hooks->visualization_callback_, solver_params_provider_func, object_merger, gba_checker, device_id);
+    hooks->ignored_hooks_ = shaped->ignoredHooks();
+    runner_holder = std::move(shaped);
+  } else {
+    runner_holder = std::make_unique<Runner>(config.object_visual_pose_graph_residual_params_, config.pgo_solver_params_, window_provider_func, output_data_extractor, gba_checker, solver_params_provider_func, device_id);
+    if (pose_graph_creator) runner_holder->setPoseGraphCreator(pose_graph_creator);
+    runner_holder->setObjectMerger(object_merger);
+    if (visual_feature_adder) runner_holder->setVisualFeatureAdder(visual_feature_adder);   // the visual front end decides what enters the graph (obvi_visual_feature_front_end.h)
+    if (hooks != nullptr) {
+      runner_holder->setLimitTrajectoryEvaluationParams(hooks->limit_trajectory_eval_params_);
+      if (hooks->visualization_callback_) runner_holder->setVisualizationCallback(hooks->visualization_callback_);
+      runner_holder->setContinueOptChecker(hooks->continue_opt_checker_);
+    }
+  }
+  Runner& runner = *runner_holder;
+  runner_ptr = &runner;
   runner.setExtractLongTermMap(extract_long_term_map);
   runner.setLongTermMapTunableParams(config.ltm_tunable_params_);
   const bool ok = runner.runOptimization(problem_data, config.optimization_factors_enabled_params_, opt_logger, output_results, start_at_frame, add_data_for_starting_frame);

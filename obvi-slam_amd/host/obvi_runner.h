@@ -43,7 +43,7 @@ typedef std::shared_ptr<MainPg> MainPgPtr;
 // `visual_feature_adder` (optional): the visual-feature front end (obvi_visual_feature_front_end.h) decides which of the frame's
 // observations and features enter the graph (pose_graph_frame_data_adder.h:75-82); without it every observation is added.
 typedef std::function<bool(const OfflineProblemData&, const MainPgPtr&, const FrameId& /*min_frame_id*/, const FrameId& /*max_frame_id*/)> VisualFeatureAdder;
-inline void addFrameDataToPoseGraph(const OfflineProblemData& d, MainPgPtr& pg, const FrameId& frame,
+inline void addFrameDataToPoseGraph(const OfflineProblemData& d, const MainPgPtr& pg, const FrameId& frame,
                                     const pose_graph_optimization::RelativePoseCovarianceOdomModelParams& odom,
                                     const VisualFeatureAdder& visual_feature_adder = nullptr, const FrameId& min_frame_id = 0) {
   if (frame == 0) {
@@ -120,11 +120,25 @@ struct OptimizationRecord {   // one row per solve, for tests / logging
 // an object of the long-term map as the extraction hands it over: estimate + its 7x7 marginal covariance
 struct LongTermMapEntry { ObjectId object_id_; std::array<double, 7> ellipsoid_mean_; std::array<double, 49> covariance_; };
 
-// OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType>
-// (offline_problem_runner.h:23-98) with the input, factor, cache and pose-graph types this path has fixed; the output type and its
-// extractor stay the caller's, as in the reference (:63-67, :100-107, :269-273).
+// offline_problem_runner.h:17-25
+enum VisualizationTypeEnum { BEFORE_ANY_OPTIMIZATION, BEFORE_EACH_OPTIMIZATION, AFTER_EACH_OPTIMIZATION, AFTER_PGO_PLUS_OBJ_OPTIMIZATION, AFTER_ALL_OPTIMIZATION, AFTER_ALL_POSTPROCESSING };
+// limit_trajectory_evaluation_params.h:15-30
+struct LimitTrajectoryEvaluationParams {
+  bool should_limit_trajectory_evaluation_ = false;
+  FrameId max_frame_id_ = 0;   // ignored if should_limit_trajectory_evaluation_ is false
+  bool operator==(const LimitTrajectoryEvaluationParams& rhs) const { return should_limit_trajectory_evaluation_ == rhs.should_limit_trajectory_evaluation_ && max_frame_id_ == rhs.max_frame_id_; }
+  bool operator!=(const LimitTrajectoryEvaluationParams& rhs) const { return !operator==(rhs); }
+};
+
+// OfflineProblemRunner comes in two shapes (one name: a variadic primary with two specialisations).
+//   OfflineProblemRunner<OutputProblemData>: the input, factor, cache and pose-graph types this path has fixed; the output type and its extractor stay the
+//     caller's, as in the reference (offline_problem_runner.h:63-67, :100-107, :269-273).  What the driver and runFullOptimization use.
+//   OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType>: the reference's own template parameter
+//     list and its fifteen-argument constructor (:27-98), below.
+template <typename... Ts> class OfflineProblemRunner;
+
 template <typename OutputProblemData>
-class OfflineProblemRunner {
+class OfflineProblemRunner<OutputProblemData> {
  public:
   using LongTermMapEntry = vslam_types_refactor::LongTermMapEntry;
   using OutputDataExtractor = std::function<void(const OfflineProblemData&, const MainPgPtr&, const pose_graph_optimizer::OptimizationFactorsEnabledParams&, OutputProblemData&)>;
@@ -153,26 +167,38 @@ class OfflineProblemRunner {
     scope.poses_prior_to_window_to_keep_constant_ = enabled.poses_prior_to_window_to_keep_constant_;
     scope.min_low_level_feature_observations_ = enabled.min_low_level_feature_observations_;
     scope.min_object_observations_ = enabled.min_object_observations_;
-    const FrameId max_frame_id = problem_data.getMaxFrameId();
+    FrameId max_frame_id = problem_data.getMaxFrameId();
+    if (limit_trajectory_eval_params_.should_limit_trajectory_evaluation_) max_frame_id = std::min(limit_trajectory_eval_params_.max_frame_id_, max_frame_id);   // :143-147
+    current_problem_data_ = &problem_data;
     MainPgPtr pose_graph;
     if (pose_graph_creator_) pose_graph_creator_(problem_data, pose_graph);                                                  // :149-150 (a checkpoint's graph: run_opt_from_pg_state.cpp:182-185)
     else pose_graph = std::make_shared<MainPg>(problem_data.camera_extrinsics_by_camera_, problem_data.camera_intrinsics_by_camera_);
     if (!pose_graph) return false;
     for (const auto& ltm : problem_data.long_term_map_)
       pose_graph->addLongTermMapObject(ltm.object_id_, ltm.ellipsoid_mean_, problem_data.object_class_.count(ltm.object_id_) ? problem_data.object_class_.at(ltm.object_id_) : "", ltm);
-    if (start_at_frame == 0 && add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_, visual_feature_adder_, 0);
+    if (start_at_frame == 0 && add_data_for_starting_frame) {                                                                // :160-162
+      if (frame_data_adder_) frame_data_adder_(problem_data, pose_graph, 0, 0);
+      else addFrameDataToPoseGraph(problem_data, pose_graph, 0, residual_params_.relative_pose_cov_params_, visual_feature_adder_, 0);
+    }
+    visualize(pose_graph, 0, max_frame_id, BEFORE_ANY_OPTIMIZATION, 0);                                                       // :164-169
     const FrameId first_frame = std::max<FrameId>(1, start_at_frame);
     for (FrameId next_frame_id = first_frame; next_frame_id <= max_frame_id; ++next_frame_id) {                               // :174-226
+      if (have_continue_opt_checker_ && !continue_opt_checker_) { std::cerr << "Halted optimization due to continue checker reporting false" << std::endl; return false; }   // :183-187
       const FrameId start_opt_with_frame = window_provider_func_(next_frame_id);
       scope.min_frame_id_ = start_opt_with_frame; scope.max_frame_id_ = next_frame_id;
       const auto t_add0 = std::chrono::steady_clock::now();
-      if (next_frame_id != start_at_frame || add_data_for_starting_frame) addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_, visual_feature_adder_, start_opt_with_frame);
+      if (next_frame_id != start_at_frame || add_data_for_starting_frame) {                                                  // :196-199
+        if (frame_data_adder_) frame_data_adder_(problem_data, pose_graph, start_opt_with_frame, next_frame_id);
+        else addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_, visual_feature_adder_, start_opt_with_frame);
+      }
       time_add_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_add0).count();
       if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
       IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                 // :219
     }
     if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
+    visualize(pose_graph, 0, max_frame_id, AFTER_ALL_OPTIMIZATION, 1);                                                        // :245-250
     if (!mergeObjectsAtSessionEnd(max_frame_id, enabled, scope, opt_logger, pose_graph, problem)) return false;              // :254-262
+    visualize(pose_graph, 0, max_frame_id, AFTER_ALL_POSTPROCESSING, 1);                                                      // :263-268
     IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();
     // The output extractor's covariance
     // step (IndependentEllipsoidsLongTermObjectMapExtractor::extractLongTermObjectMap, long_term_object_map_extraction.h:
@@ -216,6 +242,17 @@ class OfflineProblemRunner {
     return true;
   }
   void setPoseGraphCreator(const std::function<void(const OfflineProblemData&, MainPgPtr&)>& creator) { pose_graph_creator_ = creator; }
+  // the reference's remaining constructor hooks (offline_problem_runner.h:27-98), optional here:
+  //   frame data adder (:47-51): replaces the built-in addFrameDataToPoseGraph; called with (data, graph, first frame of the window, new frame), (.., 0, 0) for frame 0
+  //   visualization callback (:62-67): called where the reference calls it (:164, :392, :512, :908, :245, :263)
+  //   limit on the evaluated trajectory (:143-147)
+  //   continue-optimisation checker (:183-187): the reference tests the std::function OBJECT (`if (!continue_opt_checker_)`), never calls it; so does this
+  using FrameDataAdder = std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&)>;
+  using VisualizationCallback = std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&, const VisualizationTypeEnum&, const int&)>;
+  void setFrameDataAdder(const FrameDataAdder& adder) { frame_data_adder_ = adder; }
+  void setVisualizationCallback(const VisualizationCallback& cb) { visualization_callback_ = cb; }
+  void setLimitTrajectoryEvaluationParams(const LimitTrajectoryEvaluationParams& p) { limit_trajectory_eval_params_ = p; }
+  void setContinueOptChecker(const std::function<bool()>& checker) { continue_opt_checker_ = checker; have_continue_opt_checker_ = true; }
   void setObjectMerger(const std::function<bool(const MainPgPtr&)>& merger) { object_merger_ = merger; }
   size_t mergeRounds() const { return n_merge_rounds_; }
   const std::vector<OptimizationRecord>& records() const { return records_; }
@@ -272,6 +309,7 @@ class OfflineProblemRunner {
                                 const pose_graph_optimizer::OptimizationScopeParams& scope, const FrameId& max_frame_id, std::optional<OptimizationLogger>& opt_logger,
                                 MainPgPtr& pose_graph, obvi::Problem& problem, const int& attempt_num = 0) {
     const pose_graph_optimization::OptimizationIterationParams iteration_params = iteration_params_provider_func_(next_frame_id);
+    visualize(pose_graph, start_opt_with_frame, next_frame_id, BEFORE_EACH_OPTIMIZATION, attempt_num);                        // :392-397
     if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, false, attempt_num);
     const bool global_ba = gba_checker_(next_frame_id);                                                                      // :407
     bool run_visual_feature_opt = true;
@@ -302,6 +340,7 @@ class OfflineProblemRunner {
           std::cerr << "PGO+objs failed at frame " << next_frame_id << std::endl;
         time_pgo_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pgo0).count(); ++n_pgo_;
         records_.push_back({0, next_frame_id, "pgo", 0, 0, 0, (size_t)next_frame_id + 1, 0, 0, 0});
+        visualize(pose_graph, start_opt_with_frame, next_frame_id, AFTER_PGO_PLUS_OBJ_OPTIMIZATION, attempt_num);             // :512-518
       }
     }
     if (!run_visual_feature_opt) return true;                                                                                // :522
@@ -453,7 +492,11 @@ class OfflineProblemRunner {
       restoreValues(pose_graph_copy);
       records_.push_back({scope.min_frame_id_, next_frame_id, "reverted", 0, 0, 0, 0, 0, 0, 0});
     }
+    visualize(pose_graph, start_opt_with_frame, next_frame_id, AFTER_EACH_OPTIMIZATION, attempt_num);                         // :908-913
     return true;
+  }
+  void visualize(const MainPgPtr& pose_graph, const FrameId& min_f, const FrameId& max_f, const VisualizationTypeEnum& when, const int& attempt_num) {
+    if (visualization_callback_ && current_problem_data_ != nullptr) visualization_callback_(*current_problem_data_, pose_graph, min_f, max_f, when, attempt_num);
   }
   void record(const std::string& kind, FrameId min_f, FrameId max_f, const obvi::Problem& problem, size_t n_excl) {
     const obvi::SolverSummary& s = optimizer_.lastSummary();
@@ -469,6 +512,12 @@ class OfflineProblemRunner {
   std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)> iteration_params_provider_func_;
   int device_id_;
   std::function<void(const OfflineProblemData&, MainPgPtr&)> pose_graph_creator_;
+  FrameDataAdder frame_data_adder_;
+  VisualizationCallback visualization_callback_;
+  LimitTrajectoryEvaluationParams limit_trajectory_eval_params_;
+  std::function<bool()> continue_opt_checker_;
+  bool have_continue_opt_checker_ = false;
+  const OfflineProblemData* current_problem_data_ = nullptr;
   std::function<bool(const MainPgPtr&)> object_merger_;
   size_t n_merge_rounds_ = 0;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
@@ -481,6 +530,61 @@ class OfflineProblemRunner {
   LongTermMapExtractionTunableParams ltm_tunable_params_;
   std::vector<obvi::CovarianceRankRepair> covariance_rank_repairs_;
   std::vector<LongTermMapEntry> long_term_map_;
+};
+
+// stands in for ceres::IterationCallback in the reference-shaped constructor below: the LM loop runs on the device, nothing calls it per iteration
+namespace obvi_placeholder { struct IterationCallback { virtual ~IterationCallback() = default; }; }
+
+// The reference's own shape (offline_problem_runner.h:27-98): five template parameters, fifteen constructor arguments in the reference's order, so that a
+// construction site written for the reference (offline_problem_runner construction in ellipsoid_estimator / run_opt_from_pg_state) compiles against this header with
+// ceres::Problem* -> obvi::Problem*, ceres::ResidualBlockId -> obvi::ResidualBlockId, ceres::IterationCallback -> obvi_placeholder::IterationCallback.
+//   used     residual_params, limit_trajectory_eval_params, pgo_solver_params, continue_opt_checker (tested as the reference tests it), window_provider_func,
+//            pose_graph_creator, frame_data_adder, output_data_extractor, visualization_callback, iteration_params_provider_func, object_merger, gba_checker
+//   ignored  refresh_residual_checker, residual_creator: per-factor hooks into ceres::Problem; here the optimiser uploads whole factor tables to the device
+//            (obvi_optimizer.h buildPoseGraphOptimization), there is no per-residual call to route through them.  ceres_callback_creator: see above.
+//            ignoredHooks() names the ones that were non-empty, so that a caller relying on one finds out.
+// InputProblemData, VisualFeatureFactorType and PoseGraphType must be the types this path has fixed; CachedFactorInfo is free (it only types the ignored hooks).
+template <typename InputProblemData, typename VisualFeatureFactorType, typename OutputProblemData, typename CachedFactorInfo, typename PoseGraphType>
+class OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType> : public OfflineProblemRunner<OutputProblemData> {
+  static_assert(std::is_same<InputProblemData, OfflineProblemData>::value, "this backend runs the offline path's input type (OfflineProblemData; the reference's UnassociatedBoundingBoxOfflineProblemData after its front ends)");
+  static_assert(std::is_same<VisualFeatureFactorType, ReprojectionErrorFactor>::value, "the visual factor of this path is the reprojection error factor");
+  static_assert(std::is_same<PoseGraphType, MainPg>::value, "the pose graph of this path is ObjectAndReprojectionFeaturePoseGraph");
+  using Base = OfflineProblemRunner<OutputProblemData>;
+ public:
+  using RefreshResidualChecker = std::function<bool(const std::pair<FactorType, FeatureFactorId>&, const std::shared_ptr<PoseGraphType>&, const CachedFactorInfo&)>;
+  using ResidualCreator = std::function<bool(const std::pair<FactorType, FeatureFactorId>&, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams&,
+                                             const std::shared_ptr<PoseGraphType>&, obvi::Problem*, obvi::ResidualBlockId&, CachedFactorInfo&)>;
+  using CallbackCreator = std::function<std::vector<std::shared_ptr<obvi_placeholder::IterationCallback>>(const InputProblemData&, const std::shared_ptr<PoseGraphType>&, const FrameId&, const FrameId&)>;
+  OfflineProblemRunner(const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params,
+                       const LimitTrajectoryEvaluationParams& limit_trajectory_eval_params,
+                       const pose_graph_optimization::PoseGraphPlusObjectsOptimizationParams& pgo_solver_params,
+                       const std::function<bool()>& continue_opt_checker,
+                       const std::function<FrameId(const FrameId&)>& window_provider_func,
+                       const RefreshResidualChecker& refresh_residual_checker,
+                       const ResidualCreator& residual_creator,
+                       const std::function<void(const InputProblemData&, std::shared_ptr<PoseGraphType>&)>& pose_graph_creator,
+                       const std::function<void(const InputProblemData&, const std::shared_ptr<PoseGraphType>&, const FrameId&, const FrameId&)>& frame_data_adder,
+                       const std::function<void(const InputProblemData&, const std::shared_ptr<PoseGraphType>&, const pose_graph_optimizer::OptimizationFactorsEnabledParams&, OutputProblemData&)>& output_data_extractor,
+                       const CallbackCreator& ceres_callback_creator,
+                       const std::function<void(const InputProblemData&, const std::shared_ptr<PoseGraphType>&, const FrameId&, const FrameId&, const VisualizationTypeEnum&, const int&)>& visualization_callback,
+                       const std::function<pose_graph_optimization::OptimizationIterationParams(const FrameId&)>& iteration_params_provider_func,
+                       const std::function<bool(const std::shared_ptr<PoseGraphType>&)> object_merger,
+                       const std::function<bool(const FrameId&)>& gba_checker,
+                       int device_id = 0)
+      : Base(residual_params, pgo_solver_params, window_provider_func, output_data_extractor, gba_checker, iteration_params_provider_func, device_id) {
+    Base::setLimitTrajectoryEvaluationParams(limit_trajectory_eval_params);
+    Base::setContinueOptChecker(continue_opt_checker);
+    if (pose_graph_creator) Base::setPoseGraphCreator(pose_graph_creator);
+    if (frame_data_adder) Base::setFrameDataAdder(frame_data_adder);
+    if (visualization_callback) Base::setVisualizationCallback(visualization_callback);
+    if (object_merger) Base::setObjectMerger(object_merger);
+    if (refresh_residual_checker) ignored_hooks_.push_back("refresh_residual_checker");
+    if (residual_creator) ignored_hooks_.push_back("residual_creator");
+    if (ceres_callback_creator) ignored_hooks_.push_back("ceres_callback_creator");
+  }
+  const std::vector<std::string>& ignoredHooks() const { return ignored_hooks_; }
+ private:
+  std::vector<std::string> ignored_hooks_;
 };
 
 }  // namespace vslam_types_refactor

@@ -189,6 +189,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
+  RunnerHooks hooks; bool count_visualization_calls = false;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
   front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
@@ -212,6 +213,9 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--excluded-every") && i + 1 < argc) excluded_every = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--frames-reversed")) frames_reversed = true;   // --dump-build: the frames' sightings enter the pose graph last frame first (factor ids descend with the frame)
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
+    else if (!std::strcmp(argv[i], "--reference-shaped-runner")) hooks.reference_shaped_runner_ = true;   // OfflineProblemRunner<5 types>(15 arguments), as the reference constructs it
+    else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
+    else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
   }
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
@@ -397,7 +401,17 @@ int main(int argc, char** argv) {
   const bool start_at_end = from_checkpoint || global_ba_only;
   LongTermObjectMapAndResults results;
   const auto t_run0 = std::chrono::steady_clock::now();
-  const bool ok = runFullOptimization(logger, config, data, creator, checkpoint_dir, results, start_at_end ? max_frame_id : 0, !start_at_end, device, ltm, nullptr, visual_adder);
+  std::array<size_t, 6> visualization_calls{};   // by VisualizationTypeEnum
+  if (count_visualization_calls)
+    hooks.visualization_callback_ = [&](const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&, const VisualizationTypeEnum& when, const int&) { visualization_calls[(size_t)when]++; };
+  const bool ok = runFullOptimization(logger, config, data, creator, checkpoint_dir, results, start_at_end ? max_frame_id : 0, !start_at_end, device, ltm, nullptr, visual_adder, &hooks);
+  if (count_visualization_calls || hooks.reference_shaped_runner_) {
+    std::cerr << "runner_hooks {\"visualization_calls\": [";
+    for (size_t k = 0; k < visualization_calls.size(); ++k) std::cerr << (k ? ", " : "") << visualization_calls[k];
+    std::cerr << "], \"ignored_hooks\": [";
+    for (size_t k = 0; k < hooks.ignored_hooks_.size(); ++k) std::cerr << (k ? ", " : "") << "\"" << hooks.ignored_hooks_[k] << "\"";
+    std::cerr << "]}" << std::endl;
+  }
   if (front_end) { std::cerr << "front_end "; front_end_report(std::cerr); std::cerr << std::endl; front_end.reset(); obvi_ba_destroy(front_end_handle); }
   const auto t_run1 = std::chrono::steady_clock::now();
   IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                     // offline_object_visual_slam_main.cpp:1108

@@ -241,6 +241,49 @@ def test_offline_runner_session_through_the_oracle(oracle_session, scene):
     check_session(scene[0], *oracle_session)
 
 
+def _runner_hooks(stderr):
+    return json.loads([ln for ln in stderr.splitlines() if ln.startswith("runner_hooks ")][-1][len("runner_hooks "):])
+
+
+def test_reference_shaped_runner_is_the_same_session(oracle_driver, oracle_session, scene, tmp_path):
+    """OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType> with the reference's fifteen
+    constructor arguments (offline_problem_runner.h:27-98; a construction site as optimization_runner.h:509-543 writes it): the same session, digit for
+    digit, as the short constructor + setters; the per-factor ceres hooks are accepted and reported as unused; the visualization callback is called where
+    the reference calls it (:164, :392, :512, :908, :245, :263)."""
+    prob, path, _ = scene
+    out = str(tmp_path / "out.json")
+    r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25", "--ltm", "--reference-shaped-runner", "--count-visualization-calls"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = json.load(open(out)), json.load(open(oracle_session[0]))
+    assert a["records"] == b["records"] and a["poses"] == b["poses"] and a["objects"] == b["objects"] and a.get("long_term_map") == b.get("long_term_map")
+    hooks = _runner_hooks(r.stderr)
+    assert hooks["ignored_hooks"] == ["refresh_residual_checker", "residual_creator", "ceres_callback_creator"]
+    before_any, before_each, after_each, after_pgo, after_all, after_post = hooks["visualization_calls"]
+    P = len(prob["poses"])
+    n_gba = sum(1 for rec in a["records"] if rec["kind"] == "pgo")
+    attempts = sum(1 for rec in a["records"] if rec["kind"].endswith("phase_1"))
+    assert before_any == 1 and after_all == 1 and after_post == 1
+    assert before_each >= P and after_each == attempts <= before_each                # one runOptimizationIteration per frame from 1 on + the final one (+ re-runs after
+                                                                                     # merges); AFTER_EACH only where the visual-feature optimisation ran (:522, :908)
+    assert after_pgo == n_gba and n_gba >= 1
+
+
+def test_limit_on_the_evaluated_trajectory(oracle_driver, scene, tmp_path):
+    """LimitTrajectoryEvaluationParams (offline_problem_runner.h:143-147): the session stops at min(max_frame_id_, last frame) -- through either runner shape."""
+    prob, path, _ = scene
+    outs = []
+    for extra in ([], ["--reference-shaped-runner"]):
+        out = str(tmp_path / "out.json")
+        r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25", "--max-frame", "30"] + extra, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.load(open(out)))
+    a, b = outs
+    assert a["records"] == b["records"] and a["poses"] == b["poses"]
+    assert max(rec["max_frame"] for rec in a["records"]) == 30
+    assert 26 <= sum(1 for rec in a["records"] if rec["kind"].endswith("phase_1")) <= 40   # frames 1..30 + the final one, less the first frames without a visual-feature optimisation
+
+
 def test_big_builds_flatten_on_host_threads_into_the_same_arrays(driver, tmp_path):
     """A global-BA frame flattens millions of sightings: above 2^18 records buildPoseGraphOptimization writes the frames' spans on host
     threads.  Same flat problem, array for array, as the plain loop (OBVI_HOST_BUILD_THREADS=1) -- also when frames were filled last
