@@ -261,6 +261,15 @@ int obvi_ba_get_state(obvi_ba_handle* h, double* poses /*[n][6]*/, double* point
 /* overwrite values only (feature re-attachment after PGO,
  * pose_graph_plus_objects_optimizer.h:238-283) */
 int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
+/* the same for all three kinds of block at once (a null pointer keeps one; counts as uploaded): values only -- constness, factors and the
+ * symbolic plan stay.  With obvi_ba_prepare this lets a caller upload and plan a window AHEAD, on a second handle and a second host
+ * thread, while the previous window is still being solved, and hand over the values once they exist (the start values of a window are
+ * the previous window's result: offline_problem_runner.h:183-229).  A snapshot taken before is dropped. */
+int obvi_ba_update_state(obvi_ba_handle* h, const double* poses /*[n][6]*/, const double* points /*[n][3]*/, const double* objects /*[n][7]*/);
+/* the symbolic phase of what has been uploaded (elimination order, Schur work lists, tile plan), now instead of inside the first
+ * obvi_ba_solve / obvi_ba_evaluate: structure only, reads no parameter value (exception: the order of SHARED objects follows the (x, y)
+ * given to obvi_ba_set_objects).  Returns when the plan is on the device. */
+int obvi_ba_prepare(obvi_ba_handle* h);
 
 /* ---- multi-GPU (no reference counterpart) -------------------------------
  * Independent windows / sessions, one per rank, that share object blocks.  Every rank uploads ALL shared objects

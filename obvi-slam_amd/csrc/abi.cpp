@@ -138,6 +138,18 @@ int obvi_ba_reset(obvi_ba_handle* h) {
   OBVI_API_END(h)
 }
 
+int obvi_ba_prepare(obvi_ba_handle* h) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "prepare: cameras not set");
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
+  prepare(h);
+  sync(h);   // the plan's uploads have left the host arrays they were issued from
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
 int obvi_ba_evaluate(obvi_ba_handle* h, int32_t apply_loss, double* cost, double* residuals, double* block_sqnorm) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
   if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "evaluate: cameras not set");

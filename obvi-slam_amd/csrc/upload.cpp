@@ -65,6 +65,19 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz) {
   OBVI_API_END(h)
 }
 
+int obvi_ba_update_state(obvi_ba_handle* h, const double* poses, const double* points, const double* objects) {
+  if (!h) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  if (poses && h->P > 0) h2d_async(h->d_pose.get(), poses, sizeof(double) * 6 * h->P, h->stream);
+  if (points && h->L > 0) h2d_async(h->d_point.get(), points, sizeof(double) * 3 * h->L, h->stream);
+  if (objects && h->O > 0) h2d_async(h->d_obj.get(), objects, sizeof(double) * 7 * h->O, h->stream);
+  finish_upload(h);
+  h->have_snapshot = false;
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
+
 int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, const uint32_t* point_idx, const uint16_t* cam_idx,
                        const double* pixel, const double* sigma, double sigma_scalar, double huber) {
   if (!h || n < 0 || (n > 0 && (!pose_idx || !point_idx || !pixel))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_reproj: bad arguments");

@@ -13,6 +13,7 @@
 #include <obvi_ba.h>
 
 #include <chrono>
+#include <atomic>
 #include <condition_variable>
 #include <thread>
 #include <cstdio>
@@ -99,9 +100,12 @@ class HandlePool {
   obvi_ba_handle* acquire(const obvi_ba_options& opt) {
     {
       std::unique_lock<std::mutex> lock(mu_);
-      warm_cv_.wait(lock, [&] { return warming_ == 0; });   // a handle that is being created in the background (warm) is worth waiting for
-      for (size_t i = 0; i < parked_.size(); ++i)
-        if (same(parked_[i].first, opt)) { obvi_ba_handle* h = parked_[i].second; parked_.erase(parked_.begin() + (long)i); return h; }
+      for (;;) {
+        for (size_t i = 0; i < parked_.size(); ++i)
+          if (same(parked_[i].first, opt)) { obvi_ba_handle* h = parked_[i].second; parked_.erase(parked_.begin() + (long)i); return h; }
+        if (warming_ == 0) break;
+        warm_cv_.wait(lock);   // a handle that is being created in the background (warm) is worth waiting for
+      }
     }
     obvi_ba_handle* h = nullptr;
     const int rc = obvi_ba_create(&opt, &h);
@@ -168,8 +172,12 @@ class Problem {
   // Hands the device handle to the pool until the next handle() call: a stage that runs on a Problem of its own in between
   // (runPgoPlusEllipsoids at a global-BA frame) then works on this handle -- its streams, pinned pages and grown allocations -- instead
   // of creating a second one.  Whatever was on the device is gone; the next build uploads everything anyway.
-  void parkHandle() { if (h_) { HandlePool::instance().release(opt_, h_); h_ = nullptr; } }
+  void parkHandle() { if (h_) { HandlePool::instance().release(opt_, h_); h_ = nullptr; uploaded_ahead_ = false; } }
+  // set by ObjectPoseGraphOptimizer::uploadAndPlanAhead: `flat` is on the device with its symbolic plan; the next solveOptimization hands over values only
+  bool uploadedAhead() const { return uploaded_ahead_; }
+  void setUploadedAhead(bool v) { uploaded_ahead_ = v; }
  private:
+  bool uploaded_ahead_ = false;
   int device_id_; bool dry_run_;
   obvi_ba_handle* h_ = nullptr;
   obvi_ba_options opt_{};
@@ -407,6 +415,63 @@ class OptimizationLogger {
 namespace pose_graph_optimizer {
 using namespace vslam_types_refactor;   // NOLINT (the reference's optimiser header does the same through its includes)
 typedef ObjectAndReprojectionFeaturePoseGraph PoseGraphType;
+
+// One persistent host thread for work that runs BESIDE a solve (solveOptimization's `beside` hooks): post() hands it a job, wait() returns when the job has
+// ended.  Between jobs the thread spins for a while before it sleeps (OBVI_HOST_BESIDE_SPIN_US, default 4000): in a session a job arrives every few
+// milliseconds, and a thread that slept wakes up on a core that has gone idle -- measured on the 300-frame session, a thread created per job ran the same work
+// (frame data, window build, upload, symbolic phase) in 3.3 ms instead of 1.9.
+class BesideThread {
+ public:
+  BesideThread() = default;
+  BesideThread(const BesideThread&) = delete;
+  BesideThread& operator=(const BesideThread&) = delete;
+  ~BesideThread() {
+    if (!thread_.joinable()) return;
+    { std::lock_guard<std::mutex> lock(m_); stop_ = true; state_.store(kPosted, std::memory_order_release); }
+    cv_.notify_all();
+    thread_.join();
+  }
+  void post(const std::function<void()>& job) {
+    if (!thread_.joinable()) thread_ = std::thread([this] { loop(); });
+    { std::lock_guard<std::mutex> lock(m_); job_ = job; state_.store(kPosted, std::memory_order_release); }
+    cv_.notify_all();
+  }
+  void wait() {
+    while (state_.load(std::memory_order_acquire) != kDone) std::this_thread::yield();
+    state_.store(kIdle, std::memory_order_release);
+  }
+ private:
+  enum { kIdle = 0, kPosted = 1, kDone = 2 };
+  void loop() {
+    static const long spin_us = std::getenv("OBVI_HOST_BESIDE_SPIN_US") ? std::atol(std::getenv("OBVI_HOST_BESIDE_SPIN_US")) : 4000;
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (state_.load(std::memory_order_acquire) != kPosted && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      }
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return state_.load(std::memory_order_acquire) == kPosted; });
+        if (stop_) return;
+        job.swap(job_);
+      }
+      job();
+      state_.store(kDone, std::memory_order_release);
+    }
+  }
+  std::thread thread_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::atomic<int> state_{kIdle};
+  std::function<void()> job_;
+  bool stop_ = false;
+};
+
+// solveOptimization's hooks around its wait for the device (see there)
+struct BesideSolve { std::function<void()> start, join; };
 
 // What buildPoseGraphOptimization returns: the reference hands back std::unordered_map<ceres::ResidualBlockId, FactorInfo>
 // (object_pose_graph_optimizer.h:126, :631).  Residual block ids here are the positions in the flat problem's block list, so the map is
@@ -822,7 +887,9 @@ class ObjectPoseGraphOptimizer {
   bool solveOptimization(obvi::Problem* problem, const pose_graph_optimization::OptimizationSolverParams& solver_params,
                          std::optional<OptimizationLogger>& opt_logger, std::vector<obvi::ResidualBlockId>* residual_block_id_ptrs = nullptr,
                          std::vector<double>* residual_ptrs = nullptr, std::shared_ptr<obvi::SolverSummary> solver_summary = nullptr,
-                         const PhaseTwoMasks* phase_two_masks = nullptr, bool keep_for_phase_two = false) {
+                         const PhaseTwoMasks* phase_two_masks = nullptr, bool keep_for_phase_two = false, const BesideSolve* beside = nullptr) {
+    // beside (optional): the caller's hooks around the wait for the device inside obvi_ba_solve -- start() right before it, join() right after it and
+    // before the result is written into the pose graph's blocks (the runner plans the next window on a second thread there: obvi_runner.h)
     if (problem == nullptr) return false;
     obvi_ba_handle* h = problem->handle();
     if (h == nullptr) { std::cerr << "solveOptimization: no device handle" << std::endl; return false; }
@@ -844,17 +911,12 @@ class ObjectPoseGraphOptimizer {
       if (rc) { std::cerr << "obvi_ba phase-II masks failed: " << obvi_ba_last_error(h) << std::endl; return false; }
     }
     if (phase_two_masks == nullptr) {
-    rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
-    if (!rc) rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
-    if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
-    if (!rc) rc = obvi_ba_set_objects(h, (int64_t)fp.objects.size(), objects.data(), fp.object_const.data());
-    if (!rc) rc = obvi_ba_set_reproj(h, (int64_t)fp.rp_pose.size(), fp.rp_pose.data(), fp.rp_point.data(), fp.rp_cam.data(), fp.rp_pixel.data(), fp.rp_sigma.data(), 0.0,
-                                     rp.visual_residual_params_.reprojection_error_huber_loss_param_);
-    if (!rc) rc = obvi_ba_set_bbox(h, (int64_t)fp.bb_obj.size(), fp.bb_obj.data(), fp.bb_pose.data(), fp.bb_cam.data(), fp.bb_corners.data(), fp.bb_cov.data(),
-                                   rp.object_residual_params_.object_observation_huber_loss_param_, rp.object_residual_params_.invalid_ellipsoid_error_val_);
-    if (!rc) rc = obvi_ba_set_shape_priors(h, (int64_t)fp.sp_obj.size(), fp.sp_obj.data(), fp.sp_mean.data(), fp.sp_cov.data(), rp.object_residual_params_.shape_dim_prior_factor_huber_loss_param_);
-    if (!rc) rc = obvi_ba_set_ltm_priors(h, (int64_t)fp.lt_obj.size(), fp.lt_obj.data(), fp.lt_mean.data(), fp.lt_cov.data(), rp.long_term_map_params_.pair_huber_loss_param_);
-    if (!rc) rc = obvi_ba_set_relpose(h, (int64_t)fp.rl_a.size(), fp.rl_a.data(), fp.rl_b.data(), fp.rl_t.data(), fp.rl_aa.data(), fp.rl_cov.data(), fp.rl_huber);
+    if (problem->uploadedAhead()) {   // structure and plan went up while the previous window was being solved: the values exist only now
+      rc = obvi_ba_update_state(h, poses.data(), points.data(), objects.data());
+      problem->setUploadedAhead(false);
+    } else {
+      rc = uploadFlatProblem(h, fp, rp, poses, points, objects);
+    }
     if (rc) { std::cerr << "obvi_ba upload failed: " << obvi_ba_last_error(h) << std::endl; return false; }
     if ((residual_ptrs != nullptr || keep_for_phase_two) && obvi_ba_snapshot(h)) return false;   // phase I of a two-phase optimisation: phase II starts from these values
     }
@@ -863,8 +925,10 @@ class ObjectPoseGraphOptimizer {
                          solver_params.max_trust_region_radius_};
     obvi_summary s;
     const auto t_solve = std::chrono::steady_clock::now();
+    if (beside != nullptr && beside->start) beside->start();
     rc = obvi_ba_solve(h, &p, &s);
     const auto t_solved = std::chrono::steady_clock::now();
+    if (beside != nullptr && beside->join) { beside->join(); time_beside_wait_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_solved).count(); }
     if (rc) { std::cerr << "obvi_ba_solve failed: " << obvi_ba_last_error(h) << std::endl; return false; }
     obvi::SolverSummary summary;
     summary.termination_type = s.termination_type; summary.usable = s.is_solution_usable != 0;
@@ -899,6 +963,29 @@ class ObjectPoseGraphOptimizer {
     return summary.IsSolutionUsable();
   }
 
+  // What buildPoseGraphOptimization left in `problem->flat`, onto the device WITH its symbolic plan, ahead of the solve (obvi_ba_prepare): for a caller that
+  // builds window f+1 while window f is solved.  The values uploaded are placeholders (zeros: the blocks' values may be written by another thread at this
+  // moment, and the symbolic phase reads none); solveOptimization puts the real ones there (obvi_ba_update_state).
+  bool uploadAndPlanAhead(obvi::Problem* problem) {
+    if (problem == nullptr || problem->dryRun()) return false;
+    obvi_ba_handle* h = problem->handle();
+    if (h == nullptr) return false;
+    const obvi::FlatProblem& fp = problem->flat;
+    const std::vector<double> poses(fp.pose_ptrs.size() * 6, 0.0), points(fp.point_ptrs.size() * 3, 0.0), objects(fp.object_ptrs.size() * 7, 0.0);
+    int rc = uploadFlatProblem(h, fp, residual_params_, poses, points, objects);
+    if (!rc) rc = obvi_ba_prepare(h);
+    if (rc) { std::cerr << "obvi_ba upload ahead failed: " << obvi_ba_last_error(h) << std::endl; return false; }
+    problem->setUploadedAhead(true);
+    return true;
+  }
+  // the build another optimiser instance made (the one that planned ahead) becomes this one's: what solveOptimization and the logger read of a build
+  void adoptBuild(const ObjectPoseGraphOptimizer& other, std::optional<OptimizationLogger>& opt_logger) {
+    residual_params_ = other.residual_params_;
+    last_optimized_objects_ = other.last_optimized_objects_; last_optimized_features_ = other.last_optimized_features_; last_optimized_nodes_ = other.last_optimized_nodes_;
+    if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);
+  }
+  double besideWaitMs() const { return time_beside_wait_ms_; }
+
   void clearPastOptimizationData() { last_optimized_objects_ = last_optimized_features_ = last_optimized_nodes_ = 0; }     // :792-797
   const obvi::SolverSummary& lastSummary() const { return last_summary_; }
   // where a solveOptimization call spends its wall time: upload (set_*), obvi_ba_solve (symbolic phase + LM loop), read-back; the LM loop alone
@@ -909,6 +996,21 @@ class ObjectPoseGraphOptimizer {
   }
 
  private:
+  static int uploadFlatProblem(obvi_ba_handle* h, const obvi::FlatProblem& fp, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& rp,
+                               const std::vector<double>& poses, const std::vector<double>& points, const std::vector<double>& objects) {
+    int rc = obvi_ba_set_cameras(h, (int32_t)fp.cameras.size(), fp.cam_K.data(), fp.cam_ext.data());
+    if (!rc) rc = obvi_ba_set_poses(h, (int64_t)fp.frames.size(), poses.data(), fp.pose_const.data());
+    if (!rc) rc = obvi_ba_set_points(h, (int64_t)fp.features.size(), points.data(), fp.point_const.data());
+    if (!rc) rc = obvi_ba_set_objects(h, (int64_t)fp.objects.size(), objects.data(), fp.object_const.data());
+    if (!rc) rc = obvi_ba_set_reproj(h, (int64_t)fp.rp_pose.size(), fp.rp_pose.data(), fp.rp_point.data(), fp.rp_cam.data(), fp.rp_pixel.data(), fp.rp_sigma.data(), 0.0,
+                                     rp.visual_residual_params_.reprojection_error_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_bbox(h, (int64_t)fp.bb_obj.size(), fp.bb_obj.data(), fp.bb_pose.data(), fp.bb_cam.data(), fp.bb_corners.data(), fp.bb_cov.data(),
+                                   rp.object_residual_params_.object_observation_huber_loss_param_, rp.object_residual_params_.invalid_ellipsoid_error_val_);
+    if (!rc) rc = obvi_ba_set_shape_priors(h, (int64_t)fp.sp_obj.size(), fp.sp_obj.data(), fp.sp_mean.data(), fp.sp_cov.data(), rp.object_residual_params_.shape_dim_prior_factor_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_ltm_priors(h, (int64_t)fp.lt_obj.size(), fp.lt_obj.data(), fp.lt_mean.data(), fp.lt_cov.data(), rp.long_term_map_params_.pair_huber_loss_param_);
+    if (!rc) rc = obvi_ba_set_relpose(h, (int64_t)fp.rl_a.size(), fp.rl_a.data(), fp.rl_b.data(), fp.rl_t.data(), fp.rl_aa.data(), fp.rl_cov.data(), fp.rl_huber);
+    return rc;
+  }
   template <class Id>
   static void applyMinObs(size_t min_obs, std::map<Id, FactorInfoSet>& by_id, std::map<FactorType, std::set<FeatureFactorId>>& required, const std::unordered_set<Id>& ignore) {   // :826-861
     for (auto it = by_id.begin(); it != by_id.end();) {
@@ -924,7 +1026,7 @@ class ObjectPoseGraphOptimizer {
   std::vector<int32_t> point_of_slot_;
   std::vector<std::pair<FeatureId, uint32_t>> scratch_keyed_;
   obvi::SolverSummary last_summary_;
-  double time_upload_ms_ = 0, time_solve_ms_ = 0, time_readback_ms_ = 0, time_lm_ms_ = 0; size_t n_solves_ = 0;
+  double time_upload_ms_ = 0, time_solve_ms_ = 0, time_readback_ms_ = 0, time_lm_ms_ = 0, time_beside_wait_ms_ = 0; size_t n_solves_ = 0;
 };
 
 // pose_graph_plus_objects_optimizer.h:23-353

@@ -45,13 +45,15 @@ typedef std::shared_ptr<MainPg> MainPgPtr;
 typedef std::function<bool(const OfflineProblemData&, const MainPgPtr&, const FrameId& /*min_frame_id*/, const FrameId& /*max_frame_id*/)> VisualFeatureAdder;
 inline void addFrameDataToPoseGraph(const OfflineProblemData& d, const MainPgPtr& pg, const FrameId& frame,
                                     const pose_graph_optimization::RelativePoseCovarianceOdomModelParams& odom,
-                                    const VisualFeatureAdder& visual_feature_adder = nullptr, const FrameId& min_frame_id = 0) {
+                                    const VisualFeatureAdder& visual_feature_adder = nullptr, const FrameId& min_frame_id = 0, bool provisional_pose = false) {
+  // provisional_pose: the previous frame is still being optimised (the runner adds this frame's data beside that solve and reads no value of the graph);
+  // the caller sets the pose once the previous one exists
   if (frame == 0) {
     pg->addFrame(0, d.robot_poses_[0]);
   } else {
     const Pose3D rel = getPose2RelativeToPose1(d.robot_poses_[frame - 1], d.robot_poses_[frame]);
-    const Pose3D prev = convertToPose3D(pg->getRobotPose(frame - 1).value());
-    pg->addFrame(frame, combinePoses(prev, rel));
+    if (provisional_pose) pg->addFrame(frame, d.robot_poses_[frame]);
+    else pg->addFrame(frame, combinePoses(convertToPose3D(pg->getRobotPose(frame - 1).value()), rel));
     RelPoseFactor f;
     f.frame_id_1_ = frame - 1; f.frame_id_2_ = frame; f.measured_pose_deviation_ = rel;
     f.pose_deviation_cov_ = generateOdomCov(rel, odom.transl_error_mult_for_transl_error_, odom.transl_error_mult_for_rot_error_,
@@ -158,7 +160,10 @@ class OfflineProblemRunner<OutputProblemData> {
                        const bool& add_data_for_starting_frame = true) {
     pose_graph_.reset();
     if (opt_logger.has_value()) opt_logger->writeOptInfoHeader();
-    obvi::Problem problem(device_id_);
+    // two problem objects (two device handles): the session's current one and the one the NEXT window is planned on beside this window's last solve
+    obvi::Problem problem_objects[2] = {obvi::Problem(device_id_), obvi::Problem(device_id_)};
+    int current = 0;
+    ahead_ = Ahead();
     pose_graph_optimizer::OptimizationScopeParams scope;                                                                     // :115-142
     scope.min_low_level_feature_observations_per_frame_ = enabled.min_low_level_feature_observations_per_frame_;
     scope.fix_poses_ = enabled.fix_poses_; scope.fix_objects_ = enabled.fix_objects_; scope.fix_visual_features_ = enabled.fix_visual_features_;
@@ -187,14 +192,58 @@ class OfflineProblemRunner<OutputProblemData> {
       const FrameId start_opt_with_frame = window_provider_func_(next_frame_id);
       scope.min_frame_id_ = start_opt_with_frame; scope.max_frame_id_ = next_frame_id;
       const auto t_add0 = std::chrono::steady_clock::now();
-      if (next_frame_id != start_at_frame || add_data_for_starting_frame) {                                                  // :196-199
+      const bool planned_ahead = ahead_.valid && ahead_.frame == next_frame_id && ahead_.start == start_opt_with_frame;
+      if (planned_ahead) {
+        // the frame's data entered the graph beside the previous window's last solve, with a provisional pose: now that the previous pose is optimised, the
+        // pose the adder would have given it (pose_graph_frame_data_adder.h:30-45; same arithmetic as addFrameDataToPoseGraph)
+        const Pose3D rel = getPose2RelativeToPose1(problem_data.robot_poses_[next_frame_id - 1], problem_data.robot_poses_[next_frame_id]);
+        const RawPose3d init = convertPoseToArray(combinePoses(convertToPose3D(pose_graph->getRobotPose(next_frame_id - 1).value()), rel));
+        double* pose_ptr = nullptr;
+        if (!pose_graph->getPosePointers(next_frame_id, &pose_ptr)) return false;
+        std::copy_n(init.data(), 6, pose_ptr);
+        current = 1 - current;   // the problem that was planned ahead is the session's problem now
+      } else if (next_frame_id != start_at_frame || add_data_for_starting_frame) {                                           // :196-199
+        if (ahead_.valid) { std::cerr << "a window planned ahead was not used (frame " << ahead_.frame << ")" << std::endl; return false; }   // its frame data is in the graph already
         if (frame_data_adder_) frame_data_adder_(problem_data, pose_graph, start_opt_with_frame, next_frame_id);
         else addFrameDataToPoseGraph(problem_data, pose_graph, next_frame_id, residual_params_.relative_pose_cov_params_, visual_feature_adder_, start_opt_with_frame);
       }
       time_add_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_add0).count();
-      if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem)) return false;
+      obvi::Problem& problem = problem_objects[current];
+      if (gba_checker_(next_frame_id)) problem_objects[1 - current].parkHandle();   // a global-BA iteration runs its pose-graph stage on a problem of its own: this handle is free for it
+      // Plan the next window beside this one's solves?  Its STRUCTURE (frame data, window, factor selection) depends on nothing this window computes; its
+      // start values do, and are handed over when they exist.  Not when a hook could see or change the graph in between (a custom adder, the visual front end,
+      // a visualization callback), not across a global-BA frame (that iteration starts with other problems), not with the phase-II cross-check.
+      ahead_job_ = nullptr;
+      const FrameId ahead_frame = next_frame_id + 1;
+      static const bool phase_two_check = std::getenv("OBVI_HOST_PHASE2_CHECK") && std::atoi(std::getenv("OBVI_HOST_PHASE2_CHECK")) != 0;
+      if (planAheadEnabled() && !phase_two_check && ahead_frame <= max_frame_id && !frame_data_adder_ && !visual_feature_adder_ && !visualization_callback_ && !gba_checker_(ahead_frame)) {
+        obvi::Problem* ahead_problem = &problem_objects[1 - current];
+        ahead_job_ = [this, &problem_data, &pose_graph, ahead_frame, ahead_problem, scope]() {
+          const auto t0 = std::chrono::steady_clock::now();
+          Ahead a;
+          a.frame = ahead_frame; a.start = window_provider_func_(ahead_frame);
+          addFrameDataToPoseGraph(problem_data, pose_graph, ahead_frame, residual_params_.relative_pose_cov_params_, nullptr, a.start, /*provisional_pose=*/true);
+          const auto t1 = std::chrono::steady_clock::now();
+          pose_graph_optimizer::OptimizationScopeParams ahead_scope = scope;
+          ahead_scope.min_frame_id_ = a.start; ahead_scope.max_frame_id_ = ahead_frame;
+          std::optional<OptimizationLogger> null_logger;
+          a.block_info = ahead_optimizer_.buildPoseGraphOptimization(ahead_scope, residual_params_, pose_graph, ahead_problem, null_logger);
+          const auto t2 = std::chrono::steady_clock::now();
+          ahead_graph_done_.store(true, std::memory_order_release);   // from here on the job works on the flat problem and the library only
+          a.uploaded = ahead_optimizer_.uploadAndPlanAhead(ahead_problem);
+          a.valid = true;
+          ahead_ = std::move(a);
+          const auto t3 = std::chrono::steady_clock::now();
+          const auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+          time_ahead_ms_ += ms(t0, t3); time_ahead_add_ms_ += ms(t0, t1); time_ahead_build_ms_ += ms(t1, t2); time_ahead_upload_ms_ += ms(t2, t3); ++n_ahead_;
+        };
+      }
+      if (!runOptimizationIteration(start_opt_with_frame, next_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 0, planned_ahead)) return false;
       IterationLoggerFactory::getInstance().writeAllIterationLoggerStates();                                                 // :219
     }
+    if (ahead_.valid) { std::cerr << "a window planned ahead was not used (frame " << ahead_.frame << ")" << std::endl; return false; }
+    obvi::Problem& problem = problem_objects[current];
+    problem_objects[1 - current].parkHandle();
     if (!runOptimizationIteration(0, max_frame_id, enabled, scope, max_frame_id, opt_logger, pose_graph, problem, 1)) return false;   // :232-243
     visualize(pose_graph, 0, max_frame_id, AFTER_ALL_OPTIMIZATION, 1);                                                        // :245-250
     if (!mergeObjectsAtSessionEnd(max_frame_id, enabled, scope, opt_logger, pose_graph, problem)) return false;              // :254-262
@@ -260,6 +309,11 @@ class OfflineProblemRunner<OutputProblemData> {
     optimizer_.printTiming(os);
     if (n_iterations_) os << "runOptimizationIteration x" << n_iterations_ << ": phase-I build " << time_build_ms_ / n_iterations_ << " ms, pose-graph copy " << time_copy_ms_ / n_iterations_ << " ms per call; phase II on the phase-I problem (masks) x"
                           << n_phase_two_masked_ << ", rebuilt x" << n_phase_two_rebuilt_ << std::endl;
+    if (n_ahead_) os << "windows planned ahead (frame data, build, upload, symbolic phase beside the previous window's last solve) x" << n_ahead_ << ": " << time_ahead_ms_ / n_ahead_
+                     << " ms each on the second thread (frame data " << time_ahead_add_ms_ / n_ahead_ << ", build " << time_ahead_build_ms_ / n_ahead_ << ", upload + symbolic phase "
+                     << time_ahead_upload_ms_ / n_ahead_ << "), " << optimizer_.besideWaitMs() / n_ahead_ << " ms of it after the solve had ended" << std::endl;
+    if (n_stage_beside_) os << "global BAs built, uploaded and planned beside their pose-graph + object stage x" << n_stage_beside_ << ": " << time_stage_beside_ms_ / n_stage_beside_
+                            << " ms each on the second thread, waited for " << time_stage_beside_wait_ms_ / n_stage_beside_ << " ms after the stage" << std::endl;
     if (n_pgo_) os << "pose-graph + object stages at the global-BA frames x" << n_pgo_ << ": " << time_pgo_ms_ / n_pgo_ << " ms per call (own problem: handle, build, solves)" << std::endl;
     if (n_iterations_) os << "frame data adder " << time_add_ms_ / n_iterations_ << " ms, outlier selection on the host " << time_select_ms_ / n_iterations_ << " ms per frame" << std::endl;
     if (check_.windows) os << "phase2_check windows " << check_.windows << " failures " << check_.failures << " iteration_mismatches " << check_.iteration_mismatches << " size_mismatches "
@@ -307,7 +361,8 @@ class OfflineProblemRunner<OutputProblemData> {
   // offline_problem_runner.h:376-916
   bool runOptimizationIteration(const FrameId& start_opt_with_frame, const FrameId& next_frame_id, const pose_graph_optimizer::OptimizationFactorsEnabledParams& enabled,
                                 const pose_graph_optimizer::OptimizationScopeParams& scope, const FrameId& max_frame_id, std::optional<OptimizationLogger>& opt_logger,
-                                MainPgPtr& pose_graph, obvi::Problem& problem, const int& attempt_num = 0) {
+                                MainPgPtr& pose_graph, obvi::Problem& problem, const int& attempt_num = 0, bool planned_ahead = false) {   // (planned_ahead: by value, set below at a global-BA frame)
+    // planned_ahead: `problem` holds this window's build already, uploaded with its symbolic plan (runOptimization)
     const pose_graph_optimization::OptimizationIterationParams iteration_params = iteration_params_provider_func_(next_frame_id);
     visualize(pose_graph, start_opt_with_frame, next_frame_id, BEFORE_EACH_OPTIMIZATION, attempt_num);                        // :392-397
     if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(next_frame_id, start_opt_with_frame == 0, false, false, attempt_num);
@@ -334,10 +389,34 @@ class OfflineProblemRunner<OutputProblemData> {
         }
         record("pre_pgo_track", tracking.min_frame_id_, next_frame_id, problem, 0);
         const auto t_pgo0 = std::chrono::steady_clock::now();
-        problem.parkHandle();   // the stage builds a Problem of its own (:pose_graph_plus_objects_optimizer.h:86): let it have this one's device handle
+        // The global BA that follows the stage has the whole trajectory's structure to flatten, upload and plan (config #3: 89 + 11 + 38 ms), none of which
+        // depends on what the stage computes: a second thread does it on this problem's handle while the stage runs on another one (the session's second
+        // problem object parked its handle for that: runOptimization); the values are handed over afterwards.  The stage reads the graph's structure and
+        // writes block values; the build reads structure only.
+        const bool plan_beside_stage = planAheadEnabled() && run_visual_feature_opt && !planned_ahead && !problem.dryRun();
+        if (plan_beside_stage) {
+          stage_beside_thread_.post([this, &scope, &pose_graph, &problem]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::optional<OptimizationLogger> null_logger;
+            Ahead a;
+            a.block_info = ahead_optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, null_logger);
+            a.uploaded = ahead_optimizer_.uploadAndPlanAhead(&problem);
+            a.valid = true;
+            ahead_ = std::move(a);
+            time_stage_beside_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++n_stage_beside_;
+          });
+        } else {
+          problem.parkHandle();   // the stage builds a Problem of its own (:pose_graph_plus_objects_optimizer.h:86): let it have this one's device handle
+        }
         if (!pose_graph_optimizer::runPgoPlusEllipsoids(next_frame_id, scope, residual_params_, pgo_solver_params_, next_frame_id == max_frame_id, opt_logger, pose_graph,
                                                         device_id_, attempt_num))
           std::cerr << "PGO+objs failed at frame " << next_frame_id << std::endl;
+        if (plan_beside_stage) {
+          const auto t_w0 = std::chrono::steady_clock::now();
+          stage_beside_thread_.wait();
+          time_stage_beside_wait_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w0).count();
+          planned_ahead = ahead_.valid;
+        }
         time_pgo_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pgo0).count(); ++n_pgo_;
         records_.push_back({0, next_frame_id, "pgo", 0, 0, 0, (size_t)next_frame_id + 1, 0, 0, 0});
         visualize(pose_graph, start_opt_with_frame, next_frame_id, AFTER_PGO_PLUS_OBJ_OPTIMIZATION, attempt_num);             // :512-518
@@ -348,7 +427,27 @@ class OfflineProblemRunner<OutputProblemData> {
     const std::string kind = global_ba ? "gba" : "lba";
     // PHASE I  (:541-660)
     const auto t_b0 = std::chrono::steady_clock::now();
-    auto block_info = optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger);
+    pose_graph_optimizer::ResidualBlockInfoMap block_info;
+    if (planned_ahead && ahead_.valid) {
+      block_info = std::move(ahead_.block_info);
+      optimizer_.adoptBuild(ahead_optimizer_, opt_logger);
+      ahead_ = Ahead();
+    } else {
+      block_info = optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger);
+    }
+    // The next window is planned beside this iteration's solves: the job starts with the phase-I solve; its first part (frame data into the graph, build:
+    // the graph's structure is written, then read; no value is read) has ended before this thread goes on behind that solve, the rest (upload, symbolic
+    // phase: the flat problem and the library only) may run until the last solve has ended.
+    std::function<void()> ahead_job; ahead_job.swap(ahead_job_);
+    bool ahead_posted = false, ahead_joined = false;
+    const std::function<void()> ahead_wait_all = [&]() { if (ahead_posted && !ahead_joined) { ahead_thread_.wait(); ahead_joined = true; } };
+    struct JoinAtExit { const std::function<void()>& f; ~JoinAtExit() { f(); } } join_at_exit{ahead_wait_all};
+    pose_graph_optimizer::BesideSolve beside_first, beside_last;
+    if (ahead_job) {
+      beside_first.start = [&]() { ahead_graph_done_.store(false, std::memory_order_release); ahead_thread_.post(ahead_job); ahead_posted = true; };
+      beside_first.join = [&]() { while (!ahead_graph_done_.load(std::memory_order_acquire)) std::this_thread::yield(); };
+      beside_last.join = ahead_wait_all;
+    }
     const auto t_b1 = std::chrono::steady_clock::now();
     // :594 deep-copies the whole pose graph; all that is ever read back (:811, :903) are the values of the parameter blocks this
     // optimisation can move, i.e. the blocks of the phase-I problem: those are saved (the device-side equivalent is obvi_ba_snapshot)
@@ -364,7 +463,9 @@ class OfflineProblemRunner<OutputProblemData> {
     static const bool select_on_host = std::getenv("OBVI_HOST_SELECT_ON_HOST") && std::atoi(std::getenv("OBVI_HOST_SELECT_ON_HOST")) != 0;
     const bool device_selection = two_phase && !select_on_host;
     const bool ok1 = (two_phase && !device_selection) ? optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, &residual_block_ids, &residuals)
-                                                      : optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, nullptr, nullptr, nullptr, nullptr, /*keep_for_phase_two=*/two_phase);
+                                                      : optimizer_.solveOptimization(&problem, iteration_params.phase_one_opt_params_, opt_logger, nullptr, nullptr, nullptr, nullptr, /*keep_for_phase_two=*/two_phase,
+                                                                                     &beside_first);
+    if (!two_phase) ahead_wait_all();
     if (!ok1) { std::cerr << "Phase I Optimization failed at max frame id " << next_frame_id << std::endl; return false; }
     if (opt_logger.has_value()) opt_logger->writeCurrentOptInfo();
     record(kind + "_phase_1", scope.min_frame_id_, next_frame_id, problem, 0);
@@ -431,7 +532,7 @@ class OfflineProblemRunner<OutputProblemData> {
       if (device_selection && (!have_masks || check_rebuild)) materialise_excluded();
       if (have_masks) {
         optimizer_.setPhaseTwoLogCounts(masks, opt_logger);
-        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger, nullptr, nullptr, nullptr, &masks);
+        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger, nullptr, nullptr, nullptr, &masks, false, &beside_last);
         ++n_phase_two_masked_;
         // OBVI_HOST_PHASE2_CHECK=1 (tests): the same phase II the reference's way -- rebuild with the excluded set, upload, solve -- on a
         // scratch handle from the same start values, window by window; the session goes on with the masked result
@@ -476,7 +577,7 @@ class OfflineProblemRunner<OutputProblemData> {
         }
       } else {
         optimizer_.buildPoseGraphOptimization(scope, residual_params_, pose_graph, &problem, opt_logger, excluded);
-        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger);
+        ok2 = optimizer_.solveOptimization(&problem, iteration_params.phase_two_opt_params_, opt_logger, nullptr, nullptr, nullptr, nullptr, false, &beside_last);
         ++n_phase_two_rebuilt_;
       }
       if (!ok2) {
@@ -521,6 +622,16 @@ class OfflineProblemRunner<OutputProblemData> {
   std::function<bool(const MainPgPtr&)> object_merger_;
   size_t n_merge_rounds_ = 0;
   pose_graph_optimizer::ObjectPoseGraphOptimizer optimizer_;
+  // planning the next window beside this window's last solve (runOptimization; OBVI_HOST_PLAN_AHEAD=0: off)
+  struct Ahead { bool valid = false, uploaded = false; FrameId frame = 0, start = 0; pose_graph_optimizer::ResidualBlockInfoMap block_info; };
+  Ahead ahead_;
+  std::function<void()> ahead_job_;
+  pose_graph_optimizer::ObjectPoseGraphOptimizer ahead_optimizer_;   // the build beside a solve has scratch of its own
+  pose_graph_optimizer::BesideThread stage_beside_thread_, ahead_thread_;
+  std::atomic<bool> ahead_graph_done_{true};
+  double time_stage_beside_ms_ = 0, time_stage_beside_wait_ms_ = 0; size_t n_stage_beside_ = 0;
+  double time_ahead_ms_ = 0, time_ahead_add_ms_ = 0, time_ahead_build_ms_ = 0, time_ahead_upload_ms_ = 0; size_t n_ahead_ = 0;
+  static bool planAheadEnabled() { static const bool on = !std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0; return on; }
   std::vector<OptimizationRecord> records_;
   double time_build_ms_ = 0, time_copy_ms_ = 0, time_add_ms_ = 0, time_select_ms_ = 0, time_pgo_ms_ = 0; size_t n_pgo_ = 0; size_t n_iterations_ = 0, n_phase_two_masked_ = 0, n_phase_two_rebuilt_ = 0;
   struct PhaseTwoCheck { size_t windows = 0, failures = 0, iteration_mismatches = 0, size_mismatches = 0, points = 0, points_apart = 0, objects = 0, objects_apart = 0; double max_initial_cost_rel = 0, max_final_cost_rel = 0, max_value_diff = 0; } check_;

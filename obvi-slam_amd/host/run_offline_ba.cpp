@@ -11,6 +11,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#if defined(__GLIBC__)
+#include <malloc.h>
+#endif
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -219,8 +222,18 @@ int main(int argc, char** argv) {
   }
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
+#if defined(__GLIBC__)
+  // A window's flat arrays (hundreds of kB) are allocated and freed once per frame, half of them on the runner's second thread: with glibc's defaults they
+  // are mmap'ed / the arena is trimmed every time and every frame pays the page faults again (300-frame session 1.9 -> 1.7 s with these three).  A host
+  // program's choice, not the library's.
+  mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 64 << 20);
+#endif
   // the device handle of the session is created beside the scene load and the pose-graph fill (HIP runtime start + allocations: ~0.1 s)
-  if (!dump && !front_end_only) obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
+  // (two: the runner plans the next window / the global BA on a second handle beside the solve that is running, unless OBVI_HOST_PLAN_AHEAD=0)
+  if (!dump && !front_end_only) {
+    obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
+    if (!std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0) obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
+  }
   OfflineProblemData data;
   MainPgPtr checkpoint_graph;
   if (from_checkpoint) {

@@ -362,6 +362,17 @@ class BundleAdjuster:
         x = _f64(xyz, (-1, 3))
         self._check(self._fn("ba_update_points")(self._h, C.c_int64(len(x)), _ptr(x, C.c_double)), "update_points")
 
+    def update_state(self, poses=None, points=None, objects=None):
+        """Values only (obvi_ba_update_state): constness, factors and the symbolic plan stay."""
+        po = None if poses is None else _f64(poses, (self.P, 6))
+        pt = None if points is None else _f64(points, (self.L, 3))
+        ob = None if objects is None else _f64(objects, (self.O, 7))
+        self._check(self._fn("ba_update_state")(self._h, _ptr(po, C.c_double), _ptr(pt, C.c_double), _ptr(ob, C.c_double)), "update_state")
+
+    def prepare(self):
+        """The symbolic phase now (obvi_ba_prepare) instead of inside the first solve / evaluate."""
+        self._check(self._fn("ba_prepare")(self._h), "prepare")
+
     # ---- multi-GPU / test hooks ----------------------------------------------------------
     def set_allreduce(self, pyfunc):
         """pyfunc(device_ptr:int, count_f64:int, op:int (0 sum, 1 max), stream:int) -> int (0 = ok)."""

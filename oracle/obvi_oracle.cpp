@@ -1517,6 +1517,16 @@ int oracle_ba_update_objects(oracle_handle* h, int64_t n, const double* v) {
   h->pb.objects.assign(v, v + 7 * n); return OBVI_OK;
 }
 
+// include/obvi_ba.h obvi_ba_update_state / obvi_ba_prepare as the drivers built against this library see them (tests/oracle_abi_shim.h): values only;
+// the restatement has no symbolic phase to run ahead (Ceres orders and analyses inside Solve())
+int oracle_ba_update_state(oracle_handle* h, const double* poses, const double* points, const double* objects) {
+  if (poses) h->pb.poses.assign(poses, poses + 6 * h->pb.P);
+  if (points) h->pb.points.assign(points, points + 3 * h->pb.L);
+  if (objects) h->pb.objects.assign(objects, objects + 7 * h->pb.O);
+  return OBVI_OK;
+}
+int oracle_ba_prepare(oracle_handle*) { return OBVI_OK; }
+
 // ---- factor-level entry points for golden-vector tests ---------------------------------
 void oracle_reproj(const double* pose6, const double* point3, const double* K4, const double* ext7, const double* pixel2,
                    double sigma, double* r2, double* Jpose, double* Jpoint) {

@@ -1,10 +1,13 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05e
-mkdir -p $O
-export PYTHONPATH=$R/obvi-slam_amd/python:$R/tests
-cd $R
-OBVI_HOST_TIMING=2 timeout 600 python scripts/e2e_cpp.py 2000 300000 200 2 > $O/e2e_cpp.txt 2>&1
-OBVI_DEBUG_PREPARE=1 timeout 300 python scripts/window_iter.py > $O/window_plan.txt 2>&1
-OBVI_HOST_TIMING=1 OBVI_API_TIMING=1 timeout 600 python scripts/session_time.py > $O/session.txt 2>&1
-tail -60 $O/e2e_cpp.txt
+# stage times of the symbolic phase over the windows of the 300-frame session
+mkdir -p gpurun_out
+OBVI_DEBUG_PREPARE=1 python scripts/session_time.py 2> gpurun_out/prepare_stages.txt | tail -2
+python - <<'PY'
+import re, collections
+tot = collections.defaultdict(float); n = collections.Counter()
+for ln in open("gpurun_out/prepare_stages.txt"):
+    m = re.match(r"prepare: (.*?)\s+([0-9.]+) ms", ln)
+    if m: tot[m.group(1).strip()] += float(m.group(2)); n[m.group(1).strip()] += 1
+for k in tot: print("%-28s %8.1f ms over %4d calls = %.4f ms each" % (k, tot[k], n[k], tot[k] / n[k]))
+print("sum %.1f ms" % sum(tot.values()))
+PY

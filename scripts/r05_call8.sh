@@ -1,10 +1,16 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05f
-mkdir -p $O
-export PYTHONPATH=$R/obvi-slam_amd/python:$R/tests
-cd $R
-for i in 1 2 3; do OBVI_HOST_TIMING=1 OBVI_API_TIMING=1 timeout 600 python scripts/session_time.py > $O/session_$i.txt 2>&1; tail -1 $O/session_$i.txt; grep "prepare (symbolic\|set_reproj: gather\|LM step" $O/session_$i.txt; done
-OBVI_HOST_TIMING=1 timeout 600 python scripts/e2e_cpp.py 2000 300000 200 3 > $O/e2e_cpp.txt 2>&1; head -3 $O/e2e_cpp.txt
-timeout 1500 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; echo "all rc=$?"; tail -4 $O/t_all.log | head -2
-bash scripts/profile_round.sh r05a > $O/profile_round.log 2>&1; echo "profile rc=$?"; tail -2 $O/profile_round.log | cut -c1-200
+# the next window planned beside the solve: the 300-frame session with and without it
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_structure.py -x -q -m gpu -k "planned_ahead or update_state" 2>&1 | tail -5
+for rep in 1 2 3; do
+  for mode in 0 1; do
+    echo "== plan ahead $mode, run $rep"
+    OBVI_HOST_PLAN_AHEAD=$mode OBVI_HOST_TIMING=1 python scripts/session_time.py 2>&1 | grep -E "wall|planned ahead|solveOptimization|runOptimizationIteration|driver:"
+  done
+done 2>&1 | tee gpurun_out/plan_ahead_session.txt
+echo "== spin 0"
+OBVI_HOST_BESIDE_SPIN_US=0 OBVI_HOST_TIMING=1 python scripts/session_time.py 2>&1 | grep -E "wall|planned ahead"
+echo "== 8 host threads"
+OBVI_HOST_THREADS=8 OBVI_HOST_TIMING=1 python scripts/session_time.py 2>&1 | grep -E "wall|planned ahead"
+OBVI_HOST_PLAN_AHEAD=1 OBVI_HOST_TIMING=1 OBVI_API_TIMING=1 python scripts/session_time.py > gpurun_out/plan_ahead_session_api.txt 2>&1
+grep "api timing" gpurun_out/plan_ahead_session_api.txt | cut -c1-200

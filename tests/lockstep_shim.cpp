@@ -151,6 +151,15 @@ int lock_ba_get_points(obvi_ba_handle* h, double* out) { return obvi_ba_get_poin
 int lock_ba_get_objects(obvi_ba_handle* h, double* out) { return obvi_ba_get_objects(L_(h)->hip, out); }
 int lock_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* objects) { return obvi_ba_get_state(L_(h)->hip, poses, points, objects); }
 int lock_ba_update_points(obvi_ba_handle* h, int64_t n, const double* x) { ARB(update_points(L_(h)->arb, n, x)); return both(obvi_ba_update_points(L_(h)->hip, n, x), oracle_ba_update_points(L_(h)->ora, n, x), "update_points"); }
+int lock_ba_update_state(obvi_ba_handle* h, const double* po, const double* pt, const double* ob) {
+  Lock* l = L_(h);
+  if (l->arb) { if (po) arb().update_poses(l->arb, l->P, po); if (pt) arb().update_points(l->arb, l->L, pt); if (ob) arb().update_objects(l->arb, l->O, ob); }
+  if (po) oracle_ba_update_poses(l->ora, l->P, po);
+  if (pt) oracle_ba_update_points(l->ora, l->L, pt);
+  if (ob) oracle_ba_update_objects(l->ora, l->O, ob);
+  return obvi_ba_update_state(l->hip, po, pt, ob);
+}
+int lock_ba_prepare(obvi_ba_handle* h) { return obvi_ba_prepare(L_(h)->hip); }   // the oracles have no symbolic phase
 int lock_ba_get_iterations(const obvi_ba_handle* h, obvi_iteration_summary* out, int32_t cap) { return obvi_ba_get_iterations(L_(h)->hip, out, cap); }
 
 int lock_ba_evaluate(obvi_ba_handle* h, int32_t loss, double* cost, double* res, double* sq) {

@@ -34,6 +34,8 @@
 #define obvi_ba_get_objects lock_ba_get_objects
 #define obvi_ba_get_state lock_ba_get_state
 #define obvi_ba_update_points lock_ba_update_points
+#define obvi_ba_update_state lock_ba_update_state
+#define obvi_ba_prepare lock_ba_prepare
 #define obvi_ba_num_residuals lock_ba_num_residuals
 #define obvi_ba_num_factors lock_ba_num_factors
 #endif

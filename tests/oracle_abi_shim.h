@@ -33,6 +33,8 @@
 #define obvi_ba_get_objects oracle_ba_get_objects
 #define obvi_ba_get_state oracle_ba_get_state
 #define obvi_ba_update_points oracle_ba_update_points
+#define obvi_ba_update_state oracle_ba_update_state
+#define obvi_ba_prepare oracle_ba_prepare
 #define obvi_ba_num_residuals oracle_ba_num_residuals
 #define obvi_ba_num_factors oracle_ba_num_factors
 #define obvi_frontend_epipolar_votes oracle_frontend_epipolar_votes

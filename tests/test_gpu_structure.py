@@ -424,3 +424,69 @@ def test_get_state_reads_what_the_three_getters_read():
             assert np.array_equal(po, g.get_poses()) and np.array_equal(pt, g.get_points()) and np.array_equal(ob, g.get_objects())
             if not solved:
                 assert np.array_equal(po, prob["poses"]) and np.array_equal(pt, prob["points"])
+
+
+def test_a_window_planned_ahead_and_given_its_values_later():
+    """obvi_ba_prepare + obvi_ba_update_state: a window is uploaded with PLACEHOLDER values and planned while another handle solves on another host thread (what
+    the host mirror's runner does beside a window's last solve); the start values arrive afterwards.  The symbolic phase reads no value, so the solve is the one of
+    a handle that was given the values at upload -- bit for bit in deterministic mode -- and the oracle's; the first solve does not run the symbolic phase again."""
+    import threading
+    prob = synth.make_problem(P=50, L=3000, O=5, seed=23, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=6)
+    other = synth.make_problem(P=60, L=4000, O=3, seed=24, object_classes=("bench",), bbox_noise=5.0, min_obj_obs=6)
+    prm = helpers.ba_params(max_it=8, ftol=0, gtol=0, ptol=0)
+    rng = np.random.default_rng(1)
+    placeholder = dict(prob)
+    placeholder["poses"] = prob["poses"] + rng.normal(scale=0.3, size=prob["poses"].shape)
+    placeholder["points"] = prob["points"] + rng.normal(scale=1.0, size=prob["points"].shape)
+    placeholder["objects"] = prob["objects"] + rng.normal(scale=0.2, size=prob["objects"].shape) * (np.arange(7) != 3)
+    for det in (True, False):
+        plain, ahead, busy = helpers.product_ba(deterministic=det), helpers.product_ba(deterministic=det), helpers.product_ba(deterministic=det)
+        synth.upload(plain, prob)
+        s_plain = plain.solve(prm)
+        synth.upload(busy, other)
+        errors = []
+
+        def plan():
+            try:
+                synth.upload(ahead, placeholder)
+                ahead.prepare()
+            except Exception as e:   # noqa: BLE001 -- reported by the main thread
+                errors.append(e)
+        t = threading.Thread(target=plan)
+        t.start()
+        s_busy = busy.solve(helpers.ba_params(max_it=30, ftol=0, gtol=0, ptol=0))
+        t.join()
+        assert not errors, errors
+        assert s_busy.num_iterations >= 30 or s_busy.termination_type >= 0
+        levels = ahead.problem_stats()["chol_levels"]
+        assert levels == plain.problem_stats()["chol_levels"] and levels > 0          # the plan exists before any solve
+        ahead.update_state(prob["poses"], prob["points"], prob["objects"])
+        assert np.array_equal(ahead.get_poses(), prob["poses"]) and np.array_equal(ahead.get_points(), prob["points"]) and np.array_equal(ahead.get_objects(), prob["objects"])
+        s_ahead = ahead.solve(prm)
+        assert s_ahead.num_iterations == s_plain.num_iterations
+        if det:
+            assert s_ahead.final_cost == s_plain.final_cost and np.array_equal(ahead.get_poses(), plain.get_poses()) and np.array_equal(ahead.get_points(), plain.get_points())
+        else:
+            assert abs(s_ahead.final_cost - s_plain.final_cost) <= 1e-9 * s_plain.final_cost and np.abs(ahead.get_poses() - plain.get_poses()).max() < 1e-7
+        # one kind of block only; the others stay
+        points_before = ahead.get_points()
+        ahead.update_state(poses=placeholder["poses"])
+        assert np.array_equal(ahead.get_poses(), placeholder["poses"]) and np.array_equal(ahead.get_points(), points_before)
+    o = helpers.oracle_ba()
+    synth.upload(o, placeholder); o.prepare(); o.update_state(prob["poses"], prob["points"], prob["objects"])
+    so = o.solve(prm)
+    assert so.num_iterations == s_plain.num_iterations and abs(so.final_cost - s_plain.final_cost) <= 1e-8 * so.final_cost
+
+
+def test_update_state_and_prepare_refuse_what_they_cannot_do():
+    g = helpers.product_ba()
+    g.prepare()                                                                      # the empty problem is a problem (as for obvi_ba_solve)
+    prob = synth.make_problem(P=20, L=300, O=0, seed=2)
+    synth.upload(g, prob)
+    with pytest.raises(ValueError):
+        g.update_state(points=prob["points"][:-1])                                   # (the binding checks the count: the ABI takes the counts as uploaded)
+    g.snapshot()
+    g.update_state(points=prob["points"] + 1.0)
+    with pytest.raises(obvi_ba.ObviError):
+        g.restore()                                                                  # the snapshot was dropped with the values it belonged to
+    assert np.array_equal(g.get_points(), prob["points"] + 1.0) and np.array_equal(g.get_poses(), prob["poses"])

@@ -241,6 +241,9 @@ def test_offline_runner_session_through_the_oracle(oracle_session, scene):
     check_session(scene[0], *oracle_session)
 
 
+TIMING_COLUMNS = (8, 9, 10, 11)   # total_ceres_time, linear_solver_time, jacobian_time, residual_time of ceres_opt_summary.csv
+
+
 def _runner_hooks(stderr):
     return json.loads([ln for ln in stderr.splitlines() if ln.startswith("runner_hooks ")][-1][len("runner_hooks "):])
 
@@ -267,6 +270,30 @@ def test_reference_shaped_runner_is_the_same_session(oracle_driver, oracle_sessi
     assert before_each >= P and after_each == attempts <= before_each                # one runOptimizationIteration per frame from 1 on + the final one (+ re-runs after
                                                                                      # merges); AFTER_EACH only where the visual-feature optimisation ran (:522, :908)
     assert after_pgo == n_gba and n_gba >= 1
+
+
+def test_planning_the_next_window_beside_the_solve_is_the_same_session(oracle_driver, oracle_session, scene, tmp_path):
+    """The runner adds frame f+1's data, builds window f+1 and uploads it with its symbolic plan on a second thread while window f's last solve runs, and hands
+    the start values over when they exist (obvi_ba_prepare / obvi_ba_update_state; obvi_runner.h runOptimization).  Nothing of a window's structure depends on the
+    previous window's result, so the session is the serial one DIGIT FOR DIGIT (OBVI_HOST_PLAN_AHEAD=0 = serial; the module's oracle_session ran with the default)."""
+    prob, path, _ = scene
+    out, csv = str(tmp_path / "out.json"), str(tmp_path / "opt.csv")
+    r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25", "--csv", csv, "--ltm"], capture_output=True, text=True, timeout=1200,
+                       env=dict(os.environ, OBVI_HOST_PLAN_AHEAD="0", OBVI_HOST_TIMING="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "windows planned ahead" not in r.stderr
+    a, b = json.load(open(out)), json.load(open(oracle_session[0]))
+    assert a["records"] == b["records"] and a["poses"] == b["poses"] and a["objects"] == b["objects"] and a.get("long_term_map") == b.get("long_term_map")
+    strip = lambda text: [",".join(c for i, c in enumerate(ln.split(",")) if i not in TIMING_COLUMNS) for ln in text.strip().split("\n")]
+    assert strip(open(csv).read()) == strip(open(oracle_session[1]).read())
+    # and the default did plan ahead: every local-BA window that follows a window of the loop
+    r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25"], capture_output=True, text=True, timeout=1200, env=dict(os.environ, OBVI_HOST_TIMING="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stderr.splitlines() if ln.startswith("windows planned ahead")]
+    assert line, r.stderr[-2000:]
+    n = int(line[0].split(" x")[1].split(":")[0])
+    n_gba = sum(1 for rec in a["records"] if rec["kind"] == "pgo")
+    assert len(prob["poses"]) - 2 - n_gba - 6 <= n <= len(prob["poses"]) - 2   # not across global-BA frames, not from the first frames (no visual-feature optimisation there)
 
 
 def test_limit_on_the_evaluated_trajectory(oracle_driver, scene, tmp_path):
