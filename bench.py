@@ -331,7 +331,7 @@ def end_to_end_global_ba(obvi_ba, synth, prob, device):
 
 
 def end_to_end_cpp(prob, device):
-    """The same "run as specified" global BA through the C++ DROP-IN layer instead of the Python re-enactment above: the scene goes to
+    """The same "run as specified" global BA through the C++ host mirror instead of the Python re-enactment above: the scene goes to
     obvi-slam_amd/host/run_offline_ba (the mirror of the reference's runner: frame data adder -> pose graph -> OfflineProblemRunner ->
     runOptimizationIteration's global-BA branch = runPgoPlusEllipsoids + two-phase optimisation with base7a_2_fallback values ->
     ObjectPoseGraphOptimizer::buildPoseGraphOptimization / solveOptimization -> C ABI), `--global-ba`: every frame enters the pose graph,
@@ -359,7 +359,10 @@ def end_to_end_cpp(prob, device):
     api = {}
     for m in re.finditer(r"^api timing: (.+?)\s+([0-9.]+) ms in\s+(\d+) calls", r.stderr, re.M):
         api[m.group(1).strip()] = {"ms": float(m.group(2)), "calls": int(m.group(3))}
+    lm_ms = api.get("LM step (submit + wait)", {}).get("ms")
     rep.update(process_wall_ms=round(1e3 * wall, 1), scene_write_ms=round(1e3 * t_write, 1), lm_iterations_total=sum(x["iterations"] for x in rep["records"]),
+               outside_lm_steps_ms=None if lm_ms is None else round(rep["run_full_optimization_ms"] - lm_ms, 1),   # the LM iteration count of this run varies (chaotic phase I): this part does not
+               planned_beside_pgo_stage=os.environ.get("OBVI_HOST_PLAN_AHEAD", "1") != "0",
                api_timing=api or r.stderr[-1500:],
                note="C++ host mirror end to end: scene_load + pose_graph (frame data adder, all frames) + run_full_optimization (build, upload, symbolic, PGO stage, "
                     "features-only BA, phase I, selection, phase II, read-back); process_wall_ms adds process start, HIP context creation and the result file")

@@ -362,6 +362,23 @@ def test_offline_runner_session(driver, scene, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_session_planned_ahead_is_the_serial_session_bit_for_bit(driver, scene, tmp_path):
+    """On the device: with fixed-order sums (--deterministic) a session is reproducible, so the session whose windows are planned on the second thread and handle
+    beside the solves (the default) must be the serial one (OBVI_HOST_PLAN_AHEAD=0) digit for digit -- every optimisation's iteration count and costs, every pose."""
+    prob, path, _ = scene
+    res = []
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("out_%s.json" % mode))
+        r = subprocess.run([driver, path, out, "--window", "20", "--gba-frequency", "25", "--deterministic", "--ltm"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, OBVI_HOST_PLAN_AHEAD=mode, OBVI_HOST_TIMING="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("windows planned ahead" in r.stderr) == (mode == "1")
+        res.append(json.load(open(out)))
+    a, b = res
+    assert a["records"] == b["records"] and a["poses"] == b["poses"] and a["objects"] == b["objects"] and a.get("long_term_map") == b.get("long_term_map")
+
+
+@pytest.mark.gpu
 def test_hip_session_against_the_oracle_session(driver, oracle_session, scene, tmp_path):
     prob, path, _ = scene
     out = str(tmp_path / "out.json")
