@@ -63,7 +63,9 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
     assert all(r["params_reduced_equal"] == 1 for r in solves) and max(r["initial_cost_rel"] for r in busy) <= 1e-11     # the same problem, the same objective at the same point: everywhere
     # (1) Where the two LM runs are the same run: the stated end-state tolerances.
     assert med["final_cost_rel"] <= 1e-10 and med["pose_diff"] <= 1e-10 and med["point_diff"] <= 1e-9      # measured: 5e-13, 1.4e-13, 3.5e-12
-    assert worst["max_iteration_cost_rel"] <= 2e-4 and worst["final_cost_rel"] <= 2e-4 and worst["pose_diff"] <= 1e-4   # measured: 1.5e-4, 2.5e-5, 1.7e-5 (the long global-BA runs)
+    # END state of the worst such run over ten sessions (1 551 runs): cost 2.3e-5, poses 1.6e-5.  An INTERMEDIATE iterate may be further off than the end state (a
+    # 9-iteration window: 1.6e-4 at one iterate, 9e-7 at the end; the tail over those 1 551 runs: 1.6e-4, 8.8e-5, 8.3e-5, 6.1e-5, ...): it gets a sanity bound only
+    assert worst["final_cost_rel"] <= 2e-4 and worst["pose_diff"] <= 1e-4 and worst["max_iteration_cost_rel"] <= 1e-3
     assert med["object_diff"] <= 1e-6 and worst["object_diff"] <= 1.0       # measured: 5e-8; 0.26 -- an object a window sees from a few frames only is weakly constrained along its viewing ray (yaw excluded altogether)
     # (2) Where they are not, the END STATE says why, run by run (round 5; before: a bar on the share of such runs, taken from its distribution over sixty sessions):
     #   (a) the stopping rule.  A run of the reference's blocks ends when |cost change| <= function_tolerance * cost; decided in the last bits, two runs that agree to
