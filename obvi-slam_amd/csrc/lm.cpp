@@ -11,6 +11,7 @@ namespace obvi_lib {
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
 void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, bool keep_factor) {
   ApiTimer api_timer_("  LM step (submit + wait)");
+  const double t_submit0 = api_times() ? wall_s() : 0.0;
   hipStream_t s = h->stream;
   const BlocksDev b = blocks_dev(h);
   const ReprojDev rp = reproj_dev(h);
@@ -142,6 +143,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     OBVI_HIP(hipMemcpyAsync(h->h_scal, scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
     if (!keep_factor) { launch_zero_tiles(s, rd.S, rd.nt, h->d_tiles.get(), h->ntiles, h->d_is_pad.get(), step_clear(h, fixed)); h->tiles_cleared = true; }
   }
+  if (ApiTimes* t = api_times()) t->add("    LM step: host time until everything is enqueued", 1e3 * (wall_s() - t_submit0));   // the part that threads of one process share the runtime for
   if (poll) wait_scalars(h); else sync(h);
   if (h->h_scal[SC_WAIT_TIMEOUT] != 0.0) {
     // a scheduling event, not a numerical one: nothing the step wrote is kept (the current point is untouched, the accumulators were

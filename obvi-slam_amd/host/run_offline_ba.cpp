@@ -8,6 +8,7 @@
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 //   any mode: [--deterministic] fixed-order device sums (bit-identical reruns)   [--analytic-reprojection] the reference's analytic-Jacobian reprojection functor
 // Parameter values: config/base7a_2_fallback.json of the reference.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -192,7 +193,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
-  RunnerHooks hooks; bool count_visualization_calls = false;
+  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
   front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
@@ -219,6 +220,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--reference-shaped-runner")) hooks.reference_shaped_runner_ = true;   // OfflineProblemRunner<5 types>(15 arguments), as the reference constructs it
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
+    else if (!std::strcmp(argv[i], "--sessions-in-process") && i + 1 < argc) sessions_in_process = std::max(1, std::atoi(argv[++i]));   // K sessions over the scene at once, a host thread each (results: out, out.1, ...)
   }
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
@@ -231,8 +233,8 @@ int main(int argc, char** argv) {
   // the device handle of the session is created beside the scene load and the pose-graph fill (HIP runtime start + allocations: ~0.1 s)
   // (two: the runner plans the next window / the global BA on a second handle beside the solve that is running, unless OBVI_HOST_PLAN_AHEAD=0)
   if (!dump && !front_end_only) {
-    obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
-    if (!std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0) obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
+    const bool plan_ahead = !std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0;
+    for (int k = 0; k < sessions_in_process * (plan_ahead ? 2 : 1) && k < 8; ++k) obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
   }
   OfflineProblemData data;
   MainPgPtr checkpoint_graph;
@@ -394,6 +396,40 @@ int main(int argc, char** argv) {
     out << "]}\n";
     front_end.reset(); obvi_ba_destroy(front_end_handle);
     return 0;
+  }
+
+  if (sessions_in_process > 1) {
+    // K sessions in ONE process, a host thread each (SURVEY 8e "2 sessions per GPU"): the streams of one process share the device kernel by kernel, where the
+    // queues of K processes take turns (scripts/concurrent_sessions.py measures both).  Every session has its own runner, pose graph, device handles and
+    // summary CSV; the scene is read-only and shared, and so are the library's host threads.  The plain session only: no checkpoint, no front end, no iteration logs.
+    if (from_checkpoint || global_ba_only || visual_front_end || pending || !iteration_log_dir.empty()) { std::cerr << "--sessions-in-process: plain sessions only" << std::endl; return 2; }
+    out.close();
+    std::vector<int> oks((size_t)sessions_in_process, 0);
+    std::vector<double> seconds((size_t)sessions_in_process, 0.0);
+    std::vector<std::thread> threads;
+    const auto t_all0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < sessions_in_process; ++k)
+      threads.emplace_back([&, k]() {
+        const std::string suffix = k == 0 ? std::string() : "." + std::to_string(k);
+        std::optional<OptimizationLogger> session_logger;
+        if (!csv.empty()) session_logger.emplace(csv + suffix);
+        LongTermObjectMapAndResults session_results;
+        RunnerHooks session_hooks = hooks;
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool ok = runFullOptimization(session_logger, config, data, nullptr, std::string(), session_results, 0, true, device, ltm, nullptr, nullptr, &session_hooks);
+        seconds[(size_t)k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::ofstream session_out(out_path + suffix);
+        session_out << std::setprecision(17);
+        writeResults(session_out, ok, session_results, max_frame_id, ltm);
+        oks[(size_t)k] = ok ? 1 : 0;
+      });
+    for (auto& t : threads) t.join();
+    const double all_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all0).count();
+    std::cout << "{\"sessions_in_process\": " << sessions_in_process << ", \"all_sessions_s\": " << all_s << ", \"session_s\": [";
+    for (int k = 0; k < sessions_in_process; ++k) std::cout << (k ? ", " : "") << seconds[(size_t)k];
+    std::cout << "], \"frames\": " << (max_frame_id + 1) << "}" << std::endl;
+    obvi::HandlePool::instance().drain();
+    return std::all_of(oks.begin(), oks.end(), [](int v) { return v == 1; }) ? 0 : 1;
   }
 
   std::optional<OptimizationLogger> logger;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""K independent sliding-window sessions at once on ONE GPU ("2 sessions per GPU"): K processes of the C++ host mirror's driver (run_offline_ba: per-frame
+two-phase local BA over 50 frames, global BA every 100), each with its own device handles and host threads, started together.  A window's LM iteration keeps the device
+busy for about a seventh of its time, so sessions should overlap almost freely until the host's CPUs or the device's queues run out.  Prints, per K: wall time of the
+slowest session, frames / s and LM iterations / s of all K together, against K times one session alone.
+usage: python scripts/concurrent_sessions.py [P L O] [K list, default 1,2,4,8]"""
+import json, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "obvi-slam_amd", "python")]
+import synth, scene_io
+P, L, O = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (300, 30000, 20)
+ks = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "1,2,4,8").split(",")]
+cpus = len(os.sched_getaffinity(0))
+try:   # cgroup v2 quota, as the library reads it
+    q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+    if q != "max":
+        cpus = min(cpus, max(1, int(int(q) / int(per))))
+except (OSError, ValueError):
+    pass
+d = tempfile.mkdtemp()
+scenes = []
+for s in range(max(ks)):
+    prob = synth.make_problem(P=P, L=L, O=O, seed=4 + s, min_obj_obs=10, bbox_noise=5.0, object_classes=("bench",))
+    path = os.path.join(d, "scene_%d.bin" % s)
+    scene_io.write_scene_binary(prob, path)
+    scenes.append(path)
+exe = os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba")
+in_process = os.environ.get("OBVI_SESSIONS_IN_PROCESS", "0") != "0"   # K threads of ONE driver process (run_offline_ba --sessions-in-process K, all over scene 0) instead of K processes
+base = None
+for k in ks:
+    if in_process:
+        t0 = time.time()
+        r = subprocess.run([exe, scenes[0], os.path.join(d, "outp_%d.json" % k), "--window", "50", "--gba-frequency", "100", "--csv", os.path.join(d, "optp_%d.csv" % k)]
+                           + (["--sessions-in-process", str(k)] if k > 1 else []), capture_output=True, text=True)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stderr[-2000:]
+        its = 0
+        for s in range(k):
+            rows = [ln.split(",") for ln in open(os.path.join(d, "optp_%d.csv" % k) + ("" if s == 0 else ".%d" % s)).read().strip().split("\n")[1:]]
+            its += sum(int(r2[12]) for r2 in rows)
+        if base is None:
+            base = wall if k == 1 else None
+        print("K=%d sessions in ONE process (%d usable CPUs): process wall %.2f s; together %.0f frames/s, %.0f LM iterations/s%s"
+              % (k, cpus, wall, k * P / wall, its / wall, (" = %.2f x one session alone" % (k * base / wall)) if base else ""), flush=True)
+        continue
+    threads = max(2, cpus // k - 1)
+    env = dict(os.environ, OBVI_HOST_THREADS=str(threads))
+    t0 = time.time()
+    procs = [subprocess.Popen([exe, scenes[s], os.path.join(d, "out_%d_%d.json" % (k, s)), "--window", "50", "--gba-frequency", "100", "--csv", os.path.join(d, "opt_%d_%d.csv" % (k, s))],
+                              env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for s in range(k)]
+    ends = []
+    for p in procs:
+        rc = p.wait()
+        ends.append(time.time() - t0)
+        assert rc == 0, rc
+    wall = max(ends)
+    its = 0
+    for s in range(k):
+        rows = [ln.split(",") for ln in open(os.path.join(d, "opt_%d_%d.csv" % (k, s))).read().strip().split("\n")[1:]]
+        its += sum(int(r[12]) for r in rows)
+    if base is None:
+        base = wall / k if k == 1 else None
+    print("K=%d sessions (%d host threads each, %d usable CPUs): slowest %.2f s, fastest %.2f s; together %.0f frames/s, %.0f LM iterations/s%s"
+          % (k, threads, cpus, wall, min(ends), k * P / wall, its / wall, (" = %.2f x one session alone" % (k * base / wall)) if base else ""), flush=True)

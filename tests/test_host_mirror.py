@@ -296,6 +296,23 @@ def test_planning_the_next_window_beside_the_solve_is_the_same_session(oracle_dr
     assert len(prob["poses"]) - 2 - n_gba - 6 <= n <= len(prob["poses"]) - 2   # not across global-BA frames, not from the first frames (no visual-feature optimisation there)
 
 
+def test_sessions_in_one_process_are_the_single_session_each(oracle_driver, oracle_session, scene, tmp_path):
+    """`run_offline_ba --sessions-in-process K`: K sessions over the scene at once, a host thread, a runner, a pose graph and device handles each (sessions
+    per GPU).  Nothing is shared but the read-only scene and the library's host threads: every one of them is the single session digit for digit."""
+    prob, path, _ = scene
+    out, csv = str(tmp_path / "out.json"), str(tmp_path / "opt.csv")
+    r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25", "--csv", csv, "--ltm", "--sessions-in-process", "3"], capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["sessions_in_process"] == 3 and len(line["session_s"]) == 3 and line["frames"] == len(prob["poses"])
+    b = json.load(open(oracle_session[0]))
+    strip = lambda text: [",".join(c for i, c in enumerate(ln.split(",")) if i not in TIMING_COLUMNS) for ln in text.strip().split("\n")]
+    for suffix in ("", ".1", ".2"):
+        a = json.load(open(out + suffix))
+        assert a["records"] == b["records"] and a["poses"] == b["poses"] and a["objects"] == b["objects"] and a.get("long_term_map") == b.get("long_term_map"), suffix
+        assert strip(open(csv + suffix).read()) == strip(open(oracle_session[1]).read()), suffix
+
+
 def test_limit_on_the_evaluated_trajectory(oracle_driver, scene, tmp_path):
     """LimitTrajectoryEvaluationParams (offline_problem_runner.h:143-147): the session stops at min(max_frame_id_, last frame) -- through either runner shape."""
     prob, path, _ = scene
