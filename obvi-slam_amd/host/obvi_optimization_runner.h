@@ -31,6 +31,13 @@ struct FullOVSLAMConfig {
   SlidingWindowParams sliding_window_params_;
   PostSessionObjectMergeParams post_session_object_merge_params_;   // bounding_box_front_end_params_.post_session_object_merge_params_
   LongTermMapExtractionTunableParams ltm_tunable_params_;
+  // what a parameter file adds (obvi_config_io.h): its schema version and id, the pixel noise of the visual factors (visual_feature_params_), the shape priors by
+  // semantic class (shape_dimension_priors_), the limit on the evaluated trajectory
+  int config_schema_version_ = 12;                   // base7a_2_fallback.json's
+  std::string config_version_id_ = "base7a_2";
+  struct VisualFeatureParams { double reprojection_error_std_dev_ = 1.5; } visual_feature_params_;
+  std::unordered_map<std::string, std::pair<ObjectDim, Covariance<3>>> shape_dimension_priors_;
+  LimitTrajectoryEvaluationParams limit_traj_eval_params_;
 
   static pose_graph_optimization::OptimizationSolverParams solverParams(int iterations, double function_tolerance) {
     pose_graph_optimization::OptimizationSolverParams p;
@@ -57,6 +64,8 @@ struct FullOVSLAMConfig {
     c.local_ba_iteration_params_.phase_one_opt_params_ = solverParams(50, 1e-3); c.local_ba_iteration_params_.phase_two_opt_params_ = solverParams(100, 1e-4);
     c.global_ba_iteration_params_.phase_one_opt_params_ = solverParams(250, 1e-6); c.global_ba_iteration_params_.phase_two_opt_params_ = solverParams(250, 1e-6);
     c.final_ba_iteration_params_.phase_one_opt_params_ = solverParams(300, 1e-6); c.final_ba_iteration_params_.phase_two_opt_params_ = solverParams(300, 1e-6);
+    c.ltm_tunable_params_.far_feature_threshold_ = 75.0; c.ltm_tunable_params_.min_col_norm_ = 5e-4; c.ltm_tunable_params_.fallback_to_prev_for_failed_extraction_ = true;
+    c.post_session_object_merge_params_.max_merge_distance_ = 2.0; c.post_session_object_merge_params_.x_y_only_merge_ = true;
     return c;
   }
 };

@@ -20,6 +20,7 @@
 #include <iostream>
 
 #include "obvi_optimization_runner.h"
+#include "obvi_config_io.h"
 #include "obvi_visual_feature_front_end.h"
 #include "obvi_pending_object_estimator.h"
 
@@ -190,6 +191,21 @@ int main(int argc, char** argv) {
   const char* scene_path = from_checkpoint ? nullptr : argv[1];
   const char* out_path = from_checkpoint ? argv[3] : argv[2];
   FullOVSLAMConfig config = FullOVSLAMConfig::base7a2Fallback();   // config/base7a_2_fallback.json
+  // --params-config-file F (the reference's --params_config_file, offline_object_visual_slam_main.cpp:731): one of the reference's config/*.json; read before the
+  // other options, which then override single values.  --accept-older-config-schema: files older than schema 14 (the reference's reader refuses those).
+  bool config_from_file = false, print_config = false;
+  {
+    const char* config_file = nullptr; bool older = false;
+    for (int i = first_opt; i < argc; ++i) {
+      if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) config_file = argv[i + 1];
+      else if (!std::strcmp(argv[i], "--accept-older-config-schema")) older = true;
+      else if (!std::strcmp(argv[i], "--print-config")) print_config = true;
+    }
+    if (config_file != nullptr) {
+      try { readConfiguration(config_file, config, older); config_from_file = true; }
+      catch (const std::exception& e) { std::cerr << "run_offline_ba: " << e.what() << std::endl; return 3; }
+    }
+  }
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
@@ -220,8 +236,11 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--reference-shaped-runner")) hooks.reference_shaped_runner_ = true;   // OfflineProblemRunner<5 types>(15 arguments), as the reference constructs it
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
+    else if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) ++i;   // (read above)
+    else if (!std::strcmp(argv[i], "--accept-older-config-schema") || !std::strcmp(argv[i], "--print-config")) {}
     else if (!std::strcmp(argv[i], "--sessions-in-process") && i + 1 < argc) sessions_in_process = std::max(1, std::atoi(argv[++i]));   // K sessions over the scene at once, a host thread each (results: out, out.1, ...)
   }
+  if (print_config) { writeConfigurationToStream(std::cout, config); return 0; }   // the configuration in force (file + options), in the parameter file's layout
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
 #if defined(__GLIBC__)
@@ -251,6 +270,11 @@ int main(int argc, char** argv) {
     data.visual_obs_by_frame_.resize(data.robot_poses_.size()); data.box_obs_by_frame_.resize(data.robot_poses_.size());
     data.shape_priors_by_class_ = st.obj_only_pose_graph_state_.mean_and_cov_by_semantic_class_;
   } else if (!loadScene(scene_path, &data)) { std::cerr << "could not read scene " << scene_path << std::endl; return 2; }
+  if (config_from_file) {   // what the reference takes from its parameter file and this driver otherwise from the scene: pixel noise, shape priors by class, trajectory limit
+    data.reprojection_error_std_dev_ = config.visual_feature_params_.reprojection_error_std_dev_;
+    for (const auto& e : config.shape_dimension_priors_) data.shape_priors_by_class_[e.first] = e.second;
+    if (!hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_) hooks.limit_trajectory_eval_params_ = config.limit_traj_eval_params_;
+  }
   const auto t_loaded = std::chrono::steady_clock::now();
   const FrameId max_frame_id = data.getMaxFrameId();
   const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& rp = config.object_visual_pose_graph_residual_params_;
