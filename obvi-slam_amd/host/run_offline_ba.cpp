@@ -21,6 +21,7 @@
 
 #include "obvi_optimization_runner.h"
 #include "obvi_config_io.h"
+#include "obvi_ltm_io.h"
 #include "obvi_visual_feature_front_end.h"
 #include "obvi_pending_object_estimator.h"
 
@@ -179,6 +180,12 @@ int main(int argc, char** argv) {
   // decide that for an application: host_util.h, OBVI_HOST_AFFINITY)
   setenv("OBVI_HOST_AFFINITY", "1", 0);
   if (argc < 3) { std::cerr << "usage: run_offline_ba scene.txt out.json [options] | --from-checkpoint state.json out.json | --checkpoint-roundtrip in.json out.json" << std::endl; return 2; }
+  if (!std::strcmp(argv[1], "--long-term-map-roundtrip")) {   // no GPU: the reader and the writer of obvi_ltm_io.h
+    if (argc < 4) return 2;
+    LongTermObjectMapFile map;
+    if (!readLongTermObjectMapFromFile(argv[2], map)) return 1;
+    return writeLongTermObjectMapToFile(argv[3], map) ? 0 : 1;
+  }
   if (!std::strcmp(argv[1], "--checkpoint-roundtrip")) {   // no GPU: the reader and the writer of obvi_checkpoint_io.h
     if (argc < 4) return 2;
     ObjectAndReprojectionFeaturePoseGraphState st;
@@ -209,7 +216,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
-  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1;
+  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1; std::string ltm_in_path, ltm_out_path;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
   front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
@@ -237,6 +244,8 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
     else if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) ++i;   // (read above)
+    else if (!std::strcmp(argv[i], "--long-term-map-input") && i + 1 < argc) ltm_in_path = argv[++i];     // the reference's --long_term_map_input: the previous session's map file
+    else if (!std::strcmp(argv[i], "--long-term-map-output") && i + 1 < argc) { ltm_out_path = argv[++i]; ltm = true; }   // ... --long_term_map_output (implies --ltm)
     else if (!std::strcmp(argv[i], "--accept-older-config-schema") || !std::strcmp(argv[i], "--print-config")) {}
     else if (!std::strcmp(argv[i], "--sessions-in-process") && i + 1 < argc) sessions_in_process = std::max(1, std::atoi(argv[++i]));   // K sessions over the scene at once, a host thread each (results: out, out.1, ...)
   }
@@ -270,6 +279,18 @@ int main(int argc, char** argv) {
     data.visual_obs_by_frame_.resize(data.robot_poses_.size()); data.box_obs_by_frame_.resize(data.robot_poses_.size());
     data.shape_priors_by_class_ = st.obj_only_pose_graph_state_.mean_and_cov_by_semantic_class_;
   } else if (!loadScene(scene_path, &data)) { std::cerr << "could not read scene " << scene_path << std::endl; return 2; }
+  if (!ltm_in_path.empty()) {
+    // offline_object_visual_slam_main.cpp:789-805: the map of the previous session.  Every mapped ellipsoid enters the pose graph under its id with its estimate and
+    // the prior (estimate, covariance) before the first frame (runOptimization); the scene's sightings of those ids then are sightings of map objects, and objects
+    // the scene sees for the first time take the ids behind the map's.
+    LongTermObjectMapFile map;
+    if (!readLongTermObjectMapFromFile(ltm_in_path, map)) return 2;
+    data.long_term_map_.clear();
+    for (const auto& e : map.ellipsoid_results_) {
+      data.long_term_map_.push_back(LongTermMapObjectPrior{e.first, e.second.second, map.ellipsoid_covariances_.at(e.first)});
+      data.object_class_[e.first] = e.second.first;
+    }
+  }
   if (config_from_file) {   // what the reference takes from its parameter file and this driver otherwise from the scene: pixel noise, shape priors by class, trajectory limit
     data.reprojection_error_std_dev_ = config.visual_feature_params_.reprojection_error_std_dev_;
     for (const auto& e : config.shape_dimension_priors_) data.shape_priors_by_class_[e.first] = e.second;
@@ -493,6 +514,16 @@ int main(int argc, char** argv) {
               << std::chrono::duration<double, std::milli>(t_run1 - t_run0).count() << " ms" << std::endl;
   obvi::HandlePool::instance().drain();
   writeResults(out, ok, results, max_frame_id, ltm);
+  if (!ltm_out_path.empty() && ok) {   // offline_object_visual_slam_main.cpp:1070-1076
+    LongTermObjectMapFile map;
+    auto class_of = [&](ObjectId id) { const auto it = data.object_class_.find(id); return it == data.object_class_.end() ? std::string() : it->second; };
+    for (const auto& e : results.long_term_map_) {
+      map.ellipsoid_results_[e.object_id_] = {class_of(e.object_id_), e.ellipsoid_mean_};
+      map.ellipsoid_covariances_[e.object_id_] = e.covariance_;
+    }
+    for (const auto& e : results.ellipsoid_results_) map.prev_traj_est_ellipsoid_results_[e.first] = {class_of(e.first), e.second};
+    if (!writeLongTermObjectMapToFile(ltm_out_path, map)) { std::cerr << "could not write the long-term map to " << ltm_out_path << std::endl; return 1; }
+  }
   if (global_ba_only) {   // one JSON line for bench.py's end_to_end_cpp: wall clock of this process, stage by stage
     const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::cout << "{\"scene_load_ms\": " << ms(t_main0, t_loaded) << ", \"pose_graph_ms\": " << ms(t_loaded, t_run0) << ", \"run_full_optimization_ms\": " << ms(t_run0, t_run1) << ", \"ok\": " << (ok ? "true" : "false")

@@ -1,5 +1,6 @@
-"""The reference's parameter files through the host mirror's reader (obvi-slam_amd/host/obvi_config_io.h; the reference: readConfiguration,
+"""The reference's files either side of the path.  (1) Its parameter files through the host mirror's reader (obvi-slam_amd/host/obvi_config_io.h; the reference: readConfiguration,
 include/file_io/cv_file_storage/config_file_storage_io.h:1884-1898, and its round-trip test test/file_io/cv_file_storage/config_file_storage_io_tests.cc:28).
+(2) Its long-term object map file (obvi_ltm_io.h), written by one session and read by the next.
 Fixtures: tests/golden/config_*.json = the path's entries of two of the reference's config files (values only; tests/golden/gen_config_fixtures.py)."""
 import json
 import os
@@ -112,3 +113,51 @@ def test_a_session_under_a_parameter_file(oracle_driver, scene, tmp_path):   # n
     assert filed[first]["kind"] == "lba_phase_1" and filed[first]["n_features"] == base[first]["n_features"]
     ratio = filed[first]["initial_cost"] / base[first]["initial_cost"]
     assert 1.45 <= ratio <= 2.2501, ratio   # between the Huber loss's linear regime (1.5 x) and the quadratic one (2.25 x); measured 1.55 at the noisy start
+
+
+def test_long_term_map_file_chains_two_sessions(oracle_driver, scene, tmp_path):   # noqa: F811
+    _long_term_map_chain(oracle_driver, scene, tmp_path)
+
+
+@pytest.mark.gpu
+def test_long_term_map_file_chains_two_sessions_on_the_device(driver, scene, tmp_path):   # noqa: F811
+    _long_term_map_chain(driver, scene, tmp_path)
+
+
+def _long_term_map_chain(oracle_driver, scene, tmp_path):   # noqa: F811
+    """obvi_ltm_io.h: a session writes its map in the reference's file layout (long_term_object_map_file_storage_io.h:29-115), the next one starts from it
+    (--long_term_map_input, offline_object_visual_slam_main.cpp:789-805): the mapped ellipsoids enter the graph with (estimate, covariance) priors, are not created
+    again, and come out of the second session better determined than they went in.  The file reads back to the same text."""
+    import numpy as np
+    prob, path, _ = scene
+    m1, m2, m1b = str(tmp_path / "map1.json"), str(tmp_path / "map2.json"), str(tmp_path / "map1_again.json")
+    args = ["--window", "20", "--gba-frequency", "25"]
+    r = subprocess.run([oracle_driver, path, str(tmp_path / "o1.json")] + args + ["--long-term-map-output", m1], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = json.load(open(m1))["long_term_map"]
+    assert a["ellipsoid_parameterization"] == "yaw_only" and set(a) == {"ellipsoid_parameterization", "ellipsoid_results", "prev_traj_est_ellipsoid_results", "obj_id_covariance_map", "front_end_map_data"}
+    entries = a["ellipsoid_results"]["ellipsoid_results_map"]
+    n_obj = len(prob["objects"])
+    assert [e["object_id"] for e in entries] == [str(i) for i in range(n_obj)]                      # every object of the scene was mapped, ids as decimal strings
+    assert set(entries[0]) == {"object_id", "class", "state"} and set(entries[0]["state"]) == {"pose", "dim"} and set(entries[0]["state"]["pose"]) == {"transl", "yaw"}
+    assert entries[0]["class"] in ("bench", "trashcan") and entries[0]["state"]["dim"] == {"Rows": 3, "Cols": 1, "Data": entries[0]["state"]["dim"]["Data"]}
+    cov1 = {e["k"]: np.array(e["v"]["Data"]).reshape(7, 7) for e in a["obj_id_covariance_map"]}
+    assert all(e["v"]["Rows"] == 7 and e["v"]["Cols"] == 7 for e in a["obj_id_covariance_map"]) and all(np.allclose(c, c.T, rtol=1e-9, atol=1e-12) and np.all(np.diag(c) > 0) for c in cov1.values())
+    # the file reads back to the same text
+    assert subprocess.run([oracle_driver, "--long-term-map-roundtrip", m1, m1b], timeout=60).returncode == 0 and open(m1).read() == open(m1b).read()
+    # the next session over the same place starts from the map
+    r = subprocess.run([oracle_driver, path, str(tmp_path / "o2.json")] + args + ["--long-term-map-input", m1, "--long-term-map-output", m2], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0 and "object id mismatch" not in r.stderr, r.stderr[-2000:]
+    o1, o2 = json.load(open(str(tmp_path / "o1.json"))), json.load(open(str(tmp_path / "o2.json")))
+    assert len(o2["objects"]) == len(o1["objects"]) == n_obj                                           # the map's objects were observed again, none was created twice
+    first_with_objects = lambda recs: next(x for x in recs if x["kind"] == "lba_phase_1" and x["n_objects"] > 0)   # noqa: E731
+    assert first_with_objects(o2["records"])["max_frame"] <= first_with_objects(o1["records"])["max_frame"]   # a map object needs no ten sightings before it is optimised
+    b = json.load(open(m2))["long_term_map"]
+    cov2 = {e["k"]: np.array(e["v"]["Data"]).reshape(7, 7) for e in b["obj_id_covariance_map"]}
+    assert set(cov2) == set(cov1)
+    better = [k for k in cov1 if np.trace(cov2[k][:3, :3]) < np.trace(cov1[k][:3, :3])]
+    assert len(better) == len(cov1), (better, {k: (np.trace(cov1[k][:3, :3]), np.trace(cov2[k][:3, :3])) for k in cov1})
+    # a file of another parameterisation is refused (the reference exits: long_term_object_map_file_storage_io.h:61-67)
+    bad = json.load(open(m1)); bad["long_term_map"]["ellipsoid_parameterization"] = "full_dof"
+    json.dump(bad, open(m1b, "w"))
+    assert subprocess.run([oracle_driver, "--long-term-map-roundtrip", m1b, m2], capture_output=True, timeout=60).returncode == 1
