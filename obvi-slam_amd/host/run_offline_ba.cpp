@@ -22,6 +22,7 @@
 #include "obvi_optimization_runner.h"
 #include "obvi_config_io.h"
 #include "obvi_ltm_io.h"
+#include "obvi_results_io.h"
 #include "obvi_visual_feature_front_end.h"
 #include "obvi_pending_object_estimator.h"
 
@@ -216,7 +217,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
-  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1; std::string ltm_in_path, ltm_out_path;
+  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1; std::string ltm_in_path, ltm_out_path, robot_poses_results_file, ellipsoids_results_file, visual_feature_results_file;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
   front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
@@ -244,12 +245,20 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
     else if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) ++i;   // (read above)
+    else if (!std::strcmp(argv[i], "--robot-poses-results-file") && i + 1 < argc) robot_poses_results_file = argv[++i];          // the reference's --robot_poses_results_file
+    else if (!std::strcmp(argv[i], "--ellipsoids-results-file") && i + 1 < argc) ellipsoids_results_file = argv[++i];            // ... --ellipsoids_results_file
+    else if (!std::strcmp(argv[i], "--visual-feature-results-file") && i + 1 < argc) visual_feature_results_file = argv[++i];    // ... --visual_feature_results_file
     else if (!std::strcmp(argv[i], "--long-term-map-input") && i + 1 < argc) ltm_in_path = argv[++i];     // the reference's --long_term_map_input: the previous session's map file
     else if (!std::strcmp(argv[i], "--long-term-map-output") && i + 1 < argc) { ltm_out_path = argv[++i]; ltm = true; }   // ... --long_term_map_output (implies --ltm)
     else if (!std::strcmp(argv[i], "--accept-older-config-schema") || !std::strcmp(argv[i], "--print-config")) {}
     else if (!std::strcmp(argv[i], "--sessions-in-process") && i + 1 < argc) sessions_in_process = std::max(1, std::atoi(argv[++i]));   // K sessions over the scene at once, a host thread each (results: out, out.1, ...)
   }
-  if (print_config) { writeConfigurationToStream(std::cout, config); return 0; }   // the configuration in force (file + options), in the parameter file's layout
+  if (print_config) { writeConfigurationToStream(std::cout, config); return 0; }
+  {   // offline_object_visual_slam_main.cpp:1008-1023: a global BA needs visual features or the pose graph (or both); the reference exits
+    const auto& e = config.optimization_factors_enabled_params_;
+    if (!e.use_visual_features_on_global_ba_ && !e.use_pose_graph_on_global_ba_) { std::cerr << "Must have either visual features or pose graph (or both) for global ba; review/fix your config" << std::endl; return 1; }
+    if (!e.use_visual_features_on_final_global_ba_ && !e.use_pose_graph_on_final_global_ba_) { std::cerr << "Must have either visual features or pose graph (or both) for final global ba; review/fix your config" << std::endl; return 1; }
+  }   // the configuration in force (file + options), in the parameter file's layout
   if (!iteration_log_dir.empty()) IterationLoggerFactory::setLoggingDirectory(iteration_log_dir);   // offline_object_visual_slam_main.cpp:676
   const auto t_main0 = std::chrono::steady_clock::now();
 #if defined(__GLIBC__)
@@ -514,14 +523,29 @@ int main(int argc, char** argv) {
               << std::chrono::duration<double, std::milli>(t_run1 - t_run0).count() << " ms" << std::endl;
   obvi::HandlePool::instance().drain();
   writeResults(out, ok, results, max_frame_id, ltm);
-  if (!ltm_out_path.empty() && ok) {   // offline_object_visual_slam_main.cpp:1070-1076
+  auto class_of = [&](ObjectId id) { const auto it = data.object_class_.find(id); return it == data.object_class_.end() ? std::string() : it->second; };
+  if (ok) {   // offline_object_visual_slam_main.cpp:1046-1054, 1094-1102
+    bool written = true;
+    if (!robot_poses_results_file.empty()) written = writeTextFile(robot_poses_results_file, writeRobotPoseResultsToString(results.robot_pose_results_)) && written;
+    if (!ellipsoids_results_file.empty()) {
+      std::map<ObjectId, std::pair<std::string, RawEllipsoid>> ellipsoids;
+      for (const auto& e : results.ellipsoid_results_) ellipsoids[e.first] = {class_of(e.first), e.second};
+      written = writeTextFile(ellipsoids_results_file, writeEllipsoidResultsToString(ellipsoids)) && written;
+    }
+    if (!visual_feature_results_file.empty()) written = writeTextFile(visual_feature_results_file, writeVisualFeatureResultsToString(results.visual_feature_results_)) && written;
+    if (!written) { std::cerr << "could not write a results file" << std::endl; return 1; }
+  }
+  if (!ltm_out_path.empty() && ok) {   // offline_object_visual_slam_main.cpp:1056-1076
     LongTermObjectMapFile map;
-    auto class_of = [&](ObjectId id) { const auto it = data.object_class_.find(id); return it == data.object_class_.end() ? std::string() : it->second; };
     for (const auto& e : results.long_term_map_) {
       map.ellipsoid_results_[e.object_id_] = {class_of(e.object_id_), e.ellipsoid_mean_};
       map.ellipsoid_covariances_[e.object_id_] = e.covariance_;
     }
     for (const auto& e : results.ellipsoid_results_) map.prev_traj_est_ellipsoid_results_[e.first] = {class_of(e.first), e.second};
+    if (map.ellipsoid_results_.empty() && config.ltm_tunable_params_.fallback_to_prev_for_failed_extraction_ && !ltm_in_path.empty()) {   // :1057-1068: nothing extracted: the map the session started from
+      std::cerr << "Long term map extraction failed; falling back to previous long-term map" << std::endl;
+      if (!readLongTermObjectMapFromFile(ltm_in_path, map)) return 1;
+    }
     if (!writeLongTermObjectMapToFile(ltm_out_path, map)) { std::cerr << "could not write the long-term map to " << ltm_out_path << std::endl; return 1; }
   }
   if (global_ba_only) {   // one JSON line for bench.py's end_to_end_cpp: wall clock of this process, stage by stage

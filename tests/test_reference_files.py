@@ -132,8 +132,22 @@ def _long_term_map_chain(oracle_driver, scene, tmp_path):   # noqa: F811
     prob, path, _ = scene
     m1, m2, m1b = str(tmp_path / "map1.json"), str(tmp_path / "map2.json"), str(tmp_path / "map1_again.json")
     args = ["--window", "20", "--gba-frequency", "25"]
-    r = subprocess.run([oracle_driver, path, str(tmp_path / "o1.json")] + args + ["--long-term-map-output", m1], capture_output=True, text=True, timeout=1800)
+    rp, el, vf = str(tmp_path / "robot_poses.json"), str(tmp_path / "ellipsoids.json"), str(tmp_path / "visual_feats.json")
+    r = subprocess.run([oracle_driver, path, str(tmp_path / "o1.json")] + args + ["--long-term-map-output", m1, "--robot-poses-results-file", rp, "--ellipsoids-results-file", el,
+                                                                                  "--visual-feature-results-file", vf], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the result files of the reference's executable (output_problem_data_file_storage_io.h): the same estimates as the driver's own output, in the reference's layout
+    own = json.load(open(str(tmp_path / "o1.json")))
+    poses = json.load(open(rp))["robot_poses"]["robot_pose_results_map"]
+    assert [e["frame_id"] for e in poses] == [str(f) for f in range(len(prob["poses"]))]
+    for e, p6 in zip(poses, own["poses"]):
+        rot = e["pose"]["rot"]
+        assert e["pose"]["transl"] == {"Rows": 3, "Cols": 1, "Data": p6[:3]}
+        assert np.allclose(rot["angle"] * np.array(rot["axis"]["Data"]), p6[3:], rtol=0, atol=1e-14) and abs(np.linalg.norm(rot["axis"]["Data"]) - 1.0) < 1e-14
+    ells = json.load(open(el))["ellipsoids"]["ellipsoid_results_map"]
+    assert {e["object_id"]: e["state"]["pose"]["transl"]["Data"] + [e["state"]["pose"]["yaw"]] + e["state"]["dim"]["Data"] for e in ells} == own["objects"]
+    feats = json.load(open(vf))["visual_feats"]["visual_feature_results_map"]
+    assert len(feats) >= 0.9 * len(prob["points"]) and set(feats[0]) == {"k", "v"} and feats[0]["v"]["Rows"] == 3 and [int(e["k"]) for e in feats] == sorted(int(e["k"]) for e in feats)
     a = json.load(open(m1))["long_term_map"]
     assert a["ellipsoid_parameterization"] == "yaw_only" and set(a) == {"ellipsoid_parameterization", "ellipsoid_results", "prev_traj_est_ellipsoid_results", "obj_id_covariance_map", "front_end_map_data"}
     entries = a["ellipsoid_results"]["ellipsoid_results_map"]
