@@ -23,6 +23,7 @@
 #include "obvi_config_io.h"
 #include "obvi_ltm_io.h"
 #include "obvi_results_io.h"
+#include "obvi_reference_inputs_io.h"
 #include "obvi_visual_feature_front_end.h"
 #include "obvi_pending_object_estimator.h"
 
@@ -217,7 +218,7 @@ int main(int argc, char** argv) {
   SlidingWindowParams& sw = config.sliding_window_params_;
   bool global_ba_only = false;
   int device = 0; std::string csv, checkpoint_dir, iteration_log_dir; bool dump = false, ltm = false, pending = false, masks_of_unexcluded_build = false, visual_front_end = false, front_end_only = false;
-  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1; std::string ltm_in_path, ltm_out_path, robot_poses_results_file, ellipsoids_results_file, visual_feature_results_file;
+  RunnerHooks hooks; bool count_visualization_calls = false; int sessions_in_process = 1; ReferenceInputFiles reference_inputs; std::string ltm_in_path, ltm_out_path, robot_poses_results_file, ellipsoids_results_file, visual_feature_results_file;
   VisualFeatureFrontendParams front_end_params;   // visual_feature_params of config/base7a_2_fallback.json: pixel parallax 5 px enforced, pose parallax not
   front_end_params.enforce_min_robot_pose_parallax_requirement_ = false; FrameId dump_min = 0, dump_max = 0; int excluded_every = 0; bool frames_reversed = false;
   for (int i = first_opt; i < argc; ++i) {
@@ -245,6 +246,10 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
     else if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) ++i;   // (read above)
+    else if (!std::strcmp(argv[i], "--intrinsics-file") && i + 1 < argc) reference_inputs.intrinsics_file = argv[++i];                  // with `--reference-inputs` in the scene's place:
+    else if (!std::strcmp(argv[i], "--extrinsics-file") && i + 1 < argc) reference_inputs.extrinsics_file = argv[++i];                  // the reference's --intrinsics_file, --extrinsics_file,
+    else if (!std::strcmp(argv[i], "--poses-by-node-id-file") && i + 1 < argc) reference_inputs.poses_by_node_id_file = argv[++i];      // --poses_by_node_id_file, --low_level_feats_dir
+    else if (!std::strcmp(argv[i], "--low-level-feats-dir") && i + 1 < argc) reference_inputs.low_level_feats_dir = argv[++i];
     else if (!std::strcmp(argv[i], "--robot-poses-results-file") && i + 1 < argc) robot_poses_results_file = argv[++i];          // the reference's --robot_poses_results_file
     else if (!std::strcmp(argv[i], "--ellipsoids-results-file") && i + 1 < argc) ellipsoids_results_file = argv[++i];            // ... --ellipsoids_results_file
     else if (!std::strcmp(argv[i], "--visual-feature-results-file") && i + 1 < argc) visual_feature_results_file = argv[++i];    // ... --visual_feature_results_file
@@ -287,6 +292,11 @@ int main(int argc, char** argv) {
     for (const auto& p : L.robot_poses_) if (p.first < data.robot_poses_.size()) data.robot_poses_[p.first] = convertToPose3D(p.second);
     data.visual_obs_by_frame_.resize(data.robot_poses_.size()); data.box_obs_by_frame_.resize(data.robot_poses_.size());
     data.shape_priors_by_class_ = st.obj_only_pose_graph_state_.mean_and_cov_by_semantic_class_;
+  } else if (!std::strcmp(scene_path, "--reference-inputs")) {   // the reference executable's own input files instead of a scene (obvi_reference_inputs_io.h): visual-feature sessions
+    std::string error;
+    LimitTrajectoryEvaluationParams limit = hooks.limit_trajectory_eval_params_;
+    if (!limit.should_limit_trajectory_evaluation_ && config_from_file) limit = config.limit_traj_eval_params_;
+    if (!loadReferenceInputs(reference_inputs, limit, &data, &error)) { std::cerr << "run_offline_ba --reference-inputs: " << error << std::endl; return 2; }
   } else if (!loadScene(scene_path, &data)) { std::cerr << "could not read scene " << scene_path << std::endl; return 2; }
   if (!ltm_in_path.empty()) {
     // offline_object_visual_slam_main.cpp:789-805: the map of the previous session.  Every mapped ellipsoid enters the pose graph under its id with its estimate and

@@ -4,6 +4,8 @@ include/file_io/cv_file_storage/config_file_storage_io.h:1884-1898, and its roun
 Fixtures: tests/golden/config_*.json = the path's entries of two of the reference's config files (values only; tests/golden/gen_config_fixtures.py)."""
 import json
 import os
+
+import numpy as np
 import subprocess
 
 import pytest
@@ -128,7 +130,6 @@ def _long_term_map_chain(oracle_driver, scene, tmp_path):   # noqa: F811
     """obvi_ltm_io.h: a session writes its map in the reference's file layout (long_term_object_map_file_storage_io.h:29-115), the next one starts from it
     (--long_term_map_input, offline_object_visual_slam_main.cpp:789-805): the mapped ellipsoids enter the graph with (estimate, covariance) priors, are not created
     again, and come out of the second session better determined than they went in.  The file reads back to the same text."""
-    import numpy as np
     prob, path, _ = scene
     m1, m2, m1b = str(tmp_path / "map1.json"), str(tmp_path / "map2.json"), str(tmp_path / "map1_again.json")
     args = ["--window", "20", "--gba-frequency", "25"]
@@ -175,3 +176,72 @@ def _long_term_map_chain(oracle_driver, scene, tmp_path):   # noqa: F811
     bad = json.load(open(m1)); bad["long_term_map"]["ellipsoid_parameterization"] = "full_dof"
     json.dump(bad, open(m1b, "w"))
     assert subprocess.run([oracle_driver, "--long-term-map-roundtrip", m1b, m2], capture_output=True, timeout=60).returncode == 1
+
+
+def _write_reference_inputs(d, poses_tq, feature_xyz, directory):
+    """The fixture's frames as the reference executable's input files (formats: obvi_reference_inputs_io.h)."""
+    os.makedirs(os.path.join(directory, "feats", "features"))
+    fx, fy, cx, cy = (float(v) for v in d["K"])
+    open(os.path.join(directory, "intrinsics.csv"), "w").write("camera_id, img_width, img_height, mat_00, mat_01, mat_02, mat_10, mat_11, mat_12, mat_20, mat_21, mat_22\n"
+                                                               "0, 640, 480, %r, 0, %r, 0, %r, %r, 0, 0, 1\n" % (fx, cx, fy, cy))
+    open(os.path.join(directory, "extrinsics.csv"), "w").write("camera_id, transl_x, transl_y, transl_z, quat_x, quat_y, quat_z, quat_w\n0, 0, 0, 0, -0.5, 0.5, -0.5, 0.5\n")
+    with open(os.path.join(directory, "poses.csv"), "w") as f:
+        f.write("node_id, x, y, z, qx, qy, qz, qw\n")
+        for i in reversed(range(len(poses_tq))):                                      # (any order)
+            f.write("%d, %s\n" % (i, ", ".join(repr(float(v)) for v in poses_tq[i])))
+    with open(os.path.join(directory, "feats", "features", "features.txt"), "w") as f:
+        f.write("feat_id, x, y, z\n")
+        for i, p in zip(d["feature_ids"], feature_xyz):
+            f.write("%d, %s\n" % (i, ", ".join(repr(float(v)) for v in p)))
+    for fr in range(len(poses_tq)):
+        sel = np.flatnonzero(d["obs_frame"] == fr)
+        with open(os.path.join(directory, "feats", "%06d.txt" % (fr + 1)), "w") as f:
+            f.write("%d\n0 0 0 0 0 0 1\n" % fr)
+            for k in sel[::-1]:                                                        # (any order: the reader sorts by feature id)
+                f.write("%d 0 %s %s\n" % (d["obs_feature"][k], repr(float(np.float32(d["obs_pixel"][k, 0]))), repr(float(np.float32(d["obs_pixel"][k, 1])))))
+    return ["--intrinsics-file", os.path.join(directory, "intrinsics.csv"), "--extrinsics-file", os.path.join(directory, "extrinsics.csv"),
+            "--poses-by-node-id-file", os.path.join(directory, "poses.csv"), "--low-level-feats-dir", os.path.join(directory, "feats")]
+
+
+def test_a_session_from_the_reference_executables_input_files(oracle_driver, tmp_path):   # noqa: F811
+    """`run_offline_ba --reference-inputs`: intrinsics / extrinsics / poses-by-node-id CSVs and the low-level feature directory (per-frame files + features/features.txt)
+    as the reference's offline executable reads them, here written from the reference's own data set vslam_set2 (fixture) with a perturbed start.  The session is, digit
+    for digit, the one the same data gives through the driver's scene file."""
+    import dataset_io
+    import scene_io
+    from scipy.spatial.transform import Rotation as Rot
+    d = dataset_io.last_sighting_wins(dataset_io.load_fixture("vslam_set2"))
+    rng = np.random.default_rng(5)
+    n = len(d["poses_tq"])
+    poses_tq = d["poses_tq"].copy()
+    poses_tq[1:, 0:3] += rng.normal(scale=0.03, size=(n - 1, 3))
+    q = Rot.from_quat(poses_tq[:, 3:7]) * Rot.from_rotvec(np.concatenate([np.zeros((1, 3)), rng.normal(scale=0.005, size=(n - 1, 3))]))
+    poses_tq[:, 3:7] = q.as_quat()
+    xyz = d["feature_xyz"] + rng.normal(scale=0.1, size=d["feature_xyz"].shape)
+    d32 = dict(d, obs_pixel=d["obs_pixel"].astype(np.float32).astype(np.float64), poses_tq=poses_tq)
+    files = _write_reference_inputs(d32, poses_tq, xyz, str(tmp_path / "inputs"))
+    prob = dataset_io.problem_from_dataset(d32, min_obs=2, const_poses=1, features=(d["feature_ids"].astype(np.int64), xyz))
+    assert np.all(np.diff(prob["feature_ids"]) > 0)                                  # feature order = id order: the two routes add the factors in the same order
+    order = np.lexsort((prob["rp_point"], prob["rp_pose"]))                           # the scene lists a frame's sightings by feature, as the reader of the directory does
+    for k in ("rp_pose", "rp_point", "rp_cam", "rp_pixel"):
+        prob[k] = prob[k][order]
+    scene_path = str(tmp_path / "scene.txt")
+    scene_io.write_scene(prob, scene_path)
+    args = ["--window", "8", "--gba-frequency", "10"]
+    outs = []
+    for first in ([scene_path], ["--reference-inputs"]):
+        out = str(tmp_path / "out.json")
+        r = subprocess.run([oracle_driver] + first + [out] + args + (files if first[0] == "--reference-inputs" else []), capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.load(open(out)))
+    a, b = outs
+    # (not digit for digit: the two routes turn the files' quaternions into rotation vectors with different code -- scipy there, the reader here -- and differ in the last bit)
+    assert len(a["records"]) > 2 * (n - 2) and len(a["records"]) == len(b["records"])
+    for x, y in zip(a["records"], b["records"]):
+        assert {k: x[k] for k in ("min_frame", "max_frame", "kind", "n_poses", "n_features", "n_objects", "n_excluded")} == {k: y[k] for k in ("min_frame", "max_frame", "kind", "n_poses", "n_features", "n_objects", "n_excluded")}
+        assert abs(x["initial_cost"] - y["initial_cost"]) <= 1e-9 * max(1e-6, y["initial_cost"]) and abs(x["final_cost"] - y["final_cost"]) <= 1e-6 * max(1e-6, y["final_cost"]), (x, y)
+    assert np.abs(np.array(a["poses"]) - np.array(b["poses"])).max() < 1e-8
+    assert max(x["n_features"] for x in a["records"]) > 50
+    # a missing file is an error, not an empty session
+    r = subprocess.run([oracle_driver, "--reference-inputs", str(tmp_path / "o.json")] + files[:-1] + [str(tmp_path / "nowhere")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "nowhere" in r.stderr
