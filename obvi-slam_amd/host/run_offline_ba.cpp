@@ -7,7 +7,12 @@
 //   run_offline_ba --checkpoint-roundtrip <in.json> <out.json>                                  (no GPU) read a pose-graph state and write it back
 //   run_offline_ba <scene.txt> <out.json> --pending-objects [--device D]   refineInitialEstimateForPendingObjects over every object of the scene
 //   any mode: [--deterministic] fixed-order device sums (bit-identical reruns)   [--analytic-reprojection] the reference's analytic-Jacobian reprojection functor
-// Parameter values: config/base7a_2_fallback.json of the reference.
+//   the reference's own files: [--params-config-file config/X.json [--accept-older-config-schema]] [--print-config]
+//     [--long-term-map-input F] [--long-term-map-output F]   [--robot-poses-results-file F] [--ellipsoids-results-file F] [--visual-feature-results-file F]
+//     run_offline_ba --reference-inputs <out.json> --intrinsics-file A --extrinsics-file B --poses-by-node-id-file C --low-level-feats-dir D   (instead of a scene)
+//     run_offline_ba --long-term-map-roundtrip <in.json> <out.json>                                (no GPU)
+//   [--sessions-in-process K] K sessions over the scene at once, a host thread each   [--reference-shaped-runner] OfflineProblemRunner<5 types>(15 arguments)   [--max-frame N]
+// Parameter values without a parameter file: config/base7a_2_fallback.json of the reference.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
