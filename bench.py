@@ -369,6 +369,32 @@ def end_to_end_cpp(prob, device):
     return rep
 
 
+def sliding_window_session_cpp(synth, device, frames=300, features=30000, objects=20):
+    """A sliding-window session through the C++ host mirror (the reference's per-frame shape: two-phase local BA over 50 frames, global BA every 100 frames, final
+    global BA; base7a_2_fallback values): 300 keyframes / 30 000 features / 20 objects, the workload of profiles/r0X_session_300_frames.txt.  Wall clock of the driver
+    process and what it did; the next window is planned beside the running solve unless OBVI_HOST_PLAN_AHEAD=0."""
+    import subprocess
+    import tempfile
+    import scene_io
+    exe = os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba")
+    if not os.path.exists(exe):
+        return {"error": "obvi-slam_amd/host/run_offline_ba not built"}
+    prob = synth.make_problem(P=frames, L=features, O=objects, seed=4, min_obj_obs=10, bbox_noise=5.0, object_classes=("bench",))
+    with tempfile.TemporaryDirectory() as td:
+        scene, out, csv = os.path.join(td, "scene.bin"), os.path.join(td, "out.json"), os.path.join(td, "opt.csv")
+        scene_io.write_scene_binary(prob, scene)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, scene, out, "--window", "50", "--gba-frequency", "100", "--csv", csv, "--device", str(device)], capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "run_offline_ba failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
+        rows = [ln.split(",") for ln in open(csv).read().strip().split("\n")[1:]]
+    its = sum(int(x[12]) for x in rows)
+    return {"workload": "%d keyframes / %d features / %d objects, window 50, global BA every 100 frames" % (frames, features, objects), "process_wall_s": round(wall, 3),
+            "optimisations": len(rows), "lm_iterations": its, "frames_per_s": round(frames / wall, 1), "solver_time_s": round(sum(float(x[8]) for x in rows), 3),
+            "next_window_planned_beside_the_solve": os.environ.get("OBVI_HOST_PLAN_AHEAD", "1") != "0"}
+
+
 def collective_latency(torch, ba, comm, dist, args, prob, world, reps=50):
     """Microseconds per all-reduce of the three per-step sizes of the config-4 exchange (shared objects' blocks 56 doubles each; the shared
     tail tiles + right-hand side; the scalar sums + one slot per rank), on the live communicator / process group, back to back on one stream.
@@ -1078,6 +1104,7 @@ def main():
         if world == 1 and args.config == 3 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end_global_ba(obvi_ba, synth, prob, local_rank)
             out["end_to_end_cpp"] = end_to_end_cpp(prob, local_rank)
+            out["sliding_window_session_cpp"] = sliding_window_session_cpp(synth, local_rank)
         if not args.no_cpu_baseline:
             legs = {}
             if world == 1:

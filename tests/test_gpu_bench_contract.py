@@ -41,3 +41,21 @@ def test_default_workload_line():
     assert 1 <= h["host_threads_used"] <= 16 and 1 <= h["usable_cpus"] <= h["cpu_count"]
     cu = cfg["collectives_us"]
     assert isinstance(cu, dict) and {"shared_blocks", "shared_tail", "scalars"} <= set(cu["config_5_200_shared_objects"]) and cu["config_5_200_shared_objects"]["shared_tail"]["doubles"] == 1037696
+
+
+def test_the_host_mirror_legs_of_the_bench_line():
+    """`end_to_end_cpp` and `sliding_window_session_cpp` (bench.py, config 3 only; the contract test above skips them for time): the functions themselves on small
+    scenes -- the driver runs, the records parse, the fields the docs quote are there."""
+    import importlib.util
+    sys.path[:0] = [os.path.join(helpers.ROOT, "obvi-slam_amd", "python")]
+    import synth
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(helpers.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.sliding_window_session_cpp(synth, 0, frames=60, features=4000, objects=4)
+    assert "error" not in s, s
+    assert s["optimisations"] >= 100 and s["lm_iterations"] > s["optimisations"] and s["frames_per_s"] > 0 and s["next_window_planned_beside_the_solve"] is True
+    prob = synth.make_problem(P=120, L=6000, O=6, seed=9, const_poses=1, min_obj_obs=10)
+    e = bench.end_to_end_cpp(prob, 0)
+    assert "error" not in e, e
+    assert e["ok"] and e["run_full_optimization_ms"] > 0 and e["outside_lm_steps_ms"] is not None and 0 < e["outside_lm_steps_ms"] < e["run_full_optimization_ms"] and e["planned_beside_pgo_stage"] is True
