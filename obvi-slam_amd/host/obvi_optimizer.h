@@ -1092,8 +1092,31 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
   if (opt_logger.has_value()) opt_logger->setOptimizationTypeParams(max_frame_id, false, true, true, attempt_num);          // :201-204
   optimizer.buildPoseGraphOptimization(scope_pgo, residual_params, pose_graph, &problem, opt_logger);
   lap("build (objects + relative poses)");
+  // The features-only adjustment behind the pose-graph solve has every feature sighting of the scope to flatten, upload and plan (config #3: 60-90 ms), and its
+  // STRUCTURE depends on nothing the pose-graph solve computes: a second thread builds it on a problem (and device handle) of its own while that solve runs; the
+  // values -- poses from the solve, features moved along with their first frame -- are handed over before it is solved (solveOptimization: obvi_ba_update_state).
+  // OBVI_HOST_PLAN_AHEAD=0: one after the other on the stage's one problem.
+  static const bool plan_ahead = !std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0;
+  const bool vf_beside = plan_ahead && pgo_solver_params.enable_visual_feats_only_opt_post_pgo_ && !problem.dryRun();
+  OptimizationScopeParams scope_vf = optimization_scope_params;
+  scope_vf.fix_poses_ = true; scope_vf.fix_objects_ = true; scope_vf.include_object_factors_ = false;
+  obvi::Problem vf_problem(device_id, problem.dryRun());
+  ObjectPoseGraphOptimizer vf_optimizer;
+  BesideThread vf_thread;
+  bool vf_planned = false;
+  BesideSolve beside_pgo;
+  if (vf_beside) {
+    beside_pgo.start = [&]() {
+      vf_thread.post([&]() {
+        std::optional<OptimizationLogger> no_logger;
+        vf_optimizer.buildPoseGraphOptimization(scope_vf, residual_params, pose_graph, &vf_problem, no_logger);
+        vf_planned = vf_optimizer.uploadAndPlanAhead(&vf_problem);
+      });
+    };
+    beside_pgo.join = [&]() { vf_thread.wait(); };
+  }
   if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_pgo_optimization_solver_params_ : pgo_solver_params.pgo_optimization_solver_params_,
-                                   opt_logger)) {                                                                            // :221-232
+                                   opt_logger, nullptr, nullptr, nullptr, nullptr, false, vf_beside ? &beside_pgo : nullptr)) {   // :221-232
     std::cerr << "Pose-graph + object optimization failed at max frame id " << max_frame_id << std::endl;
     return false;
   }
@@ -1112,11 +1135,11 @@ inline bool runPgoPlusEllipsoids(const FrameId& max_frame_id, const Optimization
   lap("features follow their first frame");
   if (pgo_solver_params.enable_visual_feats_only_opt_post_pgo_) {                                                            // :284-350
     std::optional<OptimizationLogger> null_logger;
-    OptimizationScopeParams scope_vf = optimization_scope_params;
-    scope_vf.fix_poses_ = true; scope_vf.fix_objects_ = true; scope_vf.include_object_factors_ = false;
-    optimizer.buildPoseGraphOptimization(scope_vf, residual_params, pose_graph, &problem, null_logger);
-    lap("build (features only)");
-    if (!optimizer.solveOptimization(&problem, final_run ? pgo_solver_params.final_post_pgo_vf_adjustment_solver_params_ : pgo_solver_params.post_pgo_vf_adjustment_solver_params_,
+    obvi::Problem* vf = &problem;
+    if (vf_beside && vf_planned) { optimizer.adoptBuild(vf_optimizer, null_logger); vf = &vf_problem; problem.parkHandle(); }
+    else optimizer.buildPoseGraphOptimization(scope_vf, residual_params, pose_graph, &problem, null_logger);
+    lap(vf_beside && vf_planned ? "build (features only): done beside the pose-graph solve" : "build (features only)");
+    if (!optimizer.solveOptimization(vf, final_run ? pgo_solver_params.final_post_pgo_vf_adjustment_solver_params_ : pgo_solver_params.post_pgo_vf_adjustment_solver_params_,
                                      null_logger)) {
       std::cerr << "Visual feature adjustment after pose-graph optimization failed at max frame id " << max_frame_id << std::endl;
       return false;

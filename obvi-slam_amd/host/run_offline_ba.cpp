@@ -281,7 +281,8 @@ int main(int argc, char** argv) {
   // (two: the runner plans the next window / the global BA on a second handle beside the solve that is running, unless OBVI_HOST_PLAN_AHEAD=0)
   if (!dump && !front_end_only) {
     const bool plan_ahead = !std::getenv("OBVI_HOST_PLAN_AHEAD") || std::atoi(std::getenv("OBVI_HOST_PLAN_AHEAD")) != 0;
-    for (int k = 0; k < sessions_in_process * (plan_ahead ? 2 : 1) && k < 8; ++k) obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
+    for (int k = 0; k < sessions_in_process * (plan_ahead ? 3 : 1) && k < 8; ++k)   // (planned ahead: the session's two problems + the pose-graph stage's)
+      obvi::HandlePool::instance().warm(obvi::makeHandleOptions(device));
   }
   OfflineProblemData data;
   MainPgPtr checkpoint_graph;

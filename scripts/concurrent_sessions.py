@@ -30,7 +30,7 @@ base = None
 for k in ks:
     if in_process:
         t0 = time.time()
-        r = subprocess.run([exe, scenes[0], os.path.join(d, "outp_%d.json" % k), "--window", "50", "--gba-frequency", "100", "--csv", os.path.join(d, "optp_%d.csv" % k)]
+        r = subprocess.run([exe, scenes[0], os.path.join(d, "outp_%d.json" % k), "--window", "50", "--gba-frequency", "100", "--merge-distance", "-1", "--csv", os.path.join(d, "optp_%d.csv" % k)]
                            + (["--sessions-in-process", str(k)] if k > 1 else []), capture_output=True, text=True)
         wall = time.time() - t0
         assert r.returncode == 0, r.stderr[-2000:]
@@ -46,7 +46,7 @@ for k in ks:
     threads = max(2, cpus // k - 1)
     env = dict(os.environ, OBVI_HOST_THREADS=str(threads))
     t0 = time.time()
-    procs = [subprocess.Popen([exe, scenes[s], os.path.join(d, "out_%d_%d.json" % (k, s)), "--window", "50", "--gba-frequency", "100", "--csv", os.path.join(d, "opt_%d_%d.csv" % (k, s))],
+    procs = [subprocess.Popen([exe, scenes[s], os.path.join(d, "out_%d_%d.json" % (k, s)), "--window", "50", "--gba-frequency", "100", "--merge-distance", "-1", "--csv", os.path.join(d, "opt_%d_%d.csv" % (k, s))],
                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for s in range(k)]
     ends = []
     for p in procs:

@@ -13,7 +13,7 @@ with tempfile.TemporaryDirectory() as td:
     scene_io.write_scene_binary(prob, scene)
     for r in range(runs):
         t0 = time.perf_counter()
-        p = subprocess.run([os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba"), scene, out, "--global-ba"], capture_output=True, text=True, timeout=900,
+        p = subprocess.run([os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba"), scene, out, "--global-ba", "--merge-distance", "-1"], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, OBVI_HOST_TIMING=os.environ.get("OBVI_HOST_TIMING", "1"), OBVI_API_TIMING="1"))
         wall = time.perf_counter() - t0
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -12,7 +12,7 @@ d = tempfile.mkdtemp()
 scene, out, csv = os.path.join(d, "scene.bin"), os.path.join(d, "out.json"), os.path.join(d, "opt.csv")
 (scene_io.write_scene if os.environ.get("OBVI_SCENE_TEXT") else scene_io.write_scene_binary)(prob, scene)   # the binary form loads in ~5 ms, the text form in ~95
 t = time.time()
-subprocess.check_call([os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba"), scene, out, "--window", "50", "--gba-frequency", "100", "--csv", csv])
+subprocess.check_call([os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba"), scene, out, "--window", "50", "--gba-frequency", "100", "--csv", csv, "--merge-distance", "-1"])
 wall = time.time() - t
 res = json.load(open(out))
 rows = [ln.split(",") for ln in open(csv).read().strip().split("\n")[1:]]
