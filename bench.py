@@ -397,6 +397,33 @@ def sliding_window_session_cpp(synth, device, frames=300, features=30000, object
             "next_window_planned_beside_the_solve": os.environ.get("OBVI_HOST_PLAN_AHEAD", "1") != "0"}
 
 
+def concurrent_sessions_cpp(synth, device, k=4, frames=300, features=30000, objects=20):
+    """k sliding-window sessions at once on this GPU, as k host threads of ONE driver process (run_offline_ba --sessions-in-process k: a runner, a pose graph and device
+    handles per session; VERDICT r4 item 5 for window-sized solves), against one such session alone; serial sessions (OBVI_HOST_PLAN_AHEAD=0: from k = 4 on the host's CPUs
+    are the limit and a second busy thread per session does not pay).  Frames / s of all k together, process wall clock including start-up."""
+    import subprocess
+    import tempfile
+    import scene_io
+    exe = os.path.join(ROOT, "obvi-slam_amd", "host", "run_offline_ba")
+    if not os.path.exists(exe):
+        return {"error": "obvi-slam_amd/host/run_offline_ba not built"}
+    prob = synth.make_problem(P=frames, L=features, O=objects, seed=4, min_obj_obs=10, bbox_noise=5.0, object_classes=("bench",))
+    out = {"workload": "%d keyframes / %d features / %d objects per session, window 50, global BA every 100 frames; serial sessions" % (frames, features, objects)}
+    with tempfile.TemporaryDirectory() as td:
+        scene = os.path.join(td, "scene.bin")
+        scene_io.write_scene_binary(prob, scene)
+        for n in (1, k):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, scene, os.path.join(td, "out_%d.json" % n), "--window", "50", "--gba-frequency", "100", "--device", str(device), "--merge-distance", "-1"]
+                               + (["--sessions-in-process", str(n)] if n > 1 else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, OBVI_HOST_PLAN_AHEAD="0"))
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "run_offline_ba failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
+            out["sessions_%d" % n] = {"process_wall_s": round(wall, 3), "frames_per_s": round(n * frames / wall, 1)}
+    out["speedup_vs_one_session"] = round(out["sessions_%d" % k]["frames_per_s"] / out["sessions_1"]["frames_per_s"], 3)
+    return out
+
+
 def collective_latency(torch, ba, comm, dist, args, prob, world, reps=50):
     """Microseconds per all-reduce of the three per-step sizes of the config-4 exchange (shared objects' blocks 56 doubles each; the shared
     tail tiles + right-hand side; the scalar sums + one slot per rank), on the live communicator / process group, back to back on one stream.
@@ -1107,6 +1134,7 @@ def main():
             out["end_to_end"] = end_to_end_global_ba(obvi_ba, synth, prob, local_rank)
             out["end_to_end_cpp"] = end_to_end_cpp(prob, local_rank)
             out["sliding_window_session_cpp"] = sliding_window_session_cpp(synth, local_rank)
+            out["concurrent_sessions_cpp"] = concurrent_sessions_cpp(synth, local_rank)
         if not args.no_cpu_baseline:
             legs = {}
             if world == 1:
