@@ -1,4 +1,5 @@
 #!/bin/bash
+# the round's full check: every -m gpu test, the profile set of scripts/profile_round.sh (copy gpurun_out/r05a/{manifest.json,r05a_*} into profiles/ afterwards), smoke()
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05d
 mkdir -p $O
