@@ -298,6 +298,7 @@ int main(int argc, char** argv) {
     for (const auto& p : L.robot_poses_) if (p.first < data.robot_poses_.size()) data.robot_poses_[p.first] = convertToPose3D(p.second);
     data.visual_obs_by_frame_.resize(data.robot_poses_.size()); data.box_obs_by_frame_.resize(data.robot_poses_.size());
     data.shape_priors_by_class_ = st.obj_only_pose_graph_state_.mean_and_cov_by_semantic_class_;
+    for (const auto& e : st.obj_only_pose_graph_state_.semantic_class_for_object_) data.object_class_[e.first] = e.second;   // (the map file written at the end names every object's class)
   } else if (!std::strcmp(scene_path, "--reference-inputs")) {   // the reference executable's own input files instead of a scene (obvi_reference_inputs_io.h): visual-feature sessions
     std::string error;
     LimitTrajectoryEvaluationParams limit = hooks.limit_trajectory_eval_params_;

@@ -200,8 +200,11 @@ def test_checkpoint_replay_the_run_opt_from_pg_state_way(driver, tmp_path):
     assert max(abs(a - b) / b for a, b in zip(cg, co)) < 1e-8 and np.abs(pg_ - po).max() < 1e-7 and np.abs(og - oo).max() < 1e-6
     # (b) end-to-end replay
     out2 = str(tmp_path / "replay.json")
-    subprocess.check_call([driver, "--from-checkpoint", ckpt, out2, "--ltm"], timeout=600)
+    ltm_file = str(tmp_path / "long_term_map.json")
+    subprocess.check_call([driver, "--from-checkpoint", ckpt, out2, "--ltm", "--long-term-map-output", ltm_file], timeout=600)
     rep = json.load(open(out2))
+    written = json.load(open(ltm_file))["long_term_map"]                                   # the reference's map file from a replayed checkpoint (ltm_extraction_only's job)
+    assert {e["object_id"] for e in written["ellipsoid_results"]["ellipsoid_results_map"]} == set(rep["long_term_map"]) and all(e["class"] for e in written["ellipsoid_results"]["ellipsoid_results_map"])
     kinds = [r["kind"] for r in rep["records"]]
     assert rep["ok"] and "gba_phase_1" in kinds and "gba_phase_2" in kinds and "pgo" in kinds and not any(k.startswith("lba") for k in kinds)
     gba1 = [r for r in rep["records"] if r["kind"] == "gba_phase_1"][0]
