@@ -78,12 +78,12 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
     #   Anything else -- a short run that differs by more than its own tolerance explains -- fails.
     def stopping_rule(r):
         # k iterations apart: each of the iterations the longer run went on for lowered the cost by more than the tolerance (or it would have stopped) and, this
-        # close to the end, by not much more -- measured 0.8 ... 1.7 x k x tolerance over the sessions of rounds 4-5; allowed 2 (k + 1) x.  (k itself: up to 5 on the
+        # close to the end, by not much more -- measured 0.8 ... 1.7 x k x tolerance over the sessions of rounds 4-5; allowed 3 (k + 1) x.  (k itself: up to 5 on the
         # local BAs; a final BA at tolerance 1e-6 was seen to go on for 7 more -- 16 against 23 iterations, costs 8.5e-6 apart = 1.2 x k x tolerance; the bound that
         # binds is the cost one, which grows with k)
         k = abs(r["iterations_hip"] - r["iterations_oracle"])
         return k <= 10 and max(r["iterations_hip"], r["iterations_oracle"]) <= 40 and \
-            r["final_cost_rel"] <= 2.0 * (k + 1) * max(r["function_tolerance"], 1e-8) and r["pose_diff"] <= 5e-3
+            r["final_cost_rel"] <= 3.0 * (k + 1) * max(r["function_tolerance"], 1e-8) and r["pose_diff"] <= 5e-3   # (profiles/r05_lockstep_distribution.txt, 40 sessions: k <= 7, ratio median 0.51, max 1.99)
     def long_run(r):
         return max(r["iterations_hip"], r["iterations_oracle"]) >= 25 and r["final_cost_rel"] <= 2e-2 and r["pose_diff"] <= 5e-2
     unexplained = [r for r in bad if not (stopping_rule(r) or long_run(r))]
