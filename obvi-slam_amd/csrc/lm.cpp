@@ -7,6 +7,13 @@
 
 namespace obvi_lib {
 
+// Solves running in this process right now (obvi_ba_solve on as many handles, a host thread each).  Window-sized solves are chains of short launches; the runtime's
+// four hardware queues carry about four such chains at once, and a handle that forks a side stream takes two of them: measured with K sessions in one process
+// (profiles/r05_concurrent_sessions.txt), 8 sessions reach 603 frames/s together with one stream per handle against 481 with two.  So a window-sized step forks its
+// side stream only while at most OBVI_SIDE_MAX_SOLVERS solves (default 2) are in flight.
+static std::atomic<int> g_active_solves{0};
+struct ActiveSolve { ActiveSolve() { g_active_solves.fetch_add(1, std::memory_order_relaxed); } ~ActiveSolve() { g_active_solves.fetch_sub(1, std::memory_order_relaxed); } };
+
 // One LM step on the device: linearise at the current point, assemble and solve the damped reduced
 // system, form the candidate, evaluate it.  `solve` false: linearisation only (gradient norms).
 void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, bool keep_factor) {
@@ -31,7 +38,10 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // With a multi-GPU exchange the first collective (the shared objects' blocks) rides on the side stream too: it needs the pose pass and the
   // small factors, and only the diagonal-block kernel behind it needs its result.  Not in an instrumented solve.
   static const bool side_ok = !std::getenv("OBVI_SIDE") || std::atoi(std::getenv("OBVI_SIDE")) != 0;   // tuning knob
-  const bool side = h->profiling < 2 && side_ok && !h->deterministic;   // deterministic mode: one stream, so that the kernels that add to the same tiles do so in a fixed order
+  static const int side_max_solvers = std::getenv("OBVI_SIDE_MAX_SOLVERS") ? std::atoi(std::getenv("OBVI_SIDE_MAX_SOLVERS")) : 2;   // tuning knob (see g_active_solves)
+  const int64_t fork_early_below = std::getenv("OBVI_FORK_EARLY_BELOW") ? std::atoll(std::getenv("OBVI_FORK_EARLY_BELOW")) : 400000;   // tuning knob (observations); read per step: the tests flip it
+  const bool crowded_window = h->n_rp < fork_early_below && g_active_solves.load(std::memory_order_relaxed) > side_max_solvers;
+  const bool side = h->profiling < 2 && side_ok && !h->deterministic && !crowded_window;   // deterministic mode: one stream, so that the kernels that add to the same tiles do so in a fixed order
   hipStream_t s2 = side ? h->stream2 : s;
   // the point pass first, alone: it and the pose-side pass stream the same observation arrays and are both HBM-bound (side by side the
   // point pass took 0.35 ms instead of 0.24); the side stream starts behind it and runs beside the Schur complement, which is bound
@@ -39,7 +49,6 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   // ... on a big problem.  On a sliding window every kernel is a few microseconds of latency, nothing is bandwidth-bound, and the side stream
   // (pose pass + small factors + diagonal blocks + far pairs: 63 us for 50 frames) is longer than point pass + Schur complement (47 us): there
   // it forks in front of the point pass.
-  const int64_t fork_early_below = std::getenv("OBVI_FORK_EARLY_BELOW") ? std::atoll(std::getenv("OBVI_FORK_EARLY_BELOW")) : 400000;   // tuning knob (observations); read per step: the tests flip it
   const bool fork_early = side && h->n_rp < fork_early_below;
   auto side_pose_pass = [&] {
     record(h, PH_POSE_PASS, s2);
@@ -182,6 +191,7 @@ int obvi_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
   if (!check_ready(h)) return fail(h, OBVI_ERR_NOT_READY, "solve: cameras not set");
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
+  obvi_lib::ActiveSolve active_solve_;
   const double t_start = wall_s();
   std::memset(sum, 0, sizeof(*sum));
   h->iterations.clear();
