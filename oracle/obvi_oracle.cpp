@@ -96,8 +96,9 @@ double now_s() {
 // Host threads for the embarrassingly parallel parts (linearisation of the factors, trial-point cost, elimination of the points):
 // bench.py's cpu_baseline leg sets min(20, hardware threads) -- 20 is the reference's own num_threads
 // (object_pose_graph_optimizer.h:662) -- through oracle_set_threads().  The default, and what every parity test runs, is 1: the
-// sequential code below, whose summation order is fixed.  With more threads the factor records are the same and in the same
-// order; only the order in which the points' Schur contributions are added changes (round-off).
+// sequential code below.  With more threads every sum still adds the same terms in the same order (round 6: the points'
+// Schur contributions are added row by row by one thread each, the trial cost is one running sum over per-factor values), so
+// the oracle's results are bit-identical for any thread count (tests/test_oracle_solver.py).
 int g_threads = 1;
 template <class F>
 void parallel_ranges(int64_t n, F&& fn) {   // fn(thread, begin, end), contiguous ranges in order
@@ -374,19 +375,18 @@ int64_t reduced_row(const Reduced& rd, BlockKind k, int64_t i) {
 double reduced_cost(const OracleProblem& pb, const Reduced& rd) {
   real cost = 0.0;
   for (const Family& fam : families(pb)) {
-    std::vector<real> part((size_t)std::max(1, g_threads), 0.0);
-    parallel_ranges(fam.n, [&](int t, int64_t i0, int64_t i1) {
-      real c = 0.0;
+    // every factor's cost on the host threads, then ONE running sum in factor order: the same bits for any thread count
+    std::vector<real> each((size_t)fam.n, 0.0);
+    parallel_ranges(fam.n, [&](int, int64_t i0, int64_t i1) {
       for (int64_t i = i0; i < i1; ++i) {
         if (!(*fam.active)[i]) continue;
         FactorLin f; fam.lin(pb, i, false, &f);
         if (!is_var(pb, rd, f.k0, f.i0) && !is_var(pb, rd, f.k1, f.i1)) continue;
         robustify(&f, fam.huber, true);
-        c += f.cost;
+        each[(size_t)i] = f.cost;
       }
-      part[t] = c;
     });
-    for (real c : part) cost += c;   // one thread: the plain running sum
+    for (real c : each) cost += c;
   }
   return (double)cost;
 }
@@ -542,10 +542,14 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
   }
   // eliminate points
   Hll_inv->assign(9 * pb.L, 0.0);
-  // host threads (g_threads > 1): ranges of points; a point's contributions to a pose's rows (right-hand side and the blocks of
-  // that block row) are added under that pose's lock, so the sums are complete but their order depends on the schedule
-  std::unique_ptr<std::mutex[]> row_lock(g_threads > 1 ? new std::mutex[(size_t)rd.nPv + 1] : nullptr);
+  // Host threads (g_threads > 1), in two passes so that the result does not depend on their number (round 6: an oracle whose bits change with
+  // the thread count cannot back a committed end state):
+  //   (A) ranges of points: H_ll^-1 and W_i = J_p,i^T J_l,i of every observation -- independent per point;
+  //   (B) ranges of pose block rows: a row's right-hand side and blocks are written by ONE thread, which walks the row's observations in
+  //       ascending (point, observation) order -- the order in which the one-thread loop reaches them -- so every entry subtracts the same
+  //       products in the same order whatever g_threads is (1 included).
   std::vector<uint8_t> bad_part((size_t)std::max(1, g_threads), 0);
+  std::vector<real> Wall(18 * ws->lin.size());   // by factor record
   parallel_ranges(pb.L, [&](int tid, int64_t l_begin, int64_t l_end) {
   for (int64_t l = l_begin; l < l_end; ++l) {
     if (!rd.point_var[l]) continue;
@@ -560,35 +564,47 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
     Hi[0] = c00 / det; Hi[1] = (H[2] * H[7] - H[1] * H[8]) / det; Hi[2] = (H[1] * H[5] - H[2] * H[4]) / det;
     Hi[3] = Hi[1];     Hi[4] = (H[0] * H[8] - H[2] * H[6]) / det; Hi[5] = (H[2] * H[3] - H[0] * H[5]) / det;
     Hi[6] = Hi[2];     Hi[7] = Hi[5];                             Hi[8] = (H[0] * H[4] - H[1] * H[3]) / det;
-    const std::vector<int64_t>& obs = ws->point_obs[l];
     // W_i = J_p,i^T J_l,i (6x3) for observations with a variable pose
-    std::vector<real> W(18 * obs.size()), Y(18 * obs.size());
-    for (size_t a = 0; a < obs.size(); ++a) {
-      const FactorLin& f = ws->lin[obs[a]];
+    for (int64_t idx : ws->point_obs[l]) {
+      const FactorLin& f = ws->lin[idx];
       if (rd.pose_vid[f.i0] < 0) continue;
-      real* Wa = &W[18 * a]; real* Ya = &Y[18 * a];
+      real* Wa = &Wall[18 * idx];
       for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
         Wa[3 * x + k] = (real)f.J0[x] * f.J1[k] + (real)f.J0[6 + x] * f.J1[3 + k];
+    }
+  }
+  });
+  for (uint8_t b : bad_part) if (b) return false;
+  // the observations of every variable pose: (point, position in the point's list), ascending
+  std::vector<std::vector<std::pair<int64_t, int32_t>>> by_pose((size_t)rd.nPv);
+  for (int64_t l = 0; l < pb.L; ++l) {
+    if (!rd.point_var[l]) continue;
+    const std::vector<int64_t>& obs = ws->point_obs[l];
+    for (size_t a = 0; a < obs.size(); ++a) {
+      const int32_t vid = rd.pose_vid[ws->lin[obs[a]].i0];
+      if (vid >= 0) by_pose[(size_t)vid].push_back({l, (int32_t)a});
+    }
+  }
+  parallel_ranges(rd.nPv, [&](int, int64_t v_begin, int64_t v_end) {
+  for (int64_t v = v_begin; v < v_end; ++v) {
+    for (const auto& la : by_pose[(size_t)v]) {
+      const int64_t l = la.first;
+      const std::vector<int64_t>& obs = ws->point_obs[l];
+      const FactorLin& fa = ws->lin[obs[la.second]];
+      const real* Hi = &(*Hll_inv)[9 * l];
+      const real* Wa = &Wall[18 * obs[la.second]];
+      real Ya[18];
       for (int x = 0; x < 6; ++x) for (int k = 0; k < 3; ++k)
         Ya[3 * x + k] = Wa[3 * x] * Hi[k] + Wa[3 * x + 1] * Hi[3 + k] + Wa[3 * x + 2] * Hi[6 + k];
-      const int64_t ra = pose_row(rd, f.i0);
-      std::unique_lock<std::mutex> lock;
-      if (row_lock) lock = std::unique_lock<std::mutex>(row_lock[rd.pose_vid[f.i0]]);
+      const int64_t ra = pose_row(rd, fa.i0);
       for (int x = 0; x < 6; ++x)
         ws->rhs[ra + x] -= Ya[3 * x] * ws->gl[3 * l] + Ya[3 * x + 1] * ws->gl[3 * l + 1] + Ya[3 * x + 2] * ws->gl[3 * l + 2];
-    }
-    for (size_t a = 0; a < obs.size(); ++a) {
-      const FactorLin& fa = ws->lin[obs[a]];
-      if (rd.pose_vid[fa.i0] < 0) continue;
-      const int64_t ra = pose_row(rd, fa.i0);
-      std::unique_lock<std::mutex> lock;
-      if (row_lock) lock = std::unique_lock<std::mutex>(row_lock[rd.pose_vid[fa.i0]]);
       for (size_t b = 0; b < obs.size(); ++b) {
         const FactorLin& fb = ws->lin[obs[b]];
         if (rd.pose_vid[fb.i0] < 0) continue;
         const int64_t rb = pose_row(rd, fb.i0);
         if (rb > ra) continue;
-        const real* Ya = &Y[18 * a]; const real* Wb = &W[18 * b];
+        const real* Wb = &Wall[18 * obs[b]];
         for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) {
           if (ra == rb && y > x) continue;
           Sat(ws, ra + x, rb + y) -= Ya[3 * x] * Wb[3 * y] + Ya[3 * x + 1] * Wb[3 * y + 1] + Ya[3 * x + 2] * Wb[3 * y + 2];
@@ -597,7 +613,6 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
     }
   }
   });
-  for (uint8_t b : bad_part) if (b) return false;
   return true;
 }
 

@@ -205,26 +205,34 @@ def test_parameter_priors_enter_the_covariance_as_jacobian_rows():
     assert np.all(p6[prob["pose_const"] == 1] == -1) and np.all(o7 > 0) and o7[0, 0] > 1 / sd[0] ** 2
 
 
-def test_host_threads_change_round_off_only():
-    """bench.py's cpu_baseline runs the oracle with min(20, hardware) host threads (the reference's num_threads = 20): same factor
-    records in the same order, bit-identical skyline factor (arrow split), only the order of the points' Schur contributions
-    differs.  The trajectory must be that of the sequential oracle to round-off."""
+def test_the_oracle_is_bit_identical_for_any_number_of_host_threads():
+    """bench.py's cpu_baseline and the committed end states run the oracle with min(20, hardware) host threads (the reference's num_threads = 20).
+    Since round 6 every sum of the oracle adds the same terms in the same order whatever the thread count is (the points' Schur contributions
+    row by row by one thread each, the trial cost as one running sum, the arrow split of the skyline factor): the LM trajectory, the blocks it
+    ends at and the covariance blocks are the SAME BITS at 1, 3, 4 and 7 threads (a checker whose result depends on its
+    thread count cannot back a committed fixture)."""
     import ctypes
     lib = ctypes.CDLL(helpers.ensure_oracle())
     prob = synth.make_problem(P=60, L=2500, O=4, seed=9, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0)
     out = []
     try:
-        for threads in (1, 4):
+        for threads in (1, 3, 4, 7):
             lib.oracle_set_threads(ctypes.c_int32(threads))
             ba = helpers.oracle_ba(); synth.upload(ba, prob)
             s = ba.solve(helpers.ba_params(max_it=6, ftol=0, gtol=0, ptol=0))
-            out.append((s.num_iterations, [i.cost for i in ba.iterations()], [i.step_is_successful for i in ba.iterations()], ba.get_poses(), ba.get_objects()))
+            its = ba.iterations()
+            out.append((s.num_iterations, np.array([i.cost for i in its]), np.array([i.step_norm for i in its]), [i.step_is_successful for i in its],
+                        ba.get_poses(), ba.get_points(), ba.get_objects(), ba.object_covariances(np.arange(4)), ba.evaluate(True, True)))
     finally:
         lib.oracle_set_threads(ctypes.c_int32(1))
-    (n1, c1, a1, p1, o1), (n4, c4, a4, p4, o4) = out
-    assert n1 == n4 and a1 == a4
-    assert max(abs(x - y) / y for x, y in zip(c4, c1)) < 1e-11
-    assert np.abs(p4 - p1).max() < 1e-9 and np.abs(o4 - o1).max() < 1e-8
+    ref = out[0]
+    assert ref[0] == 7 and sum(ref[3]) >= 3
+    for other in out[1:]:
+        assert other[0] == ref[0] and other[3] == ref[3]
+        for a, b in zip(other, ref):
+            if isinstance(a, np.ndarray):
+                assert np.array_equal(a, b)
+        assert other[8][0] == ref[8][0] and np.array_equal(other[8][1], ref[8][1])
 
 
 def test_flat_problem_file_for_the_ceres_harness(tmp_path):
