@@ -184,18 +184,13 @@ constexpr int kSchurRows = 8, kSchurWindowFrames = 40, kSchurGroupCols = 5, kSch
 // (bit 15: two records per frame), the slot its image starts at inside its batch and the offset of its slots from the first slot of its workgroup
 struct PlanVisit { uint32_t l; uint16_t twin_bits; uint16_t base; uint32_t rel; };
 void launch_plan_visit_slots(hipStream_t s, int64_t nvis, const PlanVisit* pv, const uint32_t* wg_ptr, const uint32_t* wg_slot0, int32_t nwg, const int32_t* wg_f0, const int32_t* wg_group,
-                             const uint32_t* point_ptr, const uint8_t* rp_active, const uint32_t* rp_pose, const int32_t* frame_of_pose, uint32_t zero16, uint32_t* visits, uint32_t* slot_src, uint32_t* slot_obs /* or null */);
+                             const uint32_t* point_ptr, const uint8_t* rp_active, const uint32_t* rp_pose, const int32_t* frame_of_pose, uint32_t zero16, uint32_t* visits, uint32_t* slot_src);
 void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat,
                          const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot, const uint32_t* visits, const uint32_t* slot_src,
                          const int32_t* wg_f0, const int32_t* wg_group);
-// experiment (round 6, OBVI_SCHUR_MF=1): the same strips with every Z record formed in the kernel from the observation, the pose cache and the point's (X, C) instead of gathered
-void launch_schur_window_mf(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
-                            const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat, const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot,
-                            const uint32_t* visits, const uint32_t* slot_obs, const int32_t* wg_f0, const int32_t* wg_group);
 // point back-substitution and the candidate poses / objects (with the candidate's pose cache, both layouts of launch_pose_cache), one launch
 void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
-                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal,
-                          const DevCam* mf_cams = nullptr, const PoseCache* mf_pc = nullptr /* experiment OBVI_SCHUR_MF=2 */);
+                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal);
 // trial-point cost + model cost change.  mode 0: cost at (poses,points,objects) into SC_COST_CAND and
 // model change of the step (cand - current); mode 1: cost only, split into SC_COST / SC_COST_FIXED.
 void launch_cost(hipStream_t s, const BlocksDev& b, const ReprojPoseDev& rq, const SmallFactorsDev& sf, const DevCam* cams,

@@ -33,8 +33,6 @@ using namespace obvi;  // NOLINT
 namespace obvi_lib {
 
 
-// experiment knob (round 6): the Schur strip kernel forms every Z record itself (matrix-free strips) instead of gathering what k_point_pass stored
-inline bool schur_matrix_free() { const char* v = std::getenv("OBVI_SCHUR_MF"); return v && std::atoi(v) != 0; }
 inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 enum Phase { PH_POSE_CACHE = 0, PH_POINT_PASS, PH_POSE_PASS, PH_SMALL, PH_DIAG, PH_SCHUR, PH_SCHUR_BLOCKS, PH_CHOL, PH_BACKSUB, PH_APPLY, PH_COST, PH_COUNT };
@@ -123,7 +121,7 @@ struct obvi_ba_handle {
   DevBuf<double> d_Ci, d_u, d_scale_l, d_Z, d_gl, d_lam_l;
   DevBuf<uint32_t> d_blk_row, d_blk_col, d_blk_ptr, d_pair_a, d_pair_b, d_chunk_ptr, d_chunk_points;
   DevBuf<int32_t> d_row_of_nat, d_chunk_f0, d_chunk_group;
-  DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src, d_slot_obs;
+  DevBuf<uint32_t> d_batch_first, d_batch_slot, d_slot_src;
   DevBuf<PlanVisit> d_plan_visits; DevBuf<uint32_t> d_plan_wg_ptr, d_plan_wg_slot0; DevBuf<int32_t> d_plan_frame;   // inputs of the device-side slot fill (plan.cpp, plan_kernels.hip)
   int32_t schur_twins = 0;
   int64_t nchunks = 0, npairs_window = 0;

@@ -281,8 +281,6 @@ __global__ void __launch_bounds__(kBlock, kPointImageDoubles <= 1264 ? 4 : 3) k_
   __shared__ __attribute__((aligned(16))) double ex[kBlock / 64][kPointImageDoubles];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t gw = blockIdx.x * (int64_t)(kBlock / 64) + wv;
-  const bool no_z = (first_iter & 2) != 0;   // experiment (OBVI_SCHUR_MF=2): the strip kernel and the back-substitution form Z themselves, nothing is stored
-  first_iter &= 1;
   double cost = 0.0, gsq = 0.0, gmax = 0.0, xsq = 0.0, fail = 0.0;
   if (gw < n_waves) {
     const uint32_t a0 = wave_obs[2 * gw], n = wave_obs[2 * gw + 1];
@@ -370,7 +368,6 @@ __global__ void __launch_bounds__(kBlock, kPointImageDoubles <= 1264 ? 4 : 3) k_
         ut[0] = ul0; ut[1] = ul1; ut[2] = ul2; ut[3] = 0.0;
       }
       // Z = rho' Jp^T (Jl Ci^T); w = 0 for an observation without a Z record (inactive / constant pose): its slot is never read
-      if (!no_z) {
       const double wz = (live && vid >= 0) ? w : 0.0;
       const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
       const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
@@ -380,7 +377,6 @@ __global__ void __launch_bounds__(kBlock, kPointImageDoubles <= 1264 ? 4 : 3) k_
         Z[3 * x] = wz * (Jp[x] * m00 + Jp[6 + x] * m10);
         Z[3 * x + 1] = wz * (Jp[x] * m01 + Jp[6 + x] * m11);
         Z[3 * x + 2] = wz * (Jp[x] * m02 + Jp[6 + x] * m12);
-      }
       }
     } else if (have) {
       // a point that is not variable (constant, or -- under a plan kept across a mask change -- one that lost all its factors): zero
@@ -396,7 +392,7 @@ __global__ void __launch_bounds__(kBlock, kPointImageDoubles <= 1264 ? 4 : 3) k_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // write the image: contiguous in global memory, 16 bytes per lane per store
-    const int total2 = no_z ? 0 : (18 * (int)n + 4 * (int)(l1 - l0 + 1)) / 2;
+    const int total2 = (18 * (int)n + 4 * (int)(l1 - l0 + 1)) / 2;
     double2* dst = reinterpret_cast<double2*>(pt.Z + z_off(a0, l0));
     const double2* src = reinterpret_cast<const double2*>(img);
     for (int i = lane; i < total2; i += 64) dst[i] = src[i];
@@ -1036,13 +1032,12 @@ __device__ __forceinline__ void mfma_f64_acc(sf64x4& acc, double a, double bv) {
 #ifndef OBVI_SCHUR_VISIT_GROUP
 #define OBVI_SCHUR_VISIT_GROUP 2
 #endif
-struct SchurMfArgs { ReprojDev rp; const DevCam* cams; const PoseCache* pc; const double* points; };   // MF: what a Z record is formed from
-template <bool TWIN, bool MF = false>
-__global__ void __launch_bounds__(64 * kSWv, MF ? 2 : 1) k_schur_window(BlocksDev b, PointDev pt, ReducedDev rd, const int32_t* __restrict__ row_of_nat,
+template <bool TWIN>
+__global__ void __launch_bounds__(64 * kSWv) k_schur_window(BlocksDev b, PointDev pt, ReducedDev rd, const int32_t* __restrict__ row_of_nat,
                                                           const uint32_t* __restrict__ wg_bptr, const uint32_t* __restrict__ bfirst,
                                                           const uint32_t* __restrict__ bslot, const uint4* __restrict__ visits,
                                                           const uint32_t* __restrict__ slot_src, const int32_t* __restrict__ wg_f0,
-                                                          const int32_t* __restrict__ wg_group, SchurMfArgs mf) {
+                                                          const int32_t* __restrict__ wg_group) {
   // two batch buffers as separate objects, each addressed statically (the loop below is unrolled by two): the compiler then
   // knows that the reads of one do not alias the gather in flight into the other and does not wait for it
   __shared__ __attribute__((aligned(16))) unsigned char zbuf0[kSchurBatchBytes], zbuf1[kSchurBatchBytes];
@@ -1081,7 +1076,6 @@ __global__ void __launch_bounds__(64 * kSWv, MF ? 2 : 1) k_schur_window(BlocksDe
   uint32_t src_next[kIters];   // table entries of the batch to stream next, loaded one batch ahead
   auto load_table = [&](uint32_t bi) {
     const uint32_t s0 = bslot[bi], ns = bslot[bi + 1] - s0;
-    if (MF) { src_next[0] = (uint32_t)tid < ns ? slot_src[s0 + tid] : 0xfffffffeu; return; }   // one lane per 144-byte slot (a batch holds <= 227)
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
       const uint32_t slot = ((uint32_t)(64 * kSWv * i) + (uint32_t)tid) / 9u;
@@ -1093,56 +1087,12 @@ __global__ void __launch_bounds__(64 * kSWv, MF ? 2 : 1) k_schur_window(BlocksDe
   auto stream_batch = [&](uint32_t bi, auto which) {   // global -> LDS, asynchronous (vmcnt); the LDS image is lane-linear
     unsigned char* zb_ = decltype(which)::value ? zbuf1 : zbuf0;
     uint4* rb_ = decltype(which)::value ? recbuf1 : recbuf0;
-    if (MF) {
-      // matrix-free: the lane forms its slot's record -- Z = rho' Jp^T Jl C^-T of observation `code`, (u_l, 0) for a tail, zeros for a frame the point skips
-      const uint32_t code = src_next[0];
-      if (code != 0xfffffffeu) {
-        double Z[18];
 #pragma unroll
-        for (int x = 0; x < 18; ++x) Z[x] = 0.0;
-        if (code == 0xffffffffu) {
-        } else if (code & 0x80000000u) {
-          const int64_t l = code & 0x7fffffffu;
-          Z[0] = pt.u[3 * l]; Z[1] = pt.u[3 * l + 1]; Z[2] = pt.u[3 * l + 2];
-        } else {
-          const uint32_t a = code, l = mf.rp.point[a], p = mf.rp.pose[a];
-          if (mf.rp.active[a] && b.pose_vid[p] >= 0 && b.point_var[l]) {
-            const double X[3] = {mf.points[3 * (int64_t)l], mf.points[3 * (int64_t)l + 1], mf.points[3 * (int64_t)l + 2]};
-            const double* Ci = pt.Ci + 6 * (int64_t)l;
-            const double i00 = Ci[0], i10 = Ci[1], i11 = Ci[2], i20 = Ci[3], i21 = Ci[4], i22 = Ci[5];
-            const double2 px = mf.rp.pixel[a];
-            PoseCache cache;
-            {
-              const double* soa = reinterpret_cast<const double*>(mf.pc + b.P + 1) + p;
-              double* f = reinterpret_cast<double*>(&cache);
-#pragma unroll
-              for (int k = 0; k < 21; ++k) f[k] = soa[k * b.P];
-            }
-            double r[2], Jp[12], Jl[6], rho0, w;
-            reproj_eval<true>(cache, mf.cams[mf.rp.cam[a]], X, px.x, px.y, mf.rp.sigma[a], r, Jp, Jl);
-            huber_eval(r[0] * r[0] + r[1] * r[1], mf.rp.huber, &rho0, &w);
-            const double m00 = Jl[0] * i00, m01 = Jl[0] * i10 + Jl[1] * i11, m02 = Jl[0] * i20 + Jl[1] * i21 + Jl[2] * i22;
-            const double m10 = Jl[3] * i00, m11 = Jl[3] * i10 + Jl[4] * i11, m12 = Jl[3] * i20 + Jl[4] * i21 + Jl[5] * i22;
-#pragma unroll
-            for (int x = 0; x < 6; ++x) {
-              Z[3 * x] = w * (Jp[x] * m00 + Jp[6 + x] * m10);
-              Z[3 * x + 1] = w * (Jp[x] * m01 + Jp[6 + x] * m11);
-              Z[3 * x + 2] = w * (Jp[x] * m02 + Jp[6 + x] * m12);
-            }
-          }
-        }
-        double2* dst = reinterpret_cast<double2*>(zb_ + 144u * (uint32_t)tid);
-#pragma unroll
-        for (int x = 0; x < 9; ++x) dst[x] = double2{Z[2 * x], Z[2 * x + 1]};
+    for (int i = 0; i < kIters; ++i)
+      if (src_next[i] != 0xffffffffu) {
+        const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid;
+        gather16_to_lds(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * (src_next[i] + q % 9u), lds_address(zb_) + 16u * (uint32_t)(64 * kSWv * i + 64 * wv));
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < kIters; ++i)
-        if (src_next[i] != 0xffffffffu) {
-          const uint32_t q = (uint32_t)(64 * kSWv * i) + (uint32_t)tid;
-          gather16_to_lds(reinterpret_cast<const unsigned char*>(pt.Z) + 16ull * (src_next[i] + q % 9u), lds_address(zb_) + 16u * (uint32_t)(64 * kSWv * i + 64 * wv));
-        }
-    }
     const uint32_t vb = bfirst[bi], nv = bfirst[bi + 1] - vb;
     if (wv == 0)
       for (uint32_t c0 = 0; c0 < nv; c0 += 64)
@@ -1299,10 +1249,9 @@ __global__ void __launch_bounds__(64 * kSWv, MF ? 2 : 1) k_schur_window(BlocksDe
 // feature walks all of a feature's records one dependent round trip after the other (300 k features x 10 sightings: 169 us with one
 // lane, 116 us with eight).  A workgroup takes feature groups block, block + stride, ... and adds its three sums to the step's scalars
 // once: they are single addresses of one cache line, and a same-line atomic costs ~40 ns (12 500 workgroups were measured at 1.5 ms).
-struct BacksubMfArgs { const DevCam* cams; const PoseCache* pc; };
-template <int G, bool MF = false>
+template <int G>
 __device__ __forceinline__ void point_backsub_block(int64_t block, int64_t stride, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd,
-                                                    const double* __restrict__ points, double* __restrict__ points_cand, double* scal, BacksubMfArgs mf = BacksubMfArgs{}) {
+                                                    const double* __restrict__ points, double* __restrict__ points_cand, double* scal) {
   const uint32_t g = threadIdx.x % G;
   double stepsq = 0.0, bad = 0.0, model = 0.0;
   for (int64_t l = (block * (int64_t)kBlock + threadIdx.x) / G; l < b.L; l += stride * (kBlock / G)) {   // uniform over the G lanes of a feature
@@ -1312,35 +1261,6 @@ __device__ __forceinline__ void point_backsub_block(int64_t block, int64_t strid
       // Branch-free: an observation of a constant pose (yr < 0) reads y[0..5] and multiplies by zero instead of skipping, so that the row
       // lookup and the record (whose address does not depend on it) are requested together: one exposed latency less per observation.
       // 16-byte loads: z_off() is even, and a pose's rows start at an even row of the tile grid.
-      if (MF) {
-        // matrix-free: sum_obs Z^T y = C^-1 sum_obs rho' Jl^T (Jp y): the Jacobians are formed again from the observation, nothing is read of Z
-        const double X[3] = {points[3 * l], points[3 * l + 1], points[3 * l + 2]};
-        for (uint32_t a = rp.point_ptr[l] + g; a < end; a += G) {
-          const int32_t yr = rp.yrow[a];
-          if (yr < 0) continue;
-          const uint32_t p = rp.pose[a];
-          const double2 px = rp.pixel[a];
-          PoseCache cache;
-          {
-            const double* soa = reinterpret_cast<const double*>(mf.pc + b.P + 1) + p;
-            double* f = reinterpret_cast<double*>(&cache);
-#pragma unroll
-            for (int k = 0; k < 21; ++k) f[k] = soa[k * b.P];
-          }
-          const double2* y2 = reinterpret_cast<const double2*>(rd.y + yr);
-          double y[6];
-#pragma unroll
-          for (int x = 0; x < 3; ++x) { const double2 v = y2[x]; y[2 * x] = v.x; y[2 * x + 1] = v.y; }
-          double r[2], Jp[12], Jl[6], rho0, w;
-          reproj_eval<true>(cache, mf.cams[rp.cam[a]], X, px.x, px.y, rp.sigma[a], r, Jp, Jl);
-          huber_eval(r[0] * r[0] + r[1] * r[1], rp.huber, &rho0, &w);
-          double q0 = 0.0, q1 = 0.0;
-#pragma unroll
-          for (int x = 0; x < 6; ++x) { q0 += Jp[x] * y[x]; q1 += Jp[6 + x] * y[x]; }
-          q0 *= w; q1 *= w;
-          t0 -= Jl[0] * q0 + Jl[3] * q1; t1 -= Jl[1] * q0 + Jl[4] * q1; t2 -= Jl[2] * q0 + Jl[5] * q1;
-        }
-      } else
       for (uint32_t a = rp.point_ptr[l] + g; a < end; a += G) {
         const int32_t yr = rp.yrow[a];   // one lookup instead of active -> pose -> variable id -> row
         const double2* Z2 = reinterpret_cast<const double2*>(pt.Z + z_off(a, l));
@@ -1361,9 +1281,8 @@ __device__ __forceinline__ void point_backsub_block(int64_t block, int64_t strid
         else { t0 += __shfl_xor(t0, m); t1 += __shfl_xor(t1, m); t2 += __shfl_xor(t2, m); }
       }
       if (g == 0) {
-        const double* Ci = pt.Ci + 6 * l;
-        if (MF) { const double s0 = t0, s1 = t1, s2 = t2; t0 = Ci[0] * s0; t1 = Ci[1] * s0 + Ci[2] * s1; t2 = Ci[3] * s0 + Ci[4] * s1 + Ci[5] * s2; }   // C^-1 (sum)
         t0 += pt.u[3 * l]; t1 += pt.u[3 * l + 1]; t2 += pt.u[3 * l + 2];
+        const double* Ci = pt.Ci + 6 * l;
         // y_l = Ci^T t ; delta = -y_l
         const double d0 = -(Ci[0] * t0 + Ci[1] * t1 + Ci[3] * t2), d1 = -(Ci[2] * t1 + Ci[4] * t2), d2 = -(Ci[5] * t2);
         if (!isfinite(d0) || !isfinite(d1) || !isfinite(d2)) bad = 1.0;
@@ -1423,11 +1342,11 @@ __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const Bl
 }
 
 // K6 + K9 in one launch (both only read y): workgroups [0, n_point_blocks) back-substitute the features, the rest form the candidate poses / objects
-template <int G, bool MF = false>
+template <int G>
 __global__ void __launch_bounds__(kBlock) k_backsub_apply(BlocksDev b, ReprojDev rp, PointDev pt, ReducedDev rd, const double* __restrict__ points, double* __restrict__ points_cand,
                                                          const double* __restrict__ poses, const double* __restrict__ objects, double* __restrict__ poses_cand,
-                                                         double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, int n_point_blocks, double* scal, BacksubMfArgs mf) {
-  if ((int)blockIdx.x < n_point_blocks) point_backsub_block<G, MF>(blockIdx.x, n_point_blocks, b, rp, pt, rd, points, points_cand, scal, mf);
+                                                         double* __restrict__ objects_cand, PoseCache* __restrict__ pc_cand, int n_point_blocks, double* scal) {
+  if ((int)blockIdx.x < n_point_blocks) point_backsub_block<G>(blockIdx.x, n_point_blocks, b, rp, pt, rd, points, points_cand, scal);
   else apply_reduced_step_block((int64_t)blockIdx.x - n_point_blocks, b, rd, poses, objects, poses_cand, objects_cand, pc_cand, scal);
 }
 
@@ -1757,9 +1676,7 @@ void launch_point_pass(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, c
                        const ReducedDev& rd, const PointDev& pt, double radius, int first_iter, double* scal, const uint32_t* wave_obs, int64_t n_waves,
                        const uint32_t* long_points, int64_t n_long) {
   if (n_waves > 0) {
-    const char* mfenv = getenv("OBVI_SCHUR_MF");   // experiment: 2 = no Z storage at all (strips and back-substitution matrix-free)
-    const int no_z = (mfenv && atoi(mfenv) == 2) ? 2 : 0;
-    hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter | no_z, scal, wave_obs, n_waves);
+    hipLaunchKernelGGL(k_point_pass, dim3(grid_for(n_waves, kBlock / 64)), dim3(kBlock), 0, s, b, rp, cams, pc, points, rd, pt, radius, first_iter, scal, wave_obs, n_waves);
     if (b.deterministic) launch_det_reduce(s, scal, grid_for(n_waves, kBlock / 64), OBVI_SC(SC_COST) | OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
   }
   if (n_long > 0) {
@@ -1822,21 +1739,11 @@ void launch_schur_window(hipStream_t s, int64_t nwg, int has_twins, const Blocks
                          const int32_t* wg_f0, const int32_t* wg_group) {
   if (nwg <= 0) return;
   const uint4* v = reinterpret_cast<const uint4*>(visits);
-  if (has_twins) hipLaunchKernelGGL((k_schur_window<true, false>), dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group, SchurMfArgs{});
-  else hipLaunchKernelGGL((k_schur_window<false, false>), dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group, SchurMfArgs{});
-}
-void launch_schur_window_mf(hipStream_t s, int64_t nwg, int has_twins, const BlocksDev& b, const ReprojDev& rp, const DevCam* cams, const PoseCache* pc, const double* points,
-                            const PointDev& pt, const ReducedDev& rd, const int32_t* row_of_nat, const uint32_t* wg_bptr, const uint32_t* bfirst, const uint32_t* bslot,
-                            const uint32_t* visits, const uint32_t* slot_obs, const int32_t* wg_f0, const int32_t* wg_group) {
-  if (nwg <= 0) return;
-  const uint4* v = reinterpret_cast<const uint4*>(visits);
-  const SchurMfArgs mf{rp, cams, pc, points};
-  if (has_twins) hipLaunchKernelGGL((k_schur_window<true, true>), dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_obs, wg_f0, wg_group, mf);
-  else hipLaunchKernelGGL((k_schur_window<false, true>), dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_obs, wg_f0, wg_group, mf);
+  if (has_twins) hipLaunchKernelGGL(k_schur_window<true>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
+  else hipLaunchKernelGGL(k_schur_window<false>, dim3((unsigned)nwg), dim3(64 * kSWv), 0, s, b, pt, rd, row_of_nat, wg_bptr, bfirst, bslot, v, slot_src, wg_f0, wg_group);
 }
 void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, const PointDev& pt, const ReducedDev& rd, const double* points,
-                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal,
-                          const DevCam* mf_cams, const PoseCache* mf_pc) {
+                          double* points_cand, const double* poses, const double* objects, double* poses_cand, double* objects_cand, PoseCache* pc_cand, double* scal) {
   // lanes per feature: enough that the features' sightings spread over the chip, no more than a feature has sightings to hand out.
   // Measured on 300 k features x 10 sightings (us): 1 lane 169, 2 133, 4 120, 8 116, 16 146, 32 156 -- past 8 the wavefronts' record lines
   // push each other out of the 32 KB vector cache between the nine loads of a record.
@@ -1848,15 +1755,7 @@ void launch_backsub_apply(hipStream_t s, const BlocksDev& b, const ReprojDev& rp
   const int n_point_blocks = (int)std::min<int64_t>(grid_for(b.L * G, kBlock), 2048);   // 8 per CU, each walks its share (flat between 512 and 2048)
   const unsigned grid = (unsigned)n_point_blocks + grid_for(b.P + b.O, kBlock);
   if (grid == 0) return;
-  const char* mfenv = getenv("OBVI_SCHUR_MF");
-  if (mfenv && atoi(mfenv) == 2 && mf_cams != nullptr) {   // experiment: matrix-free back-substitution
-    const BacksubMfArgs mf{mf_cams, mf_pc};
-#define OBVI_BACKSUB_MF(GG) hipLaunchKernelGGL((k_backsub_apply<GG, true>), dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal, mf)
-    switch (G) { case 8: OBVI_BACKSUB_MF(8); break; case 4: OBVI_BACKSUB_MF(4); break; case 2: OBVI_BACKSUB_MF(2); break; default: OBVI_BACKSUB_MF(1); }
-#undef OBVI_BACKSUB_MF
-    return;
-  }
-#define OBVI_BACKSUB(GG) hipLaunchKernelGGL((k_backsub_apply<GG, false>), dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal, BacksubMfArgs{})
+#define OBVI_BACKSUB(GG) hipLaunchKernelGGL(k_backsub_apply<GG>, dim3(grid), dim3(kBlock), 0, s, b, rp, pt, rd, points, points_cand, poses, objects, poses_cand, objects_cand, pc_cand, n_point_blocks, scal)
   switch (G) { case 32: OBVI_BACKSUB(32); break; case 16: OBVI_BACKSUB(16); break; case 8: OBVI_BACKSUB(8); break; case 4: OBVI_BACKSUB(4); break; case 2: OBVI_BACKSUB(2); break; default: OBVI_BACKSUB(1); }
 #undef OBVI_BACKSUB
   if (b.deterministic) launch_det_reduce(s, scal, grid, OBVI_SC(SC_STEPSQ) | OBVI_SC(SC_MODEL_CHANGE), b.deterministic);

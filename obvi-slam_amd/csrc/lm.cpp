@@ -73,9 +73,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
   };
   auto main_schur_window = [&] {
     record(h, PH_SCHUR);
-    if (solve && schur_matrix_free() && h->d_slot_obs.get() != nullptr)
-      launch_schur_window_mf(s, h->nchunks, h->schur_twins, b, rp, h->d_cams.get(), h->d_pc.get(), h->d_point.get(), pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_obs.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
-    else if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
+    if (solve) launch_schur_window(s, h->nchunks, h->schur_twins, b, pt, rd, h->d_row_of_nat.get(), h->d_chunk_ptr.get(), h->d_batch_first.get(), h->d_batch_slot.get(), h->d_chunk_points.get(), h->d_slot_src.get(), h->d_chunk_f0.get(), h->d_chunk_group.get());
   };
   auto schur_blocks_on = [&](hipStream_t st) {
     launch_schur_blocks(st, h->nblk, h->d_blk_row.get(), h->d_blk_col.get(), h->d_blk_ptr.get(), h->d_pair_a.get(), h->d_pair_b.get(), rp.point, pt, rd);
@@ -129,7 +127,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     h->ck_used = 0;
   }
   record(h, PH_BACKSUB);
-  if (solve) launch_backsub_apply(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), h->d_pc_c.get(), scal, h->d_cams.get(), h->d_pc.get());
+  if (solve) launch_backsub_apply(s, b, rp, pt, rd, h->d_point.get(), h->d_point_c.get(), h->d_pose.get(), h->d_obj.get(), h->d_pose_c.get(), h->d_obj_c.get(), h->d_pc_c.get(), scal);
   record(h, PH_APPLY);   // (the candidate poses / objects are formed in the same launch)
   record(h, PH_COST);
   if (solve) launch_cost(s, b, reproj_pose_dev(h), sf, h->d_cams.get(), h->d_pc.get(), h->d_pose.get(), h->d_point.get(), h->d_obj.get(), h->d_pc_c.get(),

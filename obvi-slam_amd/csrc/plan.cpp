@@ -898,10 +898,8 @@ struct PlanBuilder {
       for (int64_t pz = 0; pz < P; ++pz) if (pose_vid[pz] >= 0) frame_of_pose[pz] = nat[pz];
       h->d_plan_frame.upload(frame_of_pose, s); h->d_plan_visits.upload(plan_visits, s); h->d_plan_wg_ptr.upload(plan_wg_ptr, s); h->d_plan_wg_slot0.upload(plan_wg_slot0, s);
       h->d_chunk_points.resize(4 * plan_visits.size() + 4); h->d_slot_src.resize(total_slots + 4);
-      const bool mf = schur_matrix_free();
-      if (mf) h->d_slot_obs.resize(total_slots + 4);
       launch_plan_visit_slots(s, (int64_t)plan_visits.size(), h->d_plan_visits.get(), h->d_plan_wg_ptr.get(), h->d_plan_wg_slot0.get(), (int32_t)plan_wg_ptr.size(), h->d_chunk_f0.get(), h->d_chunk_group.get(),
-                              h->d_point_ptr.get(), h->d_rp_active.get(), h->d_rp_pose.get(), h->d_plan_frame.get(), zero16, h->d_chunk_points.get(), h->d_slot_src.get(), mf ? h->d_slot_obs.get() : nullptr);
+                              h->d_point_ptr.get(), h->d_rp_active.get(), h->d_rp_pose.get(), h->d_plan_frame.get(), zero16, h->d_chunk_points.get(), h->d_slot_src.get());
       // (the kernel's inputs went through the pinned arena, or -- too big for it -- straight from vectors of this function: finish_upload() at its end waits then)
     }
     h->d_row_of_nat.upload(h->h_row_of_nat, s);

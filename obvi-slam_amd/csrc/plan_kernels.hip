@@ -20,7 +20,7 @@ constexpr int W = kSchurWindowFrames, SR = kSchurRows, SBACK = W - SR, kRowTile0
 __global__ void __launch_bounds__(256) k_plan_visit_slots(int64_t nvis, const PlanVisit* __restrict__ pv, const uint32_t* __restrict__ wg_ptr, const uint32_t* __restrict__ wg_slot0, int32_t nwg,
                                                          const int32_t* __restrict__ wg_f0, const int32_t* __restrict__ wg_group, const uint32_t* __restrict__ point_ptr,
                                                          const uint8_t* __restrict__ rp_active, const uint32_t* __restrict__ rp_pose, const int32_t* __restrict__ frame_of_pose,
-                                                         uint32_t zero16, uint32_t* __restrict__ visits, uint32_t* __restrict__ slot_src, uint32_t* __restrict__ slot_obs) {
+                                                         uint32_t zero16, uint32_t* __restrict__ visits, uint32_t* __restrict__ slot_src) {
   const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
   if (t >= nvis) return;
   // the workgroup (slice of a (chunk, group) work list) the visit belongs to: the last g with wg_ptr[g] <= t
@@ -48,9 +48,6 @@ __global__ void __launch_bounds__(256) k_plan_visit_slots(int64_t nvis, const Pl
   uint32_t prim[W], sec[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) prim[i] = sec[i] = zero16;
-  // matrix-free strips (OBVI_SCHUR_MF): a slot names the observation whose Z record the strip kernel forms itself: 9 a + 2 l -> a is recovered as (src - 2 l) / 9
-  const uint32_t l2 = 2u * v.l;
-  auto code_of = [&](uint32_t src) -> uint32_t { return src == zero16 ? 0xffffffffu : (src - l2) / 9u; };
   const uint32_t beg = point_ptr[v.l], end = point_ptr[v.l + 1];
   for (uint32_t a = beg; a < end; ++a) {
     if (!rp_active[a]) continue;
@@ -62,7 +59,6 @@ __global__ void __launch_bounds__(256) k_plan_visit_slots(int64_t nvis, const Pl
     if (prim[fo] == zero16) prim[fo] = src; else sec[fo] = src;
   }
   uint32_t* out = slot_src + (size_t)wg_slot0[g] + v.rel;
-  uint32_t* outc = slot_obs ? slot_obs + (size_t)wg_slot0[g] + v.rel : nullptr;
   const uint32_t tail_src = (uint32_t)((18ull * end + 4ull * v.l) / 2);   // z_tail(): (u_l, 0) behind the point's records
   int32_t slotA0, slotB0;
   uint32_t tail, n = 0;
@@ -84,9 +80,6 @@ __global__ void __launch_bounds__(256) k_plan_visit_slots(int64_t nvis, const Pl
       for (int32_t fo = B0; fo <= B1; ++fo) out[n++] = sec[fo];
     }
   }
-  if (outc) {
-    for (uint32_t i = 0; i < n; ++i) outc[i] = out[i] == tail_src ? (0x80000000u | v.l) : code_of(out[i]);
-  }
   const uint32_t layer = twin ? n / 2 + (merged ? 1u : 0u) : 0u;   // slots from a record to its second-layer twin
   uint32_t* rec = visits + 4 * (size_t)t;
   rec[0] = (uint32_t)(144 * slotA0);
@@ -98,9 +91,9 @@ __global__ void __launch_bounds__(256) k_plan_visit_slots(int64_t nvis, const Pl
 }  // namespace
 
 void launch_plan_visit_slots(hipStream_t s, int64_t nvis, const PlanVisit* pv, const uint32_t* wg_ptr, const uint32_t* wg_slot0, int32_t nwg, const int32_t* wg_f0, const int32_t* wg_group,
-                             const uint32_t* point_ptr, const uint8_t* rp_active, const uint32_t* rp_pose, const int32_t* frame_of_pose, uint32_t zero16, uint32_t* visits, uint32_t* slot_src, uint32_t* slot_obs) {
+                             const uint32_t* point_ptr, const uint8_t* rp_active, const uint32_t* rp_pose, const int32_t* frame_of_pose, uint32_t zero16, uint32_t* visits, uint32_t* slot_src) {
   if (nvis > 0) hipLaunchKernelGGL(k_plan_visit_slots, dim3((unsigned)((nvis + 255) / 256)), dim3(256), 0, s, nvis, pv, wg_ptr, wg_slot0, nwg, wg_f0, wg_group, point_ptr, rp_active, rp_pose,
-                                   frame_of_pose, zero16, visits, slot_src, slot_obs);
+                                   frame_of_pose, zero16, visits, slot_src);
 }
 
 }  // namespace obvi
