@@ -412,15 +412,19 @@ def concurrent_sessions_cpp(synth, device, k=4, frames=300, features=30000, obje
     with tempfile.TemporaryDirectory() as td:
         scene = os.path.join(td, "scene.bin")
         scene_io.write_scene_binary(prob, scene)
-        for n in (1, k):
+        # three runs: one session serial (the mode the k sessions run in), one session in the driver's default mode (next window planned beside the solve: the
+        # best single-session configuration), k sessions.  The speed-up that counts is against the BEST single session.
+        for name, n, ahead in (("sessions_1", 1, "0"), ("sessions_1_planned_ahead", 1, "1"), ("sessions_%d" % k, k, "0")):
             t0 = time.perf_counter()
-            r = subprocess.run([exe, scene, os.path.join(td, "out_%d.json" % n), "--window", "50", "--gba-frequency", "100", "--device", str(device), "--merge-distance", "-1"]
-                               + (["--sessions-in-process", str(n)] if n > 1 else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, OBVI_HOST_PLAN_AHEAD="0"))
+            r = subprocess.run([exe, scene, os.path.join(td, "out_%s.json" % name), "--window", "50", "--gba-frequency", "100", "--device", str(device), "--merge-distance", "-1"]
+                               + (["--sessions-in-process", str(n)] if n > 1 else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, OBVI_HOST_PLAN_AHEAD=ahead))
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": "run_offline_ba failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
-            out["sessions_%d" % n] = {"process_wall_s": round(wall, 3), "frames_per_s": round(n * frames / wall, 1)}
-    out["speedup_vs_one_session"] = round(out["sessions_%d" % k]["frames_per_s"] / out["sessions_1"]["frames_per_s"], 3)
+            out[name] = {"process_wall_s": round(wall, 3), "frames_per_s": round(n * frames / wall, 1)}
+    best_single = max(out["sessions_1"]["frames_per_s"], out["sessions_1_planned_ahead"]["frames_per_s"])
+    out["speedup_vs_one_serial_session"] = round(out["sessions_%d" % k]["frames_per_s"] / out["sessions_1"]["frames_per_s"], 3)
+    out["speedup_vs_best_single_session"] = round(out["sessions_%d" % k]["frames_per_s"] / best_single, 3)
     return out
 
 

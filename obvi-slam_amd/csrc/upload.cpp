@@ -71,7 +71,22 @@ int obvi_ba_update_state(obvi_ba_handle* h, const double* poses, const double* p
   OBVI_HIP(hipSetDevice(h->device));
   if (poses && h->P > 0) h2d_async(h->d_pose.get(), poses, sizeof(double) * 6 * h->P, h->stream);
   if (points && h->L > 0) h2d_async(h->d_point.get(), points, sizeof(double) * 3 * h->L, h->stream);
-  if (objects && h->O > 0) h2d_async(h->d_obj.get(), objects, sizeof(double) * 7 * h->O, h->stream);
+  if (objects && h->O > 0) {
+    h2d_async(h->d_obj.get(), objects, sizeof(double) * 7 * h->O, h->stream);
+    // The order of the shared tail follows the shared objects' (x, y) AS UPLOADED (plan.cpp), and every rank derives it from its own copy: values that arrive
+    // here -- a handle planned ahead with placeholders, obvi_ba_prepare + obvi_ba_update_state -- are "as uploaded" too.  If a shared object moved, the key is
+    // refreshed and the plan rebuilt at the next prepare / solve, so that this rank orders the tail like a rank that got the same values through
+    // obvi_ba_set_objects (such a handle used to keep the placeholder order and was then refused by the order check of the solve).
+    if (!h->h_is_shared.empty() && (int64_t)h->h_obj_xy.size() == 2 * h->O) {
+      bool moved = false;
+      for (int64_t o = 0; o < h->O; ++o) {
+        if (!h->h_is_shared[o]) continue;
+        if (h->h_obj_xy[2 * o] != objects[7 * o] || h->h_obj_xy[2 * o + 1] != objects[7 * o + 1]) moved = true;
+      }
+      if (moved) h->dirty = true;
+    }
+    if ((int64_t)h->h_obj_xy.size() == 2 * h->O) for (int64_t o = 0; o < h->O; ++o) { h->h_obj_xy[2 * o] = objects[7 * o]; h->h_obj_xy[2 * o + 1] = objects[7 * o + 1]; }
+  }
   finish_upload(h);
   h->have_snapshot = false;
   return OBVI_OK;

@@ -436,9 +436,18 @@ class BesideThread {
     { std::lock_guard<std::mutex> lock(m_); job_ = job; state_.store(kPosted, std::memory_order_release); }
     cv_.notify_all();
   }
+  // returns when the job has ended; an exception the job threw is rethrown HERE, on the caller's thread (the same exception would have propagated
+  // on the caller's thread had the work run serially), never std::terminate on the second thread.  Spins briefly, then sleeps: K sessions in one
+  // process on few CPUs must not burn a core each.
   void wait() {
-    while (state_.load(std::memory_order_acquire) != kDone) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (state_.load(std::memory_order_acquire) != kDone) {
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < 200) { std::this_thread::yield(); continue; }
+      std::unique_lock<std::mutex> lock(m_);
+      done_cv_.wait_for(lock, std::chrono::milliseconds(2), [&] { return state_.load(std::memory_order_acquire) == kDone; });
+    }
     state_.store(kIdle, std::memory_order_release);
+    if (error_) { std::exception_ptr e = error_; error_ = nullptr; std::rethrow_exception(e); }
   }
  private:
   enum { kIdle = 0, kPosted = 1, kDone = 2 };
@@ -458,13 +467,15 @@ class BesideThread {
         if (stop_) return;
         job.swap(job_);
       }
-      job();
-      state_.store(kDone, std::memory_order_release);
+      try { job(); } catch (...) { error_ = std::current_exception(); }   // kDone is ALWAYS reached: wait() can never spin on a job that died
+      { std::lock_guard<std::mutex> lock(m_); state_.store(kDone, std::memory_order_release); }
+      done_cv_.notify_all();
     }
   }
   std::thread thread_;
   std::mutex m_;
-  std::condition_variable cv_;
+  std::condition_variable cv_, done_cv_;
+  std::exception_ptr error_;
   std::atomic<int> state_{kIdle};
   std::function<void()> job_;
   bool stop_ = false;

@@ -564,7 +564,7 @@ int main(int argc, char** argv) {
     if (!visual_feature_results_file.empty()) written = writeTextFile(visual_feature_results_file, writeVisualFeatureResultsToString(results.visual_feature_results_)) && written;
     if (!written) { std::cerr << "could not write a results file" << std::endl; return 1; }
   }
-  if (!ltm_out_path.empty() && ok) {   // offline_object_visual_slam_main.cpp:1056-1076
+  if (!ltm_out_path.empty()) {   // offline_object_visual_slam_main.cpp:1056-1076: written whether or not the optimisation succeeded (a failed session of a chain hands the previous map on)
     LongTermObjectMapFile map;
     for (const auto& e : results.long_term_map_) {
       map.ellipsoid_results_[e.object_id_] = {class_of(e.object_id_), e.ellipsoid_mean_};

@@ -134,8 +134,11 @@ def odom_cov(t, aa, m_tt, m_tr, m_rt, m_rr):
 
 
 def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pixel_noise=1.0,
-                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0, stereo=False, object_seed=None):
-    """Returns a dict of flat arrays accepted by upload(); 'gt_*' hold the ground truth."""
+                 point_noise=0.1, with_relpose=True, min_obj_obs=10, object_classes=None, bbox_noise=30.0, stereo=False, object_seed=None, min_parallax_deg=0.0):
+    """Returns a dict of flat arrays accepted by upload(); 'gt_*' hold the ground truth.
+    min_parallax_deg > 0 (the "w" problems, make_well_posed): only features whose rays from the first and the last frame of their track meet at that angle or
+    more are kept -- the camera looks along the direction of travel, so a feature near the optical axis 15 m ahead has no observable depth and LM walks
+    it to infinity at its own pace (the 600-m features of profiles/r05_end_state_config3.txt).  0 = the generator of rounds 1-5, same random stream."""
     rng = np.random.Generator(np.random.MT19937(seed))
     rp = RESIDUAL_PARAMS
     pos, R = _trajectory(P, rng)
@@ -173,6 +176,10 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
         vis = (z > 0.5) & (pix[:, 0] > 2) & (pix[:, 0] < IMG_W - 2) & (pix[:, 1] > 2) & (pix[:, 1] < IMG_H - 2)
         cnt = np.bincount(pi_[vis], minlength=nb)
         keep_pt = cnt >= 5
+        if min_parallax_deg > 0.0:
+            ra, rb = X - pos[first], X - pos[np.minimum(first + run - 1, P - 1)]
+            cosang = (ra * rb).sum(axis=1) / np.maximum(np.linalg.norm(ra, axis=1) * np.linalg.norm(rb, axis=1), 1e-12)
+            keep_pt &= np.degrees(np.arccos(np.clip(cosang, -1.0, 1.0))) >= min_parallax_deg
         keep_pt &= np.cumsum(keep_pt) <= (L - n_have)
         new_id = np.cumsum(keep_pt) - 1 + n_have
         sel = vis & keep_pt[pi_]
@@ -296,6 +303,57 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
         prob.update(rl_a=np.arange(P - 1, dtype=np.uint32), rl_b=np.arange(1, P, dtype=np.uint32),
                     rl_t=odom_t, rl_aa=odom_aa, rl_cov=odom_cov(odom_t, odom_aa, m, m, m, m), rl_huber=rp["relpose_huber"])
     return prob
+
+
+def make_well_posed(prob, min_depth=0.5):
+    """The "w" variant of a problem (round 6, VERDICT r5 item 2: an end state that two fp64 implementations can be held to).  Same structure, same measurements;
+    what changes is the START, the way a SLAM front end would have produced it: a feature / an object is initialised relative to the ESTIMATED pose of the
+    frame it is first anchored to (middle frame of a feature's track, first observing frame of an object) instead of at ground truth in a world frame the
+    drifted trajectory has long left -- so no sighting starts at near-zero or negative depth (`min_depth` metres in front of EVERY observing camera, pushed
+    along the ray of its anchor camera otherwise) -- and the caller uploads the odometry factors of all consecutive frames (upload(relpose=True)) with
+    `const_poses` >= 1 poses constant, which fixes the scale gauge everywhere along the trajectory.  Deterministic: no random draw."""
+    q = dict(prob)
+    P = len(prob["poses"])
+    Rg = Rot.from_rotvec(prob["gt_poses"][:, 3:6]).as_matrix(); tg = prob["gt_poses"][:, :3]
+    Re_ = Rot.from_rotvec(prob["poses"][:, 3:6]).as_matrix(); te = prob["poses"][:, :3]
+    # ---- features: anchor = the middle observation of the track (the observations are sorted by (point, pose))
+    L = len(prob["points"])
+    rp_point, rp_pose = prob["rp_point"].astype(np.int64), prob["rp_pose"].astype(np.int64)
+    ptr = np.searchsorted(rp_point, np.arange(L + 1))
+    has = ptr[1:] > ptr[:-1]
+    mid = np.where(has, rp_pose[np.minimum((ptr[:-1] + ptr[1:]) // 2, len(rp_pose) - 1)], 0)
+    Xg = prob["points"]                                     # ground truth + the generator's noise, in the ground-truth world
+    local = np.einsum("nji,nj->ni", Rg[mid], Xg - tg[mid])  # ... as seen from the anchor's true pose
+    X = np.einsum("nij,nj->ni", Re_[mid], local) + te[mid]  # ... re-attached to the anchor's estimated pose
+    X = np.where(has[:, None], X, Xg)
+    for _ in range(8):                                      # push along the anchor ray until every observing camera sees it >= min_depth ahead
+        _, z = project_points(prob["poses"][rp_pose], X[rp_point], prob["K"][0], prob["ext"][0])
+        zmin = np.full(L, np.inf); np.minimum.at(zmin, rp_point, z)
+        bad = has & (zmin < min_depth)
+        if not bad.any():
+            break
+        ray = X[bad] - te[mid[bad]]
+        X[bad] = X[bad] + ray / np.maximum(np.linalg.norm(ray, axis=1, keepdims=True), 1e-9) * (min_depth - zmin[bad] + 0.25)[:, None]
+    q["points"] = X
+    # ---- objects: anchor = the first observing frame
+    O = len(prob["objects"])
+    if O:
+        first = np.full(O, P, np.int64); np.minimum.at(first, prob["bb_obj"].astype(np.int64), prob["bb_pose"].astype(np.int64))
+        first = np.where(first >= P, 0, first)
+        obj = prob["objects"].copy()
+        c_local = np.einsum("nji,nj->ni", Rg[first], obj[:, :3] - tg[first])
+        obj[:, :3] = np.einsum("nij,nj->ni", Re_[first], c_local) + te[first]
+        # yaw rides along with the heading error of the anchor (rotation about z of R_est R_gt^T)
+        dR = np.einsum("nij,nkj->nik", Re_[first], Rg[first])
+        obj[:, 3] += np.arctan2(dR[:, 1, 0], dR[:, 0, 0])
+        q["objects"] = obj
+    return q
+
+
+def config3w(P=2000, L=300000, O=200, seed=20241008 + 3):
+    """"Config 3w": BASELINE config #3's sizes as a well-posed problem (tests/golden/gen_config3w_end_state.py has the recipe in words).
+    Upload with the odometry factors (upload(relpose=True), the default)."""
+    return make_well_posed(make_problem(P=P, L=L, O=O, seed=seed, const_poses=5, min_obj_obs=10, object_classes=("bench",), min_parallax_deg=3.0))
 
 
 def upload(ba, prob, relpose=True, objects=True, reproj=True):

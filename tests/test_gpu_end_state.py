@@ -98,3 +98,50 @@ def test_with_objects_the_hip_end_state_is_as_close_to_the_arbiter_as_the_fp64_o
         assert c["phase_2"]["final_cost_rel"] <= max(5.0 * ref["phase_2"]["final_cost_rel"], 3e-4), (c["phase_2"], ref["phase_2"])
         for key, spread in (("pose_translation_max_m", 3e-3), ("pose_rotation_max_rad", 1e-4), ("point_median_m", 3e-3)):
             assert c["state_after_phase_2"][key] <= max(5.0 * ref["state_after_phase_2"][key], spread), (key, c["state_after_phase_2"][key], ref["state_after_phase_2"][key])
+
+
+# ---- config 3w: BASELINE config #3's sizes as a well-posed problem, against the committed end state of the oracle (round 6) -----------------------
+def _fixture_3w():
+    path = os.path.join(helpers.ROOT, "tests", "golden", "config3w_end_state.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def config3w_legs():
+    prob = synth.config3w()
+    out = {}
+    for name, make in (("default", lambda: helpers.product_ba()), ("deterministic", lambda: helpers.product_ba(deterministic=True))):
+        ba = make()
+        out[name] = end_state.run_two_phase(ba, prob, obvi_ba, synth, block=end_state.GLOBAL_BA, polish_iterations=int(_fixture_3w()["polish_iterations"]))
+        ba.close()
+    return prob, out
+
+
+@pytest.mark.parametrize("leg", ["default", "deterministic"])
+def test_config3w_end_state_at_2000_keyframes_equals_the_committed_oracle_run(config3w_legs, leg):
+    """end-state parity DECIDED at the headline size.  Config 3w (tests/golden/gen_config3w_end_state.py: 2 000 keyframes / 300 000
+    features / 200 objects; five constant poses + odometry factors, features with >= 3 degrees of parallax, every start value in front of its cameras,
+    ellipsoids with distinct horizontal axes) through the reference's two-phase global-BA block: both HIP modes exclude the oracle's factors, take its LM
+    sequence and land on its end state at BASELINE.md 2.4 (iii)'s bar -- final cost 1e-6 relative, poses 1e-6 m / 1e-6 rad -- where the reference's
+    tolerances stop the run AND 20 iterations further down."""
+    import hashlib
+    prob, legs = config3w_legs
+    fx, r = _fixture_3w(), legs[leg]
+    assert list(fx["stats"]) == [len(prob["poses"]), len(prob["points"]), len(prob["objects"]), len(prob["rp_pose"]), len(prob["bb_obj"])]   # the same problem
+    for t in (0, 2):
+        m = np.asarray(r["excluded"][t], np.uint8)
+        assert int((m == 0).sum()) == int(fx["excluded_%d_count" % t])
+        assert hashlib.sha256(m.tobytes()).hexdigest() == str(fx["excluded_%d_sha256" % t]), "another set of excluded factors (type %d)" % t
+    for ph in ("phase_1", "phase_2", "polish"):
+        assert r[ph]["iterations"] == int(fx[ph + "_iterations"]) and list(np.array(r[ph]["accepted"], np.uint8)) == list(fx[ph + "_accepted"]), ph
+        rel = abs(r[ph]["final_cost"] - float(fx[ph + "_final_cost"])) / float(fx[ph + "_final_cost"])
+        print(leg, ph, "iterations", r[ph]["iterations"], "final cost rel", rel)
+        assert rel < 1e-6, (ph, rel)
+    for st in ("state_2", "state_polished"):
+        dp = np.abs(r[st]["poses"][:, :3] - fx[st + "_poses"][:, :3]).max()
+        dr = float(end_state.rotation_angle_between(r[st]["poses"][:, 3:6], fx[st + "_poses"][:, 3:6]).max())
+        dx = np.abs(r[st]["points"][::100] - fx[st + "_points_every_100th"]).max(axis=1)
+        do = np.abs(r[st]["objects"] - fx[st + "_objects"])
+        print(leg, st, "poses %.2e m %.2e rad | features median %.2e max %.2e m | objects centre %.2e m dims %.2e m yaw %.2e rad" % (dp, dr, np.median(dx), dx.max(), do[:, :3].max(), do[:, 4:].max(), do[:, 3].max()))
+        assert dp < 1e-6 and dr < 1e-6, (st, dp, dr)
+        assert np.median(dx) < 1e-6 and np.median(do[:, :3].max(axis=1)) < 1e-6

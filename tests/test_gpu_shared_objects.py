@@ -156,6 +156,42 @@ def test_ranks_that_upload_the_shared_objects_differently_are_refused(scene):
     assert emu.calls == 1                                               # the solve stopped at its first collective, on both ranks
 
 
+def test_a_rank_planned_ahead_with_placeholder_objects_orders_the_tail_like_the_others(scene):
+    """a handle uploaded with PLACEHOLDER object values and planned ahead (obvi_ba_prepare) used to keep the tail order of the placeholders
+    after obvi_ba_update_state had delivered the real values, and was then refused by the order check of the solve.  The values that arrive through
+    update_state count as uploaded: the key is refreshed, the plan rebuilt, and the rank solves with the others -- the same joint solution as two
+    ranks uploaded normally."""
+    wins, joint, keep_pts = split_problem(scene, 30)
+    prm = helpers.ba_params(max_it=8)
+    emu0 = EmulatedAllReduce(2)
+    ref_handles, ref_out = run_windows(wins, prm, [emu0.hook(0), emu0.hook(1)])
+    emu = EmulatedAllReduce(2)
+    handles, out = [], [None, None]
+    for rank, (q, pts, rng) in enumerate(wins):
+        ba = helpers.product_ba()
+        if rank == 1:
+            ph = dict(q); ph["objects"] = np.zeros_like(q["objects"]); ph["objects"][:, 4:] = 1.0; ph["poses"] = np.zeros_like(q["poses"]); ph["points"] = np.ones_like(q["points"])
+            synth.upload(ba, ph)
+            ba.set_shared_objects(np.ones(len(q["objects"]), np.uint8), rank, 2)
+            ba.prepare()
+            ba.update_state(q["poses"], q["points"], q["objects"])
+        else:
+            synth.upload(ba, q)
+            ba.set_shared_objects(np.ones(len(q["objects"]), np.uint8), rank, 2)
+        ba.set_allreduce(emu.hook(rank))
+        handles.append(ba)
+
+    def run(rank):
+        out[rank] = handles[rank].solve(prm)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert all(o is not None for o in out)
+    for rank in range(2):
+        assert out[rank].num_iterations == ref_out[rank].num_iterations
+        assert abs(out[rank].final_cost - ref_out[rank].final_cost) <= 1e-9 * ref_out[rank].final_cost
+        assert np.abs(handles[rank].get_objects() - ref_handles[rank].get_objects()).max() < 1e-8
+
+
 def config4_windows(world, P=500, L=50000, O=25):
     """BASELINE configs[3] as bench.py builds it: `world` local-BA windows over the same place (own seed each) sharing one object
     set; object-only factors of a shared object are uploaded by rank 0 only."""
