@@ -87,7 +87,10 @@ enum {
 
 typedef struct {
   int32_t device_id;             /* HIP device ordinal (LOCAL_RANK for one-process-per-GPU) */
-  int32_t object_block_size;     /* 7 = yaw-only ellipsoid (the only variant the reference compiles) */
+  int32_t object_block_size;     /* parameters of an ellipsoid block, called `od` below.  0 or 7: (x y z yaw dx dy dz), the reference's build
+                                  * (CONSTRAIN_ELLIPSOID_ORIENTATION, CMakeLists.txt:8-15).  9: (x y z ax ay az dx dy dz), the unconstrained block of
+                                  * vslam_obj_opt_types_refactor.h:15-21 / ellipsoid_utils.h:217-229 (`#else`), rotation VectorToAxisAngle(ax ay az).  Every
+                                  * "[7]" / "[49]" of an object in this header reads [od] / [od*od] on a handle created with 9. */
   int32_t reprojection_variant;  /* OBVI_REPROJECTION_* (0 = the production functor) */
   int32_t deterministic;         /* != 0: every cross-workgroup accumulation of a solve runs in a fixed order (no floating-point atomics whose
                                     order can change between runs): two solves of the same problem are bit-identical, as Ceres is at a fixed
@@ -171,7 +174,7 @@ int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* pose6 /*[n][6]
                       const uint8_t* is_const /*[n] or NULL = all variable*/);
 int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* xyz /*[n][3]*/,
                        const uint8_t* is_const);
-int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* ell7 /*[n][7]*/,
+int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* ell7 /*[n][od]*/,
                         const uint8_t* is_const);
 /* change constness without re-uploading values (window slide / PGO stage) */
 int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pose_const, const uint8_t* point_const,
@@ -194,7 +197,7 @@ int obvi_ba_set_shape_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_i
 /* LTM prior -> IndependentObjectMapFactor (independent_object_map_factor.h:21-33, .cpp:7-11;
  * long_term_map_factor_creator.h:265-322). */
 int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx,
-                           const double* mean7, const double* cov49, double huber);
+                           const double* mean7 /*[n][od]*/, const double* cov49 /*[n][od*od]*/, double huber);
 /* RelPoseFactor -> RelativePoseFactor (relative_pose_factor.h:32-61, .cpp:7-19); measured
  * relative pose given as translation + axis-angle vector of Pose3D::orientation_. */
 int obvi_ba_set_relpose(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx_a,
@@ -234,7 +237,7 @@ int obvi_ba_select_outliers(obvi_ba_handle* h, int32_t factor_type, double fract
  * A rank-deficient problem (free gauge, unobserved feature) fails with OBVI_ERR_NUMERICAL, as Covariance::Compute
  * fails on it.  Computed on the device from the tile Cholesky factor of the undamped reduced system. */
 int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_t* obj_a, const uint32_t* obj_b,
-                               double* cov49 /*[n_pairs][49]*/);
+                               double* cov49 /*[n_pairs][od*od]*/);
 
 /* ParameterPrior (include/refactoring/factors/parameter_prior.h:17-50): residual (block[param_idx] - mean) / std_dev, no loss
  * function.  The reference adds such factors in one place only -- to the problem the long-term-map covariance is extracted from,
@@ -247,17 +250,17 @@ int obvi_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* bl
 /* Squared column norms of the robustified Jacobian at the current estimate, one per scalar parameter (what findRankDeficiencies
  * accumulates from the CRS Jacobian, long_term_object_map_extraction.cpp:585-608; parameter priors included); -1 for the parameters
  * of a block that is constant or touched by no active factor.  Any output may be NULL. */
-int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6 /*[P][6]*/, double* point3 /*[L][3]*/, double* object7 /*[O][7]*/);
+int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6 /*[P][6]*/, double* point3 /*[L][3]*/, double* object7 /*[O][od]*/);
 
 /* ---- state ------------------------------------------------------------------------- */
 int obvi_ba_snapshot(obvi_ba_handle* h);
 int obvi_ba_restore(obvi_ba_handle* h);
 int obvi_ba_get_poses(obvi_ba_handle* h, double* out /*[n][6]*/);
 int obvi_ba_get_points(obvi_ba_handle* h, double* out /*[n][3]*/);
-int obvi_ba_get_objects(obvi_ba_handle* h, double* out /*[n][7]*/);
+int obvi_ba_get_objects(obvi_ba_handle* h, double* out /*[n][od]*/);
 /* all three at once (a null pointer skips one): what the reference reads in place after Solve() -- Ceres has updated the pose graph's
  * parameter blocks (object_pose_graph_optimizer.h:664-667) -- with one wait for the device instead of three */
-int obvi_ba_get_state(obvi_ba_handle* h, double* poses /*[n][6]*/, double* points /*[n][3]*/, double* objects /*[n][7]*/);
+int obvi_ba_get_state(obvi_ba_handle* h, double* poses /*[n][6]*/, double* points /*[n][3]*/, double* objects /*[n][od]*/);
 /* overwrite values only (feature re-attachment after PGO,
  * pose_graph_plus_objects_optimizer.h:238-283) */
 int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
@@ -265,7 +268,7 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz);
  * symbolic plan stay.  With obvi_ba_prepare this lets a caller upload and plan a window AHEAD, on a second handle and a second host
  * thread, while the previous window is still being solved, and hand over the values once they exist (the start values of a window are
  * the previous window's result: offline_problem_runner.h:183-229).  A snapshot taken before is dropped. */
-int obvi_ba_update_state(obvi_ba_handle* h, const double* poses /*[n][6]*/, const double* points /*[n][3]*/, const double* objects /*[n][7]*/);
+int obvi_ba_update_state(obvi_ba_handle* h, const double* poses /*[n][6]*/, const double* points /*[n][3]*/, const double* objects /*[n][od]*/);
 /* the symbolic phase of what has been uploaded (elimination order, Schur work lists, tile plan), now instead of inside the first
  * obvi_ba_solve / obvi_ba_evaluate: structure only, reads no parameter value (exception: the order of SHARED objects follows the (x, y)
  * given to obvi_ba_set_objects).  Returns when the plan is on the device. */
@@ -278,7 +281,7 @@ int obvi_ba_prepare(obvi_ba_handle* h);
  * LM step the library calls `fn` three times on the handle's stream (and once at the start of a solve, op SUM on 2 doubles: the job's fixed cost and a hash of this
  * rank's order of the shared objects -- the shared tail follows the objects' UPLOADED positions, so a rank whose shared objects carry other values is refused with
  * OBVI_ERR_INVALID_ARGUMENT instead of having its tiles summed against the wrong objects):
- *   (1) op SUM  on the packed J^T J diagonal blocks and gradients of the shared objects   (n_shared * 56 doubles)
+ *   (1) op SUM  on the packed J^T J diagonal blocks and gradients of the shared objects   (n_shared * (od*od + od) doubles: 56 each, 90 with the 9-parameter block)
  *   (2) op SUM  on the trailing shared-object tiles of the reduced system + right-hand side, after the rank's own
  *               poses / points / private objects have been eliminated
  *   (3) op SUM  on the scalar block (costs, model change, step and gradient norms) followed by one slot per rank that carries
@@ -295,8 +298,8 @@ int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared /*[n 
 /* raw (un-robustified) residual and Jacobians of every factor of one type at the current
  * estimate, row-major: J0 w.r.t. the first block of the factor, J1 the second
  *   type 0: r[n][2], J0 = d/dpose [n][2][6], J1 = d/dpoint  [n][2][3]
- *   type 2: r[n][4], J0 = d/dobject [n][4][7], J1 = d/dpose [n][4][6]
- *   type 3: r[n][3], J0 [n][3][7]          type 4: r[n][7], J0 [n][7][7]
+ *   type 2: r[n][4], J0 = d/dobject [n][4][od], J1 = d/dpose [n][4][6]
+ *   type 3: r[n][3], J0 [n][3][od]         type 4: r[n][od], J0 [n][od][od]
  *   type 5: r[n][6], J0 = d/dpose_a [n][6][6], J1 = d/dpose_b [n][6][6]  */
 int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t factor_type, double* r, double* J0, double* J1);
 /* the selection rule of obvi_ba_select_outliers (offline_problem_runner.h:769-800) on block norms given by the caller: mask_out[i] = 0

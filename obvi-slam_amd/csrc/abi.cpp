@@ -20,7 +20,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
   ApiTimer api_timer_(__func__);
   *out = nullptr;
-  if (options && options->object_block_size != 0 && options->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  if (options && options->object_block_size != 0 && options->object_block_size != 7 && options->object_block_size != 9) return OBVI_ERR_INVALID_ARGUMENT;   // 7: yaw only (the reference's build); 9: axis-angle
   if (options && options->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && options->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
   // OBVI_DEBUG_CREATE: where the time of a create goes, on stderr (the first one of a process also starts the HIP runtime)
   const bool create_times = std::getenv("OBVI_DEBUG_CREATE") != nullptr;
@@ -39,7 +39,7 @@ int obvi_ba_create(const obvi_ba_options* options, obvi_ba_handle** out) {
   obvi_ba_handle* h = new (std::nothrow) obvi_ba_handle();
   if (!h) return OBVI_ERR_HIP;
   h->device = dev;
-  if (options) { h->reproj_variant = options->reprojection_variant; h->deterministic = options->deterministic != 0; }
+  if (options) { h->reproj_variant = options->reprojection_variant; h->deterministic = options->deterministic != 0; if (options->object_block_size == 9) h->od = 9; }
   if (const char* env = std::getenv("OBVI_FUSED_POTRF")) h->fused_potrf = std::atoi(env) != 0;   // 0: two launches per level from the start (CI parity run)
   if (const char* env = std::getenv("OBVI_DETERMINISTIC")) { if (std::atoi(env) != 0) h->deterministic = true; }   // every handle of the process (a session driven through a host that does not set the option)
   try {
@@ -185,9 +185,9 @@ int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t type, double* r, double* 
   int m, d0, d1; int64_t n;
   switch (type) {
     case OBVI_FACTOR_REPROJECTION: m = 2; d0 = 6; d1 = 3; n = h->n_rp; break;
-    case OBVI_FACTOR_BBOX: m = 4; d0 = 7; d1 = 6; n = h->n_bb; break;
-    case OBVI_FACTOR_SHAPE_PRIOR: m = 3; d0 = 7; d1 = 0; n = h->n_sp; break;
-    case OBVI_FACTOR_LTM_PRIOR: m = 7; d0 = 7; d1 = 0; n = h->n_lt; break;
+    case OBVI_FACTOR_BBOX: m = 4; d0 = h->od; d1 = 6; n = h->n_bb; break;
+    case OBVI_FACTOR_SHAPE_PRIOR: m = 3; d0 = h->od; d1 = 0; n = h->n_sp; break;
+    case OBVI_FACTOR_LTM_PRIOR: m = h->od; d0 = h->od; d1 = 0; n = h->n_lt; break;
     case OBVI_FACTOR_REL_POSE: m = 6; d0 = 6; d1 = 6; n = h->n_rl; break;
     default: return fail(h, OBVI_ERR_INVALID_ARGUMENT, "debug_linearize: unknown factor type");
   }
@@ -258,7 +258,8 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   OBVI_HIP(hipSetDevice(h->device));
   { const int vrc = validate_indices(h); if (vrc != OBVI_OK) return vrc; }
   prepare(h);
-  std::fill(cov49, cov49 + 49 * n_pairs, 0.0);
+  const int od = h->od, od2 = od * od;
+  std::fill(cov49, cov49 + od2 * n_pairs, 0.0);
   if (n_pairs == 0 || h->nOv == 0 || h->m == 0) return OBVI_OK;
   if (h->allreduce != nullptr && !h->h_shared_ov.empty()) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "object_covariances: not available with objects shared across ranks");
   // the undamped reduced system S = J_c^T J_c - (Schur complement of the features) at the current point, factorised: one
@@ -273,30 +274,30 @@ int obvi_ba_object_covariances(obvi_ba_handle* h, int64_t n_pairs, const uint32_
   if (h->h_scal[SC_CHOL_FAIL] != 0.0 || h->h_scal[SC_NONFINITE] != 0.0 || !std::isfinite(h->h_scal[SC_STEPSQ]))
     return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: the normal equations are rank deficient at the current estimate");
   hipStream_t s = h->stream;
-  const int nslabs = (int)((7 * h->nOv + kTile - 1) / kTile);
+  const int nslabs = (int)((od * h->nOv + kTile - 1) / kTile);
   const int64_t ldt = (int64_t)h->nt * kTile, nrhs = (int64_t)nslabs * kTile;   // Y = L^-1 E transposed: [nrhs][ldt]
   std::vector<int32_t> slab_first(nslabs, h->nt);
   for (int64_t w = 0; w < h->nOv; ++w) {
-    const int sl0 = (int)(7 * w / kTile), sl1 = (int)((7 * w + 6) / kTile);
+    const int sl0 = (int)(od * w / kTile), sl1 = (int)((od * w + od - 1) / kTile);
     for (int sl = sl0; sl <= sl1; ++sl) slab_first[sl] = std::min(slab_first[sl], h->h_obj_row[w] / kTile);
   }
   std::vector<int32_t> cols(2 * n_pairs), first_row(n_pairs);
   for (int64_t i = 0; i < n_pairs; ++i) {
     const int32_t va = h->h_obj_vid[obj_a[i]], vb = h->h_obj_vid[obj_b[i]];
-    cols[2 * i] = va >= 0 && vb >= 0 ? 7 * va : -1; cols[2 * i + 1] = va >= 0 && vb >= 0 ? 7 * vb : -1;
+    cols[2 * i] = va >= 0 && vb >= 0 ? od * va : -1; cols[2 * i + 1] = va >= 0 && vb >= 0 ? od * vb : -1;
     first_row[i] = va >= 0 && vb >= 0 ? std::max(h->h_obj_row[va], h->h_obj_row[vb]) / kTile * kTile : 0;   // both columns are zero above
   }
   h->d_cov_Y.resize((size_t)(nrhs * ldt));
   OBVI_HIP(hipMemsetAsync(h->d_cov_Y.get(), 0, sizeof(double) * (size_t)(nrhs * ldt), s));
   h->d_cov_slab.upload(slab_first, s); h->d_cov_cols.upload(cols, s); h->d_cov_first.upload(first_row, s);
-  h->d_cov_out.resize((size_t)(49 * n_pairs));
+  h->d_cov_out.resize((size_t)(od2 * n_pairs));
   const CholPlan plan = chol_plan(h);
-  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldt, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv, h->h_row_split.data());
-  launch_cov_pairs(s, h->d_cov_Y.get(), ldt, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get());
+  launch_forward_multi(s, plan, h->d_S.get(), h->d_Linv.get(), h->d_cov_Y.get(), ldt, nslabs, h->d_cov_slab.get(), h->d_obj_row.get(), (int32_t)h->nOv, h->h_row_split.data(), od);
+  launch_cov_pairs(s, h->d_cov_Y.get(), ldt, n_pairs, h->d_cov_cols.get(), h->d_cov_first.get(), h->d_cov_out.get(), od);
   OBVI_HIP(hipGetLastError());
-  h->d_cov_out.download(cov49, (size_t)(49 * n_pairs), s);
+  h->d_cov_out.download(cov49, (size_t)(od2 * n_pairs), s);
   sync(h);
-  for (int64_t i = 0; i < 49 * n_pairs; ++i) if (!std::isfinite(cov49[i])) return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: non-finite covariance");
+  for (int64_t i = 0; i < od2 * n_pairs; ++i) if (!std::isfinite(cov49[i])) return fail(h, OBVI_ERR_NUMERICAL, "object_covariances: non-finite covariance");
   return OBVI_OK;
   OBVI_API_END(h)
 }
@@ -306,7 +307,7 @@ int obvi_ba_set_parameter_priors(obvi_ba_handle* h, int64_t n, const uint8_t* ki
   OBVI_API_BEGIN
   for (int64_t i = 0; i < n; ++i) {
     const int64_t cnt = kind[i] == 0 ? h->P : kind[i] == 1 ? h->L : kind[i] == 2 ? h->O : -1;
-    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : 7;
+    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : h->od;
     if (cnt < 0 || param[i] >= dim) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_parameter_priors: unknown block kind or parameter index");
     if ((int64_t)block[i] >= cnt) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_parameter_priors: index out of range");
     if (!(std_dev[i] > 0.0) || !std::isfinite(std_dev[i]) || !std::isfinite(mean[i])) return fail(h, OBVI_ERR_NUMERICAL, "set_parameter_priors: standard deviation must be positive and finite");
@@ -342,13 +343,13 @@ int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6, double* point3, dou
   auto colsq = [](double scale) { const double r = 1.0 / scale - 1.0; return r * r; };
   if (pose6) for (int64_t p = 0; p < h->P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = pose_vid[p] >= 0 ? colsq(sc[6 * (int64_t)pose_vid[p] + k]) : -1.0;
   if (point3) for (int64_t l = 0; l < h->L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = point_var[l] ? colsq(sl[3 * l + k]) : -1.0;
-  if (object7) for (int64_t o = 0; o < h->O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = obj_vid[o] >= 0 ? colsq(sc[6 * h->nPv + 7 * (int64_t)obj_vid[o] + k]) : -1.0;
+  if (object7) for (int64_t o = 0; o < h->O; ++o) for (int k = 0; k < h->od; ++k) object7[h->od * o + k] = obj_vid[o] >= 0 ? colsq(sc[6 * h->nPv + h->od * (int64_t)obj_vid[o] + k]) : -1.0;
   for (size_t i = 0; i < h->h_pp_kind.size(); ++i) {
     const double w = 1.0 / (h->h_pp_std[i] * h->h_pp_std[i]);
     const int64_t b = h->h_pp_block[i];
     if (h->h_pp_kind[i] == 0 && pose6 && pose_vid[b] >= 0) pose6[6 * b + h->h_pp_param[i]] += w;
     else if (h->h_pp_kind[i] == 1 && point3 && point_var[b]) point3[3 * b + h->h_pp_param[i]] += w;
-    else if (h->h_pp_kind[i] == 2 && object7 && obj_vid[b] >= 0) object7[7 * b + h->h_pp_param[i]] += w;
+    else if (h->h_pp_kind[i] == 2 && object7 && obj_vid[b] >= 0) object7[h->od * b + h->h_pp_param[i]] += w;
   }
   return OBVI_OK;
   OBVI_API_END(h)
@@ -470,7 +471,7 @@ static int get_blocks(obvi_ba_handle* h, const DevBuf<double>& d, int64_t n, int
 }
 int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_pose, h->P, 6, out) : OBVI_ERR_INVALID_ARGUMENT; }
 int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_point, h->L, 3, out) : OBVI_ERR_INVALID_ARGUMENT; }
-int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_obj, h->O, 7, out) : OBVI_ERR_INVALID_ARGUMENT; }
+int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_obj, h->O, h->od, out) : OBVI_ERR_INVALID_ARGUMENT; }
 
 int obvi_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* objects) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
@@ -478,7 +479,7 @@ int obvi_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* 
   OBVI_HIP(hipSetDevice(h->device));
   // the three copies land in the handle's pinned arena (a copy into pageable memory blocks, one after the other), ONE wait, then out
   struct Part { double* out; const DevBuf<double>* d; size_t n; void* pinned; } parts[3] = {
-      {poses, &h->d_pose, (size_t)h->P * 6, nullptr}, {points, &h->d_point, (size_t)h->L * 3, nullptr}, {objects, &h->d_obj, (size_t)h->O * 7, nullptr}};
+      {poses, &h->d_pose, (size_t)h->P * 6, nullptr}, {points, &h->d_point, (size_t)h->L * 3, nullptr}, {objects, &h->d_obj, (size_t)h->O * (size_t)h->od, nullptr}};
   for (Part& p : parts) {
     if (!p.out || !p.n) continue;
     p.pinned = h->staging.take(p.n * sizeof(double));

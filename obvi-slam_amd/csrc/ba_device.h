@@ -103,7 +103,7 @@ struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   int64_t nPv, nOv;         // variable+used poses / objects
   int64_t m;                // rows of the tile grid in use (elimination order, nodes padded to tile boundaries)
   const int32_t* pose_row;  // [nPv] reduced pose index -> first row of its 6x6 diagonal block in the tile grid
-  const int32_t* obj_row;   // [nOv] reduced object index -> first row of its 7x7 diagonal block
+  const int32_t* obj_row;   // [nOv] reduced object index -> first row of its od x od diagonal block
   const uint8_t* obj_shared; // [nOv] or NULL: object block is shared across ranks (multi-GPU exchange)
   int32_t shared_owner;     // 1 on the rank that contributes the shared objects' diagonal blocks and scalars
   const int32_t* pose_vid;  // [P]  reduced index or -1
@@ -111,13 +111,15 @@ struct BlocksDev {          // parameter blocks + reduced-program bookkeeping
   const uint8_t* point_var; // [L]
   int32_t analytic_rotation; // the pose caches follow the analytic-Jacobian functor (make_pose_cache, ba_math.h)
   int32_t deterministic;     // obvi_ba_options.deterministic: 0, or the stride of the per-workgroup partial sums behind the scalar block that replace the fp64 atomics
+  int32_t od;                // parameters of an ellipsoid block: 7 (x y z yaw dx dy dz: the reference's build) or 9 (x y z ax ay az dx dy dz; obvi_ba_options.object_block_size)
 };
 
 struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
+  int32_t od;               // parameters of an ellipsoid block (BlocksDev.od)
   // bounding boxes
   int64_t n_bb; const uint32_t* bb_obj; const uint32_t* bb_pose; const uint16_t* bb_cam;
   const double* bb_rect; const double* bb_sqrt_inf; const uint8_t* bb_active; double bb_huber, bb_invalid;
-  double* bb_blk;                                       // [n_bb][62] per-factor diagonal blocks (big problems: k_small_lin_lanes<true> / k_bbox_gather)
+  double* bb_blk;                                       // [n_bb][62] ([81] with the 9-parameter block) per-factor diagonal blocks (big problems: k_small_lin_lanes<true> / k_bbox_gather)
   int32_t bb_pairs_unique;                              // no (object, pose) pair occurs twice: the off-diagonal block of a factor is its own
   const uint32_t* bbo_ptr; const uint32_t* bbo_idx;     // factors by object: [O+1], [n_bb]
   const uint32_t* bbp_ptr; const uint32_t* bbp_idx;     // factors by pose:   [P+1], [n_bb]
@@ -135,8 +137,8 @@ struct SmallFactorsDev {    // N <= ~3e4 each; arrays in caller order
 };
 
 struct ReducedDev {         // accumulators of the reduced system
-  double* Hdiag;            // pose v: 36 doubles at 36 v; object w: 49 doubles at 36 nPv + 49 w (row-major, lower part used)
-  double* g;                // [6 nPv + 7 nOv] gradient J^T r (compact index: pose v at 6v, object w at 6 nPv + 7w)
+  double* Hdiag;            // pose v: 36 doubles at 36 v; object w: od^2 doubles at 36 nPv + od^2 w (row-major, lower part used)
+  double* g;                // [6 nPv + od nOv] gradient J^T r (compact index: pose v at 6v, object w at 6 nPv + od w)
   double* scale;            // same index: Jacobi scaling (fixed at iteration 0)
   double* lam;              // same index: LM damping of the unscaled normal equations
   double* S;                // tile grid
@@ -290,11 +292,11 @@ void launch_cholesky_factor(hipStream_t s, const CholPlan& plan, int level0, int
 void launch_cholesky_backward(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* rhs /* z in, overwritten */, double* y, CholTimers* timers = nullptr);
 
 // covariance blocks: Y = L^-1 E for the unit vectors of every variable object's rows, kept transposed (Yt row-major
-// [64 nslabs][ldt = 64 nt], cleared by the caller), then 7x7 blocks Yt[ca..] Yt[cb..]^T for pairs of row offsets (cols: 2 per
+// [64 nslabs][ldt = 64 nt], cleared by the caller), then od x od blocks Yt[ca..] Yt[cb..]^T for pairs of row offsets (cols: 2 per
 // pair, negative: zero block)
 void launch_forward_multi(hipStream_t s, const CholPlan& plan, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
-                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split /* host [nlevels]: workgroups per row, or null */);
-void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out);
+                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split /* host [nlevels]: workgroups per row, or null */, int od = 7);
+void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out, int od = 7);
 
 }  // namespace obvi
 #endif  // OBVI_BA_DEVICE_H_

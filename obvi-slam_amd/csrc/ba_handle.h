@@ -46,6 +46,7 @@ using namespace obvi_lib;  // NOLINT
 struct obvi_ba_handle {
   int device = 0;
   int reproj_variant = OBVI_REPROJECTION_AUTODIFF;   // obvi_ba_options.reprojection_variant
+  int od = 7;                                        // obvi_ba_options.object_block_size: parameters of an ellipsoid block, 7 (x y z yaw dx dy dz) or 9 (x y z ax ay az dx dy dz)
   bool deterministic = false;                        // obvi_ba_options.deterministic
   int32_t det_stride = 0;                            // ... workgroups each partial-sum slot behind d_scal has room for (ensure_det_slots)
   bool fused_potrf = true;                           // k_update_potrf (updates of level l + potrf of level l + 1 in one grid); switched off for the rest of the handle's life
@@ -152,7 +153,7 @@ struct obvi_ba_handle {
   // subsets of these runs on the same plan (rows of dropped blocks become padding, masked observations contribute zeros)
   std::vector<int32_t> plan_pose_vid, plan_obj_vid;
   std::vector<uint8_t> plan_point_var, plan_is_pad, plan_rp_active, plan_bb_active, plan_sp_active, plan_lt_active, plan_rl_active;
-  int64_t live_rows = 0;                 // 6 (variable poses) + 7 (variable objects) of the current state (== m_canon right after a full plan)
+  int64_t live_rows = 0;                 // 6 (variable poses) + od (variable objects) of the current state (== m_canon right after a full plan)
   int64_t nPv = 0, nOv = 0, nLv = 0, m = 0, m_canon = 0, num_params = 0, num_residuals = 0;
   int32_t nt = 0;
   int64_t nblk = 0, npairs = 0;
@@ -296,6 +297,7 @@ inline BlocksDev blocks_dev(const obvi_ba_handle* h) {
   b.obj_shared = (h->allreduce && !h->h_shared_ov.empty()) ? h->d_obj_shared.get() : nullptr; b.shared_owner = h->rank == 0 ? 1 : 0;
   b.pose_vid = h->d_pose_vid.get(); b.obj_vid = h->d_obj_vid.get(); b.point_var = h->d_point_var.get();
   b.analytic_rotation = h->reproj_variant == OBVI_REPROJECTION_ANALYTIC ? 1 : 0;
+  b.od = h->od;
   b.deterministic = h->deterministic ? h->det_stride : 0;
   return b;
 }
@@ -314,6 +316,7 @@ inline ReprojPoseDev reproj_pose_dev(const obvi_ba_handle* h) {
 }
 inline SmallFactorsDev small_dev(const obvi_ba_handle* h) {
   SmallFactorsDev s;
+  s.od = h->od;
   s.n_bb = h->n_bb; s.bb_obj = h->d_bb_obj.get(); s.bb_pose = h->d_bb_pose.get(); s.bb_cam = h->d_bb_cam.get();
   s.bb_rect = h->d_bb_rect.get(); s.bb_sqrt_inf = h->d_bb_sqrt_inf.get(); s.bb_active = h->d_bb_active.get();
   s.bb_huber = h->bb_huber; s.bb_invalid = h->bb_invalid;
@@ -503,12 +506,12 @@ inline double scal_gmax(const obvi_ba_handle* h) { double v; std::memcpy(&v, &h-
 
 inline void copy_current(obvi_ba_handle* h, DevBuf<double>& dp, DevBuf<double>& dl, DevBuf<double>& dobj) {
   hipStream_t s = h->stream;
-  dp.resize((size_t)6 * h->P + 1); dl.resize((size_t)3 * h->L + 1); dobj.resize((size_t)7 * h->O + 1);
-  launch_copy3(s, dp.get(), h->d_pose.get(), 6 * h->P, dl.get(), h->d_point.get(), 3 * h->L, dobj.get(), h->d_obj.get(), 7 * h->O);
+  dp.resize((size_t)6 * h->P + 1); dl.resize((size_t)3 * h->L + 1); dobj.resize((size_t)h->od * h->O + 1);
+  launch_copy3(s, dp.get(), h->d_pose.get(), 6 * h->P, dl.get(), h->d_point.get(), 3 * h->L, dobj.get(), h->d_obj.get(), h->od * h->O);
 }
 inline void restore_from(obvi_ba_handle* h, const DevBuf<double>& dp, const DevBuf<double>& dl, const DevBuf<double>& dobj) {
   hipStream_t s = h->stream;
-  launch_copy3(s, h->d_pose.get(), dp.get(), 6 * h->P, h->d_point.get(), dl.get(), 3 * h->L, h->d_obj.get(), dobj.get(), 7 * h->O);
+  launch_copy3(s, h->d_pose.get(), dp.get(), 6 * h->P, h->d_point.get(), dl.get(), 3 * h->L, h->d_obj.get(), dobj.get(), h->od * h->O);
   h->pc_valid = false;
 }
 
@@ -530,7 +533,7 @@ inline void upload_parameter_prior_diagonals(obvi_ba_handle* h) {
     const int64_t b = h->h_pp_block[i];
     if (h->h_pp_kind[i] == 0) { if (pose_vid[b] >= 0) ec[6 * (int64_t)pose_vid[b] + h->h_pp_param[i]] += w; }
     else if (h->h_pp_kind[i] == 1) el[3 * b + h->h_pp_param[i]] += w;
-    else if (obj_vid[b] >= 0) ec[6 * h->nPv + 7 * (int64_t)obj_vid[b] + h->h_pp_param[i]] += w;
+    else if (obj_vid[b] >= 0) ec[6 * h->nPv + h->od * (int64_t)obj_vid[b] + h->h_pp_param[i]] += w;
   }
   h->d_extra_c.upload(ec, h->stream); h->d_extra_l.upload(el, h->stream);
   sync(h);

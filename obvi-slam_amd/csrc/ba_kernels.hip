@@ -525,10 +525,11 @@ __device__ __forceinline__ void store_diag_block(double* slot, int d, const doub
     slot[e++] = w * acc;
   }
 }
-constexpr int kSmBlk = 62, kSmSecond = 35;   // scratch slot of a prior / relative-pose factor: first block at 0, second at 35 (the layout of kBbBlk)
+constexpr int kSmBlk = 62, kSmSecond = 35;   // scratch slot of a prior / relative-pose factor: first block at 0 (an object's: 35 entries, 54 for the 9-parameter block), a relative-pose factor's second block at 35
 
 __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
   const int64_t t = block * 64LL + threadIdx.x;
+  const int od = b.od;   // 7, or 9 for the unconstrained ellipsoid block
   double cost = 0.0;
   bool stored = false;
   if (t < sf.n_sp) {
@@ -537,13 +538,13 @@ __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev
       const uint32_t o = sf.sp_obj[i];
       const int32_t ov = b.obj_vid[o];
       if (ov >= 0) {
-        double r[3], J[21];
-        shape_prior_eval(objects + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
+        double r[3], J[27];
+        shape_prior_eval(objects + od * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J, od);
         double rho0, w;
         huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, 7, J, r, 3, w); stored = true; }
-        else add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 3, w);
+        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, od, J, r, 3, w); stored = true; }
+        else add_diag_block(rd.Hdiag + 36 * b.nPv + od * od * (int64_t)ov, rd.g + 6 * b.nPv + od * (int64_t)ov, od, J, r, 3, w);
       }
     }
   } else if (t < sf.n_sp + sf.n_lt) {
@@ -552,21 +553,21 @@ __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev
       const uint32_t o = sf.lt_obj[i];
       const int32_t ov = b.obj_vid[o];
       if (ov >= 0) {
-        double r[7], J[49];
-        ltm_prior_eval(objects + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
+        double r[9], J[81];
+        ltm_prior_eval(objects + od * (int64_t)o, sf.lt_mean + od * i, sf.lt_sqrt_inf + od * od * i, r, J, od);
         double s = 0.0;
-        for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+        for (int a = 0; a < od; ++a) s += r[a] * r[a];
         double rho0, w;
         huber_eval(s, sf.lt_huber, &rho0, &w);
         cost = 0.5 * rho0;
-        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, 7, J, r, 7, w); stored = true; }
-        else add_diag_block(rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov, rd.g + 6 * b.nPv + 7 * (int64_t)ov, 7, J, r, 7, w);
+        if (b.deterministic) { store_diag_block(sf.sm_blk + (int64_t)kSmBlk * t, od, J, r, od, w); stored = true; }
+        else add_diag_block(rd.Hdiag + 36 * b.nPv + od * od * (int64_t)ov, rd.g + 6 * b.nPv + od * (int64_t)ov, od, J, r, od, w);
       }
     }
   }
   if (b.deterministic && !stored && t < sf.n_sp + sf.n_lt) {   // an inactive factor / a constant object: a zero block (k_small_gather reads every slot of its lists)
     double* slot = sf.sm_blk + (int64_t)kSmBlk * t;
-    for (int e = 0; e < 35; ++e) slot[e] = 0.0;
+    for (int e = 0; e < od * (od + 1) / 2 + od; ++e) slot[e] = 0.0;
   }
   cost = wave_sum(cost);
   if (threadIdx.x == 0) scal_add(scal, b.deterministic, SC_COST, cost);
@@ -581,8 +582,11 @@ __device__ __forceinline__ void object_priors_lin(int64_t block, const BlocksDev
 // scratch (kBbBlk doubles: H_oo lower-packed 28 | g_o 7 | H_pp lower-packed 21 | g_p 6), and k_bbox_gather sums the slots per
 // object and per pose; the off-diagonal 7x6 block goes straight into its tile.  Tens of thousands of factors would otherwise mean millions of fp64 atomics (32-byte memory-side
 // transactions each): that, not the dual arithmetic, was the duration of the thread-per-factor kernel this replaces.
-constexpr int kBbBlk = 62, kBbHoo = 0, kBbGo = 28, kBbHpp = 35, kBbGp = 56;
-template <bool STORE>
+// (9-parameter ellipsoid block: H_oo 45 | g_o 9 | H_pp 21 | g_p 6 = 81 doubles per slot, 15 of the 16 lanes carry a direction)
+template <int OD> struct BbSlot { static constexpr int kHoo = 0, kGo = OD * (OD + 1) / 2, kHpp = kGo + OD, kGp = kHpp + 21, kBlk = kGp + 6; };
+constexpr int kBbBlk = BbSlot<7>::kBlk, kBbGo = BbSlot<7>::kGo, kBbHpp = BbSlot<7>::kHpp, kBbGp = BbSlot<7>::kGp;
+static_assert(kBbBlk == 62 && kBbGo == 28 && kBbHpp == 35 && kBbGp == 56 && BbSlot<9>::kBlk == 81, "slot layout");
+template <bool STORE, int OD>
 __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                const double* __restrict__ objects, const ReducedDev& rd, double* scal) {
   const int64_t i = block * 4LL + (threadIdx.x >> 4);
@@ -594,31 +598,32 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
   double r[4] = {0.0, 0.0, 0.0, 0.0}, J[4] = {0.0, 0.0, 0.0, 0.0}, cost = 0.0, w = 0.0;
   if (work) {
     Dual<1> res[4];
-    bbox_eval_n<1>(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res, dir);
+    bbox_eval_n<1, OD>(objects + OD * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res, dir);
     for (int a = 0; a < 4; ++a) { r[a] = res[a].v; J[a] = res[a].d[0]; }
     double rho0;
     huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], sf.bb_huber, &rho0, &w);
     if (dir == 0) cost = 0.5 * rho0;
   }
-  double Jk[4][13];                                   // the factor's whole Jacobian, column k from lane base + k
+  double Jk[4][OD + 6];                                   // the factor's whole Jacobian, column k from lane base + k
 #pragma unroll
-  for (int k = 0; k < 13; ++k)
+  for (int k = 0; k < OD + 6; ++k)
 #pragma unroll
     for (int a = 0; a < 4; ++a) Jk[a][k] = __shfl(J[a], base + k, 64);
   if (STORE) {
-    double* slot = sf.bb_blk + (int64_t)kBbBlk * i;
-    if (work && dir < 7 && ov >= 0) {
+    typedef BbSlot<OD> SL;
+    double* slot = sf.bb_blk + (int64_t)SL::kBlk * i;
+    if (work && dir < OD && ov >= 0) {
       const int x = dir;
 #pragma unroll
-      for (int y = 0; y < 7; ++y) {
+      for (int y = 0; y < OD; ++y) {
         if (y > x) continue;
         double acc = 0.0;
         for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][y];
-        slot[kBbHoo + x * (x + 1) / 2 + y] = w * acc;
+        slot[SL::kHoo + x * (x + 1) / 2 + y] = w * acc;
       }
       double acc = 0.0;
       for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
-      slot[kBbGo + x] = w * acc;
+      slot[SL::kGo + x] = w * acc;
       if (pv >= 0) {
         // the 7x6 block between the object and the pose belongs to this factor alone when no (object, pose) pair occurs twice
         // (host: bb_pairs_unique; false only with several cameras seeing the object from one frame): plain stores into the cleared tile
@@ -627,55 +632,55 @@ __device__ __forceinline__ void bbox_lin_lanes(int64_t block, const BlocksDev& b
 #pragma unroll
         for (int y = 0; y < 6; ++y) {
           double acc2 = 0.0;
-          for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
+          for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][OD + y];
           double* dst = obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x);
           if (sf.bb_pairs_unique) *dst = w * acc2; else atomic_add_f64(dst, w * acc2);
         }
       }
-    } else if (work && dir >= 7 && dir < 13 && pv >= 0) {
-      const int x = dir - 7;
+    } else if (work && dir >= OD && dir < OD + 6 && pv >= 0) {
+      const int x = dir - OD;
 #pragma unroll
       for (int y = 0; y < 6; ++y) {
         if (y > x) continue;
         double acc = 0.0;
-        for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][7 + y];
-        slot[kBbHpp + x * (x + 1) / 2 + y] = w * acc;
+        for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][OD + y];
+        slot[SL::kHpp + x * (x + 1) / 2 + y] = w * acc;
       }
       double acc = 0.0;
       for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
-      slot[kBbGp + x] = w * acc;
+      slot[SL::kGp + x] = w * acc;
     }
-  } else if (work && dir < 7 && ov >= 0) {
+  } else if (work && dir < OD && ov >= 0) {
     const int x = dir;
-    double* Hd = rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov;
+    double* Hd = rd.Hdiag + 36 * b.nPv + OD * OD * (int64_t)ov;
 #pragma unroll
-    for (int y = 0; y < 7; ++y) {
+    for (int y = 0; y < OD; ++y) {
       if (y > x) continue;
       double acc = 0.0;
       for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][y];
-      atomic_add_f64(Hd + 7 * x + y, w * acc);
+      atomic_add_f64(Hd + OD * x + y, w * acc);
     }
     double acc = 0.0;
     for (int a = 0; a < 4; ++a) acc += J[a] * r[a];
-    atomic_add_f64(rd.g + 6 * b.nPv + 7 * (int64_t)ov + x, w * acc);
+    atomic_add_f64(rd.g + 6 * b.nPv + OD * (int64_t)ov + x, w * acc);
     if (pv >= 0) {
       const int64_t orow = b.obj_row[ov], prow = b.pose_row[pv];
       const bool obj_low = orow > prow;
 #pragma unroll
       for (int y = 0; y < 6; ++y) {
         double acc2 = 0.0;
-        for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][7 + y];
+        for (int a = 0; a < 4; ++a) acc2 += J[a] * Jk[a][OD + y];
         atomic_add_f64(obj_low ? S_at(rd.S, rd.nt, orow + x, prow + y) : S_at(rd.S, rd.nt, prow + y, orow + x), w * acc2);
       }
     }
-  } else if (work && dir >= 7 && dir < 13 && pv >= 0) {
-    const int x = dir - 7;
+  } else if (work && dir >= OD && dir < OD + 6 && pv >= 0) {
+    const int x = dir - OD;
     double* Hd = rd.Hdiag + 36 * (int64_t)pv;
 #pragma unroll
     for (int y = 0; y < 6; ++y) {
       if (y > x) continue;
       double acc = 0.0;
-      for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][7 + y];
+      for (int a = 0; a < 4; ++a) acc += J[a] * Jk[a][OD + y];
       atomic_add_f64(Hd + 6 * x + y, w * acc);
     }
     double acc = 0.0;
@@ -761,11 +766,11 @@ __device__ __forceinline__ void relpose_lin_lanes(int64_t block, const BlocksDev
 }
 
 // the three small-factor families of a small problem in one launch (at this size an iteration's first half is bound by the host's launches)
-template <bool STORE>
+template <bool STORE, int OD>
 __global__ void __launch_bounds__(64) k_small_lin_lanes(BlocksDev b, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                        const double* __restrict__ objects, ReducedDev rd, double* scal, int nb_bbox, int nb_priors) {
   const int blk = blockIdx.x;
-  if (blk < nb_bbox) bbox_lin_lanes<STORE>(blk, b, sf, cams, poses, objects, rd, scal);
+  if (blk < nb_bbox) bbox_lin_lanes<STORE, OD>(blk, b, sf, cams, poses, objects, rd, scal);
   else if (blk < nb_bbox + nb_priors) object_priors_lin(blk - nb_bbox, b, sf, objects, rd, scal);
   else relpose_lin_lanes(blk - nb_bbox - nb_priors, b, sf, poses, rd, scal);
 }
@@ -776,36 +781,39 @@ __global__ void __launch_bounds__(64) k_small_lin_lanes(BlocksDev b, SmallFactor
 // One writer per block: plain read-modify-write, a fixed summation order.  Runs after the kernels that add to the diagonal blocks
 // atomically (same stream).
 __global__ void __launch_bounds__(kBlock) k_bbox_gather(BlocksDev b, SmallFactorsDev sf, ReducedDev rd) {
+  const int od = b.od, nho = od * (od + 1) / 2, ne = nho + od;                          // 7: 28 + 7 = 35 entries per slot;  9: 45 + 9 = 54
+  const int blk = nho + od + 27, hpp = nho + od;                                         // slot size and the offset of H_pp | g_p (BbSlot<OD>)
   if ((int64_t)blockIdx.x < b.O) {
-    __shared__ double part[7][36];
+    __shared__ double part[7][64];
     const int64_t o = blockIdx.x;
     const int32_t ov = b.obj_vid[o];
     if (ov < 0) return;   // uniform per workgroup
-    const int slice = threadIdx.x / 36, e = threadIdx.x % 36;
+    const int width = od == 7 ? 36 : 64, nslice = od == 7 ? 7 : 4;                      // lanes per slice x slices <= 256
+    const int slice = threadIdx.x / width, e = threadIdx.x % width;
     const uint32_t q0 = sf.bbo_ptr[o], q1 = sf.bbo_ptr[o + 1];
-    if (threadIdx.x < 252) {
+    if (slice < nslice) {
       double acc = 0.0;
-      if (e < 35) {
+      if (e < ne) {
 #pragma unroll 4
-        for (uint32_t q = q0 + slice; q < q1; q += 7) {
+        for (uint32_t q = q0 + slice; q < q1; q += nslice) {
           const uint32_t f = sf.bbo_idx[q];
-          const double v = sf.bb_blk[(int64_t)kBbBlk * f + e];
+          const double v = sf.bb_blk[(int64_t)blk * f + e];
           acc += sf.bb_active[f] ? v : 0.0;
         }
       }
       part[slice][e] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < 35) {
+    if ((int)threadIdx.x < ne) {
       const int lane = threadIdx.x;
       double acc = 0.0;
-      for (int i = 0; i < 7; ++i) acc += part[i][lane];
-      if (lane < 28) {
+      for (int i = 0; i < nslice; ++i) acc += part[i][lane];
+      if (lane < nho) {
         int x = 0, base = 0;
         while (base + x + 1 <= lane) { base += x + 1; ++x; }
-        rd.Hdiag[36 * b.nPv + 49 * (int64_t)ov + 7 * x + (lane - base)] += acc;
+        rd.Hdiag[36 * b.nPv + od * od * (int64_t)ov + od * x + (lane - base)] += acc;
       } else {
-        rd.g[6 * b.nPv + 7 * (int64_t)ov + (lane - 28)] += acc;
+        rd.g[6 * b.nPv + od * (int64_t)ov + (lane - nho)] += acc;
       }
     }
     return;
@@ -821,7 +829,7 @@ __global__ void __launch_bounds__(kBlock) k_bbox_gather(BlocksDev b, SmallFactor
 #pragma unroll 4
   for (uint32_t q = q0; q < q1; ++q) {
     const uint32_t f = sf.bbp_idx[q];
-    const double v = sf.bb_blk[(int64_t)kBbBlk * f + kBbHpp + lane];
+    const double v = sf.bb_blk[(int64_t)blk * f + hpp + lane];
     acc += sf.bb_active[f] ? v : 0.0;
   }
   if (lane < 21) {
@@ -842,7 +850,7 @@ __global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFacto
   if (t >= b.O + b.P) return;
   const bool is_obj = t < b.O;
   const int32_t vid = is_obj ? b.obj_vid[t] : b.pose_vid[t - b.O];
-  const int d = is_obj ? 7 : 6, nh = d * (d + 1) / 2;
+  const int d = is_obj ? b.od : 6, nh = d * (d + 1) / 2;
   if (vid < 0 || lane >= nh + d) return;
   const uint32_t q0 = sf.smt_ptr[t], q1 = sf.smt_ptr[t + 1];
   if (q1 == q0) return;
@@ -851,8 +859,8 @@ __global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFacto
     const uint32_t e = sf.smt_idx[q];
     acc += sf.sm_blk[(int64_t)kSmBlk * (e >> 1) + ((e & 1u) ? kSmSecond : 0) + lane];
   }
-  double* Hd = is_obj ? rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid : rd.Hdiag + 36 * (int64_t)vid;
-  double* gd = is_obj ? rd.g + 6 * b.nPv + 7 * (int64_t)vid : rd.g + 6 * (int64_t)vid;
+  double* Hd = is_obj ? rd.Hdiag + 36 * b.nPv + d * d * (int64_t)vid : rd.Hdiag + 36 * (int64_t)vid;
+  double* gd = is_obj ? rd.g + 6 * b.nPv + d * (int64_t)vid : rd.g + 6 * (int64_t)vid;
   if (lane < nh) {
     int x = 0, base = 0;
     while (base + x + 1 <= lane) { base += x + 1; ++x; }
@@ -865,21 +873,22 @@ __global__ void __launch_bounds__(kBlock) k_small_gather(BlocksDev b, SmallFacto
 // diagonal blocks of the reduced system: scaling, damping, gradient norms, |x|^2
 __global__ void __launch_bounds__(kBlock) k_reduced_diag(BlocksDev b, const double* __restrict__ poses, const double* __restrict__ objects,
                                                         ReducedDev rd, double radius, int first_iter, double* scal) {
-  // 8 threads per block: thread k handles row k of the block
-  const int64_t t = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 3;
-  const int k = threadIdx.x & 7;
+  // 8 threads per block (16 with the 9-parameter ellipsoid block): thread k handles row k of the block
+  const int sh = b.od > 8 ? 4 : 3;
+  const int64_t t = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> sh;
+  const int k = threadIdx.x & ((1 << sh) - 1);
   double gsq = 0.0, gmax = 0.0, xsq = 0.0;
   const int64_t nblk = b.P + b.O;
   if (t < nblk) {
     const bool is_pose = t < b.P;
     const int64_t idx = is_pose ? t : t - b.P;
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
-    const int d = is_pose ? 6 : 7;
+    const int d = is_pose ? 6 : b.od;
     if (vid >= 0 && k < d) {
-      const int64_t crow = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + 7 * (int64_t)vid;   // compact index (g, scale, lam)
+      const int64_t crow = is_pose ? 6 * (int64_t)vid : 6 * b.nPv + d * (int64_t)vid;   // compact index (g, scale, lam)
       const int64_t row = is_pose ? b.pose_row[vid] : b.obj_row[vid];                     // row of the tile grid (S, rhs, y)
-      const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + 49 * (int64_t)vid;
-      const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
+      const double* Hd = is_pose ? rd.Hdiag + 36 * (int64_t)vid : rd.Hdiag + 36 * b.nPv + d * d * (int64_t)vid;
+      const double* x = is_pose ? poses + 6 * idx : objects + d * idx;
       // a shared object's (already globally summed) diagonal block, gradient and norms are contributed by one rank only
       const bool contribute = is_pose || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
       const double c = Hd[d * k + k];
@@ -1306,12 +1315,12 @@ __device__ __forceinline__ void apply_reduced_step_block(int64_t block, const Bl
   if (t < b.P + b.O) {
     const bool is_pose = t < b.P;
     const int64_t idx = is_pose ? t : t - b.P;
-    const int d = is_pose ? 6 : 7;
+    const int d = is_pose ? 6 : b.od;
     const int32_t vid = is_pose ? b.pose_vid[idx] : b.obj_vid[idx];
-    const double* x = is_pose ? poses + 6 * idx : objects + 7 * idx;
-    double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + 7 * idx;
+    const double* x = is_pose ? poses + 6 * idx : objects + d * idx;
+    double* xc = is_pose ? poses_cand + 6 * idx : objects_cand + d * idx;
     const int64_t row = vid < 0 ? 0 : (is_pose ? b.pose_row[vid] : b.obj_row[vid]);
-    const int64_t ci = vid < 0 ? 0 : (is_pose ? 6 * (int64_t)vid : 6 * (int64_t)b.nPv + 7 * (int64_t)vid);   // compact index of g, lam
+    const int64_t ci = vid < 0 ? 0 : (is_pose ? 6 * (int64_t)vid : 6 * (int64_t)b.nPv + d * (int64_t)vid);   // compact index of g, lam
     const bool count = is_pose || vid < 0 || b.obj_shared == nullptr || !b.obj_shared[vid] || b.shared_owner;
     for (int k = 0; k < d; ++k) {
       double v = x[k];
@@ -1409,13 +1418,14 @@ __device__ __forceinline__ void cost_reproj_block(int64_t p, const BlocksDev& b,
 __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev& b, const SmallFactorsDev& sf, const DevCam* __restrict__ cams,
                                                  const double* __restrict__ poses, const double* __restrict__ objects, int mode, double* scal) {
   int64_t t = block * (int64_t)kBlock + threadIdx.x;
+  const int od = b.od;
   double cost = 0.0, rho0, w;
   if (t < sf.n_bb) {
     const int64_t i = t;
     const uint32_t o = sf.bb_obj[i], p = sf.bb_pose[i];
     if (sf.bb_active[i] && (b.obj_vid[o] >= 0 || b.pose_vid[p] >= 0) == (mode == 0)) {
       Dual<1> res[4];
-      bbox_eval_n<1>(objects + 7 * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+      bbox_eval_1(od, objects + od * (int64_t)o, poses + 6 * (int64_t)p, cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
       huber_eval(res[0].v * res[0].v + res[1].v * res[1].v + res[2].v * res[2].v + res[3].v * res[3].v, sf.bb_huber, &rho0, &w);
       cost = 0.5 * rho0;
     }
@@ -1424,7 +1434,7 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
     const uint32_t o = sf.sp_obj[i];
     if (sf.sp_active[i] && (b.obj_vid[o] >= 0) == (mode == 0)) {
       double r[3];
-      shape_prior_eval(objects + 7 * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+      shape_prior_eval(objects + od * (int64_t)o, sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr, od);
       huber_eval(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sf.sp_huber, &rho0, &w);
       cost = 0.5 * rho0;
     }
@@ -1432,9 +1442,9 @@ __device__ __forceinline__ void cost_small_block(int64_t block, const BlocksDev&
     const int64_t i = t;
     const uint32_t o = sf.lt_obj[i];
     if (sf.lt_active[i] && (b.obj_vid[o] >= 0) == (mode == 0)) {
-      double r[7], s = 0.0;
-      ltm_prior_eval(objects + 7 * (int64_t)o, sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
-      for (int a = 0; a < 7; ++a) s += r[a] * r[a];
+      double r[9], s = 0.0;
+      ltm_prior_eval(objects + od * (int64_t)o, sf.lt_mean + od * i, sf.lt_sqrt_inf + od * od * i, r, nullptr, od);
+      for (int a = 0; a < od; ++a) s += r[a] * r[a];
       huber_eval(s, sf.lt_huber, &rho0, &w);
       cost = 0.5 * rho0;
     }
@@ -1520,29 +1530,36 @@ __global__ void __launch_bounds__(64) k_eval_small(SmallFactorsDev sf, const Dev
                                                   const double* __restrict__ objects, int apply_loss, double* res_bb, double* sq_bb,
                                                   double* res_sp, double* sq_sp, double* res_lt, double* sq_lt, double* res_rl, double* sq_rl, double* scal, int det) {
   int64_t t = blockIdx.x * 64LL + threadIdx.x;
+  const int od = sf.od;
   double cost = 0.0;
   if (t < sf.n_bb) {
     const int64_t i = t;
     double r[4] = {0, 0, 0, 0};
     const bool act = sf.bb_active[i] != 0;
     if (act) {
-      D13 res[4];
-      bbox_eval(objects + 7 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
-      for (int a = 0; a < 4; ++a) r[a] = res[a].v;
+      if (od == 7) {   // (the 13-direction form: the values every earlier round's fixtures were taken with)
+        D13 res[4];
+        bbox_eval(objects + 7 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+        for (int a = 0; a < 4; ++a) r[a] = res[a].v;
+      } else {
+        Dual<1> res[4];
+        bbox_eval_n<1, 9>(objects + 9 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+        for (int a = 0; a < 4; ++a) r[a] = res[a].v;
+      }
     }
     cost = finish_eval<4>(r, sf.bb_huber, apply_loss, res_bb, sq_bb, i, act);
   } else if ((t -= sf.n_bb) < sf.n_sp) {
     const int64_t i = t;
     double r[3] = {0, 0, 0};
     const bool act = sf.sp_active[i] != 0;
-    if (act) shape_prior_eval(objects + 7 * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr);
+    if (act) shape_prior_eval(objects + od * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, nullptr, od);
     cost = finish_eval<3>(r, sf.sp_huber, apply_loss, res_sp, sq_sp, i, act);
   } else if ((t -= sf.n_sp) < sf.n_lt) {
     const int64_t i = t;
-    double r[7] = {0, 0, 0, 0, 0, 0, 0};
+    double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool act = sf.lt_active[i] != 0;
-    if (act) ltm_prior_eval(objects + 7 * (int64_t)sf.lt_obj[i], sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, nullptr);
-    cost = finish_eval<7>(r, sf.lt_huber, apply_loss, res_lt, sq_lt, i, act);
+    if (act) ltm_prior_eval(objects + od * (int64_t)sf.lt_obj[i], sf.lt_mean + od * i, sf.lt_sqrt_inf + od * od * i, r, nullptr, od);
+    cost = od == 7 ? finish_eval<7>(r, sf.lt_huber, apply_loss, res_lt, sq_lt, i, act) : finish_eval<9>(r, sf.lt_huber, apply_loss, res_lt, sq_lt, i, act);
   } else if ((t -= sf.n_lt) < sf.n_rl) {
     const int64_t i = t;
     double r[6] = {0, 0, 0, 0, 0, 0};
@@ -1594,7 +1611,8 @@ __global__ void __launch_bounds__(kBlock) k_debug_lin_reproj(ReprojDev rp, const
 __global__ void __launch_bounds__(64) k_debug_lin_small(int type, SmallFactorsDev sf, const DevCam* __restrict__ cams, const double* __restrict__ poses,
                                                        const double* __restrict__ objects, double* r_out, double* J0, double* J1) {
   const int64_t i = blockIdx.x * 64LL + threadIdx.x;
-  if (type == 2 && i < sf.n_bb) {
+  const int od = sf.od;
+  if (type == 2 && i < sf.n_bb && od == 7) {
     D13 res[4];
     bbox_eval(objects + 7 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
     for (int a = 0; a < 4; ++a) {
@@ -1602,16 +1620,24 @@ __global__ void __launch_bounds__(64) k_debug_lin_small(int type, SmallFactorsDe
       for (int k = 0; k < 7; ++k) J0[28 * i + 7 * a + k] = res[a].d[k];
       for (int k = 0; k < 6; ++k) J1[24 * i + 6 * a + k] = res[a].d[7 + k];
     }
+  } else if (type == 2 && i < sf.n_bb) {
+    Dual<15> res[4];
+    bbox_eval_n<15, 9>(objects + 9 * (int64_t)sf.bb_obj[i], poses + 6 * (int64_t)sf.bb_pose[i], cams[sf.bb_cam[i]], sf.bb_rect + 4 * i, sf.bb_sqrt_inf + 16 * i, sf.bb_invalid, res);
+    for (int a = 0; a < 4; ++a) {
+      r_out[4 * i + a] = res[a].v;
+      for (int k = 0; k < 9; ++k) J0[36 * i + 9 * a + k] = res[a].d[k];
+      for (int k = 0; k < 6; ++k) J1[24 * i + 6 * a + k] = res[a].d[9 + k];
+    }
   } else if (type == 3 && i < sf.n_sp) {
-    double r[3], J[21];
-    shape_prior_eval(objects + 7 * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J);
+    double r[3], J[27];
+    shape_prior_eval(objects + od * (int64_t)sf.sp_obj[i], sf.sp_mean + 3 * i, sf.sp_sqrt_inf + 9 * i, r, J, od);
     for (int a = 0; a < 3; ++a) r_out[3 * i + a] = r[a];
-    for (int k = 0; k < 21; ++k) J0[21 * i + k] = J[k];
+    for (int k = 0; k < 3 * od; ++k) J0[3 * od * i + k] = J[k];
   } else if (type == 4 && i < sf.n_lt) {
-    double r[7], J[49];
-    ltm_prior_eval(objects + 7 * (int64_t)sf.lt_obj[i], sf.lt_mean + 7 * i, sf.lt_sqrt_inf + 49 * i, r, J);
-    for (int a = 0; a < 7; ++a) r_out[7 * i + a] = r[a];
-    for (int k = 0; k < 49; ++k) J0[49 * i + k] = J[k];
+    double r[9], J[81];
+    ltm_prior_eval(objects + od * (int64_t)sf.lt_obj[i], sf.lt_mean + od * i, sf.lt_sqrt_inf + od * od * i, r, J, od);
+    for (int a = 0; a < od; ++a) r_out[od * i + a] = r[a];
+    for (int k = 0; k < od * od; ++k) J0[od * od * i + k] = J[k];
   } else if (type == 5 && i < sf.n_rl) {
     D12 res[6];
     relpose_eval(poses + 6 * (int64_t)sf.rl_a[i], poses + 6 * (int64_t)sf.rl_b[i], sf.rl_t + 3 * i, sf.rl_R + 9 * i, sf.rl_sqrt_inf + 36 * i, res);
@@ -1626,13 +1652,13 @@ __global__ void __launch_bounds__(kBlock) k_fill(double* p, int64_t n, double v)
   for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
 }
 
-// multi-GPU exchange (1): (Hdiag 49 | g 7) of the shared objects <-> contiguous buffer
-__global__ void __launch_bounds__(64) k_pack_shared_blocks(BlocksDev b, ReducedDev rd, const int32_t* __restrict__ shared_ov, int32_t n_shared, double* buf, int unpack) {
-  const int o = blockIdx.x;
-  if (o >= n_shared || threadIdx.x >= 56) return;
+// multi-GPU exchange (1): (Hdiag od^2 | g od) of the shared objects <-> contiguous buffer (56 doubles per object; 90 with the 9-parameter block)
+__global__ void __launch_bounds__(128) k_pack_shared_blocks(BlocksDev b, ReducedDev rd, const int32_t* __restrict__ shared_ov, int32_t n_shared, double* buf, int unpack) {
+  const int o = blockIdx.x, od = b.od, nh = od * od, n = nh + od;
+  if (o >= n_shared || (int)threadIdx.x >= n) return;
   const int32_t ov = shared_ov[o];
-  double* src = threadIdx.x < 49 ? rd.Hdiag + 36 * b.nPv + 49 * (int64_t)ov + threadIdx.x : rd.g + 6 * b.nPv + 7 * (int64_t)ov + (threadIdx.x - 49);
-  if (unpack) *src = buf[56 * (int64_t)o + threadIdx.x]; else buf[56 * (int64_t)o + threadIdx.x] = *src;
+  double* src = (int)threadIdx.x < nh ? rd.Hdiag + 36 * b.nPv + nh * (int64_t)ov + threadIdx.x : rd.g + 6 * b.nPv + od * (int64_t)ov + (threadIdx.x - nh);
+  if (unpack) *src = buf[n * (int64_t)o + threadIdx.x]; else buf[n * (int64_t)o + threadIdx.x] = *src;
 }
 // multi-GPU exchange (2): lower tiles (i >= j >= t0) of the tile grid, then rhs rows [t0*64, nt*64)
 __global__ void __launch_bounds__(kBlock) k_pack_tail(ReducedDev rd, int32_t t0, double* buf, int unpack) {
@@ -1705,29 +1731,34 @@ void launch_small_factors(hipStream_t s, const BlocksDev& b, const SmallFactorsD
   const int64_t lanes_below = std::getenv("OBVI_SMALL_LANES_BELOW") ? std::atoll(std::getenv("OBVI_SMALL_LANES_BELOW")) : 4096;   // tuning knob
   const int nb_bbox = (int)grid_for(sf.n_bb, 4), nb_priors = (int)grid_for(sf.n_sp + sf.n_lt, 64), nb_rel = (int)grid_for(sf.n_rl, 4);
   if (nb_bbox + nb_priors + nb_rel == 0) return;
+  // (the bounding-box lanes are compiled per ellipsoid block size: 13 or 15 directions on the factor's 16 lanes)
+#define OBVI_SMALL_LIN(STORE) do { if (b.od == 9) hipLaunchKernelGGL((k_small_lin_lanes<STORE, 9>), dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors); \
+                                   else hipLaunchKernelGGL((k_small_lin_lanes<STORE, 7>), dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors); } while (0)
   if (b.deterministic) {
     // no fp64 atomics on the diagonal blocks: every factor leaves its blocks in a scratch slot, the gathers add them per target in list order
-    hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+    OBVI_SMALL_LIN(true);
     launch_det_reduce(s, scal, nb_bbox + nb_priors + nb_rel, OBVI_SC(SC_COST), b.deterministic);
     if (sf.n_bb > 0) hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
     if (sf.n_sp + sf.n_lt + sf.n_rl > 0) hipLaunchKernelGGL(k_small_gather, dim3(grid_for(b.O + b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
     return;
   }
   if (sf.n_bb < lanes_below) {
-    hipLaunchKernelGGL(k_small_lin_lanes<false>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+    OBVI_SMALL_LIN(false);
     return;
   }
   // many bounding boxes: per-factor blocks into the scratch, then one wavefront per object / pose sums them (no atomics); the priors and
   // the relative-pose factors ride in the first launch, 16 lanes per factor at every size (a thread per factor left the 2 000 odometry
   // factors of the global problem as 32 wavefronts dragging a 12-direction dual: 250 us)
-  hipLaunchKernelGGL(k_small_lin_lanes<true>, dim3(nb_bbox + nb_priors + nb_rel), dim3(64), 0, s, b, sf, cams, poses, objects, rd, scal, nb_bbox, nb_priors);
+  OBVI_SMALL_LIN(true);
   hipLaunchKernelGGL(k_bbox_gather, dim3((unsigned)b.O + grid_for(b.P, kBlock / 64)), dim3(kBlock), 0, s, b, sf, rd);
+#undef OBVI_SMALL_LIN
 }
 void launch_reduced_diag(hipStream_t s, const BlocksDev& b, const double* poses, const double* objects, const ReducedDev& rd, double radius,
                          int first_iter, double* scal) {
   if (b.P + b.O > 0) {
-    hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(8 * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
-    if (b.deterministic) launch_det_reduce(s, scal, grid_for(8 * (b.P + b.O), kBlock), OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
+    const int per = b.od > 8 ? 16 : 8;   // threads per diagonal block
+    hipLaunchKernelGGL(k_reduced_diag, dim3(grid_for(per * (b.P + b.O), kBlock)), dim3(kBlock), 0, s, b, poses, objects, rd, radius, first_iter, scal);
+    if (b.deterministic) launch_det_reduce(s, scal, grid_for(per * (b.P + b.O), kBlock), OBVI_SC(SC_GSQ) | OBVI_SC(SC_XSQ), b.deterministic);
   }
 }
 void launch_schur_blocks(hipStream_t s, int64_t nblk, const uint32_t* blk_row, const uint32_t* blk_col, const uint32_t* blk_ptr,
@@ -1789,7 +1820,7 @@ void launch_evaluate(hipStream_t s, const BlocksDev& b, const ReprojDev& rp, con
     double* r_bb = residuals ? residuals + 2 * rp.n : nullptr;
     double* r_sp = residuals ? r_bb + 4 * sf.n_bb : nullptr;
     double* r_lt = residuals ? r_sp + 3 * sf.n_sp : nullptr;
-    double* r_rl = residuals ? r_lt + 7 * sf.n_lt : nullptr;
+    double* r_rl = residuals ? r_lt + sf.od * sf.n_lt : nullptr;
     double* q_bb = sqnorm ? sqnorm + rp.n : nullptr;
     double* q_sp = sqnorm ? q_bb + sf.n_bb : nullptr;
     double* q_lt = sqnorm ? q_sp + sf.n_sp : nullptr;
@@ -1808,7 +1839,7 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
   if (n > 0) hipLaunchKernelGGL(k_debug_lin_small, dim3(grid_for(n, 64)), dim3(64), 0, s, factor_type, sf, cams, poses, objects, r, J0, J1);
 }
 void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack) {
-  if (n_shared > 0) hipLaunchKernelGGL(k_pack_shared_blocks, dim3(n_shared), dim3(64), 0, s, b, rd, shared_ov, n_shared, buf, unpack);
+  if (n_shared > 0) hipLaunchKernelGGL(k_pack_shared_blocks, dim3(n_shared), dim3(128), 0, s, b, rd, shared_ov, n_shared, buf, unpack);
 }
 // multi-GPU: the scalar block's sums and the gradient maximum in ONE all-reduce (sum): buf = [SC_COST, SC_SUM_END) | one slot per rank
 // holding that rank's maximum (zero elsewhere), so that after the sum every rank sees every maximum and takes the largest itself

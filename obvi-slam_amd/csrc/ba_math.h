@@ -214,6 +214,16 @@ template <int N> OBVI_HD void dual_inverse_pose(const Dual<N>* pose, Dual<N>* Ri
   for (int i = 0; i < 3; ++i) tinv[i] = -(Rinv[3 * i] * pose[0] + Rinv[3 * i + 1] * pose[1] + Rinv[3 * i + 2] * pose[2]);
 }
 
+// rotation of a (t, aa) block, forward: PoseArrayToAffine (vslam_math_util.h:121-141) / VectorToAxisAngle (:31-42): identity at or below 1e-8
+template <int N>
+OBVI_HD void dual_forward_rotation(const Dual<N>* pose, Dual<N>* R) {
+  typedef Dual<N> D12;
+  const D12 angle = dsqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5]);
+  if (!(angle.v > OBVI_SMALL_ANGLE)) { dual_identity(R); return; }
+  const D12 axis[3] = {pose[3] / angle, pose[4] / angle, pose[5] / angle};
+  dual_rotation(angle, axis, R);
+}
+
 // BoundingBoxFactor::operator() (bounding_box_factor.h:68-136) over
 // getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273).  13 directions: ellipsoid 0..6,
 // pose 7..12.  Returns false (constant residual, zero Jacobian) in the invalid-ellipse case.
@@ -226,13 +236,17 @@ template <int N> OBVI_HD Dual<N> dvar_n(double c, int k, int dir = -1) {
   else if (k < N) r.d[k] = 1.0;
   return r;
 }
-template <int N>
+// OD = 7: the reference's build (CONSTRAIN_ELLIPSOID_ORIENTATION, CMakeLists.txt:8-15): block (x y z yaw dx dy dz), rotation about z.
+// OD = 9 (round 6): the unconstrained block of vslam_obj_opt_types_refactor.h:15-21 -- (x y z ax ay az dx dy dz), rotation VectorToAxisAngle(ax ay az)
+// (ellipsoid_utils.h:217-229 `#else`; vslam_math_util.h:31-42: the constant AngleAxis(0, e_x) at or below 1e-8) -- OD + 6 directions, ellipsoid first.
+template <int N, int OD = 7>
 OBVI_HD bool bbox_eval_n(const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
                          const double* sqrt_inf, double invalid_err, Dual<N>* res, int dir = -1) {
   typedef Dual<N> D13;
-  D13 ell[7], pose[6];
-  for (int k = 0; k < 7; ++k) ell[k] = dvar_n<N>(ell_v[k], k, dir);
-  for (int k = 0; k < 6; ++k) pose[k] = dvar_n<N>(pose_v[k], 7 + k, dir);
+  static_assert(OD == 7 || OD == 9, "ellipsoid block: 7 (yaw only) or 9 (axis-angle)");
+  D13 ell[OD], pose[6];
+  for (int k = 0; k < OD; ++k) ell[k] = dvar_n<N>(ell_v[k], k, dir);
+  for (int k = 0; k < 6; ++k) pose[k] = dvar_n<N>(pose_v[k], OD + k, dir);
   D13 Rinv[9], tinv[3];
   dual_inverse_pose(pose, Rinv, tinv);
   D13 Rcw[9], tcw[3];
@@ -241,16 +255,25 @@ OBVI_HD bool bbox_eval_n(const double* ell_v, const double* pose_v, const DevCam
       Rcw[3 * i + j] = Rinv[j] * cam.Rinv[3 * i] + Rinv[3 + j] * cam.Rinv[3 * i + 1] + Rinv[6 + j] * cam.Rinv[3 * i + 2];
     tcw[i] = tinv[0] * cam.Rinv[3 * i] + tinv[1] * cam.Rinv[3 * i + 1] + tinv[2] * cam.Rinv[3 * i + 2] + cam.tinv[i];
   }
-  const D13 cy = dcos(ell[3]), sy = dsin(ell[3]);
   D13 M[12];
-  for (int i = 0; i < 3; ++i) {
-    M[4 * i + 0] = Rcw[3 * i] * cy + Rcw[3 * i + 1] * sy;
-    M[4 * i + 1] = Rcw[3 * i + 1] * cy - Rcw[3 * i] * sy;
-    M[4 * i + 2] = Rcw[3 * i + 2];
-    M[4 * i + 3] = Rcw[3 * i] * ell[0] + Rcw[3 * i + 1] * ell[1] + Rcw[3 * i + 2] * ell[2] + tcw[i];
+  if (OD == 7) {
+    const D13 cy = dcos(ell[3]), sy = dsin(ell[3]);
+    for (int i = 0; i < 3; ++i) {
+      M[4 * i + 0] = Rcw[3 * i] * cy + Rcw[3 * i + 1] * sy;
+      M[4 * i + 1] = Rcw[3 * i + 1] * cy - Rcw[3 * i] * sy;
+      M[4 * i + 2] = Rcw[3 * i + 2];
+      M[4 * i + 3] = Rcw[3 * i] * ell[0] + Rcw[3 * i + 1] * ell[1] + Rcw[3 * i + 2] * ell[2] + tcw[i];
+    }
+  } else {
+    D13 Re[9];
+    dual_forward_rotation(ell, Re);   // reads ell[3..5]: the same (angle, axis) -> Rodrigues form and small-angle branch as a pose's rotation
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) M[4 * i + j] = Rcw[3 * i] * Re[j] + Rcw[3 * i + 1] * Re[3 + j] + Rcw[3 * i + 2] * Re[6 + j];
+      M[4 * i + 3] = Rcw[3 * i] * ell[0] + Rcw[3 * i + 1] * ell[1] + Rcw[3 * i + 2] * ell[2] + tcw[i];
+    }
   }
   D13 dm[3];
-  for (int k = 0; k < 3; ++k) { const D13 h = ell[4 + k] * 0.5; dm[k] = h * h + OBVI_DIM_REG; }
+  for (int k = 0; k < 3; ++k) { const D13 h = ell[OD - 3 + k] * 0.5; dm[k] = h * h + OBVI_DIM_REG; }
 #define OBVI_Q(a, b) (M[4 * a] * dm[0] * M[4 * b] + M[4 * a + 1] * dm[1] * M[4 * b + 1] + M[4 * a + 2] * dm[2] * M[4 * b + 2] - M[4 * a + 3] * M[4 * b + 3])
   const D13 q11 = OBVI_Q(0, 0), q13 = OBVI_Q(0, 2), q22 = OBVI_Q(1, 1), q23 = OBVI_Q(1, 2), q33 = OBVI_Q(2, 2);
 #undef OBVI_Q
@@ -272,18 +295,16 @@ OBVI_HD bool bbox_eval(const double* ell_v, const double* pose_v, const DevCam& 
                        const double* sqrt_inf, double invalid_err, D13* res) {
   return bbox_eval_n<13>(ell_v, pose_v, cam, rect_corners, sqrt_inf, invalid_err, res);
 }
+// value only / one direction, ellipsoid block size at run time
+OBVI_HD bool bbox_eval_1(int od, const double* ell_v, const double* pose_v, const DevCam& cam, const double* rect_corners,
+                         const double* sqrt_inf, double invalid_err, Dual<1>* res, int dir = -1) {
+  return od == 9 ? bbox_eval_n<1, 9>(ell_v, pose_v, cam, rect_corners, sqrt_inf, invalid_err, res, dir)
+                 : bbox_eval_n<1, 7>(ell_v, pose_v, cam, rect_corners, sqrt_inf, invalid_err, res, dir);
+}
 
 // RelativePoseFactor::operator() (relative_pose_factor.h:32-61).  12 directions: pose_before
 // 0..5, pose_after 6..11.  Pose rotation: PoseArrayToAffine (vslam_math_util.h:121-141);
 // rotation log: Eigen::AngleAxis(Matrix3) via its quaternion (see oracle/README.md).
-template <int N>
-OBVI_HD void dual_forward_rotation(const Dual<N>* pose, Dual<N>* R) {
-  typedef Dual<N> D12;
-  const D12 angle = dsqrt(pose[3] * pose[3] + pose[4] * pose[4] + pose[5] * pose[5]);
-  if (!(angle.v > OBVI_SMALL_ANGLE)) { dual_identity(R); return; }
-  const D12 axis[3] = {pose[3] / angle, pose[4] / angle, pose[5] / angle};
-  dual_rotation(angle, axis, R);
-}
 template <int N>
 OBVI_HD void relpose_eval_n(const double* pa_v, const double* pb_v, const double* t_meas, const double* R_meas,
                             const double* sqrt_inf, Dual<N>* res, int dir = -1) {
@@ -344,22 +365,22 @@ OBVI_HD void relpose_eval(const double* pa_v, const double* pb_v, const double* 
 // ShapePriorFactor (shape_prior_factor.h:46-61) and IndependentObjectMapFactor
 // (independent_object_map_factor.h:21-33) are linear in the ellipsoid block:
 // r = A (e_sub - mean),  J = A placed in the matching columns.
-OBVI_HD void shape_prior_eval(const double* ell, const double* mean3, const double* sqrt_inf, double* r, double* J /*3x7*/) {
-  const double d0 = ell[4] - mean3[0], d1 = ell[5] - mean3[1], d2 = ell[6] - mean3[2];
+OBVI_HD void shape_prior_eval(const double* ell, const double* mean3, const double* sqrt_inf, double* r, double* J /*3 x od*/, int od = 7) {
+  const double d0 = ell[od - 3] - mean3[0], d1 = ell[od - 2] - mean3[1], d2 = ell[od - 1] - mean3[2];   // shape_prior_factor.h:49-51: the last three entries
   for (int i = 0; i < 3; ++i) {
     r[i] = d0 * sqrt_inf[3 * i] + d1 * sqrt_inf[3 * i + 1] + d2 * sqrt_inf[3 * i + 2];
     if (J) {
-      for (int k = 0; k < 4; ++k) J[7 * i + k] = 0.0;
-      for (int k = 0; k < 3; ++k) J[7 * i + 4 + k] = sqrt_inf[3 * i + k];
+      for (int k = 0; k < od - 3; ++k) J[od * i + k] = 0.0;
+      for (int k = 0; k < 3; ++k) J[od * i + od - 3 + k] = sqrt_inf[3 * i + k];
     }
   }
 }
-OBVI_HD void ltm_prior_eval(const double* ell, const double* mean7, const double* sqrt_inf, double* r, double* J /*7x7*/) {
-  for (int i = 0; i < 7; ++i) {
+OBVI_HD void ltm_prior_eval(const double* ell, const double* mean, const double* sqrt_inf, double* r, double* J /*od x od*/, int od = 7) {
+  for (int i = 0; i < od; ++i) {
     double acc = 0.0;
-    for (int k = 0; k < 7; ++k) acc += (ell[k] - mean7[k]) * sqrt_inf[7 * i + k];
+    for (int k = 0; k < od; ++k) acc += (ell[k] - mean[k]) * sqrt_inf[od * i + k];
     r[i] = acc;
-    if (J) for (int k = 0; k < 7; ++k) J[7 * i + k] = sqrt_inf[7 * i + k];
+    if (J) for (int k = 0; k < od; ++k) J[od * i + k] = sqrt_inf[od * i + k];
   }
 }
 

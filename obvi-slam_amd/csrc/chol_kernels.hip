@@ -956,49 +956,50 @@ __global__ void __launch_bounds__(kThreads) k_forward_multi_diag(int nt, const i
     for (int r = 0; r < 4; ++r) Yk[(int64_t)(16 * rt + (lane >> 4) + 4 * r) * ldt + 16 * wv + (lane & 15)] = out[rt][r];
 }
 
-// unit right-hand sides: right-hand side 7 ov + a has its one in row obj_row[ov] + a
-__global__ void __launch_bounds__(64) k_cov_seed(double* Yt, int64_t ldt, const int32_t* __restrict__ obj_row, int32_t nOv) {
+// unit right-hand sides: right-hand side od ov + a has its one in row obj_row[ov] + a (od = 7, or 9 for the unconstrained ellipsoid block)
+__global__ void __launch_bounds__(64) k_cov_seed(double* Yt, int64_t ldt, const int32_t* __restrict__ obj_row, int32_t nOv, int od) {
   const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= 7 * nOv) return;
-  Yt[(int64_t)t * ldt + obj_row[t / 7] + t % 7] = 1.0;
+  if (t >= od * nOv) return;
+  Yt[(int64_t)t * ldt + obj_row[t / od] + t % od] = 1.0;
 }
 
 // cov[p][r][k] = Yt[ca + r] . Yt[cb + k] (rows of Yt from first_row on); one workgroup per pair; cols[2p] < 0: zero block
 constexpr int kCovThreads = 256;
+template <int OD>
 __global__ void __launch_bounds__(kCovThreads) k_cov_pairs(const double* __restrict__ Yt, int64_t ldt, const int32_t* __restrict__ cols,
                                                           const int32_t* __restrict__ first_row, double* __restrict__ out) {
-  __shared__ double red[kCovThreads / 64][49];
+  __shared__ double red[kCovThreads / 64][OD * OD];
   const int p = blockIdx.x, ca = cols[2 * p], cb = cols[2 * p + 1];
-  double acc[49];
+  double acc[OD * OD];
 #pragma unroll
-  for (int i = 0; i < 49; ++i) acc[i] = 0.0;
+  for (int i = 0; i < OD * OD; ++i) acc[i] = 0.0;
   if (ca >= 0 && cb >= 0) {
     const double* ya = Yt + (int64_t)ca * ldt;
     const double* yb = Yt + (int64_t)cb * ldt;
     for (int64_t x = first_row[p] + threadIdx.x; x < ldt; x += kCovThreads) {
-      double b[7];
+      double b[OD];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) b[k] = yb[k * ldt + x];
+      for (int k = 0; k < OD; ++k) b[k] = yb[k * ldt + x];
 #pragma unroll
-      for (int r = 0; r < 7; ++r) {
+      for (int r = 0; r < OD; ++r) {
         const double a = ya[r * ldt + x];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc[7 * r + k] = fma(a, b[k], acc[7 * r + k]);
+        for (int k = 0; k < OD; ++k) acc[OD * r + k] = fma(a, b[k], acc[OD * r + k]);
       }
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 49; ++i) {
+  for (int i = 0; i < OD * OD; ++i) {
     double v = acc[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) red[wv][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 49) {
+  if (threadIdx.x < OD * OD) {
     double v = 0.0;
     for (int w = 0; w < kCovThreads / 64; ++w) v += red[w][threadIdx.x];
-    out[49 * (int64_t)p + threadIdx.x] = v;
+    out[OD * OD * (int64_t)p + threadIdx.x] = v;
   }
 }
 
@@ -1068,9 +1069,9 @@ void launch_cholesky_backward(hipStream_t s, const CholPlan& p, const double* S,
 }
 
 void launch_forward_multi(hipStream_t s, const CholPlan& p, const double* S, const double* Linv, double* Yt, int64_t ldt, int nslabs,
-                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split) {
+                          const int32_t* slab_first, const int32_t* obj_row, int32_t nOv, const int32_t* row_split, int od) {
   if (nOv <= 0 || nslabs <= 0) return;
-  hipLaunchKernelGGL(k_cov_seed, dim3((7 * nOv + 63) / 64), dim3(64), 0, s, Yt, ldt, obj_row, nOv);
+  hipLaunchKernelGGL(k_cov_seed, dim3((od * nOv + 63) / 64), dim3(64), 0, s, Yt, ldt, obj_row, nOv, od);
   for (int l = 0; l < p.nlevels; ++l) {
     const int nk = p.lvl_k_ptr[l + 1] - p.lvl_k_ptr[l];
     if (nk <= 0) continue;
@@ -1079,8 +1080,10 @@ void launch_forward_multi(hipStream_t s, const CholPlan& p, const double* S, con
     if (nsplit > 1) hipLaunchKernelGGL(k_forward_multi_diag, dim3(nk, nslabs), dim3(kThreads), 0, s, p.nt, p.lvl_k + p.lvl_k_ptr[l], Linv, Yt, ldt, slab_first);
   }
 }
-void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out) {
-  if (n_pairs > 0) hipLaunchKernelGGL(k_cov_pairs, dim3((unsigned)n_pairs), dim3(kCovThreads), 0, s, Yt, ldt, cols, first_row, out);
+void launch_cov_pairs(hipStream_t s, const double* Yt, int64_t ldt, int64_t n_pairs, const int32_t* cols, const int32_t* first_row, double* out, int od) {
+  if (n_pairs <= 0) return;
+  if (od == 9) hipLaunchKernelGGL(k_cov_pairs<9>, dim3((unsigned)n_pairs), dim3(kCovThreads), 0, s, Yt, ldt, cols, first_row, out);
+  else hipLaunchKernelGGL(k_cov_pairs<7>, dim3((unsigned)n_pairs), dim3(kCovThreads), 0, s, Yt, ldt, cols, first_row, out);
 }
 
 }  // namespace obvi

@@ -228,11 +228,11 @@ class HostPool {
   bool stop_ = false;
 };
 
-// out = (sym(cov))^(-1/2) for an n x n (n <= 7) symmetric positive definite matrix, row-major.
+// out = (sym(cov))^(-1/2) for an n x n (n <= 9) symmetric positive definite matrix, row-major.
 // One-sided view: eigen-decomposition by threshold-free cyclic Jacobi sweeps on a working copy,
 // then out = sum_k v_k v_k^T / sqrt(lambda_k).  Returns false when cov is not finite / not SPD.
 inline bool sym_inverse_sqrt(const double* cov, int n, double* out) {
-  double a[7][7], v[7][7];
+  double a[9][9], v[9][9];
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) {
       a[i][j] = 0.5 * (cov[i * n + j] + cov[j * n + i]);

@@ -65,7 +65,7 @@ void submit_step(obvi_ba_handle* h, double radius, bool first_iter, bool solve, 
     if (exchange) {   // (1) global J^T J diagonal blocks and gradients of the shared objects
       const int32_t ns = (int32_t)h->h_shared_ov.size();
       launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 0);
-      if (h->allreduce(h->allreduce_user, h->d_xbuf2.get(), 56 * (int64_t)ns, 0, s2)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
+      if (h->allreduce(h->allreduce_user, h->d_xbuf2.get(), (int64_t)(h->od * h->od + h->od) * ns, 0, s2)) throw HipError{hipErrorUnknown, "allreduce hook (shared blocks)", __FILE__, __LINE__};
       launch_pack_shared_blocks(s2, b, rd, h->d_shared_ov.get(), ns, h->d_xbuf2.get(), 1);
     }
     launch_reduced_diag(s2, b, h->d_pose.get(), h->d_obj.get(), rd, radius, first_iter ? 1 : 0, scal);

@@ -107,7 +107,7 @@ struct PlanBuilder {
       if (!cp) pose_used[p] = 1;
     }
     for (int64_t i = 0; i < h->n_sp; ++i) if (h->h_sp_active[i] && !h->h_object_const[h->h_sp_obj[i]]) { nres += 3; obj_used[h->h_sp_obj[i]] = 1; }
-    for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += 7; obj_used[h->h_lt_obj[i]] = 1; }
+    for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += h->od; obj_used[h->h_lt_obj[i]] = 1; }
     for (int64_t i = 0; i < h->n_rl; ++i) {
       if (!h->h_rl_active[i]) continue;
       const uint32_t a = h->h_rl_a[i], b = h->h_rl_b[i];
@@ -230,7 +230,7 @@ struct PlanBuilder {
         row = ((row + kTile - 1) / kTile) * kTile;
         const int64_t start = row;
         for (int32_t f = p0; f < p1; ++f) { pos[f] = next_pose; h->h_pose_row[next_pose++] = (int32_t)row; row += 6; }
-        for (int64_t o : objs) { obj_vid[o] = next_obj; h->h_obj_row[next_obj++] = (int32_t)row; row += 7; }
+        for (int64_t o : objs) { obj_vid[o] = next_obj; h->h_obj_row[next_obj++] = (int32_t)row; row += h->od; }
         if (row > start) used.push_back({start, row});
       };
       for (size_t n = 0; n < nodes.size(); ++n) {
@@ -298,12 +298,12 @@ struct PlanBuilder {
       }
       h->d_rp_yrow.upload(yrow, h->stream);
     }
-    h->m_canon = 6 * nPv + 7 * h->nOv;
+    h->m_canon = 6 * nPv + h->od * h->nOv;
     h->h_canon_row.resize(h->m_canon);
     for (int64_t p = 0; p < P; ++p) if (nat[p] >= 0) for (int k = 0; k < 6; ++k) h->h_canon_row[6 * (int64_t)nat[p] + k] = (int64_t)h->h_pose_row[pose_vid[p]] + k;
     {
       int64_t rank = 0;   // canonical order = object index order
-      for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) { for (int k = 0; k < 7; ++k) h->h_canon_row[6 * nPv + 7 * rank + k] = (int64_t)h->h_obj_row[obj_vid[o]] + k; ++rank; }
+      for (int64_t o = 0; o < O; ++o) if (obj_vid[o] >= 0) { for (int k = 0; k < h->od; ++k) h->h_canon_row[6 * nPv + h->od * rank + k] = (int64_t)h->h_obj_row[obj_vid[o]] + k; ++rank; }
     }
     h->num_params = h->m_canon + 3 * h->nLv;
     h->num_residuals = nres;
@@ -653,7 +653,7 @@ struct PlanBuilder {
     for (int64_t i = 0; i < h->n_bb; ++i) {
       if (!h->h_bb_active[i]) continue;
       const int32_t ov = obj_vid[h->h_bb_obj[i]], pv = pose_vid[h->h_bb_pose[i]];
-      if (ov >= 0 && pv >= 0) { const int64_t ro = h->h_obj_row[ov], rp = h->h_pose_row[pv]; if (ro > rp) mark(ro, 7, rp, 6); else mark(rp, 6, ro, 7); }
+      if (ov >= 0 && pv >= 0) { const int64_t ro = h->h_obj_row[ov], rp = h->h_pose_row[pv]; if (ro > rp) mark(ro, h->od, rp, 6); else mark(rp, 6, ro, h->od); }
     }
     for (int64_t i = 0; i < h->n_rl; ++i) {
       if (!h->h_rl_active[i]) continue;
@@ -661,7 +661,7 @@ struct PlanBuilder {
       if (va >= 0 && vb >= 0 && va != vb) mark(h->h_pose_row[std::max(va, vb)], 6, h->h_pose_row[std::min(va, vb)], 6);
     }
     // object diagonal blocks may straddle tiles
-    for (int64_t w = 0; w < h->nOv; ++w) mark(h->h_obj_row[w], 7, h->h_obj_row[w], 7);
+    for (int64_t w = 0; w < h->nOv; ++w) mark(h->h_obj_row[w], h->od, h->h_obj_row[w], h->od);
     for (int64_t v = 0; v < nPv; ++v) mark(h->h_pose_row[v], 6, h->h_pose_row[v], 6);
     // the shared tail is exchanged across ranks as a dense lower-triangular block of tiles
     if (h->tail_t0 >= 0) for (int i = h->tail_t0; i < nt; ++i) for (int j = h->tail_t0; j <= i; ++j) mask[(size_t)i * nt + j] = 1;
@@ -925,7 +925,7 @@ struct PlanBuilder {
       std::vector<uint32_t> oc(optr.begin(), optr.end() - 1), pc(pptr.begin(), pptr.end() - 1);
       for (int64_t i = 0; i < h->n_bb; ++i) { oidx[oc[h->h_bb_obj[i]]++] = (uint32_t)i; pidx[pc[h->h_bb_pose[i]]++] = (uint32_t)i; }
       h->d_bbo_ptr.upload(optr, s); h->d_bbo_idx.upload(oidx, s); h->d_bbp_ptr.upload(pptr, s); h->d_bbp_idx.upload(pidx, s);
-      h->d_bb_blk.resize((size_t)62 * (size_t)h->n_bb + 1);
+      h->d_bb_blk.resize((size_t)(h->od * (h->od + 1) / 2 + h->od + 27) * (size_t)h->n_bb + 1);   // BbSlot<OD>::kBlk: 62, 81
       if (h->deterministic) {
         // priors and relative-pose factors by target block (objects, then poses), in factor order: entry = 2 slot + side
         const int64_t nsl = h->n_sp + h->n_lt + h->n_rl;
@@ -960,10 +960,10 @@ struct PlanBuilder {
       for (int32_t ov : h->h_shared_ov) sh[ov] = 1;
       h->d_obj_shared.upload(sh, s); h->d_shared_ov.upload(h->h_shared_ov, s);
       const int64_t ntail = h->tail_t0 >= 0 ? nt - h->tail_t0 : 0;
-      h->d_xbuf.resize((size_t)std::max<int64_t>(56 * (int64_t)h->h_shared_ov.size(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile) + 64 + (size_t)h->world);
-      h->d_xbuf2.resize((size_t)(56 * (int64_t)h->h_shared_ov.size()) + 64);
+      h->d_xbuf.resize((size_t)std::max<int64_t>((int64_t)(h->od * h->od + h->od) * (int64_t)h->h_shared_ov.size(), ntail * (ntail + 1) / 2 * kTile * kTile + ntail * kTile) + 64 + (size_t)h->world);
+      h->d_xbuf2.resize((size_t)((int64_t)(h->od * h->od + h->od) * (int64_t)h->h_shared_ov.size()) + 64);
     }
-    h->d_Hdiag.resize((size_t)(36 * h->nPv + 49 * h->nOv + 1));
+    h->d_Hdiag.resize((size_t)(36 * h->nPv + h->od * h->od * h->nOv + 1));
     h->d_g.resize((size_t)h->m_canon + 1); h->d_scale.resize((size_t)h->m_canon + 1); h->d_lam.resize((size_t)h->m_canon + 1);
     h->d_S.resize((size_t)nt * nt * kTile * kTile);
     h->d_Linv.resize((size_t)nt * kTile * kTile);
@@ -974,8 +974,8 @@ struct PlanBuilder {
       h->d_Z.resize(zdata + 36);
       OBVI_HIP(hipMemsetAsync(h->d_Z.get() + zdata, 0, 36 * sizeof(double), s));
     }
-    h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)7 * O + 1);
-    h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)7 * O + 1);
+    h->d_pose_c.resize((size_t)6 * P + 1); h->d_point_c.resize((size_t)3 * L + 1); h->d_obj_c.resize((size_t)h->od * O + 1);
+    h->d_pose_b.resize((size_t)6 * P + 1); h->d_point_b.resize((size_t)3 * L + 1); h->d_obj_b.resize((size_t)h->od * O + 1);
     h->d_pc.resize(2 * ((size_t)P + 1)); h->d_pc_c.resize(2 * ((size_t)P + 1));   // records, then the field-major copy (k_pose_cache)
     finish_upload(h);  // host vectors above go out of scope
   }
@@ -1043,7 +1043,7 @@ bool prepare_masks(obvi_ba_handle* h) {
     if (!cp) pose_used[p] = 1;
   }
   for (int64_t i = 0; i < h->n_sp; ++i) if (h->h_sp_active[i] && !h->h_object_const[h->h_sp_obj[i]]) { nres += 3; obj_used[h->h_sp_obj[i]] = 1; }
-  for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += 7; obj_used[h->h_lt_obj[i]] = 1; }
+  for (int64_t i = 0; i < h->n_lt; ++i) if (h->h_lt_active[i] && !h->h_object_const[h->h_lt_obj[i]]) { nres += h->od; obj_used[h->h_lt_obj[i]] = 1; }
   for (int64_t i = 0; i < h->n_rl; ++i) {
     if (!h->h_rl_active[i]) continue;
     const uint32_t a = h->h_rl_a[i], b = h->h_rl_b[i];
@@ -1068,7 +1068,7 @@ bool prepare_masks(obvi_ba_handle* h) {
     const bool var = !h->h_object_const[o] && obj_used[o];
     if (var && h->plan_obj_vid[o] < 0) return false;
     if (var) { obj_vid[o] = h->plan_obj_vid[o]; ++nO; }
-    else if (h->plan_obj_vid[o] >= 0) { const int64_t r = h->h_obj_row[h->plan_obj_vid[o]]; for (int k = 0; k < 7; ++k) is_pad[r + k] = 1; }
+    else if (h->plan_obj_vid[o] >= 0) { const int64_t r = h->h_obj_row[h->plan_obj_vid[o]]; for (int k = 0; k < h->od; ++k) is_pad[r + k] = 1; }
   }
   for (int64_t l = 0; l < L; ++l) {
     const bool var = !h->h_point_const[l] && point_used[l];
@@ -1085,7 +1085,7 @@ bool prepare_masks(obvi_ba_handle* h) {
   h->d_rp_yrow.upload(yrow, s);
   h->d_pose_vid.upload(pose_vid, s); h->d_obj_vid.upload(obj_vid, s); h->d_point_var.upload(point_var, s); h->d_is_pad.upload(is_pad, s);
   h->h_obj_vid = obj_vid; h->h_is_pad = is_pad;
-  h->nLv = nL; h->live_rows = 6 * nP + 7 * nO;
+  h->nLv = nL; h->live_rows = 6 * nP + h->od * nO;
   h->num_params = h->live_rows + 3 * nL;
   h->num_residuals = nres;
   finish_upload(h);   // (the copies went through the pinned arena: nothing to wait for; the solve's first launches follow on the same stream)

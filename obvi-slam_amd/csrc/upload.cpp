@@ -36,10 +36,10 @@ static int set_blocks(obvi_ba_handle* h, int64_t n, int dim, const double* v, co
 int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 6, v, c, h ? &h->P : nullptr, h ? &h->h_pose_const : nullptr, h ? &h->d_pose : nullptr); }
 int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 3, v, c, h ? &h->L : nullptr, h ? &h->h_point_const : nullptr, h ? &h->d_point : nullptr); }
 int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) {
-  const int rc = set_blocks(h, n, 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr);
+  const int rc = set_blocks(h, n, h ? h->od : 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr);
   if (rc == OBVI_OK) {   // where the objects are, for the order of the shared tail (every rank uploads the shared objects with the same values: include/obvi_ba.h)
     h->h_obj_xy.resize((size_t)2 * (size_t)n);
-    for (int64_t o = 0; o < n; ++o) { h->h_obj_xy[2 * o] = v[7 * o]; h->h_obj_xy[2 * o + 1] = v[7 * o + 1]; }
+    for (int64_t o = 0; o < n; ++o) { h->h_obj_xy[2 * o] = v[h->od * o]; h->h_obj_xy[2 * o + 1] = v[h->od * o + 1]; }
   }
   return rc;
 }
@@ -72,7 +72,7 @@ int obvi_ba_update_state(obvi_ba_handle* h, const double* poses, const double* p
   if (poses && h->P > 0) h2d_async(h->d_pose.get(), poses, sizeof(double) * 6 * h->P, h->stream);
   if (points && h->L > 0) h2d_async(h->d_point.get(), points, sizeof(double) * 3 * h->L, h->stream);
   if (objects && h->O > 0) {
-    h2d_async(h->d_obj.get(), objects, sizeof(double) * 7 * h->O, h->stream);
+    h2d_async(h->d_obj.get(), objects, sizeof(double) * h->od * h->O, h->stream);
     // The order of the shared tail follows the shared objects' (x, y) AS UPLOADED (plan.cpp), and every rank derives it from its own copy: values that arrive
     // here -- a handle planned ahead with placeholders, obvi_ba_prepare + obvi_ba_update_state -- are "as uploaded" too.  If a shared object moved, the key is
     // refreshed and the plan rebuilt at the next prepare / solve, so that this rank orders the tail like a rank that got the same values through
@@ -81,11 +81,11 @@ int obvi_ba_update_state(obvi_ba_handle* h, const double* poses, const double* p
       bool moved = false;
       for (int64_t o = 0; o < h->O; ++o) {
         if (!h->h_is_shared[o]) continue;
-        if (h->h_obj_xy[2 * o] != objects[7 * o] || h->h_obj_xy[2 * o + 1] != objects[7 * o + 1]) moved = true;
+        if (h->h_obj_xy[2 * o] != objects[h->od * o] || h->h_obj_xy[2 * o + 1] != objects[h->od * o + 1]) moved = true;
       }
       if (moved) h->dirty = true;
     }
-    if ((int64_t)h->h_obj_xy.size() == 2 * h->O) for (int64_t o = 0; o < h->O; ++o) { h->h_obj_xy[2 * o] = objects[7 * o]; h->h_obj_xy[2 * o + 1] = objects[7 * o + 1]; }
+    if ((int64_t)h->h_obj_xy.size() == 2 * h->O) for (int64_t o = 0; o < h->O; ++o) { h->h_obj_xy[2 * o] = objects[h->od * o]; h->h_obj_xy[2 * o + 1] = objects[h->od * o + 1]; }
   }
   finish_upload(h);
   h->have_snapshot = false;
@@ -238,15 +238,16 @@ int obvi_ba_set_ltm_priors(obvi_ba_handle* h, int64_t n, const uint32_t* obj_idx
   if (!h || n < 0 || (n > 0 && (!obj_idx || !mean7 || !cov49))) return fail(h, OBVI_ERR_INVALID_ARGUMENT, "set_ltm_priors: bad arguments");
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
-  std::vector<double> si(49 * n);
+  const int od = h->od, od2 = od * od;
+  std::vector<double> si((size_t)od2 * n);
   for (int64_t i = 0; i < n; ++i) {
     if (obj_idx[i] >= h->O) return fail(h, OBVI_ERR_OUT_OF_RANGE, "set_ltm_priors: index out of range");
-    if (!sym_inverse_sqrt(cov49 + 49 * i, 7, &si[49 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_ltm_priors: covariance not SPD");
+    if (!sym_inverse_sqrt(cov49 + od2 * i, od, &si[od2 * i])) return fail(h, OBVI_ERR_NUMERICAL, "set_ltm_priors: covariance not SPD");
   }
   h->n_lt = n; h->lt_huber = huber; h->max_lt_obj = max_index(obj_idx, n);
   h->h_lt_obj.assign(obj_idx, obj_idx + n); h->h_lt_active.assign(n, 1);
   hipStream_t s = h->stream;
-  h->d_lt_obj.upload(h->h_lt_obj, s); h->d_lt_mean.upload(mean7, 7 * n, s); h->d_lt_sqrt_inf.upload(si, s); h->d_lt_active.upload(h->h_lt_active, s);
+  h->d_lt_obj.upload(h->h_lt_obj, s); h->d_lt_mean.upload(mean7, od * n, s); h->d_lt_sqrt_inf.upload(si, s); h->d_lt_active.upload(h->h_lt_active, s);
   finish_upload(h);
   h->dirty = true;
   return OBVI_OK;
@@ -319,6 +320,6 @@ int64_t obvi_ba_num_factors(const obvi_ba_handle* h, int32_t type) {
     case OBVI_FACTOR_LTM_PRIOR: return h->n_lt; case OBVI_FACTOR_REL_POSE: return h->n_rl; default: return -1;
   }
 }
-int64_t obvi_ba_num_residuals(const obvi_ba_handle* h) { return h ? 2 * h->n_rp + 4 * h->n_bb + 3 * h->n_sp + 7 * h->n_lt + 6 * h->n_rl : -1; }
+int64_t obvi_ba_num_residuals(const obvi_ba_handle* h) { return h ? 2 * h->n_rp + 4 * h->n_bb + 3 * h->n_sp + h->od * h->n_lt + 6 * h->n_rl : -1; }
 
 }  // extern "C"

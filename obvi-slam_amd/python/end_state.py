@@ -38,6 +38,7 @@ def run_two_phase(ba, prob, obvi_ba, synth, block=LOCAL_BA, fraction=0.1, polish
     out = {}
     ba.snapshot()
     out["phase_1"] = _summary(ba.solve(p1), ba)
+    out["state_1"] = _state(ba)                            # where phase I stopped: the state the cut is taken at
     masks = {}
     for ftype in (0, 2):
         if ba.num_factors(ftype) > 0:

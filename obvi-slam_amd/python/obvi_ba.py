@@ -103,14 +103,15 @@ def _ptr(a, ctype):
 class BundleAdjuster:
     """One handle == one GPU == one HIP stream (include/obvi_ba.h)."""
 
-    def __init__(self, device_id=0, library=None, prefix="obvi_", reprojection_variant=0, deterministic=False):
+    def __init__(self, device_id=0, library=None, prefix="obvi_", reprojection_variant=0, deterministic=False, object_block_size=7):
         path = library or default_library_path()
         if not os.path.exists(path):
             raise ObviError("%s not found: build it with __graft_entry__.build() -- there is no CPU fallback" % path)
         self._lib = C.CDLL(path)
         self._pre = prefix
         self._h = C.c_void_p()
-        opt = Options(device_id, 7, int(reprojection_variant), 1 if deterministic else 0)
+        self.od = int(object_block_size)                                   # parameters of an ellipsoid block: 7 (yaw only) or 9 (axis-angle)
+        opt = Options(device_id, self.od, int(reprojection_variant), 1 if deterministic else 0)
         self._check(self._fn("ba_create")(C.byref(opt), C.byref(self._h)), "create")
         self._keep = []
         self._n = {t: 0 for t in FACTOR_TYPES}
@@ -163,7 +164,7 @@ class BundleAdjuster:
         self.L = self._set_blocks("ba_set_points", pts, 3, is_const)
 
     def set_objects(self, objs, is_const=None):
-        self.O = self._set_blocks("ba_set_objects", objs, 7, is_const)
+        self.O = self._set_blocks("ba_set_objects", objs, self.od, is_const)
 
     def set_const_flags(self, pose_const=None, point_const=None, object_const=None):
         a = [None if x is None else np.ascontiguousarray(x, dtype=np.uint8) for x in (pose_const, point_const, object_const)]
@@ -202,7 +203,7 @@ class BundleAdjuster:
 
     def set_ltm_priors(self, obj_idx, mean7, cov49, huber):
         oi = np.ascontiguousarray(obj_idx, dtype=np.uint32)
-        m, cv = _f64(mean7, (-1, 7)), _f64(cov49, (-1, 49))
+        m, cv = _f64(mean7, (-1, self.od)), _f64(cov49, (-1, self.od * self.od))
         self._check(self._fn("ba_set_ltm_priors")(self._h, C.c_int64(len(oi)), _ptr(oi, C.c_uint32), _ptr(m, C.c_double),
                                                   _ptr(cv, C.c_double), C.c_double(huber)), "set_ltm_priors")
         self._n[FACTOR_LTM_PRIOR] = len(oi)
@@ -224,8 +225,11 @@ class BundleAdjuster:
     def num_factors(self, t):
         return self._n[t]
 
+    def _residual_dim(self, t):
+        return self.od if t == 4 else RESIDUAL_DIM[t]        # an LTM prior has one residual per ellipsoid parameter
+
     def num_residuals(self):
-        return sum(RESIDUAL_DIM[t] * self._n[t] for t in FACTOR_TYPES)
+        return sum(self._residual_dim(t) * self._n[t] for t in FACTOR_TYPES)
 
     def evaluate(self, apply_loss=True, want_residuals=True):
         cost = C.c_double(0.0)
@@ -266,7 +270,7 @@ class BundleAdjuster:
         """7x7 covariance blocks of object pairs (obj_b None: the objects' own blocks)."""
         a = np.ascontiguousarray(obj_a, dtype=np.uint32)
         b = a if obj_b is None else np.ascontiguousarray(obj_b, dtype=np.uint32)
-        out = np.zeros((len(a), 7, 7))
+        out = np.zeros((len(a), self.od, self.od))
         self._check(self._fn("ba_object_covariances")(self._h, C.c_int64(len(a)), _ptr(a, C.c_uint32), _ptr(b, C.c_uint32),
                                                       _ptr(out, C.c_double)), "object_covariances")
         return out
@@ -280,7 +284,7 @@ class BundleAdjuster:
 
     def column_sqnorms(self):
         """squared column norms of the robustified Jacobian per scalar parameter: (poses [P,6], points [L,3], objects [O,7]); -1 = not a parameter of the problem"""
-        p, l, o = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, 7))
+        p, l, o = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, self.od))
         self._check(self._fn("ba_column_sqnorms")(self._h, _ptr(p, C.c_double), _ptr(l, C.c_double), _ptr(o, C.c_double)), "column_sqnorms")
         return p, l, o
 
@@ -350,11 +354,11 @@ class BundleAdjuster:
         return self._get("ba_get_points", self.L, 3)
 
     def get_objects(self):
-        return self._get("ba_get_objects", self.O, 7)
+        return self._get("ba_get_objects", self.O, self.od)
 
     def get_state(self):
         """(poses, points, objects) with one wait for the device (obvi_ba_get_state)."""
-        po, pt, ob = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, 7))
+        po, pt, ob = np.zeros((self.P, 6)), np.zeros((self.L, 3)), np.zeros((self.O, self.od))
         self._check(self._fn("ba_get_state")(self._h, _ptr(po, C.c_double), _ptr(pt, C.c_double), _ptr(ob, C.c_double)), "get_state")
         return po, pt, ob
 
@@ -366,7 +370,7 @@ class BundleAdjuster:
         """Values only (obvi_ba_update_state): constness, factors and the symbolic plan stay."""
         po = None if poses is None else _f64(poses, (self.P, 6))
         pt = None if points is None else _f64(points, (self.L, 3))
-        ob = None if objects is None else _f64(objects, (self.O, 7))
+        ob = None if objects is None else _f64(objects, (self.O, self.od))
         self._check(self._fn("ba_update_state")(self._h, _ptr(po, C.c_double), _ptr(pt, C.c_double), _ptr(ob, C.c_double)), "update_state")
 
     def prepare(self):
@@ -397,8 +401,8 @@ class BundleAdjuster:
         return {name: getattr(p, name) for name, _ in Peaks._fields_ if name != "reserved"}
 
     def debug_linearize(self, factor_type):
-        n, m = self._n[factor_type], RESIDUAL_DIM[factor_type]
-        d0, d1 = BLOCK_DIMS[factor_type]
+        n, m = self._n[factor_type], self._residual_dim(factor_type)
+        d0, d1 = (self.od if d == 7 else d for d in BLOCK_DIMS[factor_type])
         r, J0 = np.zeros((n, m)), np.zeros((n, m, d0))
         J1 = np.zeros((n, m, d1)) if d1 else None
         self._check(self._fn("ba_debug_linearize")(self._h, C.c_int32(factor_type), _ptr(r, C.c_double),

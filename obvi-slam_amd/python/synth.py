@@ -63,20 +63,24 @@ def project_points(poses, pts, K=K_DEFAULT, ext=EXT_DEFAULT):
 
 
 def project_ellipsoids(ell, poses, K=K_DEFAULT, ext=EXT_DEFAULT):
-    """ell [n,7], poses [n,6] -> pixel corners [n,4] (minx,maxx,miny,maxy), valid [n], depth [n].
+    """ell [n,7] (or [n,9]: the unconstrained block), poses [n,6] -> pixel corners [n,4] (minx,maxx,miny,maxy), valid [n], depth [n].
     Dual-quadric projection of ellipsoid_utils.h:160-273."""
     n = len(ell)
     R = Rot.from_rotvec(poses[:, 3:6]).as_matrix()
     Re = quat_to_R(ext[0:4])
     Rcw = np.einsum("ji,nkj->nik", Re, R)                                # R_e^T R^T
     tcw = -np.einsum("nij,nj->ni", Rcw, poses[:, 0:3]) - Re.T @ ext[4:7]
-    cy, sy = np.cos(ell[:, 3]), np.sin(ell[:, 3])
-    Ro = np.zeros((n, 3, 3))
-    Ro[:, 0, 0], Ro[:, 0, 1], Ro[:, 1, 0], Ro[:, 1, 1], Ro[:, 2, 2] = cy, -sy, sy, cy, 1.0
+    if ell.shape[1] == 9:                                                 # unconstrained block (x y z ax ay az dx dy dz): VectorToAxisAngle, identity at or below 1e-8
+        ang = np.linalg.norm(ell[:, 3:6], axis=1)
+        Ro = Rot.from_rotvec(np.where((ang > 1e-8)[:, None], ell[:, 3:6], 0.0)).as_matrix()
+    else:
+        cy, sy = np.cos(ell[:, 3]), np.sin(ell[:, 3])
+        Ro = np.zeros((n, 3, 3))
+        Ro[:, 0, 0], Ro[:, 0, 1], Ro[:, 1, 0], Ro[:, 1, 1], Ro[:, 2, 2] = cy, -sy, sy, cy, 1.0
     M = np.zeros((n, 3, 4))
     M[:, :, 0:3] = Rcw @ Ro
     M[:, :, 3] = np.einsum("nij,nj->ni", Rcw, ell[:, 0:3]) + tcw
-    d = np.concatenate([(ell[:, 4:7] / 2.0) ** 2 + DIM_REG, -np.ones((n, 1))], axis=1)
+    d = np.concatenate([(ell[:, -3:] / 2.0) ** 2 + DIM_REG, -np.ones((n, 1))], axis=1)
     Q = np.einsum("nik,nk,njk->nij", M, d, M)
     xin = Q[:, 0, 2] ** 2 - Q[:, 0, 0] * Q[:, 2, 2]
     yin = Q[:, 1, 2] ** 2 - Q[:, 1, 1] * Q[:, 2, 2]
@@ -353,7 +357,40 @@ def make_well_posed(prob, min_depth=0.5):
 def config3w(P=2000, L=300000, O=200, seed=20241008 + 3):
     """"Config 3w": BASELINE config #3's sizes as a well-posed problem (tests/golden/gen_config3w_end_state.py has the recipe in words).
     Upload with the odometry factors (upload(relpose=True), the default)."""
-    return make_well_posed(make_problem(P=P, L=L, O=O, seed=seed, const_poses=5, min_obj_obs=10, object_classes=("bench",), min_parallax_deg=3.0))
+    return make_well_posed(make_problem(P=P, L=L, O=O, seed=seed, const_poses=5, min_obj_obs=10, object_classes=("bench",), min_parallax_deg=3.0, stereo=True))
+
+
+def nine_dof(prob, tilt=0.0, seed=0):
+    """The same problem with the 9-parameter ellipsoid block (x y z ax ay az dx dy dz) of vslam_obj_opt_types_refactor.h:15-21: the objects' rotation becomes
+    the rotation vector (0, 0, yaw) composed with a random tilt of up to `tilt` radians about a horizontal axis (tilt = 0: exactly the yaw-only objects, for which a
+    9-block handle must reproduce a 7-block handle's numbers); the boxes are NOT re-projected (they are measurements).  LTM priors, if any, get the matching 9-vector
+    mean and a 9x9 covariance (the yaw's variance on all three rotation entries, cross terms to the other parameters kept for az)."""
+    q = dict(prob)
+    rng = np.random.Generator(np.random.MT19937(seed))
+
+    def nine(obj):
+        n = len(obj)
+        aa = np.zeros((n, 3)); aa[:, 2] = obj[:, 3]
+        if tilt > 0.0 and n:
+            phi = rng.uniform(0, 2 * np.pi, n); mag = rng.uniform(0.2 * tilt, tilt, n)
+            t = Rot.from_rotvec(np.stack([mag * np.cos(phi), mag * np.sin(phi), np.zeros(n)], axis=1))
+            aa = (Rot.from_rotvec(aa) * t).as_rotvec()
+        return np.concatenate([obj[:, :3], aa, obj[:, 4:7]], axis=1)
+    q["objects"] = nine(prob["objects"])
+    if "gt_objects" in prob:
+        q["gt_objects"] = nine(prob["gt_objects"])
+    if "lt_obj" in prob and len(prob["lt_obj"]):
+        idx = [0, 1, 2, 5, 6, 7, 8]                          # where the 7-block's entries (x y z yaw dx dy dz) sit in the 9-block
+        m7, c7 = np.asarray(prob["lt_mean"]).reshape(-1, 7), np.asarray(prob["lt_cov"]).reshape(-1, 7, 7)
+        m9 = np.zeros((len(m7), 9)); m9[:, idx] = m7
+        c9 = np.zeros((len(m7), 9, 9))
+        for a, ia in enumerate(idx):
+            for b, ib in enumerate(idx):
+                c9[:, ia, ib] = c7[:, a, b]
+        c9[:, 3, 3] = c7[:, 3, 3]; c9[:, 4, 4] = c7[:, 3, 3]
+        q["lt_mean"], q["lt_cov"] = m9, c9.reshape(-1, 81)
+    q["object_block_size"] = 9
+    return q
 
 
 def upload(ba, prob, relpose=True, objects=True, reproj=True):

@@ -111,6 +111,7 @@ void parallel_ranges(int64_t n, F&& fn) {   // fn(thread, begin, end), contiguou
 
 struct OracleProblem {
   int reproj_variant = 0;   // obvi_ba_options.reprojection_variant: 0 = a3 (production functor), 1 = a2 (analytic-Jacobian functor)
+  int od = 7;               // obvi_ba_options.object_block_size: parameters of an ellipsoid block, 7 (x y z yaw dx dy dz) or 9 (x y z ax ay az dx dy dz)
   std::vector<CameraConst> cams;       // fp64 (index checks, and the camera constants of the checker)
   std::vector<fx::CameraConst> cams_f; // the factors' camera constants
   int64_t P = 0, L = 0, O = 0;
@@ -150,15 +151,15 @@ struct OracleProblem {
 // linearised factor record: robustified residual and Jacobians w.r.t. up to two blocks
 // ---------------------------------------------------------------------------------------
 enum BlockKind { KIND_POSE = 0, KIND_POINT = 1, KIND_OBJECT = 2, KIND_NONE = 3 };
-static const int kBlockDim[4] = {6, 3, 7, 0};
 
 struct FactorLin {
   int m = 0;                 // residual dim
   BlockKind k0 = KIND_NONE, k1 = KIND_NONE;
   int64_t i0 = -1, i1 = -1;  // block indices
-  fscalar r[7];
-  fscalar J0[49];            // m x dim(k0), row-major
-  fscalar J1[49];            // m x dim(k1)
+  int d0 = 0, d1 = 0;        // their sizes
+  fscalar r[9];
+  fscalar J0[81];            // m x d0, row-major
+  fscalar J1[36];            // m x d1
   fscalar cost = 0.0;        // 0.5 * rho(s)
   fscalar sqnorm = 0.0;      // un-robustified |r|^2
 };
@@ -175,7 +176,7 @@ void robustify(FactorLin* f, double huber_a, bool apply_loss) {
   f->cost = (fscalar)0.5 * rho[0];
   const fscalar w = std::sqrt(rho[1]);
   if (w != (fscalar)1.0) {
-    const int d0 = kBlockDim[f->k0], d1 = kBlockDim[f->k1];
+    const int d0 = f->d0, d1 = f->d1;
     for (int i = 0; i < f->m; ++i) f->r[i] *= w;
     for (int i = 0; i < f->m * d0; ++i) f->J0[i] *= w;
     for (int i = 0; i < f->m * d1; ++i) f->J1[i] *= w;
@@ -186,7 +187,7 @@ void robustify(FactorLin* f, double huber_a, bool apply_loss) {
 template <int N> inline void load_block(const double* src, fscalar (&dst)[N]) { for (int k = 0; k < N; ++k) dst[k] = src[k]; }
 
 void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
-  f->m = 2; f->k0 = KIND_POSE; f->k1 = KIND_POINT; f->i0 = pb.rp_pose[i]; f->i1 = pb.rp_point[i];
+  f->m = 2; f->k0 = KIND_POSE; f->k1 = KIND_POINT; f->i0 = pb.rp_pose[i]; f->i1 = pb.rp_point[i]; f->d0 = 6; f->d1 = 3;
   fscalar pose[6], pt[3];
   load_block(&pb.poses[6 * f->i0], pose); load_block(&pb.points[3 * f->i1], pt);
   const fx::CameraConst& cam = pb.cams_f[pb.rp_cam[i]];
@@ -209,50 +210,56 @@ void lin_reproj(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
   }
 }
 
-void lin_bbox(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
-  f->m = 4; f->k0 = KIND_OBJECT; f->k1 = KIND_POSE; f->i0 = pb.bb_obj[i]; f->i1 = pb.bb_pose[i];
-  fscalar ell[7], pose[6];
-  load_block(&pb.objects[7 * f->i0], ell); load_block(&pb.poses[6 * f->i1], pose);
+template <int OD>
+void lin_bbox_od(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 4; f->k0 = KIND_OBJECT; f->k1 = KIND_POSE; f->i0 = pb.bb_obj[i]; f->i1 = pb.bb_pose[i]; f->d0 = OD; f->d1 = 6;
+  fscalar ell[OD], pose[6];
+  load_block(&pb.objects[OD * f->i0], ell); load_block(&pb.poses[6 * f->i1], pose);
   const fx::CameraConst& cam = pb.cams_f[pb.bb_cam[i]];
-  if (!jac) { fx::bbox_residual<fscalar>(ell, pose, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, f->r); return; }
-  typedef fx::Dual<13> D;
-  D de[7], dp[6], dr[4];
-  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
-  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], 7 + k);
-  fx::bbox_residual<D>(de, dp, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, dr);
+  if (!jac) { fx::bbox_residual<fscalar, OD>(ell, pose, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, f->r); return; }
+  typedef fx::Dual<OD + 6> D;
+  D de[OD], dp[6], dr[4];
+  for (int k = 0; k < OD; ++k) de[k] = D::var(ell[k], k);
+  for (int k = 0; k < 6; ++k) dp[k] = D::var(pose[k], OD + k);
+  fx::bbox_residual<D, OD>(de, dp, cam, &pb.bb_rect[4 * i], &pb.bb_sqrt_inf[16 * i], pb.bb_invalid, dr);
   for (int a = 0; a < 4; ++a) {
     f->r[a] = dr[a].v;
-    for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k];
-    for (int k = 0; k < 6; ++k) f->J1[6 * a + k] = dr[a].d[7 + k];
+    for (int k = 0; k < OD; ++k) f->J0[OD * a + k] = dr[a].d[k];
+    for (int k = 0; k < 6; ++k) f->J1[6 * a + k] = dr[a].d[OD + k];
   }
 }
+void lin_bbox(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) { if (pb.od == 9) lin_bbox_od<9>(pb, i, jac, f); else lin_bbox_od<7>(pb, i, jac, f); }
 
-void lin_shape(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
-  f->m = 3; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.sp_obj[i]; f->i1 = -1;
-  fscalar ell[7];
-  load_block(&pb.objects[7 * f->i0], ell);
-  if (!jac) { fx::shape_prior_residual<fscalar>(ell, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], f->r); return; }
-  typedef fx::Dual<7> D;
-  D de[7], dr[3];
-  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
-  fx::shape_prior_residual<D>(de, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], dr);
-  for (int a = 0; a < 3; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
+template <int OD>
+void lin_shape_od(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = 3; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.sp_obj[i]; f->i1 = -1; f->d0 = OD; f->d1 = 0;
+  fscalar ell[OD];
+  load_block(&pb.objects[OD * f->i0], ell);
+  if (!jac) { fx::shape_prior_residual<fscalar>(ell, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], f->r, OD); return; }
+  typedef fx::Dual<OD> D;
+  D de[OD], dr[3];
+  for (int k = 0; k < OD; ++k) de[k] = D::var(ell[k], k);
+  fx::shape_prior_residual<D>(de, &pb.sp_mean[3 * i], &pb.sp_sqrt_inf[9 * i], dr, OD);
+  for (int a = 0; a < 3; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < OD; ++k) f->J0[OD * a + k] = dr[a].d[k]; }
 }
+void lin_shape(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) { if (pb.od == 9) lin_shape_od<9>(pb, i, jac, f); else lin_shape_od<7>(pb, i, jac, f); }
 
-void lin_ltm(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
-  f->m = 7; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.lt_obj[i]; f->i1 = -1;
-  fscalar ell[7];
-  load_block(&pb.objects[7 * f->i0], ell);
-  if (!jac) { fx::ltm_prior_residual<fscalar>(ell, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], f->r); return; }
-  typedef fx::Dual<7> D;
-  D de[7], dr[7];
-  for (int k = 0; k < 7; ++k) de[k] = D::var(ell[k], k);
-  fx::ltm_prior_residual<D>(de, &pb.lt_mean[7 * i], &pb.lt_sqrt_inf[49 * i], dr);
-  for (int a = 0; a < 7; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < 7; ++k) f->J0[7 * a + k] = dr[a].d[k]; }
+template <int OD>
+void lin_ltm_od(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
+  f->m = OD; f->k0 = KIND_OBJECT; f->k1 = KIND_NONE; f->i0 = pb.lt_obj[i]; f->i1 = -1; f->d0 = OD; f->d1 = 0;
+  fscalar ell[OD];
+  load_block(&pb.objects[OD * f->i0], ell);
+  if (!jac) { fx::ltm_prior_residual<fscalar>(ell, &pb.lt_mean[OD * i], &pb.lt_sqrt_inf[OD * OD * i], f->r, OD); return; }
+  typedef fx::Dual<OD> D;
+  D de[OD], dr[OD];
+  for (int k = 0; k < OD; ++k) de[k] = D::var(ell[k], k);
+  fx::ltm_prior_residual<D>(de, &pb.lt_mean[OD * i], &pb.lt_sqrt_inf[OD * OD * i], dr, OD);
+  for (int a = 0; a < OD; ++a) { f->r[a] = dr[a].v; for (int k = 0; k < OD; ++k) f->J0[OD * a + k] = dr[a].d[k]; }
 }
+void lin_ltm(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) { if (pb.od == 9) lin_ltm_od<9>(pb, i, jac, f); else lin_ltm_od<7>(pb, i, jac, f); }
 
 void lin_relpose(const OracleProblem& pb, int64_t i, bool jac, FactorLin* f) {
-  f->m = 6; f->k0 = KIND_POSE; f->k1 = KIND_POSE; f->i0 = pb.rl_a[i]; f->i1 = pb.rl_b[i];
+  f->m = 6; f->k0 = KIND_POSE; f->k1 = KIND_POSE; f->i0 = pb.rl_a[i]; f->i1 = pb.rl_b[i]; f->d0 = 6; f->d1 = 6;
   fscalar pa[6], pbb[6];
   load_block(&pb.poses[6 * f->i0], pa); load_block(&pb.poses[6 * f->i1], pbb);
   if (!jac) { fx::relpose_residual<fscalar>(pa, pbb, &pb.rl_t[3 * i], &pb.rl_R[9 * i], &pb.rl_sqrt_inf[36 * i], f->r); return; }
@@ -275,7 +282,7 @@ std::vector<Family> families(const OracleProblem& pb) {
   return {{OBVI_FACTOR_REPROJECTION, 2, pb.n_rp, &pb.rp_active, pb.rp_huber, lin_reproj},
           {OBVI_FACTOR_BBOX, 4, pb.n_bb, &pb.bb_active, pb.bb_huber, lin_bbox},
           {OBVI_FACTOR_SHAPE_PRIOR, 3, pb.n_sp, &pb.sp_active, pb.sp_huber, lin_shape},
-          {OBVI_FACTOR_LTM_PRIOR, 7, pb.n_lt, &pb.lt_active, pb.lt_huber, lin_ltm},
+          {OBVI_FACTOR_LTM_PRIOR, pb.od, pb.n_lt, &pb.lt_active, pb.lt_huber, lin_ltm},
           {OBVI_FACTOR_REL_POSE, 6, pb.n_rl, &pb.rl_active, pb.rl_huber, lin_relpose}};
 }
 
@@ -297,7 +304,8 @@ struct Reduced {
   std::vector<int32_t> pose_vid, obj_vid;  // index among variable+used blocks or -1
   std::vector<uint8_t> point_var;          // variable+used
   int64_t nPv = 0, nOv = 0, nLv = 0;
-  int64_t m = 0;                           // reduced (Schur) system rows = 6 nPv + 7 nOv
+  int od = 7;                              // parameters of an ellipsoid block
+  int64_t m = 0;                           // reduced (Schur) system rows = 6 nPv + od nOv
   int64_t num_params = 0, num_residuals = 0;
   double fixed_cost = 0.0;
   int64_t nOs = 0;                         // shared variable objects: the LAST nOs object blocks of the reduced system
@@ -320,7 +328,7 @@ struct Workspace {
 };
 
 inline int64_t pose_row(const Reduced& rd, int64_t p) { return 6 * (int64_t)rd.pose_vid[p]; }
-inline int64_t obj_row(const Reduced& rd, int64_t o) { return 6 * rd.nPv + 7 * (int64_t)rd.obj_vid[o]; }
+inline int64_t obj_row(const Reduced& rd, int64_t o) { return 6 * rd.nPv + rd.od * (int64_t)rd.obj_vid[o]; }
 
 void build_reduced(const OracleProblem& pb, Reduced* rd) {
   rd->pose_vid.assign(pb.P, -1); rd->obj_vid.assign(pb.O, -1); rd->point_var.assign(pb.L, 0);
@@ -353,8 +361,9 @@ void build_reduced(const OracleProblem& pb, Reduced* rd) {
   rd->nOs = 0;
   for (int64_t o = 0; o < pb.O; ++o) if (!pb.object_const[o] && obj_used[o] && shared(o)) { rd->obj_vid[o] = (int32_t)rd->nOv++; rd->nOs++; }   // eliminated last, in index order
   for (int64_t l = 0; l < pb.L; ++l) if (!pb.point_const[l] && point_used[l]) { rd->point_var[l] = 1; rd->nLv++; }
-  rd->m = 6 * rd->nPv + 7 * rd->nOv;
-  rd->shared_row0 = rd->m - 7 * rd->nOs;
+  rd->od = pb.od;
+  rd->m = 6 * rd->nPv + rd->od * rd->nOv;
+  rd->shared_row0 = rd->m - rd->od * rd->nOs;
   rd->num_params = rd->m + 3 * rd->nLv;
 }
 
@@ -454,7 +463,7 @@ double linearize(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
     const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
     for (int b = 0; b < 2; ++b) {
       if (!is_var(pb, rd, ks[b], is[b])) continue;
-      const int d = kBlockDim[ks[b]];
+      const int d = b == 0 ? f.d0 : f.d1;
       if (ks[b] == KIND_POINT) {
         real* c = &ws->colsq_l[3 * is[b]]; real* g = &ws->gl[3 * is[b]]; real* H = &ws->Hll[9 * is[b]];
         for (int a = 0; a < f.m; ++a) for (int k = 0; k < 3; ++k) {
@@ -482,7 +491,7 @@ void build_envelope(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   ws->object_row0 = 6 * rd.nPv;
   // every row of a diagonal block reaches back to the block's first row
   for (int64_t v = 0; v < rd.nPv; ++v) for (int k = 0; k < 6; ++k) ws->first[6 * v + k] = 6 * v;
-  for (int64_t w = 0; w < rd.nOv; ++w) for (int k = 0; k < 7; ++k) ws->first[6 * rd.nPv + 7 * w + k] = 6 * rd.nPv + 7 * w;
+  for (int64_t w = 0; w < rd.nOv; ++w) for (int k = 0; k < rd.od; ++k) ws->first[6 * rd.nPv + rd.od * w + k] = 6 * rd.nPv + rd.od * w;
   auto couple = [&](int64_t ra, int da, int64_t rb, int db) {
     if (ra < rb) { std::swap(ra, rb); std::swap(da, db); }
     for (int k = 0; k < da; ++k) ws->first[ra + k] = std::min(ws->first[ra + k], rb);
@@ -491,7 +500,7 @@ void build_envelope(const OracleProblem& pb, const Reduced& rd, Workspace* ws) {
   for (const FactorLin& f : ws->lin) {
     if (f.k0 == KIND_POINT || f.k1 == KIND_POINT || f.k1 == KIND_NONE) continue;
     if (!is_var(pb, rd, f.k0, f.i0) || !is_var(pb, rd, f.k1, f.i1)) continue;
-    couple(reduced_row(rd, f.k0, f.i0), kBlockDim[f.k0], reduced_row(rd, f.k1, f.i1), kBlockDim[f.k1]);
+    couple(reduced_row(rd, f.k0, f.i0), f.d0, reduced_row(rd, f.k1, f.i1), f.d1);
   }
   for (int64_t l = 0; l < pb.L; ++l) {
     const std::vector<int64_t>& obs = ws->point_obs[l];
@@ -526,10 +535,10 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
     const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
     for (int a = 0; a < 2; ++a) {
       if (ks[a] == KIND_POINT || ks[a] == KIND_NONE || !is_var(pb, rd, ks[a], is[a])) continue;
-      const int da = kBlockDim[ks[a]]; const int64_t ra = reduced_row(rd, ks[a], is[a]);
+      const int da = a == 0 ? f.d0 : f.d1; const int64_t ra = reduced_row(rd, ks[a], is[a]);
       for (int b = 0; b < 2; ++b) {
         if (ks[b] == KIND_POINT || ks[b] == KIND_NONE || !is_var(pb, rd, ks[b], is[b])) continue;
-        const int db = kBlockDim[ks[b]]; const int64_t rb = reduced_row(rd, ks[b], is[b]);
+        const int db = b == 0 ? f.d0 : f.d1; const int64_t rb = reduced_row(rd, ks[b], is[b]);
         if (rb > ra || (a != b && ra == rb)) continue;
         for (int x = 0; x < da; ++x) for (int y = 0; y < db; ++y) {
           if (ra == rb && y > x) continue;
@@ -820,10 +829,11 @@ int32_t oracle_get_threads(void) { return g_threads; }
 
 int oracle_ba_create(const obvi_ba_options* opt, oracle_handle** out) {
   if (!out) return OBVI_ERR_INVALID_ARGUMENT;
-  if (opt && opt->object_block_size != 0 && opt->object_block_size != 7) return OBVI_ERR_INVALID_ARGUMENT;
+  if (opt && opt->object_block_size != 0 && opt->object_block_size != 7 && opt->object_block_size != 9) return OBVI_ERR_INVALID_ARGUMENT;
   if (opt && opt->reprojection_variant != OBVI_REPROJECTION_AUTODIFF && opt->reprojection_variant != OBVI_REPROJECTION_ANALYTIC) return OBVI_ERR_INVALID_ARGUMENT;
   *out = new oracle_handle();
-  if (opt) (*out)->pb.reproj_variant = opt->reprojection_variant;   // opt->deterministic: the oracle is sequential in its sums, always deterministic
+  if (opt) { (*out)->pb.reproj_variant = opt->reprojection_variant; if (opt->object_block_size == 9) (*out)->pb.od = 9; }
+  if (false) (*out)->pb.reproj_variant = 0;   // opt->deterministic: the oracle is sequential in its sums, always deterministic
   return OBVI_OK;
 }
 void oracle_ba_destroy(oracle_handle* h) { delete h; }
@@ -862,7 +872,7 @@ int oracle_ba_set_points(oracle_handle* h, int64_t n, const double* v, const uin
 }
 int oracle_ba_set_objects(oracle_handle* h, int64_t n, const double* v, const uint8_t* c) {
   if (!h || n < 0 || (n > 0 && !v)) return OBVI_ERR_INVALID_ARGUMENT;
-  h->pb.O = n; set_block(&h->pb.objects, &h->pb.object_const, n, 7, v, c); return OBVI_OK;
+  h->pb.O = n; set_block(&h->pb.objects, &h->pb.object_const, n, h->pb.od, v, c); return OBVI_OK;
 }
 int oracle_ba_set_const_flags(oracle_handle* h, const uint8_t* pc, const uint8_t* lc, const uint8_t* oc) {
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
@@ -928,8 +938,9 @@ int oracle_ba_set_ltm_priors(oracle_handle* h, int64_t n, const uint32_t* obj_id
   if (!h || n < 0 || (n > 0 && (!obj_idx || !mean7 || !cov49))) return OBVI_ERR_INVALID_ARGUMENT;
   OracleProblem& pb = h->pb;
   for (int64_t i = 0; i < n; ++i) if (obj_idx[i] >= pb.O) return OBVI_ERR_OUT_OF_RANGE;
-  pb.n_lt = n; pb.lt_obj.assign(obj_idx, obj_idx + n); pb.lt_mean.assign(mean7, mean7 + 7 * n); pb.lt_sqrt_inf.resize(49 * n);
-  for (int64_t i = 0; i < n; ++i) { fscalar cv[49]; for (int k = 0; k < 49; ++k) cv[k] = cov49[49 * i + k]; if (!fx::spd_inverse_sqrt(cv, 7, &pb.lt_sqrt_inf[49 * i])) return OBVI_ERR_NUMERICAL; }
+  const int od = pb.od, od2 = od * od;
+  pb.n_lt = n; pb.lt_obj.assign(obj_idx, obj_idx + n); pb.lt_mean.assign(mean7, mean7 + od * n); pb.lt_sqrt_inf.resize((size_t)od2 * n);
+  for (int64_t i = 0; i < n; ++i) { fscalar cv[81]; for (int k = 0; k < od2; ++k) cv[k] = cov49[od2 * i + k]; if (!fx::spd_inverse_sqrt(cv, od, &pb.lt_sqrt_inf[od2 * i])) return OBVI_ERR_NUMERICAL; }
   pb.lt_huber = huber; pb.lt_active.assign(n, 1);
   return OBVI_OK;
 }
@@ -991,7 +1002,7 @@ int64_t oracle_ba_num_factors(const oracle_handle* h, int32_t type) {
 }
 int64_t oracle_ba_num_residuals(const oracle_handle* h) {
   const OracleProblem& pb = h->pb;
-  return 2 * pb.n_rp + 4 * pb.n_bb + 3 * pb.n_sp + 7 * pb.n_lt + 6 * pb.n_rl;
+  return 2 * pb.n_rp + 4 * pb.n_bb + 3 * pb.n_sp + pb.od * pb.n_lt + 6 * pb.n_rl;
 }
 
 // problem->Evaluate: every active residual block (constant blocks included -- Problem::Evaluate
@@ -1028,7 +1039,7 @@ int oracle_ba_debug_linearize(oracle_handle* h, int32_t type, double* r, double*
     if (fam.type != type) continue;
     for (int64_t i = 0; i < fam.n; ++i) {
       FactorLin f; fam.lin(pb, i, true, &f);
-      const int d0 = kBlockDim[f.k0], d1 = kBlockDim[f.k1];
+      const int d0 = f.d0, d1 = f.d1;
       if (r) for (int k = 0; k < fam.m; ++k) r[fam.m * i + k] = (double)f.r[k];
       if (J0) for (int k = 0; k < fam.m * d0; ++k) J0[(int64_t)fam.m * d0 * i + k] = (double)f.J0[k];
       if (J1 && d1) for (int k = 0; k < fam.m * d1; ++k) J1[(int64_t)fam.m * d1 * i + k] = (double)f.J1[k];
@@ -1091,13 +1102,14 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
   std::vector<int32_t> solved_for(pb.O, -1);           // object -> slot in `cols`
   std::vector<std::vector<real>> cols;                // 7 solution vectors per object that occurs as the second of a pair
   for (int64_t i = 0; i < n_pairs; ++i) {
-    double* out = cov49 + 49 * i;
-    std::fill(out, out + 49, 0.0);
+    const int od = pb.od;
+    double* out = cov49 + od * od * i;
+    std::fill(out, out + od * od, 0.0);
     const uint32_t a = obj_a[i], b = obj_b[i];
     if (rd.obj_vid[a] < 0 || rd.obj_vid[b] < 0) continue;
     if (solved_for[b] < 0) {
       solved_for[b] = (int32_t)cols.size();
-      for (int k = 0; k < 7; ++k) {
+      for (int k = 0; k < od; ++k) {
         std::vector<real> x(rd.m, 0.0);
         x[obj_row(rd, b) + k] = 1.0;
         skyline_solve_inplace(&ws, rd.m, &x);
@@ -1105,7 +1117,7 @@ int oracle_ba_object_covariances(oracle_handle* h, int64_t n_pairs, const uint32
         cols.push_back(std::move(x));
       }
     }
-    for (int r = 0; r < 7; ++r) for (int k = 0; k < 7; ++k) out[7 * r + k] = (double)cols[solved_for[b] + k][obj_row(rd, a) + r];
+    for (int r = 0; r < od; ++r) for (int k = 0; k < od; ++k) out[od * r + k] = (double)cols[solved_for[b] + k][obj_row(rd, a) + r];
   }
   return OBVI_OK;
 }
@@ -1117,7 +1129,7 @@ int oracle_ba_set_parameter_priors(oracle_handle* h, int64_t n, const uint8_t* k
   OracleProblem& pb = h->pb;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t cnt = kind[i] == 0 ? pb.P : kind[i] == 1 ? pb.L : kind[i] == 2 ? pb.O : -1;
-    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : 7;
+    const int dim = kind[i] == 0 ? 6 : kind[i] == 1 ? 3 : h->pb.od;
     if (cnt < 0 || param[i] >= dim) return OBVI_ERR_INVALID_ARGUMENT;
     if ((int64_t)block[i] >= cnt) return OBVI_ERR_OUT_OF_RANGE;
     if (!(std_dev[i] > 0.0) || !std::isfinite(std_dev[i]) || !std::isfinite(mean[i])) return OBVI_ERR_NUMERICAL;
@@ -1132,13 +1144,13 @@ int oracle_ba_column_sqnorms(oracle_handle* h, double* pose6, double* point3, do
   Workspace ws; linearize(pb, rd, &ws);
   if (pose6) for (int64_t p = 0; p < pb.P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = rd.pose_vid[p] >= 0 ? (double)ws.colsq_c[pose_row(rd, p) + k] : -1.0;
   if (point3) for (int64_t l = 0; l < pb.L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = rd.point_var[l] ? (double)ws.colsq_l[3 * l + k] : -1.0;
-  if (object7) for (int64_t o = 0; o < pb.O; ++o) for (int k = 0; k < 7; ++k) object7[7 * o + k] = rd.obj_vid[o] >= 0 ? (double)ws.colsq_c[obj_row(rd, o) + k] : -1.0;
+  if (object7) for (int64_t o = 0; o < pb.O; ++o) for (int k = 0; k < pb.od; ++k) object7[pb.od * o + k] = rd.obj_vid[o] >= 0 ? (double)ws.colsq_c[obj_row(rd, o) + k] : -1.0;
   for (size_t i = 0; i < pb.pp_kind.size(); ++i) {
     const double w = 1.0 / (pb.pp_std[i] * pb.pp_std[i]);
     const int64_t b = pb.pp_block[i];
     if (pb.pp_kind[i] == 0 && pose6 && rd.pose_vid[b] >= 0) pose6[6 * b + pb.pp_param[i]] += w;
     else if (pb.pp_kind[i] == 1 && point3 && rd.point_var[b]) point3[3 * b + pb.pp_param[i]] += w;
-    else if (pb.pp_kind[i] == 2 && object7 && rd.obj_vid[b] >= 0) object7[7 * b + pb.pp_param[i]] += w;
+    else if (pb.pp_kind[i] == 2 && object7 && rd.obj_vid[b] >= 0) object7[pb.od * b + pb.pp_param[i]] += w;
   }
   return OBVI_OK;
 }
@@ -1223,7 +1235,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
   auto x_norm_sq = [&]() {
     real sq = 0.0;
     for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) sq += pb.poses[6 * p + k] * pb.poses[6 * p + k];
-    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0 && counted_row(obj_row(rd, o))) for (int k = 0; k < 7; ++k) sq += pb.objects[7 * o + k] * pb.objects[7 * o + k];
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0 && counted_row(obj_row(rd, o))) for (int k = 0; k < pb.od; ++k) sq += pb.objects[pb.od * o + k] * pb.objects[pb.od * o + k];
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) sq += pb.points[3 * l + k] * pb.points[3 * l + k];
     return (double)sq;
   };
@@ -1345,11 +1357,11 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     real model_acc = 0.0;
     if (finite) {
       for (const FactorLin& f : ws.lin) {
-        real Jd[7] = {0, 0, 0, 0, 0, 0, 0};
+        real Jd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         const BlockKind ks[2] = {f.k0, f.k1}; const int64_t is[2] = {f.i0, f.i1}; const fscalar* Js[2] = {f.J0, f.J1};
         for (int b = 0; b < 2; ++b) {
           if (!is_var(pb, rd, ks[b], is[b])) continue;
-          const int d = kBlockDim[ks[b]];
+          const int d = b == 0 ? f.d0 : f.d1;
           for (int k = 0; k < d; ++k) {
             const real dk = (ks[b] == KIND_POINT) ? delta_l[3 * is[b] + k] : -y_c[reduced_row(rd, ks[b], is[b]) + k];
             for (int a = 0; a < f.m; ++a) Jd[a] += Js[b][d * a + k] * dk;
@@ -1384,7 +1396,7 @@ int oracle_ba_solve(oracle_handle* h, const obvi_solver_params* prm, obvi_summar
     std::vector<double> old_poses = pb.poses, old_points = pb.points, old_objects = pb.objects;
     real step_sq = 0.0;   // (the parameter blocks are fp64 in every build: the step is rounded once, where it is added)
     for (int64_t p = 0; p < pb.P; ++p) if (rd.pose_vid[p] >= 0) for (int k = 0; k < 6; ++k) { const real d = -y_c[pose_row(rd, p) + k]; pb.poses[6 * p + k] = (double)(pb.poses[6 * p + k] + d); step_sq += d * d; }
-    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < 7; ++k) { const real d = -y_c[obj_row(rd, o) + k]; pb.objects[7 * o + k] = (double)(pb.objects[7 * o + k] + d); if (counted_row(obj_row(rd, o))) step_sq += d * d; }
+    for (int64_t o = 0; o < pb.O; ++o) if (rd.obj_vid[o] >= 0) for (int k = 0; k < pb.od; ++k) { const real d = -y_c[obj_row(rd, o) + k]; pb.objects[pb.od * o + k] = (double)(pb.objects[pb.od * o + k] + d); if (counted_row(obj_row(rd, o))) step_sq += d * d; }
     for (int64_t l = 0; l < pb.L; ++l) if (rd.point_var[l]) for (int k = 0; k < 3; ++k) { const real d = delta_l[3 * l + k]; pb.points[3 * l + k] = (double)(pb.points[3 * l + k] + d); step_sq += d * d; }
     tt = now_s();
     double cand_cost = reduced_cost(pb, rd);
@@ -1529,7 +1541,7 @@ int oracle_ba_update_poses(oracle_handle* h, int64_t n, const double* v) {
 }
 int oracle_ba_update_objects(oracle_handle* h, int64_t n, const double* v) {
   if (n != h->pb.O) return OBVI_ERR_INVALID_ARGUMENT;
-  h->pb.objects.assign(v, v + 7 * n); return OBVI_OK;
+  h->pb.objects.assign(v, v + h->pb.od * n); return OBVI_OK;
 }
 
 // include/obvi_ba.h obvi_ba_update_state / obvi_ba_prepare as the drivers built against this library see them (tests/oracle_abi_shim.h): values only;
@@ -1537,7 +1549,7 @@ int oracle_ba_update_objects(oracle_handle* h, int64_t n, const double* v) {
 int oracle_ba_update_state(oracle_handle* h, const double* poses, const double* points, const double* objects) {
   if (poses) h->pb.poses.assign(poses, poses + 6 * h->pb.P);
   if (points) h->pb.points.assign(points, points + 3 * h->pb.L);
-  if (objects) h->pb.objects.assign(objects, objects + 7 * h->pb.O);
+  if (objects) h->pb.objects.assign(objects, objects + h->pb.od * h->pb.O);
   return OBVI_OK;
 }
 int oracle_ba_prepare(oracle_handle*) { return OBVI_OK; }
@@ -1573,6 +1585,10 @@ void oracle_reproj_analytic(const double* pose6, const double* point3, const dou
 int oracle_ellipsoid_corners(const double* ell7, const double* pose6, const double* K4, const double* ext7, double* corners4) {
   CameraConst cam; make_camera_const(K4, ext7, &cam);
   return ellipsoid_corners_rectified<double>(ell7, pose6, cam, corners4) ? 1 : 0;
+}
+int oracle_ellipsoid_corners9(const double* ell9, const double* pose6, const double* K4, const double* ext7, double* corners4) {   // the 9-parameter block
+  CameraConst cam; make_camera_const(K4, ext7, &cam);
+  return ellipsoid_corners_rectified<double, 9>(ell9, pose6, cam, corners4) ? 1 : 0;
 }
 int oracle_spd_inverse_sqrt(const double* cov, int n, double* out) { return spd_inverse_sqrt(cov, n, out) ? 1 : 0; }
 void oracle_huber(double s, double a, double* rho3) { huber(s, a, rho3); }

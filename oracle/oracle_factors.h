@@ -219,13 +219,19 @@ inline void reprojection_residual_analytic(const T* pose, const T* point, const 
 }
 
 // ---------------------------------------------------------------------------------------
-// a5: getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273), yaw-only ellipsoid.
-// Returns false in the invalid case (either radicand <= 0, :257-259).
+// a5: getCornerLocationsVectorRectified (ellipsoid_utils.h:160-273).  Returns false in the invalid case (either radicand <= 0, :257-259).
+// OD = 7: the yaw-only ellipsoid block (x y z yaw dx dy dz) of the reference's build (CONSTRAIN_ELLIPSOID_ORIENTATION, CMakeLists.txt:8-15).
+// OD = 9 (round 6): the unconstrained block (x y z ax ay az dx dy dz) of vslam_obj_opt_types_refactor.h:15-21 -- the `#else` branch at
+//   ellipsoid_utils.h:217-229: rotation = VectorToAxisAngle(ax ay az) (vslam_math_util.h:31-42: AngleAxis(|v|, v / |v|) above 1e-8, the
+//   constant AngleAxis(0, e_x) otherwise).  That branch does not compile in the reference (it names `ellipsoid_data` and `axis_angle`, which
+//   the function does not declare -- SURVEY fact 6), so there is no reference output to pin it with; its pin is numpy + surface sampling
+//   (tests/test_golden.py, oracle/README.md), and a 9-block with (ax, ay) = 0 reproduces the 7-block's numbers.
 // ---------------------------------------------------------------------------------------
 static const double kDimensionRegularizationConstant = (double)1e-3f;  // a `float` in ellipsoid_utils.h:22
 
-template <class T>
+template <class T, int OD = 7>
 inline bool ellipsoid_corners_rectified(const T* ell, const T* pose, const CameraConst& cam, T* corners) {
+  static_assert(OD == 7 || OD == 9, "ellipsoid block: 7 or 9 parameters");
   T Rinv[9], tinv[3];
   inverse_robot_pose(pose, Rinv, tinv);
   // world_to_camera = robot_to_cam * robot_pose^-1   (:196-197)
@@ -235,9 +241,15 @@ inline bool ellipsoid_corners_rectified(const T* ell, const T* pose, const Camer
       Rcw[3 * i + j] = Rinv[j] * cam.Rinv[3 * i] + Rinv[3 + j] * cam.Rinv[3 * i + 1] + Rinv[6 + j] * cam.Rinv[3 * i + 2];
     tcw[i] = tinv[0] * cam.Rinv[3 * i] + tinv[1] * cam.Rinv[3 * i + 1] + tinv[2] * cam.Rinv[3 * i + 2] + cam.tinv[i];
   }
-  // ellipsoid pose: translation * Rz(yaw)   (:205-229)
-  const T cy = cos(ell[3]), sy = sin(ell[3]);
-  const T Ro[9] = {cy, -sy, T(0.0), sy, cy, T(0.0), T(0.0), T(0.0), T(1.0)};
+  // ellipsoid pose: translation * Rz(yaw)   (:205-229), or translation * R(ax ay az)
+  T Ro[9];
+  if (OD == 7) {
+    const T cy = cos(ell[3]), sy = sin(ell[3]);
+    const T Rz[9] = {cy, -sy, T(0.0), sy, cy, T(0.0), T(0.0), T(0.0), T(1.0)};
+    for (int k = 0; k < 9; ++k) Ro[k] = Rz[k];
+  } else {
+    robot_pose_to_matrix(ell, Ro);   // reads ell[3..5]: VectorToAxisAngle's two branches are PoseArrayToAffine's
+  }
   T M[12];  // 3x4 [R | t] of world_to_camera * ellipsoid_pose   (:232-233)
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j)
@@ -246,7 +258,7 @@ inline bool ellipsoid_corners_rectified(const T* ell, const T* pose, const Camer
   }
   // dual quadric  Q = M diag((d/2)^2 + c, -1) M^T    (:208-216, :236-237)
   T dm[4];
-  for (int k = 0; k < 3; ++k) { const T h = ell[4 + k] / 2.0; dm[k] = h * h + kDimensionRegularizationConstant; }
+  for (int k = 0; k < 3; ++k) { const T h = ell[OD - 3 + k] / 2.0; dm[k] = h * h + kDimensionRegularizationConstant; }   // kEllipsoidPoseParameterizationSize + k
   dm[3] = T(-1.0);
   auto q = [&](int a, int b) {
     return M[4 * a] * dm[0] * M[4 * b] + M[4 * a + 1] * dm[1] * M[4 * b + 1] +
@@ -264,11 +276,11 @@ inline bool ellipsoid_corners_rectified(const T* ell, const T* pose, const Camer
 // a4: BoundingBoxFactor::operator() (bounding_box_factor.h:68-136); constants from the ctor
 // (bounding_box_factor.cpp:26-39): sqrt_inf = (cov^-1)^(1/2) diag(fx,fx,fy,fy), rectified
 // observed corners.  Invalid case: all four residuals = invalid_ellipse_error (constant).
-template <class T>
+template <class T, int OD = 7>
 inline bool bbox_residual(const T* ell, const T* pose, const CameraConst& cam, const double* rect_corners,
                           const double* sqrt_inf /*4x4 row-major*/, double invalid_err, T* residual) {
   T corners[4];
-  if (!ellipsoid_corners_rectified(ell, pose, cam, corners)) {
+  if (!ellipsoid_corners_rectified<T, OD>(ell, pose, cam, corners)) {
     for (int i = 0; i < 4; ++i) residual[i] = T(invalid_err);
     return false;
   }
@@ -281,21 +293,21 @@ inline bool bbox_residual(const T* ell, const T* pose, const CameraConst& cam, c
 
 // a6: ShapePriorFactor::operator() (shape_prior_factor.h:46-61)
 template <class T>
-inline void shape_prior_residual(const T* ell, const double* mean3, const double* sqrt_inf /*3x3*/, T* residual) {
+inline void shape_prior_residual(const T* ell, const double* mean3, const double* sqrt_inf /*3x3*/, T* residual, int od = 7) {
   T dev[3];
-  for (int i = 0; i < 3; ++i) dev[i] = ell[4 + i] - mean3[i];
+  for (int i = 0; i < 3; ++i) dev[i] = ell[od - 3 + i] - mean3[i];   // shape_prior_factor.h:49-51: entries kEllipsoidPoseParameterizationSize ...
   for (int i = 0; i < 3; ++i)
     residual[i] = dev[0] * sqrt_inf[3 * i] + dev[1] * sqrt_inf[3 * i + 1] + dev[2] * sqrt_inf[3 * i + 2];
 }
 
 // a7: IndependentObjectMapFactor::operator() (independent_object_map_factor.h:21-33)
 template <class T>
-inline void ltm_prior_residual(const T* ell, const double* mean7, const double* sqrt_inf /*7x7*/, T* residual) {
-  T dev[7];
-  for (int i = 0; i < 7; ++i) dev[i] = ell[i] - mean7[i];
-  for (int i = 0; i < 7; ++i) {
-    T acc = dev[0] * sqrt_inf[7 * i];
-    for (int j = 1; j < 7; ++j) acc = acc + dev[j] * sqrt_inf[7 * i + j];
+inline void ltm_prior_residual(const T* ell, const double* mean7, const double* sqrt_inf /*od x od*/, T* residual, int od = 7) {
+  T dev[9];
+  for (int i = 0; i < od; ++i) dev[i] = ell[i] - mean7[i];
+  for (int i = 0; i < od; ++i) {
+    T acc = dev[0] * sqrt_inf[od * i];
+    for (int j = 1; j < od; ++j) acc = acc + dev[j] * sqrt_inf[od * i + j];
     residual[i] = acc;
   }
 }
@@ -376,7 +388,7 @@ inline void huber(double s, double a, double rho[3]) {
 // e.g. shape_prior_factor.cpp:11) by cyclic Jacobi eigen-decomposition: V diag(l^-1/2) V^T.
 // Returns false if cov is not SPD / not finite.
 inline bool spd_inverse_sqrt(const double* cov, int n, double* out) {
-  double A[49], V[49];
+  double A[81], V[81];
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
     A[i * n + j] = 0.5 * (cov[i * n + j] + cov[j * n + i]);
     V[i * n + j] = (i == j) ? 1.0 : 0.0;

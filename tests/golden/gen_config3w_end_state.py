@@ -7,7 +7,9 @@ BASELINE.md 2.4 (iii)'s bar (final cost 1e-6 relative, poses 1e-6 m / rad).
 Config 3w = synth.config3w(): config #3's generator with (a) five constant poses + the odometry factors of all consecutive frames (scale gauge fixed everywhere),
 (b) only features whose first and last ray meet at >= 3 degrees (the camera looks along the direction of travel: a feature straight ahead has no observable depth),
 (c) every feature / object initialised relative to the ESTIMATED pose of its anchor frame, >= 0.5 m in front of every observing camera, (d) one shape class with
-distinct horizontal axes (the yaw of an ellipsoid with dx = dy is unobservable).  The oracle's result does not depend on its thread count (round 6:
+distinct horizontal axes (the yaw of an ellipsoid with dx = dy is unobservable), (e) a stereo rig (second camera 0.12 m to the right: metric scale at every frame).
+Which of these it takes was measured, not assumed (scripts/r06_wellposed_variants.py, profiles/r06_end_state_config3w.txt: the distance between the library's default
+and deterministic handles, two round-off realisations of one algorithm, after the block): without (e) the 2 000-keyframe chain still ends 1e-5 apart in cost.  The oracle's result does not depend on its thread count (round 6:
 tests/test_oracle_solver.py::test_the_oracle_is_bit_identical_for_any_number_of_host_threads), so any box generates the same file up to libm's last bits.
 
 usage: python tests/golden/gen_config3w_end_state.py [threads] ; about 10 minutes on 8 threads.  Stores: poses, objects, every 100th feature, costs, LM
@@ -37,6 +39,8 @@ for ph in ("phase_1", "phase_2", "polish"):
 for t, m in r["excluded"].items():
     out["excluded_%d_count" % t] = int((np.asarray(m) == 0).sum())
     out["excluded_%d_sha256" % t] = hashlib.sha256(np.asarray(m, np.uint8).tobytes()).hexdigest()
+    out["excluded_%d_bits" % t] = np.packbits(np.asarray(m, np.uint8))          # the mask itself (1 = kept), so that a differing set can be counted
+out["phase_1_state_poses"] = r["state_1"]["poses"]                            # where phase I stopped (the state the cut is taken at)
 for st in ("state_2", "state_polished"):
     out[st + "_poses"] = r[st]["poses"]; out[st + "_objects"] = r[st]["objects"]; out[st + "_points_every_100th"] = r[st]["points"][::100]
 name = "config3w_end_state.npz" if not small else "config3w_small_end_state.npz"

@@ -38,6 +38,21 @@ int hostmath_bbox(const double* ell, const double* pose, const double* K4, const
   for (int a = 0; a < 4; ++a) { r[a] = res[a].v; for (int k = 0; k < 7; ++k) Je[7 * a + k] = res[a].d[k]; for (int k = 0; k < 6; ++k) Jp[6 * a + k] = res[a].d[7 + k]; }
   return ok ? 1 : 0;
 }
+// the 9-parameter ellipsoid block (obvi_ba_options.object_block_size = 9): 15 directions, ellipsoid first
+int hostmath_bbox9(const double* ell, const double* pose, const double* K4, const double* ext7, const double* rect,
+                   const double* sqrt_inf, double invalid, double* r, double* Je, double* Jp) {
+  DevCam cam; make_cam(K4, ext7, &cam);
+  Dual<15> res[4];
+  const bool ok = bbox_eval_n<15, 9>(ell, pose, cam, rect, sqrt_inf, invalid, res);
+  for (int a = 0; a < 4; ++a) { r[a] = res[a].v; for (int k = 0; k < 9; ++k) Je[9 * a + k] = res[a].d[k]; for (int k = 0; k < 6; ++k) Jp[6 * a + k] = res[a].d[9 + k]; }
+  // the one-direction form the lane-parallel kernels use must give the same columns
+  for (int dir = 0; dir < 15; ++dir) {
+    Dual<1> one[4];
+    bbox_eval_n<1, 9>(ell, pose, cam, rect, sqrt_inf, invalid, one, dir);
+    for (int a = 0; a < 4; ++a) if (one[a].d[0] != res[a].d[dir] || one[a].v != res[a].v) return -1;
+  }
+  return ok ? 1 : 0;
+}
 void hostmath_relpose(const double* pa, const double* pb, const double* t, const double* R, const double* si, double* r, double* Ja, double* Jb) {
   D12 res[6]; relpose_eval(pa, pb, t, R, si, res);
   for (int a = 0; a < 6; ++a) { r[a] = res[a].v; for (int k = 0; k < 6; ++k) { Ja[6 * a + k] = res[a].d[k]; Jb[6 * a + k] = res[a].d[6 + k]; } }

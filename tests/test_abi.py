@@ -76,7 +76,7 @@ def test_no_cpu_fallback(lib):
 
 def test_invalid_arguments(lib):
     assert lib.obvi_ba_create(None, None) == -1
-    bad = obvi_ba.Options(0, 9)     # the 9-parameter ellipsoid branch does not compile in the reference either
+    bad = obvi_ba.Options(0, 8)     # an ellipsoid block has 7 (yaw only) or 9 (axis-angle) parameters
     h = C.c_void_p()
     assert lib.obvi_ba_create(C.byref(bad), C.byref(h)) == -1
     assert lib.obvi_ba_solve(None, None, None) == -1

@@ -154,6 +154,69 @@ def test_bbox_vs_numpy(oracle, hostmath):
     assert n_invalid == 1
 
 
+def test_nine_parameter_ellipsoid_block(oracle, hostmath):
+    """The unconstrained ellipsoid block (x y z ax ay az dx dy dz; vslam_obj_opt_types_refactor.h:15-21, ellipsoid_utils.h:217-229 `#else`).  The reference cannot
+    compile that branch, so its pins are: (1) upright, it IS the reference's golden tuple #1; (2) tilted, an independent numpy restatement
+    (synth.project_ellipsoids with scipy's rotation vector) and brute-force sampling of the ellipsoid's surface; (3) the product's Jacobian (host build of
+    ba_math.h, 15 directions and the one-direction form of the lane-parallel kernels) against finite differences of that restatement, and -- upright --
+    against the 7-block's columns; (4) VectorToAxisAngle's constant branch at or below 1e-8 (vslam_math_util.h:31-42): identity, zero derivative."""
+    import synth
+    from scipy.spatial.transform import Rotation as Rot
+    hostmath.hostmath_bbox9.restype = C.c_int
+    t = json.load(open(os.path.join(GOLD, "reference_tuples.json")))["ellipsoid_bbox"]
+    e7 = np.array(t["ellipsoid"]); K, ext, pose = np.array(t["K"]), np.array(t["ext_qxyzw_t"]), np.array(t["pose_t_aa"])
+    e9 = np.array([e7[0], e7[1], e7[2], 0.0, 0.0, e7[3], e7[4], e7[5], e7[6]])
+    c7, c9 = np.zeros(4), np.zeros(4)
+    assert oracle.oracle_ellipsoid_corners(dp(e7), dp(pose), dp(K), dp(ext), dp(c7)) == 1 and oracle.oracle_ellipsoid_corners9(dp(e9), dp(pose), dp(K), dp(ext), dp(c9)) == 1
+    assert np.abs(c9 - c7).max() < 1e-14 and np.abs(c9 - np.array(t["rectified_corners"])).max() < t["corners_abs_tol"]          # (1)
+
+    def rectified(px):
+        return np.array([(px[0] - K[2]) / K[0], (px[1] - K[2]) / K[0], (px[2] - K[3]) / K[1], (px[3] - K[3]) / K[1]])
+    rng = np.random.default_rng(7)
+    si = np.ascontiguousarray(np.diag([K[0], K[0], K[1], K[1]]) / 30.0)
+    for case in range(40):
+        tilt = Rot.from_rotvec(rng.normal(size=3) * (0.6 if case % 2 else 0.05))
+        aa = (Rot.from_rotvec([0, 0, e7[3] + rng.normal() * 0.5]) * tilt).as_rotvec()
+        ell = np.concatenate([e7[:3] + rng.normal(size=3) * 0.3, aa, e7[4:] * (1 + rng.normal(size=3) * 0.2)])
+        out = np.zeros(4)
+        assert oracle.oracle_ellipsoid_corners9(dp(ell), dp(pose), dp(K), dp(ext), dp(out)) == 1
+        px, valid, _ = synth.project_ellipsoids(ell[None], pose[None], K, ext)
+        want = rectified(px[0])
+        assert valid[0] and np.abs(out - want).max() < 1e-12                                                               # (2) numpy restatement
+        if case < 4:                                                                                                       # (2) the surface itself
+            u, v = np.meshgrid(np.linspace(0, np.pi, 700), np.linspace(0, 2 * np.pi, 1400))
+            semi = np.sqrt((ell[6:] / 2) ** 2 + synth.DIM_REG)
+            pts = np.stack([semi[0] * np.sin(u) * np.cos(v), semi[1] * np.sin(u) * np.sin(v), semi[2] * np.cos(u)], axis=-1).reshape(-1, 3)
+            pw = pts @ Rot.from_rotvec(aa).as_matrix().T + ell[:3]
+            pix, z = synth.project_points(np.repeat(pose[None], len(pw), 0), pw, K, ext)
+            assert (z > 0).all()
+            box = rectified(np.array([pix[:, 0].min(), pix[:, 0].max(), pix[:, 1].min(), pix[:, 1].max()]))
+            assert np.abs(np.sort(out[:2]) - box[:2]).max() < 2e-5 and np.abs(np.sort(out[2:]) - box[2:]).max() < 2e-5
+        r, Je, Jp = np.zeros(4), np.zeros(36), np.zeros(24)
+        assert hostmath.hostmath_bbox9(dp(ell), dp(pose), dp(K), dp(ext), dp(want.copy()), dp(si), C.c_double(1000.0), dp(r), dp(Je), dp(Jp)) == 1
+        assert np.abs(r).max() < 1e-9                                                                                      # product == restatement
+        Je = Je.reshape(4, 9)
+        for k in range(9):                                                                                                 # (3) finite differences
+            h = 1e-6
+            ep, em = ell.copy(), ell.copy(); ep[k] += h; em[k] -= h
+            fd = si @ (rectified(synth.project_ellipsoids(ep[None], pose[None], K, ext)[0][0]) - rectified(synth.project_ellipsoids(em[None], pose[None], K, ext)[0][0])) / (2 * h)
+            assert np.abs(fd - Je[:, k]).max() < 2e-6 * max(1.0, np.abs(fd).max()), (case, k)
+    # (3) upright: the 7-block's columns
+    r7, Je7, Jp7 = np.zeros(4), np.zeros(28), np.zeros(24); r9, Je9, Jp9 = np.zeros(4), np.zeros(36), np.zeros(24)
+    rect = rectified(synth.project_ellipsoids(e7[None], pose[None], K, ext)[0][0]) + 0.01
+    assert hostmath.hostmath_bbox(dp(e7), dp(pose), dp(K), dp(ext), dp(rect), dp(si), C.c_double(1000.0), dp(r7), dp(Je7), dp(Jp7)) == 1
+    assert hostmath.hostmath_bbox9(dp(e9), dp(pose), dp(K), dp(ext), dp(rect), dp(si), C.c_double(1000.0), dp(r9), dp(Je9), dp(Jp9)) == 1
+    assert np.abs(r9 - r7).max() < 1e-12 and np.abs(Jp9 - Jp7).max() < 1e-11
+    assert np.abs(Je9.reshape(4, 9)[:, [0, 1, 2, 5, 6, 7, 8]] - Je7.reshape(4, 7)).max() < 1e-11
+    # (4) the constant branch
+    tiny = np.array([e7[0], e7[1], e7[2], 3e-9, -2e-9, 5e-9, e7[4], e7[5], e7[6]]); zero = tiny.copy(); zero[3:6] = 0.0
+    ct, cz = np.zeros(4), np.zeros(4)
+    assert oracle.oracle_ellipsoid_corners9(dp(tiny), dp(pose), dp(K), dp(ext), dp(ct)) == 1 and oracle.oracle_ellipsoid_corners9(dp(zero), dp(pose), dp(K), dp(ext), dp(cz)) == 1
+    assert np.array_equal(ct, cz)
+    assert hostmath.hostmath_bbox9(dp(tiny), dp(pose), dp(K), dp(ext), dp(rect), dp(si), C.c_double(1000.0), dp(r9), dp(Je9), dp(Jp9)) == 1
+    assert np.all(Je9.reshape(4, 9)[:, 3:6] == 0.0)
+
+
 def test_huber(oracle):
     for c in json.load(open(os.path.join(GOLD, "huber.json"))):
         rho = np.zeros(3)
