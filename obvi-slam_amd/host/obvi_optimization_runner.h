@@ -90,6 +90,11 @@ struct RunnerHooks {
   std::function<bool()> continue_opt_checker_ = []() { return true; };
   std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&, const VisualizationTypeEnum&, const int&)> visualization_callback_;
   std::vector<std::string> ignored_hooks_;   // out: the constructor hooks the reference-shaped runner accepted and does not use
+  // The residual creator the reference-shaped construction site passes: by default one that makes every residual (the reference's creator fails only on a factor
+  // it cannot build).  creator_rejects_every_ = N > 0 (the driver's --creator-rejects-every N; tests): a creator that cannot make the residual of every visual /
+  // bounding-box factor whose id is N - 1 modulo N -- the seam in action: those factors must be left out of every problem of the session.
+  int creator_rejects_every_ = 0;
+  size_t creator_calls_ = 0, creator_rejections_ = 0, refresh_calls_ = 0, factors_left_out_ = 0;   // out
 };
 
 // optimization_runner.h:22-651.  `problem_data` carries what the reference passes as bounding_boxes / visual_features / robot_poses /
@@ -133,9 +138,15 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
     // the construction site as the reference writes it (optimization_runner.h:509-543): every hook through the constructor, in the reference's order
     struct CachedInfo {};   // the reference: util::EmptyStruct
     using ReferenceShaped = OfflineProblemRunner<OfflineProblemData, ReprojectionErrorFactor, LongTermObjectMapAndResults, CachedInfo, MainPg>;
-    const ReferenceShaped::RefreshResidualChecker refresh_residual_checker = [](const std::pair<FactorType, FeatureFactorId>&, const MainPgPtr&, const CachedInfo&) { return true; };   // :273-279
-    const ReferenceShaped::ResidualCreator residual_creator = [](const std::pair<FactorType, FeatureFactorId>&, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams&, const MainPgPtr&,
-                                                                  obvi::Problem*, obvi::ResidualBlockId&, CachedInfo&) { return false; };                                               // :280-298
+    const ReferenceShaped::RefreshResidualChecker refresh_residual_checker = [hooks](const std::pair<FactorType, FeatureFactorId>&, const MainPgPtr&, const CachedInfo&) { ++hooks->refresh_calls_; return true; };   // :273-279 (always refresh)
+    const int every = hooks->creator_rejects_every_;
+    const ReferenceShaped::ResidualCreator residual_creator = [hooks, every](const std::pair<FactorType, FeatureFactorId>& factor, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams&, const MainPgPtr&,
+                                                                              obvi::Problem*, obvi::ResidualBlockId&, CachedInfo&) {                                             // :280-298
+      ++hooks->creator_calls_;
+      const bool observation = factor.first == kReprojectionErrorFactorTypeId || factor.first == kObjectObservationFactorTypeId;
+      if (every > 0 && observation && factor.second % (FeatureFactorId)every == (FeatureFactorId)(every - 1)) { ++hooks->creator_rejections_; return false; }
+      return true;
+    };
     const std::function<void(const OfflineProblemData&, const MainPgPtr&, const FrameId&, const FrameId&)> frame_data_adder =                                                         // :364-418
         [&](const OfflineProblemData& data, const MainPgPtr& pose_graph, const FrameId& min_frame_id, const FrameId& frame_to_add) {
           addFrameDataToPoseGraph(data, pose_graph, frame_to_add, config.object_visual_pose_graph_residual_params_.relative_pose_cov_params_, visual_feature_adder, min_frame_id);
@@ -165,6 +176,7 @@ inline bool runFullOptimization(std::optional<OptimizationLogger>& opt_logger, c
   runner.setLongTermMapTunableParams(config.ltm_tunable_params_);
   const bool ok = runner.runOptimization(problem_data, config.optimization_factors_enabled_params_, opt_logger, output_results, start_at_frame, add_data_for_starting_frame);
   if (std::getenv("OBVI_HOST_TIMING")) runner.printTiming(std::cerr);
+  if (hooks != nullptr) hooks->factors_left_out_ = runner.factorsLeftOutByTheCreator();
   output_results.records_ = runner.records();
   output_results.post_session_merge_rounds_ = runner.mergeRounds();
   const MainPgPtr pose_graph = runner.poseGraph();

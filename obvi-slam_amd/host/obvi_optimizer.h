@@ -500,9 +500,27 @@ class ResidualBlockInfoMap {
   std::vector<FactorInfo> blocks_;
 };
 
+// The reference's per-factor seam (object_pose_graph_optimizer.h:98-113, used at :1016-1052), type-erased: what the reference-shaped runner (obvi_runner.h) forwards a
+// caller's refresh_residual_checker / residual_creator through.  For every residual block a build selects, in Problem::GetResidualBlocks order:
+//   keep(factor, pose_graph)                 set and true  -> the caller holds a residual for it from an earlier build and does not want it refreshed: it stays
+//                                                            (the reference keeps the existing ceres block and does not call the creator, :1018-1032)
+//   create(factor, params, pose_graph, problem, id)  false -> "Could not make residual": the factor is LEFT OUT of the problem, as the reference leaves it out
+//                                                            (:1042-1051; the block count and ids the caller sees are those of the remaining blocks)
+// The numeric residual itself is not the creator's to define here -- the factors are the five of the path, evaluated on the device --, and the loss is the family's
+// (one Huber parameter per factor type, as ObjectVisualPoseGraphResidualParams has it): what a creator decides is WHICH factors enter.
+struct FactorHooks {
+  typedef std::pair<vslam_types_refactor::FactorType, vslam_types_refactor::FeatureFactorId> Key;
+  std::function<bool(const Key&, const std::shared_ptr<PoseGraphType>&)> keep;
+  std::function<bool(const Key&, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams&, const std::shared_ptr<PoseGraphType>&, obvi::Problem*, obvi::ResidualBlockId&)> create;
+  explicit operator bool() const { return (bool)create; }
+};
+
 class ObjectPoseGraphOptimizer {
  public:
   ObjectPoseGraphOptimizer() = default;
+  void setFactorHooks(const FactorHooks& hooks) { factor_hooks_ = hooks; }
+  const FactorHooks& factorHooks() const { return factor_hooks_; }
+  size_t factorsLeftOutByTheCreator() const { return n_vetoed_total_; }
 
   // object_pose_graph_optimizer.h:126-632.  Same selection rules; instead of adding Ceres residual and
   // parameter blocks the selected factors are flattened into problem->flat.
@@ -828,7 +846,52 @@ class ObjectPoseGraphOptimizer {
     last_optimized_nodes_ = optimized_frames.size(); last_optimized_features_ = fp.features.size(); last_optimized_objects_ = fp.objects.size();
     if (opt_logger.has_value()) opt_logger->setOptimizationParams(last_optimized_objects_, last_optimized_features_, last_optimized_nodes_);   // :625-629
     lap_("small factor families");
+    if (factor_hooks_) applyFactorHooks(residual_params, pose_graph, problem);
     return ResidualBlockInfoMap(fp.blocks);
+  }
+
+  // the caller's per-factor hooks over the blocks the build selected (FactorHooks above): vetoed blocks are struck from the flat problem
+  void applyFactorHooks(const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& residual_params, std::shared_ptr<PoseGraphType>& pose_graph, obvi::Problem* problem) {
+    obvi::FlatProblem& fp = problem->flat;
+    const size_t n = fp.blocks.size();
+    std::vector<uint8_t> keep(n, 1);
+    size_t dropped = 0, next_id = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const FactorHooks::Key key = fp.blocks[i];
+      if (factor_hooks_.keep && factor_hooks_.keep(key, pose_graph)) { ++next_id; continue; }
+      obvi::ResidualBlockId id = (obvi::ResidualBlockId)next_id;
+      if (!factor_hooks_.create(key, residual_params, pose_graph, problem, id)) {
+        keep[i] = 0; ++dropped;
+        std::cerr << "Could not make residual for factor type " << (int)key.first << " and factor id " << key.second << std::endl;   // object_pose_graph_optimizer.h:1049-1050
+      } else {
+        ++next_id;
+      }
+    }
+    n_vetoed_total_ += dropped;
+    if (dropped == 0) return;
+    size_t at = 0;
+    auto rows = [&](auto& vec, size_t width, size_t count) {   // keeps the rows (of `width` entries) of a family whose blocks are [at, at + count)
+      size_t w = 0;
+      for (size_t i = 0; i < count; ++i) {
+        if (!keep[at + i]) continue;
+        if (w != i) for (size_t k = 0; k < width; ++k) vec[w * width + k] = vec[i * width + k];
+        ++w;
+      }
+      vec.resize(w * width);
+    };
+    size_t c = fp.rp_pose.size();
+    rows(fp.rp_pose, 1, c); rows(fp.rp_point, 1, c); rows(fp.rp_cam, 1, c); rows(fp.rp_pixel, 2, c); rows(fp.rp_sigma, 1, c); at += c;
+    c = fp.bb_obj.size();
+    rows(fp.bb_obj, 1, c); rows(fp.bb_pose, 1, c); rows(fp.bb_cam, 1, c); rows(fp.bb_corners, 4, c); rows(fp.bb_cov, 16, c); at += c;
+    c = fp.sp_obj.size();
+    rows(fp.sp_obj, 1, c); rows(fp.sp_mean, 3, c); rows(fp.sp_cov, 9, c); at += c;
+    c = fp.lt_obj.size();
+    rows(fp.lt_obj, 1, c); rows(fp.lt_mean, 7, c); rows(fp.lt_cov, 49, c); at += c;
+    c = fp.rl_a.size();
+    rows(fp.rl_a, 1, c); rows(fp.rl_b, 1, c); rows(fp.rl_t, 3, c); rows(fp.rl_aa, 3, c); rows(fp.rl_cov, 36, c); at += c;
+    size_t w = 0;
+    for (size_t i = 0; i < n; ++i) if (keep[i]) fp.blocks[w++] = fp.blocks[i];
+    fp.blocks.resize(w);
   }
 
   // Phase II of a two-phase optimisation (offline_problem_runner.h:803-892) re-runs buildPoseGraphOptimization with the excluded
@@ -1031,6 +1094,8 @@ class ObjectPoseGraphOptimizer {
   }
   pose_graph_optimization::ObjectVisualPoseGraphResidualParams residual_params_;
   size_t last_optimized_objects_ = 0, last_optimized_features_ = 0, last_optimized_nodes_ = 0;
+  FactorHooks factor_hooks_;
+  size_t n_vetoed_total_ = 0;
   // scratch of buildPoseGraphOptimization, kept between calls (a window is built for every frame)
   std::vector<const PoseGraphType::VisualFactorRecord*> scratch_records_;
   std::vector<uint32_t> sightings_;

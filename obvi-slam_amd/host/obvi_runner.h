@@ -216,7 +216,7 @@ class OfflineProblemRunner<OutputProblemData> {
       ahead_job_ = nullptr;
       const FrameId ahead_frame = next_frame_id + 1;
       static const bool phase_two_check = std::getenv("OBVI_HOST_PHASE2_CHECK") && std::atoi(std::getenv("OBVI_HOST_PHASE2_CHECK")) != 0;
-      if (planAheadEnabled() && !phase_two_check && ahead_frame <= max_frame_id && !frame_data_adder_ && !visual_feature_adder_ && !visualization_callback_ && !gba_checker_(ahead_frame)) {
+      if (planAheadEnabled() && !phase_two_check && ahead_frame <= max_frame_id && !frame_data_adder_ && !visual_feature_adder_ && !visualization_callback_ && !factor_hooks_set_ && !gba_checker_(ahead_frame)) {
         obvi::Problem* ahead_problem = &problem_objects[1 - current];
         ahead_job_ = [this, &problem_data, &pose_graph, ahead_frame, ahead_problem, scope]() {
           const auto t0 = std::chrono::steady_clock::now();
@@ -303,6 +303,9 @@ class OfflineProblemRunner<OutputProblemData> {
   void setLimitTrajectoryEvaluationParams(const LimitTrajectoryEvaluationParams& p) { limit_trajectory_eval_params_ = p; }
   void setContinueOptChecker(const std::function<bool()>& checker) { continue_opt_checker_ = checker; have_continue_opt_checker_ = true; }
   void setObjectMerger(const std::function<bool(const MainPgPtr&)>& merger) { object_merger_ = merger; }
+  // the per-factor seam (obvi_optimizer.h FactorHooks): the hooks run on the thread that builds, so the next window is then not planned on a second thread
+  void setFactorHooks(const pose_graph_optimizer::FactorHooks& hooks) { optimizer_.setFactorHooks(hooks); ahead_optimizer_.setFactorHooks(hooks); factor_hooks_set_ = (bool)hooks; }
+  size_t factorsLeftOutByTheCreator() const { return optimizer_.factorsLeftOutByTheCreator() + ahead_optimizer_.factorsLeftOutByTheCreator(); }
   size_t mergeRounds() const { return n_merge_rounds_; }
   const std::vector<OptimizationRecord>& records() const { return records_; }
   void printTiming(std::ostream& os) const {
@@ -393,7 +396,7 @@ class OfflineProblemRunner<OutputProblemData> {
         // depends on what the stage computes: a second thread does it on this problem's handle while the stage runs on another one (the session's second
         // problem object parked its handle for that: runOptimization); the values are handed over afterwards.  The stage reads the graph's structure and
         // writes block values; the build reads structure only.
-        const bool plan_beside_stage = planAheadEnabled() && run_visual_feature_opt && !planned_ahead && !problem.dryRun();
+        const bool plan_beside_stage = planAheadEnabled() && run_visual_feature_opt && !planned_ahead && !problem.dryRun() && !factor_hooks_set_;
         if (plan_beside_stage) {
           stage_beside_thread_.post([this, &scope, &pose_graph, &problem]() {
             const auto t0 = std::chrono::steady_clock::now();
@@ -627,6 +630,7 @@ class OfflineProblemRunner<OutputProblemData> {
   Ahead ahead_;
   std::function<void()> ahead_job_;
   pose_graph_optimizer::ObjectPoseGraphOptimizer ahead_optimizer_;   // the build beside a solve has scratch of its own
+  bool factor_hooks_set_ = false;
   pose_graph_optimizer::BesideThread stage_beside_thread_, ahead_thread_;
   std::atomic<bool> ahead_graph_done_{true};
   double time_stage_beside_ms_ = 0, time_stage_beside_wait_ms_ = 0; size_t n_stage_beside_ = 0;
@@ -651,9 +655,10 @@ namespace obvi_placeholder { struct IterationCallback { virtual ~IterationCallba
 // ceres::Problem* -> obvi::Problem*, ceres::ResidualBlockId -> obvi::ResidualBlockId, ceres::IterationCallback -> obvi_placeholder::IterationCallback.
 //   used     residual_params, limit_trajectory_eval_params, pgo_solver_params, continue_opt_checker (tested as the reference tests it), window_provider_func,
 //            pose_graph_creator, frame_data_adder, output_data_extractor, visualization_callback, iteration_params_provider_func, object_merger, gba_checker
-//   ignored  refresh_residual_checker, residual_creator: per-factor hooks into ceres::Problem; here the optimiser uploads whole factor tables to the device
-//            (obvi_optimizer.h buildPoseGraphOptimization), there is no per-residual call to route through them.  ceres_callback_creator: see above.
-//            ignoredHooks() names the ones that were non-empty, so that a caller relying on one finds out.
+//   used     (round 6) refresh_residual_checker, residual_creator: run on the host at every build over the factors the build selected (obvi_optimizer.h FactorHooks):
+//            a creator that returns false leaves its factor out, cached info is kept per factor and offered to the refresh checker as the reference does.  What a
+//            creator cannot do here is define the residual's arithmetic (the five factors of the path run on the device) or a loss of its own.
+//   ignored  ceres_callback_creator: see above.  ignoredHooks() names the ignored ones that were non-empty, so that a caller relying on one finds out.
 // InputProblemData, VisualFeatureFactorType and PoseGraphType must be the types this path has fixed; CachedFactorInfo is free (it only types the ignored hooks).
 template <typename InputProblemData, typename VisualFeatureFactorType, typename OutputProblemData, typename CachedFactorInfo, typename PoseGraphType>
 class OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType> : public OfflineProblemRunner<OutputProblemData> {
@@ -689,9 +694,33 @@ class OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProb
     if (frame_data_adder) Base::setFrameDataAdder(frame_data_adder);
     if (visualization_callback) Base::setVisualizationCallback(visualization_callback);
     if (object_merger) Base::setObjectMerger(object_merger);
-    if (refresh_residual_checker) ignored_hooks_.push_back("refresh_residual_checker");
-    if (residual_creator) ignored_hooks_.push_back("residual_creator");
-    if (ceres_callback_creator) ignored_hooks_.push_back("ceres_callback_creator");
+    // The per-factor seam (object_pose_graph_optimizer.h:98-113): the caller's creator decides, factor by factor, whether a residual is made -- a `false` leaves the
+    // factor out, as in the reference (:1042-1051) --, and its CachedFactorInfo lives here, keyed by factor, exactly as residual_blocks_and_cached_info_by_factor_id_
+    // holds it there: a factor the caller has a cached residual for is offered to refresh_residual_checker first and re-created only if that says so (:1018-1032).
+    if (residual_creator) {
+      auto cache = std::make_shared<std::map<std::pair<FactorType, FeatureFactorId>, CachedFactorInfo>>();
+      pose_graph_optimizer::FactorHooks hooks;
+      if (refresh_residual_checker) {
+        hooks.keep = [cache, refresh_residual_checker](const std::pair<FactorType, FeatureFactorId>& key, const std::shared_ptr<PoseGraphType>& pg) {
+          const auto it = cache->find(key);
+          if (it == cache->end()) return false;                       // no residual yet: create
+          if (!refresh_residual_checker(key, pg, it->second)) return true;   // keep what is there
+          cache->erase(it);                                            // refresh: the creator runs again
+          return false;
+        };
+      } else {
+        hooks.keep = [cache](const std::pair<FactorType, FeatureFactorId>& key, const std::shared_ptr<PoseGraphType>&) { return cache->count(key) != 0; };
+      }
+      hooks.create = [cache, residual_creator](const std::pair<FactorType, FeatureFactorId>& key, const pose_graph_optimization::ObjectVisualPoseGraphResidualParams& params,
+                                              const std::shared_ptr<PoseGraphType>& pg, obvi::Problem* problem, obvi::ResidualBlockId& id) {
+        CachedFactorInfo info{};
+        if (!residual_creator(key, params, pg, problem, id, info)) return false;
+        (*cache)[key] = info;
+        return true;
+      };
+      Base::setFactorHooks(hooks);
+    }
+    if (ceres_callback_creator) ignored_hooks_.push_back("ceres_callback_creator");   // the LM loop runs on the device: nothing to call per iteration
   }
   const std::vector<std::string>& ignoredHooks() const { return ignored_hooks_; }
  private:

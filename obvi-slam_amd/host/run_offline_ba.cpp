@@ -11,7 +11,7 @@
 //     [--long-term-map-input F] [--long-term-map-output F]   [--robot-poses-results-file F] [--ellipsoids-results-file F] [--visual-feature-results-file F]
 //     run_offline_ba --reference-inputs <out.json> --intrinsics-file A --extrinsics-file B --poses-by-node-id-file C --low-level-feats-dir D   (instead of a scene)
 //     run_offline_ba --long-term-map-roundtrip <in.json> <out.json>                                (no GPU)
-//   [--sessions-in-process K] K sessions over the scene at once, a host thread each   [--reference-shaped-runner] OfflineProblemRunner<5 types>(15 arguments)   [--max-frame N]
+//   [--sessions-in-process K] K sessions over the scene at once, a host thread each   [--reference-shaped-runner] OfflineProblemRunner<5 types>(15 arguments)   [--creator-rejects-every N] ... with a residual_creator that fails on every N-th observation factor   [--max-frame N]
 // Parameter values without a parameter file: config/base7a_2_fallback.json of the reference.
 #include <algorithm>
 #include <chrono>
@@ -251,6 +251,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--frames-reversed")) frames_reversed = true;   // --dump-build: the frames' sightings enter the pose graph last frame first (factor ids descend with the frame)
     else if (!std::strcmp(argv[i], "--phase-two-masks")) masks_of_unexcluded_build = true;
     else if (!std::strcmp(argv[i], "--reference-shaped-runner")) hooks.reference_shaped_runner_ = true;   // OfflineProblemRunner<5 types>(15 arguments), as the reference constructs it
+    else if (!std::strcmp(argv[i], "--creator-rejects-every") && i + 1 < argc) { hooks.reference_shaped_runner_ = true; hooks.creator_rejects_every_ = std::atoi(argv[++i]); }   // a residual_creator that fails on every N-th observation factor (the per-factor seam)
     else if (!std::strcmp(argv[i], "--max-frame") && i + 1 < argc) { hooks.limit_trajectory_eval_params_.should_limit_trajectory_evaluation_ = true; hooks.limit_trajectory_eval_params_.max_frame_id_ = std::strtoull(argv[++i], nullptr, 10); }
     else if (!std::strcmp(argv[i], "--count-visualization-calls")) count_visualization_calls = true;
     else if (!std::strcmp(argv[i], "--params-config-file") && i + 1 < argc) ++i;   // (read above)
@@ -542,7 +543,8 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < visualization_calls.size(); ++k) std::cerr << (k ? ", " : "") << visualization_calls[k];
     std::cerr << "], \"ignored_hooks\": [";
     for (size_t k = 0; k < hooks.ignored_hooks_.size(); ++k) std::cerr << (k ? ", " : "") << "\"" << hooks.ignored_hooks_[k] << "\"";
-    std::cerr << "]}" << std::endl;
+    std::cerr << "], \"creator_calls\": " << hooks.creator_calls_ << ", \"creator_rejections\": " << hooks.creator_rejections_ << ", \"refresh_calls\": " << hooks.refresh_calls_
+              << ", \"factors_left_out\": " << hooks.factors_left_out_ << "}" << std::endl;
   }
   if (front_end) { std::cerr << "front_end "; front_end_report(std::cerr); std::cerr << std::endl; front_end.reset(); obvi_ba_destroy(front_end_handle); }
   const auto t_run1 = std::chrono::steady_clock::now();

@@ -103,6 +103,42 @@ double object_diff(const std::vector<double>& a, const std::vector<double>& b) {
   for (size_t i = 0; i < a.size() && i < b.size(); ++i) if (i % 7 != 3) { const double d = std::fabs(a[i] - b[i]); if (!(d <= m)) m = d; }
   return m;
 }
+// The same difference in units of the ORACLE's own uncertainty: sqrt(d^T Sigma^-1 d) per object, d = HIP block - oracle block (all seven
+// entries, the yaw included: a direction the data does not constrain has a large variance and weighs accordingly), Sigma = the oracle's 7x7 covariance block of the
+// object at ITS end state (oracle_ba_object_covariances: the block of (J^T J)^-1 the long-term map stores).  Returns the largest over the objects; -1 where the
+// oracle's normal equations are rank deficient there (no covariance exists) or an object's block is not positive definite.
+double whitened_object_diff(oracle_handle* ora, int64_t O, const std::vector<double>& hip, const std::vector<double>& orc) {
+  if (O <= 0) return 0.0;
+  std::vector<uint32_t> idx((size_t)O);
+  for (int64_t o = 0; o < O; ++o) idx[(size_t)o] = (uint32_t)o;
+  std::vector<double> cov((size_t)49 * (size_t)O);
+  if (oracle_ba_object_covariances(ora, O, idx.data(), idx.data(), cov.data()) != 0) return -1.0;
+  double worst = 0.0;
+  for (int64_t o = 0; o < O; ++o) {
+    const double* S = &cov[(size_t)49 * (size_t)o];
+    bool zero = true;
+    for (int k = 0; k < 49; ++k) if (S[k] != 0.0) zero = false;
+    if (zero) continue;                                   // a constant / unused object: no block
+    double Lc[49] = {0}, y[7];
+    bool ok = true;
+    for (int i = 0; i < 7 && ok; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double v = S[7 * i + j];
+        for (int k = 0; k < j; ++k) v -= Lc[7 * i + k] * Lc[7 * j + k];
+        if (i == j) { if (!(v > 0.0)) { ok = false; break; } Lc[7 * i + i] = std::sqrt(v); } else Lc[7 * i + j] = v / Lc[7 * j + j];
+      }
+    if (!ok) return -1.0;
+    double q = 0.0;
+    for (int i = 0; i < 7; ++i) {                         // y = L^-1 d ;  d^T Sigma^-1 d = |y|^2
+      double v = hip[(size_t)(7 * o + i)] - orc[(size_t)(7 * o + i)];
+      if (i == 3) v = std::remainder(v, 3.14159265358979323846);   // an ellipsoid's yaw is defined modulo pi; unobservable yaws drift by thousands of radians in any two runs
+      for (int k = 0; k < i; ++k) v -= Lc[7 * i + k] * y[k];
+      y[i] = v / Lc[7 * i + i]; q += y[i] * y[i];
+    }
+    worst = std::max(worst, std::sqrt(q));
+  }
+  return worst;
+}
 double rel(double a, double b) { return std::fabs(a - b) / std::max(std::fabs(b), 1e-300); }
 int both(int rh, int ro, const char* what) {
   if ((rh == 0) != (ro == 0)) { std::fprintf(stderr, "lockstep: %s: HIP status %d, oracle status %d\n", what, rh, ro); if (FILE* f = log_file()) { std::fprintf(f, "{\"call\": \"status\", \"what\": \"%s\", \"hip\": %d, \"oracle\": %d}\n", what, rh, ro); std::fflush(f); } }
@@ -196,10 +232,10 @@ int lock_ba_solve(obvi_ba_handle* h, const obvi_solver_params* prm, obvi_summary
     double it_cost_rel = 0.0;
     for (int i = 0; i < std::min(nh, no); ++i) { if (ih[i].step_is_successful != io[i].step_is_successful) same_flags = 0; it_cost_rel = std::max(it_cost_rel, rel(ih[i].cost, io[i].cost)); }
     std::fprintf(f, "{\"call\": \"solve\", \"poses\": %lld, \"points\": %lld, \"objects\": %lld, \"iterations_hip\": %d, \"iterations_oracle\": %d, \"termination_hip\": %d, \"termination_oracle\": %d, "
-                    "\"same_accept_sequence\": %d, \"initial_cost\": %.17g, \"initial_cost_rel\": %.3e, \"final_cost_rel\": %.3e, \"max_iteration_cost_rel\": %.3e, \"pose_diff\": %.3e, \"point_diff\": %.3e, \"object_diff\": %.3e, "
+                    "\"same_accept_sequence\": %d, \"initial_cost\": %.17g, \"initial_cost_rel\": %.3e, \"final_cost_rel\": %.3e, \"max_iteration_cost_rel\": %.3e, \"pose_diff\": %.3e, \"point_diff\": %.3e, \"object_diff\": %.3e, \"object_diff_whitened\": %.3e, "
                     "\"params_reduced_equal\": %d, \"function_tolerance\": %.3e, \"max_num_iterations\": %d, \"message_hip\": \"%.40s\", \"message_oracle\": \"%.40s\"}\n",
                  (long long)l->P, (long long)l->L, (long long)l->O, sum->num_iterations, so.num_iterations, sum->termination_type, so.termination_type, same_flags, so.initial_cost,
-                 rel(sum->initial_cost, so.initial_cost), rel(sum->final_cost, so.final_cost), it_cost_rel, max_abs_diff(ph, po), max_abs_diff(xh, xo), object_diff(oh, oo),
+                 rel(sum->initial_cost, so.initial_cost), rel(sum->final_cost, so.final_cost), it_cost_rel, max_abs_diff(ph, po), max_abs_diff(xh, xo), object_diff(oh, oo), whitened_object_diff(l->ora, l->O, oh, oo),
                  (sum->num_parameters_reduced == so.num_parameters_reduced && sum->num_residuals_reduced == so.num_residuals_reduced) ? 1 : 0,
                  prm->function_tolerance, (int)prm->max_num_iterations, sum->message, so.message);
     std::fflush(f);

@@ -251,7 +251,7 @@ def _runner_hooks(stderr):
 def test_reference_shaped_runner_is_the_same_session(oracle_driver, oracle_session, scene, tmp_path):
     """OfflineProblemRunner<InputProblemData, VisualFeatureFactorType, OutputProblemData, CachedFactorInfo, PoseGraphType> with the reference's fifteen
     constructor arguments (offline_problem_runner.h:27-98; a construction site as optimization_runner.h:509-543 writes it): the same session, digit for
-    digit, as the short constructor + setters; the per-factor ceres hooks are accepted and reported as unused; the visualization callback is called where
+    digit, as the short constructor + setters (the per-factor hooks run: a creator that makes every residual changes nothing); the visualization callback is called where
     the reference calls it (:164, :392, :512, :908, :245, :263)."""
     prob, path, _ = scene
     out = str(tmp_path / "out.json")
@@ -261,7 +261,8 @@ def test_reference_shaped_runner_is_the_same_session(oracle_driver, oracle_sessi
     a, b = json.load(open(out)), json.load(open(oracle_session[0]))
     assert a["records"] == b["records"] and a["poses"] == b["poses"] and a["objects"] == b["objects"] and a.get("long_term_map") == b.get("long_term_map")
     hooks = _runner_hooks(r.stderr)
-    assert hooks["ignored_hooks"] == ["refresh_residual_checker", "residual_creator", "ceres_callback_creator"]
+    assert hooks["ignored_hooks"] == ["ceres_callback_creator"]                       # round 6: the per-factor seam is honoured (test below); only the per-iteration callback has nobody to call it
+    assert hooks["creator_calls"] > 10000 and hooks["creator_rejections"] == 0 and hooks["factors_left_out"] == 0 and hooks["refresh_calls"] > 0   # a creator that makes every residual: the same session
     before_any, before_each, after_each, after_pgo, after_all, after_post = hooks["visualization_calls"]
     P = len(prob["poses"])
     n_gba = sum(1 for rec in a["records"] if rec["kind"] == "pgo")
@@ -270,6 +271,32 @@ def test_reference_shaped_runner_is_the_same_session(oracle_driver, oracle_sessi
     assert before_each >= P and after_each == attempts <= before_each                # one runOptimizationIteration per frame from 1 on + the final one (+ re-runs after
                                                                                      # merges); AFTER_EACH only where the visual-feature optimisation ran (:522, :908)
     assert after_pgo == n_gba and n_gba >= 1
+
+
+def test_a_residual_creator_that_cannot_make_a_residual_leaves_the_factor_out(oracle_driver, oracle_session, scene, tmp_path):
+    """The reference's per-factor seam (object_pose_graph_optimizer.h:98-113, :1016-1052; residual_creator.h:347-436): buildPoseGraphOptimization offers every factor
+    it selected to the caller's residual_creator, and one that returns false -- "Could not make residual" -- is left out of the problem.  Here: the reference-shaped
+    runner with a creator that fails on every observation factor (visual, bounding box) whose id is 6 modulo 7.  Every problem of the session then holds exactly
+    the other factors: the first window's residual count drops by the rejected share, every record's factor count does, the trajectory is still recovered, and the
+    creator was asked again at every build (refresh_residual_checker says "refresh", as the reference's does, offline_problem_runner.h:273-279)."""
+    prob, path, _ = scene
+    out = str(tmp_path / "out.json")
+    r = subprocess.run([oracle_driver, path, out, "--window", "20", "--gba-frequency", "25", "--ltm", "--creator-rejects-every", "7"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hooks = _runner_hooks(r.stderr)
+    assert hooks["ignored_hooks"] == ["ceres_callback_creator"]
+    assert hooks["creator_rejections"] > 1000 and hooks["factors_left_out"] == hooks["creator_rejections"]      # every rejection left a factor out, at every build
+    assert 0.10 < hooks["creator_rejections"] / hooks["creator_calls"] < 0.16                                     # about every seventh of the observation factors (1/7 = 0.143, less the other families)
+    assert r.stderr.count("Could not make residual for factor type") == hooks["creator_rejections"]              # the reference's message (:1049-1050)
+    a, b = json.load(open(out)), json.load(open(oracle_session[0]))
+    assert a["ok"] and [(x["kind"], x["min_frame"], x["max_frame"]) for x in a["records"]] == [(x["kind"], x["min_frame"], x["max_frame"]) for x in b["records"]]
+    # fewer factors in every visual optimisation: the sum of squared residuals at the start of a window is smaller than the full session's
+    pairs = [(x, y) for x, y in zip(a["records"], b["records"]) if x["kind"] == "lba_phase_1" and y["initial_cost"] > 1.0 and x["max_frame"] < 22]
+    assert pairs and all(x["initial_cost"] < y["initial_cost"] for x, y in pairs)
+    assert a["records"] != b["records"]
+    poses = np.array(a["poses"])
+    err0 = np.linalg.norm(prob["poses"][:, :3] - prob["gt_poses"][:, :3], axis=1).mean()
+    assert np.linalg.norm(poses[:, :3] - prob["gt_poses"][:, :3], axis=1).mean() < 0.7 * err0                  # six sevenths of the data still beat the odometry
 
 
 def test_planning_the_next_window_beside_the_solve_is_the_same_session(oracle_driver, oracle_session, scene, tmp_path):
@@ -431,6 +458,31 @@ def test_hip_session_against_the_oracle_session(driver, oracle_session, scene, t
         ch, co = np.array(hip["long_term_map"][oid]["covariance"]).reshape(7, 7), np.array(e["covariance"]).reshape(7, 7)
         keep = [0, 1, 2, 4, 5, 6]   # without the yaw (above)
         assert np.abs(np.sqrt(np.diag(ch)[keep]) - np.sqrt(np.diag(co)[keep])).max() <= 0.2 * np.sqrt(np.diag(co)[keep]).max()
+
+
+@pytest.mark.gpu
+def test_hip_session_with_a_rejecting_creator_against_the_oracle_session(driver, oracle_driver, scene, tmp_path):
+    """The per-factor seam on the device path: the same creator (fails on every observation factor with id 6 modulo 7) in the HIP-bound and in the oracle-bound
+    driver -- the same factors are left out of every problem, the first windows are the oracle's LM runs step for step, the session ends where the oracle's does."""
+    prob, path, _ = scene
+    outs = []
+    for exe, name in ((driver, "hip"), (oracle_driver, "oracle")):
+        out = str(tmp_path / (name + ".json"))
+        r = subprocess.run([exe, path, out, "--window", "20", "--gba-frequency", "25", "--creator-rejects-every", "7"], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((json.load(open(out)), _runner_hooks(r.stderr)))
+    (hip, hh), (ora, ho) = outs
+    assert hh["ignored_hooks"] == ho["ignored_hooks"] == ["ceres_callback_creator"] and hh["creator_rejections"] > 1000
+    rh, ro = hip["records"], ora["records"]
+    assert [(r["kind"], r["min_frame"], r["max_frame"]) for r in rh] == [(r["kind"], r["min_frame"], r["max_frame"]) for r in ro]
+    first = [(a, b) for a, b in zip(rh, ro) if b["initial_cost"] > 1e-3][:3]
+    for a, b in first:
+        assert (a["n_poses"], a["n_features"], a["n_excluded"], a["iterations"]) == (b["n_poses"], b["n_features"], b["n_excluded"], b["iterations"])
+        assert abs(a["initial_cost"] - b["initial_cost"]) <= 1e-10 * b["initial_cost"] and abs(a["final_cost"] - b["final_cost"]) <= 1e-8 * b["final_cost"]
+    same_size = sum((a["n_poses"], a["n_features"]) == (b["n_poses"], b["n_features"]) for a, b in zip(rh, ro))
+    assert same_size >= 0.95 * len(ro)
+    ph, po = np.array(hip["poses"]), np.array(ora["poses"])
+    assert np.abs(ph[:, :3] - po[:, :3]).max() <= 3e-2 and np.abs(ph[:, 3:] - po[:, 3:]).max() <= 3e-3
 
 
 @pytest.mark.gpu

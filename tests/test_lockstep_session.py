@@ -66,7 +66,17 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
     # END state of the worst such run over ten sessions (1 551 runs): cost 2.3e-5, poses 1.6e-5.  An INTERMEDIATE iterate may be further off than the end state (a
     # 9-iteration window: 1.6e-4 at one iterate, 9e-7 at the end; the tail over those 1 551 runs: 1.6e-4, 8.8e-5, 8.3e-5, 6.1e-5, ...): it gets a sanity bound only
     assert worst["final_cost_rel"] <= 2e-4 and worst["pose_diff"] <= 1e-4 and worst["max_iteration_cost_rel"] <= 1e-3
-    assert med["object_diff"] <= 1e-6 and worst["object_diff"] <= 1.0       # measured: 5e-8; 0.26 -- an object a window sees from a few frames only is weakly constrained along its viewing ray (yaw excluded altogether)
+    # objects: in units of the oracle's OWN 7x7 covariance block of the object (sqrt(d^T Sigma^-1 d), yaw included; tests/lockstep_shim.cpp whitened_object_diff) -- the
+    # absolute difference (median 5e-8 m, but 0.26 m for an object a window sees from a few frames along one viewing ray) says little: what that bar of 1.0 could hide is
+    # a defect in a well-constrained block, and the whitened difference cannot
+    wh = [r["object_diff_whitened"] for r in good if r["objects"] > 0 and r["object_diff_whitened"] >= 0.0]
+    print("whitened object differences over %d runs with objects (%d without a covariance): median %.2e, 90%% %.2e, worst %.2e; absolute: median %.2e worst %.2e"
+          % (len(wh), sum(1 for r in good if r["objects"] > 0 and r["object_diff_whitened"] < 0.0), np.median(wh), np.quantile(wh, 0.9), max(wh), med["object_diff"], worst["object_diff"]))
+    # What the bar can be: two runs of a LOOSELY converged window (function tolerance 1e-3 / 1e-4) end a fraction of a sigma apart in their weakest object -- the fp64
+    # oracle against its own extended-precision build on six windows of this size: 5e-7 ... 0.54 sigma (yaw taken modulo pi; without that, thousands of radians of drift
+    # in the yaw of ellipsoids with equal horizontal axes).  So: typically far below a sigma, never beyond one -- a block that is wrong by more than the oracle's own
+    # uncertainty about it fails.
+    assert len(wh) >= 50 and med["object_diff"] <= 1e-6 and np.median(wh) <= 1e-2 and np.quantile(wh, 0.9) <= 0.5 and max(wh) <= 1.0
     # (2) Where they are not, the END STATE says why, run by run (round 5; before: a bar on the share of such runs, taken from its distribution over sixty sessions):
     #   (a) the stopping rule.  A run of the reference's blocks ends when |cost change| <= function_tolerance * cost; decided in the last bits, two runs that agree to
     #       1e-12 up to there stop k = 1 ... 4 iterations apart, and their final costs then differ by about k x that tolerance -- measured 0.8 ... 1.7 x k x the tolerance
