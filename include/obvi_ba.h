@@ -303,7 +303,7 @@ int obvi_ba_set_shared_objects(obvi_ba_handle* h, const uint8_t* is_shared /*[n 
  *   type 5: r[n][6], J0 = d/dpose_a [n][6][6], J1 = d/dpose_b [n][6][6]  */
 int obvi_ba_debug_linearize(obvi_ba_handle* h, int32_t factor_type, double* r, double* J0, double* J1);
 /* the selection rule of obvi_ba_select_outliers (offline_problem_runner.h:769-800) on block norms given by the caller: mask_out[i] = 0
- * for the excluded ones, 1 for the kept active ones, 0 for inactive ones; active may be NULL (all).  OBVI_SELECT_SORT=1 takes the sort route. */
+ * for the excluded ones, 1 for the kept active ones, 0 for inactive ones; active may be NULL (all). */
 int obvi_ba_debug_select(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t* active, double fraction, uint8_t* mask_out, int64_t* num_excluded);
 /* dense reduced (Schur) system at the current estimate for LM diagonal 1/radius:
  * lhs [m][m] row-major symmetric, rhs [m]; order = variable poses then variable objects. */

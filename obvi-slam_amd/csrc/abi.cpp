@@ -359,16 +359,13 @@ int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6, double* point3, dou
 
 namespace {
 // the selection over `n` block norms on the device (select_kernels.hip), the mask into the caller's memory: ONE wait for the device
-// unless the threshold route has to hand over to the sort (more than 4096 distinct values sharing their top 24 bits)
 void run_selection(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t* act, const uint32_t* inv, double fraction, uint8_t* mask_out, int64_t* num_excluded) {
   h->d_sel_mask.resize((size_t)n + 1);
-  const char* sort_env = std::getenv("OBVI_SELECT_SORT");   // read per call: a host (or a test) may set it after the first selection of the process
-  const bool sort_route = sort_env != nullptr && std::atoi(sort_env) != 0;   // route (b) always (its check)
   int n_out = 0;
-  bool done = false;
-  if (!sort_route) {
+  // one round is four launches and one wait; a further round only when more than 4096 distinct values share the open bin's bits (24 more bits each: at most three rounds)
+  for (int round = 0; round <= 2; ++round) {
     const int* result_dev = nullptr;
-    OBVI_HIP(select_by_threshold(h->stream, n, sq, act, inv, fraction, h->d_sel_mask.get(), &h->sel_scratch, &result_dev));
+    OBVI_HIP(select_by_threshold(h->stream, n, sq, act, inv, fraction, h->d_sel_mask.get(), &h->sel_scratch, &result_dev, round));
     void* pinned_mask = n ? h->staging.take((size_t)n) : nullptr;
     int* pinned_result = static_cast<int*>(h->staging.take(2 * sizeof(int)));
     int pageable_result[2] = {0, 0};
@@ -376,16 +373,12 @@ void run_selection(obvi_ba_handle* h, int64_t n, const double* sq, const uint8_t
     OBVI_HIP(hipMemcpyAsync(pinned_result ? pinned_result : pageable_result, result_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     sync(h);
     const int* result = pinned_result ? pinned_result : pageable_result;
+    n_out = result[0];
     if (result[1] == 0) {
       if (pinned_mask) std::memcpy(mask_out, pinned_mask, (size_t)n);
-      n_out = result[0];
-      done = true;
+      break;
     }
-  }
-  if (!done) {
-    OBVI_HIP(select_outliers_sorted(h->stream, n, sq, act, inv, fraction, h->d_sel_mask.get(), &n_out, &h->sel_scratch));
-    h->d_sel_mask.download(mask_out, (size_t)n, h->stream);
-    sync(h);
+    if (result[1] != round + 1 || round == 2) throw HipError{hipErrorUnknown, "outlier selection: the radix select did not finish", __FILE__, __LINE__};
   }
   if (num_excluded) *num_excluded = n_out;
 }

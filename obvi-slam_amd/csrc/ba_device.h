@@ -216,17 +216,12 @@ void launch_pack_scalars(hipStream_t s, double* scal, double* buf, int32_t rank,
 
 // ---- outlier selection (select_kernels.hip) ---------------------------------------------
 struct SelectScratch {
-  void *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr, *head = nullptr, *rank = nullptr, *counters = nullptr, *tmp = nullptr;
-  size_t cap_keys_in = 0, cap_keys_out = 0, cap_vals_in = 0, cap_vals_out = 0, cap_head = 0, cap_rank = 0, cap_counters = 0, cap_tmp = 0;
-  void *tbl = nullptr, *aux = nullptr;   // route (a): hash table (keys, then representatives); histograms, counters, result, candidates
+  void *tbl = nullptr, *aux = nullptr;   // hash table (keys, then representatives); histograms, counters, result, carry between rounds, candidates
   size_t tbl_slots = 0;
 };
-// route (a) of select_kernels.hip: launches only; *result_dev -> {number excluded, 1 = unfinished: take route (b)} on the device
+// launches only; *result_dev -> {number excluded, r} on the device: r = 0 finished, r > 0: call again with round = r (more than 4096 distinct values in the last bin; r <= 2)
 hipError_t select_by_threshold(hipStream_t s, int64_t n, const double* sq, const uint8_t* active, const uint32_t* inv, double fraction,
-                               uint8_t* mask_out, SelectScratch* scratch, const int** result_dev);
-// route (b): sort; waits for the device
-hipError_t select_outliers_sorted(hipStream_t s, int64_t n, const double* sq, const uint8_t* active, const uint32_t* inv, double fraction,
-                                  uint8_t* mask_out, int* n_excluded_host, SelectScratch* scratch);
+                               uint8_t* mask_out, SelectScratch* scratch, const int** result_dev, int round = 0);
 void select_scratch_free(SelectScratch* sc);
 
 // ---- tile Cholesky (chol_kernels.hip) --------------------------------------------------

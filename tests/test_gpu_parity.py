@@ -601,14 +601,12 @@ def test_column_norms_and_parameter_priors_of_the_covariance_extraction():
         g.object_covariances(np.arange(3))
 
 
-@pytest.mark.parametrize("route", ["threshold", "sort"])
-def test_outlier_selection_rule_on_given_values(route, monkeypatch):
+def test_outlier_selection_rule_on_given_values():
     """K8 alone (obvi_ba_debug_select) against the map rule: values spread over many exponents and values packed into one (the radix
-    select's three levels), heavy ties (a handful of distinct values: the entries are the distinct ones), inactive factors, zeros,
-    fractions 0 / tiny / 0.1 / 1, one value, none, and more than 4096 distinct values sharing their top 24 bits (the threshold route hands
-    over to the sort).  Both routes -- the histogram / hash-table one and the radix sort (OBVI_SELECT_SORT=1) -- give the same masks."""
-    if route == "sort":
-        monkeypatch.setenv("OBVI_SELECT_SORT", "1")
+    select's levels), heavy ties (a handful of distinct values: the entries are the distinct ones), inactive factors, zeros,
+    fractions 0 / tiny / 0.1 / 1, one value, none, and more than 4096 distinct values sharing their top 24 bits -- 300 000 values in [1, 1.001) -- or even
+    their top 48 -- 20 000 neighbours in the last mantissa bits: the select then goes a second and a third round on the open bin alone (round 6: its own
+    continuation; rounds 1-5 handed those cases to hipCUB's radix sort)."""
     g = helpers.product_ba()
     rng = np.random.default_rng(12)
     cases = []

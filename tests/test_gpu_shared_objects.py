@@ -465,6 +465,34 @@ def test_bench_two_ranks_oversubscribed():
     assert line["roofline"]["kernel"] and "cpu_baseline" not in line
 
 
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_eight_ranks_oversubscribed(config):
+    """The command line the driver runs on an eight-GPU node -- `bench.py --gpus 8` -- with all eight ranks on this one GPU (`--oversubscribe`: process group gloo, the
+    three collectives staged through the host): config 4 (eight 500-keyframe windows sharing 25 objects) and config 5 (sixteen sessions over one 200-object map, two
+    fused per rank).  A smoke test of the WHOLE N = 8 path -- self-spawn, seeds, uploads, the scaling baseline, three collectives per step in the same order on every
+    rank, the time limit around them, the reduction of the timings, the one JSON line -- not a timing (DESIGN section 8 used to say "run by hand")."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "8", "--oversubscribe", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--config", str(config)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1700, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert cfg["rccl_ranks"] == 8 and cfg["oversubscribed"] and cfg["steps_done"] == 2
+    assert cfg["collective_issue_order"]["same_on_every_rank"] and cfg["collective_issue_order"]["collectives_issued"] >= 3 * 2
+    if config == 5:
+        assert cfg["sessions"] == 16 and cfg["sessions_per_rank"] == 2
+    assert len(line["scaling_baseline"]["per_rank_value"]) == 8
+
+
 def test_rccl_rendezvous_file(tmp_path, monkeypatch):
     """obvi_rccl_comm_create_from_file: the launcher-less rendezvous of a C++ host (rank 0 writes the id, the others poll).  The file lives only
     for the rendezvous: rank 0 replaces whatever an earlier run left at the path and removes its own file once the communicator exists, so a

@@ -76,6 +76,7 @@ def test_every_optimisation_of_a_session_follows_the_oracle(lockstep_driver, sce
     # oracle against its own extended-precision build on six windows of this size: 5e-7 ... 0.54 sigma (yaw taken modulo pi; without that, thousands of radians of drift
     # in the yaw of ellipsoids with equal horizontal axes).  So: typically far below a sigma, never beyond one -- a block that is wrong by more than the oracle's own
     # uncertainty about it fails.
+    # Measured (two sessions, 132-133 runs with objects): median 4e-5 / 6e-4 sigma, 90 % 0.06 / 0.09, worst 0.20 / 0.22; half of the runs below 1e-3.
     assert len(wh) >= 50 and med["object_diff"] <= 1e-6 and np.median(wh) <= 1e-2 and np.quantile(wh, 0.9) <= 0.5 and max(wh) <= 1.0
     # (2) Where they are not, the END STATE says why, run by run (round 5; before: a bar on the share of such runs, taken from its distribution over sixty sessions):
     #   (a) the stopping rule.  A run of the reference's blocks ends when |cost change| <= function_tolerance * cost; decided in the last bits, two runs that agree to
