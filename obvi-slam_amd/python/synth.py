@@ -218,6 +218,16 @@ def make_problem(P, L, O=0, seed=20241008, outlier_frac=0.05, const_poses=1, pix
                 rp_pose=obs_pose, rp_point=obs_point, rp_cam=obs_cam, rp_pixel=obs_pix,
                 rp_sigma=rp["reproj_sigma"], rp_huber=rp["reproj_huber"], rp_is_outlier=is_out)
     prob["pose_const"][:const_poses] = 1
+    import os as _os
+    if _os.environ.get("OBVI_SYNTH_SORT_POINTS"):
+        # experiment (round 6): feature ids in the order of first sighting, as a front end that numbers features when it first sees them hands them over
+        # (the generator's ids are random with respect to the trajectory)
+        firstf = np.full(len(points), P, np.int64); np.minimum.at(firstf, obs_point.astype(np.int64), obs_pose.astype(np.int64))
+        rank = np.empty(len(points), np.int64); rank[np.argsort(firstf, kind="stable")] = np.arange(len(points))
+        inv = np.argsort(rank)
+        q_point = rank[obs_point.astype(np.int64)].astype(np.uint32)
+        order2 = np.lexsort((obs_cam, obs_pose, q_point))
+        prob.update(points=points[inv], gt_points=gt_points[inv], rp_point=q_point[order2], rp_pose=obs_pose[order2], rp_cam=obs_cam[order2], rp_pixel=obs_pix[order2], rp_is_outlier=is_out[order2])
 
     # ---- objects --------------------------------------------------------------------------
     objects = np.zeros((0, 7)); gt_objects = np.zeros((0, 7))

@@ -485,7 +485,7 @@ def test_bench_eight_ranks_oversubscribed(config):
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
     cfg = line["config"]
-    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == ("weak" if config == 4 else "strong") and line["value"] > 0   # config 5: sixteen sessions whatever the rank count
     assert cfg["rccl_ranks"] == 8 and cfg["oversubscribed"] and cfg["steps_done"] == 2
     assert cfg["collective_issue_order"]["same_on_every_rank"] and cfg["collective_issue_order"]["collectives_issued"] >= 3 * 2
     if config == 5:
