@@ -490,7 +490,8 @@ def test_bench_eight_ranks_oversubscribed(config):
     assert cfg["collective_issue_order"]["same_on_every_rank"] and cfg["collective_issue_order"]["collectives_issued"] >= 3 * 2
     if config == 5:
         assert cfg["sessions"] == 16 and cfg["sessions_per_rank"] == 2
-    assert len(line["scaling_baseline"]["per_rank_value"]) == 8
+    if config == 4:
+        assert len(line["scaling_baseline"]["per_rank_value"]) == 8                      # (config 5 is a strong-scaling workload: no one-window baseline)
 
 
 def test_rccl_rendezvous_file(tmp_path, monkeypatch):
