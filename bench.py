@@ -1103,7 +1103,11 @@ def main():
                        "parallelism": ("windows+allreduce" if shared else "replicas") if world > 1 else "single",
                        "rccl_ranks": rccl_ranks, "allreduce_hook": (args.hook if shared else None), "oversubscribed": bool(args.oversubscribe),
                        "rccl_versions": rccl_versions, "collective_issue_order": issue_order, "collectives_us": collectives_us, "steps_done": steps_done,
-                       "final_cost": summ.final_cost, "termination": summ.message.decode()},
+                       "final_cost": summ.final_cost, "termination": summ.message.decode(),
+                       # the mix of the timed steps: a rejected step costs a full linearisation here -- with the stored Z = rho' Jp^T Jl C^-T the
+                       # point pass IS the cheapest re-damp, what a rejected step could skip is the side stream (0.1 ms of contention at this size; EXPERIMENTS round 6)
+                       "accepted_steps": int(sum(1 for it in ba_timed_iterations[1:] if it.step_is_successful)),
+                       "rejected_or_invalid_steps": int(sum(1 for it in ba_timed_iterations[1:] if not it.step_is_successful))},
             "roofline": roof,
             "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
             "phases_ms_avg": {k: round(v["ms_avg"], 4) for k, v in phases.items()},
