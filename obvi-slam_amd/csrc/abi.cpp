@@ -342,13 +342,13 @@ int obvi_ba_column_sqnorms(obvi_ba_handle* h, double* pose6, double* point3, dou
   sync(h);
   auto colsq = [](double scale) { const double r = 1.0 / scale - 1.0; return r * r; };
   if (pose6) for (int64_t p = 0; p < h->P; ++p) for (int k = 0; k < 6; ++k) pose6[6 * p + k] = pose_vid[p] >= 0 ? colsq(sc[6 * (int64_t)pose_vid[p] + k]) : -1.0;
-  if (point3) for (int64_t l = 0; l < h->L; ++l) for (int k = 0; k < 3; ++k) point3[3 * l + k] = point_var[l] ? colsq(sl[3 * l + k]) : -1.0;
+  if (point3) for (int64_t l = 0; l < h->L; ++l) { const int64_t li = pt_internal(h, l); for (int k = 0; k < 3; ++k) point3[3 * l + k] = point_var[li] ? colsq(sl[3 * li + k]) : -1.0; }
   if (object7) for (int64_t o = 0; o < h->O; ++o) for (int k = 0; k < h->od; ++k) object7[h->od * o + k] = obj_vid[o] >= 0 ? colsq(sc[6 * h->nPv + h->od * (int64_t)obj_vid[o] + k]) : -1.0;
   for (size_t i = 0; i < h->h_pp_kind.size(); ++i) {
     const double w = 1.0 / (h->h_pp_std[i] * h->h_pp_std[i]);
     const int64_t b = h->h_pp_block[i];
     if (h->h_pp_kind[i] == 0 && pose6 && pose_vid[b] >= 0) pose6[6 * b + h->h_pp_param[i]] += w;
-    else if (h->h_pp_kind[i] == 1 && point3 && point_var[b]) point3[3 * b + h->h_pp_param[i]] += w;
+    else if (h->h_pp_kind[i] == 1 && point3 && point_var[pt_internal(h, b)]) point3[3 * b + h->h_pp_param[i]] += w;
     else if (h->h_pp_kind[i] == 2 && object7 && obj_vid[b] >= 0) object7[h->od * b + h->h_pp_param[i]] += w;
   }
   return OBVI_OK;
@@ -463,7 +463,16 @@ static int get_blocks(obvi_ba_handle* h, const DevBuf<double>& d, int64_t n, int
   OBVI_API_END(h)
 }
 int obvi_ba_get_poses(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_pose, h->P, 6, out) : OBVI_ERR_INVALID_ARGUMENT; }
-int obvi_ba_get_points(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_point, h->L, 3, out) : OBVI_ERR_INVALID_ARGUMENT; }
+int obvi_ba_get_points(obvi_ba_handle* h, double* out) {
+  if (!h || (h->L > 0 && !out)) return OBVI_ERR_INVALID_ARGUMENT;
+  OBVI_API_BEGIN
+  OBVI_HIP(hipSetDevice(h->device));
+  const double* src = points_in_caller_order(h, h->d_point);
+  if (h->L > 0) OBVI_HIP(hipMemcpyAsync(out, src, sizeof(double) * 3 * (size_t)h->L, hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  return OBVI_OK;
+  OBVI_API_END(h)
+}
 int obvi_ba_get_objects(obvi_ba_handle* h, double* out) { return h ? get_blocks(h, h->d_obj, h->O, h->od, out) : OBVI_ERR_INVALID_ARGUMENT; }
 
 int obvi_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* objects) {
@@ -476,7 +485,9 @@ int obvi_ba_get_state(obvi_ba_handle* h, double* poses, double* points, double* 
   for (Part& p : parts) {
     if (!p.out || !p.n) continue;
     p.pinned = h->staging.take(p.n * sizeof(double));
-    p.d->download(p.pinned ? static_cast<double*>(p.pinned) : p.out, p.n, h->stream);
+    double* dst = p.pinned ? static_cast<double*>(p.pinned) : p.out;
+    if (p.d == &h->d_point) OBVI_HIP(hipMemcpyAsync(dst, points_in_caller_order(h, h->d_point), p.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // (the caller's feature numbering)
+    else p.d->download(dst, p.n, h->stream);
   }
   sync(h);
   for (Part& p : parts) if (p.pinned) std::memcpy(p.out, p.pinned, p.n * sizeof(double));

@@ -208,6 +208,8 @@ void launch_debug_linearize_reproj(hipStream_t s, const ReprojDev& rp, const uin
 void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFactorsDev& sf, const DevCam* cams,
                                   const double* poses, const double* objects, double* r, double* J0, double* J1);
 void launch_fill(hipStream_t s, double* p, int64_t n, double v);
+// dst row i = src row map[i], rows of three doubles (features between the caller's numbering and the internal one)
+void launch_permute_rows3(hipStream_t s, double* dst, const double* src, const uint32_t* map, int64_t n);
 // multi-GPU exchange buffers: shared objects' (Hdiag 49 | g 7) and the trailing tiles [t0, nt) + rhs rows
 void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack);
 void launch_pack_tail(hipStream_t s, const ReducedDev& rd, int32_t t0, double* buf, int unpack);

@@ -59,7 +59,16 @@ struct obvi_ba_handle {
   // ---- host mirrors ----
   std::vector<DevCam> h_cams;
   int64_t P = 0, L = 0, O = 0;
-  std::vector<uint8_t> h_pose_const, h_point_const, h_object_const;
+  std::vector<uint8_t> h_pose_const, h_point_const, h_object_const;   // (h_point_const: in the INTERNAL feature order, below)
+  // Internal feature numbering (round 6).  Everything the kernels index by feature -- d_point and its copies, the per-feature arrays, the observation lists, the plan --
+  // uses ids in the order of the features' FIRST observing pose (obvi_ba_set_reproj decides it, for problems of OBVI_POINT_RENUMBER_MIN observations or more): a
+  // wavefront's 64 observations then belong to neighbouring poses and the pose-cache gathers of the point pass, the back-substitution and the trial cost share cache
+  // lines (1.6 % of an LM step of config #3 with the generator's random ids, profiles/r06_point_order.txt).  The caller's numbering stops at the ABI: set / get / update
+  // of features, constness flags, parameter priors and column norms go through these maps (empty = identity).
+  std::vector<uint32_t> h_pt_new_of_old, h_pt_old_of_new, scr_point_internal;
+  bool pt_map_applied = false;   // d_point / h_point_const are in the internal order (false: no numbering, or the caller has just set a feature count the observations do not fit -- an error state until it is repaired)
+  DevBuf<uint32_t> d_pt_new_of_old, d_pt_old_of_new, d_pt_map_tmp;
+  DevBuf<double> d_pt_tmp;
   std::vector<double> h_obj_xy;   // (x, y) of every object AS UPLOADED (obvi_ba_set_objects): the spatial key that orders the shared tail (plan.cpp) -- the same on every rank
   // reprojection: sorted by (point, pose); perm[sorted] = caller index
   int64_t n_rp = 0;
@@ -521,6 +530,21 @@ inline bool check_ready(obvi_ba_handle* h) {
 }
 
 // 1 / std_dev^2 of every parameter prior at its parameter's place: compact reduced index for poses / objects, [L][3] for points
+inline bool pt_mapped(const obvi_ba_handle* h) { return h->pt_map_applied && !h->h_pt_new_of_old.empty() && (int64_t)h->h_pt_new_of_old.size() == h->L; }
+inline int64_t pt_internal(const obvi_ba_handle* h, int64_t caller_index) { return pt_mapped(h) ? (int64_t)h->h_pt_new_of_old[(size_t)caller_index] : caller_index; }
+// d_point (caller order, just uploaded) -> internal order; and back into d_pt_tmp for a download
+inline void points_to_internal(obvi_ba_handle* h, DevBuf<double>& buf) {
+  if (!pt_mapped(h) || h->L == 0) return;
+  h->d_pt_tmp.resize((size_t)3 * h->L + 1);
+  obvi::launch_permute_rows3(h->stream, h->d_pt_tmp.get(), buf.get(), h->d_pt_old_of_new.get(), h->L);
+  buf.swap(h->d_pt_tmp);
+}
+inline const double* points_in_caller_order(obvi_ba_handle* h, const DevBuf<double>& buf) {
+  if (!pt_mapped(h) || h->L == 0) return buf.get();
+  h->d_pt_tmp.resize((size_t)3 * h->L + 1);
+  obvi::launch_permute_rows3(h->stream, h->d_pt_tmp.get(), buf.get(), h->d_pt_new_of_old.get(), h->L);
+  return h->d_pt_tmp.get();
+}
 inline void upload_parameter_prior_diagonals(obvi_ba_handle* h) {
   if (h->h_pp_kind.empty()) return;
   std::vector<double> ec((size_t)h->m_canon + 1, 0.0), el((size_t)3 * h->L + 1, 0.0);
@@ -532,7 +556,7 @@ inline void upload_parameter_prior_diagonals(obvi_ba_handle* h) {
     const double w = 1.0 / (h->h_pp_std[i] * h->h_pp_std[i]);
     const int64_t b = h->h_pp_block[i];
     if (h->h_pp_kind[i] == 0) { if (pose_vid[b] >= 0) ec[6 * (int64_t)pose_vid[b] + h->h_pp_param[i]] += w; }
-    else if (h->h_pp_kind[i] == 1) el[3 * b + h->h_pp_param[i]] += w;
+    else if (h->h_pp_kind[i] == 1) el[3 * pt_internal(h, b) + h->h_pp_param[i]] += w;
     else if (obj_vid[b] >= 0) ec[6 * h->nPv + h->od * (int64_t)obj_vid[b] + h->h_pp_param[i]] += w;
   }
   h->d_extra_c.upload(ec, h->stream); h->d_extra_l.upload(el, h->stream);

@@ -1838,6 +1838,15 @@ void launch_debug_linearize_small(hipStream_t s, int factor_type, const SmallFac
   const int64_t n = factor_type == 2 ? sf.n_bb : factor_type == 3 ? sf.n_sp : factor_type == 4 ? sf.n_lt : sf.n_rl;
   if (n > 0) hipLaunchKernelGGL(k_debug_lin_small, dim3(grid_for(n, 64)), dim3(64), 0, s, factor_type, sf, cams, poses, objects, r, J0, J1);
 }
+__global__ void __launch_bounds__(kBlock) k_permute_rows3(double* __restrict__ dst, const double* __restrict__ src, const uint32_t* __restrict__ map, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t j = map[i];
+  dst[3 * i] = src[3 * j]; dst[3 * i + 1] = src[3 * j + 1]; dst[3 * i + 2] = src[3 * j + 2];
+}
+void launch_permute_rows3(hipStream_t s, double* dst, const double* src, const uint32_t* map, int64_t n) {
+  if (n > 0) hipLaunchKernelGGL(k_permute_rows3, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, dst, src, map, n);
+}
 void launch_pack_shared_blocks(hipStream_t s, const BlocksDev& b, const ReducedDev& rd, const int32_t* shared_ov, int32_t n_shared, double* buf, int unpack) {
   if (n_shared > 0) hipLaunchKernelGGL(k_pack_shared_blocks, dim3(n_shared), dim3(128), 0, s, b, rd, shared_ov, n_shared, buf, unpack);
 }

@@ -34,7 +34,26 @@ static int set_blocks(obvi_ba_handle* h, int64_t n, int dim, const double* v, co
   OBVI_API_END(h)
 }
 int obvi_ba_set_poses(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 6, v, c, h ? &h->P : nullptr, h ? &h->h_pose_const : nullptr, h ? &h->d_pose : nullptr); }
-int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) { return set_blocks(h, n, 3, v, c, h ? &h->L : nullptr, h ? &h->h_point_const : nullptr, h ? &h->d_point : nullptr); }
+// the caller's constness flags of the features (just assigned to h_point_const in the caller's order) into the internal order
+static void point_flags_to_internal(obvi_ba_handle* h) {
+  if (!pt_mapped(h)) return;
+  std::vector<uint8_t> in((size_t)h->L);
+  for (int64_t l = 0; l < h->L; ++l) in[h->h_pt_new_of_old[(size_t)l]] = h->h_point_const[(size_t)l];
+  h->h_point_const.swap(in);
+}
+int obvi_ba_set_points(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) {
+  // (the numbering belongs to the observations: it stays until obvi_ba_set_reproj makes another.  A feature count it does not fit leaves the values in the caller's
+  //  order -- the handle is then in the error state validate_indices reports -- and the same count again, or new observations, repair it)
+  const int rc = set_blocks(h, n, 3, v, c, h ? &h->L : nullptr, h ? &h->h_point_const : nullptr, h ? &h->d_point : nullptr);
+  if (rc == OBVI_OK) h->pt_map_applied = !h->h_pt_new_of_old.empty() && (int64_t)h->h_pt_new_of_old.size() == n;
+  if (rc == OBVI_OK && h->pt_map_applied) {
+    OBVI_API_BEGIN
+    points_to_internal(h, h->d_point); point_flags_to_internal(h);
+    sync(h);
+    OBVI_API_END(h)
+  }
+  return rc;
+}
 int obvi_ba_set_objects(obvi_ba_handle* h, int64_t n, const double* v, const uint8_t* c) {
   const int rc = set_blocks(h, n, h ? h->od : 7, v, c, h ? &h->O : nullptr, h ? &h->h_object_const : nullptr, h ? &h->d_obj : nullptr);
   if (rc == OBVI_OK) {   // where the objects are, for the order of the shared tail (every rank uploads the shared objects with the same values: include/obvi_ba.h)
@@ -48,7 +67,7 @@ int obvi_ba_set_const_flags(obvi_ba_handle* h, const uint8_t* pc, const uint8_t*
   if (!h) return OBVI_ERR_INVALID_ARGUMENT;
   OBVI_API_BEGIN
   if (pc) h->h_pose_const.assign(pc, pc + h->P);
-  if (lc) h->h_point_const.assign(lc, lc + h->L);
+  if (lc) { h->h_point_const.assign(lc, lc + h->L); point_flags_to_internal(h); }
   if (oc) h->h_object_const.assign(oc, oc + h->O);
   h->dirty = true;
   return OBVI_OK;
@@ -60,6 +79,7 @@ int obvi_ba_update_points(obvi_ba_handle* h, int64_t n, const double* xyz) {
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   h2d_async(h->d_point.get(), xyz, sizeof(double) * 3 * n, h->stream);
+  points_to_internal(h, h->d_point);
   finish_upload(h);
   return OBVI_OK;
   OBVI_API_END(h)
@@ -70,7 +90,7 @@ int obvi_ba_update_state(obvi_ba_handle* h, const double* poses, const double* p
   OBVI_API_BEGIN
   OBVI_HIP(hipSetDevice(h->device));
   if (poses && h->P > 0) h2d_async(h->d_pose.get(), poses, sizeof(double) * 6 * h->P, h->stream);
-  if (points && h->L > 0) h2d_async(h->d_point.get(), points, sizeof(double) * 3 * h->L, h->stream);
+  if (points && h->L > 0) { h2d_async(h->d_point.get(), points, sizeof(double) * 3 * h->L, h->stream); points_to_internal(h, h->d_point); }
   if (objects && h->O > 0) {
     h2d_async(h->d_obj.get(), objects, sizeof(double) * h->od * h->O, h->stream);
     // The order of the shared tail follows the shared objects' (x, y) AS UPLOADED (plan.cpp), and every rank derives it from its own copy: values that arrive
@@ -109,14 +129,60 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
   // CSC by point: counting sort on the point index, then by pose inside each point.  (A sliding window calls this for every frame with
   // about the same n: the index arrays live in the handle, the device-only arrays are filled in pinned memory -- no allocation, no
   // second copy.)
+  // Internal feature numbering (ba_handle.h): by first observing pose, for problems big enough that the gathers of the per-observation kernels are what they wait for
+  // (a sliding window is bound by its launches, and its host time matters more: it keeps the caller's numbering).  OBVI_POINT_RENUMBER_MIN: observations from which on
+  // (default 2^18; 0: never).
+  {
+    const char* env = std::getenv("OBVI_POINT_RENUMBER_MIN");
+    const int64_t min_obs = env ? std::atoll(env) : ((int64_t)1 << 18);
+    std::vector<uint32_t> old_of_new;
+    bool identity = true;
+    if (min_obs > 0 && n >= min_obs && h->L > 1) {
+      std::vector<uint32_t> first((size_t)h->L, (uint32_t)h->P);
+      for (int64_t i = 0; i < n; ++i) first[point_idx[i]] = std::min(first[point_idx[i]], pose_idx[i]);
+      std::vector<uint32_t> at((size_t)h->P + 2, 0);   // counting sort by the first pose (stable: ties and unobserved features keep the caller's order)
+      for (int64_t l = 0; l < h->L; ++l) at[first[l] + 1]++;
+      for (int64_t p = 0; p <= h->P; ++p) at[p + 1] += at[p];
+      old_of_new.resize((size_t)h->L);
+      for (int64_t l = 0; l < h->L; ++l) old_of_new[at[first[l]]++] = (uint32_t)l;
+      for (int64_t l = 0; l < h->L && identity; ++l) identity = old_of_new[l] == (uint32_t)l;
+    }
+    if (identity) old_of_new.clear();
+    const bool from_internal = pt_mapped(h);   // else: the values are in the caller's order (no numbering yet, or one that was not applied to the last obvi_ba_set_points)
+    if (from_internal ? old_of_new != h->h_pt_old_of_new : !old_of_new.empty()) {
+      // the features' values and flags are in the order of the numbering in force: move them to the new one (row `new` <- row of the same feature in the old order)
+      std::vector<uint32_t> map((size_t)h->L);
+      for (int64_t nw = 0; nw < h->L; ++nw) { const uint32_t old = old_of_new.empty() ? (uint32_t)nw : old_of_new[nw]; map[nw] = from_internal ? h->h_pt_new_of_old[old] : old; }
+      h->d_pt_map_tmp.upload(map, h->stream);
+      h->d_pt_tmp.resize((size_t)3 * h->L + 1);
+      launch_permute_rows3(h->stream, h->d_pt_tmp.get(), h->d_point.get(), h->d_pt_map_tmp.get(), h->L);
+      h->d_point.swap(h->d_pt_tmp);
+      std::vector<uint8_t> flags((size_t)h->L);
+      for (int64_t nw = 0; nw < h->L; ++nw) flags[nw] = h->h_point_const[map[nw]];
+      h->h_point_const.swap(flags);
+      h->h_pt_old_of_new = old_of_new;
+      h->h_pt_new_of_old.assign(old_of_new.size(), 0);
+      for (size_t nw = 0; nw < old_of_new.size(); ++nw) h->h_pt_new_of_old[old_of_new[nw]] = (uint32_t)nw;
+      if (!old_of_new.empty()) { h->d_pt_old_of_new.upload(h->h_pt_old_of_new, h->stream); h->d_pt_new_of_old.upload(h->h_pt_new_of_old, h->stream); }
+      sync(h);                 // (`map` is a local)
+      h->have_snapshot = false;   // a snapshot taken under the old numbering cannot be restored into the new one
+    } else if (!from_internal) {
+      h->h_pt_old_of_new.clear(); h->h_pt_new_of_old.clear();   // the caller's order stays (a numbering that was never applied is dropped)
+    }
+    h->pt_map_applied = !h->h_pt_new_of_old.empty();
+  }
+  std::vector<uint32_t>& pidx = h->scr_point_internal;   // the observations' feature indices in the internal numbering
+  pidx.resize(n);
+  if (h->h_pt_new_of_old.empty()) { for (int64_t i = 0; i < n; ++i) pidx[i] = point_idx[i]; }
+  else { for (int64_t i = 0; i < n; ++i) pidx[i] = h->h_pt_new_of_old[point_idx[i]]; }
   std::vector<uint32_t>& perm = h->h_rp_perm;
   std::vector<uint32_t>& ptr = h->h_point_ptr;
   std::vector<uint32_t>& cur = h->scr_cursor;
   perm.resize(n); ptr.assign(h->L + 1, 0);
-  for (int64_t i = 0; i < n; ++i) ptr[point_idx[i] + 1]++;
+  for (int64_t i = 0; i < n; ++i) ptr[pidx[i] + 1]++;
   for (int64_t l = 0; l < h->L; ++l) ptr[l + 1] += ptr[l];
   cur.assign(ptr.begin(), ptr.end() - 1);
-  for (int64_t i = 0; i < n; ++i) perm[cur[point_idx[i]]++] = (uint32_t)i;
+  for (int64_t i = 0; i < n; ++i) perm[cur[pidx[i]]++] = (uint32_t)i;
   // ranges of points / observations on the host's worker threads -- from a few hundred thousand observations on: a window's 50 k are
   // 0.6 ms on one thread and 0.85-1.3 ms on 2-16 (waking the workers, 256 cores on two sockets passing cache lines around)
   const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 131072));
@@ -139,7 +205,7 @@ int obvi_ba_set_reproj(obvi_ba_handle* h, int64_t n, const uint32_t* pose_idx, c
     for (int64_t a = a0; a < a1; ++a) {
       const uint32_t i = perm[a];
       h->h_rp_inv[i] = (uint32_t)a;
-      h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = point_idx[i];
+      h->h_rp_pose[a] = pose_idx[i]; h->h_rp_point[a] = pidx[i];
     }
   });
   sub("    set_reproj: gather");
