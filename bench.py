@@ -1106,6 +1106,11 @@ def main():
                        "final_cost": summ.final_cost, "termination": summ.message.decode(),
                        # the mix of the timed steps: a rejected step costs a full linearisation here -- with the stored Z = rho' Jp^T Jl C^-T the
                        # point pass IS the cheapest re-damp, what a rejected step could skip is the side stream (0.1 ms of contention at this size; EXPERIMENTS round 6)
+                       # a hiccup in the timed region shows here, not only in the average: the slowest LM step of the timed solve, and whether the fused level kernel of the
+                       # tile Cholesky ever timed out waiting for its jobs (the step is then re-run on the two-launch schedule, which the handle keeps: DESIGN section 4)
+                       "slowest_step_ms": round(1e3 * max(it.iteration_time_in_seconds for it in ba_timed_iterations[1:]), 4) if len(ba_timed_iterations) > 1 else None,
+                       "median_step_ms": round(1e3 * float(np.median([it.iteration_time_in_seconds for it in ba_timed_iterations[1:]])), 4) if len(ba_timed_iterations) > 1 else None,
+                       "potrf_wait_timeouts": int(ba.problem_stats().get("potrf_wait_timeouts", 0)), "fused_potrf_schedule": bool(ba.problem_stats().get("fused_potrf", 1)),
                        "accepted_steps": int(sum(1 for it in ba_timed_iterations[1:] if it.step_is_successful)),
                        "rejected_or_invalid_steps": int(sum(1 for it in ba_timed_iterations[1:] if not it.step_is_successful))},
             "roofline": roof,

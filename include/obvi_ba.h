@@ -314,7 +314,8 @@ int obvi_ba_debug_reduced_system(obvi_ba_handle* h, double radius, double* lhs, 
  * [5] Schur 6x6 blocks [6] Schur observation pairs [7] non-zero tiles after fill [8] trsm tile jobs
  * [9] update tile jobs [10] flops of one tile-Cholesky factorisation [11] active reprojection obs
  * [12] active bbox obs [13] levels of the tile elimination tree [14] host threads of the symbolic phase (pool + caller; OBVI_HOST_THREADS, default
- * min(16, usable CPUs)) [15] usable CPUs of the process (affinity mask and cgroup quota).  Returns the number of entries written. */
+ * min(16, usable CPUs)) [15] usable CPUs of the process (affinity mask and cgroup quota) [16] LM steps that were re-run because a workgroup of the
+ * fused level kernel of the tile Cholesky timed out waiting for its jobs [17] 1 while the handle is on the fused schedule.  Returns the number of entries written. */
 int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap);
 /* level 0 (default): no events; level 1: one HIP event pair per phase of an LM step (about 40 us of host and device time per
  * iteration: a dozen records and as many elapsed-time queries); level 2: additionally an event after every launch of the

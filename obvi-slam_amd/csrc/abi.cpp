@@ -522,10 +522,11 @@ int obvi_ba_get_problem_stats(const obvi_ba_handle* h, double* out, int32_t cap)
   int64_t act_rp = 0, act_bb = 0;
   for (uint8_t a : h->h_rp_active) act_rp += a != 0;
   for (uint8_t a : h->h_bb_active) act_bb += a != 0;
-  const double v[16] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m_canon, (double)h->nt, (double)h->nblk, (double)(h->npairs + h->npairs_window),
+  const double v[18] = {(double)h->nPv, (double)h->nOv, (double)h->nLv, (double)h->m_canon, (double)h->nt, (double)h->nblk, (double)(h->npairs + h->npairs_window),
                         (double)h->ntiles, (double)h->n_trsm_jobs, (double)h->n_upd_products, h->chol_flops, (double)act_rp, (double)act_bb,
-                        (double)h->nlevels, (double)host_threads(), (double)usable_cpus()};
-  const int n = std::min<int>(cap, 16);
+                        (double)h->nlevels, (double)host_threads(), (double)usable_cpus(),
+                        (double)h->potrf_wait_timeouts, h->fused_potrf ? 1.0 : 0.0};   // [16] LM steps re-run because a potrf workgroup of the fused level kernel timed out waiting for its jobs, [17] the fused schedule is still on
+  const int n = std::min<int>(cap, 18);
   for (int i = 0; i < n; ++i) out[i] = v[i];
   return n;
 }

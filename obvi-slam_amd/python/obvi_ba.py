@@ -418,10 +418,11 @@ class BundleAdjuster:
         return lhs.ravel()[:mm * mm].reshape(mm, mm).copy(), rhs[:mm].copy()
 
     def problem_stats(self):
-        buf = (C.c_double * 16)()
-        n = self._fn("ba_get_problem_stats")(self._h, buf, C.c_int32(16))
+        buf = (C.c_double * 18)()
+        n = self._fn("ba_get_problem_stats")(self._h, buf, C.c_int32(18))
         names = ["poses_var", "objects_var", "points_var", "reduced_rows", "tiles_per_dim", "schur_blocks", "schur_pairs",
-                 "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active", "chol_levels", "host_threads", "usable_cpus"]
+                 "tiles_nonzero", "trsm_jobs", "update_jobs", "chol_flops", "reproj_active", "bbox_active", "chol_levels", "host_threads", "usable_cpus",
+                 "potrf_wait_timeouts", "fused_potrf"]
         return {names[i]: buf[i] for i in range(n)}
 
     def set_profiling(self, level):
