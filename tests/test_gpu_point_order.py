@@ -112,3 +112,14 @@ def test_renumbered_and_callers_order_give_the_same_solve(monkeypatch):
     (sa, xa, pa), (sb, xb, pb) = out
     assert sa.num_iterations == sb.num_iterations and abs(sa.final_cost - sb.final_cost) <= 1e-10 * sa.final_cost     # another summation order, nothing else
     assert np.abs(xa - xb).max() < 1e-7 and np.abs(pa - pb).max() < 1e-9
+
+
+def test_deterministic_mode_stays_bit_identical_under_the_internal_numbering(renumber):
+    prob = shuffled(synth.make_problem(P=50, L=2500, O=3, seed=11, object_classes=("bench",), min_obj_obs=6))
+    runs = []
+    for _ in range(2):
+        g = helpers.product_ba(deterministic=True)
+        synth.upload(g, prob)
+        s = g.solve(helpers.ba_params(max_it=10))
+        runs.append(([i.cost for i in g.iterations()], g.get_points(), g.get_poses(), g.get_objects()))
+    assert runs[0][0] == runs[1][0] and all(np.array_equal(a, b) for a, b in zip(runs[0][1:], runs[1][1:]))
