@@ -324,6 +324,7 @@ struct Workspace {
   std::vector<real> colsq_c, colsq_l;     // squared column norms: reduced rows / points (3 per point)
   std::vector<real> g_c;                  // gradient, reduced rows
   std::vector<std::vector<int64_t>> point_obs;  // per point: indices into lin of its reprojection records
+  std::vector<real> Wall;                       // scratch of assemble_schur: W = J_p^T J_l per factor record (kept between calls: no 400-MB allocation per LM step)
   int64_t object_row0 = 0;                // first object row of the reduced system (= 6 nPv): rows from here on form the arrow's border
 };
 
@@ -558,7 +559,8 @@ bool assemble_schur(const OracleProblem& pb, const Reduced& rd, const std::vecto
   //       ascending (point, observation) order -- the order in which the one-thread loop reaches them -- so every entry subtracts the same
   //       products in the same order whatever g_threads is (1 included).
   std::vector<uint8_t> bad_part((size_t)std::max(1, g_threads), 0);
-  std::vector<real> Wall(18 * ws->lin.size());   // by factor record
+  std::vector<real>& Wall = ws->Wall;            // by factor record (every entry that is read below is written first)
+  if (Wall.size() < 18 * ws->lin.size()) Wall.resize(18 * ws->lin.size());
   parallel_ranges(pb.L, [&](int tid, int64_t l_begin, int64_t l_end) {
   for (int64_t l = l_begin; l < l_end; ++l) {
     if (!rd.point_var[l]) continue;
