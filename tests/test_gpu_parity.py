@@ -350,6 +350,16 @@ def test_converged_minimum_equals_scipy_on_the_numpy_restatement():
     assert np.abs(g.get_poses() - unpack(ref.x)[0]).max() < 1e-4
 
 
+def test_minimum_of_a_forty_frame_problem_is_a_minimum_of_the_numpy_restatement():
+    """The HIP solver's fixed point at a size scipy cannot reach from the start in reasonable time (40 keyframes / 400 features / 3 objects, every factor family), judged by
+    arithmetic that shares nothing with it (helpers.first_order_optimality_on_the_numpy_restatement): same cost, vanishing gradient of the restatement, nothing lower nearby."""
+    prob = synth.make_problem(P=40, L=400, O=3, seed=11, const_poses=2, outlier_frac=0.05, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0, min_parallax_deg=3.0)
+    g = helpers.product_ba(); synth.upload(g, prob)
+    s = g.solve(helpers.ba_params(max_it=200, ftol=1e-15, gtol=1e-14, ptol=1e-14, radius=1e4, max_radius=1e12))
+    cost, scaled_gradient, gain = helpers.first_order_optimality_on_the_numpy_restatement(prob, g.get_poses(), g.get_points(), g.get_objects())
+    assert abs(cost - s.final_cost) <= 1e-10 * s.final_cost and scaled_gradient < 1e-5 and gain < 1e-9, (cost, s.final_cost, scaled_gradient, gain)
+
+
 def test_bench_workload_invariants():
     """BASELINE config #3, the bench.py workload (2000 KF / 200 objects / 300k features, ~3 M observations): size-independent
     properties.  A solve at a tiny trust-region radius makes the quadratic model exact, so relative_decrease -> 1 checks

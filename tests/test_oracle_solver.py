@@ -393,6 +393,21 @@ def test_all_factor_families_minimum_matches_scipy():
     assert np.abs(ba.get_poses() - poses).max() < 1e-4    # points / objects: through the cost (flat directions)
 
 
+def test_minimum_of_a_forty_frame_problem_is_a_minimum_of_the_numpy_restatement():
+    """The pin above at forty times the size (40 keyframes / 400 features / 3 objects, every factor family): running scipy from the start takes minutes there, but
+    whether the point the LM loop converged to IS a minimum of the independent restatement takes seconds -- the restatement's cost at it equals the solver's, its
+    gradient (sparse central differences, no solver Jacobian involved) vanishes to the differences' noise, and scipy started at the point finds nothing lower.
+    (A wrong fixed point -- a factor mis-weighted, a block left out of the reduced system -- leaves a scaled gradient of 1e-2 ... 1.)"""
+    prob = synth.make_problem(P=40, L=400, O=3, seed=11, const_poses=2, outlier_frac=0.05, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0, min_parallax_deg=3.0)
+    ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    s = ba.solve(helpers.ba_params(max_it=200, ftol=1e-15, gtol=1e-14, ptol=1e-14, radius=1e4, max_radius=1e12))
+    cost, scaled_gradient, gain = helpers.first_order_optimality_on_the_numpy_restatement(prob, ba.get_poses(), ba.get_points(), ba.get_objects())
+    assert abs(cost - s.final_cost) <= 1e-10 * s.final_cost and scaled_gradient < 1e-5 and gain < 1e-9, (cost, s.final_cost, scaled_gradient, gain)
+    # and the check can tell: the same point with one object's centre 2 cm off is not a minimum
+    off = ba.get_objects(); off[0, 0] += 0.02
+    assert helpers.first_order_optimality_on_the_numpy_restatement(prob, ba.get_poses(), ba.get_points(), off)[1] > 1e-4
+
+
 def test_object_covariances_are_blocks_of_the_dense_inverse():
     """ceres::Covariance on object blocks (long_term_object_map_extraction.cpp:419-433): the oracle's Schur-complement route
     against numpy's inverse of the full J^T J (poses, objects and points, J robustified, no damping)."""
