@@ -124,6 +124,7 @@ def first_order_optimality_on_the_numpy_restatement(prob, poses, points, objects
     scaled = float((np.abs(g) / (colnorm * np.linalg.norm(r) + 1e-300)).max())
     cost = 0.5 * float(r @ r)
     ref = least_squares(f, x, method="trf", jac_sparsity=S, xtol=1e-15, ftol=1e-15, gtol=1e-14, max_nfev=30, tr_solver="lsmr")
+    first_order_optimality_on_the_numpy_restatement.last_gradient = (g, colnorm * np.linalg.norm(r))      # order: variable poses, features, objects; and the scale of each entry
     return cost, scaled, (cost - float(ref.cost)) / cost
 
 

@@ -400,6 +400,14 @@ def test_minimum_of_a_forty_frame_problem_is_a_minimum_of_the_numpy_restatement(
     (A wrong fixed point -- a factor mis-weighted, a block left out of the reduced system -- leaves a scaled gradient of 1e-2 ... 1.)"""
     prob = synth.make_problem(P=40, L=400, O=3, seed=11, const_poses=2, outlier_frac=0.05, min_obj_obs=5, object_classes=("bench",), bbox_noise=5.0, min_parallax_deg=3.0)
     ba = helpers.oracle_ba(); synth.upload(ba, prob)
+    # at the START, where the gradient is large: the oracle's own gradient J^T r (its dual-number Jacobians of every family, its Huber weights) against the restatement's
+    J, r, m, pv = dense_normal_equations(ba, prob)
+    g_oracle = J.T @ r
+    nP, nO = int((pv >= 0).sum()), len(prob["objects"])
+    g_oracle = np.concatenate([g_oracle[:6 * nP], g_oracle[6 * nP + 7 * nO:], g_oracle[6 * nP:6 * nP + 7 * nO]])          # -> poses, features, objects
+    helpers.first_order_optimality_on_the_numpy_restatement(prob, prob["poses"], prob["points"], prob["objects"])
+    g_fd, scale = helpers.first_order_optimality_on_the_numpy_restatement.last_gradient
+    assert np.abs(g_fd).max() > 1e3 and (np.abs(g_oracle - g_fd) / scale).max() < 1e-5
     s = ba.solve(helpers.ba_params(max_it=200, ftol=1e-15, gtol=1e-14, ptol=1e-14, radius=1e4, max_radius=1e12))
     cost, scaled_gradient, gain = helpers.first_order_optimality_on_the_numpy_restatement(prob, ba.get_poses(), ba.get_points(), ba.get_objects())
     assert abs(cost - s.final_cost) <= 1e-10 * s.final_cost and scaled_gradient < 1e-5 and gain < 1e-9, (cost, s.final_cost, scaled_gradient, gain)
